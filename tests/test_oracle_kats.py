@@ -1,0 +1,312 @@
+"""Pin the CPU oracle against the reference's OWN known-answer tests.
+
+Every test names the reference test it restates (file:line in /root/reference).  CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+
+def f16(x):
+    return int(o.lib().co_f32_to_f16(np.float32(x)))
+
+
+def le16(v):
+    return [v & 0xFF, (v >> 8) & 0xFF]
+
+
+# ---------------------------------------------------------------- half crate
+def test_f16_roundtrip_all_bit_patterns():
+    bits = np.arange(65536, dtype=np.uint16)
+    ours = o.f16_bits_to_f32(bits)
+    ref = bits.view(np.float16).astype(np.float32)
+    nan = np.isnan(ref)
+    assert np.array_equal(ours[~nan].view(np.uint32), ref[~nan].view(np.uint32))
+    assert np.all(np.isnan(ours[nan]))
+    back = o.f32_to_f16_bits(ours[~nan])
+    assert np.array_equal(back, bits[~nan])
+
+
+def test_f32_to_f16_rne_matches_numpy():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([
+        rng.standard_normal(200000).astype(np.float32) * np.float32(10.0) ** rng.integers(-8, 6, 200000).astype(np.float32),
+        np.array([0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 2.9802326e-8,
+                  6.1e-5, 6.097555e-5, np.inf, -np.inf], dtype=np.float32),
+    ])
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(o.f32_to_f16_bits(x), ref)
+
+
+# ---------------------------------------------------------------- block layouts + dequant goldens
+def test_q8_0_block_layout_and_dequant():  # buf_q8_0.rs:293-322
+    assert o.BLOCK_BYTES[o.Q8_0] == 34
+    buf = np.full(68, 1, dtype=np.uint8)
+    d = le16(f16(3.0))
+    buf[0:2] = d
+    buf[2], buf[3], buf[4], buf[2 + 31] = 2, 3, 4, 7
+    buf[34:36] = d
+    buf[66], buf[67] = 9, 9
+    got = o.dequantize(buf, o.Q8_0)
+    exp = [6.0, 9.0, 12.0] + [3.0] * 28 + [21.0] + [3.0] * 30 + [27.0, 27.0]
+    assert got.tolist() == exp
+
+
+def test_q4_0_block_layout_and_dequant():  # buf_q4_0.rs:260-298
+    assert o.BLOCK_BYTES[o.Q4_0] == 18
+    buf = np.full(36, 1, dtype=np.uint8)
+    d = le16(f16(3.0))
+    for base in (0, 18):
+        buf[base:base + 2] = d
+        buf[base + 2], buf[base + 3], buf[base + 4] = 2, 3, 4
+    got = o.dequantize(buf, o.Q4_0)
+    one = [-18.0, -15.0, -12.0] + [-21.0] * 13 + [-24.0] * 16
+    assert got.tolist() == one + one
+
+
+def test_q4_1_block_fields_and_quantize():  # buf_q4_1.rs:287-333
+    assert o.BLOCK_BYTES[o.Q4_1] == 20
+    data = np.array(list(range(-8, 8)) * 2, dtype=np.float32)
+    raw = o.quantize(data, o.Q4_1)
+    assert o.f16_bits_to_f32(raw[0:2].view(np.uint16))[0] == 1.0
+    assert o.f16_bits_to_f32(raw[2:4].view(np.uint16))[0] == -8.0
+    assert raw[4:20].tolist() == [16, 50, 84, 118, 152, 186, 220, 254] * 2
+    assert o.dequantize(raw, o.Q4_1).tolist() == data.tolist()  # (interleaved order round trip)
+
+
+def test_q8_1_block_layout():  # buf_q8_1.rs:136-161
+    assert o.BLOCK_BYTES[o.Q8_1] == 36
+    buf = np.full(36, 1, dtype=np.uint8)
+    buf[0:2] = le16(f16(3.0))
+    buf[2:4] = le16(f16(96.0))
+    buf[5], buf[6], buf[7], buf[35] = 2, 3, 4, 7
+    got = o.dequantize(buf, o.Q8_1)
+    assert got.tolist() == [3.0, 6.0, 9.0, 12.0] + [3.0] * 27 + [21.0]
+
+
+def test_q8_k_block_layout():  # buf_q8_k.rs:233-262
+    assert o.BLOCK_BYTES[o.Q8_K] == 292
+    buf = np.full(292, 1, dtype=np.uint8)
+    buf[0:2] = le16(f16(3.0))
+    buf[2:4] = le16(f16(1.0))
+    buf[4], buf[5], buf[6], buf[4 + 15], buf[283] = 2, 3, 4, 7, 10
+    assert buf[0:4].view(np.float32)[0] == np.float32(0.007828236)
+    assert buf[4:20].view(np.int8).tolist() == [2, 3, 4] + [1] * 12 + [7]
+    bsums = buf[260:292].view(np.int16).tolist()
+    assert bsums == [257] * 11 + [2561] + [257] * 4
+    deq = o.dequantize(buf, o.Q8_K)
+    assert deq[0] == np.float32(0.007828236) * np.float32(2.0)
+
+
+def test_q8_k_quantize():  # buf_q8_k.rs:265-292
+    data = np.array(list(range(-8, 8)) * 16, dtype=np.float32)
+    raw = o.quantize(data, o.Q8_K)
+    assert raw.size == 292
+    assert raw[0:4].view(np.float32)[0] == 0.0625
+    assert o.dequantize(raw, o.Q8_K).tolist() == data.tolist()
+    qs = raw[4:260].view(np.int8).astype(np.int32)
+    bs = raw[260:292].view(np.int16)
+    assert bs.tolist() == qs.reshape(16, 16).sum(axis=1).tolist()
+
+
+# ---------------------------------------------------------------- dot known answers
+def _q80_blocks(qs_list, d_list):
+    out = bytearray()
+    for qs, d in zip(qs_list, d_list):
+        out += bytes(le16(f16(d)))
+        out += np.array(qs, dtype=np.int8).tobytes()
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("avx2", [False, True])
+def test_vec_dot_q8_0_q8_0_known_answers(avx2):  # buf_q8_0.rs:325-389 (assert_eq! on f32)
+    if avx2 and not o.lib().co_have_avx2():
+        pytest.skip("no avx2 on this host")
+    up = list(range(1, 33))
+    down = list(range(32, 0, -1))
+    a = _q80_blocks([up, [-v for v in up]], [0.4, 0.7])
+    b = _q80_blocks([down, [-v for v in down]], [1.3, 1.4])
+    assert np.float32(o.vec_dot(a, o.Q8_0, b, 64, avx2=avx2)) == np.float32(8978.046)
+    a1 = _q80_blocks([up], [0.4])
+    b1 = _q80_blocks([down], [1.3])
+    assert np.float32(o.vec_dot(a1, o.Q8_0, b1, 32, avx2=avx2)) == np.float32(3110.453)
+
+
+def _generate_data(offset, n):  # util.rs:291-297
+    i = np.arange(n, dtype=np.float32)
+    return (np.float32(0.1) + np.float32(2.0) * np.cos(i + np.float32(offset), dtype=np.float32)).astype(np.float32)
+
+
+def test_q4_k_vec_dot_q8_k_statistical():  # buf_q4_k.rs:303-315
+    a = _generate_data(0.0, 256)
+    b = _generate_data(1.0, 256)
+    qa = o.quantize(a, o.Q4_K)
+    qb = o.quantize(b, o.Q8_K)
+    dot = o.vec_dot(qa, o.Q4_K, qb, 256)
+    ref = np.float32(0.0)
+    for x, y in zip(a, b):
+        ref = np.float32(ref + x * y)
+    assert abs(ref - dot) / 256 < 0.02
+    assert o.q4k_overflow_count(qa, qb, 256) == 0
+
+
+def test_nearest_i32():  # util.rs:328-349
+    cases = [(3_256_291.8, 3256292), (234_730.28, 234730), (3_271_636.3, 3271636), (143_427.25, 143427),
+             (624_284.7, 624285), (601459.0, 601459), (929_129.4, 929129), (196_503.23, 196503),
+             (906_489.75, 906490), (1_711_053.4, 1711053)]
+    for x, e in cases:
+        assert o.lib().co_nearest_i32(np.float32(x)) == e
+
+
+def test_get_scale_min_k4():  # util.rs:351-359
+    import ctypes as C
+    data = (C.c_uint8 * 12)(*([255] * 5 + [0] * 7))
+    sc, m = C.c_uint8(0), C.c_uint8(0)
+    o.lib().co_get_scale_min_k4(0, data, C.byref(sc), C.byref(m))
+    assert (sc.value, m.value) == (63, 63)
+
+
+# ---------------------------------------------------------------- op goldens (cpu_tensor.rs:455-606)
+def test_tensor_view(odev):  # cpu_tensor.rs:461-470
+    t = o.OracleTensor.new([1, 2, 3, 4, 5, 6], [2, 3], odev).reshape([3, 2])
+    assert t.reshape([2, 3]).to_vec().tolist() == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+
+
+def test_copy_from(odev):  # cpu_tensor.rs:472-488
+    t1 = o.OracleTensor.new([1, 2, 3, 4], [2, 2], odev)
+    t2 = o.OracleTensor.new([0, 0], [2], odev)
+    t2.copy_rows_from(t1, [1])
+    assert t2.to_vec().tolist() == [3.0, 4.0]
+    t2.copy_rows_from(t1, [0])
+    assert t2.to_vec().tolist() == [1.0, 2.0]
+
+
+def test_rms_norm_formula(odev):  # cpu_tensor.rs:490-507 goldens are for the plain formula
+    def simple(x):
+        ss = np.float32(0.0)
+        for v in x:
+            ss = np.float32(ss + v * v)
+        rms = np.sqrt(np.float32(ss / np.float32(len(x)) + np.float32(1e-5)))
+        return [np.float32(v / rms) for v in x]
+
+    got = simple(np.array([1, 2, 3, 4, 5, 6], dtype=np.float32))
+    assert got == [np.float32(v) for v in [0.2567762, 0.5135524, 0.77032864, 1.0271049, 1.2838811, 1.5406573]]
+    # the oracle primitive on a 32-multiple row agrees with the formula
+    x = np.arange(1, 129, dtype=np.float32)
+    t = o.OracleTensor.new(x, [128], odev).rms_norm_inplace(1e-5)
+    ss = np.float32(0.0)
+    for c in range(4):
+        s = np.float32(0.0)
+        for v in x[32 * c:32 * c + 32]:
+            s = np.float32(s + v * v)
+        ss = np.float32(ss + s)
+    rms = np.sqrt(np.float32(ss / np.float32(128) + np.float32(1e-5)))
+    assert t.to_vec().tolist() == (x / rms).tolist()
+
+
+def test_rope_golden(odev):  # cpu_tensor.rs:509-527
+    t = o.OracleTensor.new(np.arange(32, dtype=np.float32), [2, 16], odev)
+    out = t.rope_inplace(o.ROPE_LLAMA, 1, 2).to_vec()
+    exp = np.array([-0.841471, 0.54030234] + list(range(2, 16)) + [-5.6601696, 22.648676] + list(range(18, 32)),
+                   dtype=np.float32)
+    assert np.allclose(out, exp, rtol=0, atol=1e-5)
+
+
+def test_matmul_golden(odev):  # cpu_tensor.rs:530-541
+    w = o.OracleTensor.new([4.0] * 32, [16, 2], odev)
+    b = o.OracleTensor.new([1.0, 2.0], [2], odev)
+    assert w.matmul_vec(b).to_vec().tolist() == [12.0] * 16
+
+
+def test_matmul_golden_32x8(odev):  # wgpu_tensor.rs:880-894
+    w = o.OracleTensor.new(np.arange(256, dtype=np.float32), [32, 8], odev)
+    b = o.OracleTensor.new([2.0] * 8, [8], odev)
+    assert w.matmul_vec(b).to_vec().tolist() == [56.0 + 128.0 * i for i in range(32)]
+
+
+def test_batch_matmul_golden(odev):  # wgpu_tensor.rs:897-915
+    a = o.OracleTensor.new(np.arange(6, dtype=np.float32), [1, 3, 2], odev)
+    b = o.OracleTensor.new([2.0, 2.0], [1, 2, 1], odev)
+    assert a.batch_matmul(b).to_vec().tolist() == [2.0, 10.0, 18.0]
+
+
+def test_softmax_golden(odev):  # cpu_tensor.rs:544-555 (eps 1e-3: f16 exp table)
+    t = o.OracleTensor.new([1, 2, 3, 4, 5, 6], [2, 3], odev).softmax_inplace(1)
+    exp = [0.09003057, 0.24472848, 0.66524094] * 2
+    assert np.allclose(t.to_vec(), exp, atol=1e-3, rtol=0)
+
+
+def test_silu_golden(odev):  # cpu_tensor.rs:558-569
+    t = o.OracleTensor.new([1, 2, 3, 4, 5, 6], [6], odev).silu_inplace()
+    exp = [0.7310586, 1.761594, 2.8577225, 3.928055, 4.9665356, 5.9851646]
+    assert np.allclose(t.to_vec(), exp, atol=1e-1, rtol=0)
+    assert np.allclose(t.to_vec(), exp, atol=2e-3, rtol=0)  # what the f16 table actually achieves
+
+
+def test_gelu_golden(odev):  # wgpu_tensor.rs:1040-1056 goldens = the tanh formula
+    t = o.OracleTensor.new([1, 2, 3, 4, 5, 6], [6], odev).gelu_inplace()
+    exp = [0.8411919, 1.9545977, 2.9963627, 3.99993, 5.0, 6.0]  # gelu.rs:19-22 evaluated in f32
+    assert np.allclose(t.to_vec(), exp, atol=2e-3, rtol=0)
+
+
+def test_contiguous_golden(odev):  # cpu_tensor.rs:572-600
+    t1 = o.OracleTensor.new([1, 2, 3, 4, 5, 6], [2, 3], odev).transpose([1, 0])
+    t2 = t1.contiguous()
+    assert t2.to_vec().tolist() == [1.0, 4.0, 2.0, 5.0, 3.0, 6.0] and t2.shape() == [3, 2]
+    t1 = o.OracleTensor.new([1, 2, 3, 4, 5, 6], [1, 2, 3], odev).transpose([2, 1, 0])
+    v1 = t1.to_vec()
+    t2 = t1.contiguous()
+    assert t2.to_vec().tolist() == [1.0, 4.0, 2.0, 5.0, 3.0, 6.0] and t2.shape() == [3, 2, 1]
+    assert v1.tolist() == t2.to_vec().tolist()
+
+
+def test_concatenate_goldens(odev):  # wgpu_tensor.rs:940-998
+    t1 = o.OracleTensor.alloc([2, 2, 16], o.F32, odev).resize(0, 0)
+    t1.concatenate(o.OracleTensor.new(np.arange(32, dtype=np.float32), [1, 2, 16], odev), 0)
+    t1.concatenate(o.OracleTensor.new(np.arange(32, 64, dtype=np.float32), [1, 2, 16], odev), 0)
+    assert t1.shape() == [2, 2, 16]
+    assert t1.export().tolist() == [float(i) for i in range(64)]
+
+    t1 = o.OracleTensor.alloc([2, 2, 16], o.F32, odev).resize(1, 0)
+    t1.concatenate(o.OracleTensor.new(np.arange(32, dtype=np.float32), [2, 1, 16], odev), 1)
+    t1.concatenate(o.OracleTensor.new(np.arange(32, 64, dtype=np.float32), [2, 1, 16], odev), 1)
+    exp = list(range(0, 16)) + list(range(32, 48)) + list(range(16, 32)) + list(range(48, 64))
+    assert t1.shape() == [2, 2, 16]
+    assert t1.export().tolist() == [float(i) for i in exp]
+
+
+def test_concate_2d_primitive(odev):  # concatenate.rs:211-262 (generic 2-d)
+    t1 = o.OracleTensor(np.array([1, 0, 0, 4, 0, 0], dtype=np.float32), o.F32, o.TensorStrider([2, 1], [3, 1]), odev)
+    t2 = o.OracleTensor(np.array([2, 5], dtype=np.float32), o.F32, o.TensorStrider([2, 1], [1, 1]), odev)
+    t1.concatenate(t2, 1)
+    assert t1.storage.tolist() == [1, 2, 0, 4, 5, 0] and t1.shape() == [2, 2]
+
+
+# ---------------------------------------------------------------- strider suite (strider.rs:238-339)
+def test_strider_suite():
+    S = o.TensorStrider
+    s = S([3, 4])
+    assert (s.at([0, 0]), s.at([0, 3]), s.at([1, 0])) == (0, 3, 4)
+    with pytest.raises(o.TensorError):
+        s.reshape([4, 2])
+    s = s.reshape([2, 6])
+    assert (s.at([0, 0]), s.at([0, 5]), s.at([1, 0])) == (0, 5, 6)
+    so = S([2, 3])
+    st = so.transpose([1, 0])
+    assert st.shape() == [3, 2] and st.iter() == [0, 3, 1, 4, 2, 5]
+    assert st.at([1, 1]) == 4 and st.at([2, 1]) == 5
+    st = st.transpose([1, 0])
+    assert st.shape() == [2, 3] and st.iter() == [0, 1, 2, 3, 4, 5]
+    assert S([2, 3]).is_contiguous()
+    s1 = S([3, 3200])
+    assert s1.strides() == [3200, 1] and s1.resize([0, 3200]).strides() == [3200, 1]
+    s3 = S([3, 8, 3200])
+    assert s3.strides() == [3200 * 8, 3200, 1]
+    s4 = s3.resize([3, 0, 3200])
+    assert s4.shape() == [3, 0, 3200] and s4.strides() == [3200 * 8, 3200, 1]
+
+
+def test_argmax_returns_last_max():  # sampler.rs:109-116
+    assert o.argmax_last(np.array([1, 5, 2, 5, 0], dtype=np.float32)) == 3
