@@ -1,0 +1,170 @@
+/*
+ * crabml_hip.h -- C ABI of libcrabml_hip.so: the MI355X (gfx950) tensor backend for crabml.
+ *
+ * This is the drop-in boundary.  A `crabml-hip` Rust crate binds exactly these entry points
+ * (bindgen / `extern "C"`) and implements `crabml::tensor::Tensor`
+ * (crabml-core/src/tensor/api.rs:11-79) on top of them, so `Llama2Runner<T>`
+ * (crabml-llama2/src/llama2.rs:26-43) runs unchanged.  See INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *  - Plain C: opaque handles, pointers and sizes only.  No C++/torch types cross the boundary.
+ *  - Every function returns an int status: 0 = OK, otherwise a `crabml_hip_status` value that
+ *    maps 1:1 onto crabml::error::ErrorKind (crabml-core/src/error.rs:5-33).  Nothing throws.
+ *    crabml_hip_last_error() returns the message of the last failure on that device.
+ *  - Shape / stride bookkeeping (TensorStrider, crabml-core/src/tensor/strider.rs) stays on the
+ *    host side of the boundary: ops take explicit shapes / strides (in ELEMENTS).
+ *  - A `crabml_hip_buf_t` is a reference-counted device allocation + its GGML dtype; cloning a
+ *    Rust tensor = retain, dropping = release; views share one buf (with_strider is free).
+ *  - All work is enqueued on the device's HIP stream and returns immediately; only
+ *    crabml_hip_export / crabml_hip_device_sync / debug snapshots block the host (the same
+ *    contract as the wgpu backend: crabml-wgpu/src/wgpu_tensor.rs:293-333).
+ *  - GGML type ids are the #[repr(u32)] values of crabml-core/src/gguf.rs:86-108.
+ */
+#ifndef CRABML_HIP_H
+#define CRABML_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRABML_HIP_ABI_VERSION 1
+
+/* crabml-core/src/error.rs:5-33 */
+typedef enum crabml_hip_status {
+  CRABML_HIP_OK = 0,
+  CRABML_HIP_UNEXPECTED = 1, /* HIP runtime failures land here */
+  CRABML_HIP_IO_ERROR = 2,
+  CRABML_HIP_TENSOR_NOT_FOUND = 3,
+  CRABML_HIP_MODEL_ERROR = 4,
+  CRABML_HIP_BAD_INPUT = 5,
+  CRABML_HIP_FORMAT_ERROR = 6,
+  CRABML_HIP_TENSOR_ERROR = 7, /* shape / dtype misuse (bail!(ErrorKind::TensorError, ..)) */
+  CRABML_HIP_CHAT_TEMPLATE_NOT_FOUND = 8,
+  CRABML_HIP_NOT_IMPLEMENTED = 9
+} crabml_hip_status;
+
+/* crabml-core/src/gguf.rs:86-108 */
+typedef enum crabml_hip_ggml_type {
+  CRABML_HIP_F32 = 0,
+  CRABML_HIP_F16 = 1,
+  CRABML_HIP_Q4_0 = 2,
+  CRABML_HIP_Q4_1 = 3,
+  CRABML_HIP_Q8_0 = 8,
+  CRABML_HIP_Q8_1 = 9,
+  CRABML_HIP_Q4_K = 12,
+  CRABML_HIP_Q8_K = 15
+} crabml_hip_ggml_type;
+
+/* crabml-core/src/tensor/api.rs:5-9 */
+typedef enum crabml_hip_rope_mode { CRABML_HIP_ROPE_LLAMA = 0, CRABML_HIP_ROPE_NEOX = 1 } crabml_hip_rope_mode;
+
+typedef struct crabml_hip_device crabml_hip_device_t;
+typedef struct crabml_hip_buf crabml_hip_buf_t;
+
+/* replaces WgpuTensorDeviceOptions (crabml-wgpu/src/wgpu_device.rs:9-38) */
+typedef struct crabml_hip_device_options {
+  int32_t device_ordinal; /* HIP device index (one process per GPU: LOCAL_RANK) */
+  void* stream;           /* optional caller-owned hipStream_t; NULL = the library creates one */
+  int32_t flags;          /* reserved, must be 0 */
+} crabml_hip_device_options_t;
+
+/* ---- device ------------------------------------------------------------------------------ */
+int crabml_hip_abi_version(void);
+/* replaces WgpuTensorDevice::new (crabml-wgpu/src/wgpu_device.rs:52-75).  Uploads the 65536-entry
+ * f16 exp table the reference builds in CpuTensorDevice::init_exp_cache (cpu_device.rs:108-115). */
+int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip_device_t** out);
+int crabml_hip_device_destroy(crabml_hip_device_t* dev);
+int crabml_hip_device_sync(crabml_hip_device_t* dev);
+/* copies the last error message (NUL terminated, truncated to cap) and returns its full length */
+size_t crabml_hip_last_error(crabml_hip_device_t* dev, char* buf, size_t cap);
+/* the hipStream_t all work of this device is ordered on (for HIP-event timing / interop) */
+void* crabml_hip_device_stream(crabml_hip_device_t* dev);
+/* bytes currently held from the HIP allocator (live + pooled) */
+size_t crabml_hip_device_mem_in_use(crabml_hip_device_t* dev);
+
+/* ---- buffers ----------------------------------------------------------------------------- */
+/* Tensor::from_cpu (api.rs:14-19): uploads `nbytes` of GGML-layout bytes.  Accepts F32, F16,
+ * Q8_0, Q4_0, Q4_1, Q4_K, Q8_K.  Quantized tensors must be 2-D (m, k) (or 1-D) with k a multiple
+ * of the block size; they are re-laid-out once at upload into 16-byte-aligned planes (quants /
+ * scales) -- the unpacked integers and scales are bit-identical to the GGUF bytes. */
+int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t nbytes, const size_t* shape,
+                            int ndim, uint32_t ggml_type, crabml_hip_buf_t** out);
+/* Tensor::alloc (api.rs:21-23): F32 (zero filled) or F16 (contents unspecified), n_elems elements */
+int crabml_hip_buf_alloc(crabml_hip_device_t* dev, size_t n_elems, uint32_t ggml_type, crabml_hip_buf_t** out);
+int crabml_hip_buf_retain(crabml_hip_buf_t* buf);
+int crabml_hip_buf_release(crabml_hip_buf_t* buf);
+uint32_t crabml_hip_buf_dtype(const crabml_hip_buf_t* buf);
+size_t crabml_hip_buf_len(const crabml_hip_buf_t* buf); /* elements */
+
+/* ---- data movement ----------------------------------------------------------------------- */
+/* Tensor::export (api.rs:52): copies the first n f32 elements to host memory; BLOCKS. F32 only. */
+int crabml_hip_export(crabml_hip_device_t* dev, const crabml_hip_buf_t* buf, float* dst, size_t n);
+/* raw export of an F32/F16 buffer's bytes (tests: bit-exact KV-cache / f16 checks); BLOCKS */
+int crabml_hip_export_raw(crabml_hip_device_t* dev, const crabml_hip_buf_t* buf, void* dst, size_t nbytes);
+/* Tensor::dup (api.rs:55): fresh F32 buffer with a copy of the WHOLE storage (cpu_tensor.rs:333-337) */
+int crabml_hip_dup(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, crabml_hip_buf_t** out);
+/* Tensor::contiguous (api.rs:40): gathers a 2-/3-D strided F32/F16 view into a fresh dense buffer
+ * (contiguous.rs:6-66) */
+int crabml_hip_contiguous(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, const size_t* shape,
+                          const size_t* strides, int ndim, crabml_hip_buf_t** out);
+/* Tensor::concatenate (api.rs:46): writes rhs (strided view) into dst at element offset
+ * dst_shape[axis] * dst_strides[axis] (concatenate.rs:12-204).  F32<-F32, F16<-F16, F16<-F32 (RNE).
+ * The caller bumps shape[axis] (strider.resize) afterwards. */
+int crabml_hip_concatenate(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, const size_t* dst_shape,
+                           const size_t* dst_strides, const crabml_hip_buf_t* rhs, const size_t* rhs_shape,
+                           const size_t* rhs_strides, int ndim, int axis);
+/* Tensor::copy_rows_from (api.rs:50): dst row i <- src row rows[i] (cols elements each), dequantizing
+ * quantized sources exactly as BlockQ*::dequantize (cpu_tensor.rs:306-331, buf/api.rs:262-350).
+ * dst is F32 or F16. */
+int crabml_hip_copy_rows_from(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, const crabml_hip_buf_t* src,
+                              size_t cols, const size_t* rows, size_t n_rows);
+
+/* ---- compute (all in place ops require dense F32) ------------------------------------------ */
+/* rope.rs:10-80: x viewed as (n_batch, bi_stride) rows holding heads of head_dim; position pos+batch */
+int crabml_hip_rope_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n_batch, size_t bi_stride,
+                            size_t head_dim, uint32_t mode, size_t pos, size_t rope_dims);
+/* rms_norm.rs:9-47: x /= sqrt(mean(x^2) + eps) per row; cols % 32 == 0 */
+int crabml_hip_rms_norm_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols, float eps);
+/* softmax.rs:11-57 over the last axis; exp through the f16 table */
+int crabml_hip_softmax_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols);
+/* silu.rs:6-13 / gelu.rs:11-17 on the first n elements */
+int crabml_hip_silu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n);
+int crabml_hip_gelu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n);
+/* arithmetic.rs:5-68: a[i] op= b[i % nb]  (nb == 1: scalar broadcast) */
+int crabml_hip_mul_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, const crabml_hip_buf_t* b,
+                           size_t nb);
+int crabml_hip_add_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, const crabml_hip_buf_t* b,
+                           size_t nb);
+/* cpu_tensor.rs:404-410 */
+int crabml_hip_scale_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, float f);
+
+/* Tensor::matmul_vec (api.rs:76; cpu_tensor.rs:371-386; matmul_vec.rs:9-78):
+ * W (m,k) of any supported dtype  x  X (b,k) dense F32  ->  fresh F32 (b,m).
+ * X is quantized on the fly to W's vec_dot_rhs_dtype (buf/api.rs:142-159) with the reference's
+ * own rounding (Q8_0/Q8_1 truncate, Q8_K rounds half away). */
+int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k,
+                          const crabml_hip_buf_t* x, size_t b, crabml_hip_buf_t** out);
+/* Tensor::batch_matmul (api.rs:78; batch_matmul.rs:15-131): A (ba,m,k) dense F32  x  B (bb,k,n)
+ * strided F32|F16 (stride_k == 1 or stride_n == 1)  ->  fresh F32 (ba,m,n).
+ * Batch broadcast as the reference: F32 B -> bi % bb; F16 B -> bi / (ba/bb). */
+int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a, size_t ba, size_t m, size_t k,
+                            const crabml_hip_buf_t* b, size_t bb, size_t n, size_t sb0, size_t sb1, size_t sb2,
+                            crabml_hip_buf_t** out);
+
+/* ---- parity / debug hooks (used by tests; not on the hot path) ------------------------------ */
+/* Quantizes the first n f32 elements of x to `qtype` (Q8_0 | Q8_1 | Q8_K) on the device and returns
+ * the blocks in the reference's byte layout (buf_q8_0.rs:8-13, buf_q8_1.rs:73-79, buf_q8_k.rs:6-12). */
+int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* x, size_t n, uint32_t qtype,
+                              void* dst, size_t dst_bytes);
+/* Exact integer part of W(row) . X per 32-element group (one int32 each; k/32 values): the
+ * bit-exact gate for the nibble unpack + integer dot. */
+int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
+                                const crabml_hip_buf_t* x, int32_t* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRABML_HIP_H */
