@@ -1,0 +1,153 @@
+// common.hpp -- internal types of libcrabml_hip.so (device, buffers, pool, error plumbing).
+// Product code: nothing here may include or link anything under oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/crabml_hip.h"
+
+namespace crabml_hip {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- GGML block geometry (crabml-core/src/cpu/buf/buf_q*.rs) ---------------------------------
+inline size_t block_elems(uint32_t t) {
+  switch (t) {
+    case CRABML_HIP_F32: case CRABML_HIP_F16: return 1;
+    case CRABML_HIP_Q4_0: case CRABML_HIP_Q4_1: case CRABML_HIP_Q8_0: case CRABML_HIP_Q8_1: return 32;
+    case CRABML_HIP_Q4_K: case CRABML_HIP_Q8_K: return 256;
+    default: return 0;
+  }
+}
+inline size_t block_bytes(uint32_t t) {
+  switch (t) {
+    case CRABML_HIP_F32: return 4;
+    case CRABML_HIP_F16: return 2;
+    case CRABML_HIP_Q4_0: return 18;
+    case CRABML_HIP_Q4_1: return 20;
+    case CRABML_HIP_Q8_0: return 34;
+    case CRABML_HIP_Q8_1: return 36;
+    case CRABML_HIP_Q4_K: return 144;
+    case CRABML_HIP_Q8_K: return 292;
+    default: return 0;
+  }
+}
+// CpuTensorBuf::vec_dot_rhs_dtype, crabml-core/src/cpu/buf/api.rs:142-159
+inline uint32_t vec_dot_rhs_dtype(uint32_t t) {
+  switch (t) {
+    case CRABML_HIP_F32: return CRABML_HIP_F32;
+    case CRABML_HIP_F16: return CRABML_HIP_F16;
+    case CRABML_HIP_Q8_0: case CRABML_HIP_Q4_0: return CRABML_HIP_Q8_0;
+    case CRABML_HIP_Q8_1: case CRABML_HIP_Q4_1: return CRABML_HIP_Q8_1;
+    case CRABML_HIP_Q8_K: case CRABML_HIP_Q4_K: return CRABML_HIP_Q8_K;
+    default: return 0xffffffffu;
+  }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- device-resident layouts -----------------------------------------------------------------
+// Quantized WEIGHTS are re-laid-out once at upload ("planes"): all quants of the tensor first
+// (16-byte aligned, block-major, same block order as GGUF), then the per-block scales.  Measured
+// on MI355X (profiles/r01_gemv_lab_layout_sweep.log): 6.9 TB/s vs 3.5 TB/s for the raw 18-byte
+// AoS blocks, because a wave's 64 lanes then issue one aligned 1 KiB dwordx4 request.
+//   Q4_0: qs[n][16]            | d[n] f16
+//   Q8_0: qs[n][32]            | d[n] f16
+//   Q4_1: qs[n][16]            | dm[n] (d f16, m f16)
+//   Q4_K: unchanged 144-byte blocks (already 16-byte granular: d,dmin,scales[12] | qs[128])
+//   Q8_K: qs[n][256]           | d[n] f32            (bsums are derived data; not kept for weights)
+// Quantized ACTIVATIONS (the rhs of matmul_vec) live in a per-buffer scratch, also as planes:
+//   Q8_0: qs[n] i8 | d[n/32] f16 | isum[n/32] i32 (sum of the 32 quants; exact, derived)
+//   Q8_1: qs[n] i8 | d[n/32] f16 | s[n/32] f16
+//   Q8_K: qs[n] i8 | d[n/256] f32 | bsums[n/16] i16
+//   F16 : h[n] f16 (buf/api.rs:198)
+struct WeightLayout {
+  size_t n_blocks = 0;
+  size_t off_scale = 0;  // byte offset of the scale plane
+  size_t total = 0;      // bytes
+};
+WeightLayout weight_layout(uint32_t dtype, size_t n_elems);
+
+struct ActLayout {
+  size_t off_d = 0, off_aux = 0, total = 0;
+};
+ActLayout act_layout(uint32_t qtype, size_t n_elems);
+
+}  // namespace crabml_hip
+
+// ---- the opaque C types ------------------------------------------------------------------------
+struct crabml_hip_device {
+  int ordinal = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 256;
+  bool strict_order = false;  // CRABML_HIP_FLAG_STRICT_ORDER
+  std::mutex mu;
+  std::string last_error;
+  // caching allocator: size class -> free blocks (single stream => stream-ordered reuse is safe)
+  std::map<size_t, std::vector<void*>> pool;
+  size_t bytes_reserved = 0;
+  // f16 lookup tables (cpu_device.rs:108-125)
+  uint16_t* exp_table = nullptr;
+  uint16_t* gelu_table = nullptr;
+};
+
+struct crabml_hip_buf {
+  crabml_hip_device* dev = nullptr;
+  std::atomic<int> refcnt{1};
+  uint32_t dtype = 0;
+  size_t n_elems = 0;
+  void* ptr = nullptr;
+  size_t cap = 0;       // pool capacity in bytes
+  size_t m = 0, k = 0;  // logical 2-D shape of quantized weights
+  crabml_hip::WeightLayout wl;
+  // activation-quantization cache: matmul_vec re-quantizes its rhs on every call in the reference
+  // (matmul_vec.rs:37-40); here q/k/v and gate/up share one pass.  `version` is bumped by every
+  // op that writes the buffer, which invalidates the cache.
+  uint64_t version = 1;
+  struct {
+    uint32_t qtype = 0xffffffffu;
+    uint64_t version = 0;
+    size_t n = 0;
+    void* ptr = nullptr;
+    size_t cap = 0;
+  } qc;
+};
+
+namespace crabml_hip {
+
+int set_error(crabml_hip_device* dev, int status, const char* fmt, ...);
+int hip_fail(crabml_hip_device* dev, hipError_t e, const char* what, const char* file, int line);
+
+#define CH_HIP(dev, expr)                                                                        \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess) return ::crabml_hip::hip_fail((dev), e__, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define CH_BAIL(dev, status, ...) return ::crabml_hip::set_error((dev), (status), __VA_ARGS__)
+
+#define CH_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+int pool_alloc(crabml_hip_device* dev, size_t bytes, void** out, size_t* cap);
+void pool_free(crabml_hip_device* dev, void* ptr, size_t cap);
+int buf_new(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes, crabml_hip_buf** out);
+inline void touch(crabml_hip_buf* b) { b->version++; }
+
+}  // namespace crabml_hip

@@ -1,0 +1,462 @@
+// gemv.hip -- block-quantized decode GEMV for gfx950 (the kernel the HBM-roofline target is on).
+//
+// Replaces gemv_dense_2d_2d + CpuTensorBuf::vec_dot (crabml-core/src/cpu/primitives/matmul_vec.rs:26-78,
+// crabml-core/src/cpu/buf/api.rs:230-249) and the per-format vec_dot_* kernels:
+//   Q4_0 x Q8_0  buf_q4_0.rs:240-253      Q8_0 x Q8_0  buf_q8_0.rs:275-286
+//   Q4_1 x Q8_1  buf_q4_1.rs:266-280      Q4_K x Q8_K  buf_q4_k.rs:192-277      Q8_K x Q8_K  buf_q8_k.rs:211-224
+//   F32 x F32    buf_f32.rs:19-27         F16 x F16    buf_f16.rs:83-97
+//
+// Mapping (chosen by measurement, profiles/r01_gemv_lab_layout_sweep.log): one wavefront owns R
+// consecutive output rows; lane l owns quant blocks l, l+64, ... of each row, so one wave step is a
+// single aligned 1 KiB `global_load_dwordx4 ... nt` of packed nibbles plus a 128-byte load of the
+// f16 scales.  The integer part of every block product (nibble unpack, -8 offset, int8 dot) is exact
+// (v_dot4_i32_i8); the per-block f32 scaling follows the reference's expression
+// `(sumi as f32 * d_w) * d_x`; only the ORDER in which block terms are added differs from the scalar
+// CPU loop (lane-strided partial sums + a 64-lane butterfly), which is why logits carry an fp tolerance.
+// The kernel is HBM-bound (~3.6 flop/byte): no LDS round trip, no MFMA; x is re-read from L1/L2.
+#include "devutil.hpp"
+#include "kernels.hpp"
+
+namespace crabml_hip {
+
+// ---- exact integer block dots ----------------------------------------------------------------
+// Q4_0 block (16 bytes: byte j = elem j (low nibble) | elem j+16 (high nibble)) . 32 int8, minus 8*sum(x)
+__device__ __forceinline__ int dot_q4_0(i32x4 q, i32x4 xlo, i32x4 xhi, int xsum) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int w = q[i];
+    s = __builtin_amdgcn_sdot4(w & 0x0F0F0F0F, xlo[i], s, false);
+    s = __builtin_amdgcn_sdot4((w >> 4) & 0x0F0F0F0F, xhi[i], s, false);
+  }
+  return s - 8 * xsum;
+}
+// unsigned nibbles (Q4_1, Q4_K)
+__device__ __forceinline__ int dot_u4(i32x4 q, i32x4 xlo, i32x4 xhi) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int w = q[i];
+    s = __builtin_amdgcn_sdot4(w & 0x0F0F0F0F, xlo[i], s, false);
+    s = __builtin_amdgcn_sdot4((w >> 4) & 0x0F0F0F0F, xhi[i], s, false);
+  }
+  return s;
+}
+__device__ __forceinline__ int dot_i8x32(i32x4 a0, i32x4 a1, i32x4 b0, i32x4 b1) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    s = __builtin_amdgcn_sdot4(a0[i], b0[i], s, false);
+    s = __builtin_amdgcn_sdot4(a1[i], b1[i], s, false);
+  }
+  return s;
+}
+
+struct ActQ8_0 {
+  const i32x4* q;
+  const unsigned short* d;
+  const int* isum;
+};
+struct ActQ8_1 {
+  const i32x4* q;
+  const unsigned short* d;
+  const unsigned short* s;
+};
+struct ActQ8_K {
+  const i32x4* q;
+  const float* d;
+  const short* bsums;
+};
+
+// ---- Q4_0 x Q8_0 ---------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_q4_0(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
+                                                   ActQ8_0 act, float* __restrict__ out, int m, int nb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    i32x4 q[R];
+    unsigned short dw[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      size_t idx = (size_t)row * nb + b;
+      q[r] = __builtin_nontemporal_load(wq + idx);
+      dw[r] = __builtin_nontemporal_load(wd + idx);
+    }
+    i32x4 xlo = act.q[2 * b], xhi = act.q[2 * b + 1];
+    float dx = h2f(act.d[b]);
+    int xs = act.isum[b];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int si = dot_q4_0(q[r], xlo, xhi, xs);
+      acc[r] += ((float)si * h2f(dw[r])) * dx;  // buf_q4_0.rs:249
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
+// ---- Q8_0 x Q8_0 ---------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_q8_0(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
+                                                   ActQ8_0 act, float* __restrict__ out, int m, int nb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    i32x4 q0[R], q1[R];
+    unsigned short dw[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      size_t idx = (size_t)row * nb + b;
+      q0[r] = __builtin_nontemporal_load(wq + 2 * idx);
+      q1[r] = __builtin_nontemporal_load(wq + 2 * idx + 1);
+      dw[r] = __builtin_nontemporal_load(wd + idx);
+    }
+    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
+    float dx = h2f(act.d[b]);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int si = dot_i8x32(q0[r], q1[r], x0, x1);
+      acc[r] += ((float)si * h2f(dw[r])) * dx;  // buf_q8_0.rs:282
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
+// ---- Q4_1 x Q8_1 ---------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_q4_1(const i32x4* __restrict__ wq, const unsigned* __restrict__ wdm,
+                                                   ActQ8_1 act, float* __restrict__ out, int m, int nb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    i32x4 q[R];
+    unsigned dm[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      size_t idx = (size_t)row * nb + b;
+      q[r] = __builtin_nontemporal_load(wq + idx);
+      dm[r] = __builtin_nontemporal_load(wdm + idx);
+    }
+    i32x4 xlo = act.q[2 * b], xhi = act.q[2 * b + 1];
+    unsigned short dx = act.d[b], sx = act.s[b];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int si = dot_u4(q[r], xlo, xhi);
+      unsigned short dwh = (unsigned short)(dm[r] & 0xffffu), mwh = (unsigned short)(dm[r] >> 16);
+      // buf_q4_1.rs:276: (d_w * d_x) and (m * s) are f16 products rounded to f16 by the half crate
+      acc[r] += h2f(h_mul(dwh, dx)) * (float)si + h2f(h_mul(mwh, sx));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
+// ---- Q4_K x Q8_K ---------------------------------------------------------------------------------
+// 144-byte super-blocks: [d f16, dmin f16, scales[12]] [qs[128]].  A lane owns one 32-byte qs chunk
+// = sub-blocks 2p (low nibbles) and 2p+1 (high nibbles): 4 lanes per super-block.
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_q4_k(const unsigned char* __restrict__ w, ActQ8_K act,
+                                                   float* __restrict__ out, int m, int nsb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int nchunks = nsb * 4;
+  for (int c = lane; c < nchunks; c += 64) {
+    const int sb = c >> 2, p = c & 3;
+    const i32x4* xq = act.q + (size_t)sb * 16 + p * 4;  // 64 int8 = 4 x 16 B
+    i32x4 xl0 = xq[0], xl1 = xq[1], xh0 = xq[2], xh1 = xq[3];
+    float d8 = act.d[sb];
+    const short* bs = act.bsums + sb * 16 + p * 4;
+    int bs_lo = (int)bs[0] + (int)bs[1], bs_hi = (int)bs[2] + (int)bs[3];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      const unsigned char* blk = w + ((size_t)row * nsb + sb) * 144;
+      i32x4 hdr = __builtin_nontemporal_load((const i32x4*)blk);
+      i32x4 qa = __builtin_nontemporal_load((const i32x4*)(blk + 16 + p * 32));
+      i32x4 qb = __builtin_nontemporal_load((const i32x4*)(blk + 32 + p * 32));
+      // 6-bit (scale, min) unpack with the reference's KMASK word trick (buf_q4_k.rs:219-234), then a
+      // run-time byte select -- no per-lane indexed array, so nothing spills to scratch.
+      const unsigned u0 = (unsigned)hdr[1], u1 = (unsigned)hdr[2], u2 = (unsigned)hdr[3];
+      const unsigned S0 = u0 & 0x3f3f3f3fu, S1 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
+      const unsigned M0 = u1 & 0x3f3f3f3fu, M1 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
+      const unsigned SW = p < 2 ? S0 : S1, MW = p < 2 ? M0 : M1;
+      const int sh = (p & 1) * 16;
+      const int sc_lo = (int)((SW >> sh) & 0xffu), sc_hi = (int)((SW >> (sh + 8)) & 0xffu);
+      const int m_lo = (int)((MW >> sh) & 0xffu), m_hi = (int)((MW >> (sh + 8)) & 0xffu);
+      // low nibbles of the 32 bytes <-> x[0..32), high nibbles <-> x[32..64)   (buf_q4_k.rs:212-217)
+      int lo = 0, hi = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        lo = __builtin_amdgcn_sdot4(qa[i] & 0x0F0F0F0F, xl0[i], lo, false);
+        lo = __builtin_amdgcn_sdot4(qb[i] & 0x0F0F0F0F, xl1[i], lo, false);
+        hi = __builtin_amdgcn_sdot4((qa[i] >> 4) & 0x0F0F0F0F, xh0[i], hi, false);
+        hi = __builtin_amdgcn_sdot4((qb[i] >> 4) & 0x0F0F0F0F, xh1[i], hi, false);
+      }
+      int isum = sc_lo * lo + sc_hi * hi;          // exact (the reference's aux32 lanes hold integers < 2^24)
+      int msum = m_lo * bs_lo + m_hi * bs_hi;      // i32: the intended math of buf_q4_k.rs:238-241
+      float dd = h2f((unsigned short)(hdr[0] & 0xffff)) * d8;
+      float dmin = h2f((unsigned short)((unsigned)hdr[0] >> 16)) * d8;
+      acc[r] += dd * (float)isum - dmin * (float)msum;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
+// ---- Q8_K x Q8_K ---------------------------------------------------------------------------------
+// planes: qs[n][256] | d[n] f32.  A lane owns one 32-element group; the 8 lanes of a super-block add
+// their integer partials (exact) before the single f32 scaling `sum_i as f32 * d_a * d_b`.
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_q8_k(const i32x4* __restrict__ wq, const float* __restrict__ wd,
+                                                   ActQ8_K act, float* __restrict__ out, int m, int nsb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int ngroups = nsb * 8;
+  for (int g0 = 0; g0 < ngroups; g0 += 64) {
+    const int g = g0 + lane;
+    const bool live = g < ngroups;
+    const int gg = live ? g : ngroups - 1;
+    const int sb = gg >> 3;
+    i32x4 x0 = act.q[2 * (size_t)gg], x1 = act.q[2 * (size_t)gg + 1];
+    float d8 = act.d[sb];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      size_t gi = (size_t)row * ngroups + gg;
+      i32x4 q0 = __builtin_nontemporal_load(wq + 2 * gi);
+      i32x4 q1 = __builtin_nontemporal_load(wq + 2 * gi + 1);
+      int si = live ? dot_i8x32(q0, q1, x0, x1) : 0;
+      si += __shfl_xor(si, 1, 64);
+      si += __shfl_xor(si, 2, 64);
+      si += __shfl_xor(si, 4, 64);
+      if (live && (lane & 7) == 0) acc[r] += ((float)si * wd[(size_t)row * nsb + sb]) * d8;  // buf_q8_k.rs:220
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
+// ---- F32 / F16 weights ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemv_f32(const float* __restrict__ w, const float* __restrict__ x,
+                                                  float* __restrict__ out, int m, int k) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const float* wr = w + (size_t)row * k;
+  float acc = 0.f;
+  for (int i = lane; i < k; i += 64) acc += wr[i] * x[i];
+  acc = wave_sum_f32(acc);
+  if (lane == 0) out[row] = acc;
+}
+__global__ __launch_bounds__(256) void k_gemv_f16(const unsigned short* __restrict__ w,
+                                                  const unsigned short* __restrict__ x16, float* __restrict__ out,
+                                                  int m, int k) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const unsigned short* wr = w + (size_t)row * k;
+  float acc = 0.f;
+  for (int i = lane; i < k; i += 64) acc += h2f(wr[i]) * h2f(x16[i]);
+  acc = wave_sum_f32(acc);
+  if (lane == 0) out[row] = acc;
+}
+
+// ---- host launcher -------------------------------------------------------------------------------
+template <typename F>
+static void launch_rows(hipStream_t st, int m, int n_cu, F&& f) {
+  // R rows per wave: enough waves to cover the chip a few times over, otherwise fewer rows per wave
+  // (lab: R=2 is best from ~14k rows, R=1 below).
+  int R = m >= 8192 ? 2 : 1;
+  int waves = (m + R - 1) / R;
+  int tpb = 128;  // 2 waves per workgroup (lab: 64/128/256 within noise; 128 best on the classifier)
+  int wpb = tpb / 64;
+  int grid = (waves + wpb - 1) / wpb;
+  f(R, grid, tpb);
+  (void)n_cu;
+}
+
+int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size_t k_, const void* act, size_t b,
+                float* out) {
+  hipStream_t st = dev->stream;
+  const int m = (int)m_, k = (int)k_;
+  const char* wp = (const char*)w->ptr;
+  const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
+  const ActLayout al = act_layout(qt, k_);
+  for (size_t bi = 0; bi < b; bi++) {
+    const char* ap = (const char*)act + bi * al.total;
+    float* o = out + bi * m_;
+    switch (w->dtype) {
+      case CRABML_HIP_Q4_0: {
+        ActQ8_0 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
+        const int nb = k / 32;
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            k_gemv_q4_0<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+          else
+            k_gemv_q4_0<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+        });
+        break;
+      }
+      case CRABML_HIP_Q8_0: {
+        ActQ8_0 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
+        const int nb = k / 32;
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            k_gemv_q8_0<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+          else
+            k_gemv_q8_0<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+        });
+        break;
+      }
+      case CRABML_HIP_Q4_1: {
+        ActQ8_1 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const unsigned short*)(ap + al.off_aux)};
+        const int nb = k / 32;
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            k_gemv_q4_1<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned*)(wp + w->wl.off_scale), a, o, m, nb);
+          else
+            k_gemv_q4_1<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned*)(wp + w->wl.off_scale), a, o, m, nb);
+        });
+        break;
+      }
+      case CRABML_HIP_Q4_K: {
+        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const int nsb = k / 256;
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            k_gemv_q4_k<2><<<grid, tpb, 0, st>>>((const unsigned char*)wp, a, o, m, nsb);
+          else
+            k_gemv_q4_k<1><<<grid, tpb, 0, st>>>((const unsigned char*)wp, a, o, m, nsb);
+        });
+        break;
+      }
+      case CRABML_HIP_Q8_K: {
+        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const int nsb = k / 256;
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            k_gemv_q8_k<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), a, o, m, nsb);
+          else
+            k_gemv_q8_k<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), a, o, m, nsb);
+        });
+        break;
+      }
+      case CRABML_HIP_F32: {
+        int grid = (m + 3) / 4;
+        k_gemv_f32<<<grid, 256, 0, st>>>((const float*)wp, (const float*)ap, o, m, k);
+        break;
+      }
+      case CRABML_HIP_F16: {
+        int grid = (m + 3) / 4;
+        k_gemv_f16<<<grid, 256, 0, st>>>((const unsigned short*)wp, (const unsigned short*)ap, o, m, k);
+        break;
+      }
+      default:
+        return set_error(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
+    }
+  }
+  return 0;
+}
+
+// ---- parity hook: the exact integer part per 32-element group, through the SAME unpack code ----------
+__global__ void k_block_dots_32(const i32x4* __restrict__ wq, int wtype, ActQ8_0 a0, ActQ8_1 a1, size_t row_block0,
+                                int nb, int* __restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  size_t idx = row_block0 + b;
+  if (wtype == CRABML_HIP_Q4_0) {
+    out[b] = dot_q4_0(wq[idx], a0.q[2 * b], a0.q[2 * b + 1], a0.isum[b]);
+  } else if (wtype == CRABML_HIP_Q8_0) {
+    out[b] = dot_i8x32(wq[2 * idx], wq[2 * idx + 1], a0.q[2 * b], a0.q[2 * b + 1]);
+  } else {
+    out[b] = dot_u4(wq[idx], a1.q[2 * b], a1.q[2 * b + 1]);
+  }
+}
+__global__ void k_block_dots_k(const unsigned char* __restrict__ w, int wtype, ActQ8_K a, size_t row_sb0, int nsb,
+                               int* __restrict__ out) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;  // 32-element group
+  if (g >= nsb * 8) return;
+  int sb = g >> 3;
+  if (wtype == CRABML_HIP_Q4_K) {
+    int p = (g & 7) >> 1, hi_half = g & 1;
+    const unsigned char* blk = w + (row_sb0 + sb) * 144;
+    i32x4 qa = *(const i32x4*)(blk + 16 + p * 32), qb = *(const i32x4*)(blk + 32 + p * 32);
+    const i32x4* xq = a.q + (size_t)sb * 16 + p * 4 + hi_half * 2;
+    i32x4 x0 = xq[0], x1 = xq[1];
+    int s = 0;
+    for (int i = 0; i < 4; i++) {
+      int wa = hi_half ? (qa[i] >> 4) : qa[i], wb = hi_half ? (qb[i] >> 4) : qb[i];
+      s = __builtin_amdgcn_sdot4(wa & 0x0F0F0F0F, x0[i], s, false);
+      s = __builtin_amdgcn_sdot4(wb & 0x0F0F0F0F, x1[i], s, false);
+    }
+    out[g] = s;
+  } else {
+    const i32x4* wq = (const i32x4*)w;
+    size_t gi = row_sb0 * 8 + g;
+    out[g] = dot_i8x32(wq[2 * gi], wq[2 * gi + 1], a.q[2 * (size_t)g], a.q[2 * (size_t)g + 1]);
+  }
+}
+
+void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out) {
+  const char* wp = (const char*)w->ptr;
+  const char* ap = (const char*)act;
+  const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
+  const ActLayout al = act_layout(qt, k);
+  if (w->dtype == CRABML_HIP_Q4_K || w->dtype == CRABML_HIP_Q8_K) {
+    ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+    int nsb = (int)(k / 256);
+    k_block_dots_k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>((const unsigned char*)wp, (int)w->dtype, a, row * nsb, nsb, out);
+  } else {
+    ActQ8_0 a0{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
+    ActQ8_1 a1{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const unsigned short*)(ap + al.off_aux)};
+    int nb = (int)(k / 32);
+    k_block_dots_32<<<(nb + 63) / 64, 64, 0, st>>>((const i32x4*)wp, (int)w->dtype, a0, a1, row * nb, nb, out);
+  }
+}
+
+}  // namespace crabml_hip

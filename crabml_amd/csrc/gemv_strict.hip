@@ -1,0 +1,159 @@
+// gemv_strict.hip -- strict-order matmul_vec (CRABML_HIP_FLAG_STRICT_ORDER): a parity instrument.
+//
+// One thread per output row walks the row's blocks in order and evaluates exactly the reference's
+// scalar loops (vec_dot_*_fallback: buf_q4_0.rs:240-253, buf_q8_0.rs:275-286, buf_q4_1.rs:266-280,
+// buf_q4_k.rs:192-277, buf_q8_k.rs:211-224, buf_f32.rs:19-27, buf_f16.rs:83-97) -- same integer sums,
+// same f32 expression, same association -- on the same device planes the fast kernels read.  Logits are
+// then bit-identical to the default (non-SIMD) build of the reference, which turns the end-to-end parity
+// check into an equality test.  Not a performance path (uncoalesced by construction).
+#include "devutil.hpp"
+#include "kernels.hpp"
+
+namespace crabml_hip {
+
+__global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, int dtype, size_t off_scale,
+                                                    const char* __restrict__ act, size_t off_d, size_t off_aux,
+                                                    float* __restrict__ out, int m, int k) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
+  float sumf = 0.0f;
+  switch (dtype) {
+    case CRABML_HIP_Q4_0: {
+      const int nb = k / 32;
+      const unsigned short* wd = (const unsigned short*)(w + off_scale);
+      const unsigned short* xd = (const unsigned short*)(act + off_d);
+      for (int b = 0; b < nb; b++) {
+        const unsigned char* qs = (const unsigned char*)w + ((size_t)row * nb + b) * 16;
+        const signed char* xq = (const signed char*)act + (size_t)b * 32;
+        int sumi = 0;
+        for (int j = 0; j < 16; j++) {
+          int v0 = (int)(qs[j] & 0x0F) - 8, v1 = (int)(qs[j] >> 4) - 8;
+          sumi += v0 * (int)xq[j] + v1 * (int)xq[j + 16];
+        }
+        sumf += (float)sumi * h2f(wd[(size_t)row * nb + b]) * h2f(xd[b]);
+      }
+      break;
+    }
+    case CRABML_HIP_Q8_0: {
+      const int nb = k / 32;
+      const unsigned short* wd = (const unsigned short*)(w + off_scale);
+      const unsigned short* xd = (const unsigned short*)(act + off_d);
+      for (int b = 0; b < nb; b++) {
+        const signed char* qs = (const signed char*)w + ((size_t)row * nb + b) * 32;
+        const signed char* xq = (const signed char*)act + (size_t)b * 32;
+        int sumi = 0;
+        for (int j = 0; j < 32; j++) sumi += (int)qs[j] * (int)xq[j];
+        sumf += (float)sumi * h2f(wd[(size_t)row * nb + b]) * h2f(xd[b]);
+      }
+      break;
+    }
+    case CRABML_HIP_Q4_1: {
+      const int nb = k / 32;
+      const unsigned* wdm = (const unsigned*)(w + off_scale);
+      const unsigned short* xd = (const unsigned short*)(act + off_d);
+      const unsigned short* xs = (const unsigned short*)(act + off_aux);
+      for (int b = 0; b < nb; b++) {
+        const unsigned char* qs = (const unsigned char*)w + ((size_t)row * nb + b) * 16;
+        const signed char* xq = (const signed char*)act + (size_t)b * 32;
+        int sumi = 0;
+        for (int j = 0; j < 16; j++) {
+          int v0 = (int)(qs[j] & 0x0F), v1 = (int)((qs[j] >> 4) & 0x0F);
+          sumi += v0 * (int)xq[j] + v1 * (int)xq[j + 16];
+        }
+        unsigned dm = wdm[(size_t)row * nb + b];
+        unsigned short dw = (unsigned short)(dm & 0xffffu), mw = (unsigned short)(dm >> 16);
+        sumf += h2f(h_mul(dw, xd[b])) * (float)sumi + h2f(h_mul(mw, xs[b]));
+      }
+      break;
+    }
+    case CRABML_HIP_Q4_K: {
+      const int nsb = k / 256;
+      const float* xd = (const float*)(act + off_d);
+      const short* bsums = (const short*)(act + off_aux);
+      float sums[8];
+      for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+      for (int sb = 0; sb < nsb; sb++) {
+        const unsigned char* blk = (const unsigned char*)w + ((size_t)row * nsb + sb) * 144;
+        const signed char* q8 = (const signed char*)act + (size_t)sb * 256;
+        unsigned short dh, mh;
+        __builtin_memcpy(&dh, blk, 2);
+        __builtin_memcpy(&mh, blk + 2, 2);
+        const unsigned char* sc = blk + 4;
+        const unsigned char* q4 = blk + 16;
+        float aux32[8];
+        for (int l = 0; l < 8; l++) aux32[l] = 0.0f;
+        int scales[8], mins[8];
+        for (int j = 0; j < 8; j++) {
+          if (j < 4) {
+            scales[j] = sc[j] & 63;
+            mins[j] = sc[j + 4] & 63;
+          } else {
+            scales[j] = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4);
+            mins[j] = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4);
+          }
+        }
+        int sumi = 0;
+        for (int j = 0; j < 16; j++) sumi += (int)bsums[sb * 16 + j] * mins[j / 2];
+        for (int is = 0; is < 8; is++) {
+          const float scale = (float)scales[is];
+          const int c = is >> 1, hi = is & 1;
+          for (int g = 0; g < 4; g++)
+            for (int l = 0; l < 8; l++) {
+              int e = 8 * g + l;  // element within the 32-wide sub-block
+              unsigned char qb = q4[32 * c + e];
+              int a = hi ? (qb >> 4) : (qb & 0xF);
+              int prod = (int)q8[32 * is + e] * a;  // aux16
+              aux32[l] += scale * (float)prod;
+            }
+        }
+        const float d = h2f(dh) * xd[sb];
+        for (int l = 0; l < 8; l++) sums[l] += d * aux32[l];
+        const float dmin = h2f(mh) * xd[sb];
+        sumf -= dmin * (float)sumi;
+      }
+      for (int l = 0; l < 8; l++) sumf += sums[l];
+      break;
+    }
+    case CRABML_HIP_Q8_K: {
+      const int nsb = k / 256;
+      const float* wd = (const float*)(w + off_scale);
+      const float* xd = (const float*)(act + off_d);
+      for (int sb = 0; sb < nsb; sb++) {
+        const signed char* qs = (const signed char*)w + ((size_t)row * nsb + sb) * 256;
+        const signed char* xq = (const signed char*)act + (size_t)sb * 256;
+        int s = 0;
+        for (int j = 0; j < 256; j++) s += (int)qs[j] * (int)xq[j];
+        sumf += (float)s * wd[(size_t)row * nsb + sb] * xd[sb];
+      }
+      break;
+    }
+    case CRABML_HIP_F32: {
+      const float* wr = (const float*)w + (size_t)row * k;
+      const float* x = (const float*)act;
+      for (int i = 0; i < k; i++) sumf += wr[i] * x[i];
+      break;
+    }
+    case CRABML_HIP_F16: {
+      const unsigned short* wr = (const unsigned short*)w + (size_t)row * k;
+      const unsigned short* x = (const unsigned short*)act;
+      for (int i = 0; i < k; i++) sumf += h2f(wr[i]) * h2f(x[i]);
+      break;
+    }
+    default: break;
+  }
+  out[row] = sumf;
+}
+
+int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
+                       float* out) {
+  const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
+  if (qt == 0xffffffffu) return set_error(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
+  const ActLayout al = act_layout(qt, k);
+  for (size_t bi = 0; bi < b; bi++)
+    k_gemv_strict<<<(unsigned)((m + 63) / 64), 64, 0, dev->stream>>>((const char*)w->ptr, (int)w->dtype, w->wl.off_scale,
+                                                                     (const char*)act + bi * al.total, al.off_d,
+                                                                     al.off_aux, out + bi * m, (int)m, (int)k);
+  return 0;
+}
+
+}  // namespace crabml_hip

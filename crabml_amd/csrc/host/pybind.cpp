@@ -1,0 +1,235 @@
+// pybind.cpp -- python face of the host-side mirror (HipTensor / HipTensorDevice / TensorStrider /
+// Llama2Runner<HipTensor>), so the pytest suite can be written like the reference's own Rust tests
+// (crabml-core/src/cpu/cpu_tensor.rs:455-606, crabml-wgpu/src/wgpu_tensor.rs:742-1099).
+// Everything here calls straight through to the C ABI of libcrabml_hip.so; there is no CPU fallback.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <chrono>
+
+#include "hip_tensor.hpp"
+#include "llama2_runner.hpp"
+
+namespace py = pybind11;
+using namespace crabml_host;
+
+static py::object g_tensor_error;  // python exception class crabml_amd.TensorError
+
+static std::vector<size_t> to_shape(const py::sequence& s) {
+  std::vector<size_t> v;
+  for (auto it : s) v.push_back(it.cast<size_t>());
+  return v;
+}
+
+using Runner = Llama2Runner<HipTensor>;
+using Weights = LlamaWeights<HipTensor>;
+
+PYBIND11_MODULE(_host, m) {
+  m.doc() = "crabml-hip host mirror over the C ABI of libcrabml_hip.so";
+
+  static py::exception<Error> exc(m, "CrabmlError");
+  py::register_exception_translator([](std::exception_ptr p) {
+    try {
+      if (p) std::rethrow_exception(p);
+    } catch (const Error& e) {
+      std::string msg = std::string("ErrorKind(") + std::to_string((int)e.kind) + "): " + e.what();
+      PyErr_SetString(exc.ptr(), msg.c_str());
+    }
+  });
+  m.def("abi_version", []() { return crabml_hip_abi_version(); });
+
+  py::enum_<GGMLType>(m, "GGMLType")
+      .value("F32", GGMLType::F32).value("F16", GGMLType::F16).value("Q4_0", GGMLType::Q4_0)
+      .value("Q4_1", GGMLType::Q4_1).value("Q8_0", GGMLType::Q8_0).value("Q8_1", GGMLType::Q8_1)
+      .value("Q4K", GGMLType::Q4K).value("Q8K", GGMLType::Q8K);
+  py::enum_<RopeMode>(m, "RopeMode").value("Llama", RopeMode::Llama).value("Neox", RopeMode::Neox);
+
+  py::class_<TensorStrider>(m, "TensorStrider")
+      .def(py::init([](const py::sequence& s) { return TensorStrider(to_shape(s)); }))
+      .def(py::init([](const py::sequence& s, const py::sequence& st) { return TensorStrider(to_shape(s), to_shape(st)); }))
+      .def("shape", [](const TensorStrider& s) { return s.shape(); })
+      .def("strides", [](const TensorStrider& s) { return s.strides(); })
+      .def("dims", &TensorStrider::dims)
+      .def("len", &TensorStrider::len)
+      .def("resize", [](const TensorStrider& s, const py::sequence& ns) { return s.resize(to_shape(ns)); })
+      .def("at", [](const TensorStrider& s, const py::sequence& i) { return s.at(to_shape(i)); })
+      .def("iter", &TensorStrider::iter)
+      .def("reshape", [](const TensorStrider& s, const py::sequence& ns) { return s.reshape(to_shape(ns)); })
+      .def("transpose", [](const TensorStrider& s, const py::sequence& d) { return s.transpose(to_shape(d)); })
+      .def("is_contiguous", &TensorStrider::is_contiguous);
+
+  py::class_<HipTensorDevice, std::shared_ptr<HipTensorDevice>>(m, "HipTensorDevice")
+      .def(py::init([](int ordinal, bool debug_named_tensor, size_t stream, bool strict_order) {
+             HipTensorDeviceOptions o;
+             o.device_ordinal = ordinal;
+             o.debug_named_tensor = debug_named_tensor;
+             o.stream = reinterpret_cast<void*>(stream);
+             o.strict_order = strict_order;
+             return std::make_shared<HipTensorDevice>(o);
+           }),
+           py::arg("device_ordinal") = 0, py::arg("debug_named_tensor") = false, py::arg("stream") = 0,
+           py::arg("strict_order") = false)
+      .def("sync", &HipTensorDevice::sync, py::call_guard<py::gil_scoped_release>())
+      .def("mem_in_use", &HipTensorDevice::mem_in_use)
+      .def("stream", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(crabml_hip_device_stream(d.raw())); })
+      .def("raw_handle", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(d.raw()); })
+      .def("dump_debug_tensor", [](HipTensorDevice& d, const std::string& name) -> py::object {
+        std::vector<float> v;
+        if (!d.dump_debug_tensor(name, &v)) return py::none();
+        return py::array_t<float>(v.size(), v.data());
+      });
+
+  py::class_<HipTensor>(m, "HipTensor")
+      .def_static("from_cpu",
+                  [](py::buffer buf, const py::sequence& shape, GGMLType dtype, std::shared_ptr<HipTensorDevice> dev) {
+                    py::buffer_info info = buf.request();
+                    size_t nbytes = (size_t)info.size * (size_t)info.itemsize;
+                    return HipTensor::from_cpu(info.ptr, nbytes, to_shape(shape), dtype, std::move(dev));
+                  })
+      .def_static("new",
+                  [](py::array_t<float, py::array::c_style | py::array::forcecast> a, const py::sequence& shape,
+                     std::shared_ptr<HipTensorDevice> dev) {
+                    std::vector<float> v(a.data(), a.data() + a.size());
+                    return HipTensor::from_f32(v, to_shape(shape), std::move(dev));
+                  })
+      .def_static("alloc", [](const py::sequence& shape, GGMLType dtype, std::shared_ptr<HipTensorDevice> dev) {
+        return HipTensor::alloc(to_shape(shape), dtype, std::move(dev));
+      })
+      .def("dtype", &HipTensor::dtype)
+      .def("shape", [](const HipTensor& t) { return t.shape(); })
+      .def("strider", [](const HipTensor& t) { return t.strider(); })
+      .def("is_contiguous", &HipTensor::is_contiguous)
+      .def("buf_len", &HipTensor::buf_len)
+      .def("name", &HipTensor::name)
+      .def("resize", &HipTensor::resize)
+      .def("reshape", [](const HipTensor& t, const py::sequence& s) { return t.reshape(to_shape(s)); })
+      .def("transpose", [](const HipTensor& t, const py::sequence& s) { return t.transpose(to_shape(s)); })
+      .def("with_strider", &HipTensor::with_strider)
+      .def("with_name", &HipTensor::with_name)
+      .def("contiguous", &HipTensor::contiguous)
+      .def("concatenate", &HipTensor::concatenate)
+      .def("copy_rows_from", [](HipTensor& t, const HipTensor& src, const py::sequence& rows) { t.copy_rows_from(src, to_shape(rows)); })
+      .def("export",
+           [](const HipTensor& t) {
+             std::vector<float> v = t.export_();
+             return py::array_t<float>(v.size(), v.data());
+           })
+      .def("export_raw",
+           [](const HipTensor& t) {
+             std::vector<uint8_t> v = t.export_raw();
+             return py::array_t<uint8_t>(v.size(), v.data());
+           })
+      .def("to_vec",  // test helper like CpuTensor::to_vec (cpu_tensor.rs:100-109): gathers through the strider
+           [](const HipTensor& t) {
+             HipTensor c = t.contiguous();
+             std::vector<float> v = c.export_();
+             return py::array_t<float>(v.size(), v.data());
+           })
+      .def("dup", &HipTensor::dup)
+      .def("rope_inplace", &HipTensor::rope_inplace)
+      .def("rms_norm_inplace", &HipTensor::rms_norm_inplace)
+      .def("softmax_inplace", &HipTensor::softmax_inplace)
+      .def("silu_inplace", &HipTensor::silu_inplace)
+      .def("gelu_inplace", &HipTensor::gelu_inplace)
+      .def("mul_inplace", &HipTensor::mul_inplace)
+      .def("add_inplace", &HipTensor::add_inplace)
+      .def("scale_inplace", &HipTensor::scale_inplace)
+      .def("matmul_vec", &HipTensor::matmul_vec)
+      .def("batch_matmul", &HipTensor::batch_matmul)
+      .def("debug_quantize",
+           [](const HipTensor& t, GGMLType q) {
+             std::vector<uint8_t> v = t.debug_quantize(q);
+             return py::array_t<uint8_t>(v.size(), v.data());
+           })
+      .def("debug_block_dots", [](const HipTensor& w, size_t row, const HipTensor& x) {
+        std::vector<int32_t> v = w.debug_block_dots(row, x);
+        return py::array_t<int32_t>(v.size(), v.data());
+      });
+
+  py::class_<LlamaConfig>(m, "LlamaConfig")
+      .def(py::init([](size_t embedding_dim, size_t hidden_dim, size_t n_layers, size_t n_heads, size_t n_kv_heads,
+                       size_t vocab_size, size_t seq_len, float rms_norm_eps, py::object rope_dim) {
+             LlamaConfig c;
+             c.embedding_dim = embedding_dim;
+             c.hidden_dim = hidden_dim;
+             c.n_layers = n_layers;
+             c.n_heads = n_heads;
+             c.n_kv_heads = n_kv_heads;
+             c.vocab_size = vocab_size;
+             c.seq_len = seq_len;
+             c.rms_norm_eps = rms_norm_eps;
+             if (!rope_dim.is_none()) c.rope_dim = rope_dim.cast<size_t>();
+             return c;
+           }),
+           py::arg("embedding_dim"), py::arg("hidden_dim"), py::arg("n_layers"), py::arg("n_heads"),
+           py::arg("n_kv_heads"), py::arg("vocab_size"), py::arg("seq_len"), py::arg("rms_norm_eps") = 1e-5f,
+           py::arg("rope_dim") = py::none())
+      .def_readonly("embedding_dim", &LlamaConfig::embedding_dim)
+      .def_readonly("hidden_dim", &LlamaConfig::hidden_dim)
+      .def_readonly("n_layers", &LlamaConfig::n_layers)
+      .def_readonly("n_heads", &LlamaConfig::n_heads)
+      .def_readonly("n_kv_heads", &LlamaConfig::n_kv_heads)
+      .def_readonly("vocab_size", &LlamaConfig::vocab_size)
+      .def_readonly("seq_len", &LlamaConfig::seq_len)
+      .def("head_size", &LlamaConfig::head_size)
+      .def("kv_dim", &LlamaConfig::kv_dim);
+
+  py::class_<Weights, std::shared_ptr<Weights>>(m, "LlamaWeights")
+      .def(py::init([]() { return std::make_shared<Weights>(); }))
+      .def_readwrite("token_embed", &Weights::token_embed)
+      .def_readwrite("rms_att_weight", &Weights::rms_att_weight)
+      .def_readwrite("rms_ffn_weight", &Weights::rms_ffn_weight)
+      .def_readwrite("wq", &Weights::wq)
+      .def_readwrite("wk", &Weights::wk)
+      .def_readwrite("wv", &Weights::wv)
+      .def_readwrite("wo", &Weights::wo)
+      .def_readwrite("ffn_gate_weight", &Weights::ffn_gate_weight)
+      .def_readwrite("ffn_down_weight", &Weights::ffn_down_weight)
+      .def_readwrite("ffn_up_weight", &Weights::ffn_up_weight)
+      .def_readwrite("rms_final_weight", &Weights::rms_final_weight)
+      .def_property(
+          "output_weight", [](Weights& w) -> py::object { return w.output_weight ? py::cast(*w.output_weight) : py::none(); },
+          [](Weights& w, py::object o) {
+            if (o.is_none())
+              w.output_weight.reset();
+            else
+              w.output_weight = o.cast<HipTensor>();
+          });
+
+  py::class_<Runner>(m, "Llama2Runner")
+      .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,
+                       size_t seq_len, bool use_f16_kv_cache) {
+             return new Runner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, GGMLType::F32, GGMLType::F16);
+           }),
+           py::arg("conf"), py::arg("weights"), py::arg("device"), py::arg("seq_len"), py::arg("use_f16_kv_cache"))
+      .def("kv_cache_len", &Runner::kv_cache_len)
+      .def("forward",
+           [](Runner& r, const std::vector<size_t>& tokens, size_t pos) {
+             {
+               py::gil_scoped_release rel;
+               r.forward(tokens, pos);
+             }
+             return py::array_t<float>(r.logits().size(), r.logits().data());
+           })
+      .def("logits", [](Runner& r) { return py::array_t<float>(r.logits().size(), r.logits().data()); })
+      .def("generate_greedy",
+           [](Runner& r, const std::vector<size_t>& prompt, size_t steps) {
+             py::gil_scoped_release rel;
+             return r.generate_greedy(prompt, steps);
+           })
+      // decode `steps` tokens starting from `token` at the current kv length; returns (ids, seconds)
+      .def("timed_decode", [](Runner& r, size_t token, size_t steps) {
+        py::gil_scoped_release rel;
+        std::vector<size_t> ids;
+        size_t pos = r.kv_cache_len();
+        auto t0 = std::chrono::steady_clock::now();
+        for (size_t s = 0; s < steps; s++) {
+          r.forward({token}, pos + s);
+          token = sample_argmax(r.logits());
+          ids.push_back(token);
+        }
+        double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return std::make_pair(ids, sec);
+      });
+}

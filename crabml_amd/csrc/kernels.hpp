@@ -1,0 +1,45 @@
+// kernels.hpp -- host-side launchers of the gfx950 kernels (one per reference primitive).
+#pragma once
+#include "common.hpp"
+
+namespace crabml_hip {
+
+// ---- quantize.hip: activation quantizers (buf_q8_0.rs:87-134, buf_q8_1.rs:90-129, buf_q8_k.rs:84-131)
+void launch_quantize_act(hipStream_t st, uint32_t qtype, const float* x, size_t n, void* planes);
+
+// ---- gemv.hip: W(m,k) x quantized activations (b,k) -> out (b,m)
+// wq: weight planes; aq: activation planes (one set per batch row, stride act_layout(qtype,k).total)
+int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
+                float* out);
+// gemv_strict.hip: same contract, block terms added in the reference's scalar order (bit-exact; slow)
+int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
+                       float* out);
+void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out);
+
+// ---- elementwise.hip
+void launch_binary(hipStream_t st, int op /*0 add, 1 mul*/, float* a, size_t na, const float* b, size_t nb);
+void launch_scale(hipStream_t st, float* a, size_t n, float f);
+void launch_silu(hipStream_t st, float* x, size_t n, const uint16_t* exp_table);
+void launch_gelu(hipStream_t st, float* x, size_t n, const uint16_t* gelu_table);
+void launch_rms_norm(hipStream_t st, float* x, size_t rows, size_t cols, float eps);
+void launch_softmax(hipStream_t st, float* x, size_t rows, size_t cols, const uint16_t* exp_table);
+// rope: cos/sin of the reference's iterated-theta recurrence are evaluated on the host (same libm as
+// the reference CPU path) and passed by value; see rope.rs:47-80.
+struct RopeTable {
+  float cs[512];  // (cos, sin) pairs, up to 256 rotary pairs
+};
+void launch_rope(hipStream_t st, float* x, size_t n_heads, size_t head_dim, int mode, size_t rope_dims,
+                 const RopeTable& tab);
+void launch_contiguous(hipStream_t st, const void* src, void* dst, int elem_size, const size_t shape[3],
+                       const size_t strides[3]);
+// dst_kind/src_kind: 0 = f32, 1 = f16
+void launch_concatenate(hipStream_t st, void* dst, int dst_f16, size_t dst_off, const size_t dstrides[3],
+                        const void* src, int src_f16, const size_t shape[3], const size_t sstrides[3]);
+void launch_dequant_row(hipStream_t st, const crabml_hip_buf* src, size_t start_elem, size_t n, void* dst,
+                        int dst_f16);
+
+// ---- attention.hip: batch_matmul (batch_matmul.rs:15-131)
+void launch_batch_matmul(hipStream_t st, const float* a, size_t ba, size_t m, size_t k, const void* b, int b_f16,
+                         size_t bb, size_t n, size_t sb0, size_t sb1, size_t sb2, float* c);
+
+}  // namespace crabml_hip

@@ -1,0 +1,175 @@
+// quantize.hip -- on-the-fly activation quantization for matmul_vec's rhs.
+//
+// Replaces CpuTensorBuf::quantize (crabml-core/src/cpu/buf/api.rs:195-228) as called from
+// gemv_dense_2d_2d (crabml-core/src/cpu/primitives/matmul_vec.rs:37-40).  The arithmetic follows the
+// reference, NOT ggml:
+//   Q8_0  d = max|x| / 127 ; q = trunc(x / d)  (true division; simd cast: NaN -> 0)   buf_q8_0.rs:87-134
+//   Q8_1  d = max|x| / 127 ; q = trunc(clamp(x / d, -128, 127)) (NaN -> -128) ; s = f16(d * sum q)
+//                                                                                    buf_q8_1.rs:90-129
+//   Q8_K  mx = first element of max |x| ; scale = -128 / mx ; q = min(round_half_away(scale * x), 127) ;
+//         d = 1 / scale ; bsums over 16                                              buf_q8_k.rs:84-131
+// Output goes to "planes" (see common.hpp).  All outputs are bit-identical to the reference's blocks
+// (tests/test_hip_quantize.py compares the bytes).
+#include "devutil.hpp"
+#include "kernels.hpp"
+
+namespace crabml_hip {
+
+// one 32-lane group per block; 256 threads = 8 blocks per workgroup
+__global__ __launch_bounds__(256) void k_quantize_q8_0(const float* __restrict__ x, signed char* __restrict__ q,
+                                                       unsigned short* __restrict__ d, int* __restrict__ isum,
+                                                       size_t nblocks) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t blk = gid >> 5;
+  int j = (int)(gid & 31);
+  bool live = blk < nblocks;
+  float v = live ? x[blk * 32 + j] : 0.f;
+  float amax = fabsf(v);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+  float dd = amax / 127.0f;
+  float t = v / dd;
+  int qi = rs_f32_as_i32(t);
+  signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);  // `as i8` from i32 wraps
+  int s = (int)q8;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  if (live) {
+    q[blk * 32 + j] = q8;
+    if (j == 0) {
+      d[blk] = f2h(dd);
+      isum[blk] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_quantize_q8_1(const float* __restrict__ x, signed char* __restrict__ q,
+                                                       unsigned short* __restrict__ d, unsigned short* __restrict__ sp,
+                                                       size_t nblocks) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t blk = gid >> 5;
+  int j = (int)(gid & 31);
+  bool live = blk < nblocks;
+  float v = live ? x[blk * 32 + j] : 0.f;
+  float amax = fabsf(v);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+  float dd = amax / 127.0f;
+  float sv = v / dd;
+  // Rust f32::max / f32::min return the non-NaN operand: NaN.max(-128) = -128
+  float c = fminf(fmaxf(sv, -128.0f), 127.0f);
+  int qi = (int)c;  // |c| <= 128: exact truncation
+  int s = qi;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  if (live) {
+    q[blk * 32 + j] = (signed char)qi;
+    if (j == 0) {
+      d[blk] = f2h(dd);
+      // s accumulates small integers in f32 in the reference (exact), then `s *= d`
+      sp[blk] = f2h((float)s * dd);
+    }
+  }
+}
+
+// one wave per 256-element super-block, 4 consecutive elements per lane
+__global__ __launch_bounds__(256) void k_quantize_q8_k(const float* __restrict__ x, signed char* __restrict__ q,
+                                                       float* __restrict__ d, short* __restrict__ bsums,
+                                                       size_t nblocks) {
+  const int lane = threadIdx.x & 63;
+  size_t blk = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (blk >= nblocks) return;  // whole wave exits together
+  f32x4 v = *(const f32x4*)(x + blk * 256 + lane * 4);
+  // first occurrence of the maximum |x| (strict `>` scan in element order)
+  float best_abs = 0.f, best_val = 0.f;
+  int best_idx = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float a = fabsf(v[i]);
+    if (a > best_abs) {
+      best_abs = a;
+      best_val = v[i];
+      best_idx = lane * 4 + i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float oa = __shfl_xor(best_abs, o, 64);
+    float ov = __shfl_xor(best_val, o, 64);
+    int oi = __shfl_xor(best_idx, o, 64);
+    bool take = (oa > best_abs) || (oa == best_abs && oi < best_idx);
+    if (take) {
+      best_abs = oa;
+      best_val = ov;
+      best_idx = oi;
+    }
+  }
+  float scale = -128.0f / best_val;
+  float dd = 1.0f / scale;
+  int qi[4];
+  int s = 0;
+  if (best_abs == 0.0f) {
+    dd = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) qi[i] = 0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float r = roundf(scale * v[i]);  // half away from zero
+      r = fminf(r, 127.0f);
+      int t = rs_f32_as_i32(r);
+      t = t < -128 ? -128 : t;  // `as i8` saturates
+      qi[i] = t;
+      s += t;
+    }
+  }
+  unsigned packed = ((unsigned)qi[0] & 0xffu) | (((unsigned)qi[1] & 0xffu) << 8) | (((unsigned)qi[2] & 0xffu) << 16) |
+                    (((unsigned)qi[3] & 0xffu) << 24);
+  *(unsigned*)(q + blk * 256 + lane * 4) = packed;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if ((lane & 3) == 0) bsums[blk * 16 + (lane >> 2)] = (short)s;
+  if (lane == 0) d[blk] = dd;
+}
+
+__global__ __launch_bounds__(256) void k_quantize_f16(const float* __restrict__ x, unsigned short* __restrict__ h,
+                                                      size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) h[i] = f2h(x[i]);
+}
+
+void launch_quantize_act(hipStream_t st, uint32_t qtype, const float* x, size_t n, void* planes) {
+  if (n == 0) return;
+  ActLayout al = act_layout(qtype, n);
+  char* p = (char*)planes;
+  switch (qtype) {
+    case CRABML_HIP_Q8_0: {
+      size_t nb = n / 32;
+      unsigned grid = (unsigned)((nb * 32 + 255) / 256);
+      k_quantize_q8_0<<<grid, 256, 0, st>>>(x, (signed char*)p, (unsigned short*)(p + al.off_d), (int*)(p + al.off_aux),
+                                           nb);
+      break;
+    }
+    case CRABML_HIP_Q8_1: {
+      size_t nb = n / 32;
+      unsigned grid = (unsigned)((nb * 32 + 255) / 256);
+      k_quantize_q8_1<<<grid, 256, 0, st>>>(x, (signed char*)p, (unsigned short*)(p + al.off_d),
+                                           (unsigned short*)(p + al.off_aux), nb);
+      break;
+    }
+    case CRABML_HIP_Q8_K: {
+      size_t nb = n / 256;
+      unsigned grid = (unsigned)((nb + 3) / 4);
+      k_quantize_q8_k<<<grid, 256, 0, st>>>(x, (signed char*)p, (float*)(p + al.off_d), (short*)(p + al.off_aux), nb);
+      break;
+    }
+    case CRABML_HIP_F16: {
+      unsigned grid = (unsigned)((n + 255) / 256);
+      k_quantize_f16<<<grid, 256, 0, st>>>(x, (unsigned short*)p, n);
+      break;
+    }
+    default: break;
+  }
+}
+
+}  // namespace crabml_hip

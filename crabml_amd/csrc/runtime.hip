@@ -1,0 +1,738 @@
+// runtime.hip -- device / buffer management and the C ABI glue of libcrabml_hip.so.
+//
+// What the reference does with `Arc<CpuTensorDevice>` + `Cow<[f32]>` (crabml-core/src/cpu/cpu_device.rs,
+// cpu_tensor.rs) and the wgpu backend does with `Arc<wgpu::Buffer>` + one queue (crabml-wgpu/src/
+// wgpu_tensor.rs:20-28, wgpu_device.rs) is done here with: one HIP stream per device (all work is
+// stream-ordered, the host only blocks in export), a size-class caching allocator over hipMalloc
+// (activations are allocated and dropped ~30x per layer by the runner), and reference-counted buffers.
+#include <cmath>
+
+#include "kernels.hpp"
+
+using namespace crabml_hip;
+
+namespace crabml_hip {
+
+// ---- errors ------------------------------------------------------------------------------------------
+int set_error(crabml_hip_device* dev, int status, const char* fmt, ...) {
+  char msg[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(msg, sizeof msg, fmt, ap);
+  va_end(ap);
+  if (dev) {
+    std::lock_guard<std::mutex> g(dev->mu);
+    dev->last_error = msg;
+  }
+  return status;
+}
+int hip_fail(crabml_hip_device* dev, hipError_t e, const char* what, const char* file, int line) {
+  return set_error(dev, CRABML_HIP_UNEXPECTED, "HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what,
+                   file, line);
+}
+
+// ---- layouts -----------------------------------------------------------------------------------------
+WeightLayout weight_layout(uint32_t dtype, size_t n_elems) {
+  WeightLayout wl;
+  size_t be = block_elems(dtype);
+  wl.n_blocks = be ? n_elems / be : 0;
+  size_t n = wl.n_blocks;
+  switch (dtype) {
+    case CRABML_HIP_F32: wl.off_scale = 0; wl.total = n_elems * 4; break;
+    case CRABML_HIP_F16: wl.off_scale = 0; wl.total = n_elems * 2; break;
+    case CRABML_HIP_Q4_0: wl.off_scale = align_up(n * 16, 256); wl.total = wl.off_scale + n * 2; break;
+    case CRABML_HIP_Q8_0: wl.off_scale = align_up(n * 32, 256); wl.total = wl.off_scale + n * 2; break;
+    case CRABML_HIP_Q4_1: wl.off_scale = align_up(n * 16, 256); wl.total = wl.off_scale + n * 4; break;
+    case CRABML_HIP_Q4_K: wl.off_scale = 0; wl.total = n * 144; break;
+    case CRABML_HIP_Q8_K: wl.off_scale = align_up(n * 256, 256); wl.total = wl.off_scale + n * 4; break;
+    default: wl.total = 0;
+  }
+  return wl;
+}
+
+ActLayout act_layout(uint32_t qtype, size_t n) {
+  ActLayout al;
+  switch (qtype) {
+    case CRABML_HIP_F32: al.total = align_up(n * 4, 256); break;
+    case CRABML_HIP_F16: al.total = align_up(n * 2, 256); break;
+    case CRABML_HIP_Q8_0:
+      al.off_d = align_up(n, 256);
+      al.off_aux = al.off_d + align_up(n / 32 * 2, 256);
+      al.total = al.off_aux + align_up(n / 32 * 4, 256);
+      break;
+    case CRABML_HIP_Q8_1:
+      al.off_d = align_up(n, 256);
+      al.off_aux = al.off_d + align_up(n / 32 * 2, 256);
+      al.total = al.off_aux + align_up(n / 32 * 2, 256);
+      break;
+    case CRABML_HIP_Q8_K:
+      al.off_d = align_up(n, 256);
+      al.off_aux = al.off_d + align_up(n / 256 * 4, 256);
+      al.total = al.off_aux + align_up(n / 16 * 2, 256);
+      break;
+    default: break;
+  }
+  return al;
+}
+
+// ---- pool --------------------------------------------------------------------------------------------
+static size_t size_class(size_t bytes) {
+  if (bytes < 256) bytes = 256;
+  if (bytes <= ((size_t)1 << 20)) {
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+  }
+  return align_up(bytes, (size_t)1 << 20);
+}
+
+int pool_alloc(crabml_hip_device* dev, size_t bytes, void** out, size_t* cap) {
+  size_t cls = size_class(bytes);
+  {
+    std::lock_guard<std::mutex> g(dev->mu);
+    auto it = dev->pool.find(cls);
+    if (it != dev->pool.end() && !it->second.empty()) {
+      *out = it->second.back();
+      it->second.pop_back();
+      *cap = cls;
+      return 0;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cls);
+  if (e != hipSuccess) {
+    // give pooled blocks back to the driver once, then retry
+    {
+      std::lock_guard<std::mutex> g(dev->mu);
+      for (auto& kv : dev->pool) {
+        for (void* q : kv.second) {
+          (void)hipFree(q);
+          dev->bytes_reserved -= kv.first;
+        }
+        kv.second.clear();
+      }
+    }
+    e = hipMalloc(&p, cls);
+    if (e != hipSuccess) return hip_fail(dev, e, "hipMalloc", __FILE__, __LINE__);
+  }
+  {
+    std::lock_guard<std::mutex> g(dev->mu);
+    dev->bytes_reserved += cls;
+  }
+  *out = p;
+  *cap = cls;
+  return 0;
+}
+
+void pool_free(crabml_hip_device* dev, void* ptr, size_t cap) {
+  if (!ptr) return;
+  std::lock_guard<std::mutex> g(dev->mu);
+  dev->pool[cap].push_back(ptr);
+}
+
+int buf_new(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes, crabml_hip_buf** out) {
+  crabml_hip_buf* b = new crabml_hip_buf();
+  b->dev = dev;
+  b->dtype = dtype;
+  b->n_elems = n_elems;
+  int rc = pool_alloc(dev, bytes, &b->ptr, &b->cap);
+  if (rc != 0) {
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return 0;
+}
+
+// ---- host helpers ------------------------------------------------------------------------------------
+static uint16_t host_f2h(float f) {
+  _Float16 h = (_Float16)f;  // IEEE RNE
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+static float host_h2f(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
+static float gelu_single(float x) {  // gelu.rs:19-22
+  const float COEF_A = 0.044715f;
+  const float S = (float)0.7978845608028654;
+  return 0.5f * x * (1.0f + tanhf(S * x * (1.0f + COEF_A * x * x)));
+}
+
+// quantize rhs of matmul_vec (cached per buffer version)
+static int ensure_act(crabml_hip_device* dev, const crabml_hip_buf* x_, size_t b, size_t k, uint32_t qt,
+                      const void** act) {
+  crabml_hip_buf* x = const_cast<crabml_hip_buf*>(x_);
+  if (qt == CRABML_HIP_F32) {
+    *act = x->ptr;  // CpuTensorBuf::quantize(F32) is a copy (buf/api.rs:197)
+    return 0;
+  }
+  ActLayout al = act_layout(qt, k);
+  size_t need = al.total * b;
+  if (x->qc.qtype == qt && x->qc.version == x->version && x->qc.n == b * k && x->qc.ptr) {
+    *act = x->qc.ptr;
+    return 0;
+  }
+  if (x->qc.cap < need) {
+    if (x->qc.ptr) pool_free(dev, x->qc.ptr, x->qc.cap);
+    x->qc.ptr = nullptr;
+    x->qc.cap = 0;
+    CH_TRY(pool_alloc(dev, need, &x->qc.ptr, &x->qc.cap));
+  }
+  for (size_t bi = 0; bi < b; bi++)
+    launch_quantize_act(dev->stream, qt, (const float*)x->ptr + bi * k, k, (char*)x->qc.ptr + bi * al.total);
+  x->qc.qtype = qt;
+  x->qc.version = x->version;
+  x->qc.n = b * k;
+  *act = x->qc.ptr;
+  return 0;
+}
+
+}  // namespace crabml_hip
+
+// ===========================================================================================================
+// C ABI
+// ===========================================================================================================
+extern "C" {
+
+int crabml_hip_abi_version(void) { return CRABML_HIP_ABI_VERSION; }
+
+int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip_device_t** out) {
+  if (!out) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  crabml_hip_device* dev = new crabml_hip_device();
+  dev->ordinal = opts ? opts->device_ordinal : 0;
+  dev->strict_order = opts && (opts->flags & CRABML_HIP_FLAG_STRICT_ORDER);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || dev->ordinal >= n) {
+    delete dev;
+    return CRABML_HIP_UNEXPECTED;  // no usable MI355X: the backend fails loudly, there is no CPU fallback
+  }
+  if (hipSetDevice(dev->ordinal) != hipSuccess) {
+    delete dev;
+    return CRABML_HIP_UNEXPECTED;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev->ordinal) == hipSuccess) dev->n_cu = prop.multiProcessorCount;
+  if (opts && opts->stream) {
+    dev->stream = (hipStream_t)opts->stream;
+    dev->own_stream = false;
+  } else {
+    if (hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete dev;
+      return CRABML_HIP_UNEXPECTED;
+    }
+    dev->own_stream = true;
+  }
+  // exp table: f16 bits -> f16(exp(f32(x)))   (cpu_device.rs:108-115)
+  std::vector<uint16_t> tab(65536);
+  for (uint32_t x = 0; x < 65536; x++) tab[x] = host_f2h(expf(host_h2f((uint16_t)x)));
+  if (hipMalloc((void**)&dev->exp_table, 65536 * 2) != hipSuccess ||
+      hipMemcpy(dev->exp_table, tab.data(), 65536 * 2, hipMemcpyHostToDevice) != hipSuccess) {
+    delete dev;
+    return CRABML_HIP_UNEXPECTED;
+  }
+  *out = dev;
+  return 0;
+}
+
+int crabml_hip_device_destroy(crabml_hip_device_t* dev) {
+  if (!dev) return 0;
+  (void)hipSetDevice(dev->ordinal);
+  (void)hipStreamSynchronize(dev->stream);
+  for (auto& kv : dev->pool)
+    for (void* p : kv.second) (void)hipFree(p);
+  dev->pool.clear();
+  if (dev->exp_table) (void)hipFree(dev->exp_table);
+  if (dev->gelu_table) (void)hipFree(dev->gelu_table);
+  if (dev->own_stream) (void)hipStreamDestroy(dev->stream);
+  delete dev;
+  return 0;
+}
+
+int crabml_hip_device_sync(crabml_hip_device_t* dev) {
+  if (!dev) return CRABML_HIP_BAD_INPUT;
+  CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  return 0;
+}
+
+size_t crabml_hip_last_error(crabml_hip_device_t* dev, char* buf, size_t cap) {
+  if (!dev) return 0;
+  std::lock_guard<std::mutex> g(dev->mu);
+  if (buf && cap) {
+    size_t n = dev->last_error.size() < cap - 1 ? dev->last_error.size() : cap - 1;
+    memcpy(buf, dev->last_error.data(), n);
+    buf[n] = 0;
+  }
+  return dev->last_error.size();
+}
+
+void* crabml_hip_device_stream(crabml_hip_device_t* dev) { return dev ? (void*)dev->stream : nullptr; }
+
+size_t crabml_hip_device_mem_in_use(crabml_hip_device_t* dev) {
+  if (!dev) return 0;
+  std::lock_guard<std::mutex> g(dev->mu);
+  return dev->bytes_reserved;
+}
+
+// ---- buffers -----------------------------------------------------------------------------------------
+int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t nbytes, const size_t* shape, int ndim,
+                            uint32_t t, crabml_hip_buf_t** out) {
+  if (!dev || !out || (!bytes && nbytes) || ndim < 1 || ndim > 4 || !shape) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  size_t be = block_elems(t), bb = block_bytes(t);
+  if (be == 0 || t == CRABML_HIP_Q8_1)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "unsupported tensor type on hip %u", t);
+  size_t n_elems = 1;
+  for (int i = 0; i < ndim; i++) n_elems *= shape[i];
+  size_t k = shape[ndim - 1];
+  size_t m = k ? n_elems / k : 0;
+  if (be > 1 && k % be != 0)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "last dim %zu is not a multiple of the block size %zu", k, be);
+  size_t expect = n_elems / be * bb;
+  if (nbytes < expect)  // GGUF slices may carry trailing alignment padding (gguf.rs:743-748): >= is accepted
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "data length %zu too small for shape (need %zu)", nbytes, expect);
+  (void)hipSetDevice(dev->ordinal);
+  WeightLayout wl = weight_layout(t, n_elems);
+  crabml_hip_buf* b = nullptr;
+  CH_TRY(buf_new(dev, t, n_elems, wl.total, &b));
+  b->wl = wl;
+  b->m = m;
+  b->k = k;
+  const uint8_t* src = (const uint8_t*)bytes;
+  const size_t nblk = wl.n_blocks;
+  hipError_t e = hipSuccess;
+  if (t == CRABML_HIP_F32 || t == CRABML_HIP_F16 || t == CRABML_HIP_Q4_K) {
+    e = hipMemcpyAsync(b->ptr, src, wl.total, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  } else {
+    // one-time re-layout into planes (see common.hpp); pure byte moves, no arithmetic
+    std::vector<uint8_t> st(wl.total);
+    uint8_t* qs = st.data();
+    uint8_t* sc = st.data() + wl.off_scale;
+    switch (t) {
+      case CRABML_HIP_Q4_0:
+        for (size_t i = 0; i < nblk; i++) {
+          memcpy(qs + i * 16, src + i * 18 + 2, 16);
+          memcpy(sc + i * 2, src + i * 18, 2);
+        }
+        break;
+      case CRABML_HIP_Q8_0:
+        for (size_t i = 0; i < nblk; i++) {
+          memcpy(qs + i * 32, src + i * 34 + 2, 32);
+          memcpy(sc + i * 2, src + i * 34, 2);
+        }
+        break;
+      case CRABML_HIP_Q4_1:
+        for (size_t i = 0; i < nblk; i++) {
+          memcpy(qs + i * 16, src + i * 20 + 4, 16);
+          memcpy(sc + i * 4, src + i * 20, 4);
+        }
+        break;
+      case CRABML_HIP_Q8_K:
+        for (size_t i = 0; i < nblk; i++) {
+          memcpy(qs + i * 256, src + i * 292 + 4, 256);
+          memcpy(sc + i * 4, src + i * 292, 4);
+        }
+        break;
+      default: break;
+    }
+    e = hipMemcpyAsync(b->ptr, st.data(), wl.total, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  }
+  if (e != hipSuccess) {
+    crabml_hip_buf_release(b);
+    return hip_fail(dev, e, "upload", __FILE__, __LINE__);
+  }
+  *out = b;
+  return 0;
+}
+
+int crabml_hip_buf_alloc(crabml_hip_device_t* dev, size_t n_elems, uint32_t t, crabml_hip_buf_t** out) {
+  if (!dev || !out) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  if (t != CRABML_HIP_F32 && t != CRABML_HIP_F16) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 is supported");
+  (void)hipSetDevice(dev->ordinal);
+  size_t bytes = n_elems * (t == CRABML_HIP_F32 ? 4 : 2);
+  crabml_hip_buf* b = nullptr;
+  CH_TRY(buf_new(dev, t, n_elems, bytes, &b));
+  b->wl = weight_layout(t, n_elems);
+  if (t == CRABML_HIP_F32 && bytes) {  // vec![0.0; n] (cpu_tensor.rs:146-149); F16 contents are unspecified
+    hipError_t e = hipMemsetAsync(b->ptr, 0, bytes, dev->stream);
+    if (e != hipSuccess) {
+      crabml_hip_buf_release(b);
+      return hip_fail(dev, e, "hipMemsetAsync", __FILE__, __LINE__);
+    }
+  }
+  *out = b;
+  return 0;
+}
+
+int crabml_hip_buf_retain(crabml_hip_buf_t* b) {
+  if (!b) return CRABML_HIP_BAD_INPUT;
+  b->refcnt.fetch_add(1);
+  return 0;
+}
+
+int crabml_hip_buf_release(crabml_hip_buf_t* b) {
+  if (!b) return 0;
+  if (b->refcnt.fetch_sub(1) == 1) {
+    pool_free(b->dev, b->ptr, b->cap);
+    if (b->qc.ptr) pool_free(b->dev, b->qc.ptr, b->qc.cap);
+    delete b;
+  }
+  return 0;
+}
+
+uint32_t crabml_hip_buf_dtype(const crabml_hip_buf_t* b) { return b ? b->dtype : 0xffffffffu; }
+size_t crabml_hip_buf_len(const crabml_hip_buf_t* b) { return b ? b->n_elems : 0; }
+
+// ---- data movement -----------------------------------------------------------------------------------
+int crabml_hip_export(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, float* dst, size_t n) {
+  if (!dev || !b || (!dst && n)) return CRABML_HIP_BAD_INPUT;
+  if (b->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: not f32, but got %u", b->dtype);
+  if (n > b->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: %zu elements requested, buffer holds %zu", n, b->n_elems);
+  if (n) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, n * 4, hipMemcpyDeviceToHost, dev->stream));
+  CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  return 0;
+}
+
+int crabml_hip_export_raw(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, void* dst, size_t nbytes) {
+  if (!dev || !b || (!dst && nbytes)) return CRABML_HIP_BAD_INPUT;
+  if (b->dtype != CRABML_HIP_F32 && b->dtype != CRABML_HIP_F16)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export_raw: only f32/f16 buffers");
+  size_t have = b->n_elems * (b->dtype == CRABML_HIP_F32 ? 4 : 2);
+  if (nbytes > have) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export_raw: %zu bytes requested, buffer holds %zu", nbytes, have);
+  if (nbytes) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, nbytes, hipMemcpyDeviceToHost, dev->stream));
+  CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  return 0;
+}
+
+int crabml_hip_dup(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, crabml_hip_buf_t** out) {
+  if (!dev || !src || !out) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  if (src->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "dup: not f32, but got %u", src->dtype);
+  crabml_hip_buf* b = nullptr;
+  CH_TRY(buf_new(dev, CRABML_HIP_F32, src->n_elems, src->n_elems * 4, &b));
+  b->wl = weight_layout(CRABML_HIP_F32, src->n_elems);
+  if (src->n_elems) {
+    hipError_t e = hipMemcpyAsync(b->ptr, src->ptr, src->n_elems * 4, hipMemcpyDeviceToDevice, dev->stream);
+    if (e != hipSuccess) {
+      crabml_hip_buf_release(b);
+      return hip_fail(dev, e, "dup", __FILE__, __LINE__);
+    }
+  }
+  *out = b;
+  return 0;
+}
+
+static void pad3(const size_t* v, int ndim, size_t fill, size_t out[3]) {
+  int off = 3 - ndim;
+  for (int i = 0; i < 3; i++) out[i] = fill;
+  for (int i = 0; i < ndim; i++) out[off + i] = v[i];
+}
+
+int crabml_hip_contiguous(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, const size_t* shape,
+                          const size_t* strides, int ndim, crabml_hip_buf_t** out) {
+  if (!dev || !src || !out || !shape || !strides) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  if (ndim != 2 && ndim != 3) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "contiguous: only 2-d / 3-d tensors");
+  if (src->dtype != CRABML_HIP_F32 && src->dtype != CRABML_HIP_F16)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "contiguous: only f32/f16");
+  size_t sh[3], st[3];
+  pad3(shape, ndim, 1, sh);
+  pad3(strides, ndim, 0, st);
+  size_t n = sh[0] * sh[1] * sh[2];
+  size_t max_off = 0;
+  for (int i = 0; i < 3; i++)
+    if (sh[i]) max_off += (sh[i] - 1) * st[i];
+  if (n && max_off >= src->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "contiguous: view exceeds the buffer");
+  int es = src->dtype == CRABML_HIP_F32 ? 4 : 2;
+  crabml_hip_buf* b = nullptr;
+  CH_TRY(buf_new(dev, src->dtype, n, n * es, &b));
+  b->wl = weight_layout(src->dtype, n);
+  launch_contiguous(dev->stream, src->ptr, b->ptr, es, sh, st);
+  *out = b;
+  return 0;
+}
+
+int crabml_hip_concatenate(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, const size_t* dshape,
+                           const size_t* dstrides, const crabml_hip_buf_t* rhs, const size_t* rshape,
+                           const size_t* rstrides, int ndim, int axis) {
+  if (!dev || !dst || !rhs || !dshape || !dstrides || !rshape || !rstrides) return CRABML_HIP_BAD_INPUT;
+  if (ndim < 1 || ndim > 3 || axis < 0 || axis >= ndim) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "concatenate: bad ndim/axis");
+  if (dst->dtype != CRABML_HIP_F32 && dst->dtype != CRABML_HIP_F16)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 is supported on concatenate");
+  if (rhs->dtype != CRABML_HIP_F32 && rhs->dtype != CRABML_HIP_F16)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 is supported on concatenate rhs");
+  if (dst->dtype == CRABML_HIP_F32 && rhs->dtype == CRABML_HIP_F16)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "can not concatenate F32 and F16");
+  for (int i = 0; i < ndim; i++)
+    if (i != axis && dshape[i] != rshape[i])
+      CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "shape mismatch on concatenate");
+  size_t sh[3], ds[3], ss[3];
+  pad3(rshape, ndim, 1, sh);
+  pad3(dstrides, ndim, 0, ds);
+  pad3(rstrides, ndim, 0, ss);
+  size_t off = dshape[axis] * dstrides[axis];
+  size_t n = sh[0] * sh[1] * sh[2];
+  if (n) {
+    size_t dmax = off, smax = 0;
+    for (int i = 0; i < 3; i++) {
+      dmax += (sh[i] - 1) * ds[i];
+      smax += (sh[i] - 1) * ss[i];
+    }
+    if (dmax >= dst->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "concatenate: destination is full");
+    if (smax >= rhs->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "concatenate: rhs view exceeds its buffer");
+  }
+  launch_concatenate(dev->stream, dst->ptr, dst->dtype == CRABML_HIP_F16, off, ds, rhs->ptr,
+                     rhs->dtype == CRABML_HIP_F16, sh, ss);
+  touch(dst);
+  return 0;
+}
+
+int crabml_hip_copy_rows_from(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, const crabml_hip_buf_t* src, size_t cols,
+                              const size_t* rows, size_t n_rows) {
+  if (!dev || !dst || !src || (!rows && n_rows)) return CRABML_HIP_BAD_INPUT;
+  if (dst->dtype != CRABML_HIP_F32 && dst->dtype != CRABML_HIP_F16)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 can be copied to");
+  size_t be = block_elems(src->dtype);
+  if (be == 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "copy_rows_from: unsupported source dtype %u", src->dtype);
+  if (n_rows * cols > dst->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "copy_rows_from: destination too small");
+  for (size_t i = 0; i < n_rows; i++) {
+    size_t start = rows[i] * cols;
+    if (start + cols > src->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "copy_rows_from: row %zu out of range", rows[i]);
+    if (be > 1 && start % be != 0)  // QuantBuf*::dequantize asserts start % block == 0
+      CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "copy_rows_from: row start %zu is not block aligned", start);
+    char* d = (char*)dst->ptr + i * cols * (dst->dtype == CRABML_HIP_F32 ? 4 : 2);
+    launch_dequant_row(dev->stream, src, start, cols, d, dst->dtype == CRABML_HIP_F16);
+  }
+  touch(dst);
+  return 0;
+}
+
+// ---- compute -----------------------------------------------------------------------------------------
+static int need_f32(crabml_hip_device* dev, const crabml_hip_buf* b, size_t n, const char* op) {
+  if (b->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "%s: not f32, but got %u", op, b->dtype);
+  if (n > b->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "%s: %zu elements exceed the buffer (%zu)", op, n, b->n_elems);
+  return 0;
+}
+
+int crabml_hip_rope_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n_batch, size_t bi_stride,
+                            size_t head_dim, uint32_t mode, size_t pos, size_t rope_dims) {
+  if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, x, n_batch * bi_stride, "rope"));
+  if (head_dim == 0 || rope_dims > head_dim || (mode != 0 && mode != 1))
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rope: bad head_dim/rope_dims/mode");
+  size_t npairs = mode == 0 ? (rope_dims + 1) / 2 : rope_dims / 2;
+  if (npairs > 256) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "rope: more than 256 rotary pairs");
+  if (mode == 0 && (rope_dims & 1) && rope_dims + 1 > head_dim)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rope: odd rope_dims reaches past the head");
+  size_t n_heads = bi_stride / head_dim;
+  for (size_t bi = 0; bi < n_batch; bi++) {
+    RopeTable tab;
+    size_t p = pos + bi;  // rope.rs:35-36
+    if (mode == 0) {      // rope.rs:47-63: theta is an iterated f32 product, base 10000 hard-coded
+      float theta_scale = powf(10000.0f, -2.0f / (float)head_dim);
+      float theta = (float)p;
+      for (size_t i = 0; i < npairs; i++) {
+        tab.cs[2 * i] = cosf(theta);
+        tab.cs[2 * i + 1] = sinf(theta);
+        theta *= theta_scale;
+      }
+    } else {  // rope.rs:65-80
+      for (size_t i = 0; i < npairs; i++) {
+        float fe = 2.0f * (float)i / (float)head_dim;
+        float timescale = powf(10000.0f, fe);
+        float theta = (float)p / timescale;
+        tab.cs[2 * i] = cosf(theta);
+        tab.cs[2 * i + 1] = sinf(theta);
+      }
+    }
+    launch_rope(dev->stream, (float*)x->ptr + bi * bi_stride, n_heads, head_dim, (int)mode, rope_dims, tab);
+  }
+  touch(x);
+  return 0;
+}
+
+int crabml_hip_rms_norm_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols, float eps) {
+  if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, x, rows * cols, "rms_norm"));
+  if (cols % 32 != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rms_norm: row length %zu is not a multiple of 32", cols);
+  if (cols / 32 * 4 > 64 * 1024) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "rms_norm: row too long");
+  launch_rms_norm(dev->stream, (float*)x->ptr, rows, cols, eps);
+  touch(x);
+  return 0;
+}
+
+int crabml_hip_softmax_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols) {
+  if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, x, rows * cols, "softmax"));
+  launch_softmax(dev->stream, (float*)x->ptr, rows, cols, dev->exp_table);
+  touch(x);
+  return 0;
+}
+
+int crabml_hip_silu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) {
+  if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, x, n, "silu"));
+  launch_silu(dev->stream, (float*)x->ptr, n, dev->exp_table);
+  touch(x);
+  return 0;
+}
+
+int crabml_hip_gelu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) {
+  if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, x, n, "gelu"));
+  if (!dev->gelu_table) {  // OnceLock<Vec<f16>> (cpu_device.rs:117-124)
+    std::vector<uint16_t> tab(65536);
+    for (uint32_t i = 0; i < 65536; i++) tab[i] = host_f2h(gelu_single(host_h2f((uint16_t)i)));
+    CH_HIP(dev, hipMalloc((void**)&dev->gelu_table, 65536 * 2));
+    CH_HIP(dev, hipMemcpyAsync(dev->gelu_table, tab.data(), 65536 * 2, hipMemcpyHostToDevice, dev->stream));
+    CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  }
+  launch_gelu(dev->stream, (float*)x->ptr, n, dev->gelu_table);
+  touch(x);
+  return 0;
+}
+
+static int binary(crabml_hip_device* dev, int op, crabml_hip_buf* a, size_t na, const crabml_hip_buf* b, size_t nb) {
+  if (!dev || !a || !b) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, a, na, op ? "mul" : "add"));
+  CH_TRY(need_f32(dev, b, nb, op ? "mul" : "add"));
+  if (nb == 0 || na % nb != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "%s: lhs len %zu is not a multiple of rhs len %zu", op ? "mul" : "add", na, nb);
+  launch_binary(dev->stream, op, (float*)a->ptr, na, (const float*)b->ptr, nb);
+  touch(a);
+  return 0;
+}
+int crabml_hip_mul_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, const crabml_hip_buf_t* b, size_t nb) {
+  return binary(dev, 1, a, na, b, nb);
+}
+int crabml_hip_add_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, const crabml_hip_buf_t* b, size_t nb) {
+  return binary(dev, 0, a, na, b, nb);
+}
+int crabml_hip_scale_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, float f) {
+  if (!dev || !a) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, a, na, "scale"));
+  launch_scale(dev->stream, (float*)a->ptr, na, f);
+  touch(a);
+  return 0;
+}
+
+int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k,
+                          const crabml_hip_buf_t* x, size_t b, crabml_hip_buf_t** out) {
+  if (!dev || !w || !x || !out) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  uint32_t qt = vec_dot_rhs_dtype(w->dtype);
+  if (qt == 0xffffffffu) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
+  CH_TRY(need_f32(dev, x, b * k, "matmul_vec rhs"));
+  if (m * k > w->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: (%zu,%zu) exceeds the weight buffer", m, k);
+  if (block_elems(w->dtype) > 1 && w->k != k)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: quantized weight has k=%zu, called with k=%zu", w->k, k);
+  if (k % block_elems(qt) != 0 || k % block_elems(w->dtype) != 0)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: k=%zu is not a multiple of the block size", k);
+  if (m > 0x7fffffff || k > 0x7fffffff) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "matmul_vec: dimension too large");
+  const void* act = nullptr;
+  CH_TRY(ensure_act(dev, x, b, k, qt, &act));
+  crabml_hip_buf* o = nullptr;
+  CH_TRY(buf_new(dev, CRABML_HIP_F32, b * m, b * m * 4, &o));
+  o->wl = weight_layout(CRABML_HIP_F32, b * m);
+  int rc = dev->strict_order ? launch_gemv_strict(dev, w, m, k, act, b, (float*)o->ptr)
+                             : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr);
+  if (rc != 0) {
+    crabml_hip_buf_release(o);
+    return rc;
+  }
+  *out = o;
+  return 0;
+}
+
+int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a, size_t ba, size_t m, size_t k,
+                            const crabml_hip_buf_t* b, size_t bb, size_t n, size_t sb0, size_t sb1, size_t sb2,
+                            crabml_hip_buf_t** out) {
+  if (!dev || !a || !b || !out) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  CH_TRY(need_f32(dev, a, ba * m * k, "batch_matmul lhs"));
+  if (b->dtype != CRABML_HIP_F32 && b->dtype != CRABML_HIP_F16)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "batch_matmul: rhs must be f32/f16");
+  if (!(sb1 == 1 || sb2 == 1)) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "batch_matmul: rhs must be contiguous on k or n");
+  if (bb == 0 || ba < bb || ba % bb != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "batch_matmul: lhs batch %zu vs rhs batch %zu", ba, bb);
+  if (bb && k && n) {
+    size_t max_off = (bb - 1) * sb0 + (k - 1) * sb1 + (n - 1) * sb2;
+    if (max_off >= b->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "batch_matmul: rhs view exceeds its buffer");
+  }
+  crabml_hip_buf* o = nullptr;
+  CH_TRY(buf_new(dev, CRABML_HIP_F32, ba * m * n, ba * m * n * 4, &o));
+  o->wl = weight_layout(CRABML_HIP_F32, ba * m * n);
+  launch_batch_matmul(dev->stream, (const float*)a->ptr, ba, m, k, b->ptr, b->dtype == CRABML_HIP_F16, bb, n, sb0, sb1,
+                      sb2, (float*)o->ptr);
+  *out = o;
+  return 0;
+}
+
+// ---- parity / debug hooks ----------------------------------------------------------------------------
+int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* x, size_t n, uint32_t qt, void* dst,
+                              size_t dst_bytes) {
+  if (!dev || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_TRY(need_f32(dev, x, n, "debug_quantize"));
+  if (qt != CRABML_HIP_Q8_0 && qt != CRABML_HIP_Q8_1 && qt != CRABML_HIP_Q8_K)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_quantize: unsupported target %u", qt);
+  size_t be = block_elems(qt), bb = block_bytes(qt);
+  if (n % be != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_quantize: n is not a multiple of the block size");
+  size_t nb = n / be;
+  if (dst_bytes < nb * bb) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "debug_quantize: dst too small");
+  ActLayout al = act_layout(qt, n);
+  void* planes = nullptr;
+  size_t cap = 0;
+  CH_TRY(pool_alloc(dev, al.total, &planes, &cap));
+  launch_quantize_act(dev->stream, qt, (const float*)x->ptr, n, planes);
+  std::vector<uint8_t> h(al.total);
+  hipError_t e = hipMemcpyAsync(h.data(), planes, al.total, hipMemcpyDeviceToHost, dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  pool_free(dev, planes, cap);
+  if (e != hipSuccess) return hip_fail(dev, e, "debug_quantize", __FILE__, __LINE__);
+  uint8_t* o = (uint8_t*)dst;
+  for (size_t i = 0; i < nb; i++) {
+    if (qt == CRABML_HIP_Q8_0) {
+      memcpy(o + i * 34, h.data() + al.off_d + i * 2, 2);
+      memcpy(o + i * 34 + 2, h.data() + i * 32, 32);
+    } else if (qt == CRABML_HIP_Q8_1) {
+      memcpy(o + i * 36, h.data() + al.off_d + i * 2, 2);
+      memcpy(o + i * 36 + 2, h.data() + al.off_aux + i * 2, 2);
+      memcpy(o + i * 36 + 4, h.data() + i * 32, 32);
+    } else {
+      memcpy(o + i * 292, h.data() + al.off_d + i * 4, 4);
+      memcpy(o + i * 292 + 4, h.data() + i * 256, 256);
+      memcpy(o + i * 292 + 260, h.data() + al.off_aux + i * 32, 32);
+    }
+  }
+  return 0;
+}
+
+int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
+                                const crabml_hip_buf_t* x, int32_t* dst) {
+  if (!dev || !w || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  uint32_t qt = vec_dot_rhs_dtype(w->dtype);
+  if (block_elems(w->dtype) <= 1 || qt == 0xffffffffu)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_block_dots: quantized weights only");
+  if (row >= m || w->k != k || m * k > w->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_block_dots: bad row/shape");
+  CH_TRY(need_f32(dev, x, k, "debug_block_dots rhs"));
+  const void* act = nullptr;
+  CH_TRY(ensure_act(dev, x, 1, k, qt, &act));
+  size_t n = k / 32;
+  void* d = nullptr;
+  size_t cap = 0;
+  CH_TRY(pool_alloc(dev, n * 4, &d, &cap));
+  launch_block_dots(dev->stream, w, k, row, act, (int32_t*)d);
+  hipError_t e = hipMemcpyAsync(dst, d, n * 4, hipMemcpyDeviceToHost, dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  pool_free(dev, d, cap);
+  if (e != hipSuccess) return hip_fail(dev, e, "debug_block_dots", __FILE__, __LINE__);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""Synthetic GGUF-layout weights for the bench and the parity tests.
+
+There is no network and the reference's quantized fixtures are stripped, so models are filled directly in
+the GGML block byte layout (crabml-core/src/cpu/buf/buf_q*.rs): block scales d = f16(U(2e-3, 2e-2)),
+quants uniform over their full range.  Pure numpy -- this module never touches oracle/.
+The same bytes feed the HIP backend (HipTensor.from_cpu) and, in tests / the CPU baseline, the oracle.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 15
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q8_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q8_K: 292}
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q4_K: "Q4_K", Q8_K: "Q8_K"}
+TYPE_BY_NAME = {v: k for k, v in TYPE_NAMES.items()}
+
+
+def _f16_scales(rng, n, lo=2e-3, hi=2e-2):
+    return rng.uniform(lo, hi, size=n).astype(np.float16).view(np.uint16)
+
+
+def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: float = 1.0) -> np.ndarray:
+    """Raw bytes (uint8) of n_elems elements in GGML layout `typ`, filled with random quants."""
+    be, bb = BLOCK_ELEMS[typ], BLOCK_BYTES[typ]
+    assert n_elems % be == 0
+    nb = n_elems // be
+    if typ == F32:
+        return (rng.standard_normal(n_elems, dtype=np.float32) * np.float32(0.02 * scale_mul)).view(np.uint8)
+    if typ == F16:
+        return (rng.standard_normal(n_elems, dtype=np.float32) * np.float32(0.02 * scale_mul)).astype(np.float16).view(np.uint8)
+    out = np.empty((nb, bb), dtype=np.uint8)
+    lo, hi = 2e-3 * scale_mul, 2e-2 * scale_mul
+    if typ == Q4_0:
+        out[:, 0:2] = _f16_scales(rng, nb, lo, hi).reshape(nb, 1).view(np.uint8)
+        out[:, 2:] = rng.integers(0, 256, size=(nb, 16), dtype=np.uint8)
+    elif typ == Q8_0:
+        out[:, 0:2] = _f16_scales(rng, nb, lo / 8, hi / 8).reshape(nb, 1).view(np.uint8)
+        out[:, 2:] = rng.integers(0, 256, size=(nb, 32), dtype=np.uint8)
+    elif typ == Q4_1:
+        out[:, 0:2] = _f16_scales(rng, nb, lo, hi).reshape(nb, 1).view(np.uint8)
+        out[:, 2:4] = (-rng.uniform(8 * lo, 8 * hi, size=nb)).astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
+        out[:, 4:] = rng.integers(0, 256, size=(nb, 16), dtype=np.uint8)
+    elif typ == Q4_K:
+        out[:, 0:2] = _f16_scales(rng, nb, lo / 32, hi / 32).reshape(nb, 1).view(np.uint8)
+        out[:, 2:4] = _f16_scales(rng, nb, lo / 4, hi / 4).reshape(nb, 1).view(np.uint8)
+        out[:, 4:] = rng.integers(0, 256, size=(nb, 140), dtype=np.uint8)  # 6-bit scales/mins + nibbles
+    elif typ == Q8_K:
+        out[:, 0:4] = rng.uniform(lo / 8, hi / 8, size=nb).astype(np.float32).reshape(nb, 1).view(np.uint8)
+        q = rng.integers(-127, 128, size=(nb, 256), dtype=np.int8)
+        out[:, 4:260] = q.view(np.uint8)
+        out[:, 260:] = q.reshape(nb, 16, 16).astype(np.int16).sum(axis=2).astype(np.int16).view(np.uint8).reshape(nb, 32)
+    else:
+        raise ValueError(f"unsupported type {typ}")
+    return out.reshape(-1)
+
+
+@dataclass
+class ModelShape:
+    name: str
+    dim: int
+    hidden: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    vocab: int
+    seq_len: int
+    rms_eps: float = 1e-5
+    rope_dim: Optional[int] = None
+
+    @property
+    def head_dim(self):
+        return self.dim // self.n_heads
+
+    @property
+    def kv_dim(self):
+        return self.dim * self.n_kv_heads // self.n_heads
+
+
+# shapes of the configs
+SHAPES = {
+    "15m": ModelShape("tinyllamas-stories-15m", 288, 768, 6, 6, 6, 32000, 256, 1e-5, 48),
+    "llama3-8b": ModelShape("Llama-3-8B", 4096, 14336, 32, 32, 8, 128256, 8192, 1e-5, None),
+    "llama3-70b": ModelShape("Llama-3-70B", 8192, 28672, 80, 64, 8, 128256, 8192, 1e-5, None),
+    # a small GQA shape with every dim a multiple of 256 (valid for all formats incl. K-quants); used by tests
+    "tiny-gqa": ModelShape("tiny-gqa", 512, 1024, 2, 8, 2, 1024, 64, 1e-5, None),
+}
+
+
+@dataclass
+class RawTensor:
+    data: np.ndarray  # uint8 raw GGML bytes
+    shape: List[int]
+    typ: int
+
+
+@dataclass
+class RawModel:
+    shape: ModelShape
+    wtype: int
+    tensors: Dict[str, RawTensor] = field(default_factory=dict)
+
+    def gemv_weight_bytes_per_token(self) -> int:
+        """Algorithmic weight bytes one decode step streams through matmul_vec."""
+        s = self.shape
+        total = 0
+        for name, t in self.tensors.items():
+            if name.endswith("_norm.weight") or name == "token_embd.weight":
+                continue
+            n = 1
+            for d in t.shape:
+                n *= d
+            total += n // BLOCK_ELEMS[t.typ] * BLOCK_BYTES[t.typ]
+        if "output.weight" not in self.tensors:  # tied classifier
+            t = self.tensors["token_embd.weight"]
+            total += s.vocab * s.dim // BLOCK_ELEMS[t.typ] * BLOCK_BYTES[t.typ]
+        return total
+
+
+def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional[int] = None,
+                embed_type: Optional[int] = None) -> RawModel:
+    """All-`wtype` synthetic Llama weights with GGUF tensor names (model.rs:228-283); norms are F32
+    (the loader dequantizes them, model.rs:267-282)."""
+    rng = np.random.default_rng(seed)
+    L = shape.n_layers if n_layers is None else n_layers
+    shp = ModelShape(**{**shape.__dict__, "n_layers": L})
+    m = RawModel(shp, wtype)
+    et = wtype if embed_type is None else embed_type
+
+    def add(name, rows, cols, typ, scale_mul=1.0):
+        m.tensors[name] = RawTensor(random_blocks(rng, rows * cols, typ, scale_mul), [rows, cols], typ)
+
+    def norm(name, n):
+        w = (1.0 + rng.standard_normal(n) * 0.01).astype(np.float32)
+        m.tensors[name] = RawTensor(w.view(np.uint8), [n], F32)
+
+    add("token_embd.weight", shape.vocab, shape.dim, et, 4.0)
+    for l in range(L):
+        add(f"blk.{l}.attn_q.weight", shape.dim, shape.dim, wtype)
+        add(f"blk.{l}.attn_k.weight", shape.kv_dim, shape.dim, wtype)
+        add(f"blk.{l}.attn_v.weight", shape.kv_dim, shape.dim, wtype)
+        add(f"blk.{l}.attn_output.weight", shape.dim, shape.dim, wtype)
+        add(f"blk.{l}.ffn_gate.weight", shape.hidden, shape.dim, wtype)
+        add(f"blk.{l}.ffn_down.weight", shape.dim, shape.hidden, wtype)
+        add(f"blk.{l}.ffn_up.weight", shape.hidden, shape.dim, wtype)
+        norm(f"blk.{l}.attn_norm.weight", shape.dim)
+        norm(f"blk.{l}.ffn_norm.weight", shape.dim)
+    norm("output_norm.weight", shape.dim)
+    add("output.weight", shape.vocab, shape.dim, wtype)
+    return m
+
+
+def to_hip(model: RawModel, device):
+    """Upload a RawModel through Tensor::from_cpu -> (LlamaConfig, LlamaWeights) of the hip backend."""
+    import crabml_amd as ca
+
+    tmap = {F32: ca.GGMLType.F32, F16: ca.GGMLType.F16, Q4_0: ca.GGMLType.Q4_0, Q4_1: ca.GGMLType.Q4_1,
+            Q8_0: ca.GGMLType.Q8_0, Q4_K: ca.GGMLType.Q4K, Q8_K: ca.GGMLType.Q8K}
+    s = model.shape
+
+    def up(name):
+        t = model.tensors[name]
+        return ca.HipTensor.from_cpu(t.data, t.shape, tmap[t.typ], device)
+
+    w = ca.LlamaWeights()
+    w.token_embed = up("token_embd.weight")
+    w.wq = [up(f"blk.{l}.attn_q.weight") for l in range(s.n_layers)]
+    w.wk = [up(f"blk.{l}.attn_k.weight") for l in range(s.n_layers)]
+    w.wv = [up(f"blk.{l}.attn_v.weight") for l in range(s.n_layers)]
+    w.wo = [up(f"blk.{l}.attn_output.weight") for l in range(s.n_layers)]
+    w.ffn_gate_weight = [up(f"blk.{l}.ffn_gate.weight") for l in range(s.n_layers)]
+    w.ffn_down_weight = [up(f"blk.{l}.ffn_down.weight") for l in range(s.n_layers)]
+    w.ffn_up_weight = [up(f"blk.{l}.ffn_up.weight") for l in range(s.n_layers)]
+    w.rms_att_weight = [up(f"blk.{l}.attn_norm.weight") for l in range(s.n_layers)]
+    w.rms_ffn_weight = [up(f"blk.{l}.ffn_norm.weight") for l in range(s.n_layers)]
+    w.rms_final_weight = up("output_norm.weight")
+    if "output.weight" in model.tensors:
+        w.output_weight = up("output.weight")
+    conf = ca.LlamaConfig(embedding_dim=s.dim, hidden_dim=s.hidden, n_layers=s.n_layers, n_heads=s.n_heads,
+                          n_kv_heads=s.n_kv_heads, vocab_size=s.vocab, seq_len=s.seq_len, rms_norm_eps=s.rms_eps,
+                          rope_dim=s.rope_dim)
+    return conf, w

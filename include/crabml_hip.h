@@ -65,10 +65,15 @@ typedef struct crabml_hip_device crabml_hip_device_t;
 typedef struct crabml_hip_buf crabml_hip_buf_t;
 
 /* replaces WgpuTensorDeviceOptions (crabml-wgpu/src/wgpu_device.rs:9-38) */
+/* flags: CRABML_HIP_FLAG_STRICT_ORDER makes matmul_vec add the per-block terms in the reference's
+ * scalar-loop order (vec_dot_*_fallback), one thread per output row.  Slow; it exists so that parity
+ * can be checked BIT-EXACTLY end to end (the truncating activation quantizer amplifies 1-ulp
+ * re-association differences).  Default (0) = the fast wave-parallel kernels. */
+#define CRABML_HIP_FLAG_STRICT_ORDER 1
 typedef struct crabml_hip_device_options {
   int32_t device_ordinal; /* HIP device index (one process per GPU: LOCAL_RANK) */
   void* stream;           /* optional caller-owned hipStream_t; NULL = the library creates one */
-  int32_t flags;          /* reserved, must be 0 */
+  int32_t flags;          /* bit set of CRABML_HIP_FLAG_* */
 } crabml_hip_device_options_t;
 
 /* ---- device ------------------------------------------------------------------------------ */

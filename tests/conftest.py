@@ -24,3 +24,15 @@ def oracle():
 @pytest.fixture(scope="session")
 def odev(oracle):
     return oracle.OracleDevice(thread_num=1, use_avx2=False)
+
+
+@pytest.fixture(scope="session")
+def ca():
+    """The product package.  No skip: on the GPU box a missing extension must fail loudly."""
+    import crabml_amd
+    return crabml_amd
+
+
+@pytest.fixture(scope="session")
+def hdev(ca):
+    return ca.HipTensorDevice(device_ordinal=0, debug_named_tensor=False)

@@ -1,0 +1,174 @@
+"""GPU parity for Tensor::matmul_vec on every weight format of the hot path.
+
+Gates, strongest first:
+  1. integer level, BIT-EXACT: per 32-element group  sum(unpacked_w * q8)  through the kernel's own
+     nibble-unpack / v_dot4 code  ==  the reference's scalar loops  (north_star: "bit-exactly at the
+     integer unpack level").
+  2. dequantized rows (copy_rows_from on a quantized table), BIT-EXACT.
+  3. GEMV outputs: |hip - oracle| <= GEMV_REL * sum_i |w_i x_i|  -- the f32 re-association bound; the
+     oracle is the reference's scalar-fallback order, and its AVX2 order is checked to the same bound.
+"""
+import numpy as np
+import pytest
+
+from crabml_amd import synth
+from oracle import oracle as o
+from tests.helpers import GEMV_REL, gemv_order_bound
+
+pytestmark = pytest.mark.gpu
+
+FORMATS = ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q8_K"]
+HT = {"Q4_0": "Q4_0", "Q8_0": "Q8_0", "Q4_1": "Q4_1", "Q4_K": "Q4K", "Q8_K": "Q8K", "F32": "F32", "F16": "F16"}
+
+
+def make(fmt, m, k, seed):
+    typ = synth.TYPE_BY_NAME[fmt]
+    rng = np.random.default_rng(seed)
+    raw = synth.random_blocks(rng, m * k, typ)
+    x = rng.standard_normal(k).astype(np.float32)
+    return typ, raw, x
+
+
+# shapes: 15M model (9 / 24 blocks per row: not a multiple of 64 lanes), ragged m (odd, < R), 8B layer shapes
+SHAPES_32 = [(288, 288), (768, 288), (288, 768), (1, 32), (3, 64), (5, 2080), (1000, 4096), (4096, 4096),
+             (1024, 4096), (300, 14336)]
+SHAPES_256 = [(3, 256), (5, 768), (512, 512), (1000, 4096), (257, 14336), (1024, 1024)]
+
+
+def shapes_for(fmt):
+    return SHAPES_256 if fmt in ("Q4_K", "Q8_K") else SHAPES_32
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_block_dots_bit_exact(ca, hdev, fmt):
+    for (m, k) in shapes_for(fmt)[:6]:
+        typ, raw, x = make(fmt, m, k, m * 7 + k)
+        w = ca.HipTensor.from_cpu(raw, [m, k], getattr(ca.GGMLType, HT[fmt]), hdev)
+        hx = ca.HipTensor.new(x, [k], hdev)
+        xq = o.quantize(x, o.rhs_dtype(typ))
+        rb = o.BLOCK_BYTES[typ] * (k // o.BLOCK_ELEMS[typ])
+        for row in sorted({0, m // 2, m - 1}):
+            got = w.debug_block_dots(row, hx)
+            ref = o.block_dots(raw[row * rb:(row + 1) * rb], typ, xq, k)
+            assert np.array_equal(got, ref), f"{fmt} ({m},{k}) row {row}"
+
+
+@pytest.mark.parametrize("fmt", FORMATS + ["F32", "F16"])
+def test_dequant_rows_bit_exact(ca, hdev, odev, fmt):
+    m, k = 37, 512
+    typ, raw, _ = make(fmt, m, k, 99)
+    w = ca.HipTensor.from_cpu(raw, [m, k], getattr(ca.GGMLType, HT[fmt]), hdev)
+    ow = o.OracleTensor.from_bytes(raw, typ, [m, k], odev)
+    rows = [36, 0, 17]
+    dst = ca.HipTensor.alloc([3, k], ca.GGMLType.F32, hdev)
+    dst.copy_rows_from(w, rows)
+    odst = o.OracleTensor.alloc([3, k], o.F32, odev)
+    odst.copy_rows_from(ow, rows)
+    assert np.array_equal(dst.export().view(np.uint32), odst.export().view(np.uint32))
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_gemv_vs_oracle(ca, hdev, odev, fmt):
+    for (m, k) in shapes_for(fmt):
+        typ, raw, x = make(fmt, m, k, m * 13 + k)
+        w = ca.HipTensor.from_cpu(raw, [m, k], getattr(ca.GGMLType, HT[fmt]), hdev)
+        got = w.matmul_vec(ca.HipTensor.new(x, [k], hdev))
+        assert got.shape() == [m]
+        got = got.export()
+        ref = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(x, [k], odev)).export()
+        bound = gemv_order_bound(raw, typ, x, m, k) * GEMV_REL * (8 if fmt in ("Q4_1", "Q4_K") else 1) + 1e-30
+        err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        assert np.all(err <= bound), f"{fmt} ({m},{k}): max err/bound {np.max(err / bound):.3f}"
+        if typ == o.Q4_K:
+            xq = o.quantize(x, o.Q8_K)
+            rb = 144 * (k // 256)
+            assert o.q4k_overflow_count(raw[:rb], xq, k) >= 0  # informational: i16 hazard of buf_q4_k.rs:240
+
+
+def test_gemv_avx2_order_is_within_the_same_bound(odev):
+    """The reference has two CPU accumulation orders (scalar fallback / AVX2 when k % 1024 == 0,
+    buf_q4_0.rs:220-223); they differ from each other by the same re-association bound we allow the GPU."""
+    if not o.lib().co_have_avx2():
+        pytest.skip("no avx2")
+    m, k = 64, 4096
+    typ, raw, x = make("Q4_0", m, k, 5)
+    xq = o.quantize(x, o.Q8_0)
+    rb = 18 * (k // 32)
+    a = np.array([o.vec_dot(raw[r * rb:(r + 1) * rb], typ, xq, k, avx2=False) for r in range(m)])
+    b = np.array([o.vec_dot(raw[r * rb:(r + 1) * rb], typ, xq, k, avx2=True) for r in range(m)])
+    assert np.all(np.abs(a - b) <= gemv_order_bound(raw, typ, x, m, k) * GEMV_REL)
+
+
+def test_gemv_f32_f16_weights(ca, hdev, odev):
+    for fmt, (m, k) in [("F32", (64, 64)), ("F32", (172, 64)), ("F32", (512, 172)), ("F16", (48, 96))]:
+        typ, raw, x = make(fmt, m, k, m + k)
+        w = ca.HipTensor.from_cpu(raw, [m, k], getattr(ca.GGMLType, HT[fmt]), hdev)
+        got = w.matmul_vec(ca.HipTensor.new(x, [k], hdev)).export()
+        ref = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(x, [k], odev)).export()
+        bound = gemv_order_bound(raw, typ, x, m, k) * GEMV_REL + 1e-30
+        assert np.all(np.abs(got.astype(np.float64) - ref) <= bound)
+
+
+def test_gemv_batched_rhs_and_quant_cache(ca, hdev, odev):
+    """(m,k) @ (b,k) -> (b,m); and the per-buffer activation-quantization cache must be invalidated by
+    every in-place write (q/k/v share one quantization of x, then x changes)."""
+    m, k, b = 96, 1024, 3
+    typ, raw, _ = make("Q4_0", m, k, 1)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(b * k).astype(np.float32)
+    w = ca.HipTensor.from_cpu(raw, [m, k], ca.GGMLType.Q4_0, hdev)
+    ow = o.OracleTensor.from_bytes(raw, typ, [m, k], odev)
+    hx = ca.HipTensor.new(x, [b, k], hdev)
+    got = w.matmul_vec(hx)
+    assert got.shape() == [b, m]
+    ref = ow.matmul_vec(o.OracleTensor.new(x, [b, k], odev)).export()
+    assert np.allclose(got.export(), ref, rtol=1e-4, atol=1e-4)
+    got2 = w.matmul_vec(hx).export()  # cached quantization: identical result
+    assert np.array_equal(got.export(), got2)
+    hx = hx.scale_inplace(0.5)  # in-place write must invalidate the cache
+    got3 = w.matmul_vec(hx).export()
+    ref3 = ow.matmul_vec(o.OracleTensor.new(x * np.float32(0.5), [b, k], odev)).export()
+    assert np.allclose(got3, ref3, rtol=1e-4, atol=1e-4)
+    assert not np.array_equal(got3, got2)
+
+
+def test_gemv_errors(ca, hdev):
+    typ, raw, x = make("Q4_0", 8, 64, 3)
+    w = ca.HipTensor.from_cpu(raw, [8, 64], ca.GGMLType.Q4_0, hdev)
+    with pytest.raises(ca.CrabmlError):  # inner dims differ (matmul_vec.rs:19)
+        w.matmul_vec(ca.HipTensor.new(np.zeros(32, dtype=np.float32), [32], hdev))
+    with pytest.raises(ca.CrabmlError):  # not a block multiple
+        ca.HipTensor.from_cpu(raw[:18 * 3], [3, 30], ca.GGMLType.Q4_0, hdev)
+    with pytest.raises(ca.CrabmlError):  # too few bytes for the shape
+        ca.HipTensor.from_cpu(raw[:18], [8, 64], ca.GGMLType.Q4_0, hdev)
+    with pytest.raises(ca.CrabmlError):  # non-contiguous rhs
+        w.matmul_vec(ca.HipTensor.new(np.zeros(128, dtype=np.float32), [64, 2], hdev).transpose([1, 0]))
+
+
+def test_linearity_at_full_8b_shape(ca, hdev):
+    """Size-independent property at BASELINE.json's full shape (the CPU oracle would take minutes on
+    the whole matrix): with activations that quantize exactly (small integers * power of two),
+    W.(x1 + x2) == W.x1 + W.x2 up to f32 rounding, and rows sampled against the oracle."""
+    m, k = 14336, 4096
+    typ, raw, _ = make("Q4_0", m, k, 42)
+    w = ca.HipTensor.from_cpu(raw, [m, k], ca.GGMLType.Q4_0, hdev)
+    rng = np.random.default_rng(1)
+    # each 32-block holds +-127 so d = 1.0 exactly and q = x exactly for integer x in [-127,127]
+    def ints():
+        v = rng.integers(-60, 61, k).astype(np.float32)
+        v[::32] = 127.0
+        return v
+    x1, x2 = ints(), ints()
+    x2[::32] = 0.0
+    x12 = x1 + x2  # still has max 127 per block -> d == 1, exact
+    y1 = w.matmul_vec(ca.HipTensor.new(x1, [k], hdev)).export().astype(np.float64)
+    y2 = w.matmul_vec(ca.HipTensor.new(x2 + np.where(np.arange(k) % 32 == 0, 127.0, 0.0).astype(np.float32), [k], hdev)).export().astype(np.float64)
+    y0 = w.matmul_vec(ca.HipTensor.new(np.where(np.arange(k) % 32 == 0, 127.0, 0.0).astype(np.float32), [k], hdev)).export().astype(np.float64)
+    y12 = w.matmul_vec(ca.HipTensor.new(x12, [k], hdev)).export().astype(np.float64)
+    scale = np.abs(y1) + np.abs(y2) + np.abs(y0) + np.abs(y12) + 1.0
+    assert np.all(np.abs(y12 - (y1 + (y2 - y0))) <= 2e-4 * scale)
+    rb = 18 * (k // 32)
+    xq = o.quantize(x1, o.Q8_0)
+    for row in (0, 7777, m - 1):
+        ref = o.vec_dot(raw[row * rb:(row + 1) * rb], typ, xq, k)
+        assert abs(y1[row] - ref) <= 1e-4 * (abs(ref) + 1.0)
