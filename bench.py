@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s + Q4_0 GEMV GB/s vs the HBM roofline, Llama-3-8B shape, on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run (one rank per GPU).  A "step" is one batch-1 greedy decode token: one pass of the
+hot path (32 layers x 7 block-quantized GEMVs + classifier, RMSNorm/RoPE/softmax/KV-cache attention)
+through the HIP backend.  W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
+device synchronize; rank 0 prints ONE JSON line.  Weights are synthetic (no network): random GGUF-layout
+Q4_0 blocks of the Llama-3-8B shapes, resident in HBM before timing starts.
+
+Multi-GPU (`--gpus N`): Llama-3-8B Q4_0 (4.2 GB) fits one GPU, so per BASELINE/SURVEY 8(e) the ranks are
+independent replicas decoding their own sequence (no data-path collective): weak scaling, value =
+total tokens / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      the Q4_0 GEMV kernel: algorithmic bytes / HIP-event kernel time, measured live in an
+                instrumented pass right after the timed region (event pairs on the kernel's own stream;
+                kept out of the timed region so they do not perturb tokens/s).  peak = 8.0 TB/s HBM3E.
+  cpu_baseline  the reference's SIMD CPU path restated in C (oracle/, AVX2 lane order, crabml's row-split
+                thread pool) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the achievable copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama3-8b", help="shape key in crabml_amd.synth.SHAPES")
+    ap.add_argument("--wtype", default="Q4_0")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: truncate the layer count (INVALID as a result)")
+    ap.add_argument("--path", default="auto", choices=["auto", "trait", "fused"],
+                    help="trait = one launch per Tensor op (Llama2Runner unchanged); fused = fused decode step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self test of the rank aggregation")
+    return ap.parse_args()
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, world, local
+
+
+class Dist:
+    """barrier + max-over-ranks, via torch.distributed when WORLD_SIZE > 1 (RCCL on GPU, gloo on CPU)."""
+
+    def __init__(self, world, local, cpu_only=False):
+        self.world = world
+        self.torch = None
+        self.dev = None
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            use_nccl = (not cpu_only) and torch.cuda.is_available()
+            if use_nccl:
+                torch.cuda.set_device(local)
+                self.dev = torch.device("cuda", local)
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                self.dev = torch.device("cpu")
+                dist.init_process_group("gloo")
+
+    def barrier(self):
+        if self.world > 1:
+            if self.dev.type == "cuda":
+                self.dist.barrier(device_ids=[self.dev.index])
+                self.torch.cuda.synchronize()
+            else:
+                self.dist.barrier()
+
+    def max_sum(self, elapsed, units):
+        """(max over ranks of elapsed, sum over ranks of units)"""
+        if self.world == 1:
+            return elapsed, units
+        t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+        u = self.torch.tensor([float(units)], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(u, op=self.dist.ReduceOp.SUM)
+        return float(t.item()), float(u.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def selftest_dist(args):
+    rank, world, local = dist_env()
+    d = Dist(world, local, cpu_only=True)
+    d.barrier()
+    t, u = d.max_sum(1.0 + rank, 10)
+    d.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "dist", "n_gpus": world, "max_elapsed": t, "units": u}))
+    d.close()
+
+
+def cpu_baseline(model, steps_budget_s):
+    """crabml's CPU path (restated, oracle/) on this box's host cores: full-model greedy decode, AVX2 dot
+    order, crabml's row-split pool.  Bounded sample: a few tokens per thread count."""
+    from oracle import oracle as o
+    from tests.helpers import to_oracle
+
+    ncpu = os.cpu_count() or 1
+    results = []
+    for threads in sorted({2, min(ncpu, 32)}):
+        odev = o.OracleDevice(thread_num=threads, use_avx2=True)
+        conf, w = to_oracle(model, odev)
+        r = o.OracleLlamaRunner(conf, w, odev, 64, True)
+        r.forward([1], 0)  # touch all pages once (untimed)
+        tok, pos, n = o.argmax_last(r.logits), 1, 0
+        t0 = time.perf_counter()
+        budget = steps_budget_s / 2
+        while True:
+            r.forward([tok], pos)
+            tok = o.argmax_last(r.logits)
+            pos += 1
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 32:
+                break
+        results.append((n / el, threads, n, el))
+        del r, w, odev
+    best = max(results)
+    return {
+        "value": round(best[0], 3), "unit": "tokens/s", "cores": best[1], "kind": "port",
+        "host_cpus": ncpu, "avx2": bool(o.lib().co_have_avx2()),
+        "sample": "full-model greedy decode, same synthetic weights; " + "; ".join(
+            f"T={t}: {n} tokens in {el:.2f}s = {v:.2f} tok/s" for v, t, n, el in results),
+        "note": "reference is Rust nightly (no rustc here): its AVX2 CPU path restated in C (oracle/crabml_oracle.c)",
+    }
+
+
+def main():
+    args = parse()
+    if args.selftest_dist:
+        return selftest_dist(args)
+    rank, world, local = dist_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = Dist(world, local)  # imports torch first when world > 1 (one HIP runtime in the process)
+
+    import crabml_amd as ca
+    from crabml_amd import synth
+
+    shape = synth.SHAPES[args.model]
+    wtype = synth.TYPE_BY_NAME[args.wtype]
+    t_build = time.perf_counter()
+    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers)
+    dev = ca.HipTensorDevice(device_ordinal=local)
+    conf, weights = synth.to_hip(model, dev)
+    dev.sync()
+    t_build = time.perf_counter() - t_build
+    seq_len = args.warmup + 2 * args.steps + 16
+    runner = ca.Llama2Runner(conf, weights, dev, seq_len, True)  # f16 KV cache = the CLI default (main.rs:250)
+    path = "trait"
+    gemv_bytes = model.gemv_weight_bytes_per_token()
+
+    # ---- warm-up (untimed), then the timed region -------------------------------------------------
+    ids, _ = runner.timed_decode(1, args.warmup) if args.warmup > 0 else ([1], 0.0)
+    tok = ids[-1] if ids else 1
+    dev.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    ids, _inner = runner.timed_decode(tok, args.steps)
+    dev.sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, total_tokens = dist.max_sum(elapsed, args.steps)
+
+    # ---- instrumented pass: HIP events around every GEMV launch (same process, same weights) --------
+    roof = None
+    if rank == 0:
+        dev.prof_enable(True)
+        n_prof = min(args.steps, 16)
+        runner.timed_decode(ids[-1], n_prof)
+        recs = dev.prof_read()
+        dev.prof_enable(False)
+        rec = next((r for r in recs if r["dtype"] == wtype), None)
+        if rec and rec["kernel_ms"] > 0:
+            gbs = rec["algo_bytes"] / (rec["kernel_ms"] * 1e-3) / 1e9
+            roof = {
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": f"k_gemv_{args.wtype.lower()} (all GEMV launches of the decode step)",
+                "launches_per_token": rec["launches"] / n_prof,
+                "avg_launch_us": round(rec["kernel_ms"] * 1e3 / rec["launches"], 3),
+                "algo_bytes_per_launch": round(rec["algo_bytes"] / rec["launches"], 1),
+                "gemv_ms_per_token": round(rec["kernel_ms"] / n_prof, 4),
+                "method": "hipEvent pairs on the backend's stream around each GEMV launch, separate instrumented pass",
+            }
+
+    out = None
+    if rank == 0:
+        tps = total_tokens / elapsed_max
+        out = {
+            "metric": "decode tokens/sec (batch-1 greedy), Llama-3-8B shape " + args.wtype,
+            "value": round(tps, 2), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "q4_0 x q8_0 -> i32 dot, f32 accumulate" if args.wtype == "Q4_0" else args.wtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{shape.name}-shape all-{args.wtype} synthetic GGUF-layout weights, batch-1 greedy decode, "
+                            f"f16 KV cache, positions {args.warmup}..{args.warmup + args.steps - 1}",
+                "path": path, "n_layers": conf.n_layers, "replicas": args.gpus,
+                "gemv_weight_bytes_per_token": gemv_bytes,
+            },
+            "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / gemv_bytes, 1),
+            "frac_of_hbm_roofline_tokens": round(tps / args.gpus / (HBM_PEAK_GBS * 1e9 / gemv_bytes), 4),
+            "effective_weight_GBps_per_gpu": round(tps / args.gpus * gemv_bytes / 1e9, 1),
+            "setup_s": round(t_build, 1),
+        }
+        if args.layers is not None:
+            out["INVALID"] = "layer count truncated with --layers (debug run)"
+        if roof:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline and args.gpus == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, args.cpu_seconds)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,15 @@ struct crabml_hip_device {
   // f16 lookup tables (cpu_device.rs:108-125)
   uint16_t* exp_table = nullptr;
   uint16_t* gelu_table = nullptr;
+  // measurement hook (crabml_hip_prof_*): event pairs around GEMV launches
+  bool prof_on = false;
+  struct ProfRec {
+    hipEvent_t e0, e1;
+    uint32_t dtype;
+    double bytes;
+  };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_free_events;
 };
 
 struct crabml_hip_buf {

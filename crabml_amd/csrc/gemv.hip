@@ -327,8 +327,10 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
   const char* wp = (const char*)w->ptr;
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   const ActLayout al = act_layout(qt, k_);
+  // F32 weights take the dense f32 rhs as is (row stride k*4); quantized planes are padded per row
+  const size_t act_stride = qt == CRABML_HIP_F32 ? k_ * 4 : al.total;
   for (size_t bi = 0; bi < b; bi++) {
-    const char* ap = (const char*)act + bi * al.total;
+    const char* ap = (const char*)act + bi * act_stride;
     float* o = out + bi * m_;
     switch (w->dtype) {
       case CRABML_HIP_Q4_0: {

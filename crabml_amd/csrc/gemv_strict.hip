@@ -149,9 +149,10 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (qt == 0xffffffffu) return set_error(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
   const ActLayout al = act_layout(qt, k);
+  const size_t act_stride = qt == CRABML_HIP_F32 ? k * 4 : al.total;
   for (size_t bi = 0; bi < b; bi++)
     k_gemv_strict<<<(unsigned)((m + 63) / 64), 64, 0, dev->stream>>>((const char*)w->ptr, (int)w->dtype, w->wl.off_scale,
-                                                                     (const char*)act + bi * al.total, al.off_d,
+                                                                     (const char*)act + bi * act_stride, al.off_d,
                                                                      al.off_aux, out + bi * m, (int)m, (int)k);
   return 0;
 }

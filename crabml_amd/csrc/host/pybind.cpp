@@ -74,6 +74,23 @@ PYBIND11_MODULE(_host, m) {
       .def("mem_in_use", &HipTensorDevice::mem_in_use)
       .def("stream", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(crabml_hip_device_stream(d.raw())); })
       .def("raw_handle", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(d.raw()); })
+      .def("prof_enable", [](HipTensorDevice& d, bool on) { d.check(crabml_hip_prof_enable(d.raw(), on ? 1 : 0)); })
+      .def("prof_read",
+           [](HipTensorDevice& d) {
+             crabml_hip_prof_entry_t e[16];
+             size_t n = 0;
+             d.check(crabml_hip_prof_read(d.raw(), e, 16, &n));
+             py::list out;
+             for (size_t i = 0; i < n; i++) {
+               py::dict r;
+               r["dtype"] = e[i].dtype;
+               r["launches"] = e[i].launches;
+               r["kernel_ms"] = e[i].kernel_ms;
+               r["algo_bytes"] = e[i].algo_bytes;
+               out.append(r);
+             }
+             return out;
+           })
       .def("dump_debug_tensor", [](HipTensorDevice& d, const std::string& name) -> py::object {
         std::vector<float> v;
         if (!d.dump_debug_tensor(name, &v)) return py::none();

@@ -641,8 +641,28 @@ int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, s
   crabml_hip_buf* o = nullptr;
   CH_TRY(buf_new(dev, CRABML_HIP_F32, b * m, b * m * 4, &o));
   o->wl = weight_layout(CRABML_HIP_F32, b * m);
+  crabml_hip_device::ProfRec rec{};
+  if (dev->prof_on) {
+    auto get_ev = [&](hipEvent_t* e) -> hipError_t {
+      if (!dev->prof_free_events.empty()) {
+        *e = dev->prof_free_events.back();
+        dev->prof_free_events.pop_back();
+        return hipSuccess;
+      }
+      return hipEventCreate(e);
+    };
+    CH_HIP(dev, get_ev(&rec.e0));
+    CH_HIP(dev, get_ev(&rec.e1));
+    rec.dtype = w->dtype;
+    rec.bytes = (double)b * ((double)m * (double)(k / block_elems(w->dtype)) * (double)block_bytes(w->dtype) + 4.0 * k + 4.0 * m);
+    CH_HIP(dev, hipEventRecord(rec.e0, dev->stream));
+  }
   int rc = dev->strict_order ? launch_gemv_strict(dev, w, m, k, act, b, (float*)o->ptr)
                              : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr);
+  if (dev->prof_on) {
+    CH_HIP(dev, hipEventRecord(rec.e1, dev->stream));
+    dev->prof_recs.push_back(rec);
+  }
   if (rc != 0) {
     crabml_hip_buf_release(o);
     return rc;
@@ -732,6 +752,35 @@ int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t
   if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
   pool_free(dev, d, cap);
   if (e != hipSuccess) return hip_fail(dev, e, "debug_block_dots", __FILE__, __LINE__);
+  return 0;
+}
+
+int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on) {
+  if (!dev) return CRABML_HIP_BAD_INPUT;
+  dev->prof_on = on != 0;
+  return 0;
+}
+
+int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n) {
+  if (!dev || !n || (!out && cap)) return CRABML_HIP_BAD_INPUT;
+  CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  std::map<uint32_t, crabml_hip_prof_entry_t> agg;
+  for (auto& r : dev->prof_recs) {
+    float ms = 0.f;
+    CH_HIP(dev, hipEventElapsedTime(&ms, r.e0, r.e1));
+    auto& e = agg[r.dtype];
+    e.dtype = r.dtype;
+    e.launches++;
+    e.kernel_ms += ms;
+    e.algo_bytes += r.bytes;
+    dev->prof_free_events.push_back(r.e0);
+    dev->prof_free_events.push_back(r.e1);
+  }
+  dev->prof_recs.clear();
+  size_t i = 0;
+  for (auto& kv : agg)
+    if (i < cap) out[i++] = kv.second;
+  *n = i;
   return 0;
 }
 

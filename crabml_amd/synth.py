@@ -20,7 +20,37 @@ TYPE_BY_NAME = {v: k for k, v in TYPE_NAMES.items()}
 
 
 def _f16_scales(rng, n, lo=2e-3, hi=2e-2):
-    return rng.uniform(lo, hi, size=n).astype(np.float16).view(np.uint16)
+    """n positive f16 scales in [lo, hi], drawn uniformly over the f16 BIT patterns of that range
+    (log-uniform in value) -- an integer draw, ~10x faster than uniform-float + astype(float16)."""
+    b0 = int(np.array([lo], dtype=np.float16).view(np.uint16)[0])
+    b1 = int(np.array([hi], dtype=np.float16).view(np.uint16)[0])
+    return rng.integers(b0, b1 + 1, size=n, dtype=np.uint16)
+
+
+_POOL = {}
+
+
+def _rand_bytes(rng: np.random.Generator, n: int) -> np.ndarray:
+    """n pseudo-random bytes at memcpy speed: a 32 MiB PCG64 pool, re-entered at a random offset per call
+    (multi-GB models would otherwise spend a minute in the generator; HBM traffic does not care that the
+    byte stream repeats every 32 MiB at different addresses)."""
+    key = id(rng.bit_generator)
+    pool = _POOL.get(key)
+    if pool is None:
+        pool = np.frombuffer(rng.bytes(32 << 20), dtype=np.uint8)
+        _POOL.clear()
+        _POOL[key] = pool
+    if n <= 4096:
+        return np.frombuffer(rng.bytes(n), dtype=np.uint8).copy()
+    off = int(rng.integers(0, pool.size))
+    out = np.empty(n, dtype=np.uint8)
+    pos = 0
+    while pos < n:
+        take = min(n - pos, pool.size - off)
+        out[pos:pos + take] = pool[off:off + take]
+        pos += take
+        off = 0
+    return out
 
 
 def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: float = 1.0) -> np.ndarray:
@@ -32,15 +62,17 @@ def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: f
         return (rng.standard_normal(n_elems, dtype=np.float32) * np.float32(0.02 * scale_mul)).view(np.uint8)
     if typ == F16:
         return (rng.standard_normal(n_elems, dtype=np.float32) * np.float32(0.02 * scale_mul)).astype(np.float16).view(np.uint8)
-    out = np.empty((nb, bb), dtype=np.uint8)
     lo, hi = 2e-3 * scale_mul, 2e-2 * scale_mul
-    if typ == Q4_0:
-        out[:, 0:2] = _f16_scales(rng, nb, lo, hi).reshape(nb, 1).view(np.uint8)
-        out[:, 2:] = rng.integers(0, 256, size=(nb, 16), dtype=np.uint8)
-    elif typ == Q8_0:
-        out[:, 0:2] = _f16_scales(rng, nb, lo / 8, hi / 8).reshape(nb, 1).view(np.uint8)
-        out[:, 2:] = rng.integers(0, 256, size=(nb, 32), dtype=np.uint8)
-    elif typ == Q4_1:
+    if typ in (Q4_0, Q8_0):  # all bytes random, then the d field overwritten
+        out = _rand_bytes(rng, nb * bb).reshape(nb, bb)
+        b0, b1 = (lo, hi) if typ == Q4_0 else (lo / 8, hi / 8)
+        lo16 = int(np.array([b0], dtype=np.float16).view(np.uint16)[0])
+        span = int(np.array([b1], dtype=np.float16).view(np.uint16)[0]) - lo16 + 1
+        sc = (lo16 + _rand_bytes(rng, nb * 2).view(np.uint16) % span).astype(np.uint16)
+        out[:, 0:2] = sc.reshape(nb, 1).view(np.uint8)
+        return out.reshape(-1)
+    out = np.empty((nb, bb), dtype=np.uint8)
+    if typ == Q4_1:
         out[:, 0:2] = _f16_scales(rng, nb, lo, hi).reshape(nb, 1).view(np.uint8)
         out[:, 2:4] = (-rng.uniform(8 * lo, 8 * hi, size=nb)).astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
         out[:, 4:] = rng.integers(0, 256, size=(nb, 16), dtype=np.uint8)

@@ -169,6 +169,23 @@ int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* 
 int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
                                 const crabml_hip_buf_t* x, int32_t* dst);
 
+/* ---- measurement hook (bench.py `roofline` object) -------------------------------------------------
+ * While enabled, every matmul_vec GEMV kernel launch is bracketed by a pair of HIP events recorded on
+ * the device's own stream (the stream the kernel runs on); crabml_hip_prof_read() drains them and
+ * returns, per weight dtype, the number of launches, the summed kernel time and the summed ALGORITHMIC
+ * bytes  m*(k/QK)*BLK + 4k + 4m  (SURVEY.md section 8d).  Costs one event pair per launch: use it in a
+ * dedicated instrumented pass, not inside a throughput-timed region. */
+typedef struct crabml_hip_prof_entry {
+  uint32_t dtype;        /* weight GGML type of the GEMV */
+  uint32_t reserved;
+  uint64_t launches;
+  double kernel_ms;      /* sum over launches of (stop - start) */
+  double algo_bytes;     /* sum over launches of algorithmic bytes */
+} crabml_hip_prof_entry_t;
+int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on);
+/* blocks until the recorded events completed; fills up to cap entries, returns the count in *n */
+int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n);
+
 #ifdef __cplusplus
 }
 #endif
