@@ -168,28 +168,53 @@ def main():
     dev.sync()
     t_build = time.perf_counter() - t_build
     seq_len = args.warmup + 2 * args.steps + 16
-    runner = ca.Llama2Runner(conf, weights, dev, seq_len, True)  # f16 KV cache = the CLI default (main.rs:250)
-    path = "trait"
     gemv_bytes = model.gemv_weight_bytes_per_token()
+    trait = ca.Llama2Runner(conf, weights, dev, seq_len, True)  # f16 KV cache = the CLI default (main.rs:250)
+    path = args.path
+    fused = None
+    if path in ("auto", "fused"):
+        try:
+            fused = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True)
+            path = "fused"
+        except ca.CrabmlError:
+            if path == "fused":
+                raise
+            path = "trait"
+
+    def decode(tok, n):
+        """n greedy decode steps, returns the last sampled token"""
+        if path == "fused":
+            return int(fused.decode_greedy(tok, n)[-1])
+        return int(trait.timed_decode(tok, n)[0][-1])
 
     # ---- warm-up (untimed), then the timed region -------------------------------------------------
-    ids, _ = runner.timed_decode(1, args.warmup) if args.warmup > 0 else ([1], 0.0)
-    tok = ids[-1] if ids else 1
+    tok = decode(1, args.warmup) if args.warmup > 0 else 1
     dev.sync()
     dist.barrier()
     t0 = time.perf_counter()
-    ids, _inner = runner.timed_decode(tok, args.steps)
+    tok = decode(tok, args.steps)
     dev.sync()
     dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed_max, total_tokens = dist.max_sum(elapsed, args.steps)
+
+    # the per-op trait path (Llama2Runner<HipTensor> unchanged) is always reported next to the fused number
+    trait_tps = None
+    if rank == 0 and path == "fused":
+        n_t = min(args.steps, 16)
+        t_tok = int(trait.timed_decode(1, 2)[0][-1])
+        dev.sync()
+        tt = time.perf_counter()
+        trait.timed_decode(t_tok, n_t)
+        dev.sync()
+        trait_tps = n_t / (time.perf_counter() - tt)
 
     # ---- instrumented pass: HIP events around every GEMV launch (same process, same weights) --------
     roof = None
     if rank == 0:
         dev.prof_enable(True)
         n_prof = min(args.steps, 16)
-        runner.timed_decode(ids[-1], n_prof)
+        trait.timed_decode(1, n_prof)
         recs = dev.prof_read()
         dev.prof_enable(False)
         rec = next((r for r in recs if r["dtype"] == wtype), None)
@@ -203,7 +228,9 @@ def main():
                 "avg_launch_us": round(rec["kernel_ms"] * 1e3 / rec["launches"], 3),
                 "algo_bytes_per_launch": round(rec["algo_bytes"] / rec["launches"], 1),
                 "gemv_ms_per_token": round(rec["kernel_ms"] / n_prof, 4),
-                "method": "hipEvent pairs on the backend's stream around each GEMV launch, separate instrumented pass",
+                "method": "hipEvent pairs on the backend's stream around each matmul_vec GEMV launch of the per-op "
+                          "path, separate instrumented pass (the fused path's graph cannot carry events; its GEMV "
+                          "stages use the same mapping -- see profiles/ for rocprofv3 per-kernel durations)",
             }
 
     out = None
@@ -227,6 +254,8 @@ def main():
             "effective_weight_GBps_per_gpu": round(tps / args.gpus * gemv_bytes / 1e9, 1),
             "setup_s": round(t_build, 1),
         }
+        if trait_tps is not None:
+            out["trait_path_tokens_per_s"] = round(trait_tps, 2)
         if args.layers is not None:
             out["INVALID"] = "layer count truncated with --layers (debug run)"
         if roof:

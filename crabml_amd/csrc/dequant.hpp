@@ -1,0 +1,72 @@
+// dequant.hpp -- one element of a device-resident (planes) tensor as f32, with the reference's exact
+// expression (one or two roundings): BlockQ*::dequantize in buf_q8_0.rs:18-23, buf_q4_0.rs:18-27,
+// buf_q4_1.rs:19-30 (interleaved order, as written there), buf_q4_k.rs:24-47, buf_q8_k.rs:15-20.
+#pragma once
+#include "devutil.hpp"
+
+namespace crabml_hip {
+
+__device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dtype, size_t off_scale, size_t e) {
+  float v;
+  switch (dtype) {
+    case CRABML_HIP_F32: v = ((const float*)w)[e]; break;
+    case CRABML_HIP_F16: v = h2f(((const unsigned short*)w)[e]); break;
+    case CRABML_HIP_Q8_0: {
+      size_t b = e / 32;
+      float d = h2f(((const unsigned short*)(w + off_scale))[b]);
+      v = (float)((const signed char*)w)[e] * d;
+      break;
+    }
+    case CRABML_HIP_Q4_0: {
+      size_t b = e / 32, j = e % 32;
+      float d = h2f(((const unsigned short*)(w + off_scale))[b]);
+      unsigned char q = ((const unsigned char*)w)[b * 16 + (j & 15)];
+      int xi = (j < 16 ? (q & 0x0F) : (q >> 4)) - 8;
+      v = (float)xi * d;
+      break;
+    }
+    case CRABML_HIP_Q4_1: {  // interleaved order, exactly as buf_q4_1.rs:23-29
+      size_t b = e / 32, j = e % 32;
+      unsigned dm = ((const unsigned*)(w + off_scale))[b];
+      float d = h2f((unsigned short)(dm & 0xffffu)), m = h2f((unsigned short)(dm >> 16));
+      unsigned char q = ((const unsigned char*)w)[b * 16 + (j >> 1)];
+      float xf = (float)((j & 1) ? ((q >> 4) & 0x0F) : (q & 0x0F));
+      v = xf * d + m;
+      break;
+    }
+    case CRABML_HIP_Q4_K: {
+      size_t sb = e / 256, j = e % 256;
+      const unsigned char* blk = (const unsigned char*)w + sb * 144;
+      unsigned short dh, mh;
+      __builtin_memcpy(&dh, blk, 2);
+      __builtin_memcpy(&mh, blk + 2, 2);
+      float d = h2f(dh), mn = h2f(mh);
+      const unsigned char* sc = blk + 4;
+      int c = (int)(j / 64), l = (int)(j % 64);
+      int is = 2 * c + (l >= 32 ? 1 : 0);
+      int s6, m6;
+      if (is < 4) {
+        s6 = sc[is] & 63;
+        m6 = sc[is + 4] & 63;
+      } else {
+        s6 = (sc[is + 4] & 0xF) | ((sc[is - 4] >> 6) << 4);
+        m6 = (sc[is + 4] >> 4) | ((sc[is] >> 6) << 4);
+      }
+      float d1 = d * (float)s6, m1 = mn * (float)m6;
+      unsigned char q = blk[16 + 32 * c + (l & 31)];
+      float qf = (float)(l >= 32 ? (q >> 4) : (q & 0xF));
+      v = d1 * qf - m1;
+      break;
+    }
+    case CRABML_HIP_Q8_K: {
+      size_t sb = e / 256;
+      float d = ((const float*)(w + off_scale))[sb];
+      v = d * (float)((const signed char*)w)[e];
+      break;
+    }
+    default: v = 0.f;
+  }
+  return v;
+}
+
+}  // namespace crabml_hip

@@ -13,7 +13,7 @@
 //              buf_q4_k.rs:24-47, buf_q8_k.rs:15-20)
 // These are µs-scale, launch-bound kernels; the fused decode path (fused.hip) folds them into the
 // GEMV producers/consumers.
-#include "devutil.hpp"
+#include "dequant.hpp"
 #include "kernels.hpp"
 
 namespace crabml_hip {
@@ -212,72 +212,12 @@ void launch_concatenate(hipStream_t st, void* dst, int dst_f16, size_t dst_off, 
 }
 
 // ---- dequantize a run of elements (embedding lookup) ---------------------------------------------------
-// One thread per output element; each value is computed with the reference's expression (one or two
-// roundings), from the device planes.
+// One thread per output element; dequant_elem() (dequant.hpp) evaluates the reference's expression.
 __global__ __launch_bounds__(256) void k_dequant(const char* __restrict__ w, int dtype, size_t off_scale,
                                                  size_t start, size_t n, void* __restrict__ dst, int dst_f16) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  size_t e = start + t;
-  float v;
-  switch (dtype) {
-    case CRABML_HIP_F32: v = ((const float*)w)[e]; break;
-    case CRABML_HIP_F16: v = h2f(((const unsigned short*)w)[e]); break;
-    case CRABML_HIP_Q8_0: {
-      size_t b = e / 32;
-      float d = h2f(((const unsigned short*)(w + off_scale))[b]);
-      v = (float)((const signed char*)w)[e] * d;
-      break;
-    }
-    case CRABML_HIP_Q4_0: {
-      size_t b = e / 32, j = e % 32;
-      float d = h2f(((const unsigned short*)(w + off_scale))[b]);
-      unsigned char q = ((const unsigned char*)w)[b * 16 + (j & 15)];
-      int xi = (j < 16 ? (q & 0x0F) : (q >> 4)) - 8;
-      v = (float)xi * d;
-      break;
-    }
-    case CRABML_HIP_Q4_1: {  // interleaved order, exactly as buf_q4_1.rs:23-29
-      size_t b = e / 32, j = e % 32;
-      unsigned dm = ((const unsigned*)(w + off_scale))[b];
-      float d = h2f((unsigned short)(dm & 0xffffu)), m = h2f((unsigned short)(dm >> 16));
-      unsigned char q = ((const unsigned char*)w)[b * 16 + (j >> 1)];
-      float xf = (float)((j & 1) ? ((q >> 4) & 0x0F) : (q & 0x0F));
-      v = xf * d + m;
-      break;
-    }
-    case CRABML_HIP_Q4_K: {
-      size_t sb = e / 256, j = e % 256;
-      const unsigned char* blk = (const unsigned char*)w + sb * 144;
-      unsigned short dh, mh;
-      __builtin_memcpy(&dh, blk, 2);
-      __builtin_memcpy(&mh, blk + 2, 2);
-      float d = h2f(dh), mn = h2f(mh);
-      const unsigned char* sc = blk + 4;
-      int c = (int)(j / 64), l = (int)(j % 64);
-      int is = 2 * c + (l >= 32 ? 1 : 0);
-      int s6, m6;
-      if (is < 4) {
-        s6 = sc[is] & 63;
-        m6 = sc[is + 4] & 63;
-      } else {
-        s6 = (sc[is + 4] & 0xF) | ((sc[is - 4] >> 6) << 4);
-        m6 = (sc[is + 4] >> 4) | ((sc[is] >> 6) << 4);
-      }
-      float d1 = d * (float)s6, m1 = mn * (float)m6;
-      unsigned char q = blk[16 + 32 * c + (l & 31)];
-      float qf = (float)(l >= 32 ? (q >> 4) : (q & 0xF));
-      v = d1 * qf - m1;
-      break;
-    }
-    case CRABML_HIP_Q8_K: {
-      size_t sb = e / 256;
-      float d = ((const float*)(w + off_scale))[sb];
-      v = d * (float)((const signed char*)w)[e];
-      break;
-    }
-    default: v = 0.f;
-  }
+  float v = dequant_elem(w, dtype, off_scale, start + t);
   if (dst_f16)
     ((unsigned short*)dst)[t] = f2h(v);
   else

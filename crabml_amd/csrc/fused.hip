@@ -1,0 +1,768 @@
+// fused.hip -- the fused Llama decode step (crabml_hip_llama_*): the hot path as 8 kernels per layer,
+// replayed from one hipGraph with token id / position resident in device memory.
+//
+// It serves exactly the op sequence Llama2Runner<T> issues for one token (crabml-llama2/src/llama2.rs):
+//   forward_llama :213-281, forward_multi_query_attention :527-603, forward_ffn :605-638, classifier :184-211
+// with the reference's arithmetic (each fused stage cites the primitive it folds in).  Why fuse: the per-op
+// trait path is launch-bound (31 launches/layer, GPU busy 1/3 of the time; profiles/r01_trait_path_kernel_
+// trace.md).  The GEMV stages use the same lane-per-block / R-rows-per-wave mapping as gemv.hip and stay
+// HBM-bound; the small stages are folded into their producers/consumers so activations never round-trip
+// through extra launches:
+//   k_norm_quant   rms_norm_inplace + mul_inplace(weight) + quantize_f32_q8_0        (1 workgroup)
+//   k_qkv          wq/wk/wv matmul_vec + rope_inplace(q,k) + scale_inplace(q) + concatenate(k,v -> KV cache)
+//   k_attn         batch_matmul(q,K^T) + softmax_inplace + batch_matmul(p,V) [+ quantize for wo]
+//   k_gemv_res     wo / ffn_down matmul_vec + add_inplace(residual)
+//   k_gateup       ffn_gate/ffn_up matmul_vec + silu_inplace + mul_inplace
+//   k_argmax_step  greedy sampler (last maximum) + token/position advance
+#include <cmath>
+
+#include "dequant.hpp"
+#include "gemv_core.hpp"
+#include "kernels.hpp"
+
+namespace crabml_hip {
+
+// exp_f32_cached (buf_f32.rs:29-35)
+__device__ __forceinline__ float exp_cached_f(float x, const unsigned short* __restrict__ table) {
+  return h2f(table[f2h(x)]);
+}
+
+// ---- embedding lookup: copy_rows_from(token_embed, [token]) (llama2.rs:222-223) ----------------------
+__global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int dtype, size_t off_scale,
+                                               const int* __restrict__ token_d, int dim, float* __restrict__ x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dim) return;
+  x[i] = dequant_elem(w, dtype, off_scale, (size_t)(*token_d) * dim + i);
+}
+
+// ---- rmsnorm * weight -> Q8_0 planes ------------------------------------------------------------------
+// rms_norm.rs:33-46 (ordered 32-chunk sums, serial chunk accumulation, true division), arithmetic.rs:57-66
+// (x * w), buf_q8_0.rs:87-134 (truncating quantizer).  x itself is left untouched: it is the residual.
+__global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
+                                                    int cols, float eps, signed char* __restrict__ q,
+                                                    unsigned short* __restrict__ d, int* __restrict__ isum,
+                                                    float* __restrict__ y_out /*nullable: normalized f32 copy*/) {
+  extern __shared__ float chunk_sums[];
+  __shared__ float s_rms;
+  const int nchunks = cols / 32;
+  for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
+    const f32x4* p = (const f32x4*)(x + c * 32);
+    float s = -0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      f32x4 t = p[j];
+      s += t[0] * t[0];
+      s += t[1] * t[1];
+      s += t[2] * t[2];
+      s += t[3] * t[3];
+    }
+    chunk_sums[c] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sum = 0.0f;
+    for (int c = 0; c < nchunks; c++) sum += chunk_sums[c];
+    s_rms = sqrtf(sum / (float)cols + eps);
+  }
+  __syncthreads();
+  const float rms = s_rms;
+  const int j = threadIdx.x & 31;
+  for (int blk = threadIdx.x >> 5; blk < nchunks; blk += blockDim.x >> 5) {
+    int i = blk * 32 + j;
+    float v = (x[i] / rms) * w[i];
+    if (y_out) y_out[i] = v;
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+    float dd = amax / 127.0f;
+    int qi = rs_f32_as_i32(v / dd);
+    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+    int s = (int)q8;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+    q[i] = q8;
+    if (j == 0) {
+      d[blk] = f2h(dd);
+      isum[blk] = s;
+    }
+  }
+}
+
+// ---- QKV epilogue: rope (rope.rs:47-63) + q scale (llama2.rs:565) + KV append (concatenate.rs:172-204) ---
+struct QkvEpi {
+  float* q_out;       // (n_heads * hd) f32, roped and scaled
+  void* kc;           // K cache of this layer [n_kv][seq_cap][hd]
+  void* vc;
+  const float* rope;  // [seq_cap][npairs][2] (cos, sin)
+  const int* pos_d;
+  float scale;        // 1 / sqrt(hd)
+  int dim, kv_dim, hd, rope_dim, npairs, seq_cap, kv16;
+};
+
+__device__ __forceinline__ void qkv_epilogue(const QkvEpi& e, int row0, float s0, float s1) {
+  const int pos = *e.pos_d;
+  if (row0 < e.dim + e.kv_dim) {  // q or k: rotate the (even, odd) pair
+    const int i = (row0 < e.dim ? row0 : row0 - e.dim) % e.hd;
+    float r0 = s0, r1 = s1;
+    if (i < e.rope_dim) {
+      const float* cs = e.rope + ((size_t)pos * e.npairs + (i >> 1)) * 2;
+      float c = cs[0], s = cs[1];
+      r0 = s0 * c - s1 * s;
+      r1 = s0 * s + s1 * c;
+    }
+    if (row0 < e.dim) {
+      e.q_out[row0] = r0 * e.scale;
+      e.q_out[row0 + 1] = r1 * e.scale;
+    } else {
+      const int kr = row0 - e.dim;
+      const size_t o = ((size_t)(kr / e.hd) * e.seq_cap + pos) * e.hd + i;
+      if (e.kv16) {
+        ((unsigned short*)e.kc)[o] = f2h(r0);
+        ((unsigned short*)e.kc)[o + 1] = f2h(r1);
+      } else {
+        ((float*)e.kc)[o] = r0;
+        ((float*)e.kc)[o + 1] = r1;
+      }
+    }
+  } else {
+    const int vr = row0 - e.dim - e.kv_dim;
+    const size_t o = ((size_t)(vr / e.hd) * e.seq_cap + pos) * e.hd + (vr % e.hd);
+    if (e.kv16) {
+      ((unsigned short*)e.vc)[o] = f2h(s0);
+      ((unsigned short*)e.vc)[o + 1] = f2h(s1);
+    } else {
+      ((float*)e.vc)[o] = s0;
+      ((float*)e.vc)[o + 1] = s1;
+    }
+  }
+}
+
+struct Planes {
+  const i32x4* q;
+  const unsigned short* d;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ActQ8_0 act, int nb, QkvEpi e) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * 2;
+  const int total = e.dim + 2 * e.kv_dim;
+  if (row0 >= total) return;
+  Planes w;
+  int local, m;
+  if (row0 < e.dim) {
+    w = wq; local = row0; m = e.dim;
+  } else if (row0 < e.dim + e.kv_dim) {
+    w = wk; local = row0 - e.dim; m = e.kv_dim;
+  } else {
+    w = wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
+  }
+  float acc[2];
+  rows_partial<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
+  float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
+  if (lane == 0) qkv_epilogue(e, row0, s0, s1);
+}
+// strict mode: the three GEMVs ran in scalar order into tmp[dim + 2 kv_dim]; apply the same epilogue
+__global__ __launch_bounds__(256) void k_qkv_epi(const float* __restrict__ tmp, QkvEpi e) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = (e.dim + 2 * e.kv_dim) / 2;
+  if (p < total) qkv_epilogue(e, 2 * p, tmp[2 * p], tmp[2 * p + 1]);
+}
+
+// ---- attention: one workgroup per head -------------------------------------------------------------------
+// batch_matmul.rs: f16 cache -> q rounded to f16, f32-accumulated QK^T in k order (buf_f16.rs:83-97),
+// GQA head = h / (n_heads/n_kv); PV accumulated in f16 with a rounding after the product and after the sum
+// (buf_f16.rs:152-163).  f32 cache -> plain f32 loops, kv head = h % n_kv (batch_matmul.rs:61-67).
+// softmax.rs:36-54 with the f16 exp table; the row sum is sequential (bit-exact) up to 1024 positions and a
+// block tree beyond that (documented tolerance 1e-6 relative).
+template <bool KV16>
+__global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const void* __restrict__ kc,
+                                              const void* __restrict__ vc, const int* __restrict__ pos_d,
+                                              const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
+                                              signed char* __restrict__ xq, unsigned short* __restrict__ xd,
+                                              int* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap) {
+  extern __shared__ float lds[];
+  __shared__ float s_red[4];
+  __shared__ float s_val;
+  float* scores = lds;
+  float* qs = lds + seq_cap;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x;
+  const int seq = *pos_d + 1;
+  const int kvh = KV16 ? head / (n_heads / n_kv) : head % n_kv;
+  for (int i = tid; i < hd; i += blockDim.x) {
+    float v = q[head * hd + i];
+    qs[i] = KV16 ? h2f(f2h(v)) : v;  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+  }
+  __syncthreads();
+  // ---- scores[t] = q . K[t]
+  for (int t = tid; t < seq; t += blockDim.x) {
+    float acc = 0.0f;
+    if (KV16) {
+      const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
+      for (int i = 0; i < hd; i++) acc += qs[i] * h2f(kr[i]);
+    } else {
+      const float* kr = (const float*)kc + ((size_t)kvh * seq_cap + t) * hd;
+      for (int i = 0; i < hd; i++) acc += qs[i] * kr[i];
+    }
+    scores[t] = acc;
+  }
+  __syncthreads();
+  // ---- softmax
+  float mx = -INFINITY;
+  for (int t = tid; t < seq; t += blockDim.x) mx = fmaxf(mx, scores[t]);
+  mx = wave_max_f32(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float part = 0.0f;
+  for (int t = tid; t < seq; t += blockDim.x) {
+    float ev = exp_cached_f(scores[t] - mx, exp_tab);
+    scores[t] = ev;
+    part += ev;
+  }
+  __syncthreads();
+  if (seq <= 1024) {
+    if (tid == 0) {
+      float sum = 0.0f;
+      for (int t = 0; t < seq; t++) sum += scores[t];
+      s_val = sum;
+    }
+  } else {
+    part = wave_sum_f32(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    if (tid == 0) s_val = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  }
+  __syncthreads();
+  const float sum = s_val;
+  for (int t = tid; t < seq; t += blockDim.x) scores[t] = scores[t] / sum;
+  __syncthreads();
+  // ---- out[n] = sum_t p[t] * V[t][n]
+  float val = 0.0f;
+  const int n = tid;
+  if (n < hd) {
+    if (KV16) {
+      const unsigned short* vr = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + n;
+      unsigned short c = 0;
+      for (int t = 0; t < seq; t++) c = h_add(c, h_mul(vr[(size_t)t * hd], f2h(scores[t])));
+      val = h2f(c);
+    } else {
+      const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
+      float c = 0.0f;
+      for (int t = 0; t < seq; t++) c += scores[t] * vr[(size_t)t * hd];
+      val = c;
+    }
+    out[head * hd + n] = val;
+  }
+  // ---- quantize the head's output for wo (only when blocks do not straddle heads)
+  if (xq != nullptr) {
+    const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
+    float amax = live ? fabsf(val) : 0.f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+    float dd = amax / 127.0f;
+    int qi = rs_f32_as_i32(val / dd);
+    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+    int s = live ? (int)q8 : 0;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+    if (live) {
+      int e = head * hd + n;
+      xq[e] = q8;
+      if ((n & 31) == 0) {
+        xd[e >> 5] = f2h(dd);
+        xisum[e >> 5] = s;
+      }
+    }
+  }
+}
+
+// ---- GEMV + residual: x[row] = W[row].xq + x[row]   (matmul_vec, then add_inplace: arithmetic.rs:27-33) ---
+template <int FMT, int R>
+__global__ __launch_bounds__(128) void k_gemv_res(Planes w, ActQ8_0 act, float* __restrict__ x, int m, int nb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+  rows_partial<FMT, R>(w.q, w.d, act, row0, m, nb, lane, acc);
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) x[row0 + r] = s + x[row0 + r];
+  }
+}
+__global__ __launch_bounds__(256) void k_res_epi(const float* __restrict__ tmp, float* __restrict__ x, int m) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) x[i] = tmp[i] + x[i];
+}
+
+// ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
+__device__ __forceinline__ float silu_mul(float g, float u, const unsigned short* __restrict__ exp_tab) {
+  float nexp = exp_cached_f(-g, exp_tab);
+  return (g / (1.0f + nexp)) * u;
+}
+template <int FMT>
+__global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, ActQ8_0 act, const unsigned short* __restrict__ exp_tab,
+                                                float* __restrict__ h, int m, int nb) {
+  using F = BlockFmt<FMT>;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= m) return;
+  float ag = 0.f, au = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    size_t idx = (size_t)row * nb + b;
+    typename F::Blk bg = F::load(wg.q, wg.d, idx);
+    typename F::Blk bu = F::load(wu.q, wu.d, idx);
+    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
+    float dx = h2f(act.d[b]);
+    int xs = act.isum[b];
+    ag += F::term(bg, x0, x1, dx, xs);
+    au += F::term(bu, x0, x1, dx, xs);
+  }
+  ag = wave_sum_f32(ag);
+  au = wave_sum_f32(au);
+  if (lane == 0) h[row] = silu_mul(ag, au, exp_tab);
+}
+__global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
+                                                    const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) h[i] = silu_mul(g[i], u[i], exp_tab);
+}
+
+// plain Q8_0 activation quantizer on an f32 vector (same code as quantize.hip's, kept local for the graph)
+__global__ __launch_bounds__(256) void k_quant_q8_0_f(const float* __restrict__ x, signed char* __restrict__ q,
+                                                      unsigned short* __restrict__ d, int* __restrict__ isum, int nblocks) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int blk = gid >> 5, j = gid & 31;
+  bool live = blk < nblocks;
+  float v = live ? x[blk * 32 + j] : 0.f;
+  float amax = fabsf(v);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+  float dd = amax / 127.0f;
+  int qi = rs_f32_as_i32(v / dd);
+  signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+  int s = (int)q8;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  if (live) {
+    q[blk * 32 + j] = q8;
+    if (j == 0) {
+      d[blk] = f2h(dd);
+      isum[blk] = s;
+    }
+  }
+}
+
+// ---- greedy sampler + advance: Iterator::max_by keeps the LAST maximum (sampler.rs:109-116) ------------
+__global__ __launch_bounds__(1024) void k_argmax_step(const float* __restrict__ logits, int n, int* __restrict__ token_d,
+                                                      int* __restrict__ pos_d, int* __restrict__ step_d,
+                                                      unsigned* __restrict__ out_tokens, int out_cap) {
+  __shared__ float sv[1024];
+  __shared__ int si[1024];
+  float bv = -INFINITY;
+  int bi = -1;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = logits[i];
+    if (bi < 0 || !(bv > v)) {
+      bv = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      float ov = sv[threadIdx.x + o];
+      int oi = si[threadIdx.x + o];
+      float cv = sv[threadIdx.x];
+      int ci = si[threadIdx.x];
+      bool take = oi >= 0 && (ci < 0 || ov > cv || (!(cv > ov) && oi > ci));
+      if (take) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int tok = si[0];
+    *token_d = tok;
+    int st = *step_d;
+    if (st < out_cap) out_tokens[st] = (unsigned)tok;
+    *step_d = st + 1;
+    *pos_d = *pos_d + 1;
+  }
+}
+
+}  // namespace crabml_hip
+
+// ==============================================================================================================
+using namespace crabml_hip;
+
+struct crabml_hip_llama {
+  crabml_hip_device* dev = nullptr;
+  crabml_hip_llama_config_t cfg{};
+  uint32_t wtype = 0;
+  int hd = 0, kv_dim = 0, npairs = 0;
+  std::vector<crabml_hip_buf*> held;  // retained weight buffers
+  crabml_hip_buf* token_embed = nullptr;
+  crabml_hip_buf* rms_final = nullptr;
+  crabml_hip_buf* output = nullptr;
+  std::vector<crabml_hip_buf*> rms_att, rms_ffn, wq, wk, wv, wo, gate, down, up;
+  // device state
+  std::vector<void*> kc, vc;
+  size_t kv_bytes = 0;
+  float* x = nullptr;       // residual stream (dim)
+  float* qbuf = nullptr;    // roped, scaled q (dim)
+  float* attn = nullptr;    // attention output (dim)
+  float* h = nullptr;       // ffn hidden (hidden_dim)
+  float* logits = nullptr;  // vocab
+  float* tmp = nullptr;     // strict-mode GEMV outputs (max(dim + 2 kv_dim, 2 hidden))
+  char* act_dim = nullptr;  // Q8_0 planes of a dim-sized vector
+  char* act_hid = nullptr;  // Q8_0 planes of a hidden-sized vector
+  float* rope = nullptr;    // [seq_len][npairs][2]
+  int* state = nullptr;     // token, pos, step
+  unsigned* out_tokens = nullptr;
+  int out_cap = 0;
+  size_t kv_len = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::vector<std::pair<void*, size_t>> allocs;
+};
+
+namespace {
+
+int dalloc(crabml_hip_llama* c, size_t bytes, void** out) {
+  size_t cap = 0;
+  CH_TRY(pool_alloc(c->dev, bytes, out, &cap));
+  c->allocs.push_back({*out, cap});
+  return 0;
+}
+
+Planes planes_of(const crabml_hip_buf* b) {
+  return Planes{(const i32x4*)b->ptr, (const unsigned short*)((const char*)b->ptr + b->wl.off_scale)};
+}
+
+ActQ8_0 act_of(char* p, size_t n) {
+  ActLayout al = act_layout(CRABML_HIP_Q8_0, n);
+  return ActQ8_0{(const i32x4*)p, (const unsigned short*)(p + al.off_d), (const int*)(p + al.off_aux)};
+}
+
+template <int FMT>
+int enqueue_step_t(crabml_hip_llama* c) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const auto& g = c->cfg;
+  const int dim = (int)g.embedding_dim, hidden = (int)g.hidden_dim, hd = c->hd, kv_dim = c->kv_dim;
+  const int n_heads = (int)g.n_heads, n_kv = (int)g.n_kv_heads, seq_cap = (int)g.seq_len;
+  const bool kv16 = g.use_f16_kv_cache != 0;
+  const bool strict = dev->strict_order;
+  int* token_d = c->state;
+  int* pos_d = c->state + 1;
+  int* step_d = c->state + 2;
+  ActLayout ald = act_layout(CRABML_HIP_Q8_0, dim), alh = act_layout(CRABML_HIP_Q8_0, hidden);
+  ActQ8_0 ad = act_of(c->act_dim, dim), ah = act_of(c->act_hid, hidden);
+  signed char* adq = (signed char*)c->act_dim;
+  unsigned short* add = (unsigned short*)(c->act_dim + ald.off_d);
+  int* adi = (int*)(c->act_dim + ald.off_aux);
+  signed char* ahq = (signed char*)c->act_hid;
+  unsigned short* ahd = (unsigned short*)(c->act_hid + alh.off_d);
+  int* ahi = (int*)(c->act_hid + alh.off_aux);
+  const size_t norm_lds = (size_t)(dim / 32) * sizeof(float);
+  const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
+  const bool attn_quant = (hd % 32) == 0;
+
+  k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
+                                              c->token_embed->wl.off_scale, token_d, dim, c->x);
+  for (size_t l = 0; l < g.n_layers; l++) {
+    // attention rmsnorm (llama2.rs:230-234)
+    k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_att[l]->ptr, dim, g.rms_norm_eps, adq, add, adi, nullptr);
+    // q, k, v + rope + scale + KV append (llama2.rs:244-256, 542-554, 561-565)
+    QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
+             (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
+    const int total_rows = dim + 2 * kv_dim;
+    if (!strict) {
+      int waves = total_rows / 2;
+      k_qkv<FMT><<<(waves + 1) / 2, 128, 0, st>>>(planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), ad, dim / 32, e);
+    } else {
+      CH_TRY(launch_gemv_strict(dev, c->wq[l], dim, dim, c->act_dim, 1, c->tmp));
+      CH_TRY(launch_gemv_strict(dev, c->wk[l], kv_dim, dim, c->act_dim, 1, c->tmp + dim));
+      CH_TRY(launch_gemv_strict(dev, c->wv[l], kv_dim, dim, c->act_dim, 1, c->tmp + dim + kv_dim));
+      k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
+    }
+    // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]
+    if (kv16)
+      k_attn<true><<<n_heads, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
+                                                   attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap);
+    else
+      k_attn<false><<<n_heads, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
+                                                    attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap);
+    if (!attn_quant) k_quant_q8_0_f<<<(dim + 255) / 256, 256, 0, st>>>(c->attn, adq, add, adi, dim / 32);
+    // wo + residual (llama2.rs:600, 266)
+    if (!strict) {
+      k_gemv_res<FMT, 1><<<(dim + 1) / 2, 128, 0, st>>>(planes_of(c->wo[l]), ad, c->x, dim, dim / 32);
+    } else {
+      CH_TRY(launch_gemv_strict(dev, c->wo[l], dim, dim, c->act_dim, 1, c->tmp));
+      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
+    }
+    // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
+    k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_ffn[l]->ptr, dim, 1e-5f, adq, add, adi, nullptr);
+    // gate / up + silu * mul (llama2.rs:620-630)
+    if (!strict) {
+      k_gateup<FMT><<<(hidden + 1) / 2, 128, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, c->h, hidden, dim / 32);
+    } else {
+      CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden, dim, c->act_dim, 1, c->tmp));
+      CH_TRY(launch_gemv_strict(dev, c->up[l], hidden, dim, c->act_dim, 1, c->tmp + hidden));
+      k_gateup_epi<<<(hidden + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden, dev->exp_table, c->h, hidden);
+    }
+    k_quant_q8_0_f<<<(hidden + 255) / 256, 256, 0, st>>>(c->h, ahq, ahd, ahi, hidden / 32);
+    // down + residual (llama2.rs:633-636)
+    if (!strict) {
+      k_gemv_res<FMT, 1><<<(dim + 1) / 2, 128, 0, st>>>(planes_of(c->down[l]), ah, c->x, dim, hidden / 32);
+    } else {
+      CH_TRY(launch_gemv_strict(dev, c->down[l], dim, hidden, c->act_hid, 1, c->tmp));
+      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
+    }
+  }
+  // final rmsnorm + classifier (llama2.rs:274-278, 199-208)
+  k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, adq, add, adi, nullptr);
+  if (!strict)
+    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
+  else
+    CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
+  k_argmax_step<<<1, 1024, 0, st>>>(c->logits, (int)g.vocab_size, token_d, pos_d, step_d, c->out_tokens, c->out_cap);
+  CH_HIP(dev, hipGetLastError());
+  return 0;
+}
+
+int enqueue_step(crabml_hip_llama* c) {
+  return c->wtype == CRABML_HIP_Q4_0 ? enqueue_step_t<CRABML_HIP_Q4_0>(c) : enqueue_step_t<CRABML_HIP_Q8_0>(c);
+}
+
+int run_step(crabml_hip_llama* c) {
+  if (c->exec) {
+    CH_HIP(c->dev, hipGraphLaunch(c->exec, c->dev->stream));
+    return 0;
+  }
+  return enqueue_step(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_config_t* cfg,
+                            const crabml_hip_llama_weights_t* w, crabml_hip_llama_t** out) {
+  if (!dev || !cfg || !w || !out) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  const auto& g = *cfg;
+  if (!g.n_heads || !g.n_kv_heads || !g.n_layers || g.embedding_dim % g.n_heads || g.n_heads % g.n_kv_heads)
+    CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: inconsistent head configuration");
+  const size_t hd = g.embedding_dim / g.n_heads, kv_dim = hd * g.n_kv_heads;
+  if (g.embedding_dim % 32 || g.hidden_dim % 32 || (hd & 1) || hd > 256 || (g.rope_dim & 1) || g.rope_dim > hd || !g.seq_len)
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: needs dim,hidden % 32 == 0, even head_dim <= 256, even rope_dim");
+  if (!w->token_embed || !w->rms_final_weight || !w->wq || !w->wk || !w->wv || !w->wo || !w->ffn_gate_weight ||
+      !w->ffn_down_weight || !w->ffn_up_weight || !w->rms_att_weight || !w->rms_ffn_weight)
+    CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: missing weights");
+  if ((g.seq_len + hd) * sizeof(float) > 64 * 1024)
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: seq_len %zu needs more than 64 KiB of LDS for the score row", g.seq_len);
+  const crabml_hip_buf* outw = w->output_weight ? w->output_weight : w->token_embed;
+  const uint32_t wt = w->wq[0]->dtype;
+  if (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0)
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: weights must be Q4_0 or Q8_0 (got %u); use the Tensor ops", wt);
+  auto check = [&](const crabml_hip_buf* b, size_t m, size_t k, uint32_t t) {
+    return b && b->dtype == t && b->n_elems == m * k && (block_elems(t) == 1 || b->k == k);
+  };
+  for (size_t l = 0; l < g.n_layers; l++) {
+    if (!check(w->wq[l], g.embedding_dim, g.embedding_dim, wt) || !check(w->wk[l], kv_dim, g.embedding_dim, wt) ||
+        !check(w->wv[l], kv_dim, g.embedding_dim, wt) || !check(w->wo[l], g.embedding_dim, g.embedding_dim, wt) ||
+        !check(w->ffn_gate_weight[l], g.hidden_dim, g.embedding_dim, wt) ||
+        !check(w->ffn_up_weight[l], g.hidden_dim, g.embedding_dim, wt) ||
+        !check(w->ffn_down_weight[l], g.embedding_dim, g.hidden_dim, wt) ||
+        !check(w->rms_att_weight[l], 1, g.embedding_dim, CRABML_HIP_F32) ||
+        !check(w->rms_ffn_weight[l], 1, g.embedding_dim, CRABML_HIP_F32))
+      CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: layer %zu weights have an unexpected dtype/shape", l);
+  }
+  if (!check(outw, g.vocab_size, g.embedding_dim, wt) || !check(w->rms_final_weight, 1, g.embedding_dim, CRABML_HIP_F32) ||
+      w->token_embed->n_elems != g.vocab_size * g.embedding_dim)
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: classifier / final norm / embedding dtype or shape");
+
+  (void)hipSetDevice(dev->ordinal);
+  crabml_hip_llama* c = new crabml_hip_llama();
+  c->dev = dev;
+  c->cfg = g;
+  c->wtype = wt;
+  c->hd = (int)hd;
+  c->kv_dim = (int)kv_dim;
+  c->npairs = (int)(g.rope_dim / 2);
+  auto hold = [&](const crabml_hip_buf* b) {
+    crabml_hip_buf* m = const_cast<crabml_hip_buf*>(b);
+    crabml_hip_buf_retain(m);
+    c->held.push_back(m);
+    return m;
+  };
+  c->token_embed = hold(w->token_embed);
+  c->rms_final = hold(w->rms_final_weight);
+  c->output = hold(outw);
+  for (size_t l = 0; l < g.n_layers; l++) {
+    c->rms_att.push_back(hold(w->rms_att_weight[l]));
+    c->rms_ffn.push_back(hold(w->rms_ffn_weight[l]));
+    c->wq.push_back(hold(w->wq[l]));
+    c->wk.push_back(hold(w->wk[l]));
+    c->wv.push_back(hold(w->wv[l]));
+    c->wo.push_back(hold(w->wo[l]));
+    c->gate.push_back(hold(w->ffn_gate_weight[l]));
+    c->down.push_back(hold(w->ffn_down_weight[l]));
+    c->up.push_back(hold(w->ffn_up_weight[l]));
+  }
+  int rc = 0;
+  auto A = [&](size_t bytes, void** p) {
+    if (rc == 0) rc = dalloc(c, bytes, p);
+  };
+  const size_t es = g.use_f16_kv_cache ? 2 : 4;
+  c->kv_bytes = g.n_kv_heads * g.seq_len * hd * es;
+  c->kc.resize(g.n_layers);
+  c->vc.resize(g.n_layers);
+  for (size_t l = 0; l < g.n_layers; l++) {
+    A(c->kv_bytes, &c->kc[l]);
+    A(c->kv_bytes, &c->vc[l]);
+  }
+  A(g.embedding_dim * 4, (void**)&c->x);
+  A(g.embedding_dim * 4, (void**)&c->qbuf);
+  A(g.embedding_dim * 4, (void**)&c->attn);
+  A(g.hidden_dim * 4, (void**)&c->h);
+  A(g.vocab_size * 4, (void**)&c->logits);
+  size_t tmp_n = g.embedding_dim + 2 * kv_dim;
+  if (2 * g.hidden_dim > tmp_n) tmp_n = 2 * g.hidden_dim;
+  A(tmp_n * 4, (void**)&c->tmp);
+  A(act_layout(CRABML_HIP_Q8_0, g.embedding_dim).total, (void**)&c->act_dim);
+  A(act_layout(CRABML_HIP_Q8_0, g.hidden_dim).total, (void**)&c->act_hid);
+  A(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2 * 4, (void**)&c->rope);
+  A(3 * sizeof(int), (void**)&c->state);
+  c->out_cap = (int)g.seq_len;
+  A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
+  if (rc != 0) {
+    crabml_hip_llama_destroy(c);
+    return rc;
+  }
+  // RoPE table with the reference's own recurrence (rope.rs:47-54: theta_scale = 10000^(-2/hd), theta = pos,
+  // theta *= theta_scale per pair; base hard-coded) evaluated with the host libm, as the trait op does.
+  {
+    std::vector<float> tab(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2, 0.f);
+    const float theta_scale = powf(10000.0f, -2.0f / (float)hd);
+    for (size_t p = 0; p < g.seq_len; p++) {
+      float theta = (float)p;
+      for (int i = 0; i < c->npairs; i++) {
+        tab[(p * c->npairs + i) * 2] = cosf(theta);
+        tab[(p * c->npairs + i) * 2 + 1] = sinf(theta);
+        theta *= theta_scale;
+      }
+    }
+    hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 3 * sizeof(int), dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e != hipSuccess) {
+      crabml_hip_llama_destroy(c);
+      return hip_fail(dev, e, "llama init", __FILE__, __LINE__);
+    }
+  }
+  // capture one decode step into a graph (token / pos / step are read from device memory by the kernels)
+  if (!(g.flags & CRABML_HIP_LLAMA_NO_GRAPH)) {
+    hipError_t e = hipStreamBeginCapture(dev->stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      int erc = enqueue_step(c);
+      hipGraph_t graph = nullptr;
+      hipError_t e2 = hipStreamEndCapture(dev->stream, &graph);
+      if (erc == 0 && e2 == hipSuccess && graph) {
+        hipGraphExec_t exec = nullptr;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          c->graph = graph;
+          c->exec = exec;
+        } else {
+          (void)hipGraphDestroy(graph);
+        }
+      } else if (graph) {
+        (void)hipGraphDestroy(graph);
+      }
+    }
+    (void)hipGetLastError();
+    if (!c->exec) {  // fail loudly: the caller asked for the graph path
+      crabml_hip_llama_destroy(c);
+      CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: hipGraph capture/instantiate failed");
+    }
+  }
+  *out = c;
+  return 0;
+}
+
+int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
+  if (!c) return 0;
+  (void)hipStreamSynchronize(c->dev->stream);
+  if (c->exec) (void)hipGraphExecDestroy(c->exec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  for (auto& a : c->allocs) pool_free(c->dev, a.first, a.second);
+  for (auto* b : c->held) crabml_hip_buf_release(b);
+  delete c;
+  return 0;
+}
+
+static int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step) {
+  int st[3] = {(int)token, (int)pos, step};
+  CH_HIP(c->dev, hipMemcpyAsync(c->state, st, sizeof st, hipMemcpyHostToDevice, c->dev->stream));
+  return 0;
+}
+
+int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, float* logits) {
+  if (!c) return CRABML_HIP_BAD_INPUT;
+  crabml_hip_device* dev = c->dev;
+  if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
+  if (pos != c->kv_len) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: pos %zu != kv cache length %zu", pos, c->kv_len);
+  if (pos >= c->cfg.seq_len) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: kv cache is full (%zu)", c->cfg.seq_len);
+  CH_TRY(set_state(c, token, pos, 0));
+  CH_TRY(run_step(c));
+  c->kv_len++;
+  if (logits) {
+    CH_HIP(dev, hipMemcpyAsync(logits, c->logits, c->cfg.vocab_size * 4, hipMemcpyDeviceToHost, dev->stream));
+    CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  }
+  return 0;
+}
+
+int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n_steps, uint32_t* out_tokens) {
+  if (!c || (!out_tokens && n_steps)) return CRABML_HIP_BAD_INPUT;
+  crabml_hip_device* dev = c->dev;
+  if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
+  if (c->kv_len + n_steps > c->cfg.seq_len || n_steps > (size_t)c->out_cap)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: %zu steps do not fit the kv cache (%zu of %zu used)", n_steps, c->kv_len, c->cfg.seq_len);
+  if (n_steps == 0) return 0;
+  CH_TRY(set_state(c, token, c->kv_len, 0));
+  for (size_t s = 0; s < n_steps; s++) CH_TRY(run_step(c));
+  c->kv_len += n_steps;
+  CH_HIP(dev, hipMemcpyAsync(out_tokens, c->out_tokens, n_steps * 4, hipMemcpyDeviceToHost, dev->stream));
+  CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  return 0;
+}
+
+size_t crabml_hip_llama_kv_len(const crabml_hip_llama_t* c) { return c ? c->kv_len : 0; }
+
+int crabml_hip_llama_reset(crabml_hip_llama_t* c) {
+  if (!c) return CRABML_HIP_BAD_INPUT;
+  c->kv_len = 0;
+  return 0;
+}
+
+int crabml_hip_llama_debug_kv(crabml_hip_llama_t* c, size_t layer, int32_t which_v, void* dst, size_t nbytes) {
+  if (!c || !dst) return CRABML_HIP_BAD_INPUT;
+  if (layer >= c->cfg.n_layers || nbytes > c->kv_bytes) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: bad layer/size");
+  CH_HIP(c->dev, hipMemcpyAsync(dst, which_v ? c->vc[layer] : c->kc[layer], nbytes, hipMemcpyDeviceToHost, c->dev->stream));
+  CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -14,59 +14,10 @@
 // `(sumi as f32 * d_w) * d_x`; only the ORDER in which block terms are added differs from the scalar
 // CPU loop (lane-strided partial sums + a 64-lane butterfly), which is why logits carry an fp tolerance.
 // The kernel is HBM-bound (~3.6 flop/byte): no LDS round trip, no MFMA; x is re-read from L1/L2.
-#include "devutil.hpp"
+#include "gemv_core.hpp"
 #include "kernels.hpp"
 
 namespace crabml_hip {
-
-// ---- exact integer block dots ----------------------------------------------------------------
-// Q4_0 block (16 bytes: byte j = elem j (low nibble) | elem j+16 (high nibble)) . 32 int8, minus 8*sum(x)
-__device__ __forceinline__ int dot_q4_0(i32x4 q, i32x4 xlo, i32x4 xhi, int xsum) {
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int w = q[i];
-    s = __builtin_amdgcn_sdot4(w & 0x0F0F0F0F, xlo[i], s, false);
-    s = __builtin_amdgcn_sdot4((w >> 4) & 0x0F0F0F0F, xhi[i], s, false);
-  }
-  return s - 8 * xsum;
-}
-// unsigned nibbles (Q4_1, Q4_K)
-__device__ __forceinline__ int dot_u4(i32x4 q, i32x4 xlo, i32x4 xhi) {
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int w = q[i];
-    s = __builtin_amdgcn_sdot4(w & 0x0F0F0F0F, xlo[i], s, false);
-    s = __builtin_amdgcn_sdot4((w >> 4) & 0x0F0F0F0F, xhi[i], s, false);
-  }
-  return s;
-}
-__device__ __forceinline__ int dot_i8x32(i32x4 a0, i32x4 a1, i32x4 b0, i32x4 b1) {
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    s = __builtin_amdgcn_sdot4(a0[i], b0[i], s, false);
-    s = __builtin_amdgcn_sdot4(a1[i], b1[i], s, false);
-  }
-  return s;
-}
-
-struct ActQ8_0 {
-  const i32x4* q;
-  const unsigned short* d;
-  const int* isum;
-};
-struct ActQ8_1 {
-  const i32x4* q;
-  const unsigned short* d;
-  const unsigned short* s;
-};
-struct ActQ8_K {
-  const i32x4* q;
-  const float* d;
-  const short* bsums;
-};
 
 // ---- Q4_0 x Q8_0 ---------------------------------------------------------------------------------
 template <int R>

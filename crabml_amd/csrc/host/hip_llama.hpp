@@ -1,0 +1,93 @@
+// hip_llama.hpp -- host-side handle of the fused decode step (crabml_hip_llama_*).
+// In the Rust crate this is `impl HipLlamaRunner` next to `impl Tensor for HipTensor`: crabml-llama2's
+// `Llama2Runner::forward_llama` (llama2.rs:213-281) stays generic; a 10-line specialisation hands a whole
+// decode step to the backend when T = HipTensor.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "hip_tensor.hpp"
+#include "llama2_runner.hpp"
+
+namespace crabml_host {
+
+class HipLlamaRunner {
+ public:
+  HipLlamaRunner(const LlamaConfig& conf, std::shared_ptr<LlamaWeights<HipTensor>> w, HipTensorDeviceRef device,
+                 size_t seq_len, bool use_f16_kv_cache, bool use_graph = true)
+      : conf_(conf), weights_(std::move(w)), device_(std::move(device)) {
+    crabml_hip_llama_config_t c{};
+    c.embedding_dim = conf.embedding_dim;
+    c.hidden_dim = conf.hidden_dim;
+    c.n_layers = conf.n_layers;
+    c.n_heads = conf.n_heads;
+    c.n_kv_heads = conf.n_kv_heads;
+    c.vocab_size = conf.vocab_size;
+    c.seq_len = seq_len;
+    c.rope_dim = conf.rope_dim.value_or(conf.head_size());
+    c.rms_norm_eps = conf.rms_norm_eps;
+    c.use_f16_kv_cache = use_f16_kv_cache ? 1 : 0;
+    c.flags = use_graph ? 0 : CRABML_HIP_LLAMA_NO_GRAPH;
+    auto raws = [](const std::vector<HipTensor>& v) {
+      std::vector<const crabml_hip_buf_t*> r;
+      for (const auto& t : v) r.push_back(t.raw());
+      return r;
+    };
+    const auto& W = *weights_;
+    auto att = raws(W.rms_att_weight), ffn = raws(W.rms_ffn_weight), wq = raws(W.wq), wk = raws(W.wk), wv = raws(W.wv),
+         wo = raws(W.wo), gate = raws(W.ffn_gate_weight), down = raws(W.ffn_down_weight), up = raws(W.ffn_up_weight);
+    for (auto* v : {&att, &ffn, &wq, &wk, &wv, &wo, &gate, &down, &up})
+      if (v->size() != conf.n_layers) throw Error(ErrorKind::ModelError, "weights do not have n_layers entries");
+    crabml_hip_llama_weights_t cw{};
+    cw.token_embed = W.token_embed.raw();
+    cw.rms_att_weight = att.data();
+    cw.rms_ffn_weight = ffn.data();
+    cw.wq = wq.data();
+    cw.wk = wk.data();
+    cw.wv = wv.data();
+    cw.wo = wo.data();
+    cw.ffn_gate_weight = gate.data();
+    cw.ffn_down_weight = down.data();
+    cw.ffn_up_weight = up.data();
+    cw.rms_final_weight = W.rms_final_weight.raw();
+    cw.output_weight = W.output_weight ? W.output_weight->raw() : nullptr;
+    device_->check(crabml_hip_llama_create(device_->raw(), &c, &cw, &ctx_));
+  }
+  ~HipLlamaRunner() {
+    if (ctx_) crabml_hip_llama_destroy(ctx_);
+  }
+  HipLlamaRunner(const HipLlamaRunner&) = delete;
+  HipLlamaRunner& operator=(const HipLlamaRunner&) = delete;
+
+  size_t kv_cache_len() const { return crabml_hip_llama_kv_len(ctx_); }
+  void reset() { device_->check(crabml_hip_llama_reset(ctx_)); }
+  // Llama2Runner::forward (llama2.rs:184-211) for one token; returns the logits
+  std::vector<float> forward(size_t token, size_t pos) {
+    std::vector<float> logits(conf_.vocab_size);
+    device_->check(crabml_hip_llama_forward(ctx_, token, pos, logits.data()));
+    return logits;
+  }
+  void forward_async(size_t token, size_t pos) { device_->check(crabml_hip_llama_forward(ctx_, token, pos, nullptr)); }
+  std::vector<uint32_t> decode_greedy(size_t token, size_t steps) {
+    std::vector<uint32_t> ids(steps);
+    device_->check(crabml_hip_llama_decode_greedy(ctx_, token, steps, ids.data()));
+    return ids;
+  }
+  std::vector<uint8_t> debug_kv(size_t layer, bool v, bool f16) {
+    size_t n = conf_.n_kv_heads * seq_cap() * conf_.head_size() * (f16 ? 2 : 4);
+    std::vector<uint8_t> out(n);
+    device_->check(crabml_hip_llama_debug_kv(ctx_, layer, v ? 1 : 0, out.data(), n));
+    return out;
+  }
+  void set_seq_cap(size_t s) { seq_cap_ = s; }
+  size_t seq_cap() const { return seq_cap_; }
+
+ private:
+  LlamaConfig conf_;
+  std::shared_ptr<LlamaWeights<HipTensor>> weights_;
+  HipTensorDeviceRef device_;  // declared before ctx_ is destroyed in ~HipLlamaRunner
+  crabml_hip_llama_t* ctx_ = nullptr;
+  size_t seq_cap_ = 0;
+};
+
+}  // namespace crabml_host

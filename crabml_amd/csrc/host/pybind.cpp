@@ -8,6 +8,7 @@
 
 #include <chrono>
 
+#include "hip_llama.hpp"
 #include "hip_tensor.hpp"
 #include "llama2_runner.hpp"
 
@@ -213,6 +214,37 @@ PYBIND11_MODULE(_host, m) {
             else
               w.output_weight = o.cast<HipTensor>();
           });
+
+  py::class_<HipLlamaRunner>(m, "HipLlamaRunner")
+      .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,
+                       size_t seq_len, bool use_f16_kv_cache, bool use_graph) {
+             auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph);
+             r->set_seq_cap(seq_len);
+             return r;
+           }),
+           py::arg("conf"), py::arg("weights"), py::arg("device"), py::arg("seq_len"), py::arg("use_f16_kv_cache"),
+           py::arg("use_graph") = true)
+      .def("kv_cache_len", &HipLlamaRunner::kv_cache_len)
+      .def("reset", &HipLlamaRunner::reset)
+      .def("forward",
+           [](HipLlamaRunner& r, size_t token, size_t pos) {
+             std::vector<float> lg;
+             {
+               py::gil_scoped_release rel;
+               lg = r.forward(token, pos);
+             }
+             return py::array_t<float>(lg.size(), lg.data());
+           })
+      .def("forward_async", &HipLlamaRunner::forward_async)
+      .def("decode_greedy",
+           [](HipLlamaRunner& r, size_t token, size_t steps) {
+             py::gil_scoped_release rel;
+             return r.decode_greedy(token, steps);
+           })
+      .def("debug_kv", [](HipLlamaRunner& r, size_t layer, bool v, bool f16) {
+        std::vector<uint8_t> b = r.debug_kv(layer, v, f16);
+        return py::array_t<uint8_t>(b.size(), b.data());
+      });
 
   py::class_<Runner>(m, "Llama2Runner")
       .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,

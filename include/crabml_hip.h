@@ -169,6 +169,57 @@ int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* 
 int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
                                 const crabml_hip_buf_t* x, int32_t* dst);
 
+/* ---- fused Llama decode step (extension of the hot path) ------------------------------------------
+ * The trait above costs ~31 launches per layer (one per Tensor call of crabml-llama2/src/llama2.rs:226-271),
+ * which makes batch-1 decode launch-bound on MI355X (profiles/r01_trait_path_kernel_trace.md).  This entry
+ * point serves the SAME op sequence -- Llama2Runner::forward for the Llama architecture, n_batch = 1
+ * (llama2.rs:184-281, 527-638) -- as 8 fused kernels per layer replayed from one hipGraph:
+ *   rmsnorm*w+quantize | QKV GEMV + RoPE + scale + KV append | attention (QK^T, softmax, PV, quantize) |
+ *   wo GEMV + residual | rmsnorm*w+quantize | gate/up GEMV + SiLU*mul | quantize | down GEMV + residual
+ * with token id and position living in device memory (greedy argmax on device, sampler.rs:109-116).
+ * Arithmetic is the reference's (same rounding points; RoPE cos/sin tabulated on the host with the same
+ * libm + iterated-theta recurrence); only GEMV block terms are summed wave-parallel, exactly like
+ * crabml_hip_matmul_vec.  With CRABML_HIP_FLAG_STRICT_ORDER the GEMVs run in scalar order and the step
+ * is bit-identical to the reference.  Weights: wq..ffn_* and output must share one dtype in
+ * {Q4_0, Q8_0}; norm weights F32; otherwise CRABML_HIP_NOT_IMPLEMENTED (use the per-op trait path). */
+typedef struct crabml_hip_llama crabml_hip_llama_t;
+#define CRABML_HIP_LLAMA_NO_GRAPH 1 /* launch the kernels eagerly instead of replaying a hipGraph */
+typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
+  size_t embedding_dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size;
+  size_t seq_len;  /* KV cache capacity (Llama2Runner::new seq_len, llama2.rs:46-86) */
+  size_t rope_dim; /* conf.rope_dim.unwrap_or(head_dim) */
+  float rms_norm_eps;
+  int32_t use_f16_kv_cache;
+  int32_t flags;
+} crabml_hip_llama_config_t;
+typedef struct crabml_hip_llama_weights { /* crabml-llama2/src/model.rs:55-84; per-layer arrays of n_layers */
+  const crabml_hip_buf_t* token_embed;
+  const crabml_hip_buf_t* const* rms_att_weight;
+  const crabml_hip_buf_t* const* rms_ffn_weight;
+  const crabml_hip_buf_t* const* wq;
+  const crabml_hip_buf_t* const* wk;
+  const crabml_hip_buf_t* const* wv;
+  const crabml_hip_buf_t* const* wo;
+  const crabml_hip_buf_t* const* ffn_gate_weight;
+  const crabml_hip_buf_t* const* ffn_down_weight;
+  const crabml_hip_buf_t* const* ffn_up_weight;
+  const crabml_hip_buf_t* rms_final_weight;
+  const crabml_hip_buf_t* output_weight; /* NULL = tied to token_embed (llama2.rs:203-207) */
+} crabml_hip_llama_weights_t;
+int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_config_t* cfg,
+                            const crabml_hip_llama_weights_t* w, crabml_hip_llama_t** out);
+int crabml_hip_llama_destroy(crabml_hip_llama_t* ctx);
+/* Llama2Runner::forward(&[token], pos): pos must equal the current KV length.  If logits != NULL the
+ * vocab_size f32 logits are copied out (BLOCKS); otherwise the call only enqueues. */
+int crabml_hip_llama_forward(crabml_hip_llama_t* ctx, size_t token, size_t pos, float* logits);
+/* n_steps greedy decode steps on device: forward(token), token = argmax (last maximum), ...; the n_steps
+ * sampled ids are written to out_tokens (BLOCKS once, at the end). */
+int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* ctx, size_t token, size_t n_steps, uint32_t* out_tokens);
+size_t crabml_hip_llama_kv_len(const crabml_hip_llama_t* ctx);
+int crabml_hip_llama_reset(crabml_hip_llama_t* ctx); /* empties the KV caches */
+/* parity hook: copies the layer's K or V cache (raw f16/f32 bytes, [n_kv_heads][seq_len][head_dim]) */
+int crabml_hip_llama_debug_kv(crabml_hip_llama_t* ctx, size_t layer, int32_t which_v, void* dst, size_t nbytes);
+
 /* ---- measurement hook (bench.py `roofline` object) -------------------------------------------------
  * While enabled, every matmul_vec GEMV kernel launch is bracketed by a pair of HIP events recorded on
  * the device's own stream (the stream the kernel runs on); crabml_hip_prof_read() drains them and

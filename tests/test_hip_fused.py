@@ -1,0 +1,131 @@
+"""GPU parity for the fused decode step (crabml_hip_llama_*, crabml_amd/csrc/fused.hip) against the oracle's
+restatement of Llama2Runner<CpuTensor>::forward (llama2.rs:184-281, 527-638).
+
+  * strict-order device: logits AND the KV-cache bytes are bit-identical to the oracle at every step;
+  * fast device: logits within the stated tolerance (3e-2 * max|logit| median, 1e-1 max), and equal to the
+    per-op trait path's logits up to the same bound;
+  * the hipGraph replay equals eager launches bit for bit; on-device greedy sampling (last maximum,
+    sampler.rs:109-116) equals host argmax over exported logits."""
+import numpy as np
+import pytest
+
+from crabml_amd import synth
+from oracle import oracle as o
+from tests.helpers import to_oracle
+
+pytestmark = pytest.mark.gpu
+PROMPT = [1, 365, 400, 282]
+
+
+def oracle_logits(model, kv_f16, tokens, seq_len=64):
+    odev = o.OracleDevice(thread_num=4)
+    oconf, ow = to_oracle(model, odev)
+    r = o.OracleLlamaRunner(oconf, ow, odev, seq_len, kv_f16)
+    out = [r.forward([t], i).copy() for i, t in enumerate(tokens)]
+    return out, r
+
+
+def rel_errs(a, b):
+    return np.array([np.max(np.abs(x - y)) / np.max(np.abs(y)) for x, y in zip(a, b)])
+
+
+@pytest.mark.parametrize("shape", ["15m", "tiny-gqa"])
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0"])
+@pytest.mark.parametrize("kv_f16", [False, True])
+def test_fused_strict_is_bit_exact(ca, shape, fmt, kv_f16):
+    model = synth.build_model(synth.SHAPES[shape], synth.TYPE_BY_NAME[fmt], seed=11)
+    toks = PROMPT + [7, 9, 11, 13]
+    ref, orr = oracle_logits(model, kv_f16, toks)
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, dev)
+    for use_graph in (True, False):
+        r = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16, use_graph)
+        for i, t in enumerate(toks):
+            lg = r.forward(t, i)
+            assert np.array_equal(lg.view(np.uint32), ref[i].view(np.uint32)), f"graph={use_graph} step {i}"
+        assert r.kv_cache_len() == len(toks)
+        # KV cache contents: same bytes in the filled region (RNE f32->f16, rope, layout [n_kv][seq][hd])
+        s = model.shape
+        es = 2 if kv_f16 else 4
+        for layer in (0, s.n_layers - 1):
+            for which, cache in ((False, orr.key_cache), (True, orr.value_cache)):
+                got = r.debug_kv(layer, which, kv_f16)
+                exp = cache[layer].storage.view(np.uint8)
+                for h in range(s.n_kv_heads):
+                    lo = h * 64 * s.head_dim * es
+                    n = len(toks) * s.head_dim * es
+                    assert np.array_equal(got[lo:lo + n], exp[lo:lo + n]), (layer, which, h)
+
+
+@pytest.mark.parametrize("shape,fmt", [("15m", "Q4_0"), ("15m", "Q8_0"), ("tiny-gqa", "Q4_0")])
+def test_fused_fast_matches_oracle_and_trait_path(ca, shape, fmt):
+    model = synth.build_model(synth.SHAPES[shape], synth.TYPE_BY_NAME[fmt], seed=12)
+    toks = PROMPT + [3, 5, 8, 13, 21, 34]
+    ref, _ = oracle_logits(model, True, toks)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    fused = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    trait = ca.Llama2Runner(conf, w, dev, 64, True)
+    lf = [fused.forward(t, i).copy() for i, t in enumerate(toks)]
+    lt = [trait.forward([t], i).copy() for i, t in enumerate(toks)]
+    ef, et = rel_errs(lf, ref), rel_errs(lt, ref)
+    assert np.median(ef) <= 3e-2 and np.max(ef) <= 1e-1, ef
+    assert np.median(et) <= 3e-2 and np.max(et) <= 1e-1, et
+    # step 0 (empty cache, before anything can amplify) is tight for both
+    assert ef[0] <= 2e-2 and et[0] <= 2e-2
+
+
+def test_graph_replay_equals_eager_and_device_greedy_equals_host_argmax(ca):
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=13)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    rg = ca.HipLlamaRunner(conf, w, dev, 64, True, True)
+    re_ = ca.HipLlamaRunner(conf, w, dev, 64, True, False)
+    toks = []
+    t = 1
+    for i in range(10):
+        a, b = rg.forward(t, i), re_.forward(t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        t = o.argmax_last(a)
+        toks.append(t)
+    rd = ca.HipLlamaRunner(conf, w, dev, 64, True, True)
+    ids = rd.decode_greedy(1, 10)
+    assert list(ids) == toks
+    assert rd.kv_cache_len() == 10
+    more = rd.decode_greedy(int(ids[-1]), 5)  # continues from the cache
+    for i in range(5):
+        a = rg.forward(t, 10 + i)
+        t = o.argmax_last(a)
+        assert int(more[i]) == t
+
+
+def test_argmax_last_maximum_on_device(ca):
+    """All-zero weights -> all logits equal -> the reference's max_by picks the LAST index."""
+    s = synth.SHAPES["tiny-gqa"]
+    model = synth.build_model(s, synth.Q8_0, seed=1)
+    for name, t in model.tensors.items():
+        if name == "output.weight":
+            t.data[:] = 0
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 16, True)
+    ids = r.decode_greedy(5, 2)
+    assert list(ids) == [s.vocab - 1, s.vocab - 1]
+
+
+def test_fused_errors(ca):
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_1, seed=2)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    with pytest.raises(ca.CrabmlError):  # Q4_1 is served by the per-op path only
+        ca.HipLlamaRunner(conf, w, dev, 16, True)
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=2)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 4, True)
+    with pytest.raises(ca.CrabmlError):
+        r.forward(1, 3)  # pos != kv length
+    with pytest.raises(ca.CrabmlError):
+        r.forward(10 ** 6, 0)  # token out of range
+    r.decode_greedy(1, 4)
+    with pytest.raises(ca.CrabmlError):
+        r.decode_greedy(1, 1)  # cache full
