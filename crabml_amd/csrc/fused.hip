@@ -59,10 +59,18 @@ __global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x,
     chunk_sums[c] = s;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {
+    // chunk sums are added strictly in chunk order (rms_norm.rs:35-40).  The 64 lanes of wave 0 hold the
+    // chunk sums in registers; v_readlane feeds them one by one into a single dependent v_add chain
+    // (~5 cycles per add instead of an LDS round trip per add).  Lanes past nchunks contribute +0.0 (exact).
+    const int lane = threadIdx.x;
     float sum = 0.0f;
-    for (int c = 0; c < nchunks; c++) sum += chunk_sums[c];
-    s_rms = sqrtf(sum / (float)cols + eps);
+    for (int base = 0; base < nchunks; base += 64) {
+      float v = base + lane < nchunks ? chunk_sums[base + lane] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 64; i++) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+    }
+    if (lane == 0) s_rms = sqrtf(sum / (float)cols + eps);
   }
   __syncthreads();
   const float rms = s_rms;
@@ -201,10 +209,28 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
     float acc = 0.0f;
     if (KV16) {
       const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
-      for (int i = 0; i < hd; i++) acc += qs[i] * h2f(kr[i]);
+      int i = 0;
+      for (; i + 8 <= hd; i += 8) {  // 16-byte loads; products still added in k order
+        i32x4 kv = *(const i32x4*)(kr + i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          unsigned u = (unsigned)kv[j];
+          acc += qs[i + 2 * j] * h2f((unsigned short)(u & 0xffffu));
+          acc += qs[i + 2 * j + 1] * h2f((unsigned short)(u >> 16));
+        }
+      }
+      for (; i < hd; i++) acc += qs[i] * h2f(kr[i]);
     } else {
       const float* kr = (const float*)kc + ((size_t)kvh * seq_cap + t) * hd;
-      for (int i = 0; i < hd; i++) acc += qs[i] * kr[i];
+      int i = 0;
+      for (; i + 4 <= hd; i += 4) {
+        f32x4 kv = *(const f32x4*)(kr + i);
+        acc += qs[i] * kv[0];
+        acc += qs[i + 1] * kv[1];
+        acc += qs[i + 2] * kv[2];
+        acc += qs[i + 3] * kv[3];
+      }
+      for (; i < hd; i++) acc += qs[i] * kr[i];
     }
     scores[t] = acc;
   }
@@ -327,6 +353,65 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, ActQ8_0 ac
   au = wave_sum_f32(au);
   if (lane == 0) h[row] = silu_mul(ag, au, exp_tab);
 }
+// Same, with the Q8_0 quantization of h (the rhs of ffn_down) folded in: a workgroup owns 32 consecutive
+// hidden rows = one quant block; its 4 waves compute 8 rows each (2 at a time: 4 weight rows in flight), park
+// the 32 h values in LDS, and one half-wave quantizes them (buf_q8_0.rs:87-134).  Saves a launch per layer.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_gateup_q(Planes wg, Planes wu, ActQ8_0 act,
+                                                  const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
+                                                  unsigned short* __restrict__ d, int* __restrict__ isum, int m, int nb) {
+  using F = BlockFmt<FMT>;
+  __shared__ float hv[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int base = blk * 32 + wave * 8;
+#pragma unroll 1
+  for (int r = 0; r < 8; r += 2) {
+    const int row = base + r;  // rows row, row+1 (m % 32 == 0: always in range)
+    float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+    for (int b = lane; b < nb; b += 64) {
+      size_t i0 = (size_t)row * nb + b, i1 = i0 + nb;
+      typename F::Blk bg0 = F::load(wg.q, wg.d, i0);
+      typename F::Blk bu0 = F::load(wu.q, wu.d, i0);
+      typename F::Blk bg1 = F::load(wg.q, wg.d, i1);
+      typename F::Blk bu1 = F::load(wu.q, wu.d, i1);
+      i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
+      float dx = h2f(act.d[b]);
+      int xs = act.isum[b];
+      g0 += F::term(bg0, x0, x1, dx, xs);
+      u0 += F::term(bu0, x0, x1, dx, xs);
+      g1 += F::term(bg1, x0, x1, dx, xs);
+      u1 += F::term(bu1, x0, x1, dx, xs);
+    }
+    g0 = wave_sum_f32(g0);
+    u0 = wave_sum_f32(u0);
+    g1 = wave_sum_f32(g1);
+    u1 = wave_sum_f32(u1);
+    if (lane == 0) {
+      hv[wave * 8 + r] = silu_mul(g0, u0, exp_tab);
+      hv[wave * 8 + r + 1] = silu_mul(g1, u1, exp_tab);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float v = hv[threadIdx.x];
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+    float dd = amax / 127.0f;
+    int qi = rs_f32_as_i32(v / dd);
+    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+    int s = (int)q8;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+    q[blk * 32 + threadIdx.x] = q8;
+    if (threadIdx.x == 0) {
+      d[blk] = f2h(dd);
+      isum[blk] = s;
+    }
+  }
+  (void)m;
+}
 __global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
                                                     const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,42 +444,58 @@ __global__ __launch_bounds__(256) void k_quant_q8_0_f(const float* __restrict__ 
 }
 
 // ---- greedy sampler + advance: Iterator::max_by keeps the LAST maximum (sampler.rs:109-116) ------------
-__global__ __launch_bounds__(1024) void k_argmax_step(const float* __restrict__ logits, int n, int* __restrict__ token_d,
-                                                      int* __restrict__ pos_d, int* __restrict__ step_d,
-                                                      unsigned* __restrict__ out_tokens, int out_cap) {
-  __shared__ float sv[1024];
-  __shared__ int si[1024];
+// stage 1: ARGMAX_BLOCKS workgroups, each over a contiguous slice; stage 2: one wave combines and advances.
+#define ARGMAX_BLOCKS 128
+__device__ __forceinline__ void argmax_combine(float& cv, int& ci, float ov, int oi) {
+  // keep the later index among equal maxima; an index of -1 means "empty"
+  bool take = oi >= 0 && (ci < 0 || ov > cv || (!(cv > ov) && oi > ci));
+  if (take) {
+    cv = ov;
+    ci = oi;
+  }
+}
+__global__ __launch_bounds__(256) void k_argmax_partial(const float* __restrict__ logits, int n, float* __restrict__ pv,
+                                                        int* __restrict__ pi) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
   float bv = -INFINITY;
   int bi = -1;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float v = logits[i];
-    if (bi < 0 || !(bv > v)) {
-      bv = v;
-      bi = i;
-    }
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) argmax_combine(bv, bi, logits[i], i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    argmax_combine(bv, bi, ov, oi);
   }
-  sv[threadIdx.x] = bv;
-  si[threadIdx.x] = bi;
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = bv;
+    si[threadIdx.x >> 6] = bi;
+  }
   __syncthreads();
-  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      float ov = sv[threadIdx.x + o];
-      int oi = si[threadIdx.x + o];
-      float cv = sv[threadIdx.x];
-      int ci = si[threadIdx.x];
-      bool take = oi >= 0 && (ci < 0 || ov > cv || (!(cv > ov) && oi > ci));
-      if (take) {
-        sv[threadIdx.x] = ov;
-        si[threadIdx.x] = oi;
-      }
-    }
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) argmax_combine(bv, bi, sv[w], si[w]);
+    pv[blockIdx.x] = bv;
+    pi[blockIdx.x] = bi;
+  }
+}
+__global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
+                                                    int* __restrict__ token_d, int* __restrict__ pos_d,
+                                                    int* __restrict__ step_d, unsigned* __restrict__ out_tokens, int out_cap) {
+  float bv = -INFINITY;
+  int bi = -1;
+  for (int i = threadIdx.x; i < nparts; i += 64) argmax_combine(bv, bi, pv[i], pi[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    argmax_combine(bv, bi, ov, oi);
   }
   if (threadIdx.x == 0) {
-    int tok = si[0];
-    *token_d = tok;
+    *token_d = bi;
     int st = *step_d;
-    if (st < out_cap) out_tokens[st] = (unsigned)tok;
+    if (st < out_cap) out_tokens[st] = (unsigned)bi;
     *step_d = st + 1;
     *pos_d = *pos_d + 1;
   }
@@ -430,6 +531,8 @@ struct crabml_hip_llama {
   int* state = nullptr;     // token, pos, step
   unsigned* out_tokens = nullptr;
   int out_cap = 0;
+  float* am_val = nullptr;  // argmax partials
+  int* am_idx = nullptr;
   size_t kv_len = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -515,13 +618,13 @@ int enqueue_step_t(crabml_hip_llama* c) {
     k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_ffn[l]->ptr, dim, 1e-5f, adq, add, adi, nullptr);
     // gate / up + silu * mul (llama2.rs:620-630)
     if (!strict) {
-      k_gateup<FMT><<<(hidden + 1) / 2, 128, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, c->h, hidden, dim / 32);
+      k_gateup_q<FMT><<<hidden / 32, 256, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, hidden, dim / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden, dim, c->act_dim, 1, c->tmp));
       CH_TRY(launch_gemv_strict(dev, c->up[l], hidden, dim, c->act_dim, 1, c->tmp + hidden));
       k_gateup_epi<<<(hidden + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden, dev->exp_table, c->h, hidden);
     }
-    k_quant_q8_0_f<<<(hidden + 255) / 256, 256, 0, st>>>(c->h, ahq, ahd, ahi, hidden / 32);
+    if (strict) k_quant_q8_0_f<<<(hidden + 255) / 256, 256, 0, st>>>(c->h, ahq, ahd, ahi, hidden / 32);
     // down + residual (llama2.rs:633-636)
     if (!strict) {
       k_gemv_res<FMT, 1><<<(dim + 1) / 2, 128, 0, st>>>(planes_of(c->down[l]), ah, c->x, dim, hidden / 32);
@@ -536,7 +639,8 @@ int enqueue_step_t(crabml_hip_llama* c) {
     CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
   else
     CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
-  k_argmax_step<<<1, 1024, 0, st>>>(c->logits, (int)g.vocab_size, token_d, pos_d, step_d, c->out_tokens, c->out_cap);
+  k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
+  k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap);
   CH_HIP(dev, hipGetLastError());
   return 0;
 }
@@ -647,6 +751,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   A(3 * sizeof(int), (void**)&c->state);
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
+  A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);
+  A(ARGMAX_BLOCKS * 4, (void**)&c->am_idx);
   if (rc != 0) {
     crabml_hip_llama_destroy(c);
     return rc;
