@@ -79,15 +79,11 @@ __global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x,
     int i = blk * 32 + j;
     float v = (x[i] / rms) * w[i];
     if (y_out) y_out[i] = v;
-    float amax = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+    float amax = half_max_f32(fabsf(v));  // nchunks % 8 == 0 is not required: see the loop bound below
     float dd = amax / 127.0f;
     int qi = rs_f32_as_i32(v / dd);
     signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-    int s = (int)q8;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+    int s = half_sum_i32((int)q8);
     q[i] = q8;
     if (j == 0) {
       d[blk] = f2h(dd);
@@ -286,15 +282,11 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   // ---- quantize the head's output for wo (only when blocks do not straddle heads)
   if (xq != nullptr) {
     const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
-    float amax = live ? fabsf(val) : 0.f;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+    float amax = half_max_f32(live ? fabsf(val) : 0.f);
     float dd = amax / 127.0f;
     int qi = rs_f32_as_i32(val / dd);
     signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-    int s = live ? (int)q8 : 0;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+    int s = half_sum_i32(live ? (int)q8 : 0);
     if (live) {
       int e = head * hd + n;
       xq[e] = q8;
@@ -353,64 +345,56 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, ActQ8_0 ac
   au = wave_sum_f32(au);
   if (lane == 0) h[row] = silu_mul(ag, au, exp_tab);
 }
-// Same, with the Q8_0 quantization of h (the rhs of ffn_down) folded in: a workgroup owns 32 consecutive
-// hidden rows = one quant block; its 4 waves compute 8 rows each (2 at a time: 4 weight rows in flight), park
-// the 32 h values in LDS, and one half-wave quantizes them (buf_q8_0.rs:87-134).  Saves a launch per layer.
+// Same, with the Q8_0 quantization of h (the rhs of ffn_down) folded in: a 1024-thread workgroup owns 32
+// consecutive hidden rows = one quant block; each of its 16 waves computes 2 rows (4 weight rows in flight),
+// parks the h values in LDS, and one half-wave quantizes the block (buf_q8_0.rs:87-134).  hidden/32
+// workgroups (448 for Llama-3-8B) are all resident at once (2 per CU).  Saves a launch per layer.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_gateup_q(Planes wg, Planes wu, ActQ8_0 act,
-                                                  const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
-                                                  unsigned short* __restrict__ d, int* __restrict__ isum, int m, int nb) {
+__global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, ActQ8_0 act,
+                                                   const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
+                                                   unsigned short* __restrict__ d, int* __restrict__ isum, int nb) {
   using F = BlockFmt<FMT>;
   __shared__ float hv[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.x;
-  const int base = blk * 32 + wave * 8;
-#pragma unroll 1
-  for (int r = 0; r < 8; r += 2) {
-    const int row = base + r;  // rows row, row+1 (m % 32 == 0: always in range)
-    float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
-    for (int b = lane; b < nb; b += 64) {
-      size_t i0 = (size_t)row * nb + b, i1 = i0 + nb;
-      typename F::Blk bg0 = F::load(wg.q, wg.d, i0);
-      typename F::Blk bu0 = F::load(wu.q, wu.d, i0);
-      typename F::Blk bg1 = F::load(wg.q, wg.d, i1);
-      typename F::Blk bu1 = F::load(wu.q, wu.d, i1);
-      i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
-      float dx = h2f(act.d[b]);
-      int xs = act.isum[b];
-      g0 += F::term(bg0, x0, x1, dx, xs);
-      u0 += F::term(bu0, x0, x1, dx, xs);
-      g1 += F::term(bg1, x0, x1, dx, xs);
-      u1 += F::term(bu1, x0, x1, dx, xs);
-    }
-    g0 = wave_sum_f32(g0);
-    u0 = wave_sum_f32(u0);
-    g1 = wave_sum_f32(g1);
-    u1 = wave_sum_f32(u1);
-    if (lane == 0) {
-      hv[wave * 8 + r] = silu_mul(g0, u0, exp_tab);
-      hv[wave * 8 + r + 1] = silu_mul(g1, u1, exp_tab);
-    }
+  const int row = blk * 32 + wave * 2;  // rows row, row+1
+  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    size_t i0 = (size_t)row * nb + b, i1 = i0 + nb;
+    typename F::Blk bg0 = F::load(wg.q, wg.d, i0);
+    typename F::Blk bu0 = F::load(wu.q, wu.d, i0);
+    typename F::Blk bg1 = F::load(wg.q, wg.d, i1);
+    typename F::Blk bu1 = F::load(wu.q, wu.d, i1);
+    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
+    float dx = h2f(act.d[b]);
+    int xs = act.isum[b];
+    g0 += F::term(bg0, x0, x1, dx, xs);
+    u0 += F::term(bu0, x0, x1, dx, xs);
+    g1 += F::term(bg1, x0, x1, dx, xs);
+    u1 += F::term(bu1, x0, x1, dx, xs);
+  }
+  g0 = wave_sum_f32(g0);
+  u0 = wave_sum_f32(u0);
+  g1 = wave_sum_f32(g1);
+  u1 = wave_sum_f32(u1);
+  if (lane == 0) {
+    hv[wave * 2] = silu_mul(g0, u0, exp_tab);
+    hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);
   }
   __syncthreads();
   if (threadIdx.x < 32) {
     float v = hv[threadIdx.x];
-    float amax = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+    float amax = half_max_f32(fabsf(v));
     float dd = amax / 127.0f;
     int qi = rs_f32_as_i32(v / dd);
     signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-    int s = (int)q8;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+    int s = half_sum_i32((int)q8);
     q[blk * 32 + threadIdx.x] = q8;
     if (threadIdx.x == 0) {
       d[blk] = f2h(dd);
       isum[blk] = s;
     }
   }
-  (void)m;
 }
 __global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
                                                     const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
@@ -425,15 +409,11 @@ __global__ __launch_bounds__(256) void k_quant_q8_0_f(const float* __restrict__ 
   int blk = gid >> 5, j = gid & 31;
   bool live = blk < nblocks;
   float v = live ? x[blk * 32 + j] : 0.f;
-  float amax = fabsf(v);
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+  float amax = half_max_f32(fabsf(v));
   float dd = amax / 127.0f;
   int qi = rs_f32_as_i32(v / dd);
   signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-  int s = (int)q8;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  int s = half_sum_i32((int)q8);
   if (live) {
     q[blk * 32 + j] = q8;
     if (j == 0) {
@@ -618,7 +598,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
     k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_ffn[l]->ptr, dim, 1e-5f, adq, add, adi, nullptr);
     // gate / up + silu * mul (llama2.rs:620-630)
     if (!strict) {
-      k_gateup_q<FMT><<<hidden / 32, 256, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, hidden, dim / 32);
+      k_gateup_q<FMT><<<hidden / 32, 1024, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, dim / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden, dim, c->act_dim, 1, c->tmp));
       CH_TRY(launch_gemv_strict(dev, c->up[l], hidden, dim, c->act_dim, 1, c->tmp + hidden));

@@ -24,16 +24,12 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float* __restrict__
   int j = (int)(gid & 31);
   bool live = blk < nblocks;
   float v = live ? x[blk * 32 + j] : 0.f;
-  float amax = fabsf(v);
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+  float amax = half_max_f32(fabsf(v));  // (256-thread blocks of whole waves: all lanes converged)
   float dd = amax / 127.0f;
   float t = v / dd;
   int qi = rs_f32_as_i32(t);
   signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);  // `as i8` from i32 wraps
-  int s = (int)q8;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  int s = half_sum_i32((int)q8);
   if (live) {
     q[blk * 32 + j] = q8;
     if (j == 0) {
@@ -51,17 +47,13 @@ __global__ __launch_bounds__(256) void k_quantize_q8_1(const float* __restrict__
   int j = (int)(gid & 31);
   bool live = blk < nblocks;
   float v = live ? x[blk * 32 + j] : 0.f;
-  float amax = fabsf(v);
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 32));
+  float amax = half_max_f32(fabsf(v));
   float dd = amax / 127.0f;
   float sv = v / dd;
   // Rust f32::max / f32::min return the non-NaN operand: NaN.max(-128) = -128
   float c = fminf(fmaxf(sv, -128.0f), 127.0f);
   int qi = (int)c;  // |c| <= 128: exact truncation
-  int s = qi;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  int s = half_sum_i32(qi);
   if (live) {
     q[blk * 32 + j] = (signed char)qi;
     if (j == 0) {
