@@ -38,15 +38,33 @@ __global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int d
 // ---- rmsnorm * weight -> Q8_0 planes ------------------------------------------------------------------
 // rms_norm.rs:33-46 (ordered 32-chunk sums, serial chunk accumulation, true division), arithmetic.rs:57-66
 // (x * w), buf_q8_0.rs:87-134 (truncating quantizer).  x itself is left untouched: it is the residual.
+// One workgroup; it is pure latency, so every global load (x and the norm weight) is issued up front in one
+// batch and kept in registers (NIT values per thread); the ordered chunk sums are taken from an LDS copy.
+template <int NIT>  // cols <= NIT * 256
 __global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
                                                     int cols, float eps, signed char* __restrict__ q,
-                                                    unsigned short* __restrict__ d, int* __restrict__ isum,
-                                                    float* __restrict__ y_out /*nullable: normalized f32 copy*/) {
-  extern __shared__ float chunk_sums[];
+                                                    unsigned short* __restrict__ d, int* __restrict__ isum) {
+  extern __shared__ float lds[];  // xs[cols] | chunk_sums[cols/32]
   __shared__ float s_rms;
+  float* xs = lds;
+  float* chunk_sums = lds + cols;
   const int nchunks = cols / 32;
-  for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
-    const f32x4* p = (const f32x4*)(x + c * 32);
+  const int tid = threadIdx.x;
+  float xv[NIT], wv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int i = it * 256 + tid;
+    xv[it] = i < cols ? x[i] : 0.f;
+    wv[it] = i < cols ? w[i] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int i = it * 256 + tid;
+    if (i < cols) xs[i] = xv[it];
+  }
+  __syncthreads();
+  for (int c = tid; c < nchunks; c += 256) {
+    const f32x4* p = (const f32x4*)(xs + c * 32);
     float s = -0.0f;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -59,35 +77,37 @@ __global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x,
     chunk_sums[c] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    // chunk sums are added strictly in chunk order (rms_norm.rs:35-40).  The 64 lanes of wave 0 hold the
-    // chunk sums in registers; v_readlane feeds them one by one into a single dependent v_add chain
-    // (~5 cycles per add instead of an LDS round trip per add).  Lanes past nchunks contribute +0.0 (exact).
-    const int lane = threadIdx.x;
+  if (tid < 64) {
+    // chunk sums are added strictly in chunk order (rms_norm.rs:35-40): wave 0 holds them in registers and
+    // v_readlane feeds a single dependent v_add chain.  Lanes past nchunks contribute +0.0 (exact).
     float sum = 0.0f;
     for (int base = 0; base < nchunks; base += 64) {
-      float v = base + lane < nchunks ? chunk_sums[base + lane] : 0.0f;
+      float v = base + tid < nchunks ? chunk_sums[base + tid] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < 64; i++) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+      for (int i = 0; i < 64; i++) sum += rl_f(v, i);
     }
-    if (lane == 0) s_rms = sqrtf(sum / (float)cols + eps);
+    if (tid == 0) s_rms = sqrtf(sum / (float)cols + eps);
   }
   __syncthreads();
   const float rms = s_rms;
-  const int j = threadIdx.x & 31;
-  for (int blk = threadIdx.x >> 5; blk < nchunks; blk += blockDim.x >> 5) {
-    int i = blk * 32 + j;
-    float v = (x[i] / rms) * w[i];
-    if (y_out) y_out[i] = v;
-    float amax = half_max_f32(fabsf(v));  // nchunks % 8 == 0 is not required: see the loop bound below
-    float dd = amax / 127.0f;
-    int qi = rs_f32_as_i32(v / dd);
-    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-    int s = half_sum_i32((int)q8);
-    q[i] = q8;
-    if (j == 0) {
-      d[blk] = f2h(dd);
-      isum[blk] = s;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int i = it * 256 + tid;
+    if (it * 256 < cols) {  // wave-uniform; 32-lane halves are entirely in or out of range (cols % 32 == 0)
+      bool live = i < cols;
+      float v = live ? (xv[it] / rms) * wv[it] : 0.f;
+      float amax = half_max_f32(fabsf(v));
+      float dd = amax / 127.0f;
+      int qi = rs_f32_as_i32(v / dd);
+      signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+      int s = half_sum_i32(live ? (int)q8 : 0);
+      if (live) {
+        q[i] = q8;
+        if ((tid & 31) == 0) {
+          d[i >> 5] = f2h(dd);
+          isum[i >> 5] = s;
+        }
+      }
     }
   }
 }
@@ -206,13 +226,26 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
     if (KV16) {
       const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
       int i = 0;
-      for (; i + 8 <= hd; i += 8) {  // 16-byte loads; products still added in k order
+      for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
+        i32x4 kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            unsigned w = (unsigned)kv[u][j];
+            acc += qs[i + 8 * u + 2 * j] * h2f((unsigned short)(w & 0xffffu));
+            acc += qs[i + 8 * u + 2 * j + 1] * h2f((unsigned short)(w >> 16));
+          }
+      }
+      for (; i + 8 <= hd; i += 8) {
         i32x4 kv = *(const i32x4*)(kr + i);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          unsigned u = (unsigned)kv[j];
-          acc += qs[i + 2 * j] * h2f((unsigned short)(u & 0xffffu));
-          acc += qs[i + 2 * j + 1] * h2f((unsigned short)(u >> 16));
+          unsigned w = (unsigned)kv[j];
+          acc += qs[i + 2 * j] * h2f((unsigned short)(w & 0xffffu));
+          acc += qs[i + 2 * j + 1] * h2f((unsigned short)(w >> 16));
         }
       }
       for (; i < hd; i++) acc += qs[i] * h2f(kr[i]);
@@ -269,12 +302,28 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
     if (KV16) {
       const unsigned short* vr = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + n;
       unsigned short c = 0;
-      for (int t = 0; t < seq; t++) c = h_add(c, h_mul(vr[(size_t)t * hd], f2h(scores[t])));
+      int t = 0;
+      for (; t + 16 <= seq; t += 16) {  // 16 loads in flight, then the (inherently serial) f16 accumulate chain
+        unsigned short vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
+#pragma unroll
+        for (int u = 0; u < 16; u++) c = h_add(c, h_mul(vv[u], f2h(scores[t + u])));
+      }
+      for (; t < seq; t++) c = h_add(c, h_mul(vr[(size_t)t * hd], f2h(scores[t])));
       val = h2f(c);
     } else {
       const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
       float c = 0.0f;
-      for (int t = 0; t < seq; t++) c += scores[t] * vr[(size_t)t * hd];
+      int t = 0;
+      for (; t + 16 <= seq; t += 16) {
+        float vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
+#pragma unroll
+        for (int u = 0; u < 16; u++) c += scores[t + u] * vv[u];
+      }
+      for (; t < seq; t++) c += scores[t] * vr[(size_t)t * hd];
       val = c;
     }
     out[head * hd + n] = val;
@@ -557,7 +606,13 @@ int enqueue_step_t(crabml_hip_llama* c) {
   signed char* ahq = (signed char*)c->act_hid;
   unsigned short* ahd = (unsigned short*)(c->act_hid + alh.off_d);
   int* ahi = (int*)(c->act_hid + alh.off_aux);
-  const size_t norm_lds = (size_t)(dim / 32) * sizeof(float);
+  const size_t norm_lds = (size_t)(dim + dim / 32) * sizeof(float);
+  auto norm_quant = [&](const float* wn, float eps) {
+    if (dim <= 4096)
+      k_norm_quant<16><<<1, 256, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
+    else
+      k_norm_quant<64><<<1, 256, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
+  };
   const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
   const bool attn_quant = (hd % 32) == 0;
 
@@ -565,7 +620,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
                                               c->token_embed->wl.off_scale, token_d, dim, c->x);
   for (size_t l = 0; l < g.n_layers; l++) {
     // attention rmsnorm (llama2.rs:230-234)
-    k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_att[l]->ptr, dim, g.rms_norm_eps, adq, add, adi, nullptr);
+    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);
     // q, k, v + rope + scale + KV append (llama2.rs:244-256, 542-554, 561-565)
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
@@ -595,7 +650,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
       k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
     }
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
-    k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_ffn[l]->ptr, dim, 1e-5f, adq, add, adi, nullptr);
+    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f);
     // gate / up + silu * mul (llama2.rs:620-630)
     if (!strict) {
       k_gateup_q<FMT><<<hidden / 32, 1024, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, dim / 32);
@@ -614,7 +669,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
     }
   }
   // final rmsnorm + classifier (llama2.rs:274-278, 199-208)
-  k_norm_quant<<<1, 256, norm_lds, st>>>(c->x, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, adq, add, adi, nullptr);
+  norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps);
   if (!strict)
     CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
   else
@@ -654,6 +709,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   if (!w->token_embed || !w->rms_final_weight || !w->wq || !w->wk || !w->wv || !w->wo || !w->ffn_gate_weight ||
       !w->ffn_down_weight || !w->ffn_up_weight || !w->rms_att_weight || !w->rms_ffn_weight)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: missing weights");
+  if (g.embedding_dim > 12288)  // k_norm_quant keeps the row in 64 KiB of LDS
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: embedding_dim %zu > 12288", g.embedding_dim);
   if ((g.seq_len + hd) * sizeof(float) > 64 * 1024)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: seq_len %zu needs more than 64 KiB of LDS for the score row", g.seq_len);
   const crabml_hip_buf* outw = w->output_weight ? w->output_weight : w->token_embed;
