@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int d
 // ---- rmsnorm * weight -> Q8_0 planes ------------------------------------------------------------------
 // rms_norm.rs:33-46 (ordered 32-chunk sums, serial chunk accumulation, true division), arithmetic.rs:57-66
 // (x * w), buf_q8_0.rs:87-134 (truncating quantizer).  x itself is left untouched: it is the residual.
-// One workgroup; it is pure latency, so every global load (x and the norm weight) is issued up front in one
+// One 1024-thread workgroup (16 waves: 4 per SIMD, so the two IEEE divisions per element overlap across
+// waves); it is pure latency, so every global load (x and the norm weight) is issued up front in one
 // batch and kept in registers (NIT values per thread); the ordered chunk sums are taken from an LDS copy.
-template <int NIT>  // cols <= NIT * 256
-__global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
+template <int NIT>  // cols <= NIT * 1024
+__global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
                                                     int cols, float eps, signed char* __restrict__ q,
                                                     unsigned short* __restrict__ d, int* __restrict__ isum) {
   extern __shared__ float lds[];  // xs[cols] | chunk_sums[cols/32]
@@ -53,17 +54,17 @@ __global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x,
   float xv[NIT], wv[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    int i = it * 256 + tid;
+    int i = it * 1024 + tid;
     xv[it] = i < cols ? x[i] : 0.f;
     wv[it] = i < cols ? w[i] : 0.f;
   }
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    int i = it * 256 + tid;
+    int i = it * 1024 + tid;
     if (i < cols) xs[i] = xv[it];
   }
   __syncthreads();
-  for (int c = tid; c < nchunks; c += 256) {
+  for (int c = tid; c < nchunks; c += 1024) {
     const f32x4* p = (const f32x4*)(xs + c * 32);
     float s = -0.0f;
 #pragma unroll
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(256) void k_norm_quant(const float* __restrict__ x,
   const float rms = s_rms;
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    int i = it * 256 + tid;
-    if (it * 256 < cols) {  // wave-uniform; 32-lane halves are entirely in or out of range (cols % 32 == 0)
+    int i = it * 1024 + tid;
+    if (it * 1024 < cols) {  // wave-uniform; 32-lane halves are entirely in or out of range (cols % 32 == 0)
       bool live = i < cols;
       float v = live ? (xv[it] / rms) * wv[it] : 0.f;
       float amax = half_max_f32(fabsf(v));
@@ -609,9 +610,9 @@ int enqueue_step_t(crabml_hip_llama* c) {
   const size_t norm_lds = (size_t)(dim + dim / 32) * sizeof(float);
   auto norm_quant = [&](const float* wn, float eps) {
     if (dim <= 4096)
-      k_norm_quant<16><<<1, 256, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
+      k_norm_quant<4><<<1, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
     else
-      k_norm_quant<64><<<1, 256, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
+      k_norm_quant<12><<<1, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
   };
   const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
   const bool attn_quant = (hd % 32) == 0;
