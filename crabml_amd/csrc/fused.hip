@@ -27,6 +27,36 @@ __device__ __forceinline__ float exp_cached_f(float x, const unsigned short* __r
   return h2f(table[f2h(x)]);
 }
 
+// ---- weight prefetch into the Infinity Cache ---------------------------------------------------------
+// The norm+quantize and attention stages are latency-bound single-/few-workgroup kernels: HBM idles for
+// ~6-8 us while they run.  Spare workgroups of those launches (one per otherwise idle CU) stream the NEXT
+// GEMV's weights with plain loads and drop them: the lines land in the 256 MiB memory-side Infinity Cache,
+// so the following HBM-bound GEMV starts on warm data.  Pure performance hint: no result depends on it.
+struct PrefetchPlan {
+  const void* p[3];
+  unsigned long long n[3];  // bytes (multiples of 16)
+  int* sink;
+};
+__device__ __forceinline__ void prefetch_wg(const PrefetchPlan& pf, int wg, int nwg) {
+  int acc = 0;
+#pragma unroll 1
+  for (int sp = 0; sp < 3; sp++) {
+    const i32x4* base = (const i32x4*)pf.p[sp];
+    const size_t n16 = pf.n[sp] / 16;
+    if (!base || n16 == 0) continue;
+    const size_t per = (n16 + nwg - 1) / nwg;
+    const size_t lo = (size_t)wg * per, hi = lo + per < n16 ? lo + per : n16;
+    size_t i = lo + threadIdx.x;
+    const size_t st = blockDim.x;
+    for (; i + 3 * st < hi; i += 4 * st) {
+      i32x4 a = base[i], b = base[i + st], c = base[i + 2 * st], d = base[i + 3 * st];
+      acc ^= a[0] ^ b[1] ^ c[2] ^ d[3];
+    }
+    for (; i < hi; i += st) acc ^= base[i][0];
+  }
+  if (acc == 0x7eadbeef) *pf.sink = acc;  // never true in practice; keeps the loads alive
+}
+
 // ---- embedding lookup: copy_rows_from(token_embed, [token]) (llama2.rs:222-223) ----------------------
 __global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int dtype, size_t off_scale,
                                                const int* __restrict__ token_d, int dim, float* __restrict__ x) {
@@ -44,7 +74,12 @@ __global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int d
 template <int NIT>  // cols <= NIT * 1024
 __global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
                                                     int cols, float eps, signed char* __restrict__ q,
-                                                    unsigned short* __restrict__ d, int* __restrict__ isum) {
+                                                    unsigned short* __restrict__ d, int* __restrict__ isum,
+                                                    PrefetchPlan pf) {
+  if (blockIdx.x > 0) {  // spare workgroups: warm the Infinity Cache with the next GEMV's weights
+    prefetch_wg(pf, blockIdx.x - 1, gridDim.x - 1);
+    return;
+  }
   extern __shared__ float lds[];  // xs[cols] | chunk_sums[cols/32]
   __shared__ float s_rms;
   float* xs = lds;
@@ -206,7 +241,12 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
                                               const void* __restrict__ vc, const int* __restrict__ pos_d,
                                               const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
                                               signed char* __restrict__ xq, unsigned short* __restrict__ xd,
-                                              int* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap) {
+                                              int* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap,
+                                              PrefetchPlan pf) {
+  if ((int)blockIdx.x >= n_heads) {
+    prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
+    return;
+  }
   extern __shared__ float lds[];
   __shared__ float s_red[4];
   __shared__ float s_val;
@@ -608,11 +648,23 @@ int enqueue_step_t(crabml_hip_llama* c) {
   unsigned short* ahd = (unsigned short*)(c->act_hid + alh.off_d);
   int* ahi = (int*)(c->act_hid + alh.off_aux);
   const size_t norm_lds = (size_t)(dim + dim / 32) * sizeof(float);
-  auto norm_quant = [&](const float* wn, float eps) {
+  const bool do_pf = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_PREFETCH);
+  auto plan = [&](const crabml_hip_buf* a, const crabml_hip_buf* b, const crabml_hip_buf* cc) {
+    PrefetchPlan pf{};
+    const crabml_hip_buf* v[3] = {a, b, cc};
+    for (int i = 0; i < 3; i++) {
+      pf.p[i] = do_pf && v[i] ? v[i]->ptr : nullptr;
+      pf.n[i] = do_pf && v[i] ? (v[i]->wl.total / 16) * 16 : 0;
+    }
+    pf.sink = c->state + 3;
+    return pf;
+  };
+  const int spare = do_pf ? (dev->n_cu > 1 ? dev->n_cu - 1 : 0) : 0;
+  auto norm_quant = [&](const float* wn, float eps, const PrefetchPlan& pf) {
     if (dim <= 4096)
-      k_norm_quant<4><<<1, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
+      k_norm_quant<4><<<1 + spare, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi, pf);
     else
-      k_norm_quant<12><<<1, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi);
+      k_norm_quant<12><<<1 + spare, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi, pf);
   };
   const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
   const bool attn_quant = (hd % 32) == 0;
@@ -621,7 +673,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
                                               c->token_embed->wl.off_scale, token_d, dim, c->x);
   for (size_t l = 0; l < g.n_layers; l++) {
     // attention rmsnorm (llama2.rs:230-234)
-    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);
+    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, plan(c->wq[l], c->wk[l], c->wv[l]));
     // q, k, v + rope + scale + KV append (llama2.rs:244-256, 542-554, 561-565)
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
@@ -635,13 +687,15 @@ int enqueue_step_t(crabml_hip_llama* c) {
       CH_TRY(launch_gemv_strict(dev, c->wv[l], kv_dim, dim, c->act_dim, 1, c->tmp + dim + kv_dim));
       k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
     }
-    // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]
+    // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo + ffn_gate
+    const PrefetchPlan attn_pf = plan(c->wo[l], c->gate[l], nullptr);
+    const int attn_spare = do_pf && dev->n_cu > n_heads ? dev->n_cu - n_heads : 0;
     if (kv16)
-      k_attn<true><<<n_heads, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
-                                                   attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap);
+      k_attn<true><<<n_heads + attn_spare, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
+                                                   attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap, attn_pf);
     else
-      k_attn<false><<<n_heads, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
-                                                    attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap);
+      k_attn<false><<<n_heads + attn_spare, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
+                                                    attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap, attn_pf);
     if (!attn_quant) k_quant_q8_0_f<<<(dim + 255) / 256, 256, 0, st>>>(c->attn, adq, add, adi, dim / 32);
     // wo + residual (llama2.rs:600, 266)
     if (!strict) {
@@ -651,7 +705,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
       k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
     }
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
-    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f);
+    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, plan(c->up[l], nullptr, nullptr));
     // gate / up + silu * mul (llama2.rs:620-630)
     if (!strict) {
       k_gateup_q<FMT><<<hidden / 32, 1024, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, dim / 32);
@@ -670,7 +724,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
     }
   }
   // final rmsnorm + classifier (llama2.rs:274-278, 199-208)
-  norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps);
+  norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, plan(nullptr, nullptr, nullptr));
   if (!strict)
     CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
   else
@@ -786,7 +840,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   A(act_layout(CRABML_HIP_Q8_0, g.embedding_dim).total, (void**)&c->act_dim);
   A(act_layout(CRABML_HIP_Q8_0, g.hidden_dim).total, (void**)&c->act_hid);
   A(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2 * 4, (void**)&c->rope);
-  A(3 * sizeof(int), (void**)&c->state);
+  A(4 * sizeof(int), (void**)&c->state);
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);
@@ -809,7 +863,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       }
     }
     hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 3 * sizeof(int), dev->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 4 * sizeof(int), dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) {
       crabml_hip_llama_destroy(c);

@@ -217,13 +217,13 @@ PYBIND11_MODULE(_host, m) {
 
   py::class_<HipLlamaRunner>(m, "HipLlamaRunner")
       .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,
-                       size_t seq_len, bool use_f16_kv_cache, bool use_graph) {
-             auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph);
+                       size_t seq_len, bool use_f16_kv_cache, bool use_graph, bool prefetch) {
+             auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph, prefetch);
              r->set_seq_cap(seq_len);
              return r;
            }),
            py::arg("conf"), py::arg("weights"), py::arg("device"), py::arg("seq_len"), py::arg("use_f16_kv_cache"),
-           py::arg("use_graph") = true)
+           py::arg("use_graph") = true, py::arg("prefetch") = true)
       .def("kv_cache_len", &HipLlamaRunner::kv_cache_len)
       .def("reset", &HipLlamaRunner::reset)
       .def("forward",
