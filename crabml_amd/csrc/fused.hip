@@ -68,22 +68,20 @@ __global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int d
 // ---- rmsnorm * weight -> Q8_0 planes ------------------------------------------------------------------
 // rms_norm.rs:33-46 (ordered 32-chunk sums, serial chunk accumulation, true division), arithmetic.rs:57-66
 // (x * w), buf_q8_0.rs:87-134 (truncating quantizer).  x itself is left untouched: it is the residual.
-// One 1024-thread workgroup (16 waves: 4 per SIMD, so the two IEEE divisions per element overlap across
-// waves); it is pure latency, so every global load (x and the norm weight) is issued up front in one
-// batch and kept in registers (NIT values per thread); the ordered chunk sums are taken from an LDS copy.
-template <int NIT>  // cols <= NIT * 1024
-__global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
-                                                    int cols, float eps, signed char* __restrict__ q,
-                                                    unsigned short* __restrict__ d, int* __restrict__ isum,
-                                                    PrefetchPlan pf) {
-  if (blockIdx.x > 0) {  // spare workgroups: warm the Infinity Cache with the next GEMV's weights
-    prefetch_wg(pf, blockIdx.x - 1, gridDim.x - 1);
-    return;
-  }
-  extern __shared__ float lds[];  // xs[cols] | chunk_sums[cols/32]
-  __shared__ float s_rms;
-  float* xs = lds;
-  float* chunk_sums = lds + cols;
+// Executed by ONE 1024-thread workgroup (16 waves: 4 per SIMD, so the two IEEE divisions per element
+// overlap across waves).  It is pure latency, so every global load (x and the norm weight) is issued up
+// front in one batch and kept in registers (NIT values per thread); the ordered chunk sums are taken from
+// an LDS copy.  Outputs (q / d / isum) may live in LDS (GEMV prologue) or in global memory.
+struct NormLds {  // carved from dynamic LDS: xs[cols] f32 | chunk_sums[cols/32] f32
+  float* xs;
+  float* chunk_sums;
+};
+__host__ __device__ inline size_t norm_lds_bytes(int cols) { return (size_t)(cols + cols / 32) * sizeof(float); }
+
+template <int NIT>  // cols <= NIT * 1024, blockDim.x == 1024; ends with the outputs written (no trailing barrier)
+__device__ __forceinline__ void norm_quant_block(const float* __restrict__ x, const float* __restrict__ w, int cols,
+                                                 float eps, NormLds L, float* s_rms, signed char* q,
+                                                 unsigned short* d, int* isum) {
   const int nchunks = cols / 32;
   const int tid = threadIdx.x;
   float xv[NIT], wv[NIT];
@@ -96,11 +94,11 @@ __global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     int i = it * 1024 + tid;
-    if (i < cols) xs[i] = xv[it];
+    if (i < cols) L.xs[i] = xv[it];
   }
   __syncthreads();
   for (int c = tid; c < nchunks; c += 1024) {
-    const f32x4* p = (const f32x4*)(xs + c * 32);
+    const f32x4* p = (const f32x4*)(L.xs + c * 32);
     float s = -0.0f;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x
       s += t[2] * t[2];
       s += t[3] * t[3];
     }
-    chunk_sums[c] = s;
+    L.chunk_sums[c] = s;
   }
   __syncthreads();
   if (tid < 64) {
@@ -118,14 +116,14 @@ __global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x
     // v_readlane feeds a single dependent v_add chain.  Lanes past nchunks contribute +0.0 (exact).
     float sum = 0.0f;
     for (int base = 0; base < nchunks; base += 64) {
-      float v = base + tid < nchunks ? chunk_sums[base + tid] : 0.0f;
+      float v = base + tid < nchunks ? L.chunk_sums[base + tid] : 0.0f;
 #pragma unroll
       for (int i = 0; i < 64; i++) sum += rl_f(v, i);
     }
-    if (tid == 0) s_rms = sqrtf(sum / (float)cols + eps);
+    if (tid == 0) *s_rms = sqrtf(sum / (float)cols + eps);
   }
   __syncthreads();
-  const float rms = s_rms;
+  const float rms = *s_rms;
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     int i = it * 1024 + tid;
@@ -146,6 +144,49 @@ __global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x
       }
     }
   }
+}
+
+template <int NIT>
+__global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
+                                                    int cols, float eps, signed char* __restrict__ q,
+                                                    unsigned short* __restrict__ d, int* __restrict__ isum,
+                                                    PrefetchPlan pf) {
+  if (blockIdx.x > 0) {  // spare workgroups: warm the Infinity Cache with the next GEMV's weights
+    prefetch_wg(pf, blockIdx.x - 1, gridDim.x - 1);
+    return;
+  }
+  extern __shared__ float lds[];
+  __shared__ float s_rms;
+  NormLds L{lds, lds + cols};
+  norm_quant_block<NIT>(x, w, cols, eps, L, &s_rms, q, d, isum);
+}
+
+// LDS image of a quantized activation vector for the GEMV-with-norm-prologue kernels:
+//   [ NormLds scratch ][ q[cols] i8 ][ d[cols/32] f16 ][ isum[cols/32] i32 ]   (each part 16-byte aligned)
+struct ActLds {
+  NormLds nl;
+  signed char* q;
+  unsigned short* d;
+  int* isum;
+};
+__host__ __device__ inline size_t act_lds_bytes(int cols) {
+  size_t n = (norm_lds_bytes(cols) + 15) / 16 * 16;
+  n += ((size_t)cols + 15) / 16 * 16;
+  n += ((size_t)(cols / 32) * 2 + 15) / 16 * 16;
+  n += ((size_t)(cols / 32) * 4 + 15) / 16 * 16;
+  return n;
+}
+__device__ __forceinline__ ActLds act_lds_carve(char* base, int cols) {
+  ActLds a;
+  a.nl.xs = (float*)base;
+  a.nl.chunk_sums = a.nl.xs + cols;
+  size_t o = (norm_lds_bytes(cols) + 15) / 16 * 16;
+  a.q = (signed char*)(base + o);
+  o += ((size_t)cols + 15) / 16 * 16;
+  a.d = (unsigned short*)(base + o);
+  o += ((size_t)(cols / 32) * 2 + 15) / 16 * 16;
+  a.isum = (int*)(base + o);
+  return a;
 }
 
 // ---- QKV epilogue: rope (rope.rs:47-63) + q scale (llama2.rs:565) + KV append (concatenate.rs:172-204) ---
@@ -223,6 +264,67 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, Ac
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
   if (lane == 0) qkv_epilogue(e, row0, s0, s1);
 }
+// Same QKV stage with the attention RMSNorm folded in as a prologue: 1024-thread workgroups (32 rows each);
+// every wave first issues its weight loads, then the workgroup normalises + quantizes x into LDS
+// (norm_quant_block, bit-identical to k_norm_quant) while those loads are in flight.  Removes the separate
+// single-workgroup norm launch (a ~6 us dependent stage) from the layer.
+template <int FMT, int NIT>
+__global__ __launch_bounds__(1024) void k_qkv_n(Planes wq, Planes wk, Planes wv, const float* __restrict__ x,
+                                                const float* __restrict__ wnorm, float eps, int nb, QkvEpi e) {
+  using F = BlockFmt<FMT>;
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  __shared__ float s_rms;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * 2;
+  const int total = e.dim + 2 * e.kv_dim;
+  const bool active = row0 < total;
+  Planes w = wq;
+  int local = 0, m = e.dim;
+  if (active) {
+    if (row0 < e.dim) {
+      local = row0;
+    } else if (row0 < e.dim + e.kv_dim) {
+      w = wk; local = row0 - e.dim; m = e.kv_dim;
+    } else {
+      w = wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
+    }
+  }
+  // 1. weight loads for the first column chunk go out before anything else
+  typename F::Blk b0, b1;
+  const bool has0 = active && lane < nb;
+  if (has0) {
+    b0 = F::load(w.q, w.d, (size_t)local * nb + lane);
+    b1 = F::load(w.q, w.d, (size_t)(local + 1) * nb + lane);
+  }
+  // 2. norm + quantize into LDS (all 1024 threads)
+  ActLds A = act_lds_carve(lds_raw, e.dim);
+  norm_quant_block<NIT>(x, wnorm, e.dim, eps, A.nl, &s_rms, A.q, A.d, A.isum);
+  __syncthreads();
+  if (!active) return;
+  const i32x4* xq = (const i32x4*)A.q;
+  float a0 = 0.f, a1 = 0.f;
+  if (has0) {
+    i32x4 x0 = xq[2 * lane], x1 = xq[2 * lane + 1];
+    float dx = h2f(A.d[lane]);
+    int xs = A.isum[lane];
+    a0 += F::term(b0, x0, x1, dx, xs);
+    a1 += F::term(b1, x0, x1, dx, xs);
+  }
+  for (int b = lane + 64; b < nb; b += 64) {
+    typename F::Blk c0 = F::load(w.q, w.d, (size_t)local * nb + b);
+    typename F::Blk c1 = F::load(w.q, w.d, (size_t)(local + 1) * nb + b);
+    i32x4 x0 = xq[2 * b], x1 = xq[2 * b + 1];
+    float dx = h2f(A.d[b]);
+    int xs = A.isum[b];
+    a0 += F::term(c0, x0, x1, dx, xs);
+    a1 += F::term(c1, x0, x1, dx, xs);
+  }
+  float s0 = wave_sum_f32(a0), s1 = wave_sum_f32(a1);
+  if (lane == 0) qkv_epilogue(e, row0, s0, s1);
+  (void)m;
+}
+
 // strict mode: the three GEMVs ran in scalar order into tmp[dim + 2 kv_dim]; apply the same epilogue
 __global__ __launch_bounds__(256) void k_qkv_epi(const float* __restrict__ tmp, QkvEpi e) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,6 +588,81 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, ActQ8_0
     }
   }
 }
+// gate/up + SiLU*mul + quantize, with the FFN RMSNorm (eps = 1e-5, llama2.rs:611) folded in as a prologue
+// (see k_qkv_n): the layer's second single-workgroup norm launch disappears as well.
+template <int FMT, int NIT>
+__global__ __launch_bounds__(1024) void k_gateup_nq(Planes wg, Planes wu, const float* __restrict__ x,
+                                                    const float* __restrict__ wnorm, float eps, int dim,
+                                                    const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
+                                                    unsigned short* __restrict__ d, int* __restrict__ isum, int nb) {
+  using F = BlockFmt<FMT>;
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  __shared__ float s_rms;
+  __shared__ float hv[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int row = blk * 32 + wave * 2;  // rows row, row+1
+  typename F::Blk bg0, bu0, bg1, bu1;
+  const bool has0 = lane < nb;
+  if (has0) {
+    size_t i0 = (size_t)row * nb + lane, i1 = i0 + nb;
+    bg0 = F::load(wg.q, wg.d, i0);
+    bu0 = F::load(wu.q, wu.d, i0);
+    bg1 = F::load(wg.q, wg.d, i1);
+    bu1 = F::load(wu.q, wu.d, i1);
+  }
+  ActLds A = act_lds_carve(lds_raw, dim);
+  norm_quant_block<NIT>(x, wnorm, dim, eps, A.nl, &s_rms, A.q, A.d, A.isum);
+  __syncthreads();
+  const i32x4* xq = (const i32x4*)A.q;
+  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+  if (has0) {
+    i32x4 x0 = xq[2 * lane], x1 = xq[2 * lane + 1];
+    float dx = h2f(A.d[lane]);
+    int xs = A.isum[lane];
+    g0 += F::term(bg0, x0, x1, dx, xs);
+    u0 += F::term(bu0, x0, x1, dx, xs);
+    g1 += F::term(bg1, x0, x1, dx, xs);
+    u1 += F::term(bu1, x0, x1, dx, xs);
+  }
+  for (int b = lane + 64; b < nb; b += 64) {
+    size_t i0 = (size_t)row * nb + b, i1 = i0 + nb;
+    typename F::Blk cg0 = F::load(wg.q, wg.d, i0);
+    typename F::Blk cu0 = F::load(wu.q, wu.d, i0);
+    typename F::Blk cg1 = F::load(wg.q, wg.d, i1);
+    typename F::Blk cu1 = F::load(wu.q, wu.d, i1);
+    i32x4 x0 = xq[2 * b], x1 = xq[2 * b + 1];
+    float dx = h2f(A.d[b]);
+    int xs = A.isum[b];
+    g0 += F::term(cg0, x0, x1, dx, xs);
+    u0 += F::term(cu0, x0, x1, dx, xs);
+    g1 += F::term(cg1, x0, x1, dx, xs);
+    u1 += F::term(cu1, x0, x1, dx, xs);
+  }
+  g0 = wave_sum_f32(g0);
+  u0 = wave_sum_f32(u0);
+  g1 = wave_sum_f32(g1);
+  u1 = wave_sum_f32(u1);
+  if (lane == 0) {
+    hv[wave * 2] = silu_mul(g0, u0, exp_tab);
+    hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float v = hv[threadIdx.x];
+    float amax = half_max_f32(fabsf(v));
+    float dd = amax / 127.0f;
+    int qi = rs_f32_as_i32(v / dd);
+    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+    int s = half_sum_i32((int)q8);
+    q[blk * 32 + threadIdx.x] = q8;
+    if (threadIdx.x == 0) {
+      d[blk] = f2h(dd);
+      isum[blk] = s;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
                                                     const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -647,7 +824,9 @@ int enqueue_step_t(crabml_hip_llama* c) {
   signed char* ahq = (signed char*)c->act_hid;
   unsigned short* ahd = (unsigned short*)(c->act_hid + alh.off_d);
   int* ahi = (int*)(c->act_hid + alh.off_aux);
-  const size_t norm_lds = (size_t)(dim + dim / 32) * sizeof(float);
+  const size_t norm_lds = norm_lds_bytes(dim);
+  const size_t act_lds = act_lds_bytes(dim);
+  const bool fuse_norm = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_FUSION) && act_lds <= 60 * 1024;
   const bool do_pf = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_PREFETCH);
   auto plan = [&](const crabml_hip_buf* a, const crabml_hip_buf* b, const crabml_hip_buf* cc) {
     PrefetchPlan pf{};
@@ -672,13 +851,21 @@ int enqueue_step_t(crabml_hip_llama* c) {
   k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
                                               c->token_embed->wl.off_scale, token_d, dim, c->x);
   for (size_t l = 0; l < g.n_layers; l++) {
-    // attention rmsnorm (llama2.rs:230-234)
-    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, plan(c->wq[l], c->wk[l], c->wv[l]));
+    // attention rmsnorm (llama2.rs:230-234): its own launch, or folded into the QKV stage
+    if (!fuse_norm) norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, plan(c->wq[l], c->wk[l], c->wv[l]));
     // q, k, v + rope + scale + KV append (llama2.rs:244-256, 542-554, 561-565)
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim + 2 * kv_dim;
-    if (!strict) {
+    if (fuse_norm) {
+      const int wgs = (total_rows / 2 + 15) / 16;
+      if (dim <= 4096)
+        k_qkv_n<FMT, 4><<<wgs, 1024, act_lds, st>>>(planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), c->x,
+                                                    (const float*)c->rms_att[l]->ptr, g.rms_norm_eps, dim / 32, e);
+      else
+        k_qkv_n<FMT, 12><<<wgs, 1024, act_lds, st>>>(planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), c->x,
+                                                     (const float*)c->rms_att[l]->ptr, g.rms_norm_eps, dim / 32, e);
+    } else if (!strict) {
       int waves = total_rows / 2;
       k_qkv<FMT><<<(waves + 1) / 2, 128, 0, st>>>(planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), ad, dim / 32, e);
     } else {
@@ -688,7 +875,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
       k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
     }
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo + ffn_gate
-    const PrefetchPlan attn_pf = plan(c->wo[l], c->gate[l], nullptr);
+    const PrefetchPlan attn_pf = plan(c->wo[l], nullptr, nullptr);
     const int attn_spare = do_pf && dev->n_cu > n_heads ? dev->n_cu - n_heads : 0;
     if (kv16)
       k_attn<true><<<n_heads + attn_spare, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
@@ -704,10 +891,17 @@ int enqueue_step_t(crabml_hip_llama* c) {
       CH_TRY(launch_gemv_strict(dev, c->wo[l], dim, dim, c->act_dim, 1, c->tmp));
       k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
     }
-    // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
-    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, plan(c->up[l], nullptr, nullptr));
+    // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611): its own launch, or folded into the gate/up stage
+    if (!fuse_norm) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, plan(nullptr, nullptr, nullptr));
     // gate / up + silu * mul (llama2.rs:620-630)
-    if (!strict) {
+    if (fuse_norm) {
+      if (dim <= 4096)
+        k_gateup_nq<FMT, 4><<<hidden / 32, 1024, act_lds, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), c->x,
+                                                                (const float*)c->rms_ffn[l]->ptr, 1e-5f, dim, dev->exp_table, ahq, ahd, ahi, dim / 32);
+      else
+        k_gateup_nq<FMT, 12><<<hidden / 32, 1024, act_lds, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), c->x,
+                                                                 (const float*)c->rms_ffn[l]->ptr, 1e-5f, dim, dev->exp_table, ahq, ahd, ahi, dim / 32);
+    } else if (!strict) {
       k_gateup_q<FMT><<<hidden / 32, 1024, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, dim / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden, dim, c->act_dim, 1, c->tmp));

@@ -217,13 +217,13 @@ PYBIND11_MODULE(_host, m) {
 
   py::class_<HipLlamaRunner>(m, "HipLlamaRunner")
       .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,
-                       size_t seq_len, bool use_f16_kv_cache, bool use_graph, bool prefetch) {
-             auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph, prefetch);
+                       size_t seq_len, bool use_f16_kv_cache, bool use_graph, bool prefetch, bool fuse_norm) {
+             auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph, prefetch, fuse_norm);
              r->set_seq_cap(seq_len);
              return r;
            }),
            py::arg("conf"), py::arg("weights"), py::arg("device"), py::arg("seq_len"), py::arg("use_f16_kv_cache"),
-           py::arg("use_graph") = true, py::arg("prefetch") = true)
+           py::arg("use_graph") = true, py::arg("prefetch") = true, py::arg("fuse_norm") = true)
       .def("kv_cache_len", &HipLlamaRunner::kv_cache_len)
       .def("reset", &HipLlamaRunner::reset)
       .def("forward",
