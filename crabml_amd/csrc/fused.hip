@@ -826,7 +826,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
   int* ahi = (int*)(c->act_hid + alh.off_aux);
   const size_t norm_lds = norm_lds_bytes(dim);
   const size_t act_lds = act_lds_bytes(dim);
-  const bool fuse_norm = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_FUSION) && act_lds <= 60 * 1024;
+  const bool fuse_norm = !strict && (g.flags & CRABML_HIP_LLAMA_NORM_FUSION) && act_lds <= 60 * 1024;
   const bool do_pf = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_PREFETCH);
   auto plan = [&](const crabml_hip_buf* a, const crabml_hip_buf* b, const crabml_hip_buf* cc) {
     PrefetchPlan pf{};

@@ -14,7 +14,7 @@ namespace crabml_host {
 class HipLlamaRunner {
  public:
   HipLlamaRunner(const LlamaConfig& conf, std::shared_ptr<LlamaWeights<HipTensor>> w, HipTensorDeviceRef device,
-                 size_t seq_len, bool use_f16_kv_cache, bool use_graph = true, bool prefetch = true, bool fuse_norm = true)
+                 size_t seq_len, bool use_f16_kv_cache, bool use_graph = true, bool prefetch = true, bool fuse_norm = false)
       : conf_(conf), weights_(std::move(w)), device_(std::move(device)) {
     crabml_hip_llama_config_t c{};
     c.embedding_dim = conf.embedding_dim;
@@ -28,7 +28,7 @@ class HipLlamaRunner {
     c.rms_norm_eps = conf.rms_norm_eps;
     c.use_f16_kv_cache = use_f16_kv_cache ? 1 : 0;
     c.flags = (use_graph ? 0 : CRABML_HIP_LLAMA_NO_GRAPH) | (prefetch ? 0 : CRABML_HIP_LLAMA_NO_PREFETCH) |
-              (fuse_norm ? 0 : CRABML_HIP_LLAMA_NO_NORM_FUSION);
+              (fuse_norm ? CRABML_HIP_LLAMA_NORM_FUSION : 0);
     auto raws = [](const std::vector<HipTensor>& v) {
       std::vector<const crabml_hip_buf_t*> r;
       for (const auto& t : v) r.push_back(t.raw());

@@ -223,7 +223,7 @@ PYBIND11_MODULE(_host, m) {
              return r;
            }),
            py::arg("conf"), py::arg("weights"), py::arg("device"), py::arg("seq_len"), py::arg("use_f16_kv_cache"),
-           py::arg("use_graph") = true, py::arg("prefetch") = true, py::arg("fuse_norm") = true)
+           py::arg("use_graph") = true, py::arg("prefetch") = true, py::arg("fuse_norm") = false)
       .def("kv_cache_len", &HipLlamaRunner::kv_cache_len)
       .def("reset", &HipLlamaRunner::reset)
       .def("forward",

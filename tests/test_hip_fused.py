@@ -65,7 +65,7 @@ def test_fused_fast_matches_oracle_and_trait_path(ca, shape, fmt):
     dev = ca.HipTensorDevice(0)
     conf, w = synth.to_hip(model, dev)
     fused = ca.HipLlamaRunner(conf, w, dev, 64, True)
-    unfused_norm = ca.HipLlamaRunner(conf, w, dev, 64, True, True, False, False)
+    unfused_norm = ca.HipLlamaRunner(conf, w, dev, 64, True, True, False, True)  # no prefetch, norm folded into the GEMVs
     trait = ca.Llama2Runner(conf, w, dev, 64, True)
     lf = [fused.forward(t, i).copy() for i, t in enumerate(toks)]
     lu = [unfused_norm.forward(t, i).copy() for i, t in enumerate(toks)]
