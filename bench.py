@@ -30,6 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the achievable copy rate
+# HBM bytes per GEMV launch from rocprofv3 --pmc (FETCH_SIZE x2 correction for gfx950), see profiles/; None until measured
+PMC_TRAFFIC = None
 
 
 def parse():
@@ -211,28 +213,48 @@ def main():
         dev.sync()
         trait_tps = n_t / (time.perf_counter() - tt)
 
-    # ---- instrumented pass: HIP events around every GEMV launch (same process, same weights) --------
+    # ---- instrumented pass: HIP event pairs around every GEMV-stage launch (same process, same weights) ---
+    # Events cannot live inside the captured graph, so the fused step is replayed EAGERLY (identical kernels
+    # and launch geometry) with one event pair per GEMV stage, on the backend's own stream.
     roof = None
     if rank == 0:
-        dev.prof_enable(True)
+        STAGES = {0: "matmul_vec (per-op path)", 1: "k_qkv (wq|wk|wv + rope + KV append)", 2: "k_gemv_res (wo + residual)",
+                  3: "k_gateup_q (gate|up + silu*mul + quantize)", 4: "k_gemv_res (ffn_down + residual)",
+                  5: "k_gemv (classifier)"}
         n_prof = min(args.steps, 16)
-        trait.timed_decode(1, n_prof)
-        recs = dev.prof_read()
+        if path == "fused":
+            eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch, args.norm_fusion)
+            eager.decode_greedy(1, 4)  # warm
+            dev.sync()
+            dev.prof_enable(True)
+            eager.decode_greedy(1, n_prof)
+        else:
+            dev.prof_enable(True)
+            trait.timed_decode(1, n_prof)
+        recs = [r for r in dev.prof_read() if r["dtype"] == wtype and r["kernel_ms"] > 0]
         dev.prof_enable(False)
-        rec = next((r for r in recs if r["dtype"] == wtype), None)
-        if rec and rec["kernel_ms"] > 0:
-            gbs = rec["algo_bytes"] / (rec["kernel_ms"] * 1e-3) / 1e9
+        if recs:
+            tot_b = sum(r["algo_bytes"] for r in recs)
+            tot_ms = sum(r["kernel_ms"] for r in recs)
+            launches = sum(r["launches"] for r in recs)
+            dom = max(recs, key=lambda r: r["algo_bytes"])
+            gbs = tot_b / (tot_ms * 1e-3) / 1e9
             roof = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": f"k_gemv_{args.wtype.lower()} (all GEMV launches of the decode step)",
-                "launches_per_token": rec["launches"] / n_prof,
-                "avg_launch_us": round(rec["kernel_ms"] * 1e3 / rec["launches"], 3),
-                "algo_bytes_per_launch": round(rec["algo_bytes"] / rec["launches"], 1),
-                "gemv_ms_per_token": round(rec["kernel_ms"] / n_prof, 4),
-                "method": "hipEvent pairs on the backend's stream around each matmul_vec GEMV launch of the per-op "
-                          "path, separate instrumented pass (the fused path's graph cannot carry events; its GEMV "
-                          "stages use the same mapping -- see profiles/ for rocprofv3 per-kernel durations)",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC,
+                "kernel": "all Q4_0 GEMV stages of one decode step (bytes-weighted); dominant = " + STAGES.get(dom["stage"], "?"),
+                "launches_per_token": launches / n_prof,
+                "avg_launch_us": round(tot_ms * 1e3 / launches, 3),
+                "algo_bytes_per_launch": round(tot_b / launches, 1),
+                "gemv_ms_per_token": round(tot_ms / n_prof, 4),
+                "per_stage": {STAGES.get(r["stage"], str(r["stage"])): {
+                    "launches_per_token": r["launches"] / n_prof,
+                    "avg_us": round(r["kernel_ms"] * 1e3 / r["launches"], 2),
+                    "algo_MB_per_launch": round(r["algo_bytes"] / r["launches"] / 1e6, 2),
+                    "GBps": round(r["algo_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9, 1)} for r in recs},
+                "method": "hipEvent pairs on the backend's stream around each GEMV-stage launch; fused step replayed "
+                          "eagerly (graphs cannot carry events), separate pass right after the timed region; "
+                          "rocprofv3 per-kernel durations of the same command are committed under profiles/",
             }
 
     out = None

@@ -107,6 +107,7 @@ struct crabml_hip_device {
   struct ProfRec {
     hipEvent_t e0, e1;
     uint32_t dtype;
+    uint32_t stage;  // 0 = matmul_vec (per-op path); fused stages: 1 qkv, 2 wo+res, 3 gate/up, 4 down+res, 5 classifier
     double bytes;
   };
   std::vector<ProfRec> prof_recs;
@@ -158,5 +159,8 @@ int pool_alloc(crabml_hip_device* dev, size_t bytes, void** out, size_t* cap);
 void pool_free(crabml_hip_device* dev, void* ptr, size_t cap);
 int buf_new(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes, crabml_hip_buf** out);
 inline void touch(crabml_hip_buf* b) { b->version++; }
+// measurement hook helpers (runtime.hip)
+int prof_begin(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec, uint32_t dtype, uint32_t stage, double bytes);
+int prof_end(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec);
 
 }  // namespace crabml_hip

@@ -783,6 +783,7 @@ struct crabml_hip_llama {
   size_t kv_len = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  bool capturing = false;
   std::vector<std::pair<void*, size_t>> allocs;
 };
 
@@ -827,6 +828,14 @@ int enqueue_step_t(crabml_hip_llama* c) {
   const size_t norm_lds = norm_lds_bytes(dim);
   const size_t act_lds = act_lds_bytes(dim);
   const bool fuse_norm = !strict && (g.flags & CRABML_HIP_LLAMA_NORM_FUSION) && act_lds <= 60 * 1024;
+  // measurement hook: only meaningful for eager launches (events cannot live inside the captured graph)
+  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing;
+  const double blk_b = (double)block_bytes(c->wtype) / 32.0;  // weight bytes per element
+  auto P0 = [&](crabml_hip_device::ProfRec* r, uint32_t stage, double rows, double k) {
+    return prof ? prof_begin(dev, r, c->wtype, stage, rows * k * blk_b + 4.0 * k + 4.0 * rows) : 0;
+  };
+  auto P1 = [&](crabml_hip_device::ProfRec* r) { return prof ? prof_end(dev, r) : 0; };
+  crabml_hip_device::ProfRec pr{};
   const bool do_pf = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_PREFETCH);
   auto plan = [&](const crabml_hip_buf* a, const crabml_hip_buf* b, const crabml_hip_buf* cc) {
     PrefetchPlan pf{};
@@ -857,6 +866,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim + 2 * kv_dim;
+    CH_TRY(P0(&pr, 1, total_rows, dim));
     if (fuse_norm) {
       const int wgs = (total_rows / 2 + 15) / 16;
       if (dim <= 4096)
@@ -874,6 +884,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
       CH_TRY(launch_gemv_strict(dev, c->wv[l], kv_dim, dim, c->act_dim, 1, c->tmp + dim + kv_dim));
       k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
     }
+    CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo + ffn_gate
     const PrefetchPlan attn_pf = plan(c->wo[l], nullptr, nullptr);
     const int attn_spare = do_pf && dev->n_cu > n_heads ? dev->n_cu - n_heads : 0;
@@ -885,15 +896,18 @@ int enqueue_step_t(crabml_hip_llama* c) {
                                                     attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap, attn_pf);
     if (!attn_quant) k_quant_q8_0_f<<<(dim + 255) / 256, 256, 0, st>>>(c->attn, adq, add, adi, dim / 32);
     // wo + residual (llama2.rs:600, 266)
+    CH_TRY(P0(&pr, 2, dim, dim));
     if (!strict) {
       k_gemv_res<FMT, 1><<<(dim + 1) / 2, 128, 0, st>>>(planes_of(c->wo[l]), ad, c->x, dim, dim / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->wo[l], dim, dim, c->act_dim, 1, c->tmp));
       k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
     }
+    CH_TRY(P1(&pr));
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611): its own launch, or folded into the gate/up stage
     if (!fuse_norm) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, plan(nullptr, nullptr, nullptr));
     // gate / up + silu * mul (llama2.rs:620-630)
+    CH_TRY(P0(&pr, 3, 2.0 * hidden, dim));
     if (fuse_norm) {
       if (dim <= 4096)
         k_gateup_nq<FMT, 4><<<hidden / 32, 1024, act_lds, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), c->x,
@@ -908,21 +922,26 @@ int enqueue_step_t(crabml_hip_llama* c) {
       CH_TRY(launch_gemv_strict(dev, c->up[l], hidden, dim, c->act_dim, 1, c->tmp + hidden));
       k_gateup_epi<<<(hidden + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden, dev->exp_table, c->h, hidden);
     }
+    CH_TRY(P1(&pr));
     if (strict) k_quant_q8_0_f<<<(hidden + 255) / 256, 256, 0, st>>>(c->h, ahq, ahd, ahi, hidden / 32);
     // down + residual (llama2.rs:633-636)
+    CH_TRY(P0(&pr, 4, dim, hidden));
     if (!strict) {
       k_gemv_res<FMT, 1><<<(dim + 1) / 2, 128, 0, st>>>(planes_of(c->down[l]), ah, c->x, dim, hidden / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->down[l], dim, hidden, c->act_hid, 1, c->tmp));
       k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
     }
+    CH_TRY(P1(&pr));
   }
   // final rmsnorm + classifier (llama2.rs:274-278, 199-208)
   norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, plan(nullptr, nullptr, nullptr));
+  CH_TRY(P0(&pr, 5, (double)g.vocab_size, dim));
   if (!strict)
     CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
   else
     CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
+  CH_TRY(P1(&pr));
   k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
   k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap);
   CH_HIP(dev, hipGetLastError());
@@ -1068,7 +1087,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   if (!(g.flags & CRABML_HIP_LLAMA_NO_GRAPH)) {
     hipError_t e = hipStreamBeginCapture(dev->stream, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
+      c->capturing = true;
       int erc = enqueue_step(c);
+      c->capturing = false;
       hipGraph_t graph = nullptr;
       hipError_t e2 = hipStreamEndCapture(dev->stream, &graph);
       if (erc == 0 && e2 == hipSuccess && graph) {

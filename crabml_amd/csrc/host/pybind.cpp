@@ -85,6 +85,7 @@ PYBIND11_MODULE(_host, m) {
              for (size_t i = 0; i < n; i++) {
                py::dict r;
                r["dtype"] = e[i].dtype;
+               r["stage"] = e[i].reserved;
                r["launches"] = e[i].launches;
                r["kernel_ms"] = e[i].kernel_ms;
                r["algo_bytes"] = e[i].algo_bytes;

@@ -162,6 +162,29 @@ static float gelu_single(float x) {  // gelu.rs:19-22
   return 0.5f * x * (1.0f + tanhf(S * x * (1.0f + COEF_A * x * x)));
 }
 
+int prof_begin(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec, uint32_t dtype, uint32_t stage, double bytes) {
+  auto get_ev = [&](hipEvent_t* e) -> hipError_t {
+    if (!dev->prof_free_events.empty()) {
+      *e = dev->prof_free_events.back();
+      dev->prof_free_events.pop_back();
+      return hipSuccess;
+    }
+    return hipEventCreate(e);
+  };
+  CH_HIP(dev, get_ev(&rec->e0));
+  CH_HIP(dev, get_ev(&rec->e1));
+  rec->dtype = dtype;
+  rec->stage = stage;
+  rec->bytes = bytes;
+  CH_HIP(dev, hipEventRecord(rec->e0, dev->stream));
+  return 0;
+}
+int prof_end(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec) {
+  CH_HIP(dev, hipEventRecord(rec->e1, dev->stream));
+  dev->prof_recs.push_back(*rec);
+  return 0;
+}
+
 // quantize rhs of matmul_vec (cached per buffer version)
 static int ensure_act(crabml_hip_device* dev, const crabml_hip_buf* x_, size_t b, size_t k, uint32_t qt,
                       const void** act) {
@@ -642,27 +665,12 @@ int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, s
   CH_TRY(buf_new(dev, CRABML_HIP_F32, b * m, b * m * 4, &o));
   o->wl = weight_layout(CRABML_HIP_F32, b * m);
   crabml_hip_device::ProfRec rec{};
-  if (dev->prof_on) {
-    auto get_ev = [&](hipEvent_t* e) -> hipError_t {
-      if (!dev->prof_free_events.empty()) {
-        *e = dev->prof_free_events.back();
-        dev->prof_free_events.pop_back();
-        return hipSuccess;
-      }
-      return hipEventCreate(e);
-    };
-    CH_HIP(dev, get_ev(&rec.e0));
-    CH_HIP(dev, get_ev(&rec.e1));
-    rec.dtype = w->dtype;
-    rec.bytes = (double)b * ((double)m * (double)(k / block_elems(w->dtype)) * (double)block_bytes(w->dtype) + 4.0 * k + 4.0 * m);
-    CH_HIP(dev, hipEventRecord(rec.e0, dev->stream));
-  }
+  if (dev->prof_on)
+    CH_TRY(prof_begin(dev, &rec, w->dtype, 0,
+                      (double)b * ((double)m * (double)(k / block_elems(w->dtype)) * (double)block_bytes(w->dtype) + 4.0 * k + 4.0 * m)));
   int rc = dev->strict_order ? launch_gemv_strict(dev, w, m, k, act, b, (float*)o->ptr)
                              : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr);
-  if (dev->prof_on) {
-    CH_HIP(dev, hipEventRecord(rec.e1, dev->stream));
-    dev->prof_recs.push_back(rec);
-  }
+  if (dev->prof_on) CH_TRY(prof_end(dev, &rec));
   if (rc != 0) {
     crabml_hip_buf_release(o);
     return rc;
@@ -764,12 +772,13 @@ int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on) {
 int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n) {
   if (!dev || !n || (!out && cap)) return CRABML_HIP_BAD_INPUT;
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
-  std::map<uint32_t, crabml_hip_prof_entry_t> agg;
+  std::map<uint64_t, crabml_hip_prof_entry_t> agg;
   for (auto& r : dev->prof_recs) {
     float ms = 0.f;
     CH_HIP(dev, hipEventElapsedTime(&ms, r.e0, r.e1));
-    auto& e = agg[r.dtype];
+    auto& e = agg[((uint64_t)r.stage << 32) | r.dtype];
     e.dtype = r.dtype;
+    e.reserved = r.stage;
     e.launches++;
     e.kernel_ms += ms;
     e.algo_bytes += r.bytes;

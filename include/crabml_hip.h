@@ -231,7 +231,7 @@ int crabml_hip_llama_debug_kv(crabml_hip_llama_t* ctx, size_t layer, int32_t whi
  * dedicated instrumented pass, not inside a throughput-timed region. */
 typedef struct crabml_hip_prof_entry {
   uint32_t dtype;        /* weight GGML type of the GEMV */
-  uint32_t reserved;
+  uint32_t reserved;     /* stage: 0 = matmul_vec; fused step (eager mode only): 1 qkv, 2 wo+res, 3 gate/up, 4 down+res, 5 classifier */
   uint64_t launches;
   double kernel_ms;      /* sum over launches of (stop - start) */
   double algo_bytes;     /* sum over launches of algorithmic bytes */
