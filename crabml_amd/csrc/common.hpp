@@ -160,6 +160,9 @@ void pool_free(crabml_hip_device* dev, void* ptr, size_t cap);
 int buf_new(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes, crabml_hip_buf** out);
 inline void touch(crabml_hip_buf* b) { b->version++; }
 // measurement hook helpers (runtime.hip)
+// prof_begin hands out an event pair; the kernel is then launched with hipExtLaunchKernelGGL(start, stop), which
+// stamps the events with the dispatch packet's own begin/end timestamps (the same clock rocprofv3 reads), and
+// prof_end files the record.
 int prof_begin(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec, uint32_t dtype, uint32_t stage, double bytes);
 int prof_end(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec);
 

@@ -829,13 +829,15 @@ int enqueue_step_t(crabml_hip_llama* c) {
   const size_t act_lds = act_lds_bytes(dim);
   const bool fuse_norm = !strict && (g.flags & CRABML_HIP_LLAMA_NORM_FUSION) && act_lds <= 60 * 1024;
   // measurement hook: only meaningful for eager launches (events cannot live inside the captured graph)
-  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing;
+  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing && !dev->strict_order &&
+                    !(g.flags & CRABML_HIP_LLAMA_NORM_FUSION);
   const double blk_b = (double)block_bytes(c->wtype) / 32.0;  // weight bytes per element
   auto P0 = [&](crabml_hip_device::ProfRec* r, uint32_t stage, double rows, double k) {
     return prof ? prof_begin(dev, r, c->wtype, stage, rows * k * blk_b + 4.0 * k + 4.0 * rows) : 0;
   };
   auto P1 = [&](crabml_hip_device::ProfRec* r) { return prof ? prof_end(dev, r) : 0; };
   crabml_hip_device::ProfRec pr{};
+  crabml_hip_device::ProfRec* R = prof ? &pr : nullptr;
   const bool do_pf = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_PREFETCH);
   auto plan = [&](const crabml_hip_buf* a, const crabml_hip_buf* b, const crabml_hip_buf* cc) {
     PrefetchPlan pf{};
@@ -877,7 +879,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
                                                      (const float*)c->rms_att[l]->ptr, g.rms_norm_eps, dim / 32, e);
     } else if (!strict) {
       int waves = total_rows / 2;
-      k_qkv<FMT><<<(waves + 1) / 2, 128, 0, st>>>(planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), ad, dim / 32, e);
+      launch_k(st, R, k_qkv<FMT>, dim3((waves + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), ad, dim / 32, e);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->wq[l], dim, dim, c->act_dim, 1, c->tmp));
       CH_TRY(launch_gemv_strict(dev, c->wk[l], kv_dim, dim, c->act_dim, 1, c->tmp + dim));
@@ -898,7 +900,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
     // wo + residual (llama2.rs:600, 266)
     CH_TRY(P0(&pr, 2, dim, dim));
     if (!strict) {
-      k_gemv_res<FMT, 1><<<(dim + 1) / 2, 128, 0, st>>>(planes_of(c->wo[l]), ad, c->x, dim, dim / 32);
+      launch_k(st, R, k_gemv_res<FMT, 1>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(c->wo[l]), ad, c->x, dim, dim / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->wo[l], dim, dim, c->act_dim, 1, c->tmp));
       k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
@@ -916,7 +918,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
         k_gateup_nq<FMT, 12><<<hidden / 32, 1024, act_lds, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), c->x,
                                                                  (const float*)c->rms_ffn[l]->ptr, 1e-5f, dim, dev->exp_table, ahq, ahd, ahi, dim / 32);
     } else if (!strict) {
-      k_gateup_q<FMT><<<hidden / 32, 1024, 0, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, dim / 32);
+      launch_k(st, R, k_gateup_q<FMT>, dim3(hidden / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, dim / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden, dim, c->act_dim, 1, c->tmp));
       CH_TRY(launch_gemv_strict(dev, c->up[l], hidden, dim, c->act_dim, 1, c->tmp + hidden));
@@ -927,7 +929,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
     // down + residual (llama2.rs:633-636)
     CH_TRY(P0(&pr, 4, dim, hidden));
     if (!strict) {
-      k_gemv_res<FMT, 1><<<(dim + 1) / 2, 128, 0, st>>>(planes_of(c->down[l]), ah, c->x, dim, hidden / 32);
+      launch_k(st, R, k_gemv_res<FMT, 1>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(c->down[l]), ah, c->x, dim, hidden / 32);
     } else {
       CH_TRY(launch_gemv_strict(dev, c->down[l], dim, hidden, c->act_hid, 1, c->tmp));
       k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
@@ -938,7 +940,7 @@ int enqueue_step_t(crabml_hip_llama* c) {
   norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, plan(nullptr, nullptr, nullptr));
   CH_TRY(P0(&pr, 5, (double)g.vocab_size, dim));
   if (!strict)
-    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
+    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits, R));
   else
     CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
   CH_TRY(P1(&pr));

@@ -272,7 +272,7 @@ static void launch_rows(hipStream_t st, int m, int n_cu, F&& f) {
 }
 
 int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size_t k_, const void* act, size_t b,
-                float* out) {
+                float* out, crabml_hip_device::ProfRec* rec0) {
   hipStream_t st = dev->stream;
   const int m = (int)m_, k = (int)k_;
   const char* wp = (const char*)w->ptr;
@@ -283,15 +283,16 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
   for (size_t bi = 0; bi < b; bi++) {
     const char* ap = (const char*)act + bi * act_stride;
     float* o = out + bi * m_;
+    crabml_hip_device::ProfRec* rec = bi == 0 ? rec0 : nullptr;
     switch (w->dtype) {
       case CRABML_HIP_Q4_0: {
         ActQ8_0 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
         const int nb = k / 32;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
-            k_gemv_q4_0<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+            launch_k(st, rec, k_gemv_q4_0<2>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
           else
-            k_gemv_q4_0<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+            launch_k(st, rec, k_gemv_q4_0<1>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
         });
         break;
       }
@@ -300,9 +301,9 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         const int nb = k / 32;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
-            k_gemv_q8_0<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+            launch_k(st, rec, k_gemv_q8_0<2>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
           else
-            k_gemv_q8_0<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
+            launch_k(st, rec, k_gemv_q8_0<1>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a, o, m, nb);
         });
         break;
       }
@@ -311,9 +312,9 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         const int nb = k / 32;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
-            k_gemv_q4_1<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned*)(wp + w->wl.off_scale), a, o, m, nb);
+            launch_k(st, rec, k_gemv_q4_1<2>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const unsigned*)(wp + w->wl.off_scale), a, o, m, nb);
           else
-            k_gemv_q4_1<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const unsigned*)(wp + w->wl.off_scale), a, o, m, nb);
+            launch_k(st, rec, k_gemv_q4_1<1>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const unsigned*)(wp + w->wl.off_scale), a, o, m, nb);
         });
         break;
       }
@@ -322,9 +323,9 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         const int nsb = k / 256;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
-            k_gemv_q4_k<2><<<grid, tpb, 0, st>>>((const unsigned char*)wp, a, o, m, nsb);
+            launch_k(st, rec, k_gemv_q4_k<2>, dim3(grid), dim3(tpb), 0, (const unsigned char*)wp, a, o, m, nsb);
           else
-            k_gemv_q4_k<1><<<grid, tpb, 0, st>>>((const unsigned char*)wp, a, o, m, nsb);
+            launch_k(st, rec, k_gemv_q4_k<1>, dim3(grid), dim3(tpb), 0, (const unsigned char*)wp, a, o, m, nsb);
         });
         break;
       }
@@ -333,20 +334,20 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         const int nsb = k / 256;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
-            k_gemv_q8_k<2><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), a, o, m, nsb);
+            launch_k(st, rec, k_gemv_q8_k<2>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const float*)(wp + w->wl.off_scale), a, o, m, nsb);
           else
-            k_gemv_q8_k<1><<<grid, tpb, 0, st>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), a, o, m, nsb);
+            launch_k(st, rec, k_gemv_q8_k<1>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const float*)(wp + w->wl.off_scale), a, o, m, nsb);
         });
         break;
       }
       case CRABML_HIP_F32: {
         int grid = (m + 3) / 4;
-        k_gemv_f32<<<grid, 256, 0, st>>>((const float*)wp, (const float*)ap, o, m, k);
+        launch_k(st, rec, k_gemv_f32, dim3(grid), dim3(256), 0, (const float*)wp, (const float*)ap, o, m, k);
         break;
       }
       case CRABML_HIP_F16: {
         int grid = (m + 3) / 4;
-        k_gemv_f16<<<grid, 256, 0, st>>>((const unsigned short*)wp, (const unsigned short*)ap, o, m, k);
+        launch_k(st, rec, k_gemv_f16, dim3(grid), dim3(256), 0, (const unsigned short*)wp, (const unsigned short*)ap, o, m, k);
         break;
       }
       default:

@@ -1,16 +1,28 @@
 // kernels.hpp -- host-side launchers of the gfx950 kernels (one per reference primitive).
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 namespace crabml_hip {
+
+// kernel launch that optionally carries a profiling event pair (hipExtLaunchKernelGGL start/stop events)
+template <typename K, typename... A>
+inline void launch_k(hipStream_t st, crabml_hip_device::ProfRec* rec, K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
+  if (rec)
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, rec->e0, rec->e1, 0, args...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, args...);
+}
 
 // ---- quantize.hip: activation quantizers (buf_q8_0.rs:87-134, buf_q8_1.rs:90-129, buf_q8_k.rs:84-131)
 void launch_quantize_act(hipStream_t st, uint32_t qtype, const float* x, size_t n, void* planes);
 
 // ---- gemv.hip: W(m,k) x quantized activations (b,k) -> out (b,m)
 // wq: weight planes; aq: activation planes (one set per batch row, stride act_layout(qtype,k).total)
+// rec != nullptr: the (first) kernel is launched with the record's event pair (measurement hook)
 int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
-                float* out);
+                float* out, crabml_hip_device::ProfRec* rec = nullptr);
 // gemv_strict.hip: same contract, block terms added in the reference's scalar order (bit-exact; slow)
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out);

@@ -176,11 +176,9 @@ int prof_begin(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec, uint32_t
   rec->dtype = dtype;
   rec->stage = stage;
   rec->bytes = bytes;
-  CH_HIP(dev, hipEventRecord(rec->e0, dev->stream));
   return 0;
 }
 int prof_end(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec) {
-  CH_HIP(dev, hipEventRecord(rec->e1, dev->stream));
   dev->prof_recs.push_back(*rec);
   return 0;
 }
@@ -669,8 +667,8 @@ int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, s
     CH_TRY(prof_begin(dev, &rec, w->dtype, 0,
                       (double)b * ((double)m * (double)(k / block_elems(w->dtype)) * (double)block_bytes(w->dtype) + 4.0 * k + 4.0 * m)));
   int rc = dev->strict_order ? launch_gemv_strict(dev, w, m, k, act, b, (float*)o->ptr)
-                             : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr);
-  if (dev->prof_on) CH_TRY(prof_end(dev, &rec));
+                             : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr, dev->prof_on ? &rec : nullptr);
+  if (dev->prof_on && !dev->strict_order) CH_TRY(prof_end(dev, &rec));
   if (rc != 0) {
     crabml_hip_buf_release(o);
     return rc;
