@@ -356,8 +356,25 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   float* qs = lds + seq_cap;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x;
-  const int seq = *pos_d + 1;
   const int kvh = KV16 ? head / (n_heads / n_kv) : head % n_kv;
+  // Position-independent loads go out first, so that their (cold, cross-XCD) latency overlaps the q staging
+  // instead of adding two more serial round trips: the first 64 halves of the K row this thread will score
+  // and the first 16 V values of the output column it will accumulate.  Rows past `seq` are read but unused.
+  i32x4 kpre[8];
+  const bool kp = KV16 && hd >= 64 && tid < seq_cap;
+  if (kp) {
+    const unsigned short* kr0 = (const unsigned short*)kc + ((size_t)kvh * seq_cap + tid) * hd;
+#pragma unroll
+    for (int u = 0; u < 8; u++) kpre[u] = *(const i32x4*)(kr0 + 8 * u);
+  }
+  unsigned short vpre[16];
+  const bool vp = KV16 && tid < hd && seq_cap >= 16;
+  if (vp) {
+    const unsigned short* vr0 = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + tid;
+#pragma unroll
+    for (int u = 0; u < 16; u++) vpre[u] = vr0[(size_t)u * hd];
+  }
+  const int seq = *pos_d + 1;
   for (int i = tid; i < hd; i += blockDim.x) {
     float v = q[head * hd + i];
     qs[i] = KV16 ? h2f(f2h(v)) : v;  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
@@ -371,8 +388,13 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
       int i = 0;
       for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
         i32x4 kv[8];
+        if (kp && t == tid && i == 0) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
+          for (int u = 0; u < 8; u++) kv[u] = kpre[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
+        }
 #pragma unroll
         for (int u = 0; u < 8; u++)
 #pragma unroll
@@ -448,8 +470,13 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
       int t = 0;
       for (; t + 16 <= seq; t += 16) {  // 16 loads in flight, then the (inherently serial) f16 accumulate chain
         unsigned short vv[16];
+        if (vp && t == 0) {
 #pragma unroll
-        for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
+          for (int u = 0; u < 16; u++) vv[u] = vpre[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
+        }
 #pragma unroll
         for (int u = 0; u < 16; u++) c = h_add(c, h_mul(vv[u], f2h(scores[t + u])));
       }
