@@ -14,7 +14,7 @@ __device__ __forceinline__ unsigned short f2h(float f) {
   // The empty asm pins the f32 value in a VGPR first.  Without it hipcc folds f16(a*b) / f16(a+b) into
   // v_fma_mixlo_f16 (a*b + 0 rounded ONCE to f16): that drops the sign of a -0.0 product and skips the
   // intermediate f32 rounding the half crate performs -- seen on MI355X as Q8_1 `s` = +0 instead of -0.
-  asm volatile("" : "+v"(f));
+  asm("" : "+v"(f));  // (not volatile: may be scheduled freely, only the value is opaque)
   _Float16 x = (_Float16)f;
   unsigned short h;
   __builtin_memcpy(&h, &x, 2);

@@ -445,10 +445,16 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   }
   __syncthreads();
   if (seq <= 1024) {
-    if (tid == 0) {
+    if (tid < 64) {
+      // sequential row sum (softmax.rs:43-48) without an LDS round trip per add: wave 0 holds 64 values per
+      // pass in registers and v_readlane feeds one dependent v_add chain; lanes past `seq` add +0.0 (exact)
       float sum = 0.0f;
-      for (int t = 0; t < seq; t++) sum += scores[t];
-      s_val = sum;
+      for (int base = 0; base < seq; base += 64) {
+        float v = base + tid < seq ? scores[base + tid] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
+      }
+      if (tid == 0) s_val = sum;
     }
   } else {
     part = wave_sum_f32(part);
@@ -458,7 +464,10 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   }
   __syncthreads();
   const float sum = s_val;
-  for (int t = tid; t < seq; t += blockDim.x) scores[t] = scores[t] / sum;
+  for (int t = tid; t < seq; t += blockDim.x) {
+    float pv = scores[t] / sum;
+    scores[t] = KV16 ? h2f(f2h(pv)) : pv;  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), done once
+  }
   __syncthreads();
   // ---- out[n] = sum_t p[t] * V[t][n]
   float val = 0.0f;
@@ -478,9 +487,9 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
           for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) c = h_add(c, h_mul(vv[u], f2h(scores[t + u])));
+        for (int u = 0; u < 16; u++) c = f2h(h2f(c) + h2f(f2h(h2f(vv[u]) * scores[t + u])));
       }
-      for (; t < seq; t++) c = h_add(c, h_mul(vr[(size_t)t * hd], f2h(scores[t])));
+      for (; t < seq; t++) c = f2h(h2f(c) + h2f(f2h(h2f(vr[(size_t)t * hd]) * scores[t])));
       val = h2f(c);
     } else {
       const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
