@@ -50,7 +50,6 @@ def parse():
     ap.add_argument("--path", default="auto", choices=["auto", "trait", "fused"],
                     help="trait = one launch per Tensor op (Llama2Runner unchanged); fused = fused decode step")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: disable Infinity-Cache weight prefetch")
-    ap.add_argument("--norm-fusion", action="store_true", help="A/B: fold RMSNorm+quantize into the GEMV prologues")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self test of the rank aggregation")
@@ -187,7 +186,7 @@ def main():
     fused = None
     if path in ("auto", "fused"):
         try:
-            fused = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, args.norm_fusion)
+            fused = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch)
             path = "fused"
         except ca.CrabmlError:
             if path == "fused":
@@ -232,7 +231,7 @@ def main():
                   5: "k_gemv (classifier)"}
         n_prof = min(args.steps, 16)
         if path == "fused":
-            eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch, args.norm_fusion)
+            eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch)
             eager.decode_greedy(1, 4)  # warm
             dev.sync()
             dev.prof_enable(True)

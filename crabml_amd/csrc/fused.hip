@@ -79,9 +79,9 @@ struct NormLds {  // carved from dynamic LDS: xs[cols] f32 | chunk_sums[cols/32]
 __host__ __device__ inline size_t norm_lds_bytes(int cols) { return (size_t)(cols + cols / 32) * sizeof(float); }
 
 template <int NIT>  // cols <= NIT * 1024, blockDim.x == 1024; ends with the outputs written (no trailing barrier)
-__device__ __forceinline__ void norm_quant_block(const float* __restrict__ x, const float* __restrict__ w, int cols,
-                                                 float eps, NormLds L, float* s_rms, signed char* q,
-                                                 unsigned short* d, int* isum) {
+__device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const float* __restrict__ addv,
+                                                 const float* __restrict__ w, int cols, float eps, NormLds L,
+                                                 float* s_rms, signed char* q, unsigned short* d, int* isum) {
   const int nchunks = cols / 32;
   const int tid = threadIdx.x;
   float xv[NIT], wv[NIT];
@@ -90,6 +90,12 @@ __device__ __forceinline__ void norm_quant_block(const float* __restrict__ x, co
     int i = it * 1024 + tid;
     xv[it] = i < cols ? x[i] : 0.f;
     wv[it] = i < cols ? w[i] : 0.f;
+    // tensor-parallel: the all-reduced wo / ffn_down output is added to the residual stream here
+    // (x = matmul_out + x, llama2.rs:266 / :636) and written back
+    if (addv != nullptr && i < cols) {
+      xv[it] = addv[i] + xv[it];
+      x[i] = xv[it];
+    }
   }
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
@@ -147,10 +153,10 @@ __device__ __forceinline__ void norm_quant_block(const float* __restrict__ x, co
 }
 
 template <int NIT>
-__global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x, const float* __restrict__ w,
-                                                    int cols, float eps, signed char* __restrict__ q,
-                                                    unsigned short* __restrict__ d, int* __restrict__ isum,
-                                                    PrefetchPlan pf) {
+__global__ __launch_bounds__(1024) void k_norm_quant(float* __restrict__ x, const float* __restrict__ addv,
+                                                    const float* __restrict__ w, int cols, float eps,
+                                                    signed char* __restrict__ q, unsigned short* __restrict__ d,
+                                                    int* __restrict__ isum, PrefetchPlan pf) {
   if (blockIdx.x > 0) {  // spare workgroups: warm the Infinity Cache with the next GEMV's weights
     prefetch_wg(pf, blockIdx.x - 1, gridDim.x - 1);
     return;
@@ -158,35 +164,7 @@ __global__ __launch_bounds__(1024) void k_norm_quant(const float* __restrict__ x
   extern __shared__ float lds[];
   __shared__ float s_rms;
   NormLds L{lds, lds + cols};
-  norm_quant_block<NIT>(x, w, cols, eps, L, &s_rms, q, d, isum);
-}
-
-// LDS image of a quantized activation vector for the GEMV-with-norm-prologue kernels:
-//   [ NormLds scratch ][ q[cols] i8 ][ d[cols/32] f16 ][ isum[cols/32] i32 ]   (each part 16-byte aligned)
-struct ActLds {
-  NormLds nl;
-  signed char* q;
-  unsigned short* d;
-  int* isum;
-};
-__host__ __device__ inline size_t act_lds_bytes(int cols) {
-  size_t n = (norm_lds_bytes(cols) + 15) / 16 * 16;
-  n += ((size_t)cols + 15) / 16 * 16;
-  n += ((size_t)(cols / 32) * 2 + 15) / 16 * 16;
-  n += ((size_t)(cols / 32) * 4 + 15) / 16 * 16;
-  return n;
-}
-__device__ __forceinline__ ActLds act_lds_carve(char* base, int cols) {
-  ActLds a;
-  a.nl.xs = (float*)base;
-  a.nl.chunk_sums = a.nl.xs + cols;
-  size_t o = (norm_lds_bytes(cols) + 15) / 16 * 16;
-  a.q = (signed char*)(base + o);
-  o += ((size_t)cols + 15) / 16 * 16;
-  a.d = (unsigned short*)(base + o);
-  o += ((size_t)(cols / 32) * 2 + 15) / 16 * 16;
-  a.isum = (int*)(base + o);
-  return a;
+  norm_quant_block<NIT>(x, addv, w, cols, eps, L, &s_rms, q, d, isum);
 }
 
 // ---- QKV epilogue: rope (rope.rs:47-63) + q scale (llama2.rs:565) + KV append (concatenate.rs:172-204) ---
@@ -200,14 +178,36 @@ struct QkvEpi {
   int dim, kv_dim, hd, rope_dim, npairs, seq_cap, kv16;
 };
 
-__device__ __forceinline__ void qkv_epilogue(const QkvEpi& e, int row0, float s0, float s1) {
-  const int pos = *e.pos_d;
+// position + rotation for the pair starting at row0, loaded early (before the weight stream is consumed)
+struct QkvPre {
+  int pos;
+  float c, s;
+  bool rot;
+};
+__device__ __forceinline__ QkvPre qkv_preload(const QkvEpi& e, int row0) {
+  QkvPre p;
+  p.pos = *e.pos_d;
+  p.c = 1.f;
+  p.s = 0.f;
+  p.rot = false;
+  if (row0 < e.dim + e.kv_dim) {
+    const int i = (row0 < e.dim ? row0 : row0 - e.dim) % e.hd;
+    if (i < e.rope_dim) {
+      const float* cs = e.rope + ((size_t)p.pos * e.npairs + (i >> 1)) * 2;
+      p.c = cs[0];
+      p.s = cs[1];
+      p.rot = true;
+    }
+  }
+  return p;
+}
+__device__ __forceinline__ void qkv_epilogue(const QkvEpi& e, const QkvPre& pre, int row0, float s0, float s1) {
+  const int pos = pre.pos;
   if (row0 < e.dim + e.kv_dim) {  // q or k: rotate the (even, odd) pair
     const int i = (row0 < e.dim ? row0 : row0 - e.dim) % e.hd;
     float r0 = s0, r1 = s1;
-    if (i < e.rope_dim) {
-      const float* cs = e.rope + ((size_t)pos * e.npairs + (i >> 1)) * 2;
-      float c = cs[0], s = cs[1];
+    if (pre.rot) {
+      float c = pre.c, s = pre.s;
       r0 = s0 * c - s1 * s;
       r1 = s0 * s + s1 * c;
     }
@@ -259,77 +259,18 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, Ac
   } else {
     w = wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
   }
+  QkvPre pre{};
+  if (lane == 0) pre = qkv_preload(e, row0);
   float acc[2];
   rows_partial<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
-  if (lane == 0) qkv_epilogue(e, row0, s0, s1);
+  if (lane == 0) qkv_epilogue(e, pre, row0, s0, s1);
 }
-// Same QKV stage with the attention RMSNorm folded in as a prologue: 1024-thread workgroups (32 rows each);
-// every wave first issues its weight loads, then the workgroup normalises + quantizes x into LDS
-// (norm_quant_block, bit-identical to k_norm_quant) while those loads are in flight.  Removes the separate
-// single-workgroup norm launch (a ~6 us dependent stage) from the layer.
-template <int FMT, int NIT>
-__global__ __launch_bounds__(1024) void k_qkv_n(Planes wq, Planes wk, Planes wv, const float* __restrict__ x,
-                                                const float* __restrict__ wnorm, float eps, int nb, QkvEpi e) {
-  using F = BlockFmt<FMT>;
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  __shared__ float s_rms;
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int row0 = wave * 2;
-  const int total = e.dim + 2 * e.kv_dim;
-  const bool active = row0 < total;
-  Planes w = wq;
-  int local = 0, m = e.dim;
-  if (active) {
-    if (row0 < e.dim) {
-      local = row0;
-    } else if (row0 < e.dim + e.kv_dim) {
-      w = wk; local = row0 - e.dim; m = e.kv_dim;
-    } else {
-      w = wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
-    }
-  }
-  // 1. weight loads for the first column chunk go out before anything else
-  typename F::Blk b0, b1;
-  const bool has0 = active && lane < nb;
-  if (has0) {
-    b0 = F::load(w.q, w.d, (size_t)local * nb + lane);
-    b1 = F::load(w.q, w.d, (size_t)(local + 1) * nb + lane);
-  }
-  // 2. norm + quantize into LDS (all 1024 threads)
-  ActLds A = act_lds_carve(lds_raw, e.dim);
-  norm_quant_block<NIT>(x, wnorm, e.dim, eps, A.nl, &s_rms, A.q, A.d, A.isum);
-  __syncthreads();
-  if (!active) return;
-  const i32x4* xq = (const i32x4*)A.q;
-  float a0 = 0.f, a1 = 0.f;
-  if (has0) {
-    i32x4 x0 = xq[2 * lane], x1 = xq[2 * lane + 1];
-    float dx = h2f(A.d[lane]);
-    int xs = A.isum[lane];
-    a0 += F::term(b0, x0, x1, dx, xs);
-    a1 += F::term(b1, x0, x1, dx, xs);
-  }
-  for (int b = lane + 64; b < nb; b += 64) {
-    typename F::Blk c0 = F::load(w.q, w.d, (size_t)local * nb + b);
-    typename F::Blk c1 = F::load(w.q, w.d, (size_t)(local + 1) * nb + b);
-    i32x4 x0 = xq[2 * b], x1 = xq[2 * b + 1];
-    float dx = h2f(A.d[b]);
-    int xs = A.isum[b];
-    a0 += F::term(c0, x0, x1, dx, xs);
-    a1 += F::term(c1, x0, x1, dx, xs);
-  }
-  float s0 = wave_sum_f32(a0), s1 = wave_sum_f32(a1);
-  if (lane == 0) qkv_epilogue(e, row0, s0, s1);
-  (void)m;
-}
-
 // strict mode: the three GEMVs ran in scalar order into tmp[dim + 2 kv_dim]; apply the same epilogue
 __global__ __launch_bounds__(256) void k_qkv_epi(const float* __restrict__ tmp, QkvEpi e) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   int total = (e.dim + 2 * e.kv_dim) / 2;
-  if (p < total) qkv_epilogue(e, 2 * p, tmp[2 * p], tmp[2 * p + 1]);
+  if (p < total) qkv_epilogue(e, qkv_preload(e, 2 * p), 2 * p, tmp[2 * p], tmp[2 * p + 1]);
 }
 
 // ---- attention: one workgroup per head -------------------------------------------------------------------
@@ -527,23 +468,38 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
 }
 
 // ---- GEMV + residual: x[row] = W[row].xq + x[row]   (matmul_vec, then add_inplace: arithmetic.rs:27-33) ---
-template <int FMT, int R>
+template <int FMT, int R, bool ADD>  // ADD: x[row] += W.xq (residual); else out[row] = W.xq (tensor-parallel partial sum)
 __global__ __launch_bounds__(128) void k_gemv_res(Planes w, ActQ8_0 act, float* __restrict__ x, int m, int nb) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int row0 = wave * R;
   if (row0 >= m) return;
+  // the residual is loaded up front (its latency overlaps the weight stream instead of trailing the reduction)
+  float res[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) res[r] = (ADD && lane == 0 && row0 + r < m) ? x[row0 + r] : 0.f;
   float acc[R];
   rows_partial<FMT, R>(w.q, w.d, act, row0, m, nb, lane, acc);
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float s = wave_sum_f32(acc[r]);
-    if (lane == 0 && row0 + r < m) x[row0 + r] = s + x[row0 + r];
+    if (lane == 0 && row0 + r < m) x[row0 + r] = ADD ? s + res[r] : s;
   }
 }
-__global__ __launch_bounds__(256) void k_res_epi(const float* __restrict__ tmp, float* __restrict__ x, int m) {
+__global__ __launch_bounds__(256) void k_res_epi(const float* __restrict__ tmp, float* __restrict__ x, int m, int add) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) x[i] = tmp[i] + x[i];
+  if (i < m) x[i] = add ? tmp[i] + x[i] : tmp[i];
+}
+// single-device simulation of the tensor-parallel all-reduce: every rank's partial <- sum over ranks (rank order)
+struct SimPtrs {
+  float* p[8];
+};
+__global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = ptrs.p[0][i];
+  for (int r = 1; r < nranks; r++) s += ptrs.p[r][i];
+  for (int r = 0; r < nranks; r++) ptrs.p[r][i] = s;
 }
 
 // ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
@@ -624,81 +580,6 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, ActQ8_0
     }
   }
 }
-// gate/up + SiLU*mul + quantize, with the FFN RMSNorm (eps = 1e-5, llama2.rs:611) folded in as a prologue
-// (see k_qkv_n): the layer's second single-workgroup norm launch disappears as well.
-template <int FMT, int NIT>
-__global__ __launch_bounds__(1024) void k_gateup_nq(Planes wg, Planes wu, const float* __restrict__ x,
-                                                    const float* __restrict__ wnorm, float eps, int dim,
-                                                    const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
-                                                    unsigned short* __restrict__ d, int* __restrict__ isum, int nb) {
-  using F = BlockFmt<FMT>;
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  __shared__ float s_rms;
-  __shared__ float hv[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int blk = blockIdx.x;
-  const int row = blk * 32 + wave * 2;  // rows row, row+1
-  typename F::Blk bg0, bu0, bg1, bu1;
-  const bool has0 = lane < nb;
-  if (has0) {
-    size_t i0 = (size_t)row * nb + lane, i1 = i0 + nb;
-    bg0 = F::load(wg.q, wg.d, i0);
-    bu0 = F::load(wu.q, wu.d, i0);
-    bg1 = F::load(wg.q, wg.d, i1);
-    bu1 = F::load(wu.q, wu.d, i1);
-  }
-  ActLds A = act_lds_carve(lds_raw, dim);
-  norm_quant_block<NIT>(x, wnorm, dim, eps, A.nl, &s_rms, A.q, A.d, A.isum);
-  __syncthreads();
-  const i32x4* xq = (const i32x4*)A.q;
-  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
-  if (has0) {
-    i32x4 x0 = xq[2 * lane], x1 = xq[2 * lane + 1];
-    float dx = h2f(A.d[lane]);
-    int xs = A.isum[lane];
-    g0 += F::term(bg0, x0, x1, dx, xs);
-    u0 += F::term(bu0, x0, x1, dx, xs);
-    g1 += F::term(bg1, x0, x1, dx, xs);
-    u1 += F::term(bu1, x0, x1, dx, xs);
-  }
-  for (int b = lane + 64; b < nb; b += 64) {
-    size_t i0 = (size_t)row * nb + b, i1 = i0 + nb;
-    typename F::Blk cg0 = F::load(wg.q, wg.d, i0);
-    typename F::Blk cu0 = F::load(wu.q, wu.d, i0);
-    typename F::Blk cg1 = F::load(wg.q, wg.d, i1);
-    typename F::Blk cu1 = F::load(wu.q, wu.d, i1);
-    i32x4 x0 = xq[2 * b], x1 = xq[2 * b + 1];
-    float dx = h2f(A.d[b]);
-    int xs = A.isum[b];
-    g0 += F::term(cg0, x0, x1, dx, xs);
-    u0 += F::term(cu0, x0, x1, dx, xs);
-    g1 += F::term(cg1, x0, x1, dx, xs);
-    u1 += F::term(cu1, x0, x1, dx, xs);
-  }
-  g0 = wave_sum_f32(g0);
-  u0 = wave_sum_f32(u0);
-  g1 = wave_sum_f32(g1);
-  u1 = wave_sum_f32(u1);
-  if (lane == 0) {
-    hv[wave * 2] = silu_mul(g0, u0, exp_tab);
-    hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    float v = hv[threadIdx.x];
-    float amax = half_max_f32(fabsf(v));
-    float dd = amax / 127.0f;
-    int qi = rs_f32_as_i32(v / dd);
-    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-    int s = half_sum_i32((int)q8);
-    q[blk * 32 + threadIdx.x] = q8;
-    if (threadIdx.x == 0) {
-      d[blk] = f2h(dd);
-      isum[blk] = s;
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
                                                     const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -786,14 +667,67 @@ __global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv
 
 }  // namespace crabml_hip
 
+
 // ==============================================================================================================
+// Host side: the decode step as a list of segments.  With tensor parallelism (tp_size > 1) every segment ends
+// in a partial-sum vector that is all-reduced across ranks (RCCL over xGMI; 2 x dim f32 per layer):
+//   segment 2l   : [embed] attn-norm(+ pending residual) -> qkv(local heads) -> attention -> wo(local k-slice)
+//   segment 2l+1 : ffn-norm(+ pending residual) -> gate/up(local rows) -> down(local k-slice)
+//   segment 2L   : final norm(+ pending residual) -> classifier -> greedy argmax / advance
+// Column-parallel: wq/wk/wv by heads, gate/up by rows.  Row-parallel: wo, ffn_down by k.
+// ==============================================================================================================
+#include <dlfcn.h>
+
 using namespace crabml_hip;
+
+// ---- RCCL, bound at run time (the single-GPU product path never needs it) ------------------------------------
+struct crabml_hip_tp_comm {
+  crabml_hip_device* dev = nullptr;
+  void* nccl = nullptr;  // ncclComm_t
+  int nranks = 1, rank = 0;
+};
+namespace {
+struct NcclId {  // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+  char b[128];
+};
+struct Rccl {
+  typedef NcclId IdT;
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (r.lib) {
+      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    }
+  }
+  return (r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce) ? &r : nullptr;
+}
+}  // namespace
 
 struct crabml_hip_llama {
   crabml_hip_device* dev = nullptr;
   crabml_hip_llama_config_t cfg{};
   uint32_t wtype = 0;
-  int hd = 0, kv_dim = 0, npairs = 0;
+  int tp = 1, tp_rank = 0;
+  crabml_hip_tp_comm* comm = nullptr;
+  // local (per-rank) geometry
+  int hd = 0, npairs = 0, n_heads_l = 0, n_kv_l = 0, dim_l = 0, kv_dim_l = 0, hidden_l = 0;
   std::vector<crabml_hip_buf*> held;  // retained weight buffers
   crabml_hip_buf* token_embed = nullptr;
   crabml_hip_buf* rms_final = nullptr;
@@ -802,16 +736,18 @@ struct crabml_hip_llama {
   // device state
   std::vector<void*> kc, vc;
   size_t kv_bytes = 0;
-  float* x = nullptr;       // residual stream (dim)
-  float* qbuf = nullptr;    // roped, scaled q (dim)
-  float* attn = nullptr;    // attention output (dim)
-  float* h = nullptr;       // ffn hidden (hidden_dim)
-  float* logits = nullptr;  // vocab
-  float* tmp = nullptr;     // strict-mode GEMV outputs (max(dim + 2 kv_dim, 2 hidden))
-  char* act_dim = nullptr;  // Q8_0 planes of a dim-sized vector
-  char* act_hid = nullptr;  // Q8_0 planes of a hidden-sized vector
-  float* rope = nullptr;    // [seq_len][npairs][2]
-  int* state = nullptr;     // token, pos, step
+  float* x = nullptr;        // residual stream (dim), replicated on every rank
+  float* partial = nullptr;  // tp > 1: this rank's wo / ffn_down partial sums (dim), all-reduced in place
+  float* qbuf = nullptr;     // roped, scaled q (dim_l)
+  float* attn = nullptr;     // attention output (dim_l)
+  float* h = nullptr;        // ffn hidden (hidden_l), strict mode only
+  float* logits = nullptr;   // vocab
+  float* tmp = nullptr;      // strict-mode GEMV outputs
+  char* act_dim = nullptr;   // Q8_0 planes of the normalized residual (dim)
+  char* act_attn = nullptr;  // Q8_0 planes of the attention output (dim_l)
+  char* act_hid = nullptr;   // Q8_0 planes of the ffn hidden vector (hidden_l)
+  float* rope = nullptr;     // [seq_len][npairs][2]
+  int* state = nullptr;      // token, pos, step, sink
   unsigned* out_tokens = nullptr;
   int out_cap = 0;
   float* am_val = nullptr;  // argmax partials
@@ -836,37 +772,43 @@ Planes planes_of(const crabml_hip_buf* b) {
   return Planes{(const i32x4*)b->ptr, (const unsigned short*)((const char*)b->ptr + b->wl.off_scale)};
 }
 
-ActQ8_0 act_of(char* p, size_t n) {
+struct ActPtrs {
+  ActQ8_0 view;
+  signed char* q;
+  unsigned short* d;
+  int* isum;
+};
+ActPtrs act_ptrs(char* p, size_t n) {
   ActLayout al = act_layout(CRABML_HIP_Q8_0, n);
-  return ActQ8_0{(const i32x4*)p, (const unsigned short*)(p + al.off_d), (const int*)(p + al.off_aux)};
+  ActPtrs a;
+  a.q = (signed char*)p;
+  a.d = (unsigned short*)(p + al.off_d);
+  a.isum = (int*)(p + al.off_aux);
+  a.view = ActQ8_0{(const i32x4*)p, a.d, a.isum};
+  return a;
 }
 
+int n_segments(const crabml_hip_llama* c) { return 2 * (int)c->cfg.n_layers + 1; }
+
+// enqueue segment `seg` of one decode step on the device stream (see the banner above)
 template <int FMT>
-int enqueue_step_t(crabml_hip_llama* c) {
+int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
   const auto& g = c->cfg;
-  const int dim = (int)g.embedding_dim, hidden = (int)g.hidden_dim, hd = c->hd, kv_dim = c->kv_dim;
-  const int n_heads = (int)g.n_heads, n_kv = (int)g.n_kv_heads, seq_cap = (int)g.seq_len;
+  const int dim = (int)g.embedding_dim, hd = c->hd, seq_cap = (int)g.seq_len;
+  const int dim_l = c->dim_l, kv_dim_l = c->kv_dim_l, hidden_l = c->hidden_l;
+  const int n_heads_l = c->n_heads_l, n_kv_l = c->n_kv_l;
   const bool kv16 = g.use_f16_kv_cache != 0;
   const bool strict = dev->strict_order;
+  const bool tp = c->tp > 1;
+  const int L = (int)g.n_layers;
   int* token_d = c->state;
   int* pos_d = c->state + 1;
   int* step_d = c->state + 2;
-  ActLayout ald = act_layout(CRABML_HIP_Q8_0, dim), alh = act_layout(CRABML_HIP_Q8_0, hidden);
-  ActQ8_0 ad = act_of(c->act_dim, dim), ah = act_of(c->act_hid, hidden);
-  signed char* adq = (signed char*)c->act_dim;
-  unsigned short* add = (unsigned short*)(c->act_dim + ald.off_d);
-  int* adi = (int*)(c->act_dim + ald.off_aux);
-  signed char* ahq = (signed char*)c->act_hid;
-  unsigned short* ahd = (unsigned short*)(c->act_hid + alh.off_d);
-  int* ahi = (int*)(c->act_hid + alh.off_aux);
-  const size_t norm_lds = norm_lds_bytes(dim);
-  const size_t act_lds = act_lds_bytes(dim);
-  const bool fuse_norm = !strict && (g.flags & CRABML_HIP_LLAMA_NORM_FUSION) && act_lds <= 60 * 1024;
+  ActPtrs ad = act_ptrs(c->act_dim, dim), aa = act_ptrs(c->act_attn, dim_l), ah = act_ptrs(c->act_hid, hidden_l);
   // measurement hook: only meaningful for eager launches (events cannot live inside the captured graph)
-  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing && !dev->strict_order &&
-                    !(g.flags & CRABML_HIP_LLAMA_NORM_FUSION);
+  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing && !strict;
   const double blk_b = (double)block_bytes(c->wtype) / 32.0;  // weight bytes per element
   auto P0 = [&](crabml_hip_device::ProfRec* r, uint32_t stage, double rows, double k) {
     return prof ? prof_begin(dev, r, c->wtype, stage, rows * k * blk_b + 4.0 * k + 4.0 * rows) : 0;
@@ -886,108 +828,131 @@ int enqueue_step_t(crabml_hip_llama* c) {
     return pf;
   };
   const int spare = do_pf ? (dev->n_cu > 1 ? dev->n_cu - 1 : 0) : 0;
-  auto norm_quant = [&](const float* wn, float eps, const PrefetchPlan& pf) {
+  const size_t norm_lds = norm_lds_bytes(dim);
+  // rmsnorm * weight -> act_dim; with tp the previous segment's all-reduced output is folded into x first
+  auto norm_quant = [&](const float* wn, float eps, bool add_pending, const PrefetchPlan& pf) {
+    crabml_hip_device::ProfRec nr{};
+    if (prof) prof_begin(dev, &nr, CRABML_HIP_F32, 6, 8.0 * dim);
+    const float* addv = add_pending ? c->partial : nullptr;
     if (dim <= 4096)
-      k_norm_quant<4><<<1 + spare, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi, pf);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<4>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
     else
-      k_norm_quant<12><<<1 + spare, 1024, norm_lds, st>>>(c->x, wn, dim, eps, adq, add, adi, pf);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<12>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
+    if (prof) prof_end(dev, &nr);
   };
-  const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
-  const bool attn_quant = (hd % 32) == 0;
-
-  k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
-                                              c->token_embed->wl.off_scale, token_d, dim, c->x);
-  for (size_t l = 0; l < g.n_layers; l++) {
-    // attention rmsnorm (llama2.rs:230-234): its own launch, or folded into the QKV stage
-    if (!fuse_norm) norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, plan(c->wq[l], c->wk[l], c->wv[l]));
-    // q, k, v + rope + scale + KV append (llama2.rs:244-256, 542-554, 561-565)
-    QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
-             (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
-    const int total_rows = dim + 2 * kv_dim;
-    CH_TRY(P0(&pr, 1, total_rows, dim));
-    if (fuse_norm) {
-      const int wgs = (total_rows / 2 + 15) / 16;
-      if (dim <= 4096)
-        k_qkv_n<FMT, 4><<<wgs, 1024, act_lds, st>>>(planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), c->x,
-                                                    (const float*)c->rms_att[l]->ptr, g.rms_norm_eps, dim / 32, e);
+  // W(dim x k_local) . act -> x (+= residual) or partial (tp)
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, char* act_raw, int k, uint32_t stage) -> int {
+    CH_TRY(P0(&pr, stage, dim, k));
+    float* dst = tp ? c->partial : c->x;
+    if (!strict) {
+      if (tp)
+        launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
       else
-        k_qkv_n<FMT, 12><<<wgs, 1024, act_lds, st>>>(planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), c->x,
-                                                     (const float*)c->rms_att[l]->ptr, g.rms_norm_eps, dim / 32, e);
-    } else if (!strict) {
-      int waves = total_rows / 2;
-      launch_k(st, R, k_qkv<FMT>, dim3((waves + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), ad, dim / 32, e);
+        launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
     } else {
-      CH_TRY(launch_gemv_strict(dev, c->wq[l], dim, dim, c->act_dim, 1, c->tmp));
-      CH_TRY(launch_gemv_strict(dev, c->wk[l], kv_dim, dim, c->act_dim, 1, c->tmp + dim));
-      CH_TRY(launch_gemv_strict(dev, c->wv[l], kv_dim, dim, c->act_dim, 1, c->tmp + dim + kv_dim));
+      CH_TRY(launch_gemv_strict(dev, w, dim, k, act_raw, 1, c->tmp));
+      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+    }
+    CH_TRY(P1(&pr));
+    return 0;
+  };
+
+  if (seg == 2 * L) {  // final rmsnorm + classifier (llama2.rs:274-278, 199-208) + greedy sampler
+    norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, plan(nullptr, nullptr, nullptr));
+    CH_TRY(P0(&pr, 5, (double)g.vocab_size, dim));
+    if (!strict)
+      CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits, R));
+    else
+      CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
+    CH_TRY(P1(&pr));
+    k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
+    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap);
+    CH_HIP(dev, hipGetLastError());
+    return 0;
+  }
+  const int l = seg / 2;
+  if ((seg & 1) == 0) {
+    if (l == 0)
+      k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
+                                                  c->token_embed->wl.off_scale, token_d, dim, c->x);
+    // attention rmsnorm (llama2.rs:230-234)
+    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, plan(c->wq[l], c->wk[l], c->wv[l]));
+    // q, k, v + rope + scale + KV append (llama2.rs:244-256, 542-554, 561-565), local heads only
+    QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
+             (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
+    const int total_rows = dim_l + 2 * kv_dim_l;
+    CH_TRY(P0(&pr, 1, total_rows, dim));
+    if (!strict) {
+      int waves = total_rows / 2;
+      launch_k(st, R, k_qkv<FMT>, dim3((waves + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), ad.view, dim / 32, e);
+    } else {
+      CH_TRY(launch_gemv_strict(dev, c->wq[l], dim_l, dim, c->act_dim, 1, c->tmp));
+      CH_TRY(launch_gemv_strict(dev, c->wk[l], kv_dim_l, dim, c->act_dim, 1, c->tmp + dim_l));
+      CH_TRY(launch_gemv_strict(dev, c->wv[l], kv_dim_l, dim, c->act_dim, 1, c->tmp + dim_l + kv_dim_l));
       k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
     }
     CH_TRY(P1(&pr));
-    // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo + ffn_gate
+    // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
+    const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
+    const bool attn_quant = (hd % 32) == 0;
     const PrefetchPlan attn_pf = plan(c->wo[l], nullptr, nullptr);
-    const int attn_spare = do_pf && dev->n_cu > n_heads ? dev->n_cu - n_heads : 0;
+    const int attn_spare = do_pf && dev->n_cu > n_heads_l ? dev->n_cu - n_heads_l : 0;
+    crabml_hip_device::ProfRec ar{};
+    crabml_hip_device::ProfRec* AR = prof ? &ar : nullptr;
+    if (prof) prof_begin(dev, &ar, CRABML_HIP_F32, 7, 0.0);
     if (kv16)
-      k_attn<true><<<n_heads + attn_spare, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
-                                                   attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap, attn_pf);
+      launch_k(st, AR, k_attn<true>, dim3(n_heads_l + attn_spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
+               (const void*)c->vc[l], (const int*)pos_d, (const unsigned short*)dev->exp_table, c->attn,
+               attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, n_heads_l, n_kv_l, hd, seq_cap, attn_pf);
     else
-      k_attn<false><<<n_heads + attn_spare, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, dev->exp_table, c->attn,
-                                                    attn_quant ? adq : nullptr, add, adi, n_heads, n_kv, hd, seq_cap, attn_pf);
-    if (!attn_quant) k_quant_q8_0_f<<<(dim + 255) / 256, 256, 0, st>>>(c->attn, adq, add, adi, dim / 32);
-    // wo + residual (llama2.rs:600, 266)
-    CH_TRY(P0(&pr, 2, dim, dim));
+      launch_k(st, AR, k_attn<false>, dim3(n_heads_l + attn_spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
+               (const void*)c->vc[l], (const int*)pos_d, (const unsigned short*)dev->exp_table, c->attn,
+               attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, n_heads_l, n_kv_l, hd, seq_cap, attn_pf);
+    if (prof) prof_end(dev, &ar);
+    if (!attn_quant) k_quant_q8_0_f<<<(dim_l + 255) / 256, 256, 0, st>>>(c->attn, aa.q, aa.d, aa.isum, dim_l / 32);
+    // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
+    CH_TRY(gemv_out(c->wo[l], aa, c->act_attn, dim_l, 2));
+  } else {
+    // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
+    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
+    // gate / up + silu * mul (llama2.rs:620-630), local rows
+    CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
     if (!strict) {
-      launch_k(st, R, k_gemv_res<FMT, 1>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(c->wo[l]), ad, c->x, dim, dim / 32);
+      launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]), ad.view, dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
     } else {
-      CH_TRY(launch_gemv_strict(dev, c->wo[l], dim, dim, c->act_dim, 1, c->tmp));
-      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
+      CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden_l, dim, c->act_dim, 1, c->tmp));
+      CH_TRY(launch_gemv_strict(dev, c->up[l], hidden_l, dim, c->act_dim, 1, c->tmp + hidden_l));
+      k_gateup_epi<<<(hidden_l + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden_l, dev->exp_table, c->h, hidden_l);
+      k_quant_q8_0_f<<<(hidden_l + 255) / 256, 256, 0, st>>>(c->h, ah.q, ah.d, ah.isum, hidden_l / 32);
     }
     CH_TRY(P1(&pr));
-    // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611): its own launch, or folded into the gate/up stage
-    if (!fuse_norm) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, plan(nullptr, nullptr, nullptr));
-    // gate / up + silu * mul (llama2.rs:620-630)
-    CH_TRY(P0(&pr, 3, 2.0 * hidden, dim));
-    if (fuse_norm) {
-      if (dim <= 4096)
-        k_gateup_nq<FMT, 4><<<hidden / 32, 1024, act_lds, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), c->x,
-                                                                (const float*)c->rms_ffn[l]->ptr, 1e-5f, dim, dev->exp_table, ahq, ahd, ahi, dim / 32);
-      else
-        k_gateup_nq<FMT, 12><<<hidden / 32, 1024, act_lds, st>>>(planes_of(c->gate[l]), planes_of(c->up[l]), c->x,
-                                                                 (const float*)c->rms_ffn[l]->ptr, 1e-5f, dim, dev->exp_table, ahq, ahd, ahi, dim / 32);
-    } else if (!strict) {
-      launch_k(st, R, k_gateup_q<FMT>, dim3(hidden / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]), ad, dev->exp_table, ahq, ahd, ahi, dim / 32);
-    } else {
-      CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden, dim, c->act_dim, 1, c->tmp));
-      CH_TRY(launch_gemv_strict(dev, c->up[l], hidden, dim, c->act_dim, 1, c->tmp + hidden));
-      k_gateup_epi<<<(hidden + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden, dev->exp_table, c->h, hidden);
-    }
-    CH_TRY(P1(&pr));
-    if (strict) k_quant_q8_0_f<<<(hidden + 255) / 256, 256, 0, st>>>(c->h, ahq, ahd, ahi, hidden / 32);
-    // down + residual (llama2.rs:633-636)
-    CH_TRY(P0(&pr, 4, dim, hidden));
-    if (!strict) {
-      launch_k(st, R, k_gemv_res<FMT, 1>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(c->down[l]), ah, c->x, dim, hidden / 32);
-    } else {
-      CH_TRY(launch_gemv_strict(dev, c->down[l], dim, hidden, c->act_hid, 1, c->tmp));
-      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, c->x, dim);
-    }
-    CH_TRY(P1(&pr));
+    // down (+ residual, llama2.rs:633-636): k = the local hidden slice
+    CH_TRY(gemv_out(c->down[l], ah, c->act_hid, hidden_l, 4));
   }
-  // final rmsnorm + classifier (llama2.rs:274-278, 199-208)
-  norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, plan(nullptr, nullptr, nullptr));
-  CH_TRY(P0(&pr, 5, (double)g.vocab_size, dim));
-  if (!strict)
-    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits, R));
-  else
-    CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
-  CH_TRY(P1(&pr));
-  k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
-  k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap);
   CH_HIP(dev, hipGetLastError());
   return 0;
 }
 
+int enqueue_segment(crabml_hip_llama* c, int seg) {
+  return c->wtype == CRABML_HIP_Q4_0 ? enqueue_segment_t<CRABML_HIP_Q4_0>(c, seg) : enqueue_segment_t<CRABML_HIP_Q8_0>(c, seg);
+}
+
+int allreduce(crabml_hip_llama* c) {
+  crabml_hip_device* dev = c->dev;
+  Rccl* r = rccl();
+  if (!r || !c->comm || !c->comm->nccl) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama tp: no RCCL communicator");
+  int rc = r->AllReduce(c->partial, c->partial, c->cfg.embedding_dim, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm->nccl, dev->stream);
+  if (rc != 0) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "ncclAllReduce failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
+  return 0;
+}
+
 int enqueue_step(crabml_hip_llama* c) {
-  return c->wtype == CRABML_HIP_Q4_0 ? enqueue_step_t<CRABML_HIP_Q4_0>(c) : enqueue_step_t<CRABML_HIP_Q8_0>(c);
+  const int n = n_segments(c);
+  for (int s = 0; s < n; s++) {
+    CH_TRY(enqueue_segment(c, s));
+    if (c->tp > 1 && s + 1 < n) CH_TRY(allreduce(c));
+  }
+  return 0;
 }
 
 int run_step(crabml_hip_llama* c) {
@@ -998,27 +963,91 @@ int run_step(crabml_hip_llama* c) {
   return enqueue_step(c);
 }
 
+int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step) {
+  int st[3] = {(int)token, (int)pos, step};
+  CH_HIP(c->dev, hipMemcpyAsync(c->state, st, sizeof st, hipMemcpyHostToDevice, c->dev->stream));
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+// ---- tensor-parallel communicator (RCCL) ------------------------------------------------------------------
+int crabml_hip_tp_get_unique_id(void* id128) {
+  Rccl* r = rccl();
+  if (!r || !id128) return CRABML_HIP_UNEXPECTED;
+  return r->GetUniqueId(id128) == 0 ? 0 : CRABML_HIP_UNEXPECTED;
+}
+
+int crabml_hip_tp_comm_create(crabml_hip_device_t* dev, const void* id128, int nranks, int rank, crabml_hip_tp_comm_t** out) {
+  if (!dev || !id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  Rccl* r = rccl();
+  if (!r) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "librccl.so could not be loaded");
+  (void)hipSetDevice(dev->ordinal);
+  Rccl::IdT id;
+  memcpy(&id, id128, sizeof id);
+  void* comm = nullptr;
+  int rc = r->CommInitRank(&comm, nranks, id, rank);
+  if (rc != 0) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
+  crabml_hip_tp_comm* c = new crabml_hip_tp_comm();
+  c->dev = dev;
+  c->nccl = comm;
+  c->nranks = nranks;
+  c->rank = rank;
+  *out = c;
+  return 0;
+}
+
+int crabml_hip_tp_comm_destroy(crabml_hip_tp_comm_t* comm) {
+  if (!comm) return 0;
+  Rccl* r = rccl();
+  if (r && comm->nccl) r->CommDestroy(comm->nccl);
+  delete comm;
+  return 0;
+}
+
+// in-place sum over ranks of an F32 buffer's first n elements, on the device stream (the collective the decode
+// step issues twice per layer); exposed so the RCCL path can be exercised on its own
+int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, size_t n) {
+  if (!comm || !buf) return CRABML_HIP_BAD_INPUT;
+  crabml_hip_device* dev = comm->dev;
+  if (buf->dtype != CRABML_HIP_F32 || n > buf->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: needs an f32 buffer of >= n elements");
+  Rccl* r = rccl();
+  if (!r) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "librccl.so could not be loaded");
+  int rc = r->AllReduce(buf->ptr, buf->ptr, n, 7, 0, comm->nccl, dev->stream);
+  if (rc != 0) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "ncclAllReduce failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
+  touch(buf);
+  return 0;
+}
 
 int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_config_t* cfg,
                             const crabml_hip_llama_weights_t* w, crabml_hip_llama_t** out) {
   if (!dev || !cfg || !w || !out) return CRABML_HIP_BAD_INPUT;
   *out = nullptr;
   const auto& g = *cfg;
+  const int tp = g.tp_size > 1 ? g.tp_size : 1;
   if (!g.n_heads || !g.n_kv_heads || !g.n_layers || g.embedding_dim % g.n_heads || g.n_heads % g.n_kv_heads)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: inconsistent head configuration");
-  const size_t hd = g.embedding_dim / g.n_heads, kv_dim = hd * g.n_kv_heads;
-  if (g.embedding_dim % 32 || g.hidden_dim % 32 || (hd & 1) || hd > 256 || (g.rope_dim & 1) || g.rope_dim > hd || !g.seq_len)
-    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: needs dim,hidden % 32 == 0, even head_dim <= 256, even rope_dim");
-  if (!w->token_embed || !w->rms_final_weight || !w->wq || !w->wk || !w->wv || !w->wo || !w->ffn_gate_weight ||
-      !w->ffn_down_weight || !w->ffn_up_weight || !w->rms_att_weight || !w->rms_ffn_weight)
-    CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: missing weights");
+  if (tp > 8 || g.tp_rank < 0 || g.tp_rank >= tp || g.n_kv_heads % tp || g.hidden_dim % tp)
+    CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: tp_size %d must divide n_kv_heads and hidden_dim (and be <= 8)", tp);
+  // the F32 KV cache pairs head h with kv head h % n_kv (the batch_matmul broadcast quirk): those sets are not
+  // contiguous head slices, so a GQA model shards by heads only with the F16 cache (h / (n_heads / n_kv))
+  if (tp > 1 && !g.use_f16_kv_cache && g.n_heads != g.n_kv_heads)
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama: tensor-parallel GQA needs the f16 kv cache");
+  const size_t hd = g.embedding_dim / g.n_heads;
+  const size_t n_heads_l = g.n_heads / tp, n_kv_l = g.n_kv_heads / tp;
+  const size_t dim_l = n_heads_l * hd, kv_dim_l = n_kv_l * hd, hidden_l = g.hidden_dim / tp;
+  if (g.embedding_dim % 32 || hidden_l % 32 || dim_l % 32 || (hd & 1) || hd > 256 || (g.rope_dim & 1) || g.rope_dim > hd || !g.seq_len)
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: needs dim, local dims % 32 == 0, even head_dim <= 256, even rope_dim");
   if (g.embedding_dim > 12288)  // k_norm_quant keeps the row in 64 KiB of LDS
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: embedding_dim %zu > 12288", g.embedding_dim);
   if ((g.seq_len + hd) * sizeof(float) > 64 * 1024)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: seq_len %zu needs more than 64 KiB of LDS for the score row", g.seq_len);
+  if (!w->token_embed || !w->rms_final_weight || !w->wq || !w->wk || !w->wv || !w->wo || !w->ffn_gate_weight ||
+      !w->ffn_down_weight || !w->ffn_up_weight || !w->rms_att_weight || !w->rms_ffn_weight)
+    CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: missing weights");
   const crabml_hip_buf* outw = w->output_weight ? w->output_weight : w->token_embed;
   const uint32_t wt = w->wq[0]->dtype;
   if (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0)
@@ -1027,14 +1056,14 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     return b && b->dtype == t && b->n_elems == m * k && (block_elems(t) == 1 || b->k == k);
   };
   for (size_t l = 0; l < g.n_layers; l++) {
-    if (!check(w->wq[l], g.embedding_dim, g.embedding_dim, wt) || !check(w->wk[l], kv_dim, g.embedding_dim, wt) ||
-        !check(w->wv[l], kv_dim, g.embedding_dim, wt) || !check(w->wo[l], g.embedding_dim, g.embedding_dim, wt) ||
-        !check(w->ffn_gate_weight[l], g.hidden_dim, g.embedding_dim, wt) ||
-        !check(w->ffn_up_weight[l], g.hidden_dim, g.embedding_dim, wt) ||
-        !check(w->ffn_down_weight[l], g.embedding_dim, g.hidden_dim, wt) ||
+    if (!check(w->wq[l], dim_l, g.embedding_dim, wt) || !check(w->wk[l], kv_dim_l, g.embedding_dim, wt) ||
+        !check(w->wv[l], kv_dim_l, g.embedding_dim, wt) || !check(w->wo[l], g.embedding_dim, dim_l, wt) ||
+        !check(w->ffn_gate_weight[l], hidden_l, g.embedding_dim, wt) ||
+        !check(w->ffn_up_weight[l], hidden_l, g.embedding_dim, wt) ||
+        !check(w->ffn_down_weight[l], g.embedding_dim, hidden_l, wt) ||
         !check(w->rms_att_weight[l], 1, g.embedding_dim, CRABML_HIP_F32) ||
         !check(w->rms_ffn_weight[l], 1, g.embedding_dim, CRABML_HIP_F32))
-      CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: layer %zu weights have an unexpected dtype/shape", l);
+      CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: layer %zu weights have an unexpected dtype/shape (tp=%d)", l, tp);
   }
   if (!check(outw, g.vocab_size, g.embedding_dim, wt) || !check(w->rms_final_weight, 1, g.embedding_dim, CRABML_HIP_F32) ||
       w->token_embed->n_elems != g.vocab_size * g.embedding_dim)
@@ -1045,9 +1074,16 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->dev = dev;
   c->cfg = g;
   c->wtype = wt;
+  c->tp = tp;
+  c->tp_rank = g.tp_rank;
+  c->comm = (crabml_hip_tp_comm*)g.tp_comm;
   c->hd = (int)hd;
-  c->kv_dim = (int)kv_dim;
   c->npairs = (int)(g.rope_dim / 2);
+  c->n_heads_l = (int)n_heads_l;
+  c->n_kv_l = (int)n_kv_l;
+  c->dim_l = (int)dim_l;
+  c->kv_dim_l = (int)kv_dim_l;
+  c->hidden_l = (int)hidden_l;
   auto hold = [&](const crabml_hip_buf* b) {
     crabml_hip_buf* m = const_cast<crabml_hip_buf*>(b);
     crabml_hip_buf_retain(m);
@@ -1073,7 +1109,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     if (rc == 0) rc = dalloc(c, bytes, p);
   };
   const size_t es = g.use_f16_kv_cache ? 2 : 4;
-  c->kv_bytes = g.n_kv_heads * g.seq_len * hd * es;
+  c->kv_bytes = n_kv_l * g.seq_len * hd * es;
   c->kc.resize(g.n_layers);
   c->vc.resize(g.n_layers);
   for (size_t l = 0; l < g.n_layers; l++) {
@@ -1081,15 +1117,18 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     A(c->kv_bytes, &c->vc[l]);
   }
   A(g.embedding_dim * 4, (void**)&c->x);
-  A(g.embedding_dim * 4, (void**)&c->qbuf);
-  A(g.embedding_dim * 4, (void**)&c->attn);
-  A(g.hidden_dim * 4, (void**)&c->h);
+  A(g.embedding_dim * 4, (void**)&c->partial);
+  A(dim_l * 4, (void**)&c->qbuf);
+  A(dim_l * 4, (void**)&c->attn);
+  A(hidden_l * 4, (void**)&c->h);
   A(g.vocab_size * 4, (void**)&c->logits);
-  size_t tmp_n = g.embedding_dim + 2 * kv_dim;
-  if (2 * g.hidden_dim > tmp_n) tmp_n = 2 * g.hidden_dim;
+  size_t tmp_n = dim_l + 2 * kv_dim_l;
+  if (2 * hidden_l > tmp_n) tmp_n = 2 * hidden_l;
+  if (g.embedding_dim > tmp_n) tmp_n = g.embedding_dim;
   A(tmp_n * 4, (void**)&c->tmp);
   A(act_layout(CRABML_HIP_Q8_0, g.embedding_dim).total, (void**)&c->act_dim);
-  A(act_layout(CRABML_HIP_Q8_0, g.hidden_dim).total, (void**)&c->act_hid);
+  A(act_layout(CRABML_HIP_Q8_0, dim_l).total, (void**)&c->act_attn);
+  A(act_layout(CRABML_HIP_Q8_0, hidden_l).total, (void**)&c->act_hid);
   A(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2 * 4, (void**)&c->rope);
   A(4 * sizeof(int), (void**)&c->state);
   c->out_cap = (int)g.seq_len;
@@ -1121,8 +1160,12 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       return hip_fail(dev, e, "llama init", __FILE__, __LINE__);
     }
   }
-  // capture one decode step into a graph (token / pos / step are read from device memory by the kernels)
-  if (!(g.flags & CRABML_HIP_LLAMA_NO_GRAPH)) {
+  // capture one decode step into a graph (token / pos / step are read from device memory by the kernels).
+  // tp > 1 without a communicator = a rank of the single-device simulation: driven segment by segment, no graph.
+  // tp > 1 over RCCL launches eagerly unless CRABML_HIP_LLAMA_TP_GRAPH asks for the collectives to be captured too.
+  const bool want_graph = !(g.flags & CRABML_HIP_LLAMA_NO_GRAPH) &&
+                          (tp == 1 || (c->comm != nullptr && (g.flags & CRABML_HIP_LLAMA_TP_GRAPH)));
+  if (want_graph) {
     hipError_t e = hipStreamBeginCapture(dev->stream, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
       c->capturing = true;
@@ -1143,10 +1186,11 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       }
     }
     (void)hipGetLastError();
-    if (!c->exec) {  // fail loudly: the caller asked for the graph path
+    if (!c->exec && tp == 1) {  // fail loudly: the caller asked for the graph path
       crabml_hip_llama_destroy(c);
       CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: hipGraph capture/instantiate failed");
     }
+    // tp > 1: if RCCL could not be captured the step simply runs eagerly
   }
   *out = c;
   return 0;
@@ -1163,18 +1207,19 @@ int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
   return 0;
 }
 
-static int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step) {
-  int st[3] = {(int)token, (int)pos, step};
-  CH_HIP(c->dev, hipMemcpyAsync(c->state, st, sizeof st, hipMemcpyHostToDevice, c->dev->stream));
+static int check_step(crabml_hip_llama* c, size_t token, size_t pos) {
+  crabml_hip_device* dev = c->dev;
+  if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
+  if (pos != c->kv_len) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: pos %zu != kv cache length %zu", pos, c->kv_len);
+  if (pos >= c->cfg.seq_len) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: kv cache is full (%zu)", c->cfg.seq_len);
   return 0;
 }
 
 int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, float* logits) {
   if (!c) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
-  if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
-  if (pos != c->kv_len) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: pos %zu != kv cache length %zu", pos, c->kv_len);
-  if (pos >= c->cfg.seq_len) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: kv cache is full (%zu)", c->cfg.seq_len);
+  if (c->tp > 1 && !c->comm) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
+  CH_TRY(check_step(c, token, pos));
   CH_TRY(set_state(c, token, pos, 0));
   CH_TRY(run_step(c));
   c->kv_len++;
@@ -1188,6 +1233,7 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, fl
 int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n_steps, uint32_t* out_tokens) {
   if (!c || (!out_tokens && n_steps)) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
+  if (c->tp > 1 && !c->comm) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
   if (c->kv_len + n_steps > c->cfg.seq_len || n_steps > (size_t)c->out_cap)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: %zu steps do not fit the kv cache (%zu of %zu used)", n_steps, c->kv_len, c->cfg.seq_len);
@@ -1197,6 +1243,34 @@ int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n
   c->kv_len += n_steps;
   CH_HIP(dev, hipMemcpyAsync(out_tokens, c->out_tokens, n_steps * 4, hipMemcpyDeviceToHost, dev->stream));
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  return 0;
+}
+
+// Single-device simulation of a tensor-parallel group: `ranks[r]` was created with tp_size = n, tp_rank = r,
+// tp_comm = NULL on the SAME device.  Segments are enqueued rank by rank and the all-reduce is a local kernel
+// (sum in rank order).  Validates the sharding, the partial-sum plumbing and the residual hand-off on one GPU.
+int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, size_t token, size_t pos, float* logits) {
+  if (!ranks || n < 1 || n > 8 || !ranks[0]) return CRABML_HIP_BAD_INPUT;
+  crabml_hip_device* dev = ranks[0]->dev;
+  for (int r = 0; r < n; r++) {
+    if (!ranks[r] || ranks[r]->dev != dev || ranks[r]->tp != n || ranks[r]->tp_rank != r || ranks[r]->comm)
+      CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_sim: rank %d is not a communicator-less rank %d of %d on this device", r, r, n);
+    CH_TRY(check_step(ranks[r], token, pos));
+    CH_TRY(set_state(ranks[r], token, pos, 0));
+  }
+  const int nseg = n_segments(ranks[0]);
+  SimPtrs ptrs{};
+  for (int r = 0; r < n; r++) ptrs.p[r] = ranks[r]->partial;
+  const int dim = (int)ranks[0]->cfg.embedding_dim;
+  for (int s = 0; s < nseg; s++) {
+    for (int r = 0; r < n; r++) CH_TRY(enqueue_segment(ranks[r], s));
+    if (n > 1 && s + 1 < nseg) k_sim_allreduce<<<(dim + 255) / 256, 256, 0, dev->stream>>>(ptrs, n, dim);
+  }
+  for (int r = 0; r < n; r++) ranks[r]->kv_len++;
+  if (logits) {
+    CH_HIP(dev, hipMemcpyAsync(logits, ranks[0]->logits, ranks[0]->cfg.vocab_size * 4, hipMemcpyDeviceToHost, dev->stream));
+    CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  }
   return 0;
 }
 

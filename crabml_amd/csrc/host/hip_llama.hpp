@@ -11,11 +11,40 @@
 
 namespace crabml_host {
 
+// RAII handle of a tensor-parallel RCCL communicator (crabml_hip_tp_comm_*): one per process / GPU
+class TpComm {
+ public:
+  static std::vector<uint8_t> unique_id() {
+    std::vector<uint8_t> id(128);
+    if (crabml_hip_tp_get_unique_id(id.data()) != 0) throw Error(ErrorKind::Unexpected, "ncclGetUniqueId failed (is librccl.so loadable?)");
+    return id;
+  }
+  TpComm(HipTensorDeviceRef device, const std::vector<uint8_t>& id, int nranks, int rank) : device_(std::move(device)), nranks_(nranks), rank_(rank) {
+    if (id.size() != 128) throw Error(ErrorKind::BadInput, "a ncclUniqueId is 128 bytes");
+    device_->check(crabml_hip_tp_comm_create(device_->raw(), id.data(), nranks, rank, &comm_));
+  }
+  ~TpComm() {
+    if (comm_) crabml_hip_tp_comm_destroy(comm_);
+  }
+  TpComm(const TpComm&) = delete;
+  TpComm& operator=(const TpComm&) = delete;
+  crabml_hip_tp_comm_t* raw() const { return comm_; }
+  int nranks() const { return nranks_; }
+  int rank() const { return rank_; }
+  void all_reduce(HipTensor& t) { device_->check(crabml_hip_tp_all_reduce(comm_, t.raw(), t.strider().len())); }
+
+ private:
+  HipTensorDeviceRef device_;
+  crabml_hip_tp_comm_t* comm_ = nullptr;
+  int nranks_, rank_;
+};
+
 class HipLlamaRunner {
  public:
   HipLlamaRunner(const LlamaConfig& conf, std::shared_ptr<LlamaWeights<HipTensor>> w, HipTensorDeviceRef device,
-                 size_t seq_len, bool use_f16_kv_cache, bool use_graph = true, bool prefetch = true, bool fuse_norm = false)
-      : conf_(conf), weights_(std::move(w)), device_(std::move(device)) {
+                 size_t seq_len, bool use_f16_kv_cache, bool use_graph = true, bool prefetch = true, int tp_size = 1,
+                 int tp_rank = 0, std::shared_ptr<TpComm> comm = nullptr)
+      : conf_(conf), weights_(std::move(w)), device_(std::move(device)), comm_(std::move(comm)), tp_size_(tp_size > 1 ? tp_size : 1) {
     crabml_hip_llama_config_t c{};
     c.embedding_dim = conf.embedding_dim;
     c.hidden_dim = conf.hidden_dim;
@@ -27,8 +56,10 @@ class HipLlamaRunner {
     c.rope_dim = conf.rope_dim.value_or(conf.head_size());
     c.rms_norm_eps = conf.rms_norm_eps;
     c.use_f16_kv_cache = use_f16_kv_cache ? 1 : 0;
-    c.flags = (use_graph ? 0 : CRABML_HIP_LLAMA_NO_GRAPH) | (prefetch ? 0 : CRABML_HIP_LLAMA_NO_PREFETCH) |
-              (fuse_norm ? CRABML_HIP_LLAMA_NORM_FUSION : 0);
+    c.flags = (use_graph ? 0 : CRABML_HIP_LLAMA_NO_GRAPH) | (prefetch ? 0 : CRABML_HIP_LLAMA_NO_PREFETCH);
+    c.tp_size = tp_size;
+    c.tp_rank = tp_rank;
+    c.tp_comm = comm_ ? comm_->raw() : nullptr;
     auto raws = [](const std::vector<HipTensor>& v) {
       std::vector<const crabml_hip_buf_t*> r;
       for (const auto& t : v) r.push_back(t.raw());
@@ -61,6 +92,9 @@ class HipLlamaRunner {
   HipLlamaRunner& operator=(const HipLlamaRunner&) = delete;
 
   size_t kv_cache_len() const { return crabml_hip_llama_kv_len(ctx_); }
+  crabml_hip_llama_t* raw() const { return ctx_; }
+  const LlamaConfig& conf() const { return conf_; }
+  const HipTensorDeviceRef& device() const { return device_; }
   void reset() { device_->check(crabml_hip_llama_reset(ctx_)); }
   // Llama2Runner::forward (llama2.rs:184-211) for one token; returns the logits
   std::vector<float> forward(size_t token, size_t pos) {
@@ -75,10 +109,19 @@ class HipLlamaRunner {
     return ids;
   }
   std::vector<uint8_t> debug_kv(size_t layer, bool v, bool f16) {
-    size_t n = conf_.n_kv_heads * seq_cap() * conf_.head_size() * (f16 ? 2 : 4);
+    size_t n = conf_.n_kv_heads / tp_size_ * seq_cap() * conf_.head_size() * (f16 ? 2 : 4);
     std::vector<uint8_t> out(n);
     device_->check(crabml_hip_llama_debug_kv(ctx_, layer, v ? 1 : 0, out.data(), n));
     return out;
+  }
+  // one decode step of a single-device simulated tp group (crabml_hip_llama_tp_sim_forward); logits from rank 0
+  static std::vector<float> tp_sim_forward(const std::vector<HipLlamaRunner*>& ranks, size_t token, size_t pos) {
+    if (ranks.empty()) throw Error(ErrorKind::BadInput, "tp_sim_forward: no ranks");
+    std::vector<crabml_hip_llama_t*> ctxs;
+    for (auto* r : ranks) ctxs.push_back(r->ctx_);
+    std::vector<float> logits(ranks[0]->conf_.vocab_size);
+    ranks[0]->device_->check(crabml_hip_llama_tp_sim_forward(ctxs.data(), (int)ctxs.size(), token, pos, logits.data()));
+    return logits;
   }
   void set_seq_cap(size_t s) { seq_cap_ = s; }
   size_t seq_cap() const { return seq_cap_; }
@@ -87,6 +130,8 @@ class HipLlamaRunner {
   LlamaConfig conf_;
   std::shared_ptr<LlamaWeights<HipTensor>> weights_;
   HipTensorDeviceRef device_;  // declared before ctx_ is destroyed in ~HipLlamaRunner
+  std::shared_ptr<TpComm> comm_;
+  size_t tp_size_ = 1;
   crabml_hip_llama_t* ctx_ = nullptr;
   size_t seq_cap_ = 0;
 };

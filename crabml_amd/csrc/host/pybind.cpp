@@ -216,15 +216,43 @@ PYBIND11_MODULE(_host, m) {
               w.output_weight = o.cast<HipTensor>();
           });
 
+  py::class_<TpComm, std::shared_ptr<TpComm>>(m, "TpComm")
+      .def_static("unique_id",
+                  []() {
+                    std::vector<uint8_t> id = TpComm::unique_id();
+                    return py::bytes((const char*)id.data(), id.size());
+                  })
+      .def(py::init([](std::shared_ptr<HipTensorDevice> dev, py::bytes id, int nranks, int rank) {
+             std::string s = id;
+             py::gil_scoped_release rel;  // ncclCommInitRank blocks until every rank has joined
+             return std::make_shared<TpComm>(std::move(dev), std::vector<uint8_t>(s.begin(), s.end()), nranks, rank);
+           }),
+           py::arg("device"), py::arg("unique_id"), py::arg("nranks"), py::arg("rank"))
+      .def_property_readonly("nranks", &TpComm::nranks)
+      .def_property_readonly("rank", &TpComm::rank)
+      .def("all_reduce", &TpComm::all_reduce);
+
   py::class_<HipLlamaRunner>(m, "HipLlamaRunner")
       .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,
-                       size_t seq_len, bool use_f16_kv_cache, bool use_graph, bool prefetch, bool fuse_norm) {
-             auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph, prefetch, fuse_norm);
+                       size_t seq_len, bool use_f16_kv_cache, bool use_graph, bool prefetch, int tp_size, int tp_rank,
+                       std::shared_ptr<TpComm> comm) {
+             auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph, prefetch,
+                                          tp_size, tp_rank, std::move(comm));
              r->set_seq_cap(seq_len);
              return r;
            }),
            py::arg("conf"), py::arg("weights"), py::arg("device"), py::arg("seq_len"), py::arg("use_f16_kv_cache"),
-           py::arg("use_graph") = true, py::arg("prefetch") = true, py::arg("fuse_norm") = false)
+           py::arg("use_graph") = true, py::arg("prefetch") = true, py::arg("tp_size") = 1, py::arg("tp_rank") = 0,
+           py::arg("comm") = std::shared_ptr<TpComm>())
+      .def_static("tp_sim_forward",
+                  [](const std::vector<HipLlamaRunner*>& ranks, size_t token, size_t pos) {
+                    std::vector<float> lg;
+                    {
+                      py::gil_scoped_release rel;
+                      lg = HipLlamaRunner::tp_sim_forward(ranks, token, pos);
+                    }
+                    return py::array_t<float>(lg.size(), lg.data());
+                  })
       .def("kv_cache_len", &HipLlamaRunner::kv_cache_len)
       .def("reset", &HipLlamaRunner::reset)
       .def("forward",

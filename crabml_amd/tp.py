@@ -1,0 +1,110 @@
+"""Tensor-parallel shard planner for the fused decode step (BASELINE config C5).
+
+Megatron-style split of the per-layer GEMVs over `tp` ranks, one process per GPU:
+
+  column-parallel (rows of W):   attn_q / attn_k / attn_v by heads, ffn_gate / ffn_up by rows
+  row-parallel    (k of W):      attn_output by the local heads' columns, ffn_down by the local hidden columns
+  replicated:                    token_embd, norms, output (classifier)
+
+Both splits cut GGML block rows on block boundaries (k_local % block_elems == 0), so a shard is a plain
+byte slice of the GGUF tensor: no re-quantization, and the activation blocks each rank quantizes are the
+very blocks the unsharded model quantizes.  The two dim-sized partial sums per layer are all-reduced
+(RCCL over xGMI: 2 x dim x 4 bytes per layer per token); see crabml_hip_llama_config_t.tp_*.
+
+Pure numpy host logic -- never imports oracle/.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .synth import BLOCK_BYTES, BLOCK_ELEMS, RawModel, RawTensor
+
+
+def check_tp(shape, tp: int, wtype: int, kv_f16: bool = True) -> None:
+    """Raises ValueError unless `shape` can be split over `tp` ranks (mirrors crabml_hip_llama_create)."""
+    if tp < 1 or tp > 8:
+        raise ValueError(f"tp={tp}: 1..8 ranks (one xGMI-connected node)")
+    if shape.n_kv_heads % tp or shape.n_heads % tp or shape.hidden % tp:
+        raise ValueError(f"tp={tp} must divide n_heads={shape.n_heads}, n_kv_heads={shape.n_kv_heads} and hidden={shape.hidden}")
+    be = max(BLOCK_ELEMS[wtype], 32)
+    dim_l = shape.n_heads // tp * shape.head_dim
+    if dim_l % be or (shape.hidden // tp) % be:
+        raise ValueError(f"tp={tp}: local k slices ({dim_l}, {shape.hidden // tp}) must be multiples of the block size {be}")
+    if tp > 1 and not kv_f16 and shape.n_heads != shape.n_kv_heads:
+        raise ValueError("tensor-parallel GQA needs the f16 kv cache (the f32 cache pairs head h with kv head h % n_kv)")
+
+
+def _rows(t: RawTensor, lo: int, hi: int) -> RawTensor:
+    rows, cols = t.shape
+    rb = cols // BLOCK_ELEMS[t.typ] * BLOCK_BYTES[t.typ]
+    return RawTensor(np.ascontiguousarray(t.data.reshape(rows, rb)[lo:hi]).reshape(-1), [hi - lo, cols], t.typ)
+
+
+def _cols(t: RawTensor, lo: int, hi: int) -> RawTensor:
+    rows, cols = t.shape
+    be, bb = BLOCK_ELEMS[t.typ], BLOCK_BYTES[t.typ]
+    assert lo % be == 0 and hi % be == 0
+    blocks = t.data.reshape(rows, cols // be, bb)
+    return RawTensor(np.ascontiguousarray(blocks[:, lo // be:hi // be]).reshape(-1), [rows, hi - lo], t.typ)
+
+
+def shard_model(model: RawModel, tp: int, rank: int, kv_f16: bool = True) -> RawModel:
+    """Rank `rank`'s shard of `model`.  `.shape` stays the GLOBAL ModelShape (the runner derives the local
+    geometry from tp_size); the sharded tensors carry their local [rows, cols]."""
+    s = model.shape
+    check_tp(s, tp, model.wtype, kv_f16)
+    if not 0 <= rank < tp:
+        raise ValueError(f"rank {rank} outside 0..{tp - 1}")
+    if tp == 1:
+        return model
+    hd = s.head_dim
+    q_lo, q_hi = rank * (s.n_heads // tp) * hd, (rank + 1) * (s.n_heads // tp) * hd
+    kv_lo, kv_hi = rank * (s.n_kv_heads // tp) * hd, (rank + 1) * (s.n_kv_heads // tp) * hd
+    h_lo, h_hi = rank * (s.hidden // tp), (rank + 1) * (s.hidden // tp)
+    out = RawModel(s, model.wtype)
+    for name, t in model.tensors.items():
+        if name.endswith("attn_q.weight"):
+            out.tensors[name] = _rows(t, q_lo, q_hi)
+        elif name.endswith("attn_k.weight") or name.endswith("attn_v.weight"):
+            out.tensors[name] = _rows(t, kv_lo, kv_hi)
+        elif name.endswith("attn_output.weight"):
+            out.tensors[name] = _cols(t, q_lo, q_hi)
+        elif name.endswith("ffn_gate.weight") or name.endswith("ffn_up.weight"):
+            out.tensors[name] = _rows(t, h_lo, h_hi)
+        elif name.endswith("ffn_down.weight"):
+            out.tensors[name] = _cols(t, h_lo, h_hi)
+        else:
+            out.tensors[name] = t  # replicated
+    return out
+
+
+def allreduce_bytes_per_token(shape, tp: int) -> int:
+    """Bytes each rank contributes to all-reduces per decoded token (2 per layer, dim f32 each)."""
+    return 0 if tp <= 1 else 2 * shape.n_layers * shape.dim * 4
+
+
+def init_tp_comm(device, rank: int, world: int, broadcast_bytes):
+    """Create this rank's RCCL communicator.  `broadcast_bytes(b: Optional[bytes]) -> bytes` ships rank 0's
+    128-byte ncclUniqueId to every rank over any side channel (torch.distributed gloo/nccl object broadcast,
+    a file, MPI ...): rank 0 passes the id, the others pass None."""
+    import crabml_amd as ca
+
+    uid: Optional[bytes] = ca.TpComm.unique_id() if rank == 0 else None
+    uid = broadcast_bytes(uid)
+    if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+        raise ValueError("init_tp_comm: the broadcast did not deliver a 128-byte ncclUniqueId")
+    return ca.TpComm(device, bytes(uid), world, rank)
+
+
+def torch_broadcast(rank: int):
+    """broadcast_bytes for init_tp_comm over an initialised torch.distributed process group."""
+    import torch.distributed as dist
+
+    def bcast(b):
+        box = [b]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    return bcast

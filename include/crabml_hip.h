@@ -185,8 +185,8 @@ int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t
 typedef struct crabml_hip_llama crabml_hip_llama_t;
 #define CRABML_HIP_LLAMA_NO_GRAPH 1 /* launch the kernels eagerly instead of replaying a hipGraph */
 #define CRABML_HIP_LLAMA_NO_PREFETCH 2 /* do not warm the Infinity Cache from the latency-bound stages */
-#define CRABML_HIP_LLAMA_NORM_FUSION 4 /* A/B: fold RMSNorm+quantize into the QKV / gate-up GEMV prologues
-                                         (5 launches/layer; measured 7% SLOWER than its own launch: off by default) */
+#define CRABML_HIP_LLAMA_TP_GRAPH 8 /* tp_size > 1: capture the RCCL all-reduces into the hipGraph as well
+                                       (default for tp: eager launches; falls back to eager if capture fails) */
 typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
   size_t embedding_dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size;
   size_t seq_len;  /* KV cache capacity (Llama2Runner::new seq_len, llama2.rs:46-86) */
@@ -194,6 +194,12 @@ typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
   float rms_norm_eps;
   int32_t use_f16_kv_cache;
   int32_t flags;
+  /* tensor parallelism: this context holds rank tp_rank of tp_size shards -- wq/wk/wv split by
+   * heads and ffn_gate/ffn_up by rows (column-parallel), wo/ffn_down split along k (row-parallel); the two
+   * dim-sized partial sums per layer are all-reduced over tp_comm (RCCL).  tp_size <= 1: single GPU.
+   * The weight buffers passed to crabml_hip_llama_create are the LOCAL shards. */
+  int32_t tp_size, tp_rank;
+  void* tp_comm; /* crabml_hip_tp_comm_t*; NULL with tp_size > 1 = a rank of the single-device simulation */
 } crabml_hip_llama_config_t;
 typedef struct crabml_hip_llama_weights { /* crabml-llama2/src/model.rs:55-84; per-layer arrays of n_layers */
   const crabml_hip_buf_t* token_embed;
@@ -220,6 +226,18 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* ctx, size_t token, size_t pos, 
 int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* ctx, size_t token, size_t n_steps, uint32_t* out_tokens);
 size_t crabml_hip_llama_kv_len(const crabml_hip_llama_t* ctx);
 int crabml_hip_llama_reset(crabml_hip_llama_t* ctx); /* empties the KV caches */
+/* ---- tensor-parallel group over RCCL / xGMI (one process per GPU) ----
+ * crabml_hip_tp_get_unique_id fills a 128-byte ncclUniqueId on rank 0; the host broadcasts it (any side channel)
+ * and every rank calls crabml_hip_tp_comm_create.  librccl is bound with dlopen on first use. */
+typedef struct crabml_hip_tp_comm crabml_hip_tp_comm_t;
+int crabml_hip_tp_get_unique_id(void* id128);
+int crabml_hip_tp_comm_create(crabml_hip_device_t* dev, const void* id128, int nranks, int rank, crabml_hip_tp_comm_t** out);
+int crabml_hip_tp_comm_destroy(crabml_hip_tp_comm_t* comm);
+int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, size_t n); /* in-place f32 sum */
+/* single-device simulation of a tp group (ranks created on ONE device with tp_comm = NULL): same kernels, same
+ * sharding, the all-reduce replaced by a local sum -- validates everything but the RCCL transport itself */
+int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, size_t token, size_t pos, float* logits);
+
 /* parity hook: copies the layer's K or V cache (raw f16/f32 bytes, [n_kv_heads][seq_len][head_dim]) */
 int crabml_hip_llama_debug_kv(crabml_hip_llama_t* ctx, size_t layer, int32_t which_v, void* dst, size_t nbytes);
 

@@ -687,3 +687,72 @@ class OracleLlamaRunner:
             out.append(tok)
             pos += 1
         return out
+
+
+class OracleTpLlamaRunner:
+    """CPU restatement of the tensor-parallel decode step (include/crabml_hip.h, crabml_hip_llama_config_t.tp_*).
+
+    The reference has no tensor parallelism: this is Llama2Runner::forward_llama (llama2.rs:213-281) with the
+    Megatron split applied around the SAME reference ops -- every rank runs the reference's matmul_vec / rope /
+    batch_matmul / softmax on its shard, the wo / ffn_down partial sums are added in rank order
+    (p0 + p1 + ...) and then to the residual.  tp = 1 degenerates to OracleLlamaRunner bit for bit.
+    `rank_weights[r]` holds rank r's shards (crabml_amd.tp.shard_model)."""
+
+    def __init__(self, conf: LlamaConfig, rank_weights, device: OracleDevice, seq_len: int, use_f16_kv_cache: bool):
+        self.conf, self.device, self.tp = conf, device, len(rank_weights)
+        tp = self.tp
+        hd = conf.head_size()
+        self.local_conf = LlamaConfig(conf.n_heads // tp * hd, conf.hidden_dim // tp, conf.n_layers, conf.n_heads // tp,
+                                      conf.n_kv_heads // tp, conf.vocab_size, conf.seq_len, conf.rms_norm_eps,
+                                      conf.rope_dim if conf.rope_dim is not None else hd)
+        self.ranks = [OracleLlamaRunner(self.local_conf, w, device, seq_len, use_f16_kv_cache) for w in rank_weights]
+        self.logits = np.zeros(conf.vocab_size, dtype=np.float32)
+
+    def kv_cache_len(self):
+        return self.ranks[0].kv_cache_len()
+
+    @staticmethod
+    def _sum_in_rank_order(parts):
+        s = parts[0]
+        for p in parts[1:]:
+            s = s.add_inplace(p)
+        return s
+
+    def forward(self, tokens, pos):
+        assert len(tokens) == 1, "the tensor-parallel step decodes one token"
+        c, lc, T = self.conf, self.local_conf, OracleTensor
+        w0 = self.ranks[0].weights
+        hd = c.head_size()
+        x = T.alloc([1, c.embedding_dim], F32, self.device)
+        x.copy_rows_from(w0.token_embed, list(tokens))
+        for l in range(c.n_layers):
+            x_orig = x.dup()
+            x = x.rms_norm_inplace(c.rms_norm_eps)
+            x = x.mul_inplace(w0.rms_att_weight[l])
+            parts = []
+            for r in self.ranks:
+                w = r.weights
+                q = w.wq[l].matmul_vec(x).reshape([1, lc.n_heads, hd]).rope_inplace(ROPE_LLAMA, pos, lc.rope_dim)
+                k = w.wk[l].matmul_vec(x).reshape([1, lc.n_kv_heads, hd]).rope_inplace(ROPE_LLAMA, pos, lc.rope_dim)
+                v = w.wv[l].matmul_vec(x)
+                parts.append(r.forward_multi_query_attention(q, k, v, l, pos, lc.n_kv_heads, lc.n_heads,
+                                                             lc.embedding_dim, hd, 1))
+            x = self._sum_in_rank_order(parts).add_inplace(x_orig)
+            x_orig = x.dup()
+            x = x.rms_norm_inplace(1e-5)  # llama2.rs:611
+            x = x.mul_inplace(w0.rms_ffn_weight[l])
+            parts = []
+            for r in self.ranks:
+                w = r.weights
+                h1 = w.ffn_gate_weight[l].matmul_vec(x)
+                h2 = w.ffn_up_weight[l].matmul_vec(x)
+                h1 = h1.silu_inplace().mul_inplace(h2)
+                parts.append(w.ffn_down_weight[l].matmul_vec(h1))
+            x = self._sum_in_rank_order(parts).add_inplace(x_orig)
+        x = x.rms_norm_inplace(c.rms_norm_eps)
+        x = x.mul_inplace(w0.rms_final_weight)
+        x_final = T.alloc([c.embedding_dim], F32, self.device)
+        x_final.copy_rows_from(x, [0])
+        ow = w0.output_weight if w0.output_weight is not None else w0.token_embed
+        self.logits = ow.matmul_vec(x_final).export()
+        return self.logits

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-stage kernel times of the fused decode step (eager replay + dispatch-timestamp events).
+usage: stage_times.py [--no-prefetch] [--steps N] [--pos0 P]"""
+import argparse
+import sys
+
+sys.path.insert(0, ".")
+import crabml_amd as ca
+from crabml_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--no-prefetch", action="store_true")
+ap.add_argument("--steps", type=int, default=16)
+ap.add_argument("--pos0", type=int, default=8)
+ap.add_argument("--model", default="llama3-8b")
+ap.add_argument("--wtype", default="Q4_0")
+a = ap.parse_args()
+NAMES = {1: "qkv", 2: "wo+res", 3: "gateup_q", 4: "down+res", 5: "classifier", 6: "norm_quant", 7: "attn"}
+model = synth.build_model(synth.SHAPES[a.model], synth.TYPE_BY_NAME[a.wtype], seed=8)
+dev = ca.HipTensorDevice(0)
+conf, w = synth.to_hip(model, dev)
+r = ca.HipLlamaRunner(conf, w, dev, a.pos0 + a.steps + 8, True, False, not a.no_prefetch)
+r.decode_greedy(1, a.pos0)
+dev.sync()
+dev.prof_enable(True)
+r.decode_greedy(1, a.steps)
+recs = dev.prof_read()
+dev.prof_enable(False)
+tot = 0.0
+for x in sorted(recs, key=lambda x: x["stage"]):
+    us = x["kernel_ms"] * 1e3 / x["launches"]
+    per_tok = x["kernel_ms"] * 1e3 / a.steps
+    tot += per_tok
+    gb = x["algo_bytes"] / (x["kernel_ms"] * 1e-3) / 1e9 if x["algo_bytes"] else 0
+    print(f"{NAMES.get(x['stage'], x['stage']):12s} {x['launches'] / a.steps:6.1f}/tok  avg {us:7.2f} us  {per_tok:8.1f} us/tok  {gb:7.0f} GB/s")
+print(f"sum of kernel time {tot:.1f} us/token (positions {a.pos0}..{a.pos0 + a.steps - 1})")
