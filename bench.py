@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncate the layer count (INVALID as a result)")
     ap.add_argument("--path", default="auto", choices=["auto", "trait", "fused"],
                     help="trait = one launch per Tensor op (Llama2Runner unchanged); fused = fused decode step")
+    ap.add_argument("--no-norm-epilogue", action="store_true", help="A/B: keep RMSNorm+quantize as its own launch")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: disable Infinity-Cache weight prefetch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -186,7 +187,8 @@ def main():
     fused = None
     if path in ("auto", "fused"):
         try:
-            fused = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch)
+            fused = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch,
+                                      norm_epilogue=not args.no_norm_epilogue)
             path = "fused"
         except ca.CrabmlError:
             if path == "fused":
@@ -231,7 +233,8 @@ def main():
                   5: "k_gemv (classifier)"}
         n_prof = min(args.steps, 16)
         if path == "fused":
-            eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch)
+            eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch,
+                                      norm_epilogue=not args.no_norm_epilogue)
             eager.decode_greedy(1, 4)  # warm
             dev.sync()
             dev.prof_enable(True)

@@ -502,6 +502,152 @@ __global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks,
   for (int r = 0; r < nranks; r++) ptrs.p[r][i] = s;
 }
 
+// ---- fast mode: GEMV + residual with the NEXT RMSNorm + quantization done in the epilogue ------------------------
+// The separate norm+quantize launch is a single-workgroup latency stage (6 us x 65 per token on Llama-3-8B).  Here
+// the producer of x (wo / ffn_down + residual) finishes the job: a 1024-thread workgroup owns 32 consecutive rows
+// = one rmsnorm chunk = one Q8_0 block (the k_gateup_q shape).  It publishes its ordered chunk sum of squares as
+// one 8-byte {sum, epoch} granule (a single write-through store: data and tag travel together, no fence needed),
+// gathers all dim/32 granules (one wave polls them with relaxed agent-scope loads), adds them in chunk order like
+// rms_norm.rs:35-40, and normalizes + quantizes its own block.  Every bit of the result equals k_norm_quant's:
+// same chunk sums, same serial chain, same divisions.  All dim/32 workgroups are co-resident by construction
+// (<= one per CU, checked at create); the poll is bounded and raises `fault` instead of hanging.
+struct NormGather {
+  unsigned long long* slots;  // dim/32 chunk-sum granules
+  unsigned long long* pair;   // dim row granules (split chunks: partner rows handed to the leading workgroup)
+  const int* serial;          // decode-step serial number (never reset): makes the epoch unique per launch
+  int* fault;
+  int nseg, seg;
+};
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int FMT, int SPLIT>  // SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows)
+__global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, ActQ8_0 act, float* __restrict__ x,
+                                                      const float* __restrict__ wnext, float eps,
+                                                      signed char* __restrict__ q, unsigned short* __restrict__ d,
+                                                      int* __restrict__ isum, NormGather ng, int nb) {
+  using F = BlockFmt<FMT>;
+  constexpr int RW = 2 / SPLIT;         // rows per wave
+  constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
+  __shared__ __attribute__((aligned(16))) float hv[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+  const int nchunks = gridDim.x / SPLIT;
+  const int row = blk * 32 + part * ROWS + wave * RW;
+  float res[RW];
+  float wn = 0.f;
+  unsigned epoch = 0;
+#pragma unroll
+  for (int r = 0; r < RW; r++) res[r] = lane == 0 ? x[row + r] : 0.f;
+  if (wave == 0 || SPLIT > 1) epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
+  if (wave == 0 && part == 0) wn = wnext[blk * 32 + (lane & 31)];
+  // RW rows x two blocks per lane in flight (one workgroup per CU: the loads have to supply the parallelism);
+  // terms are added in block order, as rows_partial does
+  float acc[RW];
+#pragma unroll
+  for (int r = 0; r < RW; r++) acc[r] = 0.f;
+  const size_t base0 = (size_t)row * nb;
+  for (int b = lane; b < nb; b += 128) {
+    const int b2 = b + 64;
+    const bool two = b2 < nb;
+    const int bb = two ? b2 : b;
+    typename F::Blk ka[RW], kb[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+      ka[r] = F::load(w.q, w.d, base0 + (size_t)r * nb + b);
+      kb[r] = F::load(w.q, w.d, base0 + (size_t)r * nb + bb);
+    }
+    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
+    i32x4 y0 = act.q[2 * bb], y1 = act.q[2 * bb + 1];
+    float dx = h2f(act.d[b]), dy = h2f(act.d[bb]);
+    int xs = act.isum[b], ys = act.isum[bb];
+#pragma unroll
+    for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], x0, x1, dx, xs);
+    if (two) {
+#pragma unroll
+      for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], y0, y1, dy, ys);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; r++) {
+    const float s = wave_sum_f32(acc[r]);
+    if (lane == 0) {
+      const float xv = s + res[r];  // x = matmul_out + x (llama2.rs:266 / :636)
+      x[row + r] = xv;
+      if (part == 0)
+        hv[wave * RW + r] = xv;
+      else  // hand the value to the chunk's leading workgroup: one {value, epoch} granule per row
+        __hip_atomic_store(ng.pair + blk * 32 + part * ROWS + wave * RW + r,
+                           ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (part != 0) return;
+  __syncthreads();
+  if (wave != 0) return;
+  if (SPLIT > 1) {  // collect the partner rows
+    if (lane >= ROWS && lane < 32) {
+      unsigned long long g = ld_granule(ng.pair + blk * 32 + lane);
+      int tries = 0;
+      while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+        __builtin_amdgcn_s_sleep(1);
+        g = ld_granule(ng.pair + blk * 32 + lane);
+        tries++;
+      }
+      if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;
+      hv[lane] = __builtin_bit_cast(float, (unsigned)g);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ordered chunk sum (rms_norm.rs:35-38), computed redundantly by every lane from LDS broadcasts
+  float cs = -0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    f32x4 t = ((const f32x4*)hv)[j];
+    cs += t[0] * t[0];
+    cs += t[1] * t[1];
+    cs += t[2] * t[2];
+    cs += t[3] * t[3];
+  }
+  if (lane == 0)
+    __hip_atomic_store(ng.slots + blk, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float sum = 0.0f;
+  for (int base = 0; base < nchunks; base += 64) {
+    const int c = base + lane;
+    float v = 0.0f;
+    if (c < nchunks) {
+      unsigned long long g = ld_granule(ng.slots + c);
+      int tries = 0;
+      while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+        __builtin_amdgcn_s_sleep(2);
+        g = ld_granule(ng.slots + c);
+        tries++;
+      }
+      if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+      v = __builtin_bit_cast(float, (unsigned)g);
+    }
+#pragma unroll
+    for (int i = 0; i < 64; i++) sum += rl_f(v, i);  // strictly in chunk order; lanes past nchunks add +0.0
+  }
+  const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
+  const float v = hv[lane & 31];
+  const float xn = (v / rms) * wn;
+  const float amax = half_max_f32(fabsf(xn));
+  const float dd = amax / 127.0f;
+  const int qi = rs_f32_as_i32(xn / dd);
+  const signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+  const int qs = half_sum_i32((int)q8);
+  if (lane < 32) {
+    q[blk * 32 + lane] = q8;
+    if (lane == 0) {
+      d[blk] = f2h(dd);
+      isum[blk] = qs;
+    }
+  }
+}
+
 // ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
 __device__ __forceinline__ float silu_mul(float g, float u, const unsigned short* __restrict__ exp_tab) {
   float nexp = exp_cached_f(-g, exp_tab);
@@ -646,7 +792,8 @@ __global__ __launch_bounds__(256) void k_argmax_partial(const float* __restrict_
 }
 __global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
                                                     int* __restrict__ token_d, int* __restrict__ pos_d,
-                                                    int* __restrict__ step_d, unsigned* __restrict__ out_tokens, int out_cap) {
+                                                    int* __restrict__ step_d, unsigned* __restrict__ out_tokens, int out_cap,
+                                                    int* __restrict__ serial_d) {
   float bv = -INFINITY;
   int bi = -1;
   for (int i = threadIdx.x; i < nparts; i += 64) argmax_combine(bv, bi, pv[i], pi[i]);
@@ -662,6 +809,7 @@ __global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv
     if (st < out_cap) out_tokens[st] = (unsigned)bi;
     *step_d = st + 1;
     *pos_d = *pos_d + 1;
+    *serial_d = *serial_d + 1;
   }
 }
 
@@ -747,7 +895,9 @@ struct crabml_hip_llama {
   char* act_attn = nullptr;  // Q8_0 planes of the attention output (dim_l)
   char* act_hid = nullptr;   // Q8_0 planes of the ffn hidden vector (hidden_l)
   float* rope = nullptr;     // [seq_len][npairs][2]
-  int* state = nullptr;      // token, pos, step, sink
+  int* state = nullptr;      // token, pos, step, sink, serial (never reset), fault
+  unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
+  bool norm_epi = false;     // fast mode, tp == 1: RMSNorm + quantize run in the wo / ffn_down epilogue
   unsigned* out_tokens = nullptr;
   int out_cap = 0;
   float* am_val = nullptr;  // argmax partials
@@ -841,10 +991,26 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     if (prof) prof_end(dev, &nr);
   };
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
-  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, char* act_raw, int k, uint32_t stage) -> int {
+  const bool norm_epi = c->norm_epi;
+  // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, char* act_raw, int k, uint32_t stage, const float* wnext,
+                      float eps_next) -> int {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
-    if (!strict) {
+    if (norm_epi) {
+      NormGather ng{c->slots, c->slots + dim / 32, c->state + 4, c->state + 5, n_segments(c), seg};
+      // long rows (ffn_down): two workgroups per chunk, so that every CU streams (a CU sustains ~26 GB/s here)
+      const int split = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
+                        : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
+                        : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
+                                                                          : 1;
+      if (split == 2)
+        launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), a.view, c->x, wnext, eps_next, ad.q,
+                 ad.d, ad.isum, ng, k / 32);
+      else
+        launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), a.view, c->x, wnext, eps_next, ad.q,
+                 ad.d, ad.isum, ng, k / 32);
+    } else if (!strict) {
       if (tp)
         launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
       else
@@ -858,7 +1024,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   };
 
   if (seg == 2 * L) {  // final rmsnorm + classifier (llama2.rs:274-278, 199-208) + greedy sampler
-    norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, plan(nullptr, nullptr, nullptr));
+    if (!norm_epi) norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, plan(nullptr, nullptr, nullptr));
     CH_TRY(P0(&pr, 5, (double)g.vocab_size, dim));
     if (!strict)
       CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits, R));
@@ -866,7 +1032,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
     CH_TRY(P1(&pr));
     k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
-    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap);
+    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
+                                    c->state + 4);
     CH_HIP(dev, hipGetLastError());
     return 0;
   }
@@ -876,7 +1043,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
                                                   c->token_embed->wl.off_scale, token_d, dim, c->x);
     // attention rmsnorm (llama2.rs:230-234)
-    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, plan(c->wq[l], c->wk[l], c->wv[l]));
+    if (!norm_epi || l == 0)
+      norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, plan(c->wq[l], c->wk[l], c->wv[l]));
     // q, k, v + rope + scale + KV append (llama2.rs:244-256, 542-554, 561-565), local heads only
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
@@ -911,10 +1079,10 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     if (prof) prof_end(dev, &ar);
     if (!attn_quant) k_quant_q8_0_f<<<(dim_l + 255) / 256, 256, 0, st>>>(c->attn, aa.q, aa.d, aa.isum, dim_l / 32);
     // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
-    CH_TRY(gemv_out(c->wo[l], aa, c->act_attn, dim_l, 2));
+    CH_TRY(gemv_out(c->wo[l], aa, c->act_attn, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
   } else {
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
-    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
+    if (!norm_epi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
     // gate / up + silu * mul (llama2.rs:620-630), local rows
     CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
     if (!strict) {
@@ -927,7 +1095,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     }
     CH_TRY(P1(&pr));
     // down (+ residual, llama2.rs:633-636): k = the local hidden slice
-    CH_TRY(gemv_out(c->down[l], ah, c->act_hid, hidden_l, 4));
+    CH_TRY(gemv_out(c->down[l], ah, c->act_hid, hidden_l, 4, (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr,
+                    g.rms_norm_eps));
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
@@ -1130,7 +1299,10 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   A(act_layout(CRABML_HIP_Q8_0, dim_l).total, (void**)&c->act_attn);
   A(act_layout(CRABML_HIP_Q8_0, hidden_l).total, (void**)&c->act_hid);
   A(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2 * 4, (void**)&c->rope);
-  A(4 * sizeof(int), (void**)&c->state);
+  A(8 * sizeof(int), (void**)&c->state);
+  A((g.embedding_dim / 32 + g.embedding_dim) * 8, (void**)&c->slots);
+  c->norm_epi = !dev->strict_order && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
+                (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);
@@ -1153,7 +1325,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       }
     }
     hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 4 * sizeof(int), dev->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 8 * sizeof(int), dev->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (g.embedding_dim / 32 + g.embedding_dim) * 8, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) {
       crabml_hip_llama_destroy(c);
@@ -1224,8 +1397,11 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, fl
   CH_TRY(run_step(c));
   c->kv_len++;
   if (logits) {
+    int fault = 0;
     CH_HIP(dev, hipMemcpyAsync(logits, c->logits, c->cfg.vocab_size * 4, hipMemcpyDeviceToHost, dev->stream));
+    CH_HIP(dev, hipMemcpyAsync(&fault, c->state + 5, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
     CH_HIP(dev, hipStreamSynchronize(dev->stream));
+    if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: a norm-epilogue gather timed out (workgroups not co-resident?)");
   }
   return 0;
 }
@@ -1241,8 +1417,11 @@ int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n
   CH_TRY(set_state(c, token, c->kv_len, 0));
   for (size_t s = 0; s < n_steps; s++) CH_TRY(run_step(c));
   c->kv_len += n_steps;
+  int fault = 0;
   CH_HIP(dev, hipMemcpyAsync(out_tokens, c->out_tokens, n_steps * 4, hipMemcpyDeviceToHost, dev->stream));
+  CH_HIP(dev, hipMemcpyAsync(&fault, c->state + 5, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: a norm-epilogue gather timed out (workgroups not co-resident?)");
   return 0;
 }
 

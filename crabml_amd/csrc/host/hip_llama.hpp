@@ -43,7 +43,7 @@ class HipLlamaRunner {
  public:
   HipLlamaRunner(const LlamaConfig& conf, std::shared_ptr<LlamaWeights<HipTensor>> w, HipTensorDeviceRef device,
                  size_t seq_len, bool use_f16_kv_cache, bool use_graph = true, bool prefetch = true, int tp_size = 1,
-                 int tp_rank = 0, std::shared_ptr<TpComm> comm = nullptr)
+                 int tp_rank = 0, std::shared_ptr<TpComm> comm = nullptr, bool norm_epilogue = true, int extra_flags = 0)
       : conf_(conf), weights_(std::move(w)), device_(std::move(device)), comm_(std::move(comm)), tp_size_(tp_size > 1 ? tp_size : 1) {
     crabml_hip_llama_config_t c{};
     c.embedding_dim = conf.embedding_dim;
@@ -56,7 +56,8 @@ class HipLlamaRunner {
     c.rope_dim = conf.rope_dim.value_or(conf.head_size());
     c.rms_norm_eps = conf.rms_norm_eps;
     c.use_f16_kv_cache = use_f16_kv_cache ? 1 : 0;
-    c.flags = (use_graph ? 0 : CRABML_HIP_LLAMA_NO_GRAPH) | (prefetch ? 0 : CRABML_HIP_LLAMA_NO_PREFETCH);
+    c.flags = (use_graph ? 0 : CRABML_HIP_LLAMA_NO_GRAPH) | (prefetch ? 0 : CRABML_HIP_LLAMA_NO_PREFETCH) |
+              (norm_epilogue ? 0 : CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) | extra_flags;
     c.tp_size = tp_size;
     c.tp_rank = tp_rank;
     c.tp_comm = comm_ ? comm_->raw() : nullptr;

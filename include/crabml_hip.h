@@ -185,8 +185,12 @@ int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t
 typedef struct crabml_hip_llama crabml_hip_llama_t;
 #define CRABML_HIP_LLAMA_NO_GRAPH 1 /* launch the kernels eagerly instead of replaying a hipGraph */
 #define CRABML_HIP_LLAMA_NO_PREFETCH 2 /* do not warm the Infinity Cache from the latency-bound stages */
+#define CRABML_HIP_LLAMA_NO_NORM_EPILOGUE 4 /* A/B: keep RMSNorm + quantize as its own launch (fast mode runs it in
+                                              the wo / ffn_down epilogue; bit-identical either way) */
 #define CRABML_HIP_LLAMA_TP_GRAPH 8 /* tp_size > 1: capture the RCCL all-reduces into the hipGraph as well
                                        (default for tp: eager launches; falls back to eager if capture fails) */
+#define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
+#define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
   size_t embedding_dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size;
   size_t seq_len;  /* KV cache capacity (Llama2Runner::new seq_len, llama2.rs:46-86) */

@@ -66,12 +66,18 @@ def test_fused_fast_matches_oracle_and_trait_path(ca, shape, fmt):
     conf, w = synth.to_hip(model, dev)
     fused = ca.HipLlamaRunner(conf, w, dev, 64, True)
     no_prefetch = ca.HipLlamaRunner(conf, w, dev, 64, True, True, False)
+    separate_norm = ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, norm_epilogue=False)
+    split_chunks = ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, extra_flags=16)  # SPLIT_CHUNKS_ALWAYS
     trait = ca.Llama2Runner(conf, w, dev, 64, True)
     lf = [fused.forward(t, i).copy() for i, t in enumerate(toks)]
     lu = [no_prefetch.forward(t, i).copy() for i, t in enumerate(toks)]
     # the Infinity Cache prefetch is a pure hint: it must not change a single bit
     for a, b in zip(lf, lu):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # ... and so is running RMSNorm + quantize in the wo / ffn_down epilogue (granule gather) instead of its own launch
+    for i, t in enumerate(toks):
+        assert np.array_equal(separate_norm.forward(t, i).view(np.uint32), lf[i].view(np.uint32)), f"norm epilogue, step {i}"
+        assert np.array_equal(split_chunks.forward(t, i).view(np.uint32), lf[i].view(np.uint32)), f"split chunks, step {i}"
     lt = [trait.forward([t], i).copy() for i, t in enumerate(toks)]
     ef, et = rel_errs(lf, ref), rel_errs(lt, ref)
     assert np.median(ef) <= 3e-2 and np.max(ef) <= 1e-1, ef
