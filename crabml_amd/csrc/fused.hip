@@ -78,10 +78,12 @@ struct NormLds {  // carved from dynamic LDS: xs[cols] f32 | chunk_sums[cols/32]
 };
 __host__ __device__ inline size_t norm_lds_bytes(int cols) { return (size_t)(cols + cols / 32) * sizeof(float); }
 
-template <int NIT>  // cols <= NIT * 1024, blockDim.x == 1024; ends with the outputs written (no trailing barrier)
+// QUANT = false: the normalized row goes to xn_out as f32 (formats whose rhs is not Q8_0 quantize it afterwards)
+template <int NIT, bool QUANT>  // cols <= NIT * 1024, blockDim.x == 1024; ends with the outputs written (no trailing barrier)
 __device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const float* __restrict__ addv,
                                                  const float* __restrict__ w, int cols, float eps, NormLds L,
-                                                 float* s_rms, signed char* q, unsigned short* d, int* isum) {
+                                                 float* s_rms, signed char* q, unsigned short* d, int* isum,
+                                                 float* __restrict__ xn_out) {
   const int nchunks = cols / 32;
   const int tid = threadIdx.x;
   float xv[NIT], wv[NIT];
@@ -136,6 +138,10 @@ __device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const fl
     if (it * 1024 < cols) {  // wave-uniform; 32-lane halves are entirely in or out of range (cols % 32 == 0)
       bool live = i < cols;
       float v = live ? (xv[it] / rms) * wv[it] : 0.f;
+      if constexpr (!QUANT) {
+        if (live) xn_out[i] = v;
+        continue;
+      }
       float amax = half_max_f32(fabsf(v));
       float dd = amax / 127.0f;
       int qi = rs_f32_as_i32(v / dd);
@@ -164,7 +170,15 @@ __global__ __launch_bounds__(1024) void k_norm_quant(float* __restrict__ x, cons
   extern __shared__ float lds[];
   __shared__ float s_rms;
   NormLds L{lds, lds + cols};
-  norm_quant_block<NIT>(x, addv, w, cols, eps, L, &s_rms, q, d, isum);
+  norm_quant_block<NIT, true>(x, addv, w, cols, eps, L, &s_rms, q, d, isum, nullptr);
+}
+template <int NIT>
+__global__ __launch_bounds__(1024) void k_norm_f32(float* __restrict__ x, const float* __restrict__ addv,
+                                                  const float* __restrict__ w, int cols, float eps, float* __restrict__ xn) {
+  extern __shared__ float lds[];
+  __shared__ float s_rms;
+  NormLds L{lds, lds + cols};
+  norm_quant_block<NIT, false>(x, addv, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr, xn);
 }
 
 // ---- QKV epilogue: rope (rope.rs:47-63) + q scale (llama2.rs:565) + KV append (concatenate.rs:172-204) ---
@@ -897,6 +911,9 @@ struct crabml_hip_llama {
   float* rope = nullptr;     // [seq_len][npairs][2]
   int* state = nullptr;      // token, pos, step, sink, serial (never reset), fault
   unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
+  bool generic = false;      // per-op launches (strict-order device, or a weight format without fused kernels)
+  uint32_t qt = 0, out_qt = 0;  // vec_dot_rhs_dtype of the layer weights / of the classifier
+  float* xn = nullptr;       // generic path: normalized residual (f32, dim)
   bool norm_epi = false;     // fast mode, tp == 1: RMSNorm + quantize run in the wo / ffn_down epilogue
   unsigned* out_tokens = nullptr;
   int out_cap = 0;
@@ -940,7 +957,8 @@ ActPtrs act_ptrs(char* p, size_t n) {
 
 int n_segments(const crabml_hip_llama* c) { return 2 * (int)c->cfg.n_layers + 1; }
 
-// enqueue segment `seg` of one decode step on the device stream (see the banner above)
+// enqueue segment `seg` of one decode step on the device stream (see the banner above): the fused kernels
+// (fast mode, Q4_0 / Q8_0 weights)
 template <int FMT>
 int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   crabml_hip_device* dev = c->dev;
@@ -950,7 +968,6 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   const int dim_l = c->dim_l, kv_dim_l = c->kv_dim_l, hidden_l = c->hidden_l;
   const int n_heads_l = c->n_heads_l, n_kv_l = c->n_kv_l;
   const bool kv16 = g.use_f16_kv_cache != 0;
-  const bool strict = dev->strict_order;
   const bool tp = c->tp > 1;
   const int L = (int)g.n_layers;
   int* token_d = c->state;
@@ -958,7 +975,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   int* step_d = c->state + 2;
   ActPtrs ad = act_ptrs(c->act_dim, dim), aa = act_ptrs(c->act_attn, dim_l), ah = act_ptrs(c->act_hid, hidden_l);
   // measurement hook: only meaningful for eager launches (events cannot live inside the captured graph)
-  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing && !strict;
+  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing;
   const double blk_b = (double)block_bytes(c->wtype) / 32.0;  // weight bytes per element
   auto P0 = [&](crabml_hip_device::ProfRec* r, uint32_t stage, double rows, double k) {
     return prof ? prof_begin(dev, r, c->wtype, stage, rows * k * blk_b + 4.0 * k + 4.0 * rows) : 0;
@@ -966,7 +983,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   auto P1 = [&](crabml_hip_device::ProfRec* r) { return prof ? prof_end(dev, r) : 0; };
   crabml_hip_device::ProfRec pr{};
   crabml_hip_device::ProfRec* R = prof ? &pr : nullptr;
-  const bool do_pf = !strict && !(g.flags & CRABML_HIP_LLAMA_NO_PREFETCH);
+  const bool do_pf = !(g.flags & CRABML_HIP_LLAMA_NO_PREFETCH);
   auto plan = [&](const crabml_hip_buf* a, const crabml_hip_buf* b, const crabml_hip_buf* cc) {
     PrefetchPlan pf{};
     const crabml_hip_buf* v[3] = {a, b, cc};
@@ -993,8 +1010,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
   const bool norm_epi = c->norm_epi;
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
-  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, char* act_raw, int k, uint32_t stage, const float* wnext,
-                      float eps_next) -> int {
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next) -> int {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
     if (norm_epi) {
@@ -1010,14 +1026,10 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       else
         launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), a.view, c->x, wnext, eps_next, ad.q,
                  ad.d, ad.isum, ng, k / 32);
-    } else if (!strict) {
-      if (tp)
-        launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
-      else
-        launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
+    } else if (tp) {
+      launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
     } else {
-      CH_TRY(launch_gemv_strict(dev, w, dim, k, act_raw, 1, c->tmp));
-      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+      launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
     }
     CH_TRY(P1(&pr));
     return 0;
@@ -1026,10 +1038,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   if (seg == 2 * L) {  // final rmsnorm + classifier (llama2.rs:274-278, 199-208) + greedy sampler
     if (!norm_epi) norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, plan(nullptr, nullptr, nullptr));
     CH_TRY(P0(&pr, 5, (double)g.vocab_size, dim));
-    if (!strict)
-      CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits, R));
-    else
-      CH_TRY(launch_gemv_strict(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits));
+    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits, R));
     CH_TRY(P1(&pr));
     k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
     k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
@@ -1050,15 +1059,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(&pr, 1, total_rows, dim));
-    if (!strict) {
-      int waves = total_rows / 2;
-      launch_k(st, R, k_qkv<FMT>, dim3((waves + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]), planes_of(c->wv[l]), ad.view, dim / 32, e);
-    } else {
-      CH_TRY(launch_gemv_strict(dev, c->wq[l], dim_l, dim, c->act_dim, 1, c->tmp));
-      CH_TRY(launch_gemv_strict(dev, c->wk[l], kv_dim_l, dim, c->act_dim, 1, c->tmp + dim_l));
-      CH_TRY(launch_gemv_strict(dev, c->wv[l], kv_dim_l, dim, c->act_dim, 1, c->tmp + dim_l + kv_dim_l));
-      k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
-    }
+    launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
+             planes_of(c->wv[l]), ad.view, dim / 32, e);
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
@@ -1079,30 +1081,119 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     if (prof) prof_end(dev, &ar);
     if (!attn_quant) k_quant_q8_0_f<<<(dim_l + 255) / 256, 256, 0, st>>>(c->attn, aa.q, aa.d, aa.isum, dim_l / 32);
     // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
-    CH_TRY(gemv_out(c->wo[l], aa, c->act_attn, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
+    CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
   } else {
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
     if (!norm_epi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
     // gate / up + silu * mul (llama2.rs:620-630), local rows
     CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
-    if (!strict) {
-      launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]), ad.view, dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
-    } else {
-      CH_TRY(launch_gemv_strict(dev, c->gate[l], hidden_l, dim, c->act_dim, 1, c->tmp));
-      CH_TRY(launch_gemv_strict(dev, c->up[l], hidden_l, dim, c->act_dim, 1, c->tmp + hidden_l));
-      k_gateup_epi<<<(hidden_l + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden_l, dev->exp_table, c->h, hidden_l);
-      k_quant_q8_0_f<<<(hidden_l + 255) / 256, 256, 0, st>>>(c->h, ah.q, ah.d, ah.isum, hidden_l / 32);
-    }
+    launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]), ad.view,
+             dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
     CH_TRY(P1(&pr));
     // down (+ residual, llama2.rs:633-636): k = the local hidden slice
-    CH_TRY(gemv_out(c->down[l], ah, c->act_hid, hidden_l, 4, (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr,
+    CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr,
                     g.rms_norm_eps));
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
 }
 
+// The same segment out of per-op launches: one GEMV launch per weight matrix (any format matmul_vec supports;
+// the rhs is quantized to vec_dot_rhs_dtype(weight), buf/api.rs:142-159) plus small epilogue kernels.  Used by
+// the strict-order device (scalar summation order, bit-exact against the oracle for every format) and, in fast
+// mode, by the formats without fused kernels (Q4_1, Q4_K, Q8_K, F16, F32).  Still one hipGraph per step.
+int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const auto& g = c->cfg;
+  const int dim = (int)g.embedding_dim, hd = c->hd, seq_cap = (int)g.seq_len;
+  const int dim_l = c->dim_l, kv_dim_l = c->kv_dim_l, hidden_l = c->hidden_l;
+  const int n_heads_l = c->n_heads_l, n_kv_l = c->n_kv_l;
+  const bool kv16 = g.use_f16_kv_cache != 0;
+  const bool strict = dev->strict_order;
+  const bool tp = c->tp > 1;
+  const int L = (int)g.n_layers;
+  int* token_d = c->state;
+  int* pos_d = c->state + 1;
+  int* step_d = c->state + 2;
+  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing && !strict;
+  crabml_hip_device::ProfRec pr{};
+  auto gemv = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out, uint32_t stage) -> int {
+    if (strict) return launch_gemv_strict(dev, w, m, k, act, 1, out);
+    if (prof)
+      CH_TRY(prof_begin(dev, &pr, w->dtype, stage,
+                        (double)m * (double)(k / block_elems(w->dtype)) * (double)block_bytes(w->dtype) + 4.0 * k + 4.0 * m));
+    CH_TRY(launch_gemv(dev, w, m, k, act, 1, out, prof ? &pr : nullptr));
+    if (prof) CH_TRY(prof_end(dev, &pr));
+    return 0;
+  };
+  // CpuTensorBuf::quantize for the rhs of matmul_vec: F32 is the vector itself
+  auto quant = [&](const float* src, int n, uint32_t qt, char* planes) -> const void* {
+    if (qt == CRABML_HIP_F32) return src;
+    launch_quantize_act(st, qt, src, (size_t)n, planes);
+    return planes;
+  };
+  const size_t norm_lds = norm_lds_bytes(dim);
+  auto norm = [&](const float* wn, float eps, bool add_pending) {
+    const float* addv = add_pending ? c->partial : nullptr;
+    if (dim <= 4096)
+      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+    else
+      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+  };
+  float* dst = tp ? c->partial : c->x;
+
+  if (seg == 2 * L) {
+    norm((const float*)c->rms_final->ptr, g.rms_norm_eps, tp);
+    const void* act = quant(c->xn, dim, c->out_qt, c->act_dim);
+    CH_TRY(gemv(c->output, (int)g.vocab_size, dim, act, c->logits, 5));
+    k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
+    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
+                                    c->state + 4);
+    CH_HIP(dev, hipGetLastError());
+    return 0;
+  }
+  const int l = seg / 2;
+  if ((seg & 1) == 0) {
+    if (l == 0)
+      k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
+                                                  c->token_embed->wl.off_scale, token_d, dim, c->x);
+    norm((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0);
+    const void* act = quant(c->xn, dim, c->qt, c->act_dim);
+    QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
+             (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
+    const int total_rows = dim_l + 2 * kv_dim_l;
+    CH_TRY(gemv(c->wq[l], dim_l, dim, act, c->tmp, 1));
+    CH_TRY(gemv(c->wk[l], kv_dim_l, dim, act, c->tmp + dim_l, 1));
+    CH_TRY(gemv(c->wv[l], kv_dim_l, dim, act, c->tmp + dim_l + kv_dim_l, 1));
+    k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
+    const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
+    const PrefetchPlan nopf{};
+    if (kv16)
+      k_attn<true><<<n_heads_l, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn,
+                                                     nullptr, nullptr, nullptr, n_heads_l, n_kv_l, hd, seq_cap, nopf);
+    else
+      k_attn<false><<<n_heads_l, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn,
+                                                      nullptr, nullptr, nullptr, n_heads_l, n_kv_l, hd, seq_cap, nopf);
+    const void* aact = quant(c->attn, dim_l, c->qt, c->act_attn);
+    CH_TRY(gemv(c->wo[l], dim, dim_l, aact, c->tmp, 2));
+    k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+  } else {
+    norm((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp);  // llama2.rs:611
+    const void* act = quant(c->xn, dim, c->qt, c->act_dim);
+    CH_TRY(gemv(c->gate[l], hidden_l, dim, act, c->tmp, 3));
+    CH_TRY(gemv(c->up[l], hidden_l, dim, act, c->tmp + hidden_l, 3));
+    k_gateup_epi<<<(hidden_l + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden_l, dev->exp_table, c->h, hidden_l);
+    const void* hact = quant(c->h, hidden_l, c->qt, c->act_hid);
+    CH_TRY(gemv(c->down[l], dim, hidden_l, hact, c->tmp, 4));
+    k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+  }
+  CH_HIP(dev, hipGetLastError());
+  return 0;
+}
+
 int enqueue_segment(crabml_hip_llama* c, int seg) {
+  if (c->generic) return enqueue_segment_generic(c, seg);
   return c->wtype == CRABML_HIP_Q4_0 ? enqueue_segment_t<CRABML_HIP_Q4_0>(c, seg) : enqueue_segment_t<CRABML_HIP_Q8_0>(c, seg);
 }
 
@@ -1218,9 +1309,18 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       !w->ffn_down_weight || !w->ffn_up_weight || !w->rms_att_weight || !w->rms_ffn_weight)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: missing weights");
   const crabml_hip_buf* outw = w->output_weight ? w->output_weight : w->token_embed;
-  const uint32_t wt = w->wq[0]->dtype;
-  if (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0)
-    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: weights must be Q4_0 or Q8_0 (got %u); use the Tensor ops", wt);
+  const uint32_t wt = w->wq[0]->dtype, out_wt = outw->dtype;
+  const uint32_t qt = vec_dot_rhs_dtype(wt), out_qt = vec_dot_rhs_dtype(out_wt);
+  if (qt == 0xffffffffu || out_qt == 0xffffffffu)
+    CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama: weight dtype %u / classifier dtype %u has no matmul_vec", wt, out_wt);
+  // fused kernels exist for Q4_0 / Q8_0 layers (fast mode); everything else runs the per-op segment path
+  const bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0) || out_wt != wt;
+  {
+    const size_t be = block_elems(wt) > block_elems(qt) ? block_elems(wt) : block_elems(qt);
+    const size_t obe = block_elems(out_wt) > block_elems(out_qt) ? block_elems(out_wt) : block_elems(out_qt);
+    if (g.embedding_dim % be || dim_l % be || hidden_l % be || g.embedding_dim % obe)
+      CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama: dim / local dims are not multiples of the %zu-element blocks of dtype %u", be, wt);
+  }
   auto check = [&](const crabml_hip_buf* b, size_t m, size_t k, uint32_t t) {
     return b && b->dtype == t && b->n_elems == m * k && (block_elems(t) == 1 || b->k == k);
   };
@@ -1234,7 +1334,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
         !check(w->rms_ffn_weight[l], 1, g.embedding_dim, CRABML_HIP_F32))
       CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: layer %zu weights have an unexpected dtype/shape (tp=%d)", l, tp);
   }
-  if (!check(outw, g.vocab_size, g.embedding_dim, wt) || !check(w->rms_final_weight, 1, g.embedding_dim, CRABML_HIP_F32) ||
+  if (!check(outw, g.vocab_size, g.embedding_dim, out_wt) || !check(w->rms_final_weight, 1, g.embedding_dim, CRABML_HIP_F32) ||
       w->token_embed->n_elems != g.vocab_size * g.embedding_dim)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: classifier / final norm / embedding dtype or shape");
 
@@ -1243,6 +1343,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->dev = dev;
   c->cfg = g;
   c->wtype = wt;
+  c->generic = generic;
+  c->qt = qt;
+  c->out_qt = out_qt;
   c->tp = tp;
   c->tp_rank = g.tp_rank;
   c->comm = (crabml_hip_tp_comm*)g.tp_comm;
@@ -1295,13 +1398,18 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   if (2 * hidden_l > tmp_n) tmp_n = 2 * hidden_l;
   if (g.embedding_dim > tmp_n) tmp_n = g.embedding_dim;
   A(tmp_n * 4, (void**)&c->tmp);
-  A(act_layout(CRABML_HIP_Q8_0, g.embedding_dim).total, (void**)&c->act_dim);
-  A(act_layout(CRABML_HIP_Q8_0, dim_l).total, (void**)&c->act_attn);
-  A(act_layout(CRABML_HIP_Q8_0, hidden_l).total, (void**)&c->act_hid);
+  {
+    auto act_bytes = [](uint32_t t, size_t n) { return t == CRABML_HIP_F32 ? (size_t)16 : act_layout(t, n).total; };
+    size_t a_dim = act_bytes(qt, g.embedding_dim), a_out = act_bytes(out_qt, g.embedding_dim);
+    A(a_dim > a_out ? a_dim : a_out, (void**)&c->act_dim);
+    A(act_bytes(qt, dim_l), (void**)&c->act_attn);
+    A(act_bytes(qt, hidden_l), (void**)&c->act_hid);
+    A(g.embedding_dim * 4, (void**)&c->xn);
+  }
   A(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2 * 4, (void**)&c->rope);
   A(8 * sizeof(int), (void**)&c->state);
   A((g.embedding_dim / 32 + g.embedding_dim) * 8, (void**)&c->slots);
-  c->norm_epi = !dev->strict_order && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
+  c->norm_epi = !generic && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);

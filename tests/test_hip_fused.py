@@ -57,6 +57,37 @@ def test_fused_strict_is_bit_exact(ca, shape, fmt, kv_f16):
                     assert np.array_equal(got[lo:lo + n], exp[lo:lo + n]), (layer, which, h)
 
 
+@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q8_K", "F16", "F32"])
+@pytest.mark.parametrize("kv_f16", [False, True])
+def test_decode_step_other_formats_strict_is_bit_exact(ca, fmt, kv_f16):
+    """Formats without fused kernels run the per-op segment path inside the same graph (rhs quantized to
+    vec_dot_rhs_dtype: Q8_1 for Q4_1, Q8_K for the K-quants, buf/api.rs:142-159)."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=14)
+    toks = PROMPT + [7, 9]
+    ref, _ = oracle_logits(model, kv_f16, toks)
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16)
+    for i, t in enumerate(toks):
+        assert np.array_equal(r.forward(t, i).view(np.uint32), ref[i].view(np.uint32)), f"{fmt} step {i}"
+
+
+@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q8_K", "F16", "F32"])
+def test_decode_step_other_formats_fast(ca, fmt):
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=15)
+    toks = PROMPT + [7, 9]
+    ref, orr = oracle_logits(model, True, toks)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    got = [r.forward(t, i).copy() for i, t in enumerate(toks)]
+    err = rel_errs(got, ref)
+    assert np.median(err) <= 3e-2 and np.max(err) <= 1e-1, err
+    # greedy continuation on the device = host argmax (last maximum) over the exported logits
+    ids = r.decode_greedy(int(o.argmax_last(got[-1])), 4)
+    assert len(ids) == 4 and r.kv_cache_len() == len(toks) + 4
+
+
 @pytest.mark.parametrize("shape,fmt", [("15m", "Q4_0"), ("15m", "Q8_0"), ("tiny-gqa", "Q4_0")])
 def test_fused_fast_matches_oracle_and_trait_path(ca, shape, fmt):
     model = synth.build_model(synth.SHAPES[shape], synth.TYPE_BY_NAME[fmt], seed=12)
@@ -125,13 +156,13 @@ def test_argmax_last_maximum_on_device(ca):
 
 
 def test_fused_errors(ca):
-    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_1, seed=2)
     dev = ca.HipTensorDevice(0)
-    conf, w = synth.to_hip(model, dev)
-    with pytest.raises(ca.CrabmlError):  # Q4_1 is served by the per-op path only
-        ca.HipLlamaRunner(conf, w, dev, 16, True)
     model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=2)
     conf, w = synth.to_hip(model, dev)
+    with pytest.raises(ca.CrabmlError):  # the score row of one head must fit 64 KiB of LDS
+        ca.HipLlamaRunner(conf, w, dev, 1 << 16, True)
+    with pytest.raises(ca.CrabmlError):  # tp = 2 needs the local shards, not the full tensors
+        ca.HipLlamaRunner(conf, w, dev, 16, True, tp_size=2, tp_rank=0)
     r = ca.HipLlamaRunner(conf, w, dev, 4, True)
     with pytest.raises(ca.CrabmlError):
         r.forward(1, 3)  # pos != kv length

@@ -36,7 +36,8 @@ def hip_tp_ranks(ca, model, tp, kv_f16, dev):
 
 
 @pytest.mark.parametrize("shape,tp,kv_f16,fmt", [("tiny-gqa", 2, True, "Q4_0"), ("tiny-gqa", 2, True, "Q8_0"),
-                                                 ("15m", 3, False, "Q8_0"), ("15m", 3, True, "Q4_0")])
+                                                 ("15m", 3, False, "Q8_0"), ("15m", 3, True, "Q4_0"),
+                                                 ("tiny-gqa", 2, True, "Q4_K"), ("tiny-gqa", 2, True, "Q4_1")])
 def test_tp_sim_strict_is_bit_exact(ca, shape, tp, kv_f16, fmt):
     model = synth.build_model(synth.SHAPES[shape], synth.TYPE_BY_NAME[fmt], seed=31)
     ref = oracle_tp_logits(model, tp, kv_f16, TOKS)
