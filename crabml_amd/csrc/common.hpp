@@ -66,7 +66,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //   Q4_0: qs[n][16]            | d[n] f16
 //   Q8_0: qs[n][32]            | d[n] f16
 //   Q4_1: qs[n][16]            | dm[n] (d f16, m f16)
-//   Q4_K: unchanged 144-byte blocks (already 16-byte granular: d,dmin,scales[12] | qs[128])
+//   Q4_K: qs[n][128]           | hdr[n][16] (d f16, dmin f16, scales[12]: the block's first 16 bytes)
 //   Q8_K: qs[n][256]           | d[n] f32            (bsums are derived data; not kept for weights)
 // Quantized ACTIVATIONS (the rhs of matmul_vec) live in a per-buffer scratch, also as planes:
 //   Q8_0: qs[n] i8 | d[n/32] f16 | isum[n/32] i32 (sum of the 32 quants; exact, derived)

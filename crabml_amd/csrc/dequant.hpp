@@ -36,12 +36,13 @@ __device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dt
     }
     case CRABML_HIP_Q4_K: {
       size_t sb = e / 256, j = e % 256;
-      const unsigned char* blk = (const unsigned char*)w + sb * 144;
+      const unsigned char* hdr = (const unsigned char*)w + off_scale + sb * 16;
+      const unsigned char* qs = (const unsigned char*)w + sb * 128;
       unsigned short dh, mh;
-      __builtin_memcpy(&dh, blk, 2);
-      __builtin_memcpy(&mh, blk + 2, 2);
+      __builtin_memcpy(&dh, hdr, 2);
+      __builtin_memcpy(&mh, hdr + 2, 2);
       float d = h2f(dh), mn = h2f(mh);
-      const unsigned char* sc = blk + 4;
+      const unsigned char* sc = hdr + 4;
       int c = (int)(j / 64), l = (int)(j % 64);
       int is = 2 * c + (l >= 32 ? 1 : 0);
       int s6, m6;
@@ -53,7 +54,7 @@ __device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dt
         m6 = (sc[is + 4] >> 4) | ((sc[is] >> 6) << 4);
       }
       float d1 = d * (float)s6, m1 = mn * (float)m6;
-      unsigned char q = blk[16 + 32 * c + (l & 31)];
+      unsigned char q = qs[32 * c + (l & 31)];
       float qf = (float)(l >= 32 ? (q >> 4) : (q & 0xF));
       v = d1 * qf - m1;
       break;

@@ -132,10 +132,15 @@ __global__ __launch_bounds__(256) void k_gemv_q4_1(const i32x4* __restrict__ wq,
 }
 
 // ---- Q4_K x Q8_K ---------------------------------------------------------------------------------
-// 144-byte super-blocks: [d f16, dmin f16, scales[12]] [qs[128]].  A lane owns one 32-byte qs chunk
-// = sub-blocks 2p (low nibbles) and 2p+1 (high nibbles): 4 lanes per super-block.
+// planes: qs[n][128] | hdr[n][16] (d, dmin, scales[12]).  A lane owns one 16-byte qs chunk j of a super-block
+// (8 lanes per super-block, so a wave's load is one aligned 1 KiB request, like the Q4_0 kernel): chunk j belongs
+// to the 64-element pair p = j / 2 and carries, for positions 16 (j & 1) .. +16, the low nibbles of sub-block 2p
+// and the high nibbles of sub-block 2p + 1 (buf_q4_k.rs:212-217).  The 16-byte header is fetched by all 8 lanes
+// (one 128-byte request per wave) and the 6-bit (scale, min) pairs are unpacked in registers.  (Widening the
+// 6-bit fields to bytes at upload -- 20-byte headers, two dword loads, 20 fewer VALU ops -- measured SLOWER:
+// gate/up 8.98 -> 10.88 us; the loop is bound by memory instructions, not by VALU.)
 template <int R>
-__global__ __launch_bounds__(256) void k_gemv_q4_k(const unsigned char* __restrict__ w, ActQ8_K act,
+__global__ __launch_bounds__(256) void k_gemv_q4_k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, ActQ8_K act,
                                                    float* __restrict__ out, int m, int nsb) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -144,43 +149,42 @@ __global__ __launch_bounds__(256) void k_gemv_q4_k(const unsigned char* __restri
   float acc[R];
 #pragma unroll
   for (int r = 0; r < R; r++) acc[r] = 0.f;
-  const int nchunks = nsb * 4;
+  const int nchunks = nsb * 8;
   for (int c = lane; c < nchunks; c += 64) {
-    const int sb = c >> 2, p = c & 3;
-    const i32x4* xq = act.q + (size_t)sb * 16 + p * 4;  // 64 int8 = 4 x 16 B
-    i32x4 xl0 = xq[0], xl1 = xq[1], xh0 = xq[2], xh1 = xq[3];
-    float d8 = act.d[sb];
-    const short* bs = act.bsums + sb * 16 + p * 4;
-    int bs_lo = (int)bs[0] + (int)bs[1], bs_hi = (int)bs[2] + (int)bs[3];
+    const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
+    i32x4 qv[R], hdr[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int row = row0 + r < m ? row0 + r : m - 1;
-      const unsigned char* blk = w + ((size_t)row * nsb + sb) * 144;
-      i32x4 hdr = __builtin_nontemporal_load((const i32x4*)blk);
-      i32x4 qa = __builtin_nontemporal_load((const i32x4*)(blk + 16 + p * 32));
-      i32x4 qb = __builtin_nontemporal_load((const i32x4*)(blk + 32 + p * 32));
+      qv[r] = __builtin_nontemporal_load(wq + (size_t)row * nchunks + c);
+      hdr[r] = __builtin_nontemporal_load(wh + (size_t)row * nsb + sb);
+    }
+    const i32x4* xq = act.q + (size_t)sb * 16 + p * 4 + h;
+    const i32x4 xl = xq[0], xh = xq[2];
+    const float d8 = act.d[sb];
+    const short* bs = act.bsums + sb * 16 + p * 4 + h;
+    const int bs_lo = (int)bs[0], bs_hi = (int)bs[2];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
       // 6-bit (scale, min) unpack with the reference's KMASK word trick (buf_q4_k.rs:219-234), then a
       // run-time byte select -- no per-lane indexed array, so nothing spills to scratch.
-      const unsigned u0 = (unsigned)hdr[1], u1 = (unsigned)hdr[2], u2 = (unsigned)hdr[3];
+      const unsigned u0 = (unsigned)hdr[r][1], u1 = (unsigned)hdr[r][2], u2 = (unsigned)hdr[r][3];
       const unsigned S0 = u0 & 0x3f3f3f3fu, S1 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
       const unsigned M0 = u1 & 0x3f3f3f3fu, M1 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
       const unsigned SW = p < 2 ? S0 : S1, MW = p < 2 ? M0 : M1;
       const int sh = (p & 1) * 16;
       const int sc_lo = (int)((SW >> sh) & 0xffu), sc_hi = (int)((SW >> (sh + 8)) & 0xffu);
       const int m_lo = (int)((MW >> sh) & 0xffu), m_hi = (int)((MW >> (sh + 8)) & 0xffu);
-      // low nibbles of the 32 bytes <-> x[0..32), high nibbles <-> x[32..64)   (buf_q4_k.rs:212-217)
       int lo = 0, hi = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        lo = __builtin_amdgcn_sdot4(qa[i] & 0x0F0F0F0F, xl0[i], lo, false);
-        lo = __builtin_amdgcn_sdot4(qb[i] & 0x0F0F0F0F, xl1[i], lo, false);
-        hi = __builtin_amdgcn_sdot4((qa[i] >> 4) & 0x0F0F0F0F, xh0[i], hi, false);
-        hi = __builtin_amdgcn_sdot4((qb[i] >> 4) & 0x0F0F0F0F, xh1[i], hi, false);
+        lo = __builtin_amdgcn_sdot4(qv[r][i] & 0x0F0F0F0F, xl[i], lo, false);
+        hi = __builtin_amdgcn_sdot4((qv[r][i] >> 4) & 0x0F0F0F0F, xh[i], hi, false);
       }
-      int isum = sc_lo * lo + sc_hi * hi;          // exact (the reference's aux32 lanes hold integers < 2^24)
-      int msum = m_lo * bs_lo + m_hi * bs_hi;      // i32: the intended math of buf_q4_k.rs:238-241
-      float dd = h2f((unsigned short)(hdr[0] & 0xffff)) * d8;
-      float dmin = h2f((unsigned short)((unsigned)hdr[0] >> 16)) * d8;
+      const int isum = sc_lo * lo + sc_hi * hi;      // exact (the reference's aux32 lanes hold integers < 2^24)
+      const int msum = m_lo * bs_lo + m_hi * bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
+      const float dd = h2f((unsigned short)(hdr[r][0] & 0xffff)) * d8;
+      const float dmin = h2f((unsigned short)((unsigned)hdr[r][0] >> 16)) * d8;
       acc[r] += dd * (float)isum - dmin * (float)msum;
     }
   }
@@ -323,9 +327,9 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         const int nsb = k / 256;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
-            launch_k(st, rec, k_gemv_q4_k<2>, dim3(grid), dim3(tpb), 0, (const unsigned char*)wp, a, o, m, nsb);
+            launch_k(st, rec, k_gemv_q4_k<2>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const i32x4*)(wp + w->wl.off_scale), a, o, m, nsb);
           else
-            launch_k(st, rec, k_gemv_q4_k<1>, dim3(grid), dim3(tpb), 0, (const unsigned char*)wp, a, o, m, nsb);
+            launch_k(st, rec, k_gemv_q4_k<1>, dim3(grid), dim3(tpb), 0, (const i32x4*)wp, (const i32x4*)(wp + w->wl.off_scale), a, o, m, nsb);
         });
         break;
       }
@@ -378,8 +382,8 @@ __global__ void k_block_dots_k(const unsigned char* __restrict__ w, int wtype, A
   int sb = g >> 3;
   if (wtype == CRABML_HIP_Q4_K) {
     int p = (g & 7) >> 1, hi_half = g & 1;
-    const unsigned char* blk = w + (row_sb0 + sb) * 144;
-    i32x4 qa = *(const i32x4*)(blk + 16 + p * 32), qb = *(const i32x4*)(blk + 32 + p * 32);
+    const unsigned char* qs = w + (row_sb0 + sb) * 128;
+    i32x4 qa = *(const i32x4*)(qs + p * 32), qb = *(const i32x4*)(qs + 16 + p * 32);
     const i32x4* xq = a.q + (size_t)sb * 16 + p * 4 + hi_half * 2;
     i32x4 x0 = xq[0], x1 = xq[1];
     int s = 0;

@@ -73,13 +73,13 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
       float sums[8];
       for (int l = 0; l < 8; l++) sums[l] = 0.0f;
       for (int sb = 0; sb < nsb; sb++) {
-        const unsigned char* blk = (const unsigned char*)w + ((size_t)row * nsb + sb) * 144;
+        const unsigned char* hdr = (const unsigned char*)w + off_scale + ((size_t)row * nsb + sb) * 16;
         const signed char* q8 = (const signed char*)act + (size_t)sb * 256;
         unsigned short dh, mh;
-        __builtin_memcpy(&dh, blk, 2);
-        __builtin_memcpy(&mh, blk + 2, 2);
-        const unsigned char* sc = blk + 4;
-        const unsigned char* q4 = blk + 16;
+        __builtin_memcpy(&dh, hdr, 2);
+        __builtin_memcpy(&mh, hdr + 2, 2);
+        const unsigned char* sc = hdr + 4;
+        const unsigned char* q4 = (const unsigned char*)w + ((size_t)row * nsb + sb) * 128;
         float aux32[8];
         for (int l = 0; l < 8; l++) aux32[l] = 0.0f;
         int scales[8], mins[8];

@@ -43,7 +43,7 @@ WeightLayout weight_layout(uint32_t dtype, size_t n_elems) {
     case CRABML_HIP_Q4_0: wl.off_scale = align_up(n * 16, 256); wl.total = wl.off_scale + n * 2; break;
     case CRABML_HIP_Q8_0: wl.off_scale = align_up(n * 32, 256); wl.total = wl.off_scale + n * 2; break;
     case CRABML_HIP_Q4_1: wl.off_scale = align_up(n * 16, 256); wl.total = wl.off_scale + n * 4; break;
-    case CRABML_HIP_Q4_K: wl.off_scale = 0; wl.total = n * 144; break;
+    case CRABML_HIP_Q4_K: wl.off_scale = align_up(n * 128, 256); wl.total = wl.off_scale + n * 16; break;
     case CRABML_HIP_Q8_K: wl.off_scale = align_up(n * 256, 256); wl.total = wl.off_scale + n * 4; break;
     default: wl.total = 0;
   }
@@ -327,7 +327,7 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
   const uint8_t* src = (const uint8_t*)bytes;
   const size_t nblk = wl.n_blocks;
   hipError_t e = hipSuccess;
-  if (t == CRABML_HIP_F32 || t == CRABML_HIP_F16 || t == CRABML_HIP_Q4_K) {
+  if (t == CRABML_HIP_F32 || t == CRABML_HIP_F16) {
     e = hipMemcpyAsync(b->ptr, src, wl.total, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
   } else {
@@ -352,6 +352,12 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
         for (size_t i = 0; i < nblk; i++) {
           memcpy(qs + i * 16, src + i * 20 + 4, 16);
           memcpy(sc + i * 4, src + i * 20, 4);
+        }
+        break;
+      case CRABML_HIP_Q4_K:
+        for (size_t i = 0; i < nblk; i++) {
+          memcpy(qs + i * 128, src + i * 144 + 16, 128);
+          memcpy(sc + i * 16, src + i * 144, 16);
         }
         break;
       case CRABML_HIP_Q8_K:
