@@ -51,9 +51,12 @@ __global__ __launch_bounds__(256) void k_bmm_f16_fma(const float* __restrict__ a
   size_t bcast = ba / bb;
   const float* ar = a + bi * (m * k) + mi * k;
   const unsigned short* bc = b + (bi / bcast) * sb0 + ni;
-  unsigned short acc = 0;  // f16::ZERO
-  for (size_t ki = 0; ki < k; ki++) acc = h_add(acc, h_mul(bc[ki * sb1], f2h(ar[ki])));
-  c[i] = h2f(acc);
+  _Float16 acc = (_Float16)0.0f;  // f16::ZERO
+  for (size_t ki = 0; ki < k; ki++) {
+    const _Float16 prod = hbits(bc[ki * sb1]) * hbits(f2h(ar[ki]));  // native f16 ops: see devutil.hpp
+    acc = acc + prod;
+  }
+  c[i] = (float)acc;
 }
 
 void launch_batch_matmul(hipStream_t st, const float* a, size_t ba, size_t m, size_t k, const void* b, int b_f16,

@@ -24,6 +24,22 @@ __device__ __forceinline__ unsigned short f2h(float f) {
 __device__ __forceinline__ unsigned short h_mul(unsigned short a, unsigned short b) { return f2h(h2f(a) * h2f(b)); }
 __device__ __forceinline__ unsigned short h_add(unsigned short a, unsigned short b) { return f2h(h2f(a) + h2f(b)); }
 
+// Native f16 arithmetic.  The half crate computes `a * b` / `a + b` in f32 and rounds once to f16; for + and * that
+// double rounding is innocuous (24 >= 2 * 11 + 2 significand bits), so it equals ONE correctly rounded f16
+// operation: v_mul_f16 / v_add_f16.  Used by the f16-accumulated PV chain of attention (buf_f16.rs:152-163), where
+// the add is a serial dependency per cached position (1 dependent instruction instead of 3).  Compiled with
+// -ffp-contract=off: the product and the sum stay two roundings.
+__device__ __forceinline__ _Float16 hbits(unsigned short h) {
+  _Float16 x;
+  __builtin_memcpy(&x, &h, 2);
+  return x;
+}
+__device__ __forceinline__ unsigned short hraw(_Float16 x) {
+  unsigned short h;
+  __builtin_memcpy(&h, &x, 2);
+  return h;
+}
+
 // ---- cross-lane reductions on DPP (gfx9 data-parallel primitives) -------------------------------------
 // __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100 cycles each, and a 5-6 deep
 // dependent chain per reduction); measured on MI355X this made the single-workgroup norm+quantize stage

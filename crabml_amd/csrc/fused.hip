@@ -287,6 +287,69 @@ __global__ __launch_bounds__(256) void k_qkv_epi(const float* __restrict__ tmp, 
   if (p < total) qkv_epilogue(e, qkv_preload(e, 2 * p), 2 * p, tmp[2 * p], tmp[2 * p + 1]);
 }
 
+// softmax.rs:36-54 over scores[0..seq) in LDS, in place, by a 256-thread workgroup: max, exp through the f16 table,
+// row sum sequential up to 1024 positions (bit-exact) and a block tree beyond, true division.  F16: the
+// probabilities are then rounded to f16 (quantize_f32_f16 of the lhs, batch_matmul.rs:39).  Ends with a barrier.
+template <bool F16>
+__device__ __forceinline__ void softmax_row(float* scores, int seq, const unsigned short* __restrict__ exp_tab, float* s_red,
+                                            float* s_val_p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int t = tid; t < seq; t += blockDim.x) mx = fmaxf(mx, scores[t]);
+  mx = wave_max_f32(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float part = 0.0f;
+  {
+    // the table lookups are independent global gathers: 8 in flight per thread (long rows), summed in t order
+    const int bd = blockDim.x;
+    int t = tid;
+    for (; t + 7 * bd < seq; t += 8 * bd) {
+      float ev[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) ev[u] = exp_cached_f(scores[t + u * bd] - mx, exp_tab);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        scores[t + u * bd] = ev[u];
+        part += ev[u];
+      }
+    }
+    for (; t < seq; t += bd) {
+      float ev = exp_cached_f(scores[t] - mx, exp_tab);
+      scores[t] = ev;
+      part += ev;
+    }
+  }
+  __syncthreads();
+  if (seq <= 1024) {
+    if (tid < 64) {
+      // sequential row sum (softmax.rs:43-48) without an LDS round trip per add: wave 0 holds 64 values per
+      // pass in registers and v_readlane feeds one dependent v_add chain; lanes past `seq` add +0.0 (exact)
+      float sum = 0.0f;
+      for (int base = 0; base < seq; base += 64) {
+        float v = base + tid < seq ? scores[base + tid] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
+      }
+      if (tid == 0) *s_val_p = sum;
+    }
+  } else {
+    part = wave_sum_f32(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    if (tid == 0) *s_val_p = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  }
+  __syncthreads();
+  const float sum = *s_val_p;
+  for (int t = tid; t < seq; t += blockDim.x) {
+    float pv = scores[t] / sum;
+    scores[t] = F16 ? h2f(f2h(pv)) : pv;  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), done once
+  }
+  __syncthreads();
+}
+
 // ---- attention: one workgroup per head -------------------------------------------------------------------
 // batch_matmul.rs: f16 cache -> q rounded to f16, f32-accumulated QK^T in k order (buf_f16.rs:83-97),
 // GQA head = h / (n_heads/n_kv); PV accumulated in f16 with a rounding after the product and after the sum
@@ -309,7 +372,7 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   __shared__ float s_val;
   float* scores = lds;
   float* qs = lds + seq_cap;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int head = blockIdx.x;
   const int kvh = KV16 ? head / (n_heads / n_kv) : head % n_kv;
   // Position-independent loads go out first, so that their (cold, cross-XCD) latency overlaps the q staging
@@ -384,53 +447,15 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
     scores[t] = acc;
   }
   __syncthreads();
-  // ---- softmax
-  float mx = -INFINITY;
-  for (int t = tid; t < seq; t += blockDim.x) mx = fmaxf(mx, scores[t]);
-  mx = wave_max_f32(mx);
-  if (lane == 0) s_red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-  __syncthreads();
-  float part = 0.0f;
-  for (int t = tid; t < seq; t += blockDim.x) {
-    float ev = exp_cached_f(scores[t] - mx, exp_tab);
-    scores[t] = ev;
-    part += ev;
-  }
-  __syncthreads();
-  if (seq <= 1024) {
-    if (tid < 64) {
-      // sequential row sum (softmax.rs:43-48) without an LDS round trip per add: wave 0 holds 64 values per
-      // pass in registers and v_readlane feeds one dependent v_add chain; lanes past `seq` add +0.0 (exact)
-      float sum = 0.0f;
-      for (int base = 0; base < seq; base += 64) {
-        float v = base + tid < seq ? scores[base + tid] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
-      }
-      if (tid == 0) s_val = sum;
-    }
-  } else {
-    part = wave_sum_f32(part);
-    if (lane == 0) s_red[wave] = part;
-    __syncthreads();
-    if (tid == 0) s_val = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  }
-  __syncthreads();
-  const float sum = s_val;
-  for (int t = tid; t < seq; t += blockDim.x) {
-    float pv = scores[t] / sum;
-    scores[t] = KV16 ? h2f(f2h(pv)) : pv;  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), done once
-  }
-  __syncthreads();
+  // ---- softmax (in place; probabilities rounded to f16 for the f16 cache)
+  softmax_row<KV16>(scores, seq, exp_tab, s_red, &s_val);
   // ---- out[n] = sum_t p[t] * V[t][n]
   float val = 0.0f;
   const int n = tid;
   if (n < hd) {
     if (KV16) {
       const unsigned short* vr = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + n;
-      unsigned short c = 0;
+      _Float16 c = (_Float16)0.0f;  // native f16 product and sum (devutil.hpp): the chain is one v_add_f16 per position
       int t = 0;
       for (; t + 16 <= seq; t += 16) {  // 16 loads in flight, then the (inherently serial) f16 accumulate chain
         unsigned short vv[16];
@@ -442,10 +467,16 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
           for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) c = f2h(h2f(c) + h2f(f2h(h2f(vv[u]) * scores[t + u])));
+        for (int u = 0; u < 16; u++) {
+          const _Float16 prod = hbits(vv[u]) * (_Float16)scores[t + u];  // scores hold f16-representable values
+          c = c + prod;
+        }
       }
-      for (; t < seq; t++) c = f2h(h2f(c) + h2f(f2h(h2f(vr[(size_t)t * hd]) * scores[t])));
-      val = h2f(c);
+      for (; t < seq; t++) {
+        const _Float16 prod = hbits(vr[(size_t)t * hd]) * (_Float16)scores[t];
+        c = c + prod;
+      }
+      val = (float)c;
     } else {
       const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
       float c = 0.0f;
@@ -477,6 +508,198 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
         xd[e >> 5] = f2h(dd);
         xisum[e >> 5] = s;
       }
+    }
+  }
+}
+
+// ---- attention at long context: the same arithmetic over every CU ----------------------------------------------
+// One workgroup per head streams its whole K and V through one CU (~26 GB/s): 223 us per layer at 4000 cached
+// positions.  From `attn_long_from` positions on the step uses three kernels instead (f16 cache, head_dim % 32
+// == 0, n_heads / n_kv in {1, 2, 4, 8}); every rounding point and summation order is unchanged:
+//   k_attn_scores   (kv head, 128-position split): each thread scores ONE cached position against the G q heads
+//                   that share the kv head -- K is read once, f32 accumulation in k order (buf_f16.rs:83-97);
+//   k_attn_softmax  (head): softmax_row over the score row, probabilities rounded to f16;
+//   k_attn_pv       (kv head, 32-dim slice): V tiles are staged through LDS by the whole workgroup (read once for
+//                   the G heads), and G x 16 lanes run the f16 chains, two dims per lane on packed f16 math
+//                   (v_pk_mul_f16 + v_pk_add_f16 = the half crate's product / sum roundings, devutil.hpp).
+template <int G>
+__global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q, const unsigned short* __restrict__ kc,
+                                                     const int* __restrict__ pos_d, float* __restrict__ scores_g,
+                                                     int n_kv, int hd, int seq_cap, int nsplit) {
+  // one thread per (cached position, q head of the group): the G threads of a position sit in adjacent lanes and
+  // read the same K row (one fetch); each runs its own k-ordered f32 accumulation (buf_f16.rs:83-97)
+  extern __shared__ float lds[];  // qs[G][hd]
+  constexpr int TS = 256 / G;     // positions per workgroup
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int seq = *pos_d + 1;
+  if (sp * TS >= seq) return;
+  for (int idx = tid; idx < G * hd; idx += 256) {
+    const int g = idx / hd, i = idx - g * hd;
+    lds[idx] = h2f(f2h(q[(size_t)(j * G + g) * hd + i]));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+  }
+  __syncthreads();
+  const int g = tid % G;
+  const int t = sp * TS + tid / G;
+  if (t >= seq) return;
+  const unsigned short* kr = kc + ((size_t)j * seq_cap + t) * hd;
+  const float* qg = lds + g * hd;
+  float acc = 0.0f;
+  int i = 0;
+  for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
+    i32x4 kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int w4 = 0; w4 < 4; w4++) {
+        const unsigned w = (unsigned)kv[u][w4];
+        acc += qg[i + 8 * u + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
+        acc += qg[i + 8 * u + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
+      }
+  }
+  for (; i + 8 <= hd; i += 8) {
+    const i32x4 kv = *(const i32x4*)(kr + i);
+#pragma unroll
+    for (int w4 = 0; w4 < 4; w4++) {
+      const unsigned w = (unsigned)kv[w4];
+      acc += qg[i + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
+      acc += qg[i + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
+    }
+  }
+  for (; i < hd; i++) acc += qg[i] * h2f(kr[i]);
+  scores_g[(size_t)(j * G + g) * seq_cap + t] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ scores_g, const int* __restrict__ pos_d,
+                                                      const unsigned short* __restrict__ exp_tab,
+                                                      unsigned short* __restrict__ p16, int seq_cap) {
+  extern __shared__ float lds[];
+  __shared__ float s_red[4];
+  __shared__ float s_val;
+  const int head = blockIdx.x, seq = *pos_d + 1;
+  for (int t = threadIdx.x; t < seq; t += blockDim.x) lds[t] = scores_g[(size_t)head * seq_cap + t];
+  __syncthreads();
+  softmax_row<true>(lds, seq, exp_tab, s_red, &s_val);
+  for (int t = threadIdx.x; t < seq; t += blockDim.x) p16[(size_t)head * seq_cap + t] = f2h(lds[t]);  // exact: already f16 values
+}
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+#define ATTN_PV_TILE 256
+#define ATTN_PV_ROW (ATTN_PV_TILE + 4)  // words per LDS row: 16-byte aligned rows, shifted by 4 banks from each other
+template <int G>
+__global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restrict__ p16, const unsigned short* __restrict__ vc,
+                                                 const int* __restrict__ pos_d, float* __restrict__ out,
+                                                 signed char* __restrict__ xq, unsigned short* __restrict__ xd,
+                                                 int* __restrict__ xisum, int hd, int seq_cap) {
+  constexpr int T = ATTN_PV_TILE, ROW = ATTN_PV_ROW;
+  // LDS, two buffers each: V tile transposed to [16 dim pairs][T] words (a chain lane reads 4 consecutive positions
+  // of its dim pair with one ds_read_b128), P tile [G][T] words holding {p, p} (the packed multiplier, ready-made)
+  __shared__ __attribute__((aligned(16))) unsigned vt[2][16 * ROW];
+  __shared__ __attribute__((aligned(16))) unsigned pt[2][G * ROW];
+  const int tid = threadIdx.x;
+  const int nslice = hd / 32;
+  const int j = blockIdx.x / nslice, sl = blockIdx.x % nslice;
+  const int seq = *pos_d + 1;
+  const unsigned short* vbase = vc + (size_t)j * seq_cap * hd + sl * 32;
+  const int ntiles = (seq + T - 1) / T;
+  // loader role (all threads): V piece = 16 B (4 dim pairs) of row (tid / 4) + 64 r, piece tid % 4;
+  // P piece = 16 B = 8 positions of one head
+  i32x4 vreg[4], preg;
+  auto issue = [&](int tile) {
+    const int t0 = tile * T;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int t = t0 + (tid >> 2) + 64 * r;
+      t = t < seq_cap ? t : seq_cap - 1;  // rows past seq are read (inside the cache allocation) but never used
+      vreg[r] = *(const i32x4*)(vbase + (size_t)t * hd + (tid & 3) * 8);
+    }
+    if (tid < G * (T / 8)) {
+      const int g = tid / (T / 8), c8 = tid % (T / 8);
+      int t = t0 + c8 * 8;
+      t = t + 8 <= seq_cap ? t : seq_cap - 8;  // only past the end of the cache: those positions are never consumed
+      preg = *(const i32x4*)(p16 + (size_t)(j * G + g) * seq_cap + t);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int tl = (tid >> 2) + 64 * r;
+#pragma unroll
+      for (int i = 0; i < 4; i++) vt[buf][((tid & 3) * 4 + i) * ROW + tl] = (unsigned)vreg[r][i];
+    }
+    if (tid < G * (T / 8)) {
+      const int g = tid / (T / 8), c8 = tid % (T / 8);
+      unsigned pp[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned w = (unsigned)preg[i];
+        const unsigned a = w & 0xffffu, b = w >> 16;
+        pp[2 * i] = a | (a << 16);
+        pp[2 * i + 1] = b | (b << 16);
+      }
+      *(i32x4*)(&pt[buf][g * ROW + c8 * 8]) = i32x4{(int)pp[0], (int)pp[1], (int)pp[2], (int)pp[3]};
+      *(i32x4*)(&pt[buf][g * ROW + c8 * 8 + 4]) = i32x4{(int)pp[4], (int)pp[5], (int)pp[6], (int)pp[7]};
+    }
+  };
+  // chain role: lane c < G * 16 owns dims 2 dp, 2 dp + 1 of head j * G + g
+  const bool chain = tid < G * 16;
+  const int g = tid >> 4, dp = tid & 15;
+  h16x2 c2 = {(_Float16)0.0f, (_Float16)0.0f};
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile++) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles) issue(tile + 1);
+    if (chain) {
+      const int nt = seq - tile * T < T ? seq - tile * T : T;
+      const unsigned* vrow = &vt[buf][dp * ROW];
+      const unsigned* prow = &pt[buf][g * ROW];
+      int t = 0;
+      // NB rounds of 8 positions: all the LDS reads of a round go out before its (serial) packed adds, so the LDS
+      // latency is paid once per round
+#define PV_ROUND(NB)                                                                                         \
+  for (; t + 8 * NB <= nt; t += 8 * NB) {                                                                    \
+    i32x4 vq[2 * NB], pq[2 * NB];                                                                            \
+    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) {                                                     \
+      vq[b] = *(const i32x4*)(vrow + t + 4 * b);                                                             \
+      pq[b] = *(const i32x4*)(prow + t + 4 * b);                                                             \
+    }                                                                                                        \
+    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) _Pragma("unroll") for (int u = 0; u < 4; u++) {       \
+      const h16x2 pr = __builtin_bit_cast(h16x2, (unsigned)vq[b][u]) * __builtin_bit_cast(h16x2, (unsigned)pq[b][u]); \
+      c2 = c2 + pr;                                                                                          \
+    }                                                                                                        \
+  }
+      PV_ROUND(4)
+      PV_ROUND(1)
+#undef PV_ROUND
+      for (; t < nt; t++) {
+        const h16x2 pr = __builtin_bit_cast(h16x2, vrow[t]) * __builtin_bit_cast(h16x2, prow[t]);
+        c2 = c2 + pr;
+      }
+    }
+    if (tile + 1 < ntiles) commit(buf ^ 1);  // the other buffer was last read one iteration ago (barrier below)
+    __syncthreads();
+  }
+  if (!chain) return;
+  const float v0 = (float)c2[0], v1 = (float)c2[1];
+  const int head = j * G + g;
+  const int e0 = head * hd + sl * 32 + 2 * dp;
+  out[e0] = v0;
+  out[e0 + 1] = v1;
+  if (xq != nullptr) {  // Q8_0 block of the 32 dims held by this 16-lane DPP row (buf_q8_0.rs:87-134)
+    const float amax = row16_max_f32(fmaxf(fabsf(v0), fabsf(v1)));
+    const float dd = amax / 127.0f;
+    const int q0 = rs_f32_as_i32(v0 / dd), q1 = rs_f32_as_i32(v1 / dd);
+    const signed char b0 = (signed char)(unsigned char)((unsigned)q0 & 0xffu), b1 = (signed char)(unsigned char)((unsigned)q1 & 0xffu);
+    const int qs = row16_sum_i32((int)b0 + (int)b1);
+    xq[e0] = b0;
+    xq[e0 + 1] = b1;
+    if (dp == 0) {
+      xd[e0 >> 5] = f2h(dd);
+      xisum[e0 >> 5] = qs;
     }
   }
 }
@@ -920,9 +1143,16 @@ struct crabml_hip_llama {
   float* am_val = nullptr;  // argmax partials
   int* am_idx = nullptr;
   size_t kv_len = 0;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  // [0]: one attention workgroup per head; [1]: the long-context attention kernels (from attn_long_from positions)
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t exec[2] = {nullptr, nullptr};
+  bool use_graph = false;
   bool capturing = false;
+  int attn_variant = 0;         // which of the two the next enqueue emits
+  bool attn_long_ok = false;    // f16 cache, head_dim % 32 == 0, group size in {1, 2, 4, 8}, seq_len % 8 == 0
+  size_t attn_long_from = 0;    // cached positions (pos + 1) from which variant 1 is used
+  float* scores_g = nullptr;    // [n_heads_l][seq_len] f32
+  unsigned short* p16 = nullptr;  // [n_heads_l][seq_len] f16 probabilities
   std::vector<std::pair<void*, size_t>> allocs;
 };
 
@@ -957,6 +1187,58 @@ ActPtrs act_ptrs(char* p, size_t n) {
 
 int n_segments(const crabml_hip_llama* c) { return 2 * (int)c->cfg.n_layers + 1; }
 
+// attention of layer l (llama2.rs:571-590): qbuf x KV cache -> attn (f32), plus its Q8_0 planes for wo when xq != NULL.
+// Emits the variant selected in c->attn_variant (0: one workgroup per head, 1: the long-context kernels).
+template <int G>
+void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, int* xisum, bool prof) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const int hd = c->hd, seq_cap = (int)c->cfg.seq_len, n_kv = c->n_kv_l;
+  const int* pos_d = c->state + 1;
+  const int ts = 256 / G, nsplit = (seq_cap + ts - 1) / ts;
+  crabml_hip_device::ProfRec r[3];
+  for (int i = 0; i < 3; i++)
+    if (prof) prof_begin(dev, &r[i], CRABML_HIP_F32, 7 + i, 0.0);  // stages 7 / 8 / 9: scores / softmax / pv
+  launch_k(st, prof ? &r[0] : nullptr, k_attn_scores<G>, dim3(n_kv * nsplit), dim3(256), (size_t)G * hd * sizeof(float),
+           (const float*)c->qbuf, (const unsigned short*)c->kc[l], pos_d, c->scores_g, n_kv, hd, seq_cap, nsplit);
+  launch_k(st, prof ? &r[1] : nullptr, k_attn_softmax, dim3(c->n_heads_l), dim3(256), (size_t)seq_cap * sizeof(float),
+           (const float*)c->scores_g, pos_d, (const unsigned short*)dev->exp_table, c->p16, seq_cap);
+  launch_k(st, prof ? &r[2] : nullptr, k_attn_pv<G>, dim3(n_kv * (hd / 32)), dim3(256), 0, (const unsigned short*)c->p16,
+           (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap);
+  for (int i = 0; i < 3; i++)
+    if (prof) prof_end(dev, &r[i]);
+}
+
+void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, int* xisum, const PrefetchPlan& pf,
+                       int spare, bool prof) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const int hd = c->hd, seq_cap = (int)c->cfg.seq_len, n_heads = c->n_heads_l, n_kv = c->n_kv_l;
+  const int* pos_d = c->state + 1;
+  if (c->attn_variant == 1) {
+    switch (n_heads / n_kv) {
+      case 1: launch_attn_long<1>(c, l, xq, xd, xisum, prof); break;
+      case 2: launch_attn_long<2>(c, l, xq, xd, xisum, prof); break;
+      case 4: launch_attn_long<4>(c, l, xq, xd, xisum, prof); break;
+      default: launch_attn_long<8>(c, l, xq, xd, xisum, prof); break;
+    }
+    return;
+  }
+  const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
+  crabml_hip_device::ProfRec ar{};
+  crabml_hip_device::ProfRec* AR = prof ? &ar : nullptr;
+  if (prof) prof_begin(dev, &ar, CRABML_HIP_F32, 7, 0.0);
+  if (c->cfg.use_f16_kv_cache)
+    launch_k(st, AR, k_attn<true>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
+             (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
+             seq_cap, pf);
+  else
+    launch_k(st, AR, k_attn<false>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
+             (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
+             seq_cap, pf);
+  if (prof) prof_end(dev, &ar);
+}
+
 // enqueue segment `seg` of one decode step on the device stream (see the banner above): the fused kernels
 // (fast mode, Q4_0 / Q8_0 weights)
 template <int FMT>
@@ -966,7 +1248,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   const auto& g = c->cfg;
   const int dim = (int)g.embedding_dim, hd = c->hd, seq_cap = (int)g.seq_len;
   const int dim_l = c->dim_l, kv_dim_l = c->kv_dim_l, hidden_l = c->hidden_l;
-  const int n_heads_l = c->n_heads_l, n_kv_l = c->n_kv_l;
+  const int n_heads_l = c->n_heads_l;
   const bool kv16 = g.use_f16_kv_cache != 0;
   const bool tp = c->tp > 1;
   const int L = (int)g.n_layers;
@@ -975,7 +1257,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   int* step_d = c->state + 2;
   ActPtrs ad = act_ptrs(c->act_dim, dim), aa = act_ptrs(c->act_attn, dim_l), ah = act_ptrs(c->act_hid, hidden_l);
   // measurement hook: only meaningful for eager launches (events cannot live inside the captured graph)
-  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing;
+  const bool prof = dev->prof_on && !c->use_graph && !c->capturing;
   const double blk_b = (double)block_bytes(c->wtype) / 32.0;  // weight bytes per element
   auto P0 = [&](crabml_hip_device::ProfRec* r, uint32_t stage, double rows, double k) {
     return prof ? prof_begin(dev, r, c->wtype, stage, rows * k * blk_b + 4.0 * k + 4.0 * rows) : 0;
@@ -1063,22 +1345,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
              planes_of(c->wv[l]), ad.view, dim / 32, e);
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
-    const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
     const bool attn_quant = (hd % 32) == 0;
-    const PrefetchPlan attn_pf = plan(c->wo[l], nullptr, nullptr);
     const int attn_spare = do_pf && dev->n_cu > n_heads_l ? dev->n_cu - n_heads_l : 0;
-    crabml_hip_device::ProfRec ar{};
-    crabml_hip_device::ProfRec* AR = prof ? &ar : nullptr;
-    if (prof) prof_begin(dev, &ar, CRABML_HIP_F32, 7, 0.0);
-    if (kv16)
-      launch_k(st, AR, k_attn<true>, dim3(n_heads_l + attn_spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
-               (const void*)c->vc[l], (const int*)pos_d, (const unsigned short*)dev->exp_table, c->attn,
-               attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, n_heads_l, n_kv_l, hd, seq_cap, attn_pf);
-    else
-      launch_k(st, AR, k_attn<false>, dim3(n_heads_l + attn_spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
-               (const void*)c->vc[l], (const int*)pos_d, (const unsigned short*)dev->exp_table, c->attn,
-               attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, n_heads_l, n_kv_l, hd, seq_cap, attn_pf);
-    if (prof) prof_end(dev, &ar);
+    enqueue_attention(c, l, attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, plan(c->wo[l], nullptr, nullptr), attn_spare, prof);
     if (!attn_quant) k_quant_q8_0_f<<<(dim_l + 255) / 256, 256, 0, st>>>(c->attn, aa.q, aa.d, aa.isum, dim_l / 32);
     // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
     CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
@@ -1108,7 +1377,6 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
   const auto& g = c->cfg;
   const int dim = (int)g.embedding_dim, hd = c->hd, seq_cap = (int)g.seq_len;
   const int dim_l = c->dim_l, kv_dim_l = c->kv_dim_l, hidden_l = c->hidden_l;
-  const int n_heads_l = c->n_heads_l, n_kv_l = c->n_kv_l;
   const bool kv16 = g.use_f16_kv_cache != 0;
   const bool strict = dev->strict_order;
   const bool tp = c->tp > 1;
@@ -1116,7 +1384,7 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
   int* token_d = c->state;
   int* pos_d = c->state + 1;
   int* step_d = c->state + 2;
-  const bool prof = dev->prof_on && c->exec == nullptr && !c->capturing && !strict;
+  const bool prof = dev->prof_on && !c->use_graph && !c->capturing && !strict;
   crabml_hip_device::ProfRec pr{};
   auto gemv = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out, uint32_t stage) -> int {
     if (strict) return launch_gemv_strict(dev, w, m, k, act, 1, out);
@@ -1167,14 +1435,7 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
     CH_TRY(gemv(c->wk[l], kv_dim_l, dim, act, c->tmp + dim_l, 1));
     CH_TRY(gemv(c->wv[l], kv_dim_l, dim, act, c->tmp + dim_l + kv_dim_l, 1));
     k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
-    const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
-    const PrefetchPlan nopf{};
-    if (kv16)
-      k_attn<true><<<n_heads_l, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn,
-                                                     nullptr, nullptr, nullptr, n_heads_l, n_kv_l, hd, seq_cap, nopf);
-    else
-      k_attn<false><<<n_heads_l, 256, attn_lds, st>>>(c->qbuf, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn,
-                                                      nullptr, nullptr, nullptr, n_heads_l, n_kv_l, hd, seq_cap, nopf);
+    enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
     const void* aact = quant(c->attn, dim_l, c->qt, c->act_attn);
     CH_TRY(gemv(c->wo[l], dim, dim_l, aact, c->tmp, 2));
     k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
@@ -1215,11 +1476,14 @@ int enqueue_step(crabml_hip_llama* c) {
   return 0;
 }
 
-int run_step(crabml_hip_llama* c) {
-  if (c->exec) {
-    CH_HIP(c->dev, hipGraphLaunch(c->exec, c->dev->stream));
+// one decode step at cache position `pos` (the host tracks it; the kernels read their own copy from device memory)
+int run_step(crabml_hip_llama* c, size_t pos) {
+  const int variant = c->attn_long_ok && pos + 1 >= c->attn_long_from ? 1 : 0;
+  if (c->use_graph && c->exec[variant]) {
+    CH_HIP(c->dev, hipGraphLaunch(c->exec[variant], c->dev->stream));
     return 0;
   }
+  c->attn_variant = variant;
   return enqueue_step(c);
 }
 
@@ -1407,6 +1671,16 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     A(g.embedding_dim * 4, (void**)&c->xn);
   }
   A(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2 * 4, (void**)&c->rope);
+  {
+    const size_t grp = n_heads_l / n_kv_l;
+    c->attn_long_ok = g.use_f16_kv_cache && hd % 32 == 0 && g.seq_len % 8 == 0 && (grp == 1 || grp == 2 || grp == 4 || grp == 8) &&
+                      !(g.flags & CRABML_HIP_LLAMA_NO_LONG_ATTENTION);
+    c->attn_long_from = g.attn_long_from ? g.attn_long_from : 224;  // measured crossover on MI355X (Llama-3-8B shape): ~200-220
+    if (c->attn_long_ok) {
+      A(n_heads_l * g.seq_len * 4, (void**)&c->scores_g);
+      A(n_heads_l * g.seq_len * 2, (void**)&c->p16);
+    }
+  }
   A(8 * sizeof(int), (void**)&c->state);
   A((g.embedding_dim / 32 + g.embedding_dim) * 8, (void**)&c->slots);
   c->norm_epi = !generic && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
@@ -1447,9 +1721,14 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   const bool want_graph = !(g.flags & CRABML_HIP_LLAMA_NO_GRAPH) &&
                           (tp == 1 || (c->comm != nullptr && (g.flags & CRABML_HIP_LLAMA_TP_GRAPH)));
   if (want_graph) {
-    hipError_t e = hipStreamBeginCapture(dev->stream, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
+    const int nvar = c->attn_long_ok ? 2 : 1;
+    bool ok = true;
+    for (int v = 0; v < nvar && ok; v++) {
+      ok = false;
+      hipError_t e = hipStreamBeginCapture(dev->stream, hipStreamCaptureModeThreadLocal);
+      if (e != hipSuccess) break;
       c->capturing = true;
+      c->attn_variant = v;
       int erc = enqueue_step(c);
       c->capturing = false;
       hipGraph_t graph = nullptr;
@@ -1457,8 +1736,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       if (erc == 0 && e2 == hipSuccess && graph) {
         hipGraphExec_t exec = nullptr;
         if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-          c->graph = graph;
-          c->exec = exec;
+          c->graph[v] = graph;
+          c->exec[v] = exec;
+          ok = true;
         } else {
           (void)hipGraphDestroy(graph);
         }
@@ -1467,7 +1747,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       }
     }
     (void)hipGetLastError();
-    if (!c->exec && tp == 1) {  // fail loudly: the caller asked for the graph path
+    c->use_graph = ok;
+    c->attn_variant = 0;
+    if (!ok && tp == 1) {  // fail loudly: the caller asked for the graph path
       crabml_hip_llama_destroy(c);
       CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: hipGraph capture/instantiate failed");
     }
@@ -1480,8 +1762,10 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
 int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
   if (!c) return 0;
   (void)hipStreamSynchronize(c->dev->stream);
-  if (c->exec) (void)hipGraphExecDestroy(c->exec);
-  if (c->graph) (void)hipGraphDestroy(c->graph);
+  for (int v = 0; v < 2; v++) {
+    if (c->exec[v]) (void)hipGraphExecDestroy(c->exec[v]);
+    if (c->graph[v]) (void)hipGraphDestroy(c->graph[v]);
+  }
   for (auto& a : c->allocs) pool_free(c->dev, a.first, a.second);
   for (auto* b : c->held) crabml_hip_buf_release(b);
   delete c;
@@ -1502,7 +1786,7 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, fl
   if (c->tp > 1 && !c->comm) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   CH_TRY(check_step(c, token, pos));
   CH_TRY(set_state(c, token, pos, 0));
-  CH_TRY(run_step(c));
+  CH_TRY(run_step(c, pos));
   c->kv_len++;
   if (logits) {
     int fault = 0;
@@ -1523,7 +1807,7 @@ int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: %zu steps do not fit the kv cache (%zu of %zu used)", n_steps, c->kv_len, c->cfg.seq_len);
   if (n_steps == 0) return 0;
   CH_TRY(set_state(c, token, c->kv_len, 0));
-  for (size_t s = 0; s < n_steps; s++) CH_TRY(run_step(c));
+  for (size_t s = 0; s < n_steps; s++) CH_TRY(run_step(c, c->kv_len + s));
   c->kv_len += n_steps;
   int fault = 0;
   CH_HIP(dev, hipMemcpyAsync(out_tokens, c->out_tokens, n_steps * 4, hipMemcpyDeviceToHost, dev->stream));
@@ -1549,6 +1833,7 @@ int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, siz
   SimPtrs ptrs{};
   for (int r = 0; r < n; r++) ptrs.p[r] = ranks[r]->partial;
   const int dim = (int)ranks[0]->cfg.embedding_dim;
+  for (int r = 0; r < n; r++) ranks[r]->attn_variant = ranks[r]->attn_long_ok && pos + 1 >= ranks[r]->attn_long_from ? 1 : 0;
   for (int s = 0; s < nseg; s++) {
     for (int r = 0; r < n; r++) CH_TRY(enqueue_segment(ranks[r], s));
     if (n > 1 && s + 1 < nseg) k_sim_allreduce<<<(dim + 255) / 256, 256, 0, dev->stream>>>(ptrs, n, dim);

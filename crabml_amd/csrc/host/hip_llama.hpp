@@ -43,7 +43,8 @@ class HipLlamaRunner {
  public:
   HipLlamaRunner(const LlamaConfig& conf, std::shared_ptr<LlamaWeights<HipTensor>> w, HipTensorDeviceRef device,
                  size_t seq_len, bool use_f16_kv_cache, bool use_graph = true, bool prefetch = true, int tp_size = 1,
-                 int tp_rank = 0, std::shared_ptr<TpComm> comm = nullptr, bool norm_epilogue = true, int extra_flags = 0)
+                 int tp_rank = 0, std::shared_ptr<TpComm> comm = nullptr, bool norm_epilogue = true, int extra_flags = 0,
+                 size_t attn_long_from = 0)
       : conf_(conf), weights_(std::move(w)), device_(std::move(device)), comm_(std::move(comm)), tp_size_(tp_size > 1 ? tp_size : 1) {
     crabml_hip_llama_config_t c{};
     c.embedding_dim = conf.embedding_dim;
@@ -61,6 +62,7 @@ class HipLlamaRunner {
     c.tp_size = tp_size;
     c.tp_rank = tp_rank;
     c.tp_comm = comm_ ? comm_->raw() : nullptr;
+    c.attn_long_from = attn_long_from;
     auto raws = [](const std::vector<HipTensor>& v) {
       std::vector<const crabml_hip_buf_t*> r;
       for (const auto& t : v) r.push_back(t.raw());

@@ -189,6 +189,7 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                               the wo / ffn_down epilogue; bit-identical either way) */
 #define CRABML_HIP_LLAMA_TP_GRAPH 8 /* tp_size > 1: capture the RCCL all-reduces into the hipGraph as well
                                        (default for tp: eager launches; falls back to eager if capture fails) */
+#define CRABML_HIP_LLAMA_NO_LONG_ATTENTION 64 /* A/B: one attention workgroup per head at every context length */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
@@ -204,6 +205,7 @@ typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
    * The weight buffers passed to crabml_hip_llama_create are the LOCAL shards. */
   int32_t tp_size, tp_rank;
   void* tp_comm; /* crabml_hip_tp_comm_t*; NULL with tp_size > 1 = a rank of the single-device simulation */
+  size_t attn_long_from; /* cached positions from which attention runs as the multi-workgroup kernels (0 = default 224) */
 } crabml_hip_llama_config_t;
 typedef struct crabml_hip_llama_weights { /* crabml-llama2/src/model.rs:55-84; per-layer arrays of n_layers */
   const crabml_hip_buf_t* token_embed;

@@ -171,3 +171,41 @@ def test_fused_errors(ca):
     r.decode_greedy(1, 4)
     with pytest.raises(ca.CrabmlError):
         r.decode_greedy(1, 1)  # cache full
+
+
+@pytest.mark.parametrize("shape,group", [("tiny-gqa", 4), ("15m", 1)])
+def test_long_context_attention_kernels_are_bit_identical(ca, shape, group):
+    """From `attn_long_from` cached positions the step switches to the multi-workgroup attention kernels (scores per
+    kv head and position split, softmax per head, PV per kv head and 32-dim slice on packed f16 math).  Same
+    rounding points, same orders: with the switch forced to position 1 every logit equals the one-workgroup-per-head
+    kernel's bit for bit, in fast mode, and the strict device stays bit-identical to the oracle across the switch."""
+    s = synth.SHAPES[shape]
+    assert s.n_heads // s.n_kv_heads == group
+    model = synth.build_model(s, synth.Q8_0, seed=41, n_layers=2)
+    rng = np.random.default_rng(5)
+    toks = [int(t) for t in rng.integers(0, s.vocab, size=40)]
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    one_wg = ca.HipLlamaRunner(conf, w, dev, 320, True, extra_flags=64)  # NO_LONG_ATTENTION
+    split = ca.HipLlamaRunner(conf, w, dev, 320, True, attn_long_from=1)
+    eager = ca.HipLlamaRunner(conf, w, dev, 320, True, False, attn_long_from=9)  # no graph; switches at position 8
+    for i, t in enumerate(toks):
+        a, b, c3 = one_wg.forward(t, i), split.forward(t, i), eager.forward(t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+        assert np.array_equal(a.view(np.uint32), c3.view(np.uint32)), f"eager step {i}"
+    # strict device vs the oracle, switch in the middle of the sequence, more than one PV tile (256 positions)
+    sdev = ca.HipTensorDevice(0, False, 0, True)
+    sconf, sw = synth.to_hip(model, sdev)
+    r = ca.HipLlamaRunner(sconf, sw, sdev, 320, True, attn_long_from=20)
+    n = 300
+    long_toks = [int(t) for t in rng.integers(0, s.vocab, size=n)]
+    odev = o.OracleDevice(thread_num=8)
+    oconf, ow = to_oracle(model, odev)
+    orr = o.OracleLlamaRunner(oconf, ow, odev, 320, True)
+    for i, t in enumerate(long_toks):
+        ref = orr.forward([t], i)
+        if i in (0, 18, 19, 20, 21, 63, 64, 255, 256, 257, n - 1):
+            got = r.forward(t, i)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"strict step {i}"
+        else:
+            r.forward_async(t, i)
