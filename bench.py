@@ -177,8 +177,10 @@ def main():
     t_build = time.perf_counter()
     model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers)
     dev = ca.HipTensorDevice(device_ordinal=local)
+    t_upload = time.perf_counter()
     conf, weights = synth.to_hip(model, dev)
     dev.sync()
+    t_upload = time.perf_counter() - t_upload
     t_build = time.perf_counter() - t_build
     seq_len = args.warmup + 2 * args.steps + 16
     gemv_bytes = model.gemv_weight_bytes_per_token()
@@ -298,7 +300,7 @@ def main():
             "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / gemv_bytes, 1),
             "frac_of_hbm_roofline_tokens": round(tps / args.gpus / (HBM_PEAK_GBS * 1e9 / gemv_bytes), 4),
             "effective_weight_GBps_per_gpu": round(tps / args.gpus * gemv_bytes / 1e9, 1),
-            "setup_s": round(t_build, 1),
+            "setup_s": round(t_build, 1), "upload_s": round(t_upload, 2),
         }
         if trait_tps is not None:
             out["trait_path_tokens_per_s"] = round(trait_tps, 2)

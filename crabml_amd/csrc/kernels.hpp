@@ -26,6 +26,10 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_
 // gemv_strict.hip: same contract, block terms added in the reference's scalar order (bit-exact; slow)
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out);
+// weight upload: split `n_blocks` GGUF blocks (`bb` bytes each: `hb` header bytes, then `qb` quant bytes, then an
+// ignored trailer) starting at block `blk0` into the quant plane and the header plane (byte moves only)
+void launch_repack(hipStream_t st, const void* raw, void* qs_plane, void* hdr_plane, size_t blk0, size_t n_blocks, int bb, int hb,
+                   int qb);
 void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out);
 
 // ---- elementwise.hip
