@@ -51,6 +51,9 @@ def parse():
                     help="trait = one launch per Tensor op (Llama2Runner unchanged); fused = fused decode step")
     ap.add_argument("--no-norm-epilogue", action="store_true", help="A/B: keep RMSNorm+quantize as its own launch")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: disable Infinity-Cache weight prefetch")
+    ap.add_argument("--tp-dry", type=int, default=0,
+                    help="measure ONE rank of a tensor-parallel group of this size with its all-reduces skipped "
+                         "(per-rank kernel time; not a tokens/s result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self test of the rank aggregation")
@@ -160,6 +163,38 @@ def cpu_baseline(model, steps_budget_s):
     }
 
 
+def tp_dry_run(args, ca, synth, local):
+    """One rank of a tensor-parallel group, all-reduces skipped: what the kernels of a rank cost per token.
+    NOT a tokens/s result (the collective is the other half, and is not measurable on a 1-GPU box)."""
+    from crabml_amd import tp as tp_mod
+
+    shape = synth.SHAPES[args.model]
+    wtype = synth.TYPE_BY_NAME[args.wtype]
+    n = args.tp_dry
+    tp_mod.check_tp(shape, n, wtype, True)
+    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=n)
+    dev = ca.HipTensorDevice(device_ordinal=local)
+    conf, weights = synth.to_hip(model, dev)
+    seq_len = args.warmup + args.steps + 16
+    r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=n, tp_rank=0, extra_flags=128)
+    r.decode_greedy(1, args.warmup)
+    dev.sync()
+    t0 = time.perf_counter()
+    r.decode_greedy(1, args.steps)
+    dev.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    local_bytes = sum(t.data.nbytes for name, t in model.tensors.items()
+                      if not name.endswith("_norm.weight") and name != "token_embd.weight")
+    print(json.dumps({
+        "measurement": "tensor-parallel dry run: one rank's kernels per token, all-reduces skipped",
+        "model": shape.name, "wtype": args.wtype, "tp_size": n, "ms_per_token_rank_kernels": round(ms, 4),
+        "rank_weight_bytes_per_token": local_bytes,
+        "rank_effective_GBps": round(local_bytes / ms / 1e6, 1),
+        "all_reduces_per_token": 2 * conf.n_layers, "all_reduce_bytes": shape.dim * 4,
+        "note": "not tokens/s: add 2 x n_layers all-reduces of dim x 4 bytes over xGMI (not measurable on one GPU)",
+    }))
+
+
 def main():
     args = parse()
     if args.selftest_dist:
@@ -172,6 +207,8 @@ def main():
     import crabml_amd as ca
     from crabml_amd import synth
 
+    if args.tp_dry > 1:
+        return tp_dry_run(args, ca, synth, local)
     shape = synth.SHAPES[args.model]
     wtype = synth.TYPE_BY_NAME[args.wtype]
     t_build = time.perf_counter()
@@ -258,7 +295,7 @@ def main():
             roof = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": pmc["hbm_bytes_per_launch"] if pmc and path == "fused" and args.wtype == "Q4_0" else None,
+                "traffic": pmc["hbm_bytes_per_launch"] if pmc and path == "fused" and args.wtype == "Q4_0" and args.model == "llama3-8b" else None,
                 "traffic_source": pmc["source"] if pmc else None,
                 "kernel": STAGES.get(dom["stage"], "?"),
                 "avg_launch_us": round(d_us, 3),
@@ -285,7 +322,7 @@ def main():
     if rank == 0:
         tps = total_tokens / elapsed_max
         out = {
-            "metric": "decode tokens/sec (batch-1 greedy), Llama-3-8B shape " + args.wtype,
+            "metric": f"decode tokens/sec (batch-1 greedy), {shape.name} shape {args.wtype}",
             "value": round(tps, 2), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

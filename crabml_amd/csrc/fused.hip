@@ -1134,6 +1134,7 @@ struct crabml_hip_llama {
   float* rope = nullptr;     // [seq_len][npairs][2]
   int* state = nullptr;      // token, pos, step, sink, serial (never reset), fault
   unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
+  bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
   bool generic = false;      // per-op launches (strict-order device, or a weight format without fused kernels)
   uint32_t qt = 0, out_qt = 0;  // vec_dot_rhs_dtype of the layer weights / of the classifier
   float* xn = nullptr;       // generic path: normalized residual (f32, dim)
@@ -1460,6 +1461,7 @@ int enqueue_segment(crabml_hip_llama* c, int seg) {
 
 int allreduce(crabml_hip_llama* c) {
   crabml_hip_device* dev = c->dev;
+  if (c->tp_dry) return 0;  // timing-only rank: the partial sums are left as they are
   Rccl* r = rccl();
   if (!r || !c->comm || !c->comm->nccl) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama tp: no RCCL communicator");
   int rc = r->AllReduce(c->partial, c->partial, c->cfg.embedding_dim, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm->nccl, dev->stream);
@@ -1613,6 +1615,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->tp = tp;
   c->tp_rank = g.tp_rank;
   c->comm = (crabml_hip_tp_comm*)g.tp_comm;
+  c->tp_dry = tp > 1 && !g.tp_comm && (g.flags & CRABML_HIP_LLAMA_TP_DRY_RUN);
   c->hd = (int)hd;
   c->npairs = (int)(g.rope_dim / 2);
   c->n_heads_l = (int)n_heads_l;
@@ -1719,7 +1722,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   // tp > 1 without a communicator = a rank of the single-device simulation: driven segment by segment, no graph.
   // tp > 1 over RCCL launches eagerly unless CRABML_HIP_LLAMA_TP_GRAPH asks for the collectives to be captured too.
   const bool want_graph = !(g.flags & CRABML_HIP_LLAMA_NO_GRAPH) &&
-                          (tp == 1 || (c->comm != nullptr && (g.flags & CRABML_HIP_LLAMA_TP_GRAPH)));
+                          (tp == 1 || c->tp_dry || (c->comm != nullptr && (g.flags & CRABML_HIP_LLAMA_TP_GRAPH)));
   if (want_graph) {
     const int nvar = c->attn_long_ok ? 2 : 1;
     bool ok = true;
@@ -1783,7 +1786,8 @@ static int check_step(crabml_hip_llama* c, size_t token, size_t pos) {
 int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, float* logits) {
   if (!c) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
-  if (c->tp > 1 && !c->comm) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
+  if (c->tp > 1 && !c->comm && !c->tp_dry)
+    CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   CH_TRY(check_step(c, token, pos));
   CH_TRY(set_state(c, token, pos, 0));
   CH_TRY(run_step(c, pos));
@@ -1801,7 +1805,8 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, fl
 int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n_steps, uint32_t* out_tokens) {
   if (!c || (!out_tokens && n_steps)) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
-  if (c->tp > 1 && !c->comm) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
+  if (c->tp > 1 && !c->comm && !c->tp_dry)
+    CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
   if (c->kv_len + n_steps > c->cfg.seq_len || n_steps > (size_t)c->out_cap)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: %zu steps do not fit the kv cache (%zu of %zu used)", n_steps, c->kv_len, c->cfg.seq_len);

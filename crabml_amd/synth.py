@@ -153,9 +153,11 @@ class RawModel:
 
 
 def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional[int] = None,
-                embed_type: Optional[int] = None) -> RawModel:
+                embed_type: Optional[int] = None, tp: int = 1) -> RawModel:
     """All-`wtype` synthetic Llama weights with GGUF tensor names (model.rs:228-283); norms are F32
-    (the loader dequantizes them, model.rs:267-282)."""
+    (the loader dequantizes them, model.rs:267-282).  tp > 1: the tensors get one rank's LOCAL shard shapes
+    (what crabml_amd.tp.shard_model would cut; random bytes either way -- for timing one rank of a large model
+    without materialising all of it)."""
     rng = np.random.default_rng(seed)
     L = shape.n_layers if n_layers is None else n_layers
     shp = ModelShape(**{**shape.__dict__, "n_layers": L})
@@ -170,14 +172,15 @@ def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional
         m.tensors[name] = RawTensor(w.view(np.uint8), [n], F32)
 
     add("token_embd.weight", shape.vocab, shape.dim, et, 4.0)
+    dim_l, kv_l, hid_l = shape.dim // tp, shape.kv_dim // tp, shape.hidden // tp
     for l in range(L):
-        add(f"blk.{l}.attn_q.weight", shape.dim, shape.dim, wtype)
-        add(f"blk.{l}.attn_k.weight", shape.kv_dim, shape.dim, wtype)
-        add(f"blk.{l}.attn_v.weight", shape.kv_dim, shape.dim, wtype)
-        add(f"blk.{l}.attn_output.weight", shape.dim, shape.dim, wtype)
-        add(f"blk.{l}.ffn_gate.weight", shape.hidden, shape.dim, wtype)
-        add(f"blk.{l}.ffn_down.weight", shape.dim, shape.hidden, wtype)
-        add(f"blk.{l}.ffn_up.weight", shape.hidden, shape.dim, wtype)
+        add(f"blk.{l}.attn_q.weight", dim_l, shape.dim, wtype)
+        add(f"blk.{l}.attn_k.weight", kv_l, shape.dim, wtype)
+        add(f"blk.{l}.attn_v.weight", kv_l, shape.dim, wtype)
+        add(f"blk.{l}.attn_output.weight", shape.dim, dim_l, wtype)
+        add(f"blk.{l}.ffn_gate.weight", hid_l, shape.dim, wtype)
+        add(f"blk.{l}.ffn_down.weight", shape.dim, hid_l, wtype)
+        add(f"blk.{l}.ffn_up.weight", hid_l, shape.dim, wtype)
         norm(f"blk.{l}.attn_norm.weight", shape.dim)
         norm(f"blk.{l}.ffn_norm.weight", shape.dim)
     norm("output_norm.weight", shape.dim)
