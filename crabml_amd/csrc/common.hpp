@@ -27,7 +27,7 @@ inline size_t block_elems(uint32_t t) {
   switch (t) {
     case CRABML_HIP_F32: case CRABML_HIP_F16: return 1;
     case CRABML_HIP_Q4_0: case CRABML_HIP_Q4_1: case CRABML_HIP_Q8_0: case CRABML_HIP_Q8_1: return 32;
-    case CRABML_HIP_Q4_K: case CRABML_HIP_Q8_K: return 256;
+    case CRABML_HIP_Q4_K: case CRABML_HIP_Q6_K: case CRABML_HIP_Q8_K: return 256;
     default: return 0;
   }
 }
@@ -40,6 +40,7 @@ inline size_t block_bytes(uint32_t t) {
     case CRABML_HIP_Q8_0: return 34;
     case CRABML_HIP_Q8_1: return 36;
     case CRABML_HIP_Q4_K: return 144;
+    case CRABML_HIP_Q6_K: return 210;
     case CRABML_HIP_Q8_K: return 292;
     default: return 0;
   }
@@ -51,7 +52,7 @@ inline uint32_t vec_dot_rhs_dtype(uint32_t t) {
     case CRABML_HIP_F16: return CRABML_HIP_F16;
     case CRABML_HIP_Q8_0: case CRABML_HIP_Q4_0: return CRABML_HIP_Q8_0;
     case CRABML_HIP_Q8_1: case CRABML_HIP_Q4_1: return CRABML_HIP_Q8_1;
-    case CRABML_HIP_Q8_K: case CRABML_HIP_Q4_K: return CRABML_HIP_Q8_K;
+    case CRABML_HIP_Q8_K: case CRABML_HIP_Q4_K: case CRABML_HIP_Q6_K: return CRABML_HIP_Q8_K;
     default: return 0xffffffffu;
   }
 }
@@ -67,6 +68,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //   Q8_0: qs[n][32]            | d[n] f16
 //   Q4_1: qs[n][16]            | dm[n] (d f16, m f16)
 //   Q4_K: qs[n][128]           | hdr[n][16] (d f16, dmin f16, scales[12]: the block's first 16 bytes)
+//   Q6_K: ql[n][128]           | qh[n][64] | scales[n][16] | d[n] f16   (off_scale = n * 128 exactly, so the
+//                                kernels derive the other three plane offsets from it)
 //   Q8_K: qs[n][256]           | d[n] f32            (bsums are derived data; not kept for weights)
 // Quantized ACTIVATIONS (the rhs of matmul_vec) live in a per-buffer scratch, also as planes:
 //   Q8_0: qs[n] i8 | d[n/32] f16 | isum[n/32] i32 (sum of the 32 quants; exact, derived)

@@ -59,6 +59,20 @@ __device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dt
       v = d1 * qf - m1;
       break;
     }
+    case CRABML_HIP_Q6_K: {  // buf_q6_k.rs:21-48; planes ql | qh | scales | d with n = off_scale / 128 blocks
+      const size_t n = off_scale / 128, sb = e / 256;
+      const int j = (int)(e % 256), idx = j / 128, r = j % 128, l = r % 32, quarter = r / 32;
+      const unsigned char* ql = (const unsigned char*)w + sb * 128 + 64 * idx;
+      const unsigned char* qh = (const unsigned char*)w + off_scale + sb * 64 + 32 * idx;
+      const signed char* sc = (const signed char*)w + off_scale + n * 64 + sb * 16 + 8 * idx;
+      const float d = h2f(((const unsigned short*)(w + off_scale + n * 80))[sb]);
+      const unsigned char lo = quarter & 1 ? ql[l + 32] : ql[l];
+      const int nib = quarter >= 2 ? (lo >> 4) : (lo & 0xF);
+      const int hi2 = (qh[l] >> (2 * quarter)) & 3;
+      const int q = (nib | (hi2 << 4)) - 32;
+      v = d * (float)sc[l / 16 + 2 * quarter] * (float)q;
+      break;
+    }
     case CRABML_HIP_Q8_K: {
       size_t sb = e / 256;
       float d = ((const float*)(w + off_scale))[sb];

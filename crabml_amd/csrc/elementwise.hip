@@ -230,29 +230,29 @@ void launch_dequant_row(hipStream_t st, const crabml_hip_buf* src, size_t start,
 }
 
 // ---- weight upload: GGUF blocks -> planes -------------------------------------------------------------------
-// One thread per 2-byte unit (every block size, header size and quant size of the supported formats is even, so
-// are all offsets).  Pure byte moves; runs once per tensor behind the host-to-device copy of the raw bytes.
-__global__ __launch_bounds__(256) void k_repack(const unsigned short* __restrict__ raw, unsigned short* __restrict__ qs,
-                                                unsigned short* __restrict__ hdr, size_t blk0, size_t n_blocks, int bb2, int hb2,
-                                                int qb2) {
-  const int upb = hb2 + qb2;  // 2-byte units moved per block
+// One thread per 2-byte unit (every block size, piece offset and piece length of the supported formats is even).
+// Pure byte moves; runs once per tensor behind the host-to-device copy of the raw bytes.
+__global__ __launch_bounds__(256) void k_repack(const unsigned short* __restrict__ raw, unsigned short* __restrict__ base,
+                                                size_t blk0, size_t n_blocks, int bb2, RepackPlan plan) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n_blocks * (size_t)upb) return;
-  const size_t b = u / upb;
-  const int o = (int)(u - b * upb);
-  const unsigned short v = raw[b * bb2 + o];
-  if (o < hb2)
-    hdr[(blk0 + b) * hb2 + o] = v;
-  else
-    qs[(blk0 + b) * qb2 + (o - hb2)] = v;
+  if (u >= n_blocks * (size_t)bb2) return;
+  const size_t b = u / bb2;
+  const int o = (int)(u - b * bb2);
+  const unsigned short v = raw[u];
+  for (int s = 0; s < plan.nseg; s++) {
+    const int r = o - plan.src_off2[s];
+    if (r >= 0 && r < plan.len2[s]) {
+      base[plan.dst_off[s] / 2 + (blk0 + b) * plan.len2[s] + r] = v;
+      return;
+    }
+  }
 }
 
-void launch_repack(hipStream_t st, const void* raw, void* qs_plane, void* hdr_plane, size_t blk0, size_t n_blocks, int bb, int hb,
-                   int qb) {
+void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, size_t n_blocks, int bb, const RepackPlan& plan) {
   if (n_blocks == 0) return;
-  const size_t units = n_blocks * (size_t)((hb + qb) / 2);
-  k_repack<<<(unsigned)((units + 255) / 256), 256, 0, st>>>((const unsigned short*)raw, (unsigned short*)qs_plane,
-                                                            (unsigned short*)hdr_plane, blk0, n_blocks, bb / 2, hb / 2, qb / 2);
+  const size_t units = n_blocks * (size_t)(bb / 2);
+  k_repack<<<(unsigned)((units + 255) / 256), 256, 0, st>>>((const unsigned short*)raw, (unsigned short*)base, blk0, n_blocks,
+                                                            bb / 2, plan);
 }
 
 }  // namespace crabml_hip

@@ -4,6 +4,7 @@
 // crabml-core/src/cpu/buf/api.rs:230-249) and the per-format vec_dot_* kernels:
 //   Q4_0 x Q8_0  buf_q4_0.rs:240-253      Q8_0 x Q8_0  buf_q8_0.rs:275-286
 //   Q4_1 x Q8_1  buf_q4_1.rs:266-280      Q4_K x Q8_K  buf_q4_k.rs:192-277      Q8_K x Q8_K  buf_q8_k.rs:211-224
+//   Q6_K x Q8_K  buf_q6_k.rs:183-234
 //   F32 x F32    buf_f32.rs:19-27         F16 x F16    buf_f16.rs:83-97
 //
 // Mapping (chosen by measurement, profiles/r01_gemv_lab_layout_sweep.log): one wavefront owns R
@@ -195,6 +196,74 @@ __global__ __launch_bounds__(256) void k_gemv_q4_k(const i32x4* __restrict__ wq,
   }
 }
 
+// ---- Q6_K x Q8_K ---------------------------------------------------------------------------------
+// planes: ql[n][128] | qh[n][64] | scales[n][16] | d[n] (common.hpp).  A lane owns one 16-byte ql piece (8 lanes
+// per super-block: one aligned 1 KiB request per wave): piece (h, a, p) = ql[64 h + 32 a + 16 p .. +16) holds the low
+// 4 bits of two 16-element scale groups -- low nibbles: elements 128 h + 32 a + 16 p + [0, 16), high nibbles: the
+// same + 64 -- and the matching 2-bit planes sit in qh[32 h + 16 p .. +16) at bit 2 a and 2 a + 4
+// (buf_q6_k.rs:21-48).  6-bit values are rebuilt as bytes for v_dot4; the -32 offset is applied as -32 * bsum.
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_q6_k(const char* __restrict__ w, size_t off_qh, ActQ8_K act,
+                                                   float* __restrict__ out, int m, int nsb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  const size_t n = off_qh / 128;  // blocks in the tensor
+  const i32x4* wql = (const i32x4*)w;
+  const i32x4* wqh = (const i32x4*)(w + off_qh);
+  const char* wsc = w + off_qh + n * 64;
+  const unsigned short* wd = (const unsigned short*)(w + off_qh + n * 80);
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int npieces = nsb * 8;
+  for (int c = lane; c < npieces; c += 64) {
+    const int sb = c >> 3, h = (c >> 2) & 1, a = (c >> 1) & 1, p = c & 1;
+    const int gi = 8 * h + p + 2 * a;  // scale group of the low nibbles; the high nibbles' group is gi + 4
+    i32x4 qv[R], hv[R];
+    unsigned scw[R];
+    unsigned short dw[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      const size_t blk = (size_t)row * nsb + sb;
+      qv[r] = __builtin_nontemporal_load(wql + blk * 8 + (c & 7));
+      hv[r] = __builtin_nontemporal_load(wqh + blk * 4 + 2 * h + p);
+      const signed char* sp = (const signed char*)wsc + blk * 16 + gi;
+      scw[r] = (unsigned)(unsigned char)sp[0] | ((unsigned)(unsigned char)sp[4] << 8);
+      dw[r] = wd[blk];
+    }
+    const i32x4* xq = act.q + (size_t)sb * 16 + gi;  // 16 int8 per group
+    const i32x4 xl = xq[0], xh = xq[4];
+    const float d8 = act.d[sb];
+    const short* bs = act.bsums + sb * 16 + gi;
+    const int bs_lo = (int)bs[0], bs_hi = (int)bs[4];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int lo = 0, hi = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = (unsigned)qv[r][i], hb = (unsigned)hv[r][i] >> (2 * a);
+        const unsigned ql4 = (q & 0x0F0F0F0Fu) | ((hb & 0x03030303u) << 4);
+        const unsigned qh4 = ((q >> 4) & 0x0F0F0F0Fu) | (((hb >> 4) & 0x03030303u) << 4);
+        lo = __builtin_amdgcn_sdot4((int)ql4, xl[i], lo, false);
+        hi = __builtin_amdgcn_sdot4((int)qh4, xh[i], hi, false);
+      }
+      lo -= 32 * bs_lo;  // sum (q6 - 32) * q8, exact
+      hi -= 32 * bs_hi;
+      const int sc_lo = (int)(signed char)(scw[r] & 0xffu), sc_hi = (int)(signed char)(scw[r] >> 8);
+      const float dd = h2f(dw[r]) * d8;
+      acc[r] += dd * ((float)(sc_lo * lo) + (float)(sc_hi * hi));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
 // ---- Q8_K x Q8_K ---------------------------------------------------------------------------------
 // planes: qs[n][256] | d[n] f32.  A lane owns one 32-element group; the 8 lanes of a super-block add
 // their integer partials (exact) before the single f32 scaling `sum_i as f32 * d_a * d_b`.
@@ -333,6 +402,17 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         });
         break;
       }
+      case CRABML_HIP_Q6_K: {
+        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const int nsb = k / 256;
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            launch_k(st, rec, k_gemv_q6_k<2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, a, o, m, nsb);
+          else
+            launch_k(st, rec, k_gemv_q6_k<1>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, a, o, m, nsb);
+        });
+        break;
+      }
       case CRABML_HIP_Q8_K: {
         ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
         const int nsb = k / 256;
@@ -400,12 +480,38 @@ __global__ void k_block_dots_k(const unsigned char* __restrict__ w, int wtype, A
   }
 }
 
+// Q6_K: the exact integer part per 16-element scale group, sum (q6 - 32) * q8, through the production unpack
+__global__ void k_block_dots_q6k(const char* __restrict__ w, size_t off_qh, ActQ8_K act, size_t row_sb0, int nsb,
+                                 int* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // ql piece
+  if (c >= nsb * 8) return;
+  const int sb = c >> 3, h = (c >> 2) & 1, a = (c >> 1) & 1, p = c & 1;
+  const int gi = 8 * h + p + 2 * a;
+  const size_t blk = row_sb0 + sb;
+  const i32x4 qv = ((const i32x4*)w)[blk * 8 + (c & 7)];
+  const i32x4 hv = ((const i32x4*)(w + off_qh))[blk * 4 + 2 * h + p];
+  const i32x4* xq = act.q + (size_t)sb * 16 + gi;
+  const i32x4 xl = xq[0], xh = xq[4];
+  int lo = 0, hi = 0;
+  for (int i = 0; i < 4; i++) {
+    const unsigned q = (unsigned)qv[i], hb = (unsigned)hv[i] >> (2 * a);
+    lo = __builtin_amdgcn_sdot4((int)((q & 0x0F0F0F0Fu) | ((hb & 0x03030303u) << 4)), xl[i], lo, false);
+    hi = __builtin_amdgcn_sdot4((int)(((q >> 4) & 0x0F0F0F0Fu) | (((hb >> 4) & 0x03030303u) << 4)), xh[i], hi, false);
+  }
+  out[sb * 16 + gi] = lo - 32 * (int)act.bsums[sb * 16 + gi];
+  out[sb * 16 + gi + 4] = hi - 32 * (int)act.bsums[sb * 16 + gi + 4];
+}
+
 void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out) {
   const char* wp = (const char*)w->ptr;
   const char* ap = (const char*)act;
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   const ActLayout al = act_layout(qt, k);
-  if (w->dtype == CRABML_HIP_Q4_K || w->dtype == CRABML_HIP_Q8_K) {
+  if (w->dtype == CRABML_HIP_Q6_K) {
+    ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+    int nsb = (int)(k / 256);
+    k_block_dots_q6k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, a, row * nsb, nsb, out);
+  } else if (w->dtype == CRABML_HIP_Q4_K || w->dtype == CRABML_HIP_Q8_K) {
     ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
     int nsb = (int)(k / 256);
     k_block_dots_k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>((const unsigned char*)wp, (int)w->dtype, a, row * nsb, nsb, out);

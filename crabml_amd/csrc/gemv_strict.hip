@@ -114,6 +114,40 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
       for (int l = 0; l < 8; l++) sumf += sums[l];
       break;
     }
+    case CRABML_HIP_Q6_K: {  // buf_q6_k.rs:183-234: eight f32 lanes, element e feeds lane e % 8, blocks in order
+      const int nsb = k / 256;
+      const size_t n = off_scale / 128;
+      const float* xd = (const float*)(act + off_d);
+      float sums[8];
+      for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+      for (int sb = 0; sb < nsb; sb++) {
+        const size_t blk = (size_t)row * nsb + sb;
+        const unsigned char* ql = (const unsigned char*)w + blk * 128;
+        const unsigned char* qh = (const unsigned char*)w + off_scale + blk * 64;
+        const signed char* sc = (const signed char*)w + off_scale + n * 64 + blk * 16;
+        const signed char* q8 = (const signed char*)act + (size_t)sb * 256;
+        float aux32[8];
+        for (int l = 0; l < 8; l++) aux32[l] = 0.0f;
+        for (int j = 0; j < 16; j++) {
+          const float scale = (float)sc[j];
+          for (int half8 = 0; half8 < 2; half8++)
+            for (int l = 0; l < 8; l++) {
+              const int e = 16 * j + 8 * half8 + l;  // element within the super-block
+              const int idx = e / 128, r = e % 128, lq = r % 32, quarter = r / 32;
+              const unsigned char lo = (quarter & 1) ? ql[64 * idx + lq + 32] : ql[64 * idx + lq];
+              const int nib = quarter >= 2 ? (lo >> 4) : (lo & 0xF);
+              const int hi2 = (qh[32 * idx + lq] >> (2 * quarter)) & 3;
+              const int a8 = (nib | (hi2 << 4)) - 32;
+              const int prod = (int)q8[e] * a8;  // aux16
+              aux32[l] += scale * (float)prod;
+            }
+        }
+        const float d = h2f(((const unsigned short*)(w + off_scale + n * 80))[blk]) * xd[sb];
+        for (int l = 0; l < 8; l++) sums[l] += aux32[l] * d;
+      }
+      for (int l = 0; l < 8; l++) sumf += sums[l];
+      break;
+    }
     case CRABML_HIP_Q8_K: {
       const int nsb = k / 256;
       const float* wd = (const float*)(w + off_scale);

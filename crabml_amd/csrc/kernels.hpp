@@ -26,10 +26,15 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_
 // gemv_strict.hip: same contract, block terms added in the reference's scalar order (bit-exact; slow)
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out);
-// weight upload: split `n_blocks` GGUF blocks (`bb` bytes each: `hb` header bytes, then `qb` quant bytes, then an
-// ignored trailer) starting at block `blk0` into the quant plane and the header plane (byte moves only)
-void launch_repack(hipStream_t st, const void* raw, void* qs_plane, void* hdr_plane, size_t blk0, size_t n_blocks, int bb, int hb,
-                   int qb);
+// weight upload: scatter the pieces of `n_blocks` GGUF blocks (`bb` bytes each) starting at block `blk0` into their
+// planes (byte moves only).  Piece s = bytes [2 src_off2, 2 src_off2 + 2 len2) of a block -> base + dst_off[s],
+// packed per block; bytes covered by no piece are dropped.
+struct RepackPlan {
+  int nseg;
+  int src_off2[4], len2[4];
+  size_t dst_off[4];
+};
+void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, size_t n_blocks, int bb, const RepackPlan& plan);
 void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out);
 
 // ---- elementwise.hip

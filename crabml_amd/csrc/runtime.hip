@@ -44,6 +44,7 @@ WeightLayout weight_layout(uint32_t dtype, size_t n_elems) {
     case CRABML_HIP_Q8_0: wl.off_scale = align_up(n * 32, 256); wl.total = wl.off_scale + n * 2; break;
     case CRABML_HIP_Q4_1: wl.off_scale = align_up(n * 16, 256); wl.total = wl.off_scale + n * 4; break;
     case CRABML_HIP_Q4_K: wl.off_scale = align_up(n * 128, 256); wl.total = wl.off_scale + n * 16; break;
+    case CRABML_HIP_Q6_K: wl.off_scale = n * 128; wl.total = align_up(n * 210, 256); break;
     case CRABML_HIP_Q8_K: wl.off_scale = align_up(n * 256, 256); wl.total = wl.off_scale + n * 4; break;
     default: wl.total = 0;
   }
@@ -337,13 +338,23 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
     // touches the bytes (tools/upload_lab.hip: pageable hipMemcpyAsync in 128 MiB chunks runs at 56 GB/s on this box,
     // the PCIe rate; registering the range first or an own pinned ring are slower), and the two staging buffers
     // ping-pong so the re-layout of chunk i overlaps the copy of chunk i + 1.
-    int hb = 0, qb = 0;
+    // per format: where each piece of a GGUF block goes (source offset, length, destination plane offset)
+    RepackPlan plan{};
+    auto seg = [&](int src_off, int len, size_t dst_off) {
+      plan.src_off2[plan.nseg] = src_off / 2;
+      plan.len2[plan.nseg] = len / 2;
+      plan.dst_off[plan.nseg] = dst_off;
+      plan.nseg++;
+    };
     switch (t) {
-      case CRABML_HIP_Q4_0: hb = 2; qb = 16; break;
-      case CRABML_HIP_Q8_0: hb = 2; qb = 32; break;
-      case CRABML_HIP_Q4_1: hb = 4; qb = 16; break;
-      case CRABML_HIP_Q4_K: hb = 16; qb = 128; break;
-      case CRABML_HIP_Q8_K: hb = 4; qb = 256; break;  // the trailing bsums are derived data: dropped
+      case CRABML_HIP_Q4_0: seg(0, 2, wl.off_scale); seg(2, 16, 0); break;
+      case CRABML_HIP_Q8_0: seg(0, 2, wl.off_scale); seg(2, 32, 0); break;
+      case CRABML_HIP_Q4_1: seg(0, 4, wl.off_scale); seg(4, 16, 0); break;
+      case CRABML_HIP_Q4_K: seg(0, 16, wl.off_scale); seg(16, 128, 0); break;
+      case CRABML_HIP_Q6_K:  // ql | qh | scales | d (buf_q6_k.rs:11-18)
+        seg(0, 128, 0); seg(128, 64, wl.off_scale); seg(192, 16, wl.off_scale + nblk * 64); seg(208, 2, wl.off_scale + nblk * 80);
+        break;
+      case CRABML_HIP_Q8_K: seg(0, 4, wl.off_scale); seg(4, 256, 0); break;  // the trailing bsums are derived data: dropped
       default: break;
     }
     const size_t chunk_blocks = nblk < ((size_t)128 << 20) / bb ? nblk : ((size_t)128 << 20) / bb;
@@ -362,7 +373,7 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
         e = hipEventSynchronize(done[slot]);  // the re-layout that last read this staging buffer has finished
         if (e == hipSuccess) e = hipMemcpyAsync(stage[slot], src + b0 * bb, nb * bb, hipMemcpyHostToDevice, dev->stream);
         if (e != hipSuccess) break;
-        launch_repack(dev->stream, stage[slot], b->ptr, (char*)b->ptr + wl.off_scale, b0, nb, (int)bb, hb, qb);
+        launch_repack(dev->stream, stage[slot], b->ptr, b0, nb, (int)bb, plan);
         e = hipEventRecord(done[slot], dev->stream);
       }
       if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
@@ -760,7 +771,7 @@ int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t
   CH_TRY(need_f32(dev, x, k, "debug_block_dots rhs"));
   const void* act = nullptr;
   CH_TRY(ensure_act(dev, x, 1, k, qt, &act));
-  size_t n = k / 32;
+  size_t n = w->dtype == CRABML_HIP_Q6_K ? k / 16 : k / 32;  // Q6_K: one value per 16-element scale group
   void* d = nullptr;
   size_t cap = 0;
   CH_TRY(pool_alloc(dev, n * 4, &d, &cap));

@@ -12,10 +12,10 @@ from typing import Dict, List, Optional
 
 import numpy as np
 
-F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 15
-BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q8_K: 256}
-BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q8_K: 292}
-TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q4_K: "Q4_K", Q8_K: "Q8_K"}
+F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q6_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 14, 15
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q6_K: 256, Q8_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q6_K: 210, Q8_K: 292}
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q4_K: "Q4_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
 TYPE_BY_NAME = {v: k for k, v in TYPE_NAMES.items()}
 
 
@@ -80,6 +80,10 @@ def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: f
         out[:, 0:2] = _f16_scales(rng, nb, lo / 32, hi / 32).reshape(nb, 1).view(np.uint8)
         out[:, 2:4] = _f16_scales(rng, nb, lo / 4, hi / 4).reshape(nb, 1).view(np.uint8)
         out[:, 4:] = rng.integers(0, 256, size=(nb, 140), dtype=np.uint8)  # 6-bit scales/mins + nibbles
+    elif typ == Q6_K:  # ql[128] | qh[64] | scales i8[16] | d f16 (buf_q6_k.rs:11-18)
+        out[:, 0:192] = rng.integers(0, 256, size=(nb, 192), dtype=np.uint8)
+        out[:, 192:208] = rng.integers(-64, 64, size=(nb, 16), dtype=np.int8).view(np.uint8)
+        out[:, 208:210] = _f16_scales(rng, nb, lo / 256, hi / 256).reshape(nb, 1).view(np.uint8)
     elif typ == Q8_K:
         out[:, 0:4] = rng.uniform(lo / 8, hi / 8, size=nb).astype(np.float32).reshape(nb, 1).view(np.uint8)
         q = rng.integers(-127, 128, size=(nb, 256), dtype=np.int8)
@@ -153,7 +157,7 @@ class RawModel:
 
 
 def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional[int] = None,
-                embed_type: Optional[int] = None, tp: int = 1) -> RawModel:
+                embed_type: Optional[int] = None, tp: int = 1, output_type: Optional[int] = None) -> RawModel:
     """All-`wtype` synthetic Llama weights with GGUF tensor names (model.rs:228-283); norms are F32
     (the loader dequantizes them, model.rs:267-282).  tp > 1: the tensors get one rank's LOCAL shard shapes
     (what crabml_amd.tp.shard_model would cut; random bytes either way -- for timing one rank of a large model
@@ -184,7 +188,8 @@ def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional
         norm(f"blk.{l}.attn_norm.weight", shape.dim)
         norm(f"blk.{l}.ffn_norm.weight", shape.dim)
     norm("output_norm.weight", shape.dim)
-    add("output.weight", shape.vocab, shape.dim, wtype)
+    # llama.cpp's "Q4_0" / "Q4_K_M" files keep output.weight in Q6_K: `output_type` builds that mix
+    add("output.weight", shape.vocab, shape.dim, wtype if output_type is None else output_type)
     return m
 
 
@@ -193,7 +198,7 @@ def to_hip(model: RawModel, device):
     import crabml_amd as ca
 
     tmap = {F32: ca.GGMLType.F32, F16: ca.GGMLType.F16, Q4_0: ca.GGMLType.Q4_0, Q4_1: ca.GGMLType.Q4_1,
-            Q8_0: ca.GGMLType.Q8_0, Q4_K: ca.GGMLType.Q4K, Q8_K: ca.GGMLType.Q8K}
+            Q8_0: ca.GGMLType.Q8_0, Q4_K: ca.GGMLType.Q4K, Q6_K: ca.GGMLType.Q6K, Q8_K: ca.GGMLType.Q8K}
     s = model.shape
 
     def up(name):

@@ -55,6 +55,7 @@ typedef enum crabml_hip_ggml_type {
   CRABML_HIP_Q8_0 = 8,
   CRABML_HIP_Q8_1 = 9,
   CRABML_HIP_Q4_K = 12,
+  CRABML_HIP_Q6_K = 14, /* weights only (rhs: Q8_K), crabml-core/src/cpu/buf/buf_q6_k.rs */
   CRABML_HIP_Q8_K = 15
 } crabml_hip_ggml_type;
 
@@ -92,7 +93,7 @@ size_t crabml_hip_device_mem_in_use(crabml_hip_device_t* dev);
 
 /* ---- buffers ----------------------------------------------------------------------------- */
 /* Tensor::from_cpu (api.rs:14-19): uploads `nbytes` of GGML-layout bytes.  Accepts F32, F16,
- * Q8_0, Q4_0, Q4_1, Q4_K, Q8_K.  Quantized tensors must be 2-D (m, k) (or 1-D) with k a multiple
+ * Q8_0, Q4_0, Q4_1, Q4_K, Q6_K, Q8_K.  Quantized tensors must be 2-D (m, k) (or 1-D) with k a multiple
  * of the block size; they are re-laid-out once at upload into 16-byte-aligned planes (quants /
  * scales) -- the unpacked integers and scales are bit-identical to the GGUF bytes. */
 int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t nbytes, const size_t* shape,

@@ -112,7 +112,7 @@ size_t co_block_elems(uint32_t t) {
   switch (t) {
     case CO_F32: case CO_F16: return 1;
     case CO_Q4_0: case CO_Q4_1: case CO_Q8_0: case CO_Q8_1: return 32;
-    case CO_Q4_K: case CO_Q8_K: return 256;
+    case CO_Q4_K: case CO_Q6_K: case CO_Q8_K: return 256;
     default: return 0;
   }
 }
@@ -125,6 +125,7 @@ size_t co_block_bytes(uint32_t t) {
     case CO_Q8_0: return sizeof(co_block_q8_0);
     case CO_Q8_1: return sizeof(co_block_q8_1);
     case CO_Q4_K: return sizeof(co_block_q4_k);
+    case CO_Q6_K: return sizeof(co_block_q6_k);
     case CO_Q8_K: return sizeof(co_block_q8_k);
     default: return 0;
   }
@@ -135,7 +136,7 @@ uint32_t co_vec_dot_rhs_dtype(uint32_t t) { /* buf/api.rs:142-159 */
     case CO_F16: return CO_F16;
     case CO_Q8_0: case CO_Q4_0: return CO_Q8_0;
     case CO_Q8_1: case CO_Q4_1: return CO_Q8_1;
-    case CO_Q8_K: case CO_Q4_K: return CO_Q8_K;
+    case CO_Q8_K: case CO_Q4_K: case CO_Q6_K: return CO_Q8_K;
     default: return 0xffffffffu;
   }
 }
@@ -393,6 +394,7 @@ int co_quantize(const float* x, size_t n, uint32_t type, void* out) {
     case CO_Q4_0: co_quantize_f32_q4_0(x, n, (co_block_q4_0*)out); return 0;
     case CO_Q4_1: co_quantize_f32_q4_1(x, n, (co_block_q4_1*)out); return 0;
     case CO_Q4_K: co_quantize_f32_q4_k(x, n, (co_block_q4_k*)out); return 0;
+    case CO_Q6_K: co_quantize_f32_q6_k(x, n, (co_block_q6_k*)out); return 0;
     default: return -1;
   }
 }
@@ -449,6 +451,27 @@ static void dq_q8_k(const co_block_q8_k* b, float* o) { /* buf_q8_k.rs:15-20 */
   for (int i = 0; i < 256; i++) o[i] = b->d * (float)b->qs[i];
 }
 
+static void dq_q6_k(const co_block_q6_k* b, float* o) { /* buf_q6_k.rs:21-48 */
+  const float d = co_f16_to_f32(b->d);
+  for (int idx = 0; idx < 2; idx++) {
+    float* buf = o + 128 * idx;
+    const int8_t* sc = b->scales + 8 * idx;
+    const uint8_t* ql = b->ql + 64 * idx;
+    const uint8_t* qh = b->qh + 32 * idx;
+    for (int l = 0; l < 32; l++) {
+      int is = l / 16;
+      int8_t q1 = (int8_t)((int8_t)((ql[l] & 0xF) | ((qh[l] & 3) << 4)) - 32);
+      int8_t q2 = (int8_t)((int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32);
+      int8_t q3 = (int8_t)((int8_t)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32);
+      int8_t q4 = (int8_t)((int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32);
+      buf[l] = d * (float)sc[is] * (float)q1; /* left to right: (d * scale) * q */
+      buf[l + 32] = d * (float)sc[is + 2] * (float)q2;
+      buf[l + 64] = d * (float)sc[is + 4] * (float)q3;
+      buf[l + 96] = d * (float)sc[is + 6] * (float)q4;
+    }
+  }
+}
+
 int co_dequantize(const void* blocks, uint32_t type, size_t start, size_t n, float* out) {
   size_t be = co_block_elems(type);
   if (be == 0) return -1;
@@ -473,6 +496,7 @@ int co_dequantize(const void* blocks, uint32_t type, size_t start, size_t n, flo
       case CO_Q4_1: dq_q4_1((const co_block_q4_1*)blk, tmp); break;
       case CO_Q8_1: dq_q8_1((const co_block_q8_1*)blk, tmp); break;
       case CO_Q4_K: dq_q4_k((const co_block_q4_k*)blk, tmp); break;
+      case CO_Q6_K: dq_q6_k((const co_block_q6_k*)blk, tmp); break;
       case CO_Q8_K: dq_q8_k((const co_block_q8_k*)blk, tmp); break;
       default: return -1;
     }
@@ -586,6 +610,212 @@ float co_vec_dot_q4_k_q8_k(const co_block_q4_k* a, const co_block_q8_k* b, size_
   }
   for (int l = 0; l < 8; l++) sumf += sums[l];
   return sumf;
+}
+
+float co_vec_dot_q6_k_q8_k(const co_block_q6_k* a, const co_block_q8_k* b, size_t nb) { /* buf_q6_k.rs:183-234 */
+  int8_t aux8[256];
+  int16_t aux16[8];
+  float sums[8], aux32[8];
+  for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+  for (size_t i = 0; i < nb; i++) {
+    const uint8_t* q4b = a[i].ql;
+    const uint8_t* qhb = a[i].qh;
+    const int8_t* q8 = b[i].qs;
+    for (int l = 0; l < 8; l++) aux32[l] = 0.0f;
+    for (int j = 0; j < 256; j += 128) {
+      int8_t* x8 = aux8 + j;
+      const uint8_t* q4 = q4b + j / 2;
+      const uint8_t* qh = qhb + j / 4;
+      for (int l = 0; l < 32; l++) {
+        x8[l] = (int8_t)((int32_t)((q4[l] & 0xF) | ((qh[l] & 3) << 4)) - 32);
+        x8[l + 32] = (int8_t)((int32_t)((q4[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32);
+        x8[l + 64] = (int8_t)((int32_t)((q4[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32);
+        x8[l + 96] = (int8_t)((int32_t)((q4[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32);
+      }
+    }
+    for (int j = 0; j < 16; j++) {
+      const float scale = (float)a[i].scales[j];
+      const int8_t* q8j = q8 + 16 * j;
+      const int8_t* a8j = aux8 + 16 * j;
+      for (int l = 0; l < 8; l++) aux16[l] = (int16_t)((int16_t)q8j[l] * (int16_t)a8j[l]);
+      for (int l = 0; l < 8; l++) aux32[l] += scale * (float)aux16[l];
+      for (int l = 0; l < 8; l++) aux16[l] = (int16_t)((int16_t)q8j[8 + l] * (int16_t)a8j[8 + l]);
+      for (int l = 0; l < 8; l++) aux32[l] += scale * (float)aux16[l];
+    }
+    const float d = co_f16_to_f32(a[i].d) * b[i].d;
+    for (int l = 0; l < 8; l++) sums[l] += aux32[l] * d;
+  }
+  float sumf = 0.0f; /* Iterator::sum: left fold from 0.0 */
+  for (int l = 0; l < 8; l++) sumf += sums[l];
+  return sumf;
+}
+
+/* util.rs:29-152 (rmse_type 1 is all the Q6_K quantizer uses; the general function is restated) */
+static float make_qx_quants(int n, int nmax, const float* data, int8_t* ls, int rmse_type) {
+  float max = 0.0f, abs_max = 0.0f;
+  for (int i = 0; i < n; i++) {
+    float ax = fabsf(data[i]);
+    if (ax > abs_max) {
+      abs_max = ax;
+      max = data[i];
+    }
+  }
+  if (abs_max == 0.0f) {
+    for (int i = 0; i < n; i++) ls[i] = 0;
+    return 0.0f;
+  }
+  float iscale = -(float)nmax / max;
+  if (rmse_type == 0) {
+    for (int i = 0; i < n; i++) {
+      int l = co_nearest_i32(iscale * data[i]);
+      l = l < -nmax ? -nmax : (l > nmax - 1 ? nmax - 1 : l);
+      ls[i] = (int8_t)(nmax + l);
+    }
+    return 1.0f / iscale;
+  }
+  const int weight_type = rmse_type % 2;
+  float sumlx = 0.0f, suml2 = 0.0f;
+  for (int i = 0; i < n; i++) {
+    float xi = data[i];
+    int l = co_nearest_i32(iscale * xi);
+    l = l < -nmax ? -nmax : (l > nmax - 1 ? nmax - 1 : l);
+    ls[i] = (int8_t)(l + nmax);
+    float w = weight_type == 1 ? xi * xi : 1.0f;
+    float lf = (float)l;
+    sumlx += w * xi * lf;
+    suml2 += w * lf * lf;
+  }
+  float scale = sumlx / suml2;
+  float best = scale * sumlx;
+  for (int itry = 0; itry < 3; itry++) {
+    float isc = 1.0f / scale;
+    float slx = 0.0f, sl2 = 0.0f;
+    int changed = 0;
+    for (int i = 0; i < n; i++) {
+      float xi = data[i];
+      int l = co_nearest_i32(isc * xi);
+      l = l < -nmax ? -nmax : (l > nmax - 1 ? nmax - 1 : l);
+      if (l + nmax != (int)ls[i]) changed = 1;
+      float w = weight_type == 1 ? xi * xi : 1.0f;
+      float lf = (float)l;
+      slx += w * xi * lf;
+      sl2 += w * lf * lf;
+    }
+    if (!changed || sl2 == 0.0f || slx * slx <= best * sl2) break;
+    for (int i = 0; i < n; i++) {
+      int l = co_nearest_i32(isc * data[i]);
+      l = l < -nmax ? -nmax : (l > nmax - 1 ? nmax - 1 : l);
+      ls[i] = (int8_t)(nmax + l);
+    }
+    sumlx = slx;
+    suml2 = sl2;
+    scale = sumlx / suml2;
+    best = scale * sumlx;
+  }
+  for (int itry = 0; itry < 5; itry++) {
+    int n_changed = 0;
+    for (int i = 0; i < n; i++) {
+      float xi = data[i];
+      float w = weight_type == 1 ? xi * xi : 1.0f;
+      int l = (int)ls[i] - nmax;
+      float slx = sumlx - w * xi * (float)l;
+      if (slx > 0.0f) {
+        float sl2 = suml2 - w * (float)l * (float)l;
+        int new_l = co_nearest_i32(xi * sl2 / slx);
+        new_l = new_l < -nmax ? -nmax : (new_l > nmax - 1 ? nmax - 1 : new_l);
+        if (new_l != l) {
+          slx += w * xi * (float)new_l;
+          sl2 += w * (float)new_l * (float)new_l;
+          if (sl2 > 0.0f && slx * slx * suml2 > sumlx * sumlx * sl2) {
+            ls[i] = (int8_t)(nmax + new_l);
+            sumlx = slx;
+            suml2 = sl2;
+            scale = sumlx / suml2;
+            best = scale * sumlx;
+            n_changed++;
+          }
+        }
+      }
+    }
+    if (n_changed == 0) break;
+  }
+  if (rmse_type < 3) return scale;
+  for (int is = -4; is < 4; is++) {
+    if (is == 0) continue;
+    iscale = -((float)nmax + 0.1f * (float)is) / max;
+    float slx = 0.0f, sl2 = 0.0f;
+    for (int i = 0; i < n; i++) {
+      float xi = data[i];
+      int l = co_nearest_i32(iscale * xi);
+      l = l < -nmax ? -nmax : (l > nmax - 1 ? nmax - 1 : l);
+      float w = weight_type == 1 ? xi * xi : 1.0f;
+      float lf = (float)l;
+      slx += w * xi * lf;
+      sl2 += w * lf * lf;
+    }
+    if (sl2 > 0.0f && slx * slx > best * sl2) {
+      for (int i = 0; i < n; i++) {
+        int l = co_nearest_i32(iscale * data[i]);
+        l = l < -nmax ? -nmax : (l > nmax - 1 ? nmax - 1 : l);
+        ls[i] = (int8_t)(nmax + l);
+      }
+      scale = slx / sl2;
+      best = scale * slx;
+    }
+  }
+  return scale;
+}
+
+void co_quantize_f32_q6_k(const float* x, size_t n, co_block_q6_k* out) { /* buf_q6_k.rs:109-181 */
+  for (size_t bi = 0; bi < n / 256; bi++) {
+    const float* chunk = x + bi * 256;
+    int8_t l[256];
+    float max_scale = 0.0f, max_abs_scale = 0.0f, scales[16];
+    int8_t block_scales[16];
+    uint8_t ql[128], qh[64];
+    memset(l, 0, sizeof l);
+    memset(ql, 0, sizeof ql);
+    memset(qh, 0, sizeof qh);
+    for (int ib = 0; ib < 16; ib++) {
+      scales[ib] = make_qx_quants(16, 32, chunk + 16 * ib, l + 16 * ib, 1);
+      float as = fabsf(scales[ib]);
+      if (as > max_abs_scale) {
+        max_abs_scale = as;
+        max_scale = scales[ib];
+      }
+    }
+    const float iscale = -128.0f / max_scale;
+    const float d = 1.0f / iscale;
+    for (int j = 0; j < 16; j++) {
+      int v = co_nearest_i32(iscale * scales[j]);
+      v = v < 127 ? v : 127;
+      block_scales[j] = (int8_t)v; /* `as i8` of an i32 wraps */
+    }
+    for (int j = 0; j < 16; j++) {
+      const float dj = d * (float)block_scales[j];
+      if (dj == 0.0f) continue;
+      for (int ii = 0; ii < 16; ii++) {
+        int idx = 16 * j + ii;
+        int ll = co_nearest_i32(chunk[idx] / dj);
+        ll = ll < -32 ? -32 : (ll > 31 ? 31 : ll);
+        l[idx] = (int8_t)(ll + 32);
+      }
+    }
+    for (int j = 0; j < 256; j += 128) {
+      int qi = j / 128;
+      for (int li = 0; li < 32; li++) {
+        int base = j + li;
+        int8_t q1 = l[base] & 0xF, q2 = l[base + 32] & 0xF, q3 = l[base + 64] & 0xF, q4 = l[base + 96] & 0xF;
+        ql[qi * 64 + li] = (uint8_t)(q1 | (q3 << 4));
+        ql[qi * 64 + li + 32] = (uint8_t)(q2 | (q4 << 4));
+        qh[qi * 32 + li] = (uint8_t)((l[base] >> 4) | ((l[base + 32] >> 4) << 2) | ((l[base + 64] >> 4) << 4) | ((l[base + 96] >> 4) << 6));
+      }
+    }
+    memcpy(out[bi].ql, ql, 128);
+    memcpy(out[bi].qh, qh, 64);
+    memcpy(out[bi].scales, block_scales, 16);
+    out[bi].d = co_f32_to_f16(d);
+  }
 }
 
 float co_vec_dot_q8_k_q8_k(const co_block_q8_k* a, const co_block_q8_k* b, size_t nb) {
@@ -760,6 +990,29 @@ int co_block_dots(const void* w, uint32_t wtype, const void* x, size_t n, int32_
         }
       return 0;
     }
+    case CO_Q6_K: { /* per 16-element scale group: sum (q6 - 32) * q8 (16 per super-block) */
+      const co_block_q6_k* a = (const co_block_q6_k*)w;
+      const co_block_q8_k* b = (const co_block_q8_k*)x;
+      for (size_t i = 0; i < n / 256; i++) {
+        int8_t aux8[256];
+        for (int j = 0; j < 256; j += 128) {
+          const uint8_t* q4 = a[i].ql + j / 2;
+          const uint8_t* qh = a[i].qh + j / 4;
+          for (int l = 0; l < 32; l++) {
+            aux8[j + l] = (int8_t)((int32_t)((q4[l] & 0xF) | ((qh[l] & 3) << 4)) - 32);
+            aux8[j + l + 32] = (int8_t)((int32_t)((q4[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32);
+            aux8[j + l + 64] = (int8_t)((int32_t)((q4[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32);
+            aux8[j + l + 96] = (int8_t)((int32_t)((q4[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32);
+          }
+        }
+        for (int gq = 0; gq < 16; gq++) {
+          int32_t sacc = 0;
+          for (int l = 0; l < 16; l++) sacc += (int32_t)aux8[16 * gq + l] * b[i].qs[16 * gq + l];
+          out[i * 16 + gq] = sacc;
+        }
+      }
+      return 0;
+    }
     case CO_Q8_K: {
       const co_block_q8_k* a = (const co_block_q8_k*)w;
       const co_block_q8_k* b = (const co_block_q8_k*)x;
@@ -926,6 +1179,8 @@ static float vec_dot_dispatch(struct co_device* d, uint32_t wtype, const void* w
       return co_vec_dot_q4_1_q8_1((const co_block_q4_1*)wrow, (const co_block_q8_1*)xrow, k / 32);
     case CO_Q4_K:
       return co_vec_dot_q4_k_q8_k((const co_block_q4_k*)wrow, (const co_block_q8_k*)xrow, k / 256, 0, NULL);
+    case CO_Q6_K: /* the reference has no SIMD path for Q6_K */
+      return co_vec_dot_q6_k_q8_k((const co_block_q6_k*)wrow, (const co_block_q8_k*)xrow, k / 256);
     case CO_Q8_K:
       return d->use_avx2 ? co_vec_dot_q8_k_q8_k_avx2((const co_block_q8_k*)wrow, (const co_block_q8_k*)xrow, k / 256)
                          : co_vec_dot_q8_k_q8_k((const co_block_q8_k*)wrow, (const co_block_q8_k*)xrow, k / 256);

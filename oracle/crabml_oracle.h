@@ -37,7 +37,7 @@ extern "C" {
 /* GGML type ids: crabml-core/src/gguf.rs:86-108 */
 enum {
   CO_F32 = 0, CO_F16 = 1, CO_Q4_0 = 2, CO_Q4_1 = 3, CO_Q8_0 = 8, CO_Q8_1 = 9,
-  CO_Q4_K = 12, CO_Q8_K = 15
+  CO_Q4_K = 12, CO_Q6_K = 14, CO_Q8_K = 15
 };
 
 #pragma pack(push, 1)
@@ -46,6 +46,7 @@ typedef struct { uint16_t d; uint8_t qs[16]; } co_block_q4_0;                /* 
 typedef struct { uint16_t d; uint16_t m; uint8_t qs[16]; } co_block_q4_1;    /* buf_q4_1.rs:10-16  20 B */
 typedef struct { uint16_t d; uint16_t s; int8_t qs[32]; } co_block_q8_1;     /* buf_q8_1.rs:73-79  36 B */
 typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qs[128]; } co_block_q4_k; /* buf_q4_k.rs:14-21 144 B */
+typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; } co_block_q6_k;       /* buf_q6_k.rs:11-18  210 B */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; } co_block_q8_k;                     /* buf_q8_k.rs:6-12  292 B */
 #pragma pack(pop)
 
@@ -86,6 +87,8 @@ float co_vec_dot_q4_1_q8_1(const co_block_q4_1* a, const co_block_q8_1* b, size_
 float co_vec_dot_q4_k_q8_k(const co_block_q4_k* a, const co_block_q8_k* b, size_t nblocks,
                            int i16_wrap, size_t* n_overflow);                                /* buf_q4_k.rs:192-277 */
 float co_vec_dot_q8_k_q8_k(const co_block_q8_k* a, const co_block_q8_k* b, size_t nblocks); /* buf_q8_k.rs:211-224 */
+float co_vec_dot_q6_k_q8_k(const co_block_q6_k* a, const co_block_q8_k* b, size_t nblocks); /* buf_q6_k.rs:183-234 (scalar only) */
+void co_quantize_f32_q6_k(const float* x, size_t n, co_block_q6_k* out);                    /* buf_q6_k.rs:109-181, util.rs:29-152 */
 float co_vec_dot_f32_f32(const float* a, const float* b, size_t n);                          /* buf_f32.rs:19-27 */
 float co_vec_dot_f16_f16(const uint16_t* a, const uint16_t* b, size_t n);                    /* buf_f16.rs:83-97 */
 

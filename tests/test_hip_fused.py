@@ -57,7 +57,7 @@ def test_fused_strict_is_bit_exact(ca, shape, fmt, kv_f16):
                     assert np.array_equal(got[lo:lo + n], exp[lo:lo + n]), (layer, which, h)
 
 
-@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q8_K", "F16", "F32"])
+@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q6_K", "Q8_K", "F16", "F32"])
 @pytest.mark.parametrize("kv_f16", [False, True])
 def test_decode_step_other_formats_strict_is_bit_exact(ca, fmt, kv_f16):
     """Formats without fused kernels run the per-op segment path inside the same graph (rhs quantized to
@@ -72,7 +72,7 @@ def test_decode_step_other_formats_strict_is_bit_exact(ca, fmt, kv_f16):
         assert np.array_equal(r.forward(t, i).view(np.uint32), ref[i].view(np.uint32)), f"{fmt} step {i}"
 
 
-@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q8_K", "F16", "F32"])
+@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q6_K", "Q8_K", "F16", "F32"])
 def test_decode_step_other_formats_fast(ca, fmt):
     model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=15)
     toks = PROMPT + [7, 9]
@@ -209,3 +209,24 @@ def test_long_context_attention_kernels_are_bit_identical(ca, shape, group):
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"strict step {i}"
         else:
             r.forward_async(t, i)
+
+
+@pytest.mark.parametrize("layers", ["Q4_0", "Q4_K"])
+def test_q6_k_classifier_like_real_gguf_files(ca, layers):
+    """llama.cpp's Q4_0 / Q4_K_M files store output.weight (and the embedding) in Q6_K: layers of
+    one format, classifier + token_embd of another.  Strict device: bit-identical to the oracle; fast: tolerance."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[layers], seed=51, embed_type=synth.Q6_K,
+                              output_type=synth.Q6_K)
+    toks = PROMPT + [7, 9]
+    ref, _ = oracle_logits(model, True, toks)
+    sdev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, sdev)
+    r = ca.HipLlamaRunner(conf, w, sdev, 64, True)
+    for i, t in enumerate(toks):
+        assert np.array_equal(r.forward(t, i).view(np.uint32), ref[i].view(np.uint32)), f"step {i}"
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    fast = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    got = [fast.forward(t, i).copy() for i, t in enumerate(toks)]
+    err = rel_errs(got, ref)
+    assert np.median(err) <= 3e-2 and np.max(err) <= 1e-1, err

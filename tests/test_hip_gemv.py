@@ -17,8 +17,8 @@ from tests.helpers import GEMV_REL, gemv_order_bound
 
 pytestmark = pytest.mark.gpu
 
-FORMATS = ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q8_K"]
-HT = {"Q4_0": "Q4_0", "Q8_0": "Q8_0", "Q4_1": "Q4_1", "Q4_K": "Q4K", "Q8_K": "Q8K", "F32": "F32", "F16": "F16"}
+FORMATS = ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q6_K", "Q8_K"]
+HT = {"Q4_0": "Q4_0", "Q8_0": "Q8_0", "Q4_1": "Q4_1", "Q4_K": "Q4K", "Q6_K": "Q6K", "Q8_K": "Q8K", "F32": "F32", "F16": "F16"}
 
 
 def make(fmt, m, k, seed):
@@ -36,7 +36,7 @@ SHAPES_256 = [(3, 256), (5, 768), (512, 512), (1000, 4096), (257, 14336), (1024,
 
 
 def shapes_for(fmt):
-    return SHAPES_256 if fmt in ("Q4_K", "Q8_K") else SHAPES_32
+    return SHAPES_256 if fmt in ("Q4_K", "Q6_K", "Q8_K") else SHAPES_32
 
 
 @pytest.mark.parametrize("fmt", FORMATS)

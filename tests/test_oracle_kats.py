@@ -111,6 +111,53 @@ def test_q8_k_quantize():  # buf_q8_k.rs:265-292
     assert bs.tolist() == qs.reshape(16, 16).sum(axis=1).tolist()
 
 
+def test_q6_k_block_layout():  # buf_q6_k.rs:241-270
+    assert o.BLOCK_BYTES[o.Q6_K] == 2 + 128 + 64 + 16 == 210
+    buf = np.full(210, 1, dtype=np.uint8)
+    buf[0:2] = le16(f16(3.0))
+    buf[2:4] = le16(f16(1.0))
+    buf[4], buf[5], buf[6], buf[4 + 15], buf[208] = 2, 3, 4, 7, 10
+    # fields: ql[128] | qh[64] | scales[16] | d (f16 at 208)
+    assert buf[208:210].view(np.float16)[0].astype(np.float32) == np.float32(1.5854836e-5)
+    assert buf[0:16].tolist() == [0, 66, 0, 60, 2, 3, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+    assert buf[128 + 48:128 + 64].tolist() == [1] * 16
+    # dequantize goes through the same field offsets: element 0 = d * scales[0] * (((ql[0] & 0xF) | ((qh[0] & 3) << 4)) - 32)
+    deq = o.dequantize(buf, o.Q6_K)
+    d = np.float32(1.5854836e-5)
+    assert deq[0] == d * np.float32(1.0) * np.float32(((0 & 0xF) | ((1 & 3) << 4)) - 32)
+    assert deq[1] == d * np.float32(1.0) * np.float32(((66 & 0xF) | ((1 & 3) << 4)) - 32)
+
+
+def test_q6_k_quantize_roundtrip():  # buf_q6_k.rs:283-312 (test_q6_k_quantize_2)
+    data = np.array(list(range(-8, 8)) * 16, dtype=np.float32)
+    raw = o.quantize(data, o.Q6_K)
+    assert raw.size == 210
+    assert raw[208:210].view(np.float16)[0].astype(np.float32) == np.float32(-0.001953125)
+    assert o.dequantize(raw, o.Q6_K).tolist() == data.tolist()
+
+
+def test_q6_k_vec_dot_q8_k_matches_dequantized_dot():
+    """No value-level KAT exists for vec_dot_q6_k_q8_k (buf_q6_k.rs:183-234); the restatement is pinned through the
+    pinned dequantizers: the dot equals sum(dequant(w) * dequant(x)) up to f32 re-association, and the integer
+    part per 16-element scale group is exact."""
+    rng = np.random.default_rng(6)
+    w = (rng.standard_normal(1024) * 0.5).astype(np.float32)
+    x = rng.standard_normal(1024).astype(np.float32)
+    wq, xq = o.quantize(w, o.Q6_K), o.quantize(x, o.Q8_K)
+    got = o.vec_dot(wq, o.Q6_K, xq, 1024)
+    wd, xd = o.dequantize(wq, o.Q6_K).astype(np.float64), o.dequantize(xq, o.Q8_K).astype(np.float64)
+    ref = float(wd @ xd)
+    assert abs(got - ref) <= 1e-5 * float(np.abs(wd) @ np.abs(xd)) + 1e-6
+    dots = o.block_dots(wq, o.Q6_K, xq, 1024)
+    blocks = wq.reshape(-1, 210)
+    scales = blocks[:, 192:208].view(np.int8).astype(np.float64).reshape(-1)
+    dw = blocks[:, 208:210].copy().view(np.float16).astype(np.float64).reshape(-1)
+    dx = xq.reshape(-1, 292)[:, 0:4].copy().view(np.float32).astype(np.float64).reshape(-1)
+    per_block = (dots.astype(np.float64) * scales).reshape(-1, 16).sum(axis=1) * dw * dx
+    # (the dequantized values carry one f32 rounding each: 6e-8 relative per term)
+    assert abs(per_block.sum() - ref) <= 1e-7 * float(np.abs(wd) @ np.abs(xd)) + 1e-9
+
+
 # ---------------------------------------------------------------- dot known answers
 def _q80_blocks(qs_list, d_list):
     out = bytearray()
