@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--path", default="auto", choices=["auto", "trait", "fused"],
                     help="trait = one launch per Tensor op (Llama2Runner unchanged); fused = fused decode step")
     ap.add_argument("--no-norm-epilogue", action="store_true", help="A/B: keep RMSNorm+quantize as its own launch")
+    ap.add_argument("--flags", type=int, default=0, help="extra CRABML_HIP_LLAMA_* flags for A/B runs")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: disable Infinity-Cache weight prefetch")
     ap.add_argument("--tp-dry", type=int, default=0,
                     help="measure ONE rank of a tensor-parallel group of this size with its all-reduces skipped "
@@ -227,7 +228,7 @@ def main():
     if path in ("auto", "fused"):
         try:
             fused = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch,
-                                      norm_epilogue=not args.no_norm_epilogue)
+                                      norm_epilogue=not args.no_norm_epilogue, extra_flags=args.flags)
             path = "fused"
         except ca.CrabmlError:
             if path == "fused":

@@ -12,6 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--no-prefetch", action="store_true")
 ap.add_argument("--no-norm-epilogue", action="store_true")
 ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--hidden", type=int, default=0, help="experiment: override the ffn hidden size")
+ap.add_argument("--layers", type=int, default=0)
 ap.add_argument("--attn-long-from", type=int, default=0)
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--pos0", type=int, default=8)
@@ -19,7 +21,10 @@ ap.add_argument("--model", default="llama3-8b")
 ap.add_argument("--wtype", default="Q4_0")
 a = ap.parse_args()
 NAMES = {1: "qkv", 2: "wo+res", 3: "gateup_q", 4: "down+res", 5: "classifier", 6: "norm_quant", 7: "attn|scores", 8: "attn softmax", 9: "attn pv"}
-model = synth.build_model(synth.SHAPES[a.model], synth.TYPE_BY_NAME[a.wtype], seed=8)
+shape = synth.SHAPES[a.model]
+if a.hidden:
+    shape = synth.ModelShape(**{**shape.__dict__, "hidden": a.hidden})
+model = synth.build_model(shape, synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers or None)
 dev = ca.HipTensorDevice(0)
 conf, w = synth.to_hip(model, dev)
 r = ca.HipLlamaRunner(conf, w, dev, a.pos0 + a.steps + 8, True, False, not a.no_prefetch, norm_epilogue=not a.no_norm_epilogue, extra_flags=a.flags, attn_long_from=a.attn_long_from)
