@@ -258,7 +258,7 @@ struct Planes {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ActQ8_0 act, int nb, QkvEpi e) {
+__global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int row0 = wave * 2;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, Ac
   QkvPre pre{};
   if (lane == 0) pre = qkv_preload(e, row0);
   float acc[2];
-  rows_partial<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
+  rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
   if (lane == 0) qkv_epilogue(e, pre, row0, s0, s1);
 }
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restric
 
 // ---- GEMV + residual: x[row] = W[row].xq + x[row]   (matmul_vec, then add_inplace: arithmetic.rs:27-33) ---
 template <int FMT, int R, bool ADD>  // ADD: x[row] += W.xq (residual); else out[row] = W.xq (tensor-parallel partial sum)
-__global__ __launch_bounds__(128) void k_gemv_res(Planes w, ActQ8_0 act, float* __restrict__ x, int m, int nb) {
+__global__ __launch_bounds__(128) void k_gemv_res(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x, int m, int nb) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int row0 = wave * R;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(128) void k_gemv_res(Planes w, ActQ8_0 act, float* 
 #pragma unroll
   for (int r = 0; r < R; r++) res[r] = (ADD && lane == 0 && row0 + r < m) ? x[row0 + r] : 0.f;
   float acc[R];
-  rows_partial<FMT, R>(w.q, w.d, act, row0, m, nb, lane, acc);
+  rows_dot<FMT, R>(w.q, w.d, act, row0, m, nb, lane, acc);
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float s = wave_sum_f32(acc[r]);
@@ -891,26 +891,16 @@ __device__ __forceinline__ float silu_mul(float g, float u, const unsigned short
   return (g / (1.0f + nexp)) * u;
 }
 template <int FMT>
-__global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, ActQ8_0 act, const unsigned short* __restrict__ exp_tab,
-                                                float* __restrict__ h, int m, int nb) {
-  using F = BlockFmt<FMT>;
+__global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename ActOf<FMT>::type act,
+                                                const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m, int nb) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= m) return;
-  float ag = 0.f, au = 0.f;
-  for (int b = lane; b < nb; b += 64) {
-    size_t idx = (size_t)row * nb + b;
-    typename F::Blk bg = F::load(wg.q, wg.d, idx);
-    typename F::Blk bu = F::load(wu.q, wu.d, idx);
-    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
-    float dx = h2f(act.d[b]);
-    int xs = act.isum[b];
-    ag += F::term(bg, x0, x1, dx, xs);
-    au += F::term(bu, x0, x1, dx, xs);
-  }
-  ag = wave_sum_f32(ag);
-  au = wave_sum_f32(au);
-  if (lane == 0) h[row] = silu_mul(ag, au, exp_tab);
+  float ag[1], au[1];
+  rows_dot<FMT, 1>(wg.q, wg.d, act, row, m, nb, lane, ag);
+  rows_dot<FMT, 1>(wu.q, wu.d, act, row, m, nb, lane, au);
+  const float g = wave_sum_f32(ag[0]), u = wave_sum_f32(au[0]);
+  if (lane == 0) h[row] = silu_mul(g, u, exp_tab);
 }
 // Same, with the Q8_0 quantization of h (the rhs of ffn_down) folded in: a 1024-thread workgroup owns 32
 // consecutive hidden rows = one quant block; each of its 16 waves computes 2 rows (4 weight rows in flight),
@@ -1135,6 +1125,7 @@ struct crabml_hip_llama {
   int* state = nullptr;      // token, pos, step, sink, serial (never reset), fault
   unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
+  bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
   bool generic = false;      // per-op launches (strict-order device, or a weight format without fused kernels)
   uint32_t qt = 0, out_qt = 0;  // vec_dot_rhs_dtype of the layer weights / of the classifier
   float* xn = nullptr;       // generic path: normalized residual (f32, dim)
@@ -1454,7 +1445,104 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
   return 0;
 }
 
+// Q4_K layers (fast mode): the fused GEMV kernels with the Q4_K inner loop and Q8_K activation planes.  The rhs
+// quantizer is its own launch here (a Q8_K super-block spans 256 rows: eight 32-row workgroups), so a layer is
+// 11 launches instead of the per-op path's 18.
+int enqueue_segment_k(crabml_hip_llama* c, int seg) {
+  constexpr int FMT = CRABML_HIP_Q4_K;
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const auto& g = c->cfg;
+  const int dim = (int)g.embedding_dim, hd = c->hd, seq_cap = (int)g.seq_len;
+  const int dim_l = c->dim_l, kv_dim_l = c->kv_dim_l, hidden_l = c->hidden_l;
+  const bool kv16 = g.use_f16_kv_cache != 0;
+  const bool tp = c->tp > 1;
+  const int L = (int)g.n_layers;
+  int* token_d = c->state;
+  int* pos_d = c->state + 1;
+  int* step_d = c->state + 2;
+  const bool prof = dev->prof_on && !c->use_graph && !c->capturing;
+  crabml_hip_device::ProfRec pr{};
+  crabml_hip_device::ProfRec* R = prof ? &pr : nullptr;
+  const double blk_b = 144.0 / 256.0;
+  auto P0 = [&](uint32_t stage, double rows, double k) {
+    return prof ? prof_begin(dev, &pr, FMT, stage, rows * k * blk_b + 4.0 * k + 4.0 * rows) : 0;
+  };
+  auto P1 = [&]() { return prof ? prof_end(dev, &pr) : 0; };
+  auto act_k = [&](char* planes, int n) {
+    ActLayout al = act_layout(CRABML_HIP_Q8_K, (size_t)n);
+    return ActQ8_K{(const i32x4*)planes, (const float*)(planes + al.off_d), (const short*)(planes + al.off_aux)};
+  };
+  auto planes_k = [&](const crabml_hip_buf* b) {
+    return Planes{(const i32x4*)b->ptr, (const unsigned short*)((const char*)b->ptr + b->wl.off_scale)};
+  };
+  const size_t norm_lds = norm_lds_bytes(dim);
+  // rmsnorm * weight -> xn -> Q8_K planes (buf_q8_k.rs:84-131)
+  auto norm_quant = [&](const float* wn, float eps, bool add_pending, uint32_t qt) -> const void* {
+    const float* addv = add_pending ? c->partial : nullptr;
+    if (dim <= 4096)
+      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+    else
+      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+    if (qt == CRABML_HIP_F32) return c->xn;
+    launch_quantize_act(st, qt, c->xn, (size_t)dim, c->act_dim);
+    return c->act_dim;
+  };
+  float* dst = tp ? c->partial : c->x;
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActQ8_K& a, int k, uint32_t stage) -> int {
+    CH_TRY(P0(stage, dim, k));
+    if (tp)
+      launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_k(w), a, dst, dim, k / 256);
+    else
+      launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_k(w), a, dst, dim, k / 256);
+    return P1();
+  };
+
+  if (seg == 2 * L) {
+    const void* act = norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, c->out_qt);
+    if (prof)
+      CH_TRY(prof_begin(dev, &pr, c->output->dtype, 5,
+                        (double)g.vocab_size * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
+                            4.0 * dim + 4.0 * g.vocab_size));
+    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, act, 1, c->logits, R));
+    CH_TRY(P1());
+    k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
+    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
+                                    c->state + 4);
+    CH_HIP(dev, hipGetLastError());
+    return 0;
+  }
+  const int l = seg / 2;
+  if ((seg & 1) == 0) {
+    if (l == 0)
+      k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
+                                                  c->token_embed->wl.off_scale, token_d, dim, c->x);
+    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, CRABML_HIP_Q8_K);
+    QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
+             (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
+    const int total_rows = dim_l + 2 * kv_dim_l;
+    CH_TRY(P0(1, total_rows, dim));
+    launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
+             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / 256, e);
+    CH_TRY(P1());
+    enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
+    launch_quantize_act(st, CRABML_HIP_Q8_K, c->attn, (size_t)dim_l, c->act_attn);
+    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), dim_l, 2));
+  } else {
+    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, CRABML_HIP_Q8_K);  // llama2.rs:611
+    CH_TRY(P0(3, 2.0 * hidden_l, dim));
+    launch_k(st, R, k_gateup<FMT>, dim3((hidden_l + 1) / 2), dim3(128), 0, planes_k(c->gate[l]), planes_k(c->up[l]),
+             act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256);
+    CH_TRY(P1());
+    launch_quantize_act(st, CRABML_HIP_Q8_K, c->h, (size_t)hidden_l, c->act_hid);
+    CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), hidden_l, 4));
+  }
+  CH_HIP(dev, hipGetLastError());
+  return 0;
+}
+
 int enqueue_segment(crabml_hip_llama* c, int seg) {
+  if (c->kfused) return enqueue_segment_k(c, seg);
   if (c->generic) return enqueue_segment_generic(c, seg);
   return c->wtype == CRABML_HIP_Q4_0 ? enqueue_segment_t<CRABML_HIP_Q4_0>(c, seg) : enqueue_segment_t<CRABML_HIP_Q8_0>(c, seg);
 }
@@ -1610,6 +1698,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->cfg = g;
   c->wtype = wt;
   c->generic = generic;
+  c->kfused = !dev->strict_order && wt == CRABML_HIP_Q4_K && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION);
   c->qt = qt;
   c->out_qt = out_qt;
   c->tp = tp;

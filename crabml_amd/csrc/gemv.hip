@@ -148,47 +148,7 @@ __global__ __launch_bounds__(256) void k_gemv_q4_k(const i32x4* __restrict__ wq,
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) acc[r] = 0.f;
-  const int nchunks = nsb * 8;
-  for (int c = lane; c < nchunks; c += 64) {
-    const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
-    i32x4 qv[R], hdr[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int row = row0 + r < m ? row0 + r : m - 1;
-      qv[r] = __builtin_nontemporal_load(wq + (size_t)row * nchunks + c);
-      hdr[r] = __builtin_nontemporal_load(wh + (size_t)row * nsb + sb);
-    }
-    const i32x4* xq = act.q + (size_t)sb * 16 + p * 4 + h;
-    const i32x4 xl = xq[0], xh = xq[2];
-    const float d8 = act.d[sb];
-    const short* bs = act.bsums + sb * 16 + p * 4 + h;
-    const int bs_lo = (int)bs[0], bs_hi = (int)bs[2];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      // 6-bit (scale, min) unpack with the reference's KMASK word trick (buf_q4_k.rs:219-234), then a
-      // run-time byte select -- no per-lane indexed array, so nothing spills to scratch.
-      const unsigned u0 = (unsigned)hdr[r][1], u1 = (unsigned)hdr[r][2], u2 = (unsigned)hdr[r][3];
-      const unsigned S0 = u0 & 0x3f3f3f3fu, S1 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
-      const unsigned M0 = u1 & 0x3f3f3f3fu, M1 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
-      const unsigned SW = p < 2 ? S0 : S1, MW = p < 2 ? M0 : M1;
-      const int sh = (p & 1) * 16;
-      const int sc_lo = (int)((SW >> sh) & 0xffu), sc_hi = (int)((SW >> (sh + 8)) & 0xffu);
-      const int m_lo = (int)((MW >> sh) & 0xffu), m_hi = (int)((MW >> (sh + 8)) & 0xffu);
-      int lo = 0, hi = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        lo = __builtin_amdgcn_sdot4(qv[r][i] & 0x0F0F0F0F, xl[i], lo, false);
-        hi = __builtin_amdgcn_sdot4((qv[r][i] >> 4) & 0x0F0F0F0F, xh[i], hi, false);
-      }
-      const int isum = sc_lo * lo + sc_hi * hi;      // exact (the reference's aux32 lanes hold integers < 2^24)
-      const int msum = m_lo * bs_lo + m_hi * bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
-      const float dd = h2f((unsigned short)(hdr[r][0] & 0xffff)) * d8;
-      const float dmin = h2f((unsigned short)((unsigned)hdr[r][0] >> 16)) * d8;
-      acc[r] += dd * (float)isum - dmin * (float)msum;
-    }
-  }
+  rows_partial_q4k<R>(wq, wh, act, row0, m, nsb, lane, acc);  // gemv_core.hpp
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float s = wave_sum_f32(acc[r]);

@@ -119,4 +119,72 @@ __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const
   }
 }
 
+// Q4_K rows (planes qs[n][128] | hdr[n][16]) against a Q8_K activation vector: lane = one 16-byte qs piece j of a
+// super-block (8 lanes per super-block: a wave's load is one aligned 1 KiB request); piece j belongs to the
+// 64-element pair p = j / 2 and carries, for positions 16 (j & 1) .. +16, the low nibbles of sub-block 2p and the
+// high nibbles of sub-block 2p + 1 (buf_q4_k.rs:212-217).  The 16-byte header is fetched by all 8 lanes and the
+// 6-bit (scale, min) pairs are unpacked in registers with the reference's KMASK word trick (buf_q4_k.rs:219-234).
+template <int R>
+__device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act,
+                                                 int row0, int m, int nsb, int lane, float acc[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int nchunks = nsb * 8;
+  for (int c = lane; c < nchunks; c += 64) {
+    const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
+    i32x4 qv[R], hdr[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      qv[r] = __builtin_nontemporal_load(wq + (size_t)row * nchunks + c);
+      hdr[r] = __builtin_nontemporal_load(wh + (size_t)row * nsb + sb);
+    }
+    const i32x4* xq = act.q + (size_t)sb * 16 + p * 4 + h;
+    const i32x4 xl = xq[0], xh = xq[2];
+    const float d8 = act.d[sb];
+    const short* bs = act.bsums + sb * 16 + p * 4 + h;
+    const int bs_lo = (int)bs[0], bs_hi = (int)bs[2];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const unsigned u0 = (unsigned)hdr[r][1], u1 = (unsigned)hdr[r][2], u2 = (unsigned)hdr[r][3];
+      const unsigned S0 = u0 & 0x3f3f3f3fu, S1 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
+      const unsigned M0 = u1 & 0x3f3f3f3fu, M1 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
+      const unsigned SW = p < 2 ? S0 : S1, MW = p < 2 ? M0 : M1;  // run-time byte select: nothing spills to scratch
+      const int sh = (p & 1) * 16;
+      const int sc_lo = (int)((SW >> sh) & 0xffu), sc_hi = (int)((SW >> (sh + 8)) & 0xffu);
+      const int m_lo = (int)((MW >> sh) & 0xffu), m_hi = (int)((MW >> (sh + 8)) & 0xffu);
+      int lo = 0, hi = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        lo = __builtin_amdgcn_sdot4(qv[r][i] & 0x0F0F0F0F, xl[i], lo, false);
+        hi = __builtin_amdgcn_sdot4((qv[r][i] >> 4) & 0x0F0F0F0F, xh[i], hi, false);
+      }
+      const int isum = sc_lo * lo + sc_hi * hi;      // exact (the reference's aux32 lanes hold integers < 2^24)
+      const int msum = m_lo * bs_lo + m_hi * bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
+      const float dd = h2f((unsigned short)(hdr[r][0] & 0xffff)) * d8;
+      const float dmin = h2f((unsigned short)((unsigned)hdr[r][0] >> 16)) * d8;
+      acc[r] += dd * (float)isum - dmin * (float)msum;
+    }
+  }
+}
+
+// R rows of a weight matrix in format FMT against its activation planes (ActQ8_0 for Q4_0 / Q8_0, ActQ8_K for
+// Q4_K); `wd` is the format's second plane (f16 scales / 16-byte headers), `nu` the blocks per row
+template <int FMT, int R, class ACT>
+__device__ __forceinline__ void rows_dot(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd, const ACT& act,
+                                         int row0, int m, int nu, int lane, float acc[R]) {
+  if constexpr (FMT == CRABML_HIP_Q4_K)
+    rows_partial_q4k<R>(wq, (const i32x4*)wd, act, row0, m, nu, lane, acc);
+  else
+    rows_partial<FMT, R>(wq, wd, act, row0, m, nu, lane, acc);
+}
+template <int FMT>
+struct ActOf {
+  typedef ActQ8_0 type;
+};
+template <>
+struct ActOf<CRABML_HIP_Q4_K> {
+  typedef ActQ8_K type;
+};
+
 }  // namespace crabml_hip

@@ -230,3 +230,16 @@ def test_q6_k_classifier_like_real_gguf_files(ca, layers):
     got = [fast.forward(t, i).copy() for i, t in enumerate(toks)]
     err = rel_errs(got, ref)
     assert np.median(err) <= 3e-2 and np.max(err) <= 1e-1, err
+
+
+def test_q4_k_fused_kernels_equal_the_per_op_segments(ca):
+    """Q4_K layers run the fused GEMV kernels (q/k/v + rope + append, wo / down + residual, gate/up + SiLU*mul) with
+    the Q4_K inner loop; per row that is the per-op kernel's arithmetic, so the logits are bit-identical."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_K, seed=61, output_type=synth.Q6_K)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    fused = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    per_op = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=256)  # NO_KQUANT_FUSION
+    for i, t in enumerate(PROMPT + [5, 6, 7]):
+        a, b = fused.forward(t, i), per_op.forward(t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
