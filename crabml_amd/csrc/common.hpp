@@ -67,7 +67,11 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //   Q4_0: qs[n][16]            | d[n] f16
 //   Q8_0: qs[n][32]            | d[n] f16
 //   Q4_1: qs[n][16]            | dm[n] (d f16, m f16)
-//   Q4_K: qs[n][128]           | hdr[n][16] (d f16, dmin f16, scales[12]: the block's first 16 bytes)
+//   Q4_K: qs[n][128]           | hdr[n][16]: d f16, dmin f16, then the 8 (scale, min) 6-bit pairs of scales[12]
+//                                re-packed pair-major -- 24 bits per 64-element pair p, little endian at bit 24 p:
+//                                scale[2p] | scale[2p+1] << 6 | min[2p] << 12 | min[2p+1] << 18 (get_scale_min_k4,
+//                                util.rs:19-27, is a bit permutation of the same 96 bits; done once at upload) --
+//                                so a lane extracts its pair's four fields with 7 VALU ops instead of 23
 //   Q6_K: ql[n][128]           | qh[n][64] | scales[n][16] | d[n] f16   (off_scale = n * 128 exactly, so the
 //                                kernels derive the other three plane offsets from it)
 //   Q8_K: qs[n][256]           | d[n] f32            (bsums are derived data; not kept for weights)

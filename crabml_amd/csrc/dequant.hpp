@@ -42,17 +42,13 @@ __device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dt
       __builtin_memcpy(&dh, hdr, 2);
       __builtin_memcpy(&mh, hdr + 2, 2);
       float d = h2f(dh), mn = h2f(mh);
-      const unsigned char* sc = hdr + 4;
       int c = (int)(j / 64), l = (int)(j % 64);
-      int is = 2 * c + (l >= 32 ? 1 : 0);
-      int s6, m6;
-      if (is < 4) {
-        s6 = sc[is] & 63;
-        m6 = sc[is + 4] & 63;
-      } else {
-        s6 = (sc[is + 4] & 0xF) | ((sc[is - 4] >> 6) << 4);
-        m6 = (sc[is + 4] >> 4) | ((sc[is] >> 6) << 4);
-      }
+      unsigned u0, u1, u2;
+      __builtin_memcpy(&u0, hdr + 4, 4);
+      __builtin_memcpy(&u1, hdr + 8, 4);
+      __builtin_memcpy(&u2, hdr + 12, 4);
+      const unsigned f = q4k_pair_field(u0, u1, u2, c);
+      const int s6 = (int)((l >= 32 ? f >> 6 : f) & 63u), m6 = (int)((l >= 32 ? f >> 18 : f >> 12) & 63u);
       float d1 = d * (float)s6, m1 = mn * (float)m6;
       unsigned char q = qs[32 * c + (l & 31)];
       float qf = (float)(l >= 32 ? (q >> 4) : (q & 0xF));

@@ -100,6 +100,15 @@ __device__ __forceinline__ int half_sum_i32(int v) {
   return (threadIdx.x & 32) ? hi : lo;
 }
 
+// Q4_K header words u0..u2 (the re-packed scales, common.hpp) -> the 24-bit field of pair p:
+// scale[2p] | scale[2p+1] << 6 | min[2p] << 12 | min[2p+1] << 18
+__device__ __forceinline__ unsigned q4k_pair_field(unsigned u0, unsigned u1, unsigned u2, int p) {
+  const unsigned lo = p == 0 ? u0 : p == 1 ? u0 : p == 2 ? u1 : u2;
+  const unsigned hi = p == 0 ? u0 : p == 1 ? u1 : p == 2 ? u2 : u2;
+  const unsigned sh = p == 0 ? 0u : p == 1 ? 24u : p == 2 ? 16u : 8u;
+  return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> sh) & 0xffffffu;
+}
+
 // Rust `f32 as i32`: saturating, NaN -> 0
 __device__ __forceinline__ int rs_f32_as_i32(float v) {
   if (v != v) return 0;

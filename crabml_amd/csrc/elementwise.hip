@@ -255,4 +255,31 @@ void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, siz
                                                             bb / 2, plan);
 }
 
+// Q4_K: scales[12] (8 x (6-bit scale, 6-bit min), util.rs:19-27) -> pair-major 24-bit fields (common.hpp), in place
+__global__ __launch_bounds__(256) void k_q4k_pack_scales(unsigned char* __restrict__ hdr, size_t blk0, size_t n_blocks) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  unsigned char* q = hdr + (blk0 + b) * 16 + 4;
+  unsigned sc[8], mn[8];
+  for (int j = 0; j < 8; j++) {
+    if (j < 4) {
+      sc[j] = q[j] & 63u;
+      mn[j] = q[j + 4] & 63u;
+    } else {
+      sc[j] = (q[j + 4] & 0xFu) | ((unsigned)(q[j - 4] >> 6) << 4);
+      mn[j] = ((unsigned)q[j + 4] >> 4) | ((unsigned)(q[j] >> 6) << 4);
+    }
+  }
+  for (int p = 0; p < 4; p++) {
+    const unsigned f = sc[2 * p] | (sc[2 * p + 1] << 6) | (mn[2 * p] << 12) | (mn[2 * p + 1] << 18);
+    q[3 * p] = (unsigned char)(f & 0xffu);
+    q[3 * p + 1] = (unsigned char)((f >> 8) & 0xffu);
+    q[3 * p + 2] = (unsigned char)(f >> 16);
+  }
+}
+void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t n_blocks) {
+  if (n_blocks == 0) return;
+  k_q4k_pack_scales<<<(unsigned)((n_blocks + 255) / 256), 256, 0, st>>>((unsigned char*)hdr_plane, blk0, n_blocks);
+}
+
 }  // namespace crabml_hip

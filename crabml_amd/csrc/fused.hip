@@ -902,6 +902,34 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename A
   const float g = wave_sum_f32(ag[0]), u = wave_sum_f32(au[0]);
   if (lane == 0) h[row] = silu_mul(g, u, exp_tab);
 }
+// Q4_K gate/up with the Q8_K activation planes staged in LDS once per workgroup (1024 threads = 32 hidden rows x
+// {gate, up}): the per-lane activation reads (2 x 16 B + d + 2 bsums per 16 B of quants) leave the vector-memory
+// path, which the K-quant inner loop otherwise keeps ~57 % busy (rocprofv3 TA_BUSY) while VALU sits at 15 %.
+__global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
+                                                       float* __restrict__ h, int m, int nsb) {
+  extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
+  const int k = nsb * 256;
+  i32x4* sq = lds_act;
+  float* sd = (float*)(sq + k / 16);
+  short* sbs = (short*)(sd + nsb);
+  for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.q[i];
+  for (int i = threadIdx.x; i < nsb; i += 1024) sd[i] = act.d[i];
+  for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
+  __syncthreads();
+  const ActQ8_K la{sq, sd, sbs};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 32 + wave * 2;
+  if (row0 >= m) return;
+  float ag[2], au[2];
+  rows_partial_q4k<2>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag);
+  rows_partial_q4k<2>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const float g = wave_sum_f32(ag[r]), u = wave_sum_f32(au[r]);
+    if (lane == 0 && row0 + r < m) h[row0 + r] = silu_mul(g, u, exp_tab);
+  }
+}
+
 // Same, with the Q8_0 quantization of h (the rhs of ffn_down) folded in: a 1024-thread workgroup owns 32
 // consecutive hidden rows = one quant block; each of its 16 waves computes 2 rows (4 weight rows in flight),
 // parks the h values in LDS, and one half-wave quantizes the block (buf_q8_0.rs:87-134).  hidden/32
@@ -1531,8 +1559,11 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   } else {
     norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, CRABML_HIP_Q8_K);  // llama2.rs:611
     CH_TRY(P0(3, 2.0 * hidden_l, dim));
-    launch_k(st, R, k_gateup<FMT>, dim3((hidden_l + 1) / 2), dim3(128), 0, planes_k(c->gate[l]), planes_k(c->up[l]),
-             act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256);
+    {
+      const size_t lds = (size_t)dim + (size_t)(dim / 256) * 4 + (size_t)(dim / 16) * 2;
+      launch_k(st, R, k_gateup_k_lds, dim3((hidden_l + 31) / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
+               act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256);
+    }
     CH_TRY(P1());
     launch_quantize_act(st, CRABML_HIP_Q8_K, c->h, (size_t)hidden_l, c->act_hid);
     CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), hidden_l, 4));

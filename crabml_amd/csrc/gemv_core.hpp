@@ -122,8 +122,9 @@ __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const
 // Q4_K rows (planes qs[n][128] | hdr[n][16]) against a Q8_K activation vector: lane = one 16-byte qs piece j of a
 // super-block (8 lanes per super-block: a wave's load is one aligned 1 KiB request); piece j belongs to the
 // 64-element pair p = j / 2 and carries, for positions 16 (j & 1) .. +16, the low nibbles of sub-block 2p and the
-// high nibbles of sub-block 2p + 1 (buf_q4_k.rs:212-217).  The 16-byte header is fetched by all 8 lanes and the
-// 6-bit (scale, min) pairs are unpacked in registers with the reference's KMASK word trick (buf_q4_k.rs:219-234).
+// high nibbles of sub-block 2p + 1 (buf_q4_k.rs:212-217).  The 16-byte header is fetched by all 8 lanes; its
+// (scale, min) fields were re-packed pair-major at upload (common.hpp), so the lane's four 6-bit values are one
+// funnel shift and four bit-field extracts.
 template <int R>
 __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act,
                                                  int row0, int m, int nsb, int lane, float acc[R]) {
@@ -146,13 +147,9 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
     const int bs_lo = (int)bs[0], bs_hi = (int)bs[2];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      const unsigned u0 = (unsigned)hdr[r][1], u1 = (unsigned)hdr[r][2], u2 = (unsigned)hdr[r][3];
-      const unsigned S0 = u0 & 0x3f3f3f3fu, S1 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
-      const unsigned M0 = u1 & 0x3f3f3f3fu, M1 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
-      const unsigned SW = p < 2 ? S0 : S1, MW = p < 2 ? M0 : M1;  // run-time byte select: nothing spills to scratch
-      const int sh = (p & 1) * 16;
-      const int sc_lo = (int)((SW >> sh) & 0xffu), sc_hi = (int)((SW >> (sh + 8)) & 0xffu);
-      const int m_lo = (int)((MW >> sh) & 0xffu), m_hi = (int)((MW >> (sh + 8)) & 0xffu);
+      const unsigned f = q4k_pair_field((unsigned)hdr[r][1], (unsigned)hdr[r][2], (unsigned)hdr[r][3], p);
+      const int sc_lo = (int)(f & 63u), sc_hi = (int)((f >> 6) & 63u);
+      const int m_lo = (int)((f >> 12) & 63u), m_hi = (int)(f >> 18);
       int lo = 0, hi = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) {

@@ -78,18 +78,21 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
         unsigned short dh, mh;
         __builtin_memcpy(&dh, hdr, 2);
         __builtin_memcpy(&mh, hdr + 2, 2);
-        const unsigned char* sc = hdr + 4;
         const unsigned char* q4 = (const unsigned char*)w + ((size_t)row * nsb + sb) * 128;
         float aux32[8];
         for (int l = 0; l < 8; l++) aux32[l] = 0.0f;
         int scales[8], mins[8];
-        for (int j = 0; j < 8; j++) {
-          if (j < 4) {
-            scales[j] = sc[j] & 63;
-            mins[j] = sc[j + 4] & 63;
-          } else {
-            scales[j] = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4);
-            mins[j] = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4);
+        {
+          unsigned u0, u1, u2;  // the re-packed (scale, min) fields (common.hpp)
+          __builtin_memcpy(&u0, hdr + 4, 4);
+          __builtin_memcpy(&u1, hdr + 8, 4);
+          __builtin_memcpy(&u2, hdr + 12, 4);
+          for (int pp = 0; pp < 4; pp++) {
+            const unsigned f = q4k_pair_field(u0, u1, u2, pp);
+            scales[2 * pp] = (int)(f & 63u);
+            scales[2 * pp + 1] = (int)((f >> 6) & 63u);
+            mins[2 * pp] = (int)((f >> 12) & 63u);
+            mins[2 * pp + 1] = (int)(f >> 18);
           }
         }
         int sumi = 0;

@@ -35,6 +35,7 @@ struct RepackPlan {
   size_t dst_off[4];
 };
 void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, size_t n_blocks, int bb, const RepackPlan& plan);
+void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t n_blocks);
 void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out);
 
 // ---- elementwise.hip

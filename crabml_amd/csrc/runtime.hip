@@ -374,6 +374,7 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
         if (e == hipSuccess) e = hipMemcpyAsync(stage[slot], src + b0 * bb, nb * bb, hipMemcpyHostToDevice, dev->stream);
         if (e != hipSuccess) break;
         launch_repack(dev->stream, stage[slot], b->ptr, b0, nb, (int)bb, plan);
+        if (t == CRABML_HIP_Q4_K) launch_q4k_pack_scales(dev->stream, (char*)b->ptr + wl.off_scale, b0, nb);
         e = hipEventRecord(done[slot], dev->stream);
       }
       if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
