@@ -313,6 +313,8 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
   const ActLayout al = act_layout(qt, k_);
   // F32 weights take the dense f32 rhs as is (row stride k*4); quantized planes are padded per row
   const size_t act_stride = qt == CRABML_HIP_F32 ? k_ * 4 : al.total;
+  // a real batch (prefill): the weights are streamed once through the matrix cores instead of once per row
+  if (b >= 16 && launch_gemm_mfma(dev, w, m_, k_, act, b, out, rec0)) return 0;
   for (size_t bi = 0; bi < b; bi++) {
     const char* ap = (const char*)act + bi * act_stride;
     float* o = out + bi * m_;

@@ -132,6 +132,23 @@ def test_gemv_batched_rhs_and_quant_cache(ca, hdev, odev):
     assert not np.array_equal(got3, got2)
 
 
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0"])
+def test_batched_rhs_on_the_matrix_cores_is_bit_exact(ca, hdev, odev, fmt):
+    """b >= 16 activation rows take the MFMA skinny-GEMM path (gemm_mfma.hip): exact integer tiles from
+    v_mfma_i32_16x16x32_i8, scaled block by block like the reference's scalar loop -- every output equals the
+    scalar-order oracle BIT FOR BIT (stronger than the single-row fast GEMV, which re-associates).  Ragged shapes:
+    m not a multiple of 16, b not a multiple of 16 / 64, k with 1 and 9 blocks."""
+    for (m, k, b) in [(16, 32, 16), (37, 288, 17), (100, 1024, 40), (288, 288, 64), (64, 2048, 100), (1000, 4096, 33)]:
+        typ, raw, _ = make(fmt, m, k, m + k + b)
+        rng = np.random.default_rng(b)
+        x = rng.standard_normal(b * k).astype(np.float32)
+        w = ca.HipTensor.from_cpu(raw, [m, k], getattr(ca.GGMLType, HT[fmt]), hdev)
+        got = w.matmul_vec(ca.HipTensor.new(x, [b, k], hdev))
+        assert got.shape() == [b, m]
+        ref = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(x, [b, k], odev)).export()
+        assert np.array_equal(got.export().view(np.uint32), ref.view(np.uint32)), f"{fmt} m={m} k={k} b={b}"
+
+
 def test_gemv_errors(ca, hdev):
     typ, raw, x = make("Q4_0", 8, 64, 3)
     w = ca.HipTensor.from_cpu(raw, [8, 64], ca.GGMLType.Q4_0, hdev)
