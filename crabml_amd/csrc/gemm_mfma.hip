@@ -21,19 +21,23 @@
 
 namespace crabml_hip {
 
-// Workgroup = 4 waves = 64 weight rows x 64 batch columns; k runs in chunks of KC = 8 blocks staged through LDS:
-// the weights with coalesced 16-byte loads (one pass over HBM), the activation planes from L2 (shared by the four
-// waves).  LDS words are laid out [block][dword of the block][row or column, padded to 72]: the fragment reads of
-// a wave (lane = (i, g): dword g / 4 + g of row / column i) then hit every bank exactly twice.
+// Workgroup = 4 waves = 64 weight rows x 64 batch columns; k runs in chunks of KC = 8 blocks staged through two LDS
+// buffers: while a chunk is multiplied, the next one is already in flight from HBM (weights, coalesced 16-byte
+// loads: one pass) and L2 (activation planes, shared by the four waves) into registers, and lands in the other
+// buffer behind a single barrier per chunk.  LDS rows are [block][row or column][RW words] with RW = 4 (Q4_0
+// quants) or 12 (8 data words + 4 pad): staging writes are 16-byte vectors and a wave's fragment reads (lane =
+// (i, g): words g / 4 + g, or 2g / 2g + 1, of row i) hit every bank exactly twice.
 template <int FMT>
 struct GemmGeo {
-  static constexpr int KC = 8;                                  // blocks per chunk
-  static constexpr int WPB = FMT == CRABML_HIP_Q4_0 ? 4 : 8;    // dwords of quants per weight block
-  static constexpr int PAD = 72;
-  static constexpr int A_WORDS = KC * WPB * PAD;
-  static constexpr int B_WORDS = KC * 8 * PAD;
-  // bytes: A quants | B quants | A scales f16 [KC][64] | B scales f16 [KC][64] | B isum i32 [KC][64]
-  static constexpr int LDS_BYTES = (A_WORDS + B_WORDS) * 4 + KC * 64 * 2 * 2 + KC * 64 * 4;
+  static constexpr int KC = 4;                                     // blocks per chunk (37 KB of LDS per workgroup: 4 workgroups per CU)
+  static constexpr int APC = FMT == CRABML_HIP_Q4_0 ? 1 : 2;       // 16-byte pieces per weight block
+  static constexpr int ARW = FMT == CRABML_HIP_Q4_0 ? 4 : 12;      // LDS words per weight block row
+  static constexpr int BRW = 12;                                   // LDS words per activation block row
+  static constexpr int A_WORDS = KC * 64 * ARW, B_WORDS = KC * 64 * BRW;
+  // one buffer: A quants | B quants | A scales f16 [KC][64] | B scales f16 [KC][64] | B isum i32 [KC][64]
+  static constexpr int BUF_BYTES = (A_WORDS + B_WORDS) * 4 + KC * 64 * 2 * 2 + KC * 64 * 4;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+  static constexpr int A_LOADS = 64 * KC * APC / 256, B_LOADS = 64 * KC * 2 / 256, S_LOADS = 64 * KC / 256;
 };
 
 template <int FMT>
@@ -41,16 +45,66 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
                                                    const char* __restrict__ act, size_t act_stride, size_t off_d, size_t off_aux,
                                                    float* __restrict__ out, int m, int nb, int b, int row_tiles) {
   using G = GemmGeo<FMT>;
-  constexpr int KC = G::KC, WPB = G::WPB, PAD = G::PAD;
-  extern __shared__ unsigned lds_w[];
-  unsigned* sA = lds_w;
-  unsigned* sB = sA + G::A_WORDS;
-  unsigned short* sAd = (unsigned short*)(sB + G::B_WORDS);
-  unsigned short* sBd = sAd + KC * 64;
-  int* sBs = (int*)(sBd + KC * 64);
+  constexpr int KC = G::KC, APC = G::APC, ARW = G::ARW, BRW = G::BRW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = (blockIdx.x % row_tiles) * 64, c0 = (blockIdx.x / row_tiles) * 64;
   const int i = lane & 15, g = lane >> 4;
+
+  // staging registers of one chunk
+  i32x4 ra[G::A_LOADS], rb[G::B_LOADS];
+  unsigned short rad[G::S_LOADS], rbd[G::S_LOADS];
+  int rbs[G::S_LOADS];
+  auto fetch = [&](int kb0) {
+#pragma unroll
+    for (int u = 0; u < G::A_LOADS; u++) {
+      const int t = tid + 256 * u, row = t / (KC * APC), rem = t % (KC * APC), kb = rem / APC, pc = rem % APC;
+      const int grow = r0 + row < m ? r0 + row : m - 1;
+      const int gkb = kb0 + kb < nb ? kb0 + kb : nb - 1;  // the tail chunk re-reads the last block (never consumed)
+      ra[u] = __builtin_nontemporal_load((const i32x4*)wq + ((size_t)grow * nb + gkb) * APC + pc);
+    }
+#pragma unroll
+    for (int u = 0; u < G::B_LOADS; u++) {
+      const int t = tid + 256 * u, col = t / (KC * 2), rem = t % (KC * 2), kb = rem / 2, pc = rem % 2;
+      const int gcol = c0 + col < b ? c0 + col : b - 1;
+      const int gkb = kb0 + kb < nb ? kb0 + kb : nb - 1;
+      rb[u] = *((const i32x4*)(act + (size_t)gcol * act_stride) + (size_t)gkb * 2 + pc);
+    }
+#pragma unroll
+    for (int u = 0; u < G::S_LOADS; u++) {
+      const int t = tid + 256 * u, rc = t / KC, kb = t % KC;
+      const int grow = r0 + rc < m ? r0 + rc : m - 1, gcol = c0 + rc < b ? c0 + rc : b - 1;
+      const int gkb = kb0 + kb < nb ? kb0 + kb : nb - 1;
+      const char* ap = act + (size_t)gcol * act_stride;
+      rad[u] = wd[(size_t)grow * nb + gkb];
+      rbd[u] = ((const unsigned short*)(ap + off_d))[gkb];
+      rbs[u] = ((const int*)(ap + off_aux))[gkb];
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned* sA = (unsigned*)(lds_raw + (size_t)buf * G::BUF_BYTES);
+    unsigned* sB = sA + G::A_WORDS;
+    unsigned short* sAd = (unsigned short*)(sB + G::B_WORDS);
+    unsigned short* sBd = sAd + KC * 64;
+    int* sBs = (int*)(sBd + KC * 64);
+#pragma unroll
+    for (int u = 0; u < G::A_LOADS; u++) {
+      const int t = tid + 256 * u, row = t / (KC * APC), rem = t % (KC * APC), kb = rem / APC, pc = rem % APC;
+      *(i32x4*)(sA + (kb * 64 + row) * ARW + pc * 4) = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < G::B_LOADS; u++) {
+      const int t = tid + 256 * u, col = t / (KC * 2), rem = t % (KC * 2), kb = rem / 2, pc = rem % 2;
+      *(i32x4*)(sB + (kb * 64 + col) * BRW + pc * 4) = rb[u];
+    }
+#pragma unroll
+    for (int u = 0; u < G::S_LOADS; u++) {
+      const int t = tid + 256 * u, rc = t / KC, kb = t % KC;
+      sAd[kb * 64 + rc] = rad[u];
+      sBd[kb * 64 + rc] = rbd[u];
+      sBs[kb * 64 + rc] = rbs[u];
+    }
+  };
 
   float F[4][4];
 #pragma unroll
@@ -58,80 +112,62 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
 #pragma unroll
     for (int r = 0; r < 4; r++) F[jt][r] = 0.0f;
 
-  for (int kb0 = 0; kb0 < nb; kb0 += KC) {
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kb0 = 0; kb0 < nb; kb0 += KC, buf ^= 1) {
     const int kc = nb - kb0 < KC ? nb - kb0 : KC;
-    __syncthreads();  // the previous chunk has been consumed
-    // ---- stage A: 64 rows x kc blocks; a thread moves 16 bytes (one Q4_0 block, half a Q8_0 block)
-    constexpr int PIECES = WPB / 4;  // 16-byte pieces per block
-    for (int t = tid; t < 64 * KC * PIECES; t += 256) {
-      const int row = t / (KC * PIECES), rem = t % (KC * PIECES), kb = rem / PIECES, pc = rem % PIECES;
-      if (kb < kc) {
-        const int grow = r0 + row < m ? r0 + row : m - 1;
-        const i32x4 v = __builtin_nontemporal_load((const i32x4*)wq + ((size_t)grow * nb + kb0 + kb) * PIECES + pc);
-#pragma unroll
-        for (int q = 0; q < 4; q++) sA[(kb * WPB + pc * 4 + q) * PAD + row] = (unsigned)v[q];
-      }
-    }
-    for (int t = tid; t < 64 * KC; t += 256) {
-      const int row = t / KC, kb = t % KC;
-      if (kb < kc) {
-        const int grow = r0 + row < m ? r0 + row : m - 1;
-        sAd[kb * 64 + row] = wd[(size_t)grow * nb + kb0 + kb];
-      }
-    }
-    // ---- stage B: 64 columns x kc blocks x 32 int8 (two 16-byte pieces), scales, block sums
-    for (int t = tid; t < 64 * KC * 2; t += 256) {
-      const int col = t / (KC * 2), rem = t % (KC * 2), kb = rem / 2, pc = rem % 2;
-      if (kb < kc) {
-        const int gcol = c0 + col < b ? c0 + col : b - 1;
-        const i32x4 v = *((const i32x4*)(act + (size_t)gcol * act_stride) + (size_t)(kb0 + kb) * 2 + pc);
-#pragma unroll
-        for (int q = 0; q < 4; q++) sB[(kb * 8 + pc * 4 + q) * PAD + col] = (unsigned)v[q];
-      }
-    }
-    for (int t = tid; t < 64 * KC; t += 256) {
-      const int col = t / KC, kb = t % KC;
-      if (kb < kc) {
-        const int gcol = c0 + col < b ? c0 + col : b - 1;
-        const char* ap = act + (size_t)gcol * act_stride;
-        sBd[kb * 64 + col] = ((const unsigned short*)(ap + off_d))[kb0 + kb];
-        sBs[kb * 64 + col] = ((const int*)(ap + off_aux))[kb0 + kb];
-      }
-    }
-    __syncthreads();
-    // ---- compute: wave = rows 16 wave .. +16, all 4 column tiles
+    const bool more = kb0 + KC < nb;
+    if (more) fetch(kb0 + KC);  // in flight while this chunk is multiplied
+    const unsigned* sA = (const unsigned*)(lds_raw + (size_t)buf * G::BUF_BYTES);
+    const unsigned* sB = sA + G::A_WORDS;
+    const unsigned short* sAd = (const unsigned short*)(sB + G::B_WORDS);
+    const unsigned short* sBd = sAd + KC * 64;
+    const int* sBs = (const int*)(sBd + KC * 64);
     for (int kb = 0; kb < kc; kb++) {
       long A;
+      const unsigned* arow = sA + (kb * 64 + 16 * wave + i) * ARW;
       if (FMT == CRABML_HIP_Q4_0) {
-        const unsigned w = sA[(kb * 4 + g) * PAD + 16 * wave + i];
+        const unsigned w = arow[g];
         A = (long)(((unsigned long long)((w >> 4) & 0x0F0F0F0Fu) << 32) | (unsigned long long)(w & 0x0F0F0F0Fu));
       } else {
-        const unsigned lo = sA[(kb * 8 + 2 * g) * PAD + 16 * wave + i], hi = sA[(kb * 8 + 2 * g + 1) * PAD + 16 * wave + i];
-        A = (long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+        A = *(const long*)(arow + 2 * g);
       }
       float dw[4];
+      {
+        const unsigned long long d4 = *(const unsigned long long*)(sAd + kb * 64 + 16 * wave + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; r++) dw[r] = h2f(sAd[kb * 64 + 16 * wave + 4 * g + r]);
+        for (int r = 0; r < 4; r++) dw[r] = h2f((unsigned short)(d4 >> (16 * r)));
+      }
+      // all four column tiles: fragments first, then the four MFMAs back to back (independent accumulators),
+      // then the scaling -- a single wave per SIMD has nothing else to hide the LDS and MFMA latencies behind
+      long Bf[4];
+      int cin[4];
+      float dx[4];
 #pragma unroll
       for (int jt = 0; jt < 4; jt++) {
         const int col = 16 * jt + i;
-        unsigned lo, hi;
-        if (FMT == CRABML_HIP_Q4_0) {
-          lo = sB[(kb * 8 + g) * PAD + col];
-          hi = sB[(kb * 8 + 4 + g) * PAD + col];
-        } else {
-          lo = sB[(kb * 8 + 2 * g) * PAD + col];
-          hi = sB[(kb * 8 + 2 * g + 1) * PAD + col];
-        }
-        const long B = (long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+        const unsigned* brow = sB + (kb * 64 + col) * BRW;
+        if (FMT == CRABML_HIP_Q4_0)
+          Bf[jt] = (long)(((unsigned long long)brow[4 + g] << 32) | (unsigned long long)brow[g]);
+        else
+          Bf[jt] = *(const long*)(brow + 2 * g);
         // Q4_0: the -8 offset rides in as the accumulator input, -8 * sum(x) of the lane's column (exact)
-        const int cin = FMT == CRABML_HIP_Q4_0 ? -8 * sBs[kb * 64 + col] : 0;
-        const i32x4 D = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, B, i32x4{cin, cin, cin, cin}, 0, 0, 0);
-        const float dx = h2f(sBd[kb * 64 + col]);
-#pragma unroll
-        for (int r = 0; r < 4; r++) F[jt][r] += ((float)D[r] * dw[r]) * dx;
+        cin[jt] = FMT == CRABML_HIP_Q4_0 ? -8 * sBs[kb * 64 + col] : 0;
+        dx[jt] = h2f(sBd[kb * 64 + col]);
       }
+      i32x4 D[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; jt++)
+        D[jt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bf[jt], i32x4{cin[jt], cin[jt], cin[jt], cin[jt]}, 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < 4; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) F[jt][r] += ((float)D[jt][r] * dw[r]) * dx[jt];
     }
+    if (more) commit(buf ^ 1);  // the other buffer was last read one iteration ago (barrier below)
+    __syncthreads();
   }
 #pragma unroll
   for (int jt = 0; jt < 4; jt++) {
