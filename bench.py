@@ -268,8 +268,8 @@ def main():
     # and launch geometry) with one event pair per GEMV stage, on the backend's own stream.
     roof = None
     if rank == 0:
-        STAGES = {0: "matmul_vec (per-op path)", 1: "k_qkv (wq|wk|wv + rope + KV append)", 2: "k_gemv_res (wo + residual)",
-                  3: "k_gateup_q (gate|up + silu*mul + quantize)", 4: "k_gemv_res (ffn_down + residual)",
+        STAGES = {0: "matmul_vec (per-op path)", 1: "k_qkv (wq|wk|wv + rope + KV append)", 2: "wo GEMV + residual (+ next rmsnorm/quantize epilogue)",
+                  3: "k_gateup_q (gate|up + silu*mul + quantize)", 4: "ffn_down GEMV + residual (+ next rmsnorm/quantize epilogue)",
                   5: "k_gemv (classifier)"}
         n_prof = min(args.steps, 16)
         if path == "fused":
