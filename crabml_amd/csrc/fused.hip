@@ -921,8 +921,8 @@ __global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, Act
   const int row0 = blockIdx.x * 32 + wave * 2;
   if (row0 >= m) return;
   float ag[2], au[2];
-  rows_partial_q4k<2>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag);
-  rows_partial_q4k<2>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
+  rows_partial_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag);
+  rows_partial_q4k<2, false>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const float g = wave_sum_f32(ag[r]), u = wave_sum_f32(au[r]);

@@ -122,10 +122,14 @@ __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const
 // Q4_K rows (planes qs[n][128] | hdr[n][16]) against a Q8_K activation vector: lane = one 16-byte qs piece j of a
 // super-block (8 lanes per super-block: a wave's load is one aligned 1 KiB request); piece j belongs to the
 // 64-element pair p = j / 2 and carries, for positions 16 (j & 1) .. +16, the low nibbles of sub-block 2p and the
-// high nibbles of sub-block 2p + 1 (buf_q4_k.rs:212-217).  The 16-byte header is fetched by all 8 lanes; its
+// high nibbles of sub-block 2p + 1 (buf_q4_k.rs:212-217).  The 16-byte header is shared by the 8 lanes; its
 // (scale, min) fields were re-packed pair-major at upload (common.hpp), so the lane's four 6-bit values are one
 // funnel shift and four bit-field extracts.
-template <int R>
+// HDR_DPP: each lane loads ONE dword of the 16-byte header (lane & 3 selects it) and the quad exchanges the four
+// dwords with DPP -- 4 instead of 16 header bytes per lane through the vector-memory path (measured: down 12.9 ->
+// 11.5 us, classifier 53.7 -> 49.3 us); with the activation planes in LDS that path is no longer the bottleneck
+// and the plain 16-byte load is faster (gate/up 15.9 vs 17.1 us), hence the switch.
+template <int R, bool HDR_DPP = true>
 __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act,
                                                  int row0, int m, int nsb, int lane, float acc[R]) {
 #pragma unroll
@@ -134,11 +138,15 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
   for (int c = lane; c < nchunks; c += 64) {
     const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
     i32x4 qv[R], hdr[R];
+    unsigned hw[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int row = row0 + r < m ? row0 + r : m - 1;
       qv[r] = __builtin_nontemporal_load(wq + (size_t)row * nchunks + c);
-      hdr[r] = __builtin_nontemporal_load(wh + (size_t)row * nsb + sb);
+      if constexpr (HDR_DPP)
+        hw[r] = __builtin_nontemporal_load((const unsigned*)wh + ((size_t)row * nsb + sb) * 4 + (lane & 3));
+      else
+        hdr[r] = __builtin_nontemporal_load(wh + (size_t)row * nsb + sb);
     }
     const i32x4* xq = act.q + (size_t)sb * 16 + p * 4 + h;
     const i32x4 xl = xq[0], xh = xq[2];
@@ -147,7 +155,19 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
     const int bs_lo = (int)bs[0], bs_hi = (int)bs[2];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      const unsigned f = q4k_pair_field((unsigned)hdr[r][1], (unsigned)hdr[r][2], (unsigned)hdr[r][3], p);
+      unsigned h0, h1, h2, h3;
+      if constexpr (HDR_DPP) {  // quad_perm broadcasts of dword 0..3
+        h0 = (unsigned)dpp_i<0x00>((int)hw[r]);
+        h1 = (unsigned)dpp_i<0x55>((int)hw[r]);
+        h2 = (unsigned)dpp_i<0xAA>((int)hw[r]);
+        h3 = (unsigned)dpp_i<0xFF>((int)hw[r]);
+      } else {
+        h0 = (unsigned)hdr[r][0];
+        h1 = (unsigned)hdr[r][1];
+        h2 = (unsigned)hdr[r][2];
+        h3 = (unsigned)hdr[r][3];
+      }
+      const unsigned f = q4k_pair_field(h1, h2, h3, p);
       const int sc_lo = (int)(f & 63u), sc_hi = (int)((f >> 6) & 63u);
       const int m_lo = (int)((f >> 12) & 63u), m_hi = (int)(f >> 18);
       int lo = 0, hi = 0;
@@ -158,8 +178,8 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
       }
       const int isum = sc_lo * lo + sc_hi * hi;      // exact (the reference's aux32 lanes hold integers < 2^24)
       const int msum = m_lo * bs_lo + m_hi * bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
-      const float dd = h2f((unsigned short)(hdr[r][0] & 0xffff)) * d8;
-      const float dmin = h2f((unsigned short)((unsigned)hdr[r][0] >> 16)) * d8;
+      const float dd = h2f((unsigned short)(h0 & 0xffff)) * d8;
+      const float dmin = h2f((unsigned short)(h0 >> 16)) * d8;
       acc[r] += dd * (float)isum - dmin * (float)msum;
     }
   }
