@@ -34,12 +34,12 @@ def _rand_bytes(rng: np.random.Generator, n: int) -> np.ndarray:
     """n pseudo-random bytes at memcpy speed: a 32 MiB PCG64 pool, re-entered at a random offset per call
     (multi-GB models would otherwise spend a minute in the generator; HBM traffic does not care that the
     byte stream repeats every 32 MiB at different addresses)."""
-    key = id(rng.bit_generator)
-    pool = _POOL.get(key)
-    if pool is None:
+    entry = _POOL.get("pool")
+    if entry is None or entry[0] is not rng:  # identity, not id(): a freed generator's id can be reused
         pool = np.frombuffer(rng.bytes(32 << 20), dtype=np.uint8)
-        _POOL.clear()
-        _POOL[key] = pool
+        _POOL["pool"] = (rng, pool)
+    else:
+        pool = entry[1]
     if n <= 4096:
         return np.frombuffer(rng.bytes(n), dtype=np.uint8).copy()
     off = int(rng.integers(0, pool.size))
