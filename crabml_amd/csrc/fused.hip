@@ -783,26 +783,23 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, ActQ8_0 act, flo
   float acc[RW];
 #pragma unroll
   for (int r = 0; r < RW; r++) acc[r] = 0.f;
-  const size_t base0 = (size_t)row * nb;
-  for (int b = lane; b < nb; b += 128) {
-    const int b2 = b + 64;
-    const bool two = b2 < nb;
-    const int bb = two ? b2 : b;
+  const int nu = nb * F::UNITS;
+  for (int u = lane; u < nu; u += 128) {
+    const int u2 = u + 64;
+    const bool two = u2 < nu;
+    const int uu = two ? u2 : u;
     typename F::Blk ka[RW], kb[RW];
 #pragma unroll
     for (int r = 0; r < RW; r++) {
-      ka[r] = F::load(w.q, w.d, base0 + (size_t)r * nb + b);
-      kb[r] = F::load(w.q, w.d, base0 + (size_t)r * nb + bb);
+      ka[r] = F::load(w.q, w.d, (size_t)(row + r), nb, u);
+      kb[r] = F::load(w.q, w.d, (size_t)(row + r), nb, uu);
     }
-    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
-    i32x4 y0 = act.q[2 * bb], y1 = act.q[2 * bb + 1];
-    float dx = h2f(act.d[b]), dy = h2f(act.d[bb]);
-    int xs = act.isum[b], ys = act.isum[bb];
+    const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
 #pragma unroll
-    for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], x0, x1, dx, xs);
+    for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], xa);
     if (two) {
 #pragma unroll
-      for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], y0, y1, dy, ys);
+      for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], xb);
     }
   }
 #pragma unroll
@@ -944,19 +941,17 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, ActQ8_0
   const int blk = blockIdx.x;
   const int row = blk * 32 + wave * 2;  // rows row, row+1
   float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
-  for (int b = lane; b < nb; b += 64) {
-    size_t i0 = (size_t)row * nb + b, i1 = i0 + nb;
-    typename F::Blk bg0 = F::load(wg.q, wg.d, i0);
-    typename F::Blk bu0 = F::load(wu.q, wu.d, i0);
-    typename F::Blk bg1 = F::load(wg.q, wg.d, i1);
-    typename F::Blk bu1 = F::load(wu.q, wu.d, i1);
-    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
-    float dx = h2f(act.d[b]);
-    int xs = act.isum[b];
-    g0 += F::term(bg0, x0, x1, dx, xs);
-    u0 += F::term(bu0, x0, x1, dx, xs);
-    g1 += F::term(bg1, x0, x1, dx, xs);
-    u1 += F::term(bu1, x0, x1, dx, xs);
+  const int nu = nb * F::UNITS;
+  for (int u = lane; u < nu; u += 64) {
+    typename F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, u);
+    typename F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, u);
+    typename F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
+    typename F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
+    const XUnit x = F::loadx(act, u);
+    g0 += F::term(bg0, x);
+    u0 += F::term(bu0, x);
+    g1 += F::term(bg1, x);
+    u1 += F::term(bu1, x);
   }
   g0 = wave_sum_f32(g0);
   u0 = wave_sum_f32(u0);

@@ -66,27 +66,7 @@ __global__ __launch_bounds__(256) void k_gemv_q8_0(const i32x4* __restrict__ wq,
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) acc[r] = 0.f;
-  for (int b = lane; b < nb; b += 64) {
-    i32x4 q0[R], q1[R];
-    unsigned short dw[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int row = row0 + r < m ? row0 + r : m - 1;
-      size_t idx = (size_t)row * nb + b;
-      q0[r] = __builtin_nontemporal_load(wq + 2 * idx);
-      q1[r] = __builtin_nontemporal_load(wq + 2 * idx + 1);
-      dw[r] = __builtin_nontemporal_load(wd + idx);
-    }
-    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
-    float dx = h2f(act.d[b]);
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int si = dot_i8x32(q0[r], q1[r], x0, x1);
-      acc[r] += ((float)si * h2f(dw[r])) * dx;  // buf_q8_0.rs:282
-    }
-  }
+  rows_partial<CRABML_HIP_Q8_0, R>(wq, wd, act, row0, m, nb, lane, acc);  // half a block per lane (gemv_core.hpp)
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float s = wave_sum_f32(acc[r]);

@@ -55,67 +55,88 @@ struct ActQ8_K {
   const short* bsums;
 };
 
-// ---- per-format block access for the 32-element formats whose rhs is Q8_0 -----------------------
+// ---- per-format access for the 32-element formats whose rhs is Q8_0 --------------------------------------
+// A lane processes one 16-byte UNIT of quants per step, so that a wave's weight load is always one aligned 1 KiB
+// request: a whole Q4_0 block (32 nibbles), or HALF a Q8_0 block (16 int8; the two lanes of a block add their
+// integer partials with one DPP swap, so the block's `sumi` stays exact and only the even lane contributes the
+// scaled term).  A row has nu = nb * UNITS units; unit u of row r is quant word r * nu + u and uses the scale of
+// block u / UNITS.
+struct XUnit {  // the activation side of one unit
+  i32x4 x0, x1;
+  float dx;
+  int xs;
+};
 template <int FMT>
 struct BlockFmt;
 
 template <>
 struct BlockFmt<CRABML_HIP_Q4_0> {
+  static constexpr int UNITS = 1;
   struct Blk {
     i32x4 q;
     unsigned short d;
   };
-  static __device__ __forceinline__ Blk load(const i32x4* wq, const unsigned short* wd, size_t idx) {
+  static __device__ __forceinline__ Blk load(const i32x4* wq, const unsigned short* wd, size_t row, int nb, int u) {
     Blk b;
-    b.q = __builtin_nontemporal_load(wq + idx);
-    b.d = __builtin_nontemporal_load(wd + idx);
+    b.q = __builtin_nontemporal_load(wq + row * nb + u);
+    b.d = __builtin_nontemporal_load(wd + row * nb + u);
     return b;
   }
+  static __device__ __forceinline__ XUnit loadx(const ActQ8_0& act, int u) {
+    return XUnit{act.q[2 * u], act.q[2 * u + 1], h2f(act.d[u]), act.isum[u]};
+  }
   // buf_q4_0.rs:249: sumi as f32 * d_w * d_x
-  static __device__ __forceinline__ float term(const Blk& b, i32x4 x0, i32x4 x1, float dx, int xs) {
-    return ((float)dot_q4_0(b.q, x0, x1, xs) * h2f(b.d)) * dx;
+  static __device__ __forceinline__ float term(const Blk& b, const XUnit& x) {
+    return ((float)dot_q4_0(b.q, x.x0, x.x1, x.xs) * h2f(b.d)) * x.dx;
   }
 };
 
 template <>
 struct BlockFmt<CRABML_HIP_Q8_0> {
+  static constexpr int UNITS = 2;
   struct Blk {
-    i32x4 q0, q1;
+    i32x4 q;
     unsigned short d;
   };
-  static __device__ __forceinline__ Blk load(const i32x4* wq, const unsigned short* wd, size_t idx) {
+  static __device__ __forceinline__ Blk load(const i32x4* wq, const unsigned short* wd, size_t row, int nb, int u) {
     Blk b;
-    b.q0 = __builtin_nontemporal_load(wq + 2 * idx);
-    b.q1 = __builtin_nontemporal_load(wq + 2 * idx + 1);
-    b.d = __builtin_nontemporal_load(wd + idx);
+    b.q = __builtin_nontemporal_load(wq + row * (2 * (size_t)nb) + u);
+    b.d = __builtin_nontemporal_load(wd + row * nb + (u >> 1));
     return b;
   }
-  // buf_q8_0.rs:282
-  static __device__ __forceinline__ float term(const Blk& b, i32x4 x0, i32x4 x1, float dx, int) {
-    return ((float)dot_i8x32(b.q0, b.q1, x0, x1) * h2f(b.d)) * dx;
+  static __device__ __forceinline__ XUnit loadx(const ActQ8_0& act, int u) {
+    return XUnit{act.q[u], i32x4{0, 0, 0, 0}, h2f(act.d[u >> 1]), 0};
+  }
+  // buf_q8_0.rs:282; lanes 2j / 2j+1 hold the two halves of a block (both active: nu is even)
+  static __device__ __forceinline__ float term(const Blk& b, const XUnit& x) {
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s = __builtin_amdgcn_sdot4(b.q[i], x.x0[i], s, false);
+    s += dpp_i<0xB1>(s);  // quad_perm [1,0,3,2]: the partner's half
+    const float t = ((float)s * h2f(b.d)) * x.dx;
+    return (threadIdx.x & 1) ? 0.0f : t;
   }
 };
 
-// Per-lane partial sums of R rows of one weight matrix against one quantized activation vector: lane l
-// owns blocks l, l+64, ...  The R block loads of a step are issued before any is consumed.
+// Per-lane partial sums of R rows of one weight matrix against one quantized activation vector: lane l owns
+// units l, l+64, ...  The R unit loads of a step are issued before any is consumed.
 template <int FMT, int R>
 __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
                                              const ActQ8_0& act, int row0, int m, int nb, int lane, float acc[R]) {
   using F = BlockFmt<FMT>;
 #pragma unroll
   for (int r = 0; r < R; r++) acc[r] = 0.f;
-  for (int b = lane; b < nb; b += 64) {
+  const int nu = nb * F::UNITS;
+  for (int u = lane; u < nu; u += 64) {
     typename F::Blk blk[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int row = row0 + r < m ? row0 + r : m - 1;
-      blk[r] = F::load(wq, wd, (size_t)row * nb + b);
+      blk[r] = F::load(wq, wd, (size_t)row, nb, u);
     }
-    i32x4 x0 = act.q[2 * b], x1 = act.q[2 * b + 1];
-    float dx = h2f(act.d[b]);
-    int xs = act.isum[b];
+    const XUnit x = F::loadx(act, u);
 #pragma unroll
-    for (int r = 0; r < R; r++) acc[r] += F::term(blk[r], x0, x1, dx, xs);
+    for (int r = 0; r < R; r++) acc[r] += F::term(blk[r], x);
   }
 }
 
