@@ -14,6 +14,7 @@ ap.add_argument("--no-norm-epilogue", action="store_true")
 ap.add_argument("--flags", type=int, default=0)
 ap.add_argument("--hidden", type=int, default=0, help="experiment: override the ffn hidden size")
 ap.add_argument("--layers", type=int, default=0)
+ap.add_argument("--vocab", type=int, default=0, help="experiment: override the vocabulary size")
 ap.add_argument("--attn-long-from", type=int, default=0)
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--pos0", type=int, default=8)
@@ -24,6 +25,8 @@ NAMES = {1: "qkv", 2: "wo+res", 3: "gateup_q", 4: "down+res", 5: "classifier", 6
 shape = synth.SHAPES[a.model]
 if a.hidden:
     shape = synth.ModelShape(**{**shape.__dict__, "hidden": a.hidden})
+if a.vocab:
+    shape = synth.ModelShape(**{**shape.__dict__, "vocab": a.vocab})
 model = synth.build_model(shape, synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers or None)
 dev = ca.HipTensorDevice(0)
 conf, w = synth.to_hip(model, dev)
