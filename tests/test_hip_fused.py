@@ -243,3 +243,20 @@ def test_q4_k_fused_kernels_equal_the_per_op_segments(ca):
     for i, t in enumerate(PROMPT + [5, 6, 7]):
         a, b = fused.forward(t, i), per_op.forward(t, i)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+
+
+def test_in_launch_hand_offs_under_load_llama3_8b_shape(ca):
+    """Soak at the benchmark's own shape (Llama-3-8B rows, 8 layers, every CU streaming): 400 greedy tokens through
+    the norm-epilogue kernels (granule gather over 128 / 256 workgroups) must equal, token for token, the run with
+    RMSNorm as its own launch -- a single stale or torn granule would change a logit and, within a few steps, the
+    sampled sequence."""
+    model = synth.build_model(synth.SHAPES["llama3-8b"], synth.Q4_0, seed=71, n_layers=8)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, 448, True)
+    b = ca.HipLlamaRunner(conf, w, dev, 448, True, norm_epilogue=False)
+    ta = a.decode_greedy(1, 400)
+    tb = b.decode_greedy(1, 400)
+    assert list(ta) == list(tb)
+    la, lb = a.forward(int(ta[-1]), 400), b.forward(int(tb[-1]), 400)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
