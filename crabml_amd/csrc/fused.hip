@@ -1468,11 +1468,14 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
   return 0;
 }
 
-// Q4_K layers (fast mode): the fused GEMV kernels with the Q4_K inner loop and Q8_K activation planes.  The rhs
-// quantizer is its own launch here (a Q8_K super-block spans 256 rows: eight 32-row workgroups), so a layer is
-// 11 launches instead of the per-op path's 18.
+// Q4_K and Q4_1 layers (fast mode): the fused GEMV kernels with the format's inner loop against Q8_K / Q8_1
+// activation planes.  The rhs quantizer is its own launch here (a Q8_K super-block spans 256 rows: eight 32-row
+// workgroups; Q8_1 keeps the same structure), so a layer is 11 launches instead of the per-op path's 18.
+template <int FMT>
 int enqueue_segment_k(crabml_hip_llama* c, int seg) {
-  constexpr int FMT = CRABML_HIP_Q4_K;
+  constexpr uint32_t QT = FMT == CRABML_HIP_Q4_K ? CRABML_HIP_Q8_K : CRABML_HIP_Q8_1;
+  constexpr int BE = FMT == CRABML_HIP_Q4_K ? 256 : 32;  // elements per weight block
+  typedef typename ActOf<FMT>::type Act;
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
   const auto& g = c->cfg;
@@ -1487,14 +1490,17 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   const bool prof = dev->prof_on && !c->use_graph && !c->capturing;
   crabml_hip_device::ProfRec pr{};
   crabml_hip_device::ProfRec* R = prof ? &pr : nullptr;
-  const double blk_b = 144.0 / 256.0;
+  const double blk_b = (double)block_bytes(FMT) / (double)BE;
   auto P0 = [&](uint32_t stage, double rows, double k) {
     return prof ? prof_begin(dev, &pr, FMT, stage, rows * k * blk_b + 4.0 * k + 4.0 * rows) : 0;
   };
   auto P1 = [&]() { return prof ? prof_end(dev, &pr) : 0; };
   auto act_k = [&](char* planes, int n) {
-    ActLayout al = act_layout(CRABML_HIP_Q8_K, (size_t)n);
-    return ActQ8_K{(const i32x4*)planes, (const float*)(planes + al.off_d), (const short*)(planes + al.off_aux)};
+    ActLayout al = act_layout(QT, (size_t)n);
+    if constexpr (FMT == CRABML_HIP_Q4_K)
+      return ActQ8_K{(const i32x4*)planes, (const float*)(planes + al.off_d), (const short*)(planes + al.off_aux)};
+    else
+      return ActQ8_1{(const i32x4*)planes, (const unsigned short*)(planes + al.off_d), (const unsigned short*)(planes + al.off_aux)};
   };
   auto planes_k = [&](const crabml_hip_buf* b) {
     return Planes{(const i32x4*)b->ptr, (const unsigned short*)((const char*)b->ptr + b->wl.off_scale)};
@@ -1512,12 +1518,12 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     return c->act_dim;
   };
   float* dst = tp ? c->partial : c->x;
-  auto gemv_out = [&](const crabml_hip_buf* w, const ActQ8_K& a, int k, uint32_t stage) -> int {
+  auto gemv_out = [&](const crabml_hip_buf* w, const Act& a, int k, uint32_t stage) -> int {
     CH_TRY(P0(stage, dim, k));
     if (tp)
-      launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_k(w), a, dst, dim, k / 256);
+      launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_k(w), a, dst, dim, k / BE);
     else
-      launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_k(w), a, dst, dim, k / 256);
+      launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_k(w), a, dst, dim, k / BE);
     return P1();
   };
 
@@ -1540,27 +1546,30 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     if (l == 0)
       k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
                                                   c->token_embed->wl.off_scale, token_d, dim, c->x);
-    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, CRABML_HIP_Q8_K);
+    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, QT);
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(1, total_rows, dim));
     launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
-             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / 256, e);
+             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e);
     CH_TRY(P1());
     enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
-    launch_quantize_act(st, CRABML_HIP_Q8_K, c->attn, (size_t)dim_l, c->act_attn);
+    launch_quantize_act(st, QT, c->attn, (size_t)dim_l, c->act_attn);
     CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), dim_l, 2));
   } else {
-    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, CRABML_HIP_Q8_K);  // llama2.rs:611
+    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, QT);  // llama2.rs:611
     CH_TRY(P0(3, 2.0 * hidden_l, dim));
-    {
+    if constexpr (FMT == CRABML_HIP_Q4_K) {
       const size_t lds = (size_t)dim + (size_t)(dim / 256) * 4 + (size_t)(dim / 16) * 2;
       launch_k(st, R, k_gateup_k_lds, dim3((hidden_l + 31) / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
                act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256);
+    } else {
+      launch_k(st, R, k_gateup<FMT>, dim3((hidden_l + 1) / 2), dim3(128), 0, planes_k(c->gate[l]), planes_k(c->up[l]),
+               act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / BE);
     }
     CH_TRY(P1());
-    launch_quantize_act(st, CRABML_HIP_Q8_K, c->h, (size_t)hidden_l, c->act_hid);
+    launch_quantize_act(st, QT, c->h, (size_t)hidden_l, c->act_hid);
     CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), hidden_l, 4));
   }
   CH_HIP(dev, hipGetLastError());
@@ -1568,7 +1577,8 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
 }
 
 int enqueue_segment(crabml_hip_llama* c, int seg) {
-  if (c->kfused) return enqueue_segment_k(c, seg);
+  if (c->kfused)
+    return c->wtype == CRABML_HIP_Q4_K ? enqueue_segment_k<CRABML_HIP_Q4_K>(c, seg) : enqueue_segment_k<CRABML_HIP_Q4_1>(c, seg);
   if (c->generic) return enqueue_segment_generic(c, seg);
   return c->wtype == CRABML_HIP_Q4_0 ? enqueue_segment_t<CRABML_HIP_Q4_0>(c, seg) : enqueue_segment_t<CRABML_HIP_Q8_0>(c, seg);
 }
@@ -1724,7 +1734,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->cfg = g;
   c->wtype = wt;
   c->generic = generic;
-  c->kfused = !dev->strict_order && wt == CRABML_HIP_Q4_K && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION);
+  c->kfused = !dev->strict_order && (wt == CRABML_HIP_Q4_K || wt == CRABML_HIP_Q4_1) && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION);
   c->qt = qt;
   c->out_qt = out_qt;
   c->tp = tp;

@@ -83,28 +83,7 @@ __global__ __launch_bounds__(256) void k_gemv_q4_1(const i32x4* __restrict__ wq,
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) acc[r] = 0.f;
-  for (int b = lane; b < nb; b += 64) {
-    i32x4 q[R];
-    unsigned dm[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int row = row0 + r < m ? row0 + r : m - 1;
-      size_t idx = (size_t)row * nb + b;
-      q[r] = __builtin_nontemporal_load(wq + idx);
-      dm[r] = __builtin_nontemporal_load(wdm + idx);
-    }
-    i32x4 xlo = act.q[2 * b], xhi = act.q[2 * b + 1];
-    unsigned short dx = act.d[b], sx = act.s[b];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int si = dot_u4(q[r], xlo, xhi);
-      unsigned short dwh = (unsigned short)(dm[r] & 0xffffu), mwh = (unsigned short)(dm[r] >> 16);
-      // buf_q4_1.rs:276: (d_w * d_x) and (m * s) are f16 products rounded to f16 by the half crate
-      acc[r] += h2f(h_mul(dwh, dx)) * (float)si + h2f(h_mul(mwh, sx));
-    }
-  }
+  rows_partial<CRABML_HIP_Q4_1, R>(wq, (const unsigned short*)wdm, act, row0, m, nb, lane, acc);  // gemv_core.hpp
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float s = wave_sum_f32(acc[r]);

@@ -64,7 +64,7 @@ struct ActQ8_K {
 struct XUnit {  // the activation side of one unit
   i32x4 x0, x1;
   float dx;
-  int xs;
+  int xs;  // Q4_0: sum of the block's quants; Q4_1: the Q8_1 block's raw f16 pair d | s << 16
 };
 template <int FMT>
 struct BlockFmt;
@@ -118,11 +118,36 @@ struct BlockFmt<CRABML_HIP_Q8_0> {
   }
 };
 
+template <>
+struct BlockFmt<CRABML_HIP_Q4_1> {  // planes qs[n][16] | (d, m)[n] f16 pairs; rhs Q8_1 (q | d | s)
+  static constexpr int UNITS = 1;
+  struct Blk {
+    i32x4 q;
+    unsigned dm;
+  };
+  static __device__ __forceinline__ Blk load(const i32x4* wq, const unsigned short* wd, size_t row, int nb, int u) {
+    Blk b;
+    b.q = __builtin_nontemporal_load(wq + row * nb + u);
+    b.dm = __builtin_nontemporal_load((const unsigned*)wd + row * nb + u);
+    return b;
+  }
+  static __device__ __forceinline__ XUnit loadx(const ActQ8_1& act, int u) {
+    return XUnit{act.q[2 * u], act.q[2 * u + 1], 0.0f, (int)((unsigned)act.d[u] | ((unsigned)act.s[u] << 16))};
+  }
+  // buf_q4_1.rs:276: (d_w * d_x) and (m * s) are f16 products rounded to f16 by the half crate
+  static __device__ __forceinline__ float term(const Blk& b, const XUnit& x) {
+    const int si = dot_u4(b.q, x.x0, x.x1);
+    const unsigned short dwh = (unsigned short)(b.dm & 0xffffu), mwh = (unsigned short)(b.dm >> 16);
+    const unsigned short dxh = (unsigned short)((unsigned)x.xs & 0xffffu), sxh = (unsigned short)((unsigned)x.xs >> 16);
+    return h2f(h_mul(dwh, dxh)) * (float)si + h2f(h_mul(mwh, sxh));
+  }
+};
+
 // Per-lane partial sums of R rows of one weight matrix against one quantized activation vector: lane l owns
 // units l, l+64, ...  The R unit loads of a step are issued before any is consumed.
-template <int FMT, int R>
+template <int FMT, int R, class ACT>
 __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
-                                             const ActQ8_0& act, int row0, int m, int nb, int lane, float acc[R]) {
+                                             const ACT& act, int row0, int m, int nb, int lane, float acc[R]) {
   using F = BlockFmt<FMT>;
 #pragma unroll
   for (int r = 0; r < R; r++) acc[r] = 0.f;
@@ -223,6 +248,10 @@ struct ActOf {
 template <>
 struct ActOf<CRABML_HIP_Q4_K> {
   typedef ActQ8_K type;
+};
+template <>
+struct ActOf<CRABML_HIP_Q4_1> {
+  typedef ActQ8_1 type;
 };
 
 }  // namespace crabml_hip

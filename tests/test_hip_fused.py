@@ -232,10 +232,12 @@ def test_q6_k_classifier_like_real_gguf_files(ca, layers):
     assert np.median(err) <= 3e-2 and np.max(err) <= 1e-1, err
 
 
-def test_q4_k_fused_kernels_equal_the_per_op_segments(ca):
-    """Q4_K layers run the fused GEMV kernels (q/k/v + rope + append, wo / down + residual, gate/up + SiLU*mul) with
-    the Q4_K inner loop; per row that is the per-op kernel's arithmetic, so the logits are bit-identical."""
-    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_K, seed=61, output_type=synth.Q6_K)
+@pytest.mark.parametrize("fmt", ["Q4_K", "Q4_1"])
+def test_q4_k_fused_kernels_equal_the_per_op_segments(ca, fmt):
+    """Q4_K / Q4_1 layers run the fused GEMV kernels (q/k/v + rope + append, wo / down + residual, gate/up +
+    SiLU*mul) with the format's inner loop; per row that is the per-op kernel's arithmetic, so the logits are
+    bit-identical."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=61, output_type=synth.Q6_K)
     dev = ca.HipTensorDevice(0)
     conf, w = synth.to_hip(model, dev)
     fused = ca.HipLlamaRunner(conf, w, dev, 64, True)
