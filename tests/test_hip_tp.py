@@ -49,8 +49,9 @@ def test_tp_sim_strict_is_bit_exact(ca, shape, tp, kv_f16, fmt):
     assert all(r.kv_cache_len() == len(TOKS) for r in ranks)
 
 
-def test_tp_sim_fast_meets_single_gpu_tolerance(ca):
-    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=32)
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_K", "Q4_1", "Q6_K"])
+def test_tp_sim_fast_meets_single_gpu_tolerance(ca, fmt):
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=32)
     odev = o.OracleDevice(thread_num=4)
     oconf, ow = to_oracle(model, odev)
     orr = o.OracleLlamaRunner(oconf, ow, odev, 64, True)
