@@ -76,6 +76,14 @@ PYBIND11_MODULE(_host, m) {
       .def("stream", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(crabml_hip_device_stream(d.raw())); })
       .def("raw_handle", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(d.raw()); })
       .def("prof_enable", [](HipTensorDevice& d, bool on) { d.check(crabml_hip_prof_enable(d.raw(), on ? 1 : 0)); })
+      .def("prof_read_launches",
+           [](HipTensorDevice& d, size_t cap) {
+             std::vector<float> ms(cap);
+             size_t n = 0;
+             d.check(crabml_hip_prof_read_launches(d.raw(), ms.data(), cap, &n));
+             return py::array_t<float>(n, ms.data());
+           },
+           py::arg("cap") = 65536)
       .def("prof_read",
            [](HipTensorDevice& d) {
              crabml_hip_prof_entry_t e[16];

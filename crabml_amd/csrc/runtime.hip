@@ -790,6 +790,22 @@ int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on) {
   return 0;
 }
 
+int crabml_hip_prof_read_launches(crabml_hip_device_t* dev, float* ms_out, size_t cap, size_t* n) {
+  if (!dev || !n || (!ms_out && cap)) return CRABML_HIP_BAD_INPUT;
+  CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  size_t i = 0;
+  for (auto& r : dev->prof_recs) {
+    float ms = 0.f;
+    CH_HIP(dev, hipEventElapsedTime(&ms, r.e0, r.e1));
+    if (i < cap) ms_out[i++] = ms;
+    dev->prof_free_events.push_back(r.e0);
+    dev->prof_free_events.push_back(r.e1);
+  }
+  dev->prof_recs.clear();
+  *n = i;
+  return 0;
+}
+
 int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n) {
   if (!dev || !n || (!out && cap)) return CRABML_HIP_BAD_INPUT;
   CH_HIP(dev, hipStreamSynchronize(dev->stream));

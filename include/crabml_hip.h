@@ -267,6 +267,9 @@ typedef struct crabml_hip_prof_entry {
 int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on);
 /* blocks until the recorded events completed; fills up to cap entries, returns the count in *n */
 int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n);
+/* the same drain, one value per launch in record order (for medians / percentiles): fills up to cap durations in
+ * milliseconds, returns the count in *n */
+int crabml_hip_prof_read_launches(crabml_hip_device_t* dev, float* ms, size_t cap, size_t* n);
 
 #ifdef __cplusplus
 }
