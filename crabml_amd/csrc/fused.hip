@@ -27,6 +27,43 @@ __device__ __forceinline__ float exp_cached_f(float x, const unsigned short* __r
   return h2f(table[f2h(x)]);
 }
 
+// ---- the rhs quantizer of matmul_vec, one 32-lane half-wave per 32-element block ------------------------------
+// Q81 = false: Q8_0 (buf_q8_0.rs:87-134: d = max|x| / 127, q = trunc(x / d) with the simd cast's NaN -> 0; aux = the
+// i32 sum of the block's quants -- exact, derived, used for Q4_0's -8 offset).  Q81 = true: Q8_1 (buf_q8_1.rs:90-129:
+// q = trunc(clamp(x / d, -128, 127)) with NaN -> -128, aux = the f16 s = d * sum q).  All 32 lanes of the half-wave
+// call it (dead lanes with live = false and v = 0).
+struct QLane {
+  signed char q;
+  unsigned short d;
+  int aux;
+};
+template <bool Q81>
+__device__ __forceinline__ QLane quant_lane32(float v, bool live) {
+  QLane o;
+  const float amax = half_max_f32(fabsf(v));
+  const float dd = amax / 127.0f;
+  o.d = f2h(dd);
+  if constexpr (!Q81) {
+    const int qi = rs_f32_as_i32(v / dd);
+    o.q = (signed char)(unsigned char)((unsigned)qi & 0xffu);  // `as i8` from i32 wraps
+    o.aux = half_sum_i32(live ? (int)o.q : 0);
+  } else {
+    const float c = fminf(fmaxf(v / dd, -128.0f), 127.0f);  // Rust f32::max / min return the non-NaN operand
+    const int qi = (int)c;
+    o.q = (signed char)qi;
+    const int s = half_sum_i32(live ? qi : 0);
+    o.aux = (int)f2h((float)s * dd);
+  }
+  return o;
+}
+template <bool Q81>
+__device__ __forceinline__ void store_qaux(void* aux, int blk, int v) {
+  if constexpr (Q81)
+    ((unsigned short*)aux)[blk] = (unsigned short)v;
+  else
+    ((int*)aux)[blk] = v;
+}
+
 // ---- weight prefetch into the Infinity Cache ---------------------------------------------------------
 // The norm+quantize and attention stages are latency-bound single-/few-workgroup kernels: HBM idles for
 // ~6-8 us while they run.  Spare workgroups of those launches (one per otherwise idle CU) stream the NEXT
@@ -79,10 +116,10 @@ struct NormLds {  // carved from dynamic LDS: xs[cols] f32 | chunk_sums[cols/32]
 __host__ __device__ inline size_t norm_lds_bytes(int cols) { return (size_t)(cols + cols / 32) * sizeof(float); }
 
 // QUANT = false: the normalized row goes to xn_out as f32 (formats whose rhs is not Q8_0 quantize it afterwards)
-template <int NIT, bool QUANT>  // cols <= NIT * 1024, blockDim.x == 1024; ends with the outputs written (no trailing barrier)
+template <int NIT, bool QUANT, bool Q81 = false>  // cols <= NIT * 1024, blockDim.x == 1024; ends with the outputs written
 __device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const float* __restrict__ addv,
                                                  const float* __restrict__ w, int cols, float eps, NormLds L,
-                                                 float* s_rms, signed char* q, unsigned short* d, int* isum,
+                                                 float* s_rms, signed char* q, unsigned short* d, void* isum,
                                                  float* __restrict__ xn_out) {
   const int nchunks = cols / 32;
   const int tid = threadIdx.x;
@@ -142,27 +179,23 @@ __device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const fl
         if (live) xn_out[i] = v;
         continue;
       }
-      float amax = half_max_f32(fabsf(v));
-      float dd = amax / 127.0f;
-      int qi = rs_f32_as_i32(v / dd);
-      signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-      int s = half_sum_i32(live ? (int)q8 : 0);
+      const QLane o = quant_lane32<Q81>(v, live);
       if (live) {
-        q[i] = q8;
+        q[i] = o.q;
         if ((tid & 31) == 0) {
-          d[i >> 5] = f2h(dd);
-          isum[i >> 5] = s;
+          d[i >> 5] = o.d;
+          store_qaux<Q81>(isum, i >> 5, o.aux);
         }
       }
     }
   }
 }
 
-template <int NIT>
+template <int NIT, bool Q81>
 __global__ __launch_bounds__(1024) void k_norm_quant(float* __restrict__ x, const float* __restrict__ addv,
                                                     const float* __restrict__ w, int cols, float eps,
                                                     signed char* __restrict__ q, unsigned short* __restrict__ d,
-                                                    int* __restrict__ isum, PrefetchPlan pf) {
+                                                    void* __restrict__ isum, PrefetchPlan pf) {
   if (blockIdx.x > 0) {  // spare workgroups: warm the Infinity Cache with the next GEMV's weights
     prefetch_wg(pf, blockIdx.x - 1, gridDim.x - 1);
     return;
@@ -170,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_norm_quant(float* __restrict__ x, cons
   extern __shared__ float lds[];
   __shared__ float s_rms;
   NormLds L{lds, lds + cols};
-  norm_quant_block<NIT, true>(x, addv, w, cols, eps, L, &s_rms, q, d, isum, nullptr);
+  norm_quant_block<NIT, true, Q81>(x, addv, w, cols, eps, L, &s_rms, q, d, isum, nullptr);
 }
 template <int NIT>
 __global__ __launch_bounds__(1024) void k_norm_f32(float* __restrict__ x, const float* __restrict__ addv,
@@ -361,8 +394,8 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
                                               const void* __restrict__ vc, const int* __restrict__ pos_d,
                                               const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
                                               signed char* __restrict__ xq, unsigned short* __restrict__ xd,
-                                              int* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap,
-                                              PrefetchPlan pf) {
+                                              void* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap,
+                                              PrefetchPlan pf, int q81) {
   if ((int)blockIdx.x >= n_heads) {
     prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
     return;
@@ -496,17 +529,17 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   // ---- quantize the head's output for wo (only when blocks do not straddle heads)
   if (xq != nullptr) {
     const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
-    float amax = half_max_f32(live ? fabsf(val) : 0.f);
-    float dd = amax / 127.0f;
-    int qi = rs_f32_as_i32(val / dd);
-    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-    int s = half_sum_i32(live ? (int)q8 : 0);
+    const float vq = live ? val : 0.f;
+    const QLane o = q81 ? quant_lane32<true>(vq, live) : quant_lane32<false>(vq, live);
     if (live) {
       int e = head * hd + n;
-      xq[e] = q8;
+      xq[e] = o.q;
       if ((n & 31) == 0) {
-        xd[e >> 5] = f2h(dd);
-        xisum[e >> 5] = s;
+        xd[e >> 5] = o.d;
+        if (q81)
+          store_qaux<true>(xisum, e >> 5, o.aux);
+        else
+          store_qaux<false>(xisum, e >> 5, o.aux);
       }
     }
   }
@@ -592,7 +625,7 @@ template <int G>
 __global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restrict__ p16, const unsigned short* __restrict__ vc,
                                                  const int* __restrict__ pos_d, float* __restrict__ out,
                                                  signed char* __restrict__ xq, unsigned short* __restrict__ xd,
-                                                 int* __restrict__ xisum, int hd, int seq_cap) {
+                                                 void* __restrict__ xisum, int hd, int seq_cap, int q81) {
   constexpr int T = ATTN_PV_TILE, ROW = ATTN_PV_ROW;
   // LDS, two buffers each: V tile transposed to [16 dim pairs][T] words (a chain lane reads 4 consecutive positions
   // of its dim pair with one ds_read_b128), P tile [G][T] words holding {p, p} (the packed multiplier, ready-made)
@@ -689,17 +722,26 @@ __global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restric
   const int e0 = head * hd + sl * 32 + 2 * dp;
   out[e0] = v0;
   out[e0 + 1] = v1;
-  if (xq != nullptr) {  // Q8_0 block of the 32 dims held by this 16-lane DPP row (buf_q8_0.rs:87-134)
+  if (xq != nullptr) {  // the rhs block of the 32 dims held by this 16-lane DPP row (quant_lane32's arithmetic)
     const float amax = row16_max_f32(fmaxf(fabsf(v0), fabsf(v1)));
     const float dd = amax / 127.0f;
-    const int q0 = rs_f32_as_i32(v0 / dd), q1 = rs_f32_as_i32(v1 / dd);
-    const signed char b0 = (signed char)(unsigned char)((unsigned)q0 & 0xffu), b1 = (signed char)(unsigned char)((unsigned)q1 & 0xffu);
-    const int qs = row16_sum_i32((int)b0 + (int)b1);
-    xq[e0] = b0;
-    xq[e0 + 1] = b1;
+    int q0, q1;
+    if (q81) {  // Q8_1 (buf_q8_1.rs:90-129)
+      q0 = (int)fminf(fmaxf(v0 / dd, -128.0f), 127.0f);
+      q1 = (int)fminf(fmaxf(v1 / dd, -128.0f), 127.0f);
+    } else {  // Q8_0 (buf_q8_0.rs:87-134)
+      q0 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(v0 / dd) & 0xffu);
+      q1 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(v1 / dd) & 0xffu);
+    }
+    const int qs = row16_sum_i32(q0 + q1);
+    xq[e0] = (signed char)q0;
+    xq[e0 + 1] = (signed char)q1;
     if (dp == 0) {
       xd[e0 >> 5] = f2h(dd);
-      xisum[e0 >> 5] = qs;
+      if (q81)
+        store_qaux<true>(xisum, e0 >> 5, (int)f2h((float)qs * dd));
+      else
+        store_qaux<false>(xisum, e0 >> 5, qs);
     }
   }
 }
@@ -759,11 +801,12 @@ __device__ __forceinline__ unsigned long long ld_granule(const unsigned long lon
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int FMT, int SPLIT>  // SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows)
-__global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, ActQ8_0 act, float* __restrict__ x,
+__global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
                                                       signed char* __restrict__ q, unsigned short* __restrict__ d,
-                                                      int* __restrict__ isum, NormGather ng, int nb) {
+                                                      void* __restrict__ isum, NormGather ng, int nb) {
   using F = BlockFmt<FMT>;
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
   __shared__ __attribute__((aligned(16))) float hv[32];
@@ -868,16 +911,12 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, ActQ8_0 act, flo
   const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
   const float v = hv[lane & 31];
   const float xn = (v / rms) * wn;
-  const float amax = half_max_f32(fabsf(xn));
-  const float dd = amax / 127.0f;
-  const int qi = rs_f32_as_i32(xn / dd);
-  const signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-  const int qs = half_sum_i32((int)q8);
+  const QLane o = quant_lane32<Q81>(xn, true);
   if (lane < 32) {
-    q[blk * 32 + lane] = q8;
+    q[blk * 32 + lane] = o.q;
     if (lane == 0) {
-      d[blk] = f2h(dd);
-      isum[blk] = qs;
+      d[blk] = o.d;
+      store_qaux<Q81>(isum, blk, o.aux);
     }
   }
 }
@@ -932,10 +971,11 @@ __global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, Act
 // parks the h values in LDS, and one half-wave quantizes the block (buf_q8_0.rs:87-134).  hidden/32
 // workgroups (448 for Llama-3-8B) are all resident at once (2 per CU).  Saves a launch per layer.
 template <int FMT>
-__global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, ActQ8_0 act,
+__global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typename ActOf<FMT>::type act,
                                                    const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
-                                                   unsigned short* __restrict__ d, int* __restrict__ isum, int nb) {
+                                                   unsigned short* __restrict__ d, void* __restrict__ isum, int nb) {
   using F = BlockFmt<FMT>;
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   __shared__ float hv[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.x;
@@ -963,16 +1003,11 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, ActQ8_0
   }
   __syncthreads();
   if (threadIdx.x < 32) {
-    float v = hv[threadIdx.x];
-    float amax = half_max_f32(fabsf(v));
-    float dd = amax / 127.0f;
-    int qi = rs_f32_as_i32(v / dd);
-    signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-    int s = half_sum_i32((int)q8);
-    q[blk * 32 + threadIdx.x] = q8;
+    const QLane o = quant_lane32<Q81>(hv[threadIdx.x], true);
+    q[blk * 32 + threadIdx.x] = o.q;
     if (threadIdx.x == 0) {
-      d[blk] = f2h(dd);
-      isum[blk] = s;
+      d[blk] = o.d;
+      store_qaux<Q81>(isum, blk, o.aux);
     }
   }
 }
@@ -980,27 +1015,6 @@ __global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g,
                                                     const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) h[i] = silu_mul(g[i], u[i], exp_tab);
-}
-
-// plain Q8_0 activation quantizer on an f32 vector (same code as quantize.hip's, kept local for the graph)
-__global__ __launch_bounds__(256) void k_quant_q8_0_f(const float* __restrict__ x, signed char* __restrict__ q,
-                                                      unsigned short* __restrict__ d, int* __restrict__ isum, int nblocks) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  int blk = gid >> 5, j = gid & 31;
-  bool live = blk < nblocks;
-  float v = live ? x[blk * 32 + j] : 0.f;
-  float amax = half_max_f32(fabsf(v));
-  float dd = amax / 127.0f;
-  int qi = rs_f32_as_i32(v / dd);
-  signed char q8 = (signed char)(unsigned char)((unsigned)qi & 0xffu);
-  int s = half_sum_i32((int)q8);
-  if (live) {
-    q[blk * 32 + j] = q8;
-    if (j == 0) {
-      d[blk] = f2h(dd);
-      isum[blk] = s;
-    }
-  }
 }
 
 // ---- greedy sampler + advance: Iterator::max_by keeps the LAST maximum (sampler.rs:109-116) ------------
@@ -1184,20 +1198,22 @@ Planes planes_of(const crabml_hip_buf* b) {
   return Planes{(const i32x4*)b->ptr, (const unsigned short*)((const char*)b->ptr + b->wl.off_scale)};
 }
 
+// the planes of a 32-block activation (Q8_0: q | d | isum i32;  Q8_1: q | d | s f16) as the kernels write them
 struct ActPtrs {
-  ActQ8_0 view;
   signed char* q;
   unsigned short* d;
-  int* isum;
+  void* isum;  // the format's third plane
 };
-ActPtrs act_ptrs(char* p, size_t n) {
-  ActLayout al = act_layout(CRABML_HIP_Q8_0, n);
-  ActPtrs a;
-  a.q = (signed char*)p;
-  a.d = (unsigned short*)(p + al.off_d);
-  a.isum = (int*)(p + al.off_aux);
-  a.view = ActQ8_0{(const i32x4*)p, a.d, a.isum};
-  return a;
+ActPtrs act_ptrs(char* p, size_t n, uint32_t qt) {
+  ActLayout al = act_layout(qt, n);
+  return ActPtrs{(signed char*)p, (unsigned short*)(p + al.off_d), (void*)(p + al.off_aux)};
+}
+template <int FMT>
+typename ActOf<FMT>::type act_view(const ActPtrs& a) {
+  if constexpr (FMT == CRABML_HIP_Q4_1)
+    return ActQ8_1{(const i32x4*)a.q, a.d, (const unsigned short*)a.isum};
+  else
+    return ActQ8_0{(const i32x4*)a.q, a.d, (const int*)a.isum};
 }
 
 int n_segments(const crabml_hip_llama* c) { return 2 * (int)c->cfg.n_layers + 1; }
@@ -1205,7 +1221,7 @@ int n_segments(const crabml_hip_llama* c) { return 2 * (int)c->cfg.n_layers + 1;
 // attention of layer l (llama2.rs:571-590): qbuf x KV cache -> attn (f32), plus its Q8_0 planes for wo when xq != NULL.
 // Emits the variant selected in c->attn_variant (0: one workgroup per head, 1: the long-context kernels).
 template <int G>
-void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, int* xisum, bool prof) {
+void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, void* xisum, bool prof) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
   const int hd = c->hd, seq_cap = (int)c->cfg.seq_len, n_kv = c->n_kv_l;
@@ -1219,12 +1235,12 @@ void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned shor
   launch_k(st, prof ? &r[1] : nullptr, k_attn_softmax, dim3(c->n_heads_l), dim3(256), (size_t)seq_cap * sizeof(float),
            (const float*)c->scores_g, pos_d, (const unsigned short*)dev->exp_table, c->p16, seq_cap);
   launch_k(st, prof ? &r[2] : nullptr, k_attn_pv<G>, dim3(n_kv * (hd / 32)), dim3(256), 0, (const unsigned short*)c->p16,
-           (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap);
+           (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap, c->qt == CRABML_HIP_Q8_1 ? 1 : 0);
   for (int i = 0; i < 3; i++)
     if (prof) prof_end(dev, &r[i]);
 }
 
-void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, int* xisum, const PrefetchPlan& pf,
+void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, void* xisum, const PrefetchPlan& pf,
                        int spare, bool prof) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
@@ -1246,11 +1262,11 @@ void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned sho
   if (c->cfg.use_f16_kv_cache)
     launch_k(st, AR, k_attn<true>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
              (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
-             seq_cap, pf);
+             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0);
   else
     launch_k(st, AR, k_attn<false>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
              (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
-             seq_cap, pf);
+             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0);
   if (prof) prof_end(dev, &ar);
 }
 
@@ -1270,7 +1286,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   int* token_d = c->state;
   int* pos_d = c->state + 1;
   int* step_d = c->state + 2;
-  ActPtrs ad = act_ptrs(c->act_dim, dim), aa = act_ptrs(c->act_attn, dim_l), ah = act_ptrs(c->act_hid, hidden_l);
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  const uint32_t qt = c->qt;
+  ActPtrs ad = act_ptrs(c->act_dim, dim, qt), aa = act_ptrs(c->act_attn, dim_l, qt), ah = act_ptrs(c->act_hid, hidden_l, qt);
   // measurement hook: only meaningful for eager launches (events cannot live inside the captured graph)
   const bool prof = dev->prof_on && !c->use_graph && !c->capturing;
   const double blk_b = (double)block_bytes(c->wtype) / 32.0;  // weight bytes per element
@@ -1299,9 +1317,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     if (prof) prof_begin(dev, &nr, CRABML_HIP_F32, 6, 8.0 * dim);
     const float* addv = add_pending ? c->partial : nullptr;
     if (dim <= 4096)
-      launch_k(st, prof ? &nr : nullptr, k_norm_quant<4>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<4, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
     else
-      launch_k(st, prof ? &nr : nullptr, k_norm_quant<12>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<12, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
     if (prof) prof_end(dev, &nr);
   };
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
@@ -1318,15 +1336,15 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
                         : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
                                                                           : 1;
       if (split == 2)
-        launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), a.view, c->x, wnext, eps_next, ad.q,
-                 ad.d, ad.isum, ng, k / 32);
+        launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next,
+                 ad.q, ad.d, ad.isum, ng, k / 32);
       else
-        launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), a.view, c->x, wnext, eps_next, ad.q,
-                 ad.d, ad.isum, ng, k / 32);
+        launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next,
+                 ad.q, ad.d, ad.isum, ng, k / 32);
     } else if (tp) {
-      launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
+      launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     } else {
-      launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), a.view, dst, dim, k / 32);
+      launch_k(st, R, k_gemv_res<FMT, 1, true>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     }
     CH_TRY(P1(&pr));
     return 0;
@@ -1357,13 +1375,13 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(&pr, 1, total_rows, dim));
     launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-             planes_of(c->wv[l]), ad.view, dim / 32, e);
+             planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e);
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;
     const int attn_spare = do_pf && dev->n_cu > n_heads_l ? dev->n_cu - n_heads_l : 0;
     enqueue_attention(c, l, attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, plan(c->wo[l], nullptr, nullptr), attn_spare, prof);
-    if (!attn_quant) k_quant_q8_0_f<<<(dim_l + 255) / 256, 256, 0, st>>>(c->attn, aa.q, aa.d, aa.isum, dim_l / 32);
+    if (!attn_quant) launch_quantize_act(st, qt, c->attn, (size_t)dim_l, c->act_attn);
     // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
     CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
   } else {
@@ -1371,8 +1389,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     if (!norm_epi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
     // gate / up + silu * mul (llama2.rs:620-630), local rows
     CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
-    launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]), ad.view,
-             dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
+    launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
+             act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
     CH_TRY(P1(&pr));
     // down (+ residual, llama2.rs:633-636): k = the local hidden slice
     CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr,
@@ -1580,7 +1598,9 @@ int enqueue_segment(crabml_hip_llama* c, int seg) {
   if (c->kfused)
     return c->wtype == CRABML_HIP_Q4_K ? enqueue_segment_k<CRABML_HIP_Q4_K>(c, seg) : enqueue_segment_k<CRABML_HIP_Q4_1>(c, seg);
   if (c->generic) return enqueue_segment_generic(c, seg);
-  return c->wtype == CRABML_HIP_Q4_0 ? enqueue_segment_t<CRABML_HIP_Q4_0>(c, seg) : enqueue_segment_t<CRABML_HIP_Q8_0>(c, seg);
+  return c->wtype == CRABML_HIP_Q4_0   ? enqueue_segment_t<CRABML_HIP_Q4_0>(c, seg)
+         : c->wtype == CRABML_HIP_Q8_0 ? enqueue_segment_t<CRABML_HIP_Q8_0>(c, seg)
+                                       : enqueue_segment_t<CRABML_HIP_Q4_1>(c, seg);
 }
 
 int allreduce(crabml_hip_llama* c) {
@@ -1704,7 +1724,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   if (qt == 0xffffffffu || out_qt == 0xffffffffu)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama: weight dtype %u / classifier dtype %u has no matmul_vec", wt, out_wt);
   // fused kernels exist for Q4_0 / Q8_0 layers (fast mode); everything else runs the per-op segment path
-  const bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0) || out_wt != wt;
+  const bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0 && wt != CRABML_HIP_Q4_1) || out_wt != wt;
   {
     const size_t be = block_elems(wt) > block_elems(qt) ? block_elems(wt) : block_elems(qt);
     const size_t obe = block_elems(out_wt) > block_elems(out_qt) ? block_elems(out_wt) : block_elems(out_qt);
@@ -1734,7 +1754,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->cfg = g;
   c->wtype = wt;
   c->generic = generic;
-  c->kfused = !dev->strict_order && (wt == CRABML_HIP_Q4_K || wt == CRABML_HIP_Q4_1) && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION);
+  // Q4_K always; Q4_1 when it cannot take the 5-kernel path (mixed classifier format) or for the A/B flag
+  c->kfused = !dev->strict_order && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
+              (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS))));
   c->qt = qt;
   c->out_qt = out_qt;
   c->tp = tp;

@@ -262,3 +262,18 @@ def test_in_launch_hand_offs_under_load_llama3_8b_shape(ca):
     assert list(ta) == list(tb)
     la, lb = a.forward(int(ta[-1]), 400), b.forward(int(tb[-1]), 400)
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+
+
+def test_q4_1_five_kernel_layers_equal_the_segment_path(ca):
+    """All-Q4_1 models take the 5-kernel layer like Q4_0 / Q8_0: the rhs is quantized to Q8_1 inside the producing
+    kernels (attention, gate/up, and the wo / ffn_down norm epilogue; buf_q8_1.rs:90-129: clamp, NaN -> -128,
+    s = f16(d * sum q)).  Same arithmetic as the stand-alone quantizer launches, so: bit-identical logits."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_1, seed=62)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    five = ca.HipLlamaRunner(conf, w, dev, 320, True, attn_long_from=12)  # crosses into the long-context kernels too
+    segs = ca.HipLlamaRunner(conf, w, dev, 320, True, extra_flags=512, attn_long_from=12)  # Q4_1_SEGMENTS
+    rng = np.random.default_rng(9)
+    for i, t in enumerate(int(v) for v in rng.integers(0, 1024, size=24)):
+        a, b = five.forward(t, i), segs.forward(t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
