@@ -793,6 +793,7 @@ __global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks,
 struct NormGather {
   unsigned long long* slots;  // dim/32 chunk-sum granules
   unsigned long long* pair;   // dim row granules (split chunks: partner rows handed to the leading workgroup)
+  unsigned long long* sbmax;  // dim/32 granules: each chunk's first-max element (Q8_K output: super-block exchange)
   const int* serial;          // decode-step serial number (never reset): makes the epoch unique per launch
   int* fault;
   int nseg, seg;
@@ -803,10 +804,10 @@ __device__ __forceinline__ unsigned long long ld_granule(const unsigned long lon
 template <int FMT, int SPLIT>  // SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows)
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
-                                                      signed char* __restrict__ q, unsigned short* __restrict__ d,
+                                                      signed char* __restrict__ q, void* __restrict__ d,
                                                       void* __restrict__ isum, NormGather ng, int nb) {
-  using F = BlockFmt<FMT>;
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
   __shared__ __attribute__((aligned(16))) float hv[32];
@@ -824,25 +825,30 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
   // RW rows x two blocks per lane in flight (one workgroup per CU: the loads have to supply the parallelism);
   // terms are added in block order, as rows_partial does
   float acc[RW];
+  if constexpr (KQ) {
+    rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
+  } else {
+    using F = BlockFmt<FMT>;
 #pragma unroll
-  for (int r = 0; r < RW; r++) acc[r] = 0.f;
-  const int nu = nb * F::UNITS;
-  for (int u = lane; u < nu; u += 128) {
-    const int u2 = u + 64;
-    const bool two = u2 < nu;
-    const int uu = two ? u2 : u;
-    typename F::Blk ka[RW], kb[RW];
+    for (int r = 0; r < RW; r++) acc[r] = 0.f;
+    const int nu = nb * F::UNITS;
+    for (int u = lane; u < nu; u += 128) {
+      const int u2 = u + 64;
+      const bool two = u2 < nu;
+      const int uu = two ? u2 : u;
+      typename F::Blk ka[RW], kb[RW];
 #pragma unroll
-    for (int r = 0; r < RW; r++) {
-      ka[r] = F::load(w.q, w.d, (size_t)(row + r), nb, u);
-      kb[r] = F::load(w.q, w.d, (size_t)(row + r), nb, uu);
-    }
-    const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
+      for (int r = 0; r < RW; r++) {
+        ka[r] = F::load(w.q, w.d, (size_t)(row + r), nb, u);
+        kb[r] = F::load(w.q, w.d, (size_t)(row + r), nb, uu);
+      }
+      const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
 #pragma unroll
-    for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], xa);
-    if (two) {
+      for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], xa);
+      if (two) {
 #pragma unroll
-      for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], xb);
+        for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], xb);
+      }
     }
   }
 #pragma unroll
@@ -911,12 +917,74 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
   const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
   const float v = hv[lane & 31];
   const float xn = (v / rms) * wn;
-  const QLane o = quant_lane32<Q81>(xn, true);
-  if (lane < 32) {
-    q[blk * 32 + lane] = o.q;
-    if (lane == 0) {
-      d[blk] = o.d;
-      store_qaux<Q81>(isum, blk, o.aux);
+  if constexpr (!KQ) {
+    const QLane o = quant_lane32<Q81>(xn, true);
+    if (lane < 32) {
+      q[blk * 32 + lane] = o.q;
+      if (lane == 0) {
+        ((unsigned short*)d)[blk] = o.d;
+        store_qaux<Q81>(isum, blk, o.aux);
+      }
+    }
+  } else {
+    // Q8_K (buf_q8_k.rs:84-131): the scale comes from the FIRST element of maximal |x| of the 256-element
+    // super-block = this chunk and its 7 neighbours: every chunk publishes its own first-max element as a granule,
+    // reads the eight of its super-block, and takes the first strictly greater one in chunk order -- the flat
+    // strict-`>` scan of the reference.
+    if (lane < 32) hv[lane] = xn;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float aloc = 0.0f, mloc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {  // every lane, from LDS broadcasts
+      f32x4 t = ((const f32x4*)hv)[j];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float a = fabsf(t[e]);
+        if (a > aloc) {
+          aloc = a;
+          mloc = t[e];
+        }
+      }
+    }
+    if (lane == 0)
+      __hip_atomic_store(ng.sbmax + blk, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, mloc),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int sb = blk >> 3;
+    float mv = 0.0f;
+    if (lane < 8) {
+      unsigned long long g = ld_granule(ng.sbmax + sb * 8 + lane);
+      int tries = 0;
+      while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+        __builtin_amdgcn_s_sleep(1);
+        g = ld_granule(ng.sbmax + sb * 8 + lane);
+        tries++;
+      }
+      if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;
+      mv = __builtin_bit_cast(float, (unsigned)g);
+    }
+    float besta = 0.0f, best = 0.0f;
+#pragma unroll
+    for (int c8 = 0; c8 < 8; c8++) {
+      const float cv = rl_f(mv, c8), ca = fabsf(cv);
+      if (ca > besta) {
+        besta = ca;
+        best = cv;
+      }
+    }
+    const float scale = -128.0f / best;
+    int qi = 0;
+    if (besta != 0.0f) {
+      float r = roundf(scale * xn);  // half away from zero
+      r = fminf(r, 127.0f);
+      qi = rs_f32_as_i32(r);
+      qi = qi < -128 ? -128 : qi;  // `as i8` saturates
+    }
+    const int bs = row16_sum_i32(qi);
+    if (lane < 32) {
+      q[blk * 32 + lane] = (signed char)qi;
+      if ((lane & 15) == 0) ((short*)isum)[sb * 16 + (blk & 7) * 2 + (lane >> 4)] = (short)bs;
+      if (lane == 0 && (blk & 7) == 0) ((float*)d)[sb] = besta != 0.0f ? 1.0f / scale : 0.0f;
     }
   }
 }
@@ -1167,6 +1235,7 @@ struct crabml_hip_llama {
   uint32_t qt = 0, out_qt = 0;  // vec_dot_rhs_dtype of the layer weights / of the classifier
   float* xn = nullptr;       // generic path: normalized residual (f32, dim)
   bool norm_epi = false;     // fast mode, tp == 1: RMSNorm + quantize run in the wo / ffn_down epilogue
+  bool norm_epi_k = false;   // the same for Q4_K layers (Q8_K planes out of the epilogue)
   unsigned* out_tokens = nullptr;
   int out_cap = 0;
   float* am_val = nullptr;  // argmax partials
@@ -1329,7 +1398,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
     if (norm_epi) {
-      NormGather ng{c->slots, c->slots + dim / 32, c->state + 4, c->state + 5, n_segments(c), seg};
+      NormGather ng{c->slots, c->slots + dim / 32, c->slots + dim / 32 + dim, c->state + 4, c->state + 5, n_segments(c), seg};
       // long rows (ffn_down): two workgroups per chunk, so that every CU streams (a CU sustains ~26 GB/s here)
       const int split = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
                         : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
@@ -1536,8 +1605,27 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     return c->act_dim;
   };
   float* dst = tp ? c->partial : c->x;
-  auto gemv_out = [&](const crabml_hip_buf* w, const Act& a, int k, uint32_t stage) -> int {
+  const bool nepi = FMT == CRABML_HIP_Q4_K && c->norm_epi_k;
+  // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
+  auto gemv_out = [&](const crabml_hip_buf* w, const Act& a, int k, uint32_t stage, const float* wnext, float eps_next) -> int {
     CH_TRY(P0(stage, dim, k));
+    if constexpr (FMT == CRABML_HIP_Q4_K) {
+      if (nepi) {
+        NormGather ng{c->slots, c->slots + dim / 32, c->slots + dim / 32 + dim, c->state + 4, c->state + 5, n_segments(c), seg};
+        ActLayout al = act_layout(QT, (size_t)dim);
+        const int split = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
+                          : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
+                          : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
+                                                                            : 1;
+        if (split == 2)
+          launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_k(w), a, c->x, wnext, eps_next,
+                   (signed char*)c->act_dim, (void*)(c->act_dim + al.off_d), (void*)(c->act_dim + al.off_aux), ng, k / BE);
+        else
+          launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_k(w), a, c->x, wnext, eps_next,
+                   (signed char*)c->act_dim, (void*)(c->act_dim + al.off_d), (void*)(c->act_dim + al.off_aux), ng, k / BE);
+        return P1();
+      }
+    }
     if (tp)
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_k(w), a, dst, dim, k / BE);
     else
@@ -1546,7 +1634,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   };
 
   if (seg == 2 * L) {
-    const void* act = norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, c->out_qt);
+    const void* act = nepi ? (const void*)c->act_dim : norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, c->out_qt);
     if (prof)
       CH_TRY(prof_begin(dev, &pr, c->output->dtype, 5,
                         (double)g.vocab_size * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
@@ -1564,7 +1652,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     if (l == 0)
       k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
                                                   c->token_embed->wl.off_scale, token_d, dim, c->x);
-    norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, QT);
+    if (!nepi || l == 0) norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, QT);
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
@@ -1574,9 +1662,9 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     CH_TRY(P1());
     enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
     launch_quantize_act(st, QT, c->attn, (size_t)dim_l, c->act_attn);
-    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), dim_l, 2));
+    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
   } else {
-    norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, QT);  // llama2.rs:611
+    if (!nepi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, QT);  // llama2.rs:611
     CH_TRY(P0(3, 2.0 * hidden_l, dim));
     if constexpr (FMT == CRABML_HIP_Q4_K) {
       const size_t lds = (size_t)dim + (size_t)(dim / 256) * 4 + (size_t)(dim / 16) * 2;
@@ -1588,7 +1676,8 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     }
     CH_TRY(P1());
     launch_quantize_act(st, QT, c->h, (size_t)hidden_l, c->act_hid);
-    CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), hidden_l, 4));
+    CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), hidden_l, 4,
+                    (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr, g.rms_norm_eps));
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
@@ -1832,9 +1921,11 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     }
   }
   A(8 * sizeof(int), (void**)&c->state);
-  A((g.embedding_dim / 32 + g.embedding_dim) * 8, (void**)&c->slots);
+  A((2 * (g.embedding_dim / 32) + g.embedding_dim) * 8, (void**)&c->slots);
   c->norm_epi = !generic && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
+  c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
+                  !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) && g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);
@@ -1858,7 +1949,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     }
     hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 8 * sizeof(int), dev->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (g.embedding_dim / 32 + g.embedding_dim) * 8, dev->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (2 * (g.embedding_dim / 32) + g.embedding_dim) * 8, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) {
       crabml_hip_llama_destroy(c);

@@ -247,6 +247,38 @@ def test_q4_k_fused_kernels_equal_the_per_op_segments(ca, fmt):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
 
 
+@pytest.mark.parametrize("flags", [0, 16])  # 16 = SPLIT_CHUNKS_ALWAYS: the two-workgroup chunk hand-off
+def test_q4_k_norm_epilogue_equals_the_quantizer_launches(ca, flags):
+    """Q4_K layers: RMSNorm + the Q8_K quantizer of the next GEMV run in the wo / ffn_down epilogue.  A Q8_K
+    super-block (buf_q8_k.rs:84-131: scale from the FIRST element of maximal |x| of 256) spans eight 32-row
+    workgroups, which exchange their first-max elements through granules; the planes -- and so the logits -- are
+    bit-identical to the stand-alone rmsnorm + quantize launches."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_K, seed=63, output_type=synth.Q6_K)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    epi = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=flags)
+    sep = ca.HipLlamaRunner(conf, w, dev, 64, True, norm_epilogue=False)
+    for i, t in enumerate(PROMPT + [5, 6, 7, 8, 9]):
+        a, b = epi.forward(t, i), sep.forward(t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+    assert list(epi.decode_greedy(3, 20)) == list(sep.decode_greedy(3, 20))
+
+
+def test_q4_k_hand_offs_under_load_llama3_8b_shape(ca):
+    """The Q4_K epilogue (three in-launch hops for ffn_down: pair, chunk sums, super-block max) at the benchmark's
+    row counts, 4 layers, 300 greedy tokens: token-for-token equal to the run with separate launches."""
+    model = synth.build_model(synth.SHAPES["llama3-8b"], synth.Q4_K, seed=72, n_layers=4)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, 320, True)
+    b = ca.HipLlamaRunner(conf, w, dev, 320, True, norm_epilogue=False)
+    ta = a.decode_greedy(1, 300)
+    tb = b.decode_greedy(1, 300)
+    assert list(ta) == list(tb)
+    la, lb = a.forward(int(ta[-1]), 300), b.forward(int(tb[-1]), 300)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+
+
 def test_in_launch_hand_offs_under_load_llama3_8b_shape(ca):
     """Soak at the benchmark's own shape (Llama-3-8B rows, 8 layers, every CU streaming): 400 greedy tokens through
     the norm-epilogue kernels (granule gather over 128 / 256 workgroups) must equal, token for token, the run with
