@@ -125,4 +125,62 @@ __device__ __forceinline__ T ld(const T* p) {
     return *p;
 }
 
+// Q8_K quantizer of one 256-element super-block by one wave, 4 consecutive elements per lane
+// (buf_q8_k.rs:84-131: scale = -128 / (the FIRST element of maximal |x|), round half away from zero, min(127),
+// `as i8` saturation).  Returns the 4 quants packed into a dword; `quad_sum` = this lane's quad's sum of 16 quants
+// (bsums entry lane/4), `d` = the block scale (0 for an all-zero block).
+struct Q8KLane {
+  unsigned packed;
+  int quad_sum;
+  float d;
+};
+__device__ __forceinline__ Q8KLane q8k_wave_quant(const f32x4 v, int lane) {
+  float best_abs = 0.f, best_val = 0.f;
+  int best_idx = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float a = fabsf(v[i]);
+    if (a > best_abs) {
+      best_abs = a;
+      best_val = v[i];
+      best_idx = lane * 4 + i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float oa = __shfl_xor(best_abs, o, 64);
+    float ov = __shfl_xor(best_val, o, 64);
+    int oi = __shfl_xor(best_idx, o, 64);
+    bool take = (oa > best_abs) || (oa == best_abs && oi < best_idx);
+    if (take) {
+      best_abs = oa;
+      best_val = ov;
+      best_idx = oi;
+    }
+  }
+  const float scale = -128.0f / best_val;
+  Q8KLane o;
+  o.d = best_abs == 0.0f ? 0.0f : 1.0f / scale;
+  int qi[4];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int t = 0;
+    if (best_abs != 0.0f) {
+      float r = roundf(scale * v[i]);  // half away from zero
+      r = fminf(r, 127.0f);
+      t = rs_f32_as_i32(r);
+      t = t < -128 ? -128 : t;  // `as i8` saturates
+    }
+    qi[i] = t;
+    s += t;
+  }
+  o.packed = ((unsigned)qi[0] & 0xffu) | (((unsigned)qi[1] & 0xffu) << 8) | (((unsigned)qi[2] & 0xffu) << 16) |
+             (((unsigned)qi[3] & 0xffu) << 24);
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  o.quad_sum = s;
+  return o;
+}
+
 }  // namespace crabml_hip

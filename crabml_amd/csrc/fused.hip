@@ -120,7 +120,7 @@ template <int NIT, bool QUANT, bool Q81 = false>  // cols <= NIT * 1024, blockDi
 __device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const float* __restrict__ addv,
                                                  const float* __restrict__ w, int cols, float eps, NormLds L,
                                                  float* s_rms, signed char* q, unsigned short* d, void* isum,
-                                                 float* __restrict__ xn_out) {
+                                                 float* __restrict__ xn_out, int half) {
   const int nchunks = cols / 32;
   const int tid = threadIdx.x;
   float xv[NIT], wv[NIT];
@@ -144,16 +144,19 @@ __device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const fl
   __syncthreads();
   for (int c = tid; c < nchunks; c += 1024) {
     const f32x4* p = (const f32x4*)(L.xs + c * 32);
-    float s = -0.0f;
+    float s = -0.0f, s1 = -0.0f;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       f32x4 t = p[j];
-      s += t[0] * t[0];
-      s += t[1] * t[1];
-      s += t[2] * t[2];
-      s += t[3] * t[3];
+      float& a = (half && j >= 4) ? s1 : s;
+      a += t[0] * t[0];
+      a += t[1] * t[1];
+      a += t[2] * t[2];
+      a += t[3] * t[3];
     }
-    L.chunk_sums[c] = s;
+    // half (fast mode): chunk = (rows 0..15 in order) + (rows 16..31 in order), the split the wo / ffn_down norm
+    // epilogue uses (two workgroups per chunk); otherwise the reference's 32-element scan (rms_norm.rs:35-38)
+    L.chunk_sums[c] = half ? s + s1 : s;
   }
   __syncthreads();
   if (tid < 64) {
@@ -195,7 +198,7 @@ template <int NIT, bool Q81>
 __global__ __launch_bounds__(1024) void k_norm_quant(float* __restrict__ x, const float* __restrict__ addv,
                                                     const float* __restrict__ w, int cols, float eps,
                                                     signed char* __restrict__ q, unsigned short* __restrict__ d,
-                                                    void* __restrict__ isum, PrefetchPlan pf) {
+                                                    void* __restrict__ isum, PrefetchPlan pf, int half) {
   if (blockIdx.x > 0) {  // spare workgroups: warm the Infinity Cache with the next GEMV's weights
     prefetch_wg(pf, blockIdx.x - 1, gridDim.x - 1);
     return;
@@ -203,15 +206,15 @@ __global__ __launch_bounds__(1024) void k_norm_quant(float* __restrict__ x, cons
   extern __shared__ float lds[];
   __shared__ float s_rms;
   NormLds L{lds, lds + cols};
-  norm_quant_block<NIT, true, Q81>(x, addv, w, cols, eps, L, &s_rms, q, d, isum, nullptr);
+  norm_quant_block<NIT, true, Q81>(x, addv, w, cols, eps, L, &s_rms, q, d, isum, nullptr, half);
 }
 template <int NIT>
 __global__ __launch_bounds__(1024) void k_norm_f32(float* __restrict__ x, const float* __restrict__ addv,
-                                                  const float* __restrict__ w, int cols, float eps, float* __restrict__ xn) {
+                                                  const float* __restrict__ w, int cols, float eps, float* __restrict__ xn, int half) {
   extern __shared__ float lds[];
   __shared__ float s_rms;
   NormLds L{lds, lds + cols};
-  norm_quant_block<NIT, false>(x, addv, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr, xn);
+  norm_quant_block<NIT, false>(x, addv, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr, xn, half);
 }
 
 // ---- QKV epilogue: rope (rope.rs:47-63) + q scale (llama2.rs:565) + KV append (concatenate.rs:172-204) ---
@@ -790,10 +793,35 @@ __global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks,
 // rms_norm.rs:35-40, and normalizes + quantizes its own block.  Every bit of the result equals k_norm_quant's:
 // same chunk sums, same serial chain, same divisions.  All dim/32 workgroups are co-resident by construction
 // (<= one per CU, checked at create); the poll is bounded and raises `fault` instead of hanging.
+// Q8_K quantizer of an f32 vector straight into LDS planes (q | d | bsums, as stage_act_q8k lays them out): one
+// wave per super-block.  The Q4_K wo / ffn_down kernels run it as their prologue on the attention output / h,
+// each workgroup for itself (16 KB / 56 KB of L2 reads), instead of a quantizer launch in front of them.
+__device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int nsb, unsigned* sq, float* sd, short* sbs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // four super-blocks of loads in flight per wave (ffn_down: 56 super-blocks over 16 waves; a round is one L2 latency)
+  for (int sb0 = wave; sb0 < nsb; sb0 += 4 * nw) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int sb = sb0 + u * nw;
+      v[u] = ((const f32x4*)x)[(sb < nsb ? sb : sb0) * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int sb = sb0 + u * nw;
+      if (sb >= nsb) break;  // wave-uniform
+      const Q8KLane o = q8k_wave_quant(v[u], lane);
+      sq[sb * 64 + lane] = o.packed;
+      if ((lane & 3) == 0) sbs[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
+      if (lane == 0) sd[sb] = o.d;
+    }
+  }
+  __syncthreads();
+}
+
 struct NormGather {
-  unsigned long long* slots;  // dim/32 chunk-sum granules
-  unsigned long long* pair;   // dim row granules (split chunks: partner rows handed to the leading workgroup)
-  unsigned long long* sbmax;  // dim/32 granules: each chunk's first-max element (Q8_K output: super-block exchange)
+  unsigned long long* slots;  // dim/16 granules: each workgroup's ordered sum of squares over its rows
+  unsigned long long* pair;   // dim row granules (read by a split chunk's partner / a Q8_K super-block's neighbours)
   const int* serial;          // decode-step serial number (never reset): makes the epoch unique per launch
   int* fault;
   int nseg, seg;
@@ -801,8 +829,10 @@ struct NormGather {
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int FMT, int SPLIT>  // SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows)
-__global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x,
+// SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows); QIN (Q4_K): the rhs is the f32 vector xin
+template <int FMT, int SPLIT, bool QIN = false>
+__global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
+                                                      float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
                                                       signed char* __restrict__ q, void* __restrict__ d,
                                                       void* __restrict__ isum, NormGather ng, int nb) {
@@ -816,16 +846,30 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
   const int nchunks = gridDim.x / SPLIT;
   const int row = blk * 32 + part * ROWS + wave * RW;
   float res[RW];
-  float wn = 0.f;
+  float wn = 0.f;                          // the next RMSNorm's weights for the rows this wave will normalize,
+  f32x4 wn4 = {0.f, 0.f, 0.f, 0.f};        // loaded up front (off the critical path after the hop)
   unsigned epoch = 0;
 #pragma unroll
   for (int r = 0; r < RW; r++) res[r] = lane == 0 ? x[row + r] : 0.f;
-  if (wave == 0 || SPLIT > 1) epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
-  if (wave == 0 && part == 0) wn = wnext[blk * 32 + (lane & 31)];
+  if (wave == 0) {
+    if constexpr (KQ)
+      wn4 = ((const f32x4*)wnext)[(blk >> 3) * 64 + lane];
+    else
+      wn = wnext[blk * 32 + (lane & 31)];
+  }
+  if (wave == 0 || SPLIT > 1 || KQ) epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
   // RW rows x two blocks per lane in flight (one workgroup per CU: the loads have to supply the parallelism);
   // terms are added in block order, as rows_partial does
   float acc[RW];
-  if constexpr (KQ) {
+  if constexpr (KQ && QIN) {
+    // the rhs arrives as f32 (attention output / h): quantize it to Q8_K in LDS first
+    extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
+    float* sd = (float*)(lds_act + nb * 16);
+    short* sbs = (short*)(sd + nb);
+    stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
+    const ActQ8_K la{lds_act, sd, sbs};
+    rows_partial_q4k<RW, false>(w.q, (const i32x4*)w.d, la, row, nchunks * 32, nb, lane, acc);
+  } else if constexpr (KQ) {
     rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
   } else {
     using F = BlockFmt<FMT>;
@@ -851,75 +895,99 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       }
     }
   }
+  // ---- epilogue: publish, one in-launch hop, normalize + quantize -------------------------------------------
+  // every row goes out as a {value, epoch} granule when another workgroup needs it (the partner of a split chunk;
+  // the seven neighbours of a Q8_K super-block), the workgroup's ordered sum of squares as one more
+  constexpr bool ROWG = SPLIT > 1 || KQ;
 #pragma unroll
   for (int r = 0; r < RW; r++) {
     const float s = wave_sum_f32(acc[r]);
     if (lane == 0) {
       const float xv = s + res[r];  // x = matmul_out + x (llama2.rs:266 / :636)
       x[row + r] = xv;
-      if (part == 0)
-        hv[wave * RW + r] = xv;
-      else  // hand the value to the chunk's leading workgroup: one {value, epoch} granule per row
-        __hip_atomic_store(ng.pair + blk * 32 + part * ROWS + wave * RW + r,
-                           ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
+      hv[part * ROWS + wave * RW + r] = xv;
+      if (ROWG)
+        __hip_atomic_store(ng.pair + row + r, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (part != 0) return;
   __syncthreads();
   if (wave != 0) return;
-  if (SPLIT > 1) {  // collect the partner rows
-    if (lane >= ROWS && lane < 32) {
-      unsigned long long g = ld_granule(ng.pair + blk * 32 + lane);
-      int tries = 0;
-      while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
-        __builtin_amdgcn_s_sleep(1);
-        g = ld_granule(ng.pair + blk * 32 + lane);
-        tries++;
-      }
-      if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;
-      hv[lane] = __builtin_bit_cast(float, (unsigned)g);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ordered chunk sum (rms_norm.rs:35-38), computed redundantly by every lane from LDS broadcasts
-  float cs = -0.0f;
+  // sum of squares of a chunk = (rows 0..15 in order) + (rows 16..31 in order): a split chunk's two workgroups
+  // each own one half (norm_quant_block<HALF> computes the same)
+  float cs;
+  {
+    float h0 = -0.0f, h1 = -0.0f;
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    f32x4 t = ((const f32x4*)hv)[j];
-    cs += t[0] * t[0];
-    cs += t[1] * t[1];
-    cs += t[2] * t[2];
-    cs += t[3] * t[3];
+    for (int j = 0; j < 4; j++) {
+      const f32x4 t = ((const f32x4*)hv)[(SPLIT > 1 ? part * 4 : 0) + j];
+      h0 += t[0] * t[0];
+      h0 += t[1] * t[1];
+      h0 += t[2] * t[2];
+      h0 += t[3] * t[3];
+    }
+    if (SPLIT == 1) {
+#pragma unroll
+      for (int j = 4; j < 8; j++) {
+        const f32x4 t = ((const f32x4*)hv)[j];
+        h1 += t[0] * t[0];
+        h1 += t[1] * t[1];
+        h1 += t[2] * t[2];
+        h1 += t[3] * t[3];
+      }
+      cs = h0 + h1;
+    } else {
+      cs = h0;
+    }
   }
   if (lane == 0)
-    __hip_atomic_store(ng.slots + blk, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
+    __hip_atomic_store(ng.slots + blockIdx.x, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  float sum = 0.0f;
-  for (int base = 0; base < nchunks; base += 64) {
-    const int c = base + lane;
-    float v = 0.0f;
-    if (c < nchunks) {
-      unsigned long long g = ld_granule(ng.slots + c);
-      int tries = 0;
-      while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
-        __builtin_amdgcn_s_sleep(2);
-        g = ld_granule(ng.slots + c);
-        tries++;
-      }
-      if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
-      v = __builtin_bit_cast(float, (unsigned)g);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granule is on its way before the polls queue up behind it
+  auto poll = [&](const unsigned long long* p) -> float {
+    unsigned long long g = ld_granule(p);
+    int tries = 0;
+    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+      __builtin_amdgcn_s_sleep(2);
+      g = ld_granule(p);
+      tries++;
     }
+    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+    return __builtin_bit_cast(float, (unsigned)g);
+  };
+  // the rows of other workgroups first (published before their sums; the loads fly while the stragglers arrive) ...
+  const int l32 = lane & 31;
+  const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
+  const int sb = blk >> 3;
+  float v = 0.0f;
+  f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (KQ) {
+    const unsigned long long* p = ng.pair + sb * 256 + lane * 4;
+    unsigned long long g[4];
 #pragma unroll
-    for (int i = 0; i < 64; i++) sum += rl_f(v, i);  // strictly in chunk order; lanes past nchunks add +0.0
+    for (int i = 0; i < 4; i++) g[i] = ld_granule(p + i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v4[i] = (unsigned)(g[i] >> 32) == epoch ? __builtin_bit_cast(float, (unsigned)g[i]) : poll(p + i);
+  } else if (SPLIT > 1) {
+    if (lane < 32) v = own ? hv[l32] : poll(ng.pair + blk * 32 + l32);
+  } else {
+    v = hv[l32];
+  }
+  // ... then the hop: every workgroup's sum, added strictly in chunk order
+  float sum = 0.0f;
+  const int nwg = (int)gridDim.x;
+  for (int base = 0; base < nwg; base += 64) {
+    const int c = base + lane;
+    float cv = c < nwg ? poll(ng.slots + c) : 0.0f;
+    if (SPLIT > 1) cv += dpp_f<0xB1>(cv);  // chunk = its two halves (the same value on both lanes of the pair)
+#pragma unroll
+    for (int i = 0; i < 64; i += SPLIT) sum += rl_f(cv, i);  // lanes past the grid add +0.0
   }
   const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
-  const float v = hv[lane & 31];
-  const float xn = (v / rms) * wn;
   if constexpr (!KQ) {
+    const float xn = (v / rms) * wn;
     const QLane o = quant_lane32<Q81>(xn, true);
-    if (lane < 32) {
+    if (lane < 32 && own) {
       q[blk * 32 + lane] = o.q;
       if (lane == 0) {
         ((unsigned short*)d)[blk] = o.d;
@@ -928,64 +996,18 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     }
   } else {
     // Q8_K (buf_q8_k.rs:84-131): the scale comes from the FIRST element of maximal |x| of the 256-element
-    // super-block = this chunk and its 7 neighbours: every chunk publishes its own first-max element as a granule,
-    // reads the eight of its super-block, and takes the first strictly greater one in chunk order -- the flat
-    // strict-`>` scan of the reference.
-    if (lane < 32) hv[lane] = xn;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    float aloc = 0.0f, mloc = 0.0f;
+    // super-block = this chunk and its 7 neighbours.  The wave holds the super-block's 256 rows (4 per lane, from
+    // their granules), normalizes them all and runs the whole block's quantizer; it stores the part that is its own.
+    f32x4 xn;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {  // every lane, from LDS broadcasts
-      f32x4 t = ((const f32x4*)hv)[j];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const float a = fabsf(t[e]);
-        if (a > aloc) {
-          aloc = a;
-          mloc = t[e];
-        }
-      }
+    for (int i = 0; i < 4; i++) xn[i] = (v4[i] / rms) * wn4[i];
+    const Q8KLane o = q8k_wave_quant(xn, lane);
+    const int l0 = (blk & 7) * 8 + part * (ROWS / 4);
+    if (lane >= l0 && lane < l0 + ROWS / 4) {
+      ((unsigned*)q)[sb * 64 + lane] = o.packed;
+      if ((lane & 3) == 0) ((short*)isum)[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
     }
-    if (lane == 0)
-      __hip_atomic_store(ng.sbmax + blk, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, mloc),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int sb = blk >> 3;
-    float mv = 0.0f;
-    if (lane < 8) {
-      unsigned long long g = ld_granule(ng.sbmax + sb * 8 + lane);
-      int tries = 0;
-      while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
-        __builtin_amdgcn_s_sleep(1);
-        g = ld_granule(ng.sbmax + sb * 8 + lane);
-        tries++;
-      }
-      if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;
-      mv = __builtin_bit_cast(float, (unsigned)g);
-    }
-    float besta = 0.0f, best = 0.0f;
-#pragma unroll
-    for (int c8 = 0; c8 < 8; c8++) {
-      const float cv = rl_f(mv, c8), ca = fabsf(cv);
-      if (ca > besta) {
-        besta = ca;
-        best = cv;
-      }
-    }
-    const float scale = -128.0f / best;
-    int qi = 0;
-    if (besta != 0.0f) {
-      float r = roundf(scale * xn);  // half away from zero
-      r = fminf(r, 127.0f);
-      qi = rs_f32_as_i32(r);
-      qi = qi < -128 ? -128 : qi;  // `as i8` saturates
-    }
-    const int bs = row16_sum_i32(qi);
-    if (lane < 32) {
-      q[blk * 32 + lane] = (signed char)qi;
-      if ((lane & 15) == 0) ((short*)isum)[sb * 16 + (blk & 7) * 2 + (lane >> 4)] = (short)bs;
-      if (lane == 0 && (blk & 7) == 0) ((float*)d)[sb] = besta != 0.0f ? 1.0f / scale : 0.0f;
-    }
+    if (lane == 0 && (blk & 7) == 0 && part == 0) ((float*)d)[sb] = o.d;
   }
 }
 
@@ -1386,9 +1408,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     if (prof) prof_begin(dev, &nr, CRABML_HIP_F32, 6, 8.0 * dim);
     const float* addv = add_pending ? c->partial : nullptr;
     if (dim <= 4096)
-      launch_k(st, prof ? &nr : nullptr, k_norm_quant<4, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<4, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf, 1);
     else
-      launch_k(st, prof ? &nr : nullptr, k_norm_quant<12, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<12, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf, 1);
     if (prof) prof_end(dev, &nr);
   };
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
@@ -1398,17 +1420,19 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
     if (norm_epi) {
-      NormGather ng{c->slots, c->slots + dim / 32, c->slots + dim / 32 + dim, c->state + 4, c->state + 5, n_segments(c), seg};
+      NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg};
       // long rows (ffn_down): two workgroups per chunk, so that every CU streams (a CU sustains ~26 GB/s here)
       const int split = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
                         : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
                         : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
                                                                           : 1;
       if (split == 2)
-        launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next,
+        launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
+                 eps_next,
                  ad.q, ad.d, ad.isum, ng, k / 32);
       else
-        launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next,
+        launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
+                 eps_next,
                  ad.q, ad.d, ad.isum, ng, k / 32);
     } else if (tp) {
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
@@ -1507,9 +1531,9 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
   auto norm = [&](const float* wn, float eps, bool add_pending) {
     const float* addv = add_pending ? c->partial : nullptr;
     if (dim <= 4096)
-      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, strict ? 0 : 1);
     else
-      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, strict ? 0 : 1);
   };
   float* dst = tp ? c->partial : c->x;
 
@@ -1597,9 +1621,9 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   auto norm_quant = [&](const float* wn, float eps, bool add_pending, uint32_t qt) -> const void* {
     const float* addv = add_pending ? c->partial : nullptr;
     if (dim <= 4096)
-      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, 1);
     else
-      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn);
+      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, 1);
     if (qt == CRABML_HIP_F32) return c->xn;
     launch_quantize_act(st, qt, c->xn, (size_t)dim, c->act_dim);
     return c->act_dim;
@@ -1607,22 +1631,36 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   float* dst = tp ? c->partial : c->x;
   const bool nepi = FMT == CRABML_HIP_Q4_K && c->norm_epi_k;
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
-  auto gemv_out = [&](const crabml_hip_buf* w, const Act& a, int k, uint32_t stage, const float* wnext, float eps_next) -> int {
+  // the rhs of wo / ffn_down quantized by the consuming kernel itself (no quantizer launch)
+  const bool qin = nepi && !(g.flags & CRABML_HIP_LLAMA_NO_RHS_PROLOGUE) && dim_l % 256 == 0 && hidden_l % 256 == 0;
+  // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only); xin: the f32 rhs
+  auto gemv_out = [&](const crabml_hip_buf* w, const Act& a, const float* xin, int k, uint32_t stage, const float* wnext,
+                      float eps_next) -> int {
     CH_TRY(P0(stage, dim, k));
     if constexpr (FMT == CRABML_HIP_Q4_K) {
       if (nepi) {
-        NormGather ng{c->slots, c->slots + dim / 32, c->slots + dim / 32 + dim, c->state + 4, c->state + 5, n_segments(c), seg};
+        NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg};
         ActLayout al = act_layout(QT, (size_t)dim);
+        signed char* oq = (signed char*)c->act_dim;
+        void* od = (void*)(c->act_dim + al.off_d);
+        void* ob = (void*)(c->act_dim + al.off_aux);
         const int split = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
                           : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
                           : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
                                                                             : 1;
-        if (split == 2)
-          launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_k(w), a, c->x, wnext, eps_next,
-                   (signed char*)c->act_dim, (void*)(c->act_dim + al.off_d), (void*)(c->act_dim + al.off_aux), ng, k / BE);
+        const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
+        if (split == 2 && qin)
+          launch_k(st, R, k_gemv_res_nq<FMT, 2, true>, dim3(dim / 16), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
+                   od, ob, ng, k / BE);
+        else if (split == 2)
+          launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
+                   ng, k / BE);
+        else if (qin)
+          launch_k(st, R, k_gemv_res_nq<FMT, 1, true>, dim3(dim / 32), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
+                   od, ob, ng, k / BE);
         else
-          launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_k(w), a, c->x, wnext, eps_next,
-                   (signed char*)c->act_dim, (void*)(c->act_dim + al.off_d), (void*)(c->act_dim + al.off_aux), ng, k / BE);
+          launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
+                   ng, k / BE);
         return P1();
       }
     }
@@ -1661,8 +1699,8 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
              planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e);
     CH_TRY(P1());
     enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
-    launch_quantize_act(st, QT, c->attn, (size_t)dim_l, c->act_attn);
-    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
+    if (!qin) launch_quantize_act(st, QT, c->attn, (size_t)dim_l, c->act_attn);
+    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), c->attn, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
   } else {
     if (!nepi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, QT);  // llama2.rs:611
     CH_TRY(P0(3, 2.0 * hidden_l, dim));
@@ -1675,8 +1713,8 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
                act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / BE);
     }
     CH_TRY(P1());
-    launch_quantize_act(st, QT, c->h, (size_t)hidden_l, c->act_hid);
-    CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), hidden_l, 4,
+    if (!qin) launch_quantize_act(st, QT, c->h, (size_t)hidden_l, c->act_hid);
+    CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), c->h, hidden_l, 4,
                     (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr, g.rms_norm_eps));
   }
   CH_HIP(dev, hipGetLastError());
@@ -1921,7 +1959,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     }
   }
   A(8 * sizeof(int), (void**)&c->state);
-  A((2 * (g.embedding_dim / 32) + g.embedding_dim) * 8, (void**)&c->slots);
+  A((g.embedding_dim / 16 + g.embedding_dim) * 8, (void**)&c->slots);
   c->norm_epi = !generic && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
@@ -1949,7 +1987,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     }
     hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 8 * sizeof(int), dev->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (2 * (g.embedding_dim / 32) + g.embedding_dim) * 8, dev->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (g.embedding_dim / 16 + g.embedding_dim) * 8, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) {
       crabml_hip_llama_destroy(c);

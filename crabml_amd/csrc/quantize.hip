@@ -71,57 +71,11 @@ __global__ __launch_bounds__(256) void k_quantize_q8_k(const float* __restrict__
   const int lane = threadIdx.x & 63;
   size_t blk = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (blk >= nblocks) return;  // whole wave exits together
-  f32x4 v = *(const f32x4*)(x + blk * 256 + lane * 4);
-  // first occurrence of the maximum |x| (strict `>` scan in element order)
-  float best_abs = 0.f, best_val = 0.f;
-  int best_idx = 0x7fffffff;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    float a = fabsf(v[i]);
-    if (a > best_abs) {
-      best_abs = a;
-      best_val = v[i];
-      best_idx = lane * 4 + i;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float oa = __shfl_xor(best_abs, o, 64);
-    float ov = __shfl_xor(best_val, o, 64);
-    int oi = __shfl_xor(best_idx, o, 64);
-    bool take = (oa > best_abs) || (oa == best_abs && oi < best_idx);
-    if (take) {
-      best_abs = oa;
-      best_val = ov;
-      best_idx = oi;
-    }
-  }
-  float scale = -128.0f / best_val;
-  float dd = 1.0f / scale;
-  int qi[4];
-  int s = 0;
-  if (best_abs == 0.0f) {
-    dd = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) qi[i] = 0;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float r = roundf(scale * v[i]);  // half away from zero
-      r = fminf(r, 127.0f);
-      int t = rs_f32_as_i32(r);
-      t = t < -128 ? -128 : t;  // `as i8` saturates
-      qi[i] = t;
-      s += t;
-    }
-  }
-  unsigned packed = ((unsigned)qi[0] & 0xffu) | (((unsigned)qi[1] & 0xffu) << 8) | (((unsigned)qi[2] & 0xffu) << 16) |
-                    (((unsigned)qi[3] & 0xffu) << 24);
-  *(unsigned*)(q + blk * 256 + lane * 4) = packed;
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  if ((lane & 3) == 0) bsums[blk * 16 + (lane >> 2)] = (short)s;
-  if (lane == 0) d[blk] = dd;
+  const f32x4 v = *(const f32x4*)(x + blk * 256 + lane * 4);
+  const Q8KLane o = q8k_wave_quant(v, lane);  // devutil.hpp
+  *(unsigned*)(q + blk * 256 + lane * 4) = o.packed;
+  if ((lane & 3) == 0) bsums[blk * 16 + (lane >> 2)] = (short)o.quad_sum;
+  if (lane == 0) d[blk] = o.d;
 }
 
 __global__ __launch_bounds__(256) void k_quantize_f16(const float* __restrict__ x, unsigned short* __restrict__ h,

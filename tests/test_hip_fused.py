@@ -247,7 +247,9 @@ def test_q4_k_fused_kernels_equal_the_per_op_segments(ca, fmt):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
 
 
-@pytest.mark.parametrize("flags", [0, 16])  # 16 = SPLIT_CHUNKS_ALWAYS: the two-workgroup chunk hand-off
+# 16 = SPLIT_CHUNKS_ALWAYS: the two-workgroup chunk hand-off; 1024 = NO_RHS_PROLOGUE: wo / ffn_down read Q8_K planes
+# from a quantizer launch instead of quantizing the f32 attention output / h themselves
+@pytest.mark.parametrize("flags", [0, 16, 1024, 1024 + 16])
 def test_q4_k_norm_epilogue_equals_the_quantizer_launches(ca, flags):
     """Q4_K layers: RMSNorm + the Q8_K quantizer of the next GEMV run in the wo / ffn_down epilogue.  A Q8_K
     super-block (buf_q8_k.rs:84-131: scale from the FIRST element of maximal |x| of 256) spans eight 32-row
