@@ -135,29 +135,21 @@ struct Q8KLane {
   float d;
 };
 __device__ __forceinline__ Q8KLane q8k_wave_quant(const f32x4 v, int lane) {
-  float best_abs = 0.f, best_val = 0.f;
-  int best_idx = 0x7fffffff;
+  // first element of maximal |x|: the lane's own first maximum (strict `>` scan), the wave maximum by DPP, then
+  // the lowest lane that holds it (ballot) hands over its element
+  float loc_abs = 0.f, loc_val = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     float a = fabsf(v[i]);
-    if (a > best_abs) {
-      best_abs = a;
-      best_val = v[i];
-      best_idx = lane * 4 + i;
+    if (a > loc_abs) {
+      loc_abs = a;
+      loc_val = v[i];
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float oa = __shfl_xor(best_abs, o, 64);
-    float ov = __shfl_xor(best_val, o, 64);
-    int oi = __shfl_xor(best_idx, o, 64);
-    bool take = (oa > best_abs) || (oa == best_abs && oi < best_idx);
-    if (take) {
-      best_abs = oa;
-      best_val = ov;
-      best_idx = oi;
-    }
-  }
+  const float best_abs = wave_max_f32(loc_abs);
+  const unsigned long long holders = __ballot(loc_abs == best_abs);
+  const int first = holders ? __builtin_ctzll(holders) : 0;
+  const float best_val = rl_f(loc_val, first);
   const float scale = -128.0f / best_val;
   Q8KLane o;
   o.d = best_abs == 0.0f ? 0.0f : 1.0f / scale;
@@ -177,8 +169,8 @@ __device__ __forceinline__ Q8KLane q8k_wave_quant(const f32x4 v, int lane) {
   }
   o.packed = ((unsigned)qi[0] & 0xffu) | (((unsigned)qi[1] & 0xffu) << 8) | (((unsigned)qi[2] & 0xffu) << 16) |
              (((unsigned)qi[3] & 0xffu) << 24);
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
+  s += dpp_i<0xB1>(s);
+  s += dpp_i<0x4E>(s);
   o.quad_sum = s;
   return o;
 }

@@ -845,19 +845,18 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
   const int blk = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
   const int nchunks = gridDim.x / SPLIT;
   const int row = blk * 32 + part * ROWS + wave * RW;
-  float res[RW];
+  float res = 0.f;                         // wave 0: the residual of row (first row of the workgroup) + lane
   float wn = 0.f;                          // the next RMSNorm's weights for the rows this wave will normalize,
   f32x4 wn4 = {0.f, 0.f, 0.f, 0.f};        // loaded up front (off the critical path after the hop)
   unsigned epoch = 0;
-#pragma unroll
-  for (int r = 0; r < RW; r++) res[r] = lane == 0 ? x[row + r] : 0.f;
   if (wave == 0) {
+    if (lane < ROWS) res = x[row + lane];
     if constexpr (KQ)
       wn4 = ((const f32x4*)wnext)[(blk >> 3) * 64 + lane];
     else
       wn = wnext[blk * 32 + (lane & 31)];
   }
-  if (wave == 0 || SPLIT > 1 || KQ) epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
+  if (wave == 0) epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
   // RW rows x two blocks per lane in flight (one workgroup per CU: the loads have to supply the parallelism);
   // terms are added in block order, as rows_partial does
   float acc[RW];
@@ -866,9 +865,30 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
     float* sd = (float*)(lds_act + nb * 16);
     short* sbs = (short*)(sd + nb);
+    // the first weight pieces are requested before the prologue (they do not depend on it): its L2 round trip
+    // and the quantizer run under the HBM latency of the stream's head
+    constexpr int PRE = 2;
+    Q4KPiece<false> pw[PRE][RW];
+#pragma unroll
+    for (int it = 0; it < PRE; it++) {
+      const int c = it * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < RW; r++) pw[it][r] = q4k_load<false>(w.q, (const i32x4*)w.d, (size_t)(row + r), nb, c < nb * 8 ? c : nb * 8 - 1, lane);
+    }
     stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
     const ActQ8_K la{lds_act, sd, sbs};
-    rows_partial_q4k<RW, false>(w.q, (const i32x4*)w.d, la, row, nchunks * 32, nb, lane, acc);
+#pragma unroll
+    for (int r = 0; r < RW; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < PRE; it++) {
+      const int c = it * 64 + lane;
+      if (c < nb * 8) {
+        const Q4KX xx = q4k_loadx(la, c);
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] += q4k_term<false>(pw[it][r], xx, c);
+      }
+    }
+    rows_partial_q4k<RW, false>(w.q, (const i32x4*)w.d, la, row, nchunks * 32, nb, lane, acc, PRE * 64);
   } else if constexpr (KQ) {
     rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
   } else {
@@ -902,17 +922,22 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
 #pragma unroll
   for (int r = 0; r < RW; r++) {
     const float s = wave_sum_f32(acc[r]);
-    if (lane == 0) {
-      const float xv = s + res[r];  // x = matmul_out + x (llama2.rs:266 / :636)
-      x[row + r] = xv;
-      hv[part * ROWS + wave * RW + r] = xv;
-      if (ROWG)
-        __hip_atomic_store(ng.pair + row + r, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 0) hv[part * ROWS + wave * RW + r] = s;
   }
   __syncthreads();
   if (wave != 0) return;
+  // wave 0 owns the stores: ROWS consecutive rows per instruction (x and the row granules are one or two lines,
+  // not 32 separate partial writes from 16 waves)
+  if (lane < ROWS) {
+    const float xv = hv[part * ROWS + lane] + res;  // x = matmul_out + x (llama2.rs:266 / :636)
+    x[row + lane] = xv;
+    hv[part * ROWS + lane] = xv;
+    if (ROWG)
+      __hip_atomic_store(ng.pair + row + lane, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
   // sum of squares of a chunk = (rows 0..15 in order) + (rows 16..31 in order): a split chunk's two workgroups
   // each own one half (norm_quant_block<HALF> computes the same)
   float cs;

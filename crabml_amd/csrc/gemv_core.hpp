@@ -175,59 +175,88 @@ __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const
 // dwords with DPP -- 4 instead of 16 header bytes per lane through the vector-memory path (measured: down 12.9 ->
 // 11.5 us, classifier 53.7 -> 49.3 us); with the activation planes in LDS that path is no longer the bottleneck
 // and the plain 16-byte load is faster (gate/up 15.9 vs 17.1 us), hence the switch.
+template <bool HDR_DPP>
+struct Q4KPiece {  // one lane's 16-byte qs piece + its super-block header (whole, or the quad's dword of it)
+  i32x4 qv, hdr;
+  unsigned hw;
+};
+template <bool HDR_DPP>
+__device__ __forceinline__ Q4KPiece<HDR_DPP> q4k_load(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, size_t row, int nsb,
+                                                      int c, int lane) {
+  Q4KPiece<HDR_DPP> w;
+  const int sb = c >> 3;
+  w.qv = __builtin_nontemporal_load(wq + row * (size_t)(nsb * 8) + c);
+  if constexpr (HDR_DPP)
+    w.hw = __builtin_nontemporal_load((const unsigned*)wh + (row * nsb + sb) * 4 + (lane & 3));
+  else
+    w.hdr = __builtin_nontemporal_load(wh + row * nsb + sb);
+  return w;
+}
+struct Q4KX {  // the activation side of piece c
+  i32x4 xl, xh;
+  float d8;
+  int bs_lo, bs_hi;
+};
+__device__ __forceinline__ Q4KX q4k_loadx(const ActQ8_K& act, int c) {
+  const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
+  Q4KX x;
+  const i32x4* xq = act.q + (size_t)sb * 16 + p * 4 + h;
+  x.xl = xq[0];
+  x.xh = xq[2];
+  x.d8 = act.d[sb];
+  const short* bs = act.bsums + sb * 16 + p * 4 + h;
+  x.bs_lo = (int)bs[0];
+  x.bs_hi = (int)bs[2];
+  return x;
+}
+template <bool HDR_DPP>
+__device__ __forceinline__ float q4k_term(const Q4KPiece<HDR_DPP>& w, const Q4KX& x, int c) {
+  const int p = (c & 7) >> 1;
+  unsigned h0, h1, h2, h3;
+  if constexpr (HDR_DPP) {  // quad_perm broadcasts of dword 0..3
+    h0 = (unsigned)dpp_i<0x00>((int)w.hw);
+    h1 = (unsigned)dpp_i<0x55>((int)w.hw);
+    h2 = (unsigned)dpp_i<0xAA>((int)w.hw);
+    h3 = (unsigned)dpp_i<0xFF>((int)w.hw);
+  } else {
+    h0 = (unsigned)w.hdr[0];
+    h1 = (unsigned)w.hdr[1];
+    h2 = (unsigned)w.hdr[2];
+    h3 = (unsigned)w.hdr[3];
+  }
+  const unsigned f = q4k_pair_field(h1, h2, h3, p);
+  const int sc_lo = (int)(f & 63u), sc_hi = (int)((f >> 6) & 63u);
+  const int m_lo = (int)((f >> 12) & 63u), m_hi = (int)(f >> 18);
+  int lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    lo = __builtin_amdgcn_sdot4(w.qv[i] & 0x0F0F0F0F, x.xl[i], lo, false);
+    hi = __builtin_amdgcn_sdot4((w.qv[i] >> 4) & 0x0F0F0F0F, x.xh[i], hi, false);
+  }
+  const int isum = sc_lo * lo + sc_hi * hi;          // exact (the reference's aux32 lanes hold integers < 2^24)
+  const int msum = m_lo * x.bs_lo + m_hi * x.bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
+  const float dd = h2f((unsigned short)(h0 & 0xffff)) * x.d8;
+  const float dmin = h2f((unsigned short)(h0 >> 16)) * x.d8;
+  return dd * (float)isum - dmin * (float)msum;
+}
 template <int R, bool HDR_DPP = true>
 __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act,
-                                                 int row0, int m, int nsb, int lane, float acc[R]) {
+                                                 int row0, int m, int nsb, int lane, float acc[R], int c0 = 0) {
+  if (c0 == 0) {
 #pragma unroll
-  for (int r = 0; r < R; r++) acc[r] = 0.f;
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
+  }
   const int nchunks = nsb * 8;
-  for (int c = lane; c < nchunks; c += 64) {
-    const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
-    i32x4 qv[R], hdr[R];
-    unsigned hw[R];
+  for (int c = c0 + lane; c < nchunks; c += 64) {  // c0: pieces below it were taken by the caller (a multiple of 64)
+    Q4KPiece<HDR_DPP> w[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int row = row0 + r < m ? row0 + r : m - 1;
-      qv[r] = __builtin_nontemporal_load(wq + (size_t)row * nchunks + c);
-      if constexpr (HDR_DPP)
-        hw[r] = __builtin_nontemporal_load((const unsigned*)wh + ((size_t)row * nsb + sb) * 4 + (lane & 3));
-      else
-        hdr[r] = __builtin_nontemporal_load(wh + (size_t)row * nsb + sb);
+      w[r] = q4k_load<HDR_DPP>(wq, wh, (size_t)row, nsb, c, lane);
     }
-    const i32x4* xq = act.q + (size_t)sb * 16 + p * 4 + h;
-    const i32x4 xl = xq[0], xh = xq[2];
-    const float d8 = act.d[sb];
-    const short* bs = act.bsums + sb * 16 + p * 4 + h;
-    const int bs_lo = (int)bs[0], bs_hi = (int)bs[2];
+    const Q4KX x = q4k_loadx(act, c);
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      unsigned h0, h1, h2, h3;
-      if constexpr (HDR_DPP) {  // quad_perm broadcasts of dword 0..3
-        h0 = (unsigned)dpp_i<0x00>((int)hw[r]);
-        h1 = (unsigned)dpp_i<0x55>((int)hw[r]);
-        h2 = (unsigned)dpp_i<0xAA>((int)hw[r]);
-        h3 = (unsigned)dpp_i<0xFF>((int)hw[r]);
-      } else {
-        h0 = (unsigned)hdr[r][0];
-        h1 = (unsigned)hdr[r][1];
-        h2 = (unsigned)hdr[r][2];
-        h3 = (unsigned)hdr[r][3];
-      }
-      const unsigned f = q4k_pair_field(h1, h2, h3, p);
-      const int sc_lo = (int)(f & 63u), sc_hi = (int)((f >> 6) & 63u);
-      const int m_lo = (int)((f >> 12) & 63u), m_hi = (int)(f >> 18);
-      int lo = 0, hi = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        lo = __builtin_amdgcn_sdot4(qv[r][i] & 0x0F0F0F0F, xl[i], lo, false);
-        hi = __builtin_amdgcn_sdot4((qv[r][i] >> 4) & 0x0F0F0F0F, xh[i], hi, false);
-      }
-      const int isum = sc_lo * lo + sc_hi * hi;      // exact (the reference's aux32 lanes hold integers < 2^24)
-      const int msum = m_lo * bs_lo + m_hi * bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
-      const float dd = h2f((unsigned short)(h0 & 0xffff)) * d8;
-      const float dmin = h2f((unsigned short)(h0 >> 16)) * d8;
-      acc[r] += dd * (float)isum - dmin * (float)msum;
-    }
+    for (int r = 0; r < R; r++) acc[r] += q4k_term<HDR_DPP>(w[r], x, c);
   }
 }
 
