@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int d
                                                const int* __restrict__ token_d, int dim, float* __restrict__ x) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= dim) return;
-  x[i] = dequant_elem(w, dtype, off_scale, (size_t)(*token_d) * dim + i);
+  // blockIdx.y: row of a prefill batch (token ids and output rows are consecutive); 0 for a decode step
+  x[(size_t)blockIdx.y * dim + i] = dequant_elem(w, dtype, off_scale, (size_t)token_d[blockIdx.y] * dim + i);
 }
 
 // ---- rmsnorm * weight -> Q8_0 planes ------------------------------------------------------------------
@@ -217,6 +218,17 @@ __global__ __launch_bounds__(1024) void k_norm_f32(float* __restrict__ x, const 
   norm_quant_block<NIT, false>(x, addv, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr, xn, half);
 }
 
+// batched prefill: one workgroup per row of x (rows, cols) -> xn (rows, cols)
+template <int NIT>
+__global__ __launch_bounds__(1024) void k_norm_f32_rows(float* __restrict__ x, const float* __restrict__ w, int cols, float eps,
+                                                       float* __restrict__ xn, int half) {
+  extern __shared__ float lds[];
+  __shared__ float s_rms;
+  NormLds L{lds, lds + cols};
+  norm_quant_block<NIT, false>(x + (size_t)blockIdx.x * cols, nullptr, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr,
+                               xn + (size_t)blockIdx.x * cols, half);
+}
+
 // ---- QKV epilogue: rope (rope.rs:47-63) + q scale (llama2.rs:565) + KV append (concatenate.rs:172-204) ---
 struct QkvEpi {
   float* q_out;       // (n_heads * hd) f32, roped and scaled
@@ -234,9 +246,9 @@ struct QkvPre {
   float c, s;
   bool rot;
 };
-__device__ __forceinline__ QkvPre qkv_preload(const QkvEpi& e, int row0) {
+__device__ __forceinline__ QkvPre qkv_preload(const QkvEpi& e, int row0, int row_of_batch = 0) {
   QkvPre p;
-  p.pos = *e.pos_d;
+  p.pos = *e.pos_d + row_of_batch;
   p.c = 1.f;
   p.s = 0.f;
   p.rot = false;
@@ -321,6 +333,20 @@ __global__ __launch_bounds__(256) void k_qkv_epi(const float* __restrict__ tmp, 
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   int total = (e.dim + 2 * e.kv_dim) / 2;
   if (p < total) qkv_epilogue(e, qkv_preload(e, 2 * p), 2 * p, tmp[2 * p], tmp[2 * p + 1]);
+}
+
+// batched prefill: the three GEMMs wrote qb (B, dim), kb / vb (B, kv_dim); row r is position *pos_d + r
+__global__ __launch_bounds__(256) void k_qkv_epi_rows(const float* __restrict__ qb, const float* __restrict__ kb,
+                                                     const float* __restrict__ vb, QkvEpi e) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (p >= (e.dim + 2 * e.kv_dim) / 2) return;
+  const int row0 = 2 * p;
+  const float* src = row0 < e.dim              ? qb + (size_t)r * e.dim + row0
+                     : row0 < e.dim + e.kv_dim ? kb + (size_t)r * e.kv_dim + (row0 - e.dim)
+                                               : vb + (size_t)r * e.kv_dim + (row0 - e.dim - e.kv_dim);
+  QkvEpi er = e;
+  er.q_out = e.q_out + (size_t)r * e.dim;
+  qkv_epilogue(er, qkv_preload(e, row0, r), row0, src[0], src[1]);
 }
 
 // softmax.rs:36-54 over scores[0..seq) in LDS, in place, by a 256-thread workgroup: max, exp through the f16 table,
@@ -411,6 +437,9 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   const int tid = threadIdx.x;
   const int head = blockIdx.x;
   const int kvh = KV16 ? head / (n_heads / n_kv) : head % n_kv;
+  // blockIdx.y: row of a prefill batch = one more cached position per row (causal); 0 for a decode step
+  q += (size_t)blockIdx.y * n_heads * hd;
+  out += (size_t)blockIdx.y * n_heads * hd;
   // Position-independent loads go out first, so that their (cold, cross-XCD) latency overlaps the q staging
   // instead of adding two more serial round trips: the first 64 halves of the K row this thread will score
   // and the first 16 V values of the output column it will accumulate.  Rows past `seq` are read but unused.
@@ -428,7 +457,7 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
 #pragma unroll
     for (int u = 0; u < 16; u++) vpre[u] = vr0[(size_t)u * hd];
   }
-  const int seq = *pos_d + 1;
+  const int seq = *pos_d + 1 + (int)blockIdx.y;
   for (int i = tid; i < hd; i += blockDim.x) {
     float v = q[head * hd + i];
     qs[i] = KV16 ? h2f(f2h(v)) : v;  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
@@ -1298,6 +1327,12 @@ struct crabml_hip_llama {
   size_t attn_long_from = 0;    // cached positions (pos + 1) from which variant 1 is used
   float* scores_g = nullptr;    // [n_heads_l][seq_len] f32
   unsigned short* p16 = nullptr;  // [n_heads_l][seq_len] f16 probabilities
+  // batched prefill (crabml_hip_llama_prefill): row buffers for pf_cap prompt rows, allocated on first use
+  size_t pf_cap = 0;
+  int* pf_tokens = nullptr;
+  float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr, *pf_qr = nullptr, *pf_attn = nullptr,
+        *pf_tmp = nullptr, *pf_g = nullptr, *pf_u = nullptr;
+  char *pf_act_dim = nullptr, *pf_act_hid = nullptr;
   std::vector<std::pair<void*, size_t>> allocs;
 };
 
@@ -1785,6 +1820,121 @@ int run_step(crabml_hip_llama* c, size_t pos) {
   return enqueue_step(c);
 }
 
+
+// ---- batched prefill ---------------------------------------------------------------------------------------
+// B prompt rows at positions pos0 .. pos0 + B - 1 through every layer as (B, k) matmul_vec calls (launch_gemv: MFMA
+// GEMM for Q4_0 / Q8_0 and B >= 16), row-wise rmsnorm / quantize / rope / append, and causal attention (row r sees
+// pos0 + r + 1 cached positions).  Per row this is the arithmetic of the per-op segment path.
+int prefill_alloc(crabml_hip_llama* c, size_t cap) {
+  if (c->pf_cap >= cap) return 0;
+  if (c->pf_cap != 0) CH_BAIL(c->dev, CRABML_HIP_UNEXPECTED, "llama prefill: row buffers already sized for %zu rows", c->pf_cap);
+  const auto& g = c->cfg;
+  const size_t dim = g.embedding_dim, kv_dim = (size_t)c->kv_dim_l, hidden = g.hidden_dim;
+  auto A = [&](size_t bytes, void** out) { return dalloc(c, bytes ? bytes : 16, out); };
+  auto act_bytes = [](uint32_t t, size_t n) { return t == CRABML_HIP_F32 ? (size_t)16 : act_layout(t, n).total; };
+  CH_TRY(A(cap * 4, (void**)&c->pf_tokens));
+  CH_TRY(A(cap * dim * 4, (void**)&c->pf_x));
+  CH_TRY(A(cap * dim * 4, (void**)&c->pf_xn));
+  CH_TRY(A(cap * dim * 4, (void**)&c->pf_q));
+  CH_TRY(A(cap * kv_dim * 4, (void**)&c->pf_k));
+  CH_TRY(A(cap * kv_dim * 4, (void**)&c->pf_v));
+  CH_TRY(A(cap * dim * 4, (void**)&c->pf_qr));
+  CH_TRY(A(cap * dim * 4, (void**)&c->pf_attn));
+  CH_TRY(A(cap * dim * 4, (void**)&c->pf_tmp));
+  CH_TRY(A(cap * hidden * 4, (void**)&c->pf_g));
+  CH_TRY(A(cap * hidden * 4, (void**)&c->pf_u));
+  CH_TRY(A(cap * act_bytes(c->qt, dim), (void**)&c->pf_act_dim));
+  CH_TRY(A(cap * act_bytes(c->qt, hidden), (void**)&c->pf_act_hid));
+  c->pf_cap = cap;
+  return 0;
+}
+
+int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t pos0, bool want_logits) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const auto& g = c->cfg;
+  const int dim = (int)g.embedding_dim, kv_dim = c->kv_dim_l, hidden = (int)g.hidden_dim, hd = c->hd, seq_cap = (int)g.seq_len;
+  const int n_heads = c->n_heads_l, n_kv = c->n_kv_l, L = (int)g.n_layers;
+  const bool kv16 = g.use_f16_kv_cache != 0, strict = dev->strict_order;
+  const int half = strict ? 0 : 1;
+  const unsigned rows = (unsigned)B;
+  {
+    std::vector<int> h(B + 1);
+    for (size_t i = 0; i < B; i++) h[i] = (int)tokens[i];
+    CH_HIP(dev, hipMemcpyAsync(c->pf_tokens, h.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    const int p0 = (int)pos0;
+    CH_HIP(dev, hipMemcpyAsync(c->state + 6, &p0, sizeof(int), hipMemcpyHostToDevice, st));
+    CH_HIP(dev, hipStreamSynchronize(st));  // the staging vectors go out of scope
+  }
+  const int* pos_d = c->state + 6;
+  const size_t norm_lds = norm_lds_bytes(dim);
+  auto norm_rows = [&](const float* wn, float eps) {
+    if (dim <= 4096)
+      k_norm_f32_rows<4><<<rows, 1024, norm_lds, st>>>(c->pf_x, wn, dim, eps, c->pf_xn, half);
+    else
+      k_norm_f32_rows<12><<<rows, 1024, norm_lds, st>>>(c->pf_x, wn, dim, eps, c->pf_xn, half);
+  };
+  // CpuTensorBuf::quantize for the rhs of matmul_vec (buf/api.rs:142-159): F32 weights take the rows as they are
+  auto quant_rows = [&](const float* src, int n, char* planes) -> const void* {
+    if (c->qt == CRABML_HIP_F32) return src;
+    launch_quantize_act_rows(st, c->qt, src, B, (size_t)n, planes);
+    return planes;
+  };
+  auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
+    return strict ? launch_gemv_strict(dev, w, m, k, act, B, out) : launch_gemv(dev, w, m, k, act, B, out, nullptr);
+  };
+  k_embed<<<dim3((dim + 255) / 256, rows), 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
+                                                         c->token_embed->wl.off_scale, c->pf_tokens, dim, c->pf_x);
+  for (int l = 0; l < L; l++) {
+    norm_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);  // llama2.rs:230-234
+    const void* a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+    CH_TRY(gemm(c->wq[l], dim, dim, a, c->pf_q));  // llama2.rs:244-246
+    CH_TRY(gemm(c->wk[l], kv_dim, dim, a, c->pf_k));
+    CH_TRY(gemm(c->wv[l], kv_dim, dim, a, c->pf_v));
+    QkvEpi e{c->pf_qr, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
+             (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
+    const int pairs = (dim + 2 * kv_dim) / 2;
+    k_qkv_epi_rows<<<dim3((pairs + 255) / 256, rows), 256, 0, st>>>(c->pf_q, c->pf_k, c->pf_v, e);
+    const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
+    if (kv16)
+      k_attn<true><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
+                                                                c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
+                                                                PrefetchPlan{}, 0);
+    else
+      k_attn<false><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
+                                                                 c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
+                                                                 PrefetchPlan{}, 0);
+    a = quant_rows(c->pf_attn, dim, c->pf_act_dim);
+    CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp));  // llama2.rs:600
+    k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);  // :266
+    norm_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f);  // llama2.rs:611
+    a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+    CH_TRY(gemm(c->gate[l], hidden, dim, a, c->pf_g));  // llama2.rs:620-630
+    CH_TRY(gemm(c->up[l], hidden, dim, a, c->pf_u));
+    k_gateup_epi<<<(unsigned)(((size_t)B * hidden + 255) / 256), 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table,
+                                                                               c->pf_g, (int)(B * hidden));
+    a = quant_rows(c->pf_g, hidden, c->pf_act_hid);
+    CH_TRY(gemm(c->down[l], dim, hidden, a, c->pf_tmp));  // llama2.rs:633-636
+    k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);
+  }
+  if (want_logits) {  // final rmsnorm + classifier of the last row only (llama2.rs:274-278, 199-208)
+    CH_HIP(dev, hipMemcpyAsync(c->x, c->pf_x + (B - 1) * (size_t)dim, (size_t)dim * 4, hipMemcpyDeviceToDevice, st));
+    if (dim <= 4096)
+      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, nullptr, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, half);
+    else
+      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, nullptr, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, half);
+    const void* act = c->xn;
+    if (c->out_qt != CRABML_HIP_F32) {
+      launch_quantize_act(st, c->out_qt, c->xn, (size_t)dim, c->act_dim);
+      act = c->act_dim;
+    }
+    CH_TRY(strict ? launch_gemv_strict(dev, c->output, g.vocab_size, dim, act, 1, c->logits)
+                  : launch_gemv(dev, c->output, g.vocab_size, dim, act, 1, c->logits, nullptr));
+  }
+  CH_HIP(dev, hipGetLastError());
+  return 0;
+}
+
 int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step) {
   int st[3] = {(int)token, (int)pos, step};
   CH_HIP(c->dev, hipMemcpyAsync(c->state, st, sizeof st, hipMemcpyHostToDevice, c->dev->stream));
@@ -2120,6 +2270,33 @@ int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n
   CH_HIP(dev, hipMemcpyAsync(&fault, c->state + 5, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
   if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: a norm-epilogue gather timed out (workgroups not co-resident?)");
+  return 0;
+}
+
+
+int crabml_hip_llama_prefill(crabml_hip_llama_t* c, const uint32_t* tokens, size_t n, float* logits) {
+  if (!c || (!tokens && n)) return CRABML_HIP_BAD_INPUT;
+  crabml_hip_device* dev = c->dev;
+  if (n == 0) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama prefill: expected at least 1 prompt token");  // llama2.rs:117-122
+  for (size_t i = 0; i < n; i++)
+    if (tokens[i] >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %u out of range", tokens[i]);
+  if (c->kv_len + n > c->cfg.seq_len)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "llama: %zu prompt tokens do not fit the kv cache (%zu of %zu used)", n, c->kv_len, c->cfg.seq_len);
+  if (c->tp > 1) {  // token loop
+    for (size_t i = 0; i < n; i++) CH_TRY(crabml_hip_llama_forward(c, tokens[i], c->kv_len, i + 1 == n ? logits : nullptr));
+    return 0;
+  }
+  const size_t chunk = c->cfg.prefill_chunk ? c->cfg.prefill_chunk : 256;
+  CH_TRY(prefill_alloc(c, chunk));
+  for (size_t i = 0; i < n; i += chunk) {
+    const size_t B = n - i < chunk ? n - i : chunk;
+    CH_TRY(prefill_chunk(c, tokens + i, B, c->kv_len, logits != nullptr && i + B == n));
+    c->kv_len += B;
+  }
+  if (logits) {
+    CH_HIP(dev, hipMemcpyAsync(logits, c->logits, c->cfg.vocab_size * 4, hipMemcpyDeviceToHost, dev->stream));
+    CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  }
   return 0;
 }
 

@@ -44,7 +44,7 @@ class HipLlamaRunner {
   HipLlamaRunner(const LlamaConfig& conf, std::shared_ptr<LlamaWeights<HipTensor>> w, HipTensorDeviceRef device,
                  size_t seq_len, bool use_f16_kv_cache, bool use_graph = true, bool prefetch = true, int tp_size = 1,
                  int tp_rank = 0, std::shared_ptr<TpComm> comm = nullptr, bool norm_epilogue = true, int extra_flags = 0,
-                 size_t attn_long_from = 0)
+                 size_t attn_long_from = 0, size_t prefill_chunk = 0)
       : conf_(conf), weights_(std::move(w)), device_(std::move(device)), comm_(std::move(comm)), tp_size_(tp_size > 1 ? tp_size : 1) {
     crabml_hip_llama_config_t c{};
     c.embedding_dim = conf.embedding_dim;
@@ -63,6 +63,7 @@ class HipLlamaRunner {
     c.tp_rank = tp_rank;
     c.tp_comm = comm_ ? comm_->raw() : nullptr;
     c.attn_long_from = attn_long_from;
+    c.prefill_chunk = prefill_chunk;
     auto raws = [](const std::vector<HipTensor>& v) {
       std::vector<const crabml_hip_buf_t*> r;
       for (const auto& t : v) r.push_back(t.raw());
@@ -103,6 +104,12 @@ class HipLlamaRunner {
   std::vector<float> forward(size_t token, size_t pos) {
     std::vector<float> logits(conf_.vocab_size);
     device_->check(crabml_hip_llama_forward(ctx_, token, pos, logits.data()));
+    return logits;
+  }
+  // the token loop of Llama2Runner::prefill (llama2.rs:111-129) as batched passes; returns the last token's logits
+  std::vector<float> prefill(const std::vector<uint32_t>& tokens) {
+    std::vector<float> logits(conf_.vocab_size);
+    device_->check(crabml_hip_llama_prefill(ctx_, tokens.data(), tokens.size(), logits.data()));
     return logits;
   }
   void forward_async(size_t token, size_t pos) { device_->check(crabml_hip_llama_forward(ctx_, token, pos, nullptr)); }

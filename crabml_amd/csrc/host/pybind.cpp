@@ -243,16 +243,27 @@ PYBIND11_MODULE(_host, m) {
   py::class_<HipLlamaRunner>(m, "HipLlamaRunner")
       .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,
                        size_t seq_len, bool use_f16_kv_cache, bool use_graph, bool prefetch, int tp_size, int tp_rank,
-                       std::shared_ptr<TpComm> comm, bool norm_epilogue, int extra_flags, size_t attn_long_from) {
+                       std::shared_ptr<TpComm> comm, bool norm_epilogue, int extra_flags, size_t attn_long_from,
+                       size_t prefill_chunk) {
              auto* r = new HipLlamaRunner(conf, std::move(w), std::move(dev), seq_len, use_f16_kv_cache, use_graph, prefetch,
-                                          tp_size, tp_rank, std::move(comm), norm_epilogue, extra_flags, attn_long_from);
+                                          tp_size, tp_rank, std::move(comm), norm_epilogue, extra_flags, attn_long_from,
+                                          prefill_chunk);
              r->set_seq_cap(seq_len);
              return r;
            }),
            py::arg("conf"), py::arg("weights"), py::arg("device"), py::arg("seq_len"), py::arg("use_f16_kv_cache"),
            py::arg("use_graph") = true, py::arg("prefetch") = true, py::arg("tp_size") = 1, py::arg("tp_rank") = 0,
            py::arg("comm") = std::shared_ptr<TpComm>(), py::arg("norm_epilogue") = true,
-           py::arg("extra_flags") = 0, py::arg("attn_long_from") = 0)
+           py::arg("extra_flags") = 0, py::arg("attn_long_from") = 0, py::arg("prefill_chunk") = 0)
+      .def("prefill",
+           [](HipLlamaRunner& r, const std::vector<uint32_t>& tokens) {
+             std::vector<float> lg;
+             {
+               py::gil_scoped_release rel;
+               lg = r.prefill(tokens);
+             }
+             return py::array_t<float>(lg.size(), lg.data());
+           })
       .def_static("tp_sim_forward",
                   [](const std::vector<HipLlamaRunner*>& ranks, size_t token, size_t pos) {
                     std::vector<float> lg;

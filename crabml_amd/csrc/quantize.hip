@@ -18,7 +18,12 @@ namespace crabml_hip {
 // one 32-lane group per block; 256 threads = 8 blocks per workgroup
 __global__ __launch_bounds__(256) void k_quantize_q8_0(const float* __restrict__ x, signed char* __restrict__ q,
                                                        unsigned short* __restrict__ d, int* __restrict__ isum,
-                                                       size_t nblocks) {
+                                                       size_t nblocks, size_t row_elems, size_t row_bytes) {
+  // blockIdx.y: row of a batch (x rows of row_elems floats; one set of planes every row_bytes bytes)
+  x += blockIdx.y * row_elems;
+  q += blockIdx.y * row_bytes;
+  d = (unsigned short*)((char*)d + blockIdx.y * row_bytes);
+  isum = (int*)((char*)isum + blockIdx.y * row_bytes);
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t blk = gid >> 5;
   int j = (int)(gid & 31);
@@ -41,7 +46,11 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float* __restrict__
 
 __global__ __launch_bounds__(256) void k_quantize_q8_1(const float* __restrict__ x, signed char* __restrict__ q,
                                                        unsigned short* __restrict__ d, unsigned short* __restrict__ sp,
-                                                       size_t nblocks) {
+                                                       size_t nblocks, size_t row_elems, size_t row_bytes) {
+  x += blockIdx.y * row_elems;
+  q += blockIdx.y * row_bytes;
+  d = (unsigned short*)((char*)d + blockIdx.y * row_bytes);
+  sp = (unsigned short*)((char*)sp + blockIdx.y * row_bytes);
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t blk = gid >> 5;
   int j = (int)(gid & 31);
@@ -67,7 +76,11 @@ __global__ __launch_bounds__(256) void k_quantize_q8_1(const float* __restrict__
 // one wave per 256-element super-block, 4 consecutive elements per lane
 __global__ __launch_bounds__(256) void k_quantize_q8_k(const float* __restrict__ x, signed char* __restrict__ q,
                                                        float* __restrict__ d, short* __restrict__ bsums,
-                                                       size_t nblocks) {
+                                                       size_t nblocks, size_t row_elems, size_t row_bytes) {
+  x += blockIdx.y * row_elems;
+  q += blockIdx.y * row_bytes;
+  d = (float*)((char*)d + blockIdx.y * row_bytes);
+  bsums = (short*)((char*)bsums + blockIdx.y * row_bytes);
   const int lane = threadIdx.x & 63;
   size_t blk = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (blk >= nblocks) return;  // whole wave exits together
@@ -79,39 +92,47 @@ __global__ __launch_bounds__(256) void k_quantize_q8_k(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void k_quantize_f16(const float* __restrict__ x, unsigned short* __restrict__ h,
-                                                      size_t n) {
+                                                      size_t n, size_t row_bytes) {
+  x += blockIdx.y * n;
+  h = (unsigned short*)((char*)h + blockIdx.y * row_bytes);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) h[i] = f2h(x[i]);
 }
 
 void launch_quantize_act(hipStream_t st, uint32_t qtype, const float* x, size_t n, void* planes) {
-  if (n == 0) return;
+  launch_quantize_act_rows(st, qtype, x, 1, n, planes);
+}
+// rows vectors of n elements each -> rows sets of planes, act_layout(qtype, n).total bytes apart (the batched rhs of
+// launch_gemv)
+void launch_quantize_act_rows(hipStream_t st, uint32_t qtype, const float* x, size_t rows, size_t n, void* planes) {
+  if (n == 0 || rows == 0) return;
   ActLayout al = act_layout(qtype, n);
+  const unsigned ry = (unsigned)rows;
   char* p = (char*)planes;
   switch (qtype) {
     case CRABML_HIP_Q8_0: {
       size_t nb = n / 32;
       unsigned grid = (unsigned)((nb * 32 + 255) / 256);
-      k_quantize_q8_0<<<grid, 256, 0, st>>>(x, (signed char*)p, (unsigned short*)(p + al.off_d), (int*)(p + al.off_aux),
-                                           nb);
+      k_quantize_q8_0<<<dim3(grid, ry), 256, 0, st>>>(x, (signed char*)p, (unsigned short*)(p + al.off_d), (int*)(p + al.off_aux),
+                                           nb, n, al.total);
       break;
     }
     case CRABML_HIP_Q8_1: {
       size_t nb = n / 32;
       unsigned grid = (unsigned)((nb * 32 + 255) / 256);
-      k_quantize_q8_1<<<grid, 256, 0, st>>>(x, (signed char*)p, (unsigned short*)(p + al.off_d),
-                                           (unsigned short*)(p + al.off_aux), nb);
+      k_quantize_q8_1<<<dim3(grid, ry), 256, 0, st>>>(x, (signed char*)p, (unsigned short*)(p + al.off_d),
+                                           (unsigned short*)(p + al.off_aux), nb, n, al.total);
       break;
     }
     case CRABML_HIP_Q8_K: {
       size_t nb = n / 256;
       unsigned grid = (unsigned)((nb + 3) / 4);
-      k_quantize_q8_k<<<grid, 256, 0, st>>>(x, (signed char*)p, (float*)(p + al.off_d), (short*)(p + al.off_aux), nb);
+      k_quantize_q8_k<<<dim3(grid, ry), 256, 0, st>>>(x, (signed char*)p, (float*)(p + al.off_d), (short*)(p + al.off_aux), nb, n, al.total);
       break;
     }
     case CRABML_HIP_F16: {
       unsigned grid = (unsigned)((n + 255) / 256);
-      k_quantize_f16<<<grid, 256, 0, st>>>(x, (unsigned short*)p, n);
+      k_quantize_f16<<<dim3(grid, ry), 256, 0, st>>>(x, (unsigned short*)p, n, al.total);
       break;
     }
     default: break;

@@ -204,8 +204,7 @@ static int ensure_act(crabml_hip_device* dev, const crabml_hip_buf* x_, size_t b
     x->qc.cap = 0;
     CH_TRY(pool_alloc(dev, need, &x->qc.ptr, &x->qc.cap));
   }
-  for (size_t bi = 0; bi < b; bi++)
-    launch_quantize_act(dev->stream, qt, (const float*)x->ptr + bi * k, k, (char*)x->qc.ptr + bi * al.total);
+  launch_quantize_act_rows(dev->stream, qt, (const float*)x->ptr, b, k, x->qc.ptr);  // one launch for the b rows
   x->qc.qtype = qt;
   x->qc.version = x->version;
   x->qc.n = b * k;

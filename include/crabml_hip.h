@@ -212,6 +212,7 @@ typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
   int32_t tp_size, tp_rank;
   void* tp_comm; /* crabml_hip_tp_comm_t*; NULL with tp_size > 1 = a rank of the single-device simulation */
   size_t attn_long_from; /* cached positions from which attention runs as the multi-workgroup kernels (0 = default 224) */
+  size_t prefill_chunk;  /* rows per batched prefill pass (0 = default 256) */
 } crabml_hip_llama_config_t;
 typedef struct crabml_hip_llama_weights { /* crabml-llama2/src/model.rs:55-84; per-layer arrays of n_layers */
   const crabml_hip_buf_t* token_embed;
@@ -236,6 +237,14 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* ctx, size_t token, size_t pos, 
 /* n_steps greedy decode steps on device: forward(token), token = argmax (last maximum), ...; the n_steps
  * sampled ids are written to out_tokens (BLOCKS once, at the end). */
 int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* ctx, size_t token, size_t n_steps, uint32_t* out_tokens);
+/* The token loop of Llama2Runner::prefill (llama2.rs:111-129: `for (pos, token) in prompt_tokens: forward(&[token],
+ * base_pos + pos)`) as batched passes of up to prefill_chunk rows: same KV cache contents and, in logits (nullable,
+ * BLOCKS), the logits of the last prompt token.  The reference's own `_batched` flag is ignored (llama2.rs:114)
+ * and its batch_matmul has no causal mask for n_batch > 1; here every row attends to the cache up to its own
+ * position, which is what the token loop computes.  Weight matrices see the prompt as a (rows, k) rhs: the
+ * matmul_vec contract (matmul_vec.rs:6-8), on the matrix cores for Q4_0 / Q8_0 weights and >= 16 rows.  Strict-order
+ * devices: bit-identical to the token loop.  tp_size > 1: falls back to the token loop. */
+int crabml_hip_llama_prefill(crabml_hip_llama_t* ctx, const uint32_t* tokens, size_t n, float* logits);
 size_t crabml_hip_llama_kv_len(const crabml_hip_llama_t* ctx);
 int crabml_hip_llama_reset(crabml_hip_llama_t* ctx); /* empties the KV caches */
 /* ---- tensor-parallel group over RCCL / xGMI (one process per GPU) ----

@@ -1,0 +1,128 @@
+"""GPU parity for the batched prefill (crabml_hip_llama_prefill): the token loop of Llama2Runner::prefill
+(llama2.rs:111-129) as (rows, k) matmul_vec passes + causal attention.
+
+  * strict-order device: the last logits AND the KV-cache bytes are bit-identical to the oracle's token loop, for any
+    chunking, and decoding continues bit-identically after it;
+  * fast device: prompts of >= 16 rows put the Q4_0 / Q8_0 weight matrices on the matrix cores (gemm_mfma.hip); the
+    last logits agree with the oracle within the fast-mode tolerance and the greedy continuation with the token loop's."""
+import numpy as np
+import pytest
+
+from crabml_amd import synth
+from oracle import oracle as o
+from tests.helpers import to_oracle
+
+pytestmark = pytest.mark.gpu
+PROMPT = [1, 365, 400, 282, 7, 9, 11, 13, 2, 77, 500, 31, 8, 19, 64, 128, 3, 5, 900, 12, 14, 16, 18]  # 23 tokens
+
+
+def oracle_run(model, kv_f16, tokens, seq_len=64):
+    odev = o.OracleDevice(thread_num=4)
+    oconf, ow = to_oracle(model, odev)
+    r = o.OracleLlamaRunner(oconf, ow, odev, seq_len, kv_f16)
+    out = [r.forward([t], i).copy() for i, t in enumerate(tokens)]
+    return out, r
+
+
+def kv_equal(runner, orr, model, n_pos, kv_f16, seq_len=64):
+    s = model.shape
+    es = 2 if kv_f16 else 4
+    for layer in range(s.n_layers):
+        for which, cache in ((False, orr.key_cache), (True, orr.value_cache)):
+            got = runner.debug_kv(layer, which, kv_f16)
+            exp = cache[layer].storage.view(np.uint8)
+            for h in range(s.n_kv_heads):
+                lo = h * seq_len * s.head_dim * es
+                n = n_pos * s.head_dim * es
+                if not np.array_equal(got[lo:lo + n], exp[lo:lo + n]):
+                    return False
+    return True
+
+
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "F32"])
+@pytest.mark.parametrize("kv_f16", [False, True])
+@pytest.mark.parametrize("chunk", [0, 5])
+def test_prefill_strict_equals_the_oracle_token_loop(ca, fmt, kv_f16, chunk):
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=81)
+    ref, orr = oracle_run(model, kv_f16, PROMPT + [21, 22])
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16, prefill_chunk=chunk)
+    lg = r.prefill(PROMPT)
+    n = len(PROMPT)
+    assert r.kv_cache_len() == n
+    assert np.array_equal(lg.view(np.uint32), ref[n - 1].view(np.uint32))
+    # decoding continues from the prefilled cache
+    for i, t in enumerate([21, 22]):
+        assert np.array_equal(r.forward(t, n + i).view(np.uint32), ref[n + i].view(np.uint32)), f"step {i} after prefill"
+    assert kv_equal(r, orr, model, n + 2, kv_f16)
+
+
+def test_prefill_15m_shape_head_dim_48_strict(ca):
+    """tinyllamas-15M geometry: head_dim 48, rope_dim 48, dim 288 (k not a multiple of 256)."""
+    model = synth.build_model(synth.SHAPES["15m"], synth.Q8_0, seed=82)
+    ref, orr = oracle_run(model, True, PROMPT)
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    assert np.array_equal(r.prefill(PROMPT).view(np.uint32), ref[-1].view(np.uint32))
+    assert kv_equal(r, orr, model, len(PROMPT), True)
+
+
+def test_prefill_in_two_calls_and_after_decode_steps(ca):
+    """prefill appends at the current KV length (base_pos = kv_cache_len(), llama2.rs:124): forward, prefill, forward,
+    prefill again -- the same cache and logits as one token loop."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=83)
+    toks = PROMPT + [40, 41, 42, 43, 44]
+    ref, orr = oracle_run(model, True, toks)
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    r.forward(toks[0], 0)
+    lg = r.prefill(toks[1:18])
+    assert np.array_equal(lg.view(np.uint32), ref[17].view(np.uint32))
+    assert np.array_equal(r.forward(toks[18], 18).view(np.uint32), ref[18].view(np.uint32))
+    lg = r.prefill(toks[19:])
+    assert np.array_equal(lg.view(np.uint32), ref[-1].view(np.uint32))
+    assert r.kv_cache_len() == len(toks)
+    assert kv_equal(r, orr, model, len(toks), True)
+
+
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0"])
+def test_prefill_fast_on_the_matrix_cores(ca, fmt):
+    """23 rows >= 16: q/k/v, wo, gate/up, down run as MFMA GEMMs.  Logits within the fast-mode tolerance of the oracle;
+    the greedy continuation equals the one after a fast token loop over the same prompt."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=84)
+    ref, _ = oracle_run(model, True, PROMPT)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    lg = a.prefill(PROMPT)
+    # fast-mode bound of tests/test_hip_fused.py: median 3e-2, max 1e-1 of max|logit| (one chaotic 126-vs-127 flip of
+    # the truncating Q8_0 quantizer, buf_q8_0.rs:119-124, moves a whole block)
+    err = np.max(np.abs(lg - ref[-1])) / np.max(np.abs(ref[-1]))
+    assert err <= 1e-1, err
+    b = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    for i, t in enumerate(PROMPT):
+        lb = b.forward(t, i)
+    assert np.max(np.abs(lg - lb)) / np.max(np.abs(lb)) <= 1e-1
+    nxt = int(np.argmax(ref[-1]))
+    ta, tb = list(a.decode_greedy(nxt, 8)), list(b.decode_greedy(nxt, 8))
+    assert a.kv_cache_len() == b.kv_cache_len() == len(PROMPT) + 8
+    assert ta[0] == tb[0]
+
+
+def test_prefill_rejects_bad_input(ca):
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=85)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 16, True)
+    with pytest.raises(Exception):
+        r.prefill([])  # "expected at least 1 prompt token" (llama2.rs:117-122)
+    with pytest.raises(Exception):
+        r.prefill([1] * 17)  # does not fit the cache
+    with pytest.raises(Exception):
+        r.prefill([model.shape.vocab_size])  # token out of range
+    assert r.kv_cache_len() == 0
+    r.prefill([1, 2, 3])
+    assert r.kv_cache_len() == 3
