@@ -226,6 +226,18 @@ class HipTensor {
     device_->check(crabml_hip_copy_rows_from(device_->raw(), buf_.get(), src.buf_.get(), cols, rows.data(), rows.size()));
   }
 
+  // Tensor::dequantize (api.rs:26; cpu_tensor.rs:135-151): an f32 copy of a stored-format tensor, rows dequantized
+  // exactly as copy_rows_from does
+  HipTensor dequantize(GGMLType dtype) const {
+    if (dtype != GGMLType::F32) throw Error(ErrorKind::NotImplemented, "dequantize: only to F32");
+    if (strider_.dims() != 1 && strider_.dims() != 2) throw Error(ErrorKind::TensorError, "dequantize: tensor is not 2d or 1d");
+    HipTensor out = alloc(shape(), GGMLType::F32, device_);
+    std::vector<size_t> rows(strider_.dims() == 2 ? shape()[0] : 1);
+    for (size_t i = 0; i < rows.size(); i++) rows[i] = i;
+    out.copy_rows_from(*this, rows);
+    return out;
+  }
+
   // ---- compute -----------------------------------------------------------------------------------
   HipTensor rope_inplace(RopeMode mode, size_t pos, size_t rope_dims) const {  // rope.rs:10-45
     need_contig("rope");

@@ -8,6 +8,7 @@
 
 #include <chrono>
 
+#include "gguf.hpp"
 #include "hip_llama.hpp"
 #include "hip_tensor.hpp"
 #include "llama2_runner.hpp"
@@ -199,6 +200,10 @@ PYBIND11_MODULE(_host, m) {
       .def_readonly("n_kv_heads", &LlamaConfig::n_kv_heads)
       .def_readonly("vocab_size", &LlamaConfig::vocab_size)
       .def_readonly("seq_len", &LlamaConfig::seq_len)
+      .def_readonly("rms_norm_eps", &LlamaConfig::rms_norm_eps)
+      .def_property_readonly("rope_dim", [](const LlamaConfig& c) -> py::object {
+        return c.rope_dim ? py::object(py::int_(*c.rope_dim)) : py::object(py::none());
+      })
       .def("head_size", &LlamaConfig::head_size)
       .def("kv_dim", &LlamaConfig::kv_dim);
 
@@ -223,6 +228,64 @@ PYBIND11_MODULE(_host, m) {
             else
               w.output_weight = o.cast<HipTensor>();
           });
+
+
+  // ---- GGUF (gguf.hpp: crabml-core/src/gguf.rs + the llama loader of crabml-llama2/src/model.rs) ---------------
+  struct PyValue {
+    static py::object conv(const GGUFValue& x) {
+      switch (x.type) {
+        case GGUFValueType::U8: case GGUFValueType::U16: case GGUFValueType::U32: case GGUFValueType::U64:
+          return py::int_(std::get<uint64_t>(x.v));
+        case GGUFValueType::Bool: return py::bool_(std::get<uint64_t>(x.v) != 0);
+        case GGUFValueType::I8: case GGUFValueType::I16: case GGUFValueType::I32: case GGUFValueType::I64:
+          return py::int_(std::get<int64_t>(x.v));
+        case GGUFValueType::F32: case GGUFValueType::F64: return py::float_(std::get<double>(x.v));
+        case GGUFValueType::String: return py::str(std::get<std::string>(x.v));
+        case GGUFValueType::Array: {
+          py::list l;
+          for (const auto& it : std::get<GGUFArray>(x.v).items) l.append(conv(it));
+          return l;
+        }
+      }
+      return py::none();
+    }
+  };
+  py::class_<GGUFFile, std::shared_ptr<GGUFFile>>(m, "GGUFFile")
+      .def(py::init([](const std::string& path) { return std::make_shared<GGUFFile>(path); }))
+      .def_property_readonly("version", &GGUFFile::version)
+      .def_property_readonly("architecture", &GGUFFile::architecture)
+      .def_property_readonly("alignment", &GGUFFile::alignment)
+      .def_property_readonly("tensor_data_offset", &GGUFFile::tensor_data_offset)
+      .def("metadata",
+           [](const GGUFFile& g) {
+             py::dict d;
+             for (const auto& kv : g.metadata()) d[py::str(kv.first)] = PyValue::conv(kv.second);
+             return d;
+           })
+      .def("metadata_type",
+           [](const GGUFFile& g, const std::string& key) -> py::object {
+             auto it = g.metadata().find(key);
+             if (it == g.metadata().end()) return py::none();
+             return py::int_((uint32_t)it->second.type);
+           })
+      .def("tensor_infos",
+           [](const GGUFFile& g) {
+             py::list l;
+             for (const auto& t : g.tensor_infos())
+               l.append(py::make_tuple(t.name, t.dimensions, t.ggml_type, t.offset, t.data_len));
+             return l;
+           })
+      .def("tensor_data",
+           [](const GGUFFile& g, const std::string& name) {
+             const GGUFTensorInfo* t = g.get_tensor_info(name);
+             if (!t) throw Error(ErrorKind::TensorNotFound, "failed to find tensor " + name);
+             return py::bytes((const char*)t->data, t->data_len);
+           })
+      .def("load_config", [](const GGUFFile& g) { return load_llama_config(g); })
+      .def("load_weights", [](const GGUFFile& g, const LlamaConfig& conf, std::shared_ptr<HipTensorDevice> dev) {
+        py::gil_scoped_release rel;
+        return load_llama_weights(g, conf, dev);
+      });
 
   py::class_<TpComm, std::shared_ptr<TpComm>>(m, "TpComm")
       .def_static("unique_id",

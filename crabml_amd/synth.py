@@ -223,3 +223,85 @@ def to_hip(model: RawModel, device):
                           n_kv_heads=s.n_kv_heads, vocab_size=s.vocab, seq_len=s.seq_len, rms_norm_eps=s.rms_eps,
                           rope_dim=s.rope_dim)
     return conf, w
+
+
+# ---- GGUF container writer (test / tool side of crabml_amd/csrc/host/gguf.hpp) ----------------------------------------
+# Layout per crabml-core/src/gguf.rs:499-566 (header + metadata), :632-646 (tensor infos), :722-724 (data alignment):
+# lengths are u32 in v1 and u64 in v2 / v3; tensor dims are stored innermost-first (model.rs:473-475 reverses them).
+_GGUF_T = {"u8": 0, "i8": 1, "u16": 2, "i16": 3, "u32": 4, "i32": 5, "f32": 6, "bool": 7, "str": 8, "arr": 9,
+           "u64": 10, "i64": 11, "f64": 12}
+_GGUF_FMT = {"u8": "<B", "i8": "<b", "u16": "<H", "i16": "<h", "u32": "<I", "i32": "<i", "f32": "<f", "bool": "<B",
+             "u64": "<Q", "i64": "<q", "f64": "<d"}
+
+
+def write_gguf(model: RawModel, path: str, version: int = 3, alignment: int = 32, write_alignment_key=None,
+               extra_kv=None, tensor_order=None) -> None:
+    """Serialize a RawModel as a llama-architecture GGUF file.  write_alignment_key: None = omit general.alignment
+    (readers assume 32), or a value-type name ("u32", "u64", "i32", ...) to store `alignment` under that type.
+    extra_kv: list of (key, type_name, value); arrays as (key, "arr", (elem_type_name, [values]))."""
+    import struct
+
+    s = model.shape
+
+    def wlen(n):
+        return struct.pack("<I" if version == 1 else "<Q", n)
+
+    def wstr(x):
+        b = x.encode("utf-8")
+        return wlen(len(b)) + b
+
+    def wval(t, v):
+        if t == "str":
+            return wstr(v)
+        if t == "arr":
+            et, items = v
+            return struct.pack("<I", _GGUF_T[et]) + wlen(len(items)) + b"".join(wval(et, i) for i in items)
+        return struct.pack(_GGUF_FMT[t], v)
+
+    kv = [("general.architecture", "str", "llama"), ("general.name", "str", s.name),
+          ("llama.context_length", "u32", s.seq_len), ("llama.embedding_length", "u32", s.dim),
+          ("llama.block_count", "u32", s.n_layers), ("llama.feed_forward_length", "u32", s.hidden),
+          ("llama.attention.head_count", "u32", s.n_heads), ("llama.attention.head_count_kv", "u32", s.n_kv_heads),
+          ("llama.attention.layer_norm_rms_epsilon", "f32", s.rms_eps)]
+    if s.rope_dim is not None:
+        kv.append(("llama.rope.dimension_count", "u32", s.rope_dim))
+    kv += [("tokenizer.ggml.model", "str", "llama"),
+           ("tokenizer.ggml.tokens", "arr", ("str", [f"<{i}>" for i in range(s.vocab)])),
+           ("tokenizer.ggml.bos_token_id", "u32", 1), ("tokenizer.ggml.eos_token_id", "u32", 2)]
+    if write_alignment_key is not None:
+        kv.append(("general.alignment", write_alignment_key, alignment))
+    kv += list(extra_kv or [])
+    names = tensor_order or list(model.tensors.keys())
+    out = struct.pack("<II", 0x46554747, version) + wlen(len(names)) + wlen(len(kv))
+    for k, t, v in kv:
+        out += wstr(k) + struct.pack("<I", _GGUF_T[t]) + wval(t, v)
+    infos = b""
+    off = 0
+    offsets = []
+    for n in names:
+        t = model.tensors[n]
+        offsets.append(off)
+        infos += wstr(n) + struct.pack("<I", len(t.shape))
+        for d in reversed(t.shape):
+            infos += struct.pack("<I" if version == 1 else "<Q", d)
+        infos += struct.pack("<IQ", t.typ, off)
+        off += (len(t.data) + alignment - 1) // alignment * alignment
+    out += infos
+    pos = len(out)
+    pad = pos - (pos % alignment) + alignment - pos  # gguf.rs:722-724: a whole extra block when already aligned
+    with open(path, "wb") as f:
+        f.write(out)
+        f.write(b"\0" * pad)
+        for n, o in zip(names, offsets):
+            t = model.tensors[n]
+            f.write(t.data.tobytes())
+            f.write(b"\0" * ((len(t.data) + alignment - 1) // alignment * alignment - len(t.data)))
+
+
+def load_gguf_hip(path: str, device):
+    """(LlamaConfig, LlamaWeights<HipTensor>) of a llama GGUF file through the C++ loader (gguf.hpp)."""
+    import crabml_amd as ca
+
+    gf = ca.GGUFFile(path)
+    conf = gf.load_config()
+    return conf, gf.load_weights(conf, device)
