@@ -56,6 +56,7 @@ def parse():
                     help="measure ONE rank of a tensor-parallel group of this size with its all-reduces skipped "
                          "(per-rank kernel time; not a tokens/s result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the batched-prefill measurement")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self test of the rank aggregation")
     return ap.parse_args()
@@ -319,6 +320,30 @@ def main():
                           "same command are committed under profiles/",
             }
 
+    # ---- batched prefill of a 512-token prompt (crabml_hip_llama_prefill), reported next to the decode number ------
+    prefill = None
+    if rank == 0 and path == "fused" and not args.no_prefill:
+        try:
+            n_p = 512
+            pr = ca.HipLlamaRunner(conf, weights, dev, n_p + 8, True)
+            toks = [(7 * i + 1) % shape.vocab for i in range(n_p)]
+            best = None
+            for _ in range(2):
+                pr.reset()
+                dev.sync()
+                tp0 = time.perf_counter()
+                pr.prefill(toks)  # blocks: returns the last token's logits
+                dtp = time.perf_counter() - tp0
+                best = dtp if best is None else min(best, dtp)
+            prefill = {"prompt_tokens": n_p, "rows_per_pass": 512, "ms": round(best * 1e3, 2),
+                       "prompt_tokens_per_s": round(n_p / best, 1),
+                       "vs_token_loop": round(n_p / best / (total_tokens / elapsed_max / args.gpus), 2),
+                       "note": "llama2.rs:124-129 token loop as (rows, k) matmul_vec passes on the int8 MFMA GEMM + causal "
+                               "attention; host clock around the blocking call, best of 2"}
+            del pr
+        except Exception as e:
+            prefill = {"error": repr(e)}
+
     out = None
     if rank == 0:
         tps = total_tokens / elapsed_max
@@ -346,6 +371,8 @@ def main():
             out["INVALID"] = "layer count truncated with --layers (debug run)"
         if roof:
             out["roofline"] = roof
+        if prefill:
+            out["prefill"] = prefill
         if not args.no_cpu_baseline and args.gpus == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, args.cpu_seconds)

@@ -24,6 +24,9 @@ LIB = os.path.join(HERE, "libcrabml_hip.so")
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-function", "-Wno-unused-result"]
+# per-file: the MFMA GEMM keeps its accumulators in VGPRs (gfx950's register file is unified; the AGPR form costs a
+# v_accvgpr_read/write per accumulator register and block: 32 of 137 VALU instructions per k-block)
+EXTRA_FLAGS = {"gemm_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(target: str, deps) -> bool:
@@ -50,7 +53,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for out in ex.map(_run, jobs):

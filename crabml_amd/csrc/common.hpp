@@ -21,6 +21,7 @@ namespace crabml_hip {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- GGML block geometry (crabml-core/src/cpu/buf/buf_q*.rs) ---------------------------------
 inline size_t block_elems(uint32_t t) {

@@ -2286,7 +2286,7 @@ int crabml_hip_llama_prefill(crabml_hip_llama_t* c, const uint32_t* tokens, size
     for (size_t i = 0; i < n; i++) CH_TRY(crabml_hip_llama_forward(c, tokens[i], c->kv_len, i + 1 == n ? logits : nullptr));
     return 0;
   }
-  const size_t chunk = c->cfg.prefill_chunk ? c->cfg.prefill_chunk : 512;  // 8B shape: 3.2k / 5.7k / 9.2k / 12.6k prompt tok/s at 64 / 128 / 256 / 512
+  const size_t chunk = c->cfg.prefill_chunk ? c->cfg.prefill_chunk : 512;  // 8B shape: 9.0k / 11.8k / 15.3k prompt tok/s at 128 / 256 / 512 rows
   CH_TRY(prefill_alloc(c, chunk));
   for (size_t i = 0; i < n; i += chunk) {
     const size_t B = n - i < chunk ? n - i : chunk;

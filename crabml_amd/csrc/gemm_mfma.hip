@@ -15,6 +15,8 @@
 //         elements 16+4g..16+4g+3 (buf_q4_0.rs:24-33); the -8 offset is applied as -8 * sum(x) per block (exact);
 //   Q8_0: lane group g takes elements [8g, 8g+8).
 // D: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15.
+#include <type_traits>
+
 #include "devutil.hpp"
 #include "gemv_core.hpp"
 #include "kernels.hpp"
@@ -27,35 +29,46 @@ namespace crabml_hip {
 // buffer behind a single barrier per chunk.  LDS rows are [block][row or column][RW words] with RW = 4 (Q4_0
 // quants) or 12 (8 data words + 4 pad): staging writes are 16-byte vectors and a wave's fragment reads (lane =
 // (i, g): words g / 4 + g, or 2g / 2g + 1, of row i) hit every bank exactly twice.
-template <int FMT>
+template <int FMT, int NT>  // NT column tiles of 16 batch rows per workgroup (4, or 2 when the grid would not fill the chip)
 struct GemmGeo {
+  static constexpr int CW = 16 * NT;                               // batch rows per workgroup
   static constexpr int KC = 4;                                     // blocks per chunk (37 KB of LDS per workgroup: 4 workgroups per CU)
   static constexpr int APC = FMT == CRABML_HIP_Q4_0 ? 1 : 2;       // 16-byte pieces per weight block
   static constexpr int ARW = FMT == CRABML_HIP_Q4_0 ? 4 : 12;      // LDS words per weight block row
   static constexpr int BRW = 12;                                   // LDS words per activation block row
-  static constexpr int A_WORDS = KC * 64 * ARW, B_WORDS = KC * 64 * BRW;
-  // one buffer: A quants | B quants | A scales f16 [KC][64] | B scales f16 [KC][64] | B isum i32 [KC][64]
-  static constexpr int BUF_BYTES = (A_WORDS + B_WORDS) * 4 + KC * 64 * 2 * 2 + KC * 64 * 4;
+  static constexpr int A_WORDS = KC * 64 * ARW, B_WORDS = KC * CW * BRW;
+  // one buffer: A quants | B quants | A scales f32 [KC][64] | B scales f32 [KC][64] (converted from f16 once, by the
+  // staging threads, instead of once per wave and block)
+  static constexpr int BUF_BYTES = (A_WORDS + B_WORDS) * 4 + KC * 64 * 4 * 2;
   static constexpr int LDS_BYTES = 2 * BUF_BYTES;
-  static constexpr int A_LOADS = 64 * KC * APC / 256, B_LOADS = 64 * KC * 2 / 256, S_LOADS = 64 * KC / 256;
+  static constexpr int A_LOADS = 64 * KC * APC / 256, B_LOADS = CW * KC * 2 / 256, S_LOADS = 64 * KC / 256;
 };
 
-template <int FMT>
+template <int FMT, int NT>
 __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, const unsigned short* __restrict__ wd,
                                                    const char* __restrict__ act, size_t act_stride, size_t off_d, size_t off_aux,
                                                    float* __restrict__ out, int m, int nb, int b, int row_tiles) {
-  using G = GemmGeo<FMT>;
-  constexpr int KC = G::KC, APC = G::APC, ARW = G::ARW, BRW = G::BRW;
+  using G = GemmGeo<FMT, NT>;
+  constexpr int KC = G::KC, APC = G::APC, ARW = G::ARW, BRW = G::BRW, CW = G::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = (blockIdx.x % row_tiles) * 64, c0 = (blockIdx.x / row_tiles) * 64;
+  const int r0 = (blockIdx.x % row_tiles) * 64, c0 = (blockIdx.x / row_tiles) * CW;
   const int i = lane & 15, g = lane >> 4;
 
-  // staging registers of one chunk
-  i32x4 ra[G::A_LOADS], rb[G::B_LOADS];
-  unsigned short rad[G::S_LOADS], rbd[G::S_LOADS];
-  int rbs[G::S_LOADS];
-  auto fetch = [&](int kb0) {
+  // staging registers: PF chunks in flight (a k-chunk's global loads are issued PF - 1 iterations before they are
+  // committed to LDS: with one chunk of slack a workgroup's serial chain of nb / KC chunks ran at the HBM round trip
+  // per chunk -- 4096 x 14336 took the same 134 us for 64 and for 256 batch rows)
+  constexpr int PF = 2;
+  struct Stage {
+    i32x4 ra[G::A_LOADS], rb[G::B_LOADS];
+    unsigned short rad[G::S_LOADS], rbd[G::S_LOADS];
+  };
+  Stage stg[PF];
+  auto fetch = [&](auto SET, int kb0) {
+    auto& ra = stg[decltype(SET)::value].ra;
+    auto& rb = stg[decltype(SET)::value].rb;
+    auto& rad = stg[decltype(SET)::value].rad;
+    auto& rbd = stg[decltype(SET)::value].rbd;
 #pragma unroll
     for (int u = 0; u < G::A_LOADS; u++) {
       const int t = tid + 256 * u, row = t / (KC * APC), rem = t % (KC * APC), kb = rem / APC, pc = rem % APC;
@@ -78,15 +91,17 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
       const char* ap = act + (size_t)gcol * act_stride;
       rad[u] = wd[(size_t)grow * nb + gkb];
       rbd[u] = ((const unsigned short*)(ap + off_d))[gkb];
-      rbs[u] = ((const int*)(ap + off_aux))[gkb];
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](auto SET, int buf) {
+    auto& ra = stg[decltype(SET)::value].ra;
+    auto& rb = stg[decltype(SET)::value].rb;
+    auto& rad = stg[decltype(SET)::value].rad;
+    auto& rbd = stg[decltype(SET)::value].rbd;
     unsigned* sA = (unsigned*)(lds_raw + (size_t)buf * G::BUF_BYTES);
     unsigned* sB = sA + G::A_WORDS;
-    unsigned short* sAd = (unsigned short*)(sB + G::B_WORDS);
-    unsigned short* sBd = sAd + KC * 64;
-    int* sBs = (int*)(sBd + KC * 64);
+    float* sAd = (float*)(sB + G::B_WORDS);
+    float* sBd = sAd + KC * 64;
 #pragma unroll
     for (int u = 0; u < G::A_LOADS; u++) {
       const int t = tid + 256 * u, row = t / (KC * APC), rem = t % (KC * APC), kb = rem / APC, pc = rem % APC;
@@ -95,88 +110,115 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
 #pragma unroll
     for (int u = 0; u < G::B_LOADS; u++) {
       const int t = tid + 256 * u, col = t / (KC * 2), rem = t % (KC * 2), kb = rem / 2, pc = rem % 2;
-      *(i32x4*)(sB + (kb * 64 + col) * BRW + pc * 4) = rb[u];
+      *(i32x4*)(sB + (kb * CW + col) * BRW + pc * 4) = rb[u];
     }
 #pragma unroll
     for (int u = 0; u < G::S_LOADS; u++) {
       const int t = tid + 256 * u, rc = t / KC, kb = t % KC;
-      sAd[kb * 64 + rc] = rad[u];
-      sBd[kb * 64 + rc] = rbd[u];
-      sBs[kb * 64 + rc] = rbs[u];
+      sAd[kb * 64 + rc] = h2f(rad[u]);
+      sBd[kb * 64 + rc] = h2f(rbd[u]);
     }
   };
 
-  float F[4][4];
+  // accumulators as f32 pairs: the block scaling runs on v_pk_mul_f32 / v_pk_add_f32 (same IEEE operations, two
+  // rows per instruction)
+  f32x2 F[NT][2];
 #pragma unroll
-  for (int jt = 0; jt < 4; jt++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) F[jt][r] = 0.0f;
+  for (int jt = 0; jt < NT; jt++) F[jt][0] = F[jt][1] = f32x2{0.0f, 0.0f};
 
-  fetch(0);
-  commit(0);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  const int nchunks = (nb + KC - 1) / KC;
+  // every fetch / commit below is unconditional (chunk indices past the end are clamped: they re-read the last
+  // chunk and are never multiplied): with a fixed number of loads per iteration the compiler's s_waitcnt vmcnt(n)
+  // before a commit waits for exactly the loads of that chunk; with conditional fetches it fell back to waiting
+  // for everything in flight, i.e. one HBM round trip per chunk
+  const int last = (nchunks - 1) * KC;
+  fetch(S0{}, 0);
+  commit(S0{}, 0);
+  fetch(S1{}, KC < last ? KC : last);
+  if constexpr (PF == 3) fetch(S2{}, 2 * KC < last ? 2 * KC : last);
   __syncthreads();
-  int buf = 0;
-  for (int kb0 = 0; kb0 < nb; kb0 += KC, buf ^= 1) {
-    const int kc = nb - kb0 < KC ? nb - kb0 : KC;
-    const bool more = kb0 + KC < nb;
-    if (more) fetch(kb0 + KC);  // in flight while this chunk is multiplied
+  // per-lane LDS offsets (words), constant over the k loop: the block index only adds immediates
+  const int a_off = (16 * wave + i) * ARW + (FMT == CRABML_HIP_Q4_0 ? g : 2 * g);
+  const int ad_off = 16 * wave + 4 * g;
+  // iteration c: request chunk c + PF into the set chunk c used, multiply chunk c (LDS buffer c & 1), commit chunk
+  // c + 1 (requested two iterations ago) to the other buffer, barrier
+  auto step = [&](auto SET_C, auto SET_N, int c) {
+    const int kb0 = c * KC, buf = c & 1;
+    const int kc = c >= nchunks ? 0 : nb - kb0 < KC ? nb - kb0 : KC;
+    fetch(SET_C, (c + PF) * KC < last ? (c + PF) * KC : last);
     const unsigned* sA = (const unsigned*)(lds_raw + (size_t)buf * G::BUF_BYTES);
     const unsigned* sB = sA + G::A_WORDS;
-    const unsigned short* sAd = (const unsigned short*)(sB + G::B_WORDS);
-    const unsigned short* sBd = sAd + KC * 64;
-    const int* sBs = (const int*)(sBd + KC * 64);
-    for (int kb = 0; kb < kc; kb++) {
+    const float* sAd = (const float*)(sB + G::B_WORDS);
+    const float* sBd = sAd + KC * 64;
+    auto mul_block = [&](int kb) {
       long A;
-      const unsigned* arow = sA + (kb * 64 + 16 * wave + i) * ARW;
       if (FMT == CRABML_HIP_Q4_0) {
-        const unsigned w = arow[g];
-        A = (long)(((unsigned long long)((w >> 4) & 0x0F0F0F0Fu) << 32) | (unsigned long long)(w & 0x0F0F0F0Fu));
+        // nibbles to signed bytes v - 8 without carries between bytes: ((v | 0x80) - 8) ^ 0x80 per byte, so the
+        // MFMA accumulates the reference's (q - 8) * x directly (buf_q4_0.rs:245-248) and starts from zero
+        const unsigned w = sA[kb * 64 * ARW + a_off];
+        const unsigned lo = (((w & 0x0F0F0F0Fu) | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+        const unsigned hi = ((((w >> 4) & 0x0F0F0F0Fu) | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+        A = (long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
       } else {
-        A = *(const long*)(arow + 2 * g);
+        A = *(const long*)(sA + kb * 64 * ARW + a_off);
       }
-      float dw[4];
-      {
-        const unsigned long long d4 = *(const unsigned long long*)(sAd + kb * 64 + 16 * wave + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; r++) dw[r] = h2f((unsigned short)(d4 >> (16 * r)));
-      }
+      const f32x4 dw4 = *(const f32x4*)(sAd + kb * 64 + ad_off);
+      const f32x2 dw01 = {dw4[0], dw4[1]}, dw23 = {dw4[2], dw4[3]};
       // all four column tiles: fragments first, then the four MFMAs back to back (independent accumulators),
-      // then the scaling -- a single wave per SIMD has nothing else to hide the LDS and MFMA latencies behind
-      long Bf[4];
-      int cin[4];
-      float dx[4];
+      // then the scaling
+      long Bf[NT];
+      float dx[NT];
 #pragma unroll
-      for (int jt = 0; jt < 4; jt++) {
+      for (int jt = 0; jt < NT; jt++) {
         const int col = 16 * jt + i;
-        const unsigned* brow = sB + (kb * 64 + col) * BRW;
+        const unsigned* brow = sB + (kb * CW + col) * BRW;
         if (FMT == CRABML_HIP_Q4_0)
           Bf[jt] = (long)(((unsigned long long)brow[4 + g] << 32) | (unsigned long long)brow[g]);
         else
           Bf[jt] = *(const long*)(brow + 2 * g);
-        // Q4_0: the -8 offset rides in as the accumulator input, -8 * sum(x) of the lane's column (exact)
-        cin[jt] = FMT == CRABML_HIP_Q4_0 ? -8 * sBs[kb * 64 + col] : 0;
-        dx[jt] = h2f(sBd[kb * 64 + col]);
+        dx[jt] = sBd[kb * 64 + col];
       }
-      i32x4 D[4];
+      i32x4 D[NT];
 #pragma unroll
-      for (int jt = 0; jt < 4; jt++)
-        D[jt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bf[jt], i32x4{cin[jt], cin[jt], cin[jt], cin[jt]}, 0, 0, 0);
+      for (int jt = 0; jt < NT; jt++) D[jt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bf[jt], i32x4{0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
-      for (int jt = 0; jt < 4; jt++)
+      for (int jt = 0; jt < NT; jt++) {
+        const f32x2 c01 = {(float)D[jt][0], (float)D[jt][1]}, c23 = {(float)D[jt][2], (float)D[jt][3]};
+        const f32x2 dxx = {dx[jt], dx[jt]};
+        F[jt][0] += (c01 * dw01) * dxx;  // sumf += (sumi as f32 * d_w) * d_x, block after block
+        F[jt][1] += (c23 * dw23) * dxx;
+      }
+    };
+    if (kc == KC) {  // straight-line: the scheduler may start block kb + 1's LDS reads under block kb's scaling
 #pragma unroll
-        for (int r = 0; r < 4; r++) F[jt][r] += ((float)D[jt][r] * dw[r]) * dx[jt];
+      for (int kb = 0; kb < KC; kb++) mul_block(kb);
+    } else {  // ragged k, or an iteration past the end (kc = 0)
+      for (int kb = 0; kb < kc; kb++) mul_block(kb);
     }
-    if (more) commit(buf ^ 1);  // the other buffer was last read one iteration ago (barrier below)
+    commit(SET_N, buf ^ 1);  // that buffer was last read one iteration ago (barrier below)
     __syncthreads();
+  };
+  for (int c = 0; c < nchunks; c += PF) {
+    if constexpr (PF == 3) {
+      step(S0{}, S1{}, c);
+      step(S1{}, S2{}, c + 1);
+      step(S2{}, S0{}, c + 2);
+    } else {
+      step(S0{}, S1{}, c);
+      step(S1{}, S0{}, c + 1);
+    }
   }
 #pragma unroll
-  for (int jt = 0; jt < 4; jt++) {
+  for (int jt = 0; jt < NT; jt++) {
     const int col = c0 + 16 * jt + i;
     if (col >= b) continue;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = r0 + 16 * wave + g * 4 + r;
-      if (row < m) out[(size_t)col * m + row] = F[jt][r];
+      if (row < m) out[(size_t)col * m + row] = F[jt][r >> 1][r & 1];
     }
   }
 }
@@ -190,15 +232,28 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
   const char* wp = (const char*)w->ptr;
   const ActLayout al = act_layout(CRABML_HIP_Q8_0, k);
   const int nb = (int)(k / 32);
-  const int row_tiles = (int)((m + 63) / 64), col_tiles = (int)((b + 63) / 64);
-  if (w->dtype == CRABML_HIP_Q4_0)
-    launch_k(st, rec, k_gemm_mfma<CRABML_HIP_Q4_0>, dim3(row_tiles * col_tiles), dim3(256), GemmGeo<CRABML_HIP_Q4_0>::LDS_BYTES, wp,
-             (const unsigned short*)(wp + w->wl.off_scale), (const char*)act, al.total, al.off_d, al.off_aux, out, (int)m, nb, (int)b,
-             row_tiles);
-  else
-    launch_k(st, rec, k_gemm_mfma<CRABML_HIP_Q8_0>, dim3(row_tiles * col_tiles), dim3(256), GemmGeo<CRABML_HIP_Q8_0>::LDS_BYTES, wp,
-             (const unsigned short*)(wp + w->wl.off_scale), (const char*)act, al.total, al.off_d, al.off_aux, out, (int)m, nb, (int)b,
-             row_tiles);
+  const int row_tiles = (int)((m + 63) / 64);
+  // 64-column tiles amortize a weight tile over more batch rows; when that grid leaves the chip under-occupied
+  // (m = 4096: 64 row tiles) 32-column tiles double the workgroups per CU -- the k loop is latency-bound per wave
+  const bool narrow = (size_t)row_tiles * ((b + 63) / 64) < (size_t)4 * dev->n_cu && b > 16;
+  const int cw = narrow ? 32 : 64;
+  const int col_tiles = (int)((b + cw - 1) / cw);
+  const unsigned short* wd = (const unsigned short*)(wp + w->wl.off_scale);
+#define CRABML_GEMM_LAUNCH(F, N)                                                                                              \
+  launch_k(st, rec, k_gemm_mfma<F, N>, dim3(row_tiles * col_tiles), dim3(256), GemmGeo<F, N>::LDS_BYTES, wp, wd, (const char*)act, \
+           al.total, al.off_d, al.off_aux, out, (int)m, nb, (int)b, row_tiles)
+  if (w->dtype == CRABML_HIP_Q4_0) {
+    if (narrow)
+      CRABML_GEMM_LAUNCH(CRABML_HIP_Q4_0, 2);
+    else
+      CRABML_GEMM_LAUNCH(CRABML_HIP_Q4_0, 4);
+  } else {
+    if (narrow)
+      CRABML_GEMM_LAUNCH(CRABML_HIP_Q8_0, 2);
+    else
+      CRABML_GEMM_LAUNCH(CRABML_HIP_Q8_0, 4);
+  }
+#undef CRABML_GEMM_LAUNCH
   return true;
 }
 
