@@ -797,6 +797,232 @@ __global__ __launch_bounds__(128) void k_gemv_res(Planes w, typename ActOf<FMT>:
     if (lane == 0 && row0 + r < m) x[row0 + r] = ADD ? s + res[r] : s;
   }
 }
+
+// ---- batched-prefill attention: one workgroup = one kv head x R consecutive prompt rows x the G q heads of its
+// group (Q = G * R queries).  Per (row, head) the arithmetic is k_attn's, value for value -- f32 dots in k order,
+// softmax_row's table exp / sequential row sum (rows up to 1024 positions; longer prompts use k_attn) / true
+// division, the f16 PV chain in position order -- but a K row is fetched once for the Q queries that score against
+// it and a V element once for the Q / (256 / hd) chains a thread carries, instead of once per (row, head) workgroup:
+// the per-row kernel moved 2.1 GB through L2 per layer for 512 prompt rows of the 8B shape.
+template <bool KV16, int G, int R>
+__global__ __launch_bounds__(256) void k_attn_tile(const float* __restrict__ q, const void* __restrict__ kc,
+                                                   const void* __restrict__ vc, const int* __restrict__ pos_d,
+                                                   const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
+                                                   int n_heads, int n_kv, int hd, int seq_cap, int n_rows, int sstride) {
+  constexpr int Q = G * R;
+  extern __shared__ float lds[];
+  float* qs = lds;            // [Q][hd]: q rows (rounded to f16 for the f16 cache, batch_matmul.rs:39)
+  float* sc = lds + Q * hd;   // [Q][sstride]: scores, then probabilities
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kvh = blockIdx.x, r0 = blockIdx.y * R;
+  const int pos0 = *pos_d;
+  const int dim = n_heads * hd;
+  auto head_of = [&](int j) { return KV16 ? kvh * G + j : kvh + j * n_kv; };  // batch_matmul.rs:61-67 GQA maps
+  const int rows_here = n_rows - r0 < R ? n_rows - r0 : R;
+  for (int e = tid; e < Q * hd; e += 256) {  // query qi = r * G + j
+    const int qi = e / hd, i = e - qi * hd, r = qi / G, j = qi - r * G;
+    const float v = r < rows_here ? q[(size_t)(r0 + r) * dim + head_of(j) * hd + i] : 0.0f;
+    qs[e] = KV16 ? h2f(f2h(v)) : v;
+  }
+  __syncthreads();
+  // ---- scores + softmax: wave w owns the QW = Q / 4 queries w * QW .. (one prompt row: its causal length bounds the
+  // loop), lane = cached position; a K row is fetched once per wave and scored against the wave's queries
+  constexpr int QW = Q / 4;
+  static_assert(Q % 4 == 0 && (G % QW == 0 || QW % G == 0), "a wave's queries belong to one row");
+  {
+    const int q0 = wave * QW, rw = q0 / G;
+    if (rw < rows_here) {
+      const int seq = pos0 + r0 + rw + 1;
+      for (int t = lane; t < seq; t += 64) {
+        float acc[QW];
+#pragma unroll
+        for (int u = 0; u < QW; u++) acc[u] = 0.0f;
+        if (KV16) {
+          const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
+          for (int i = 0; i < hd; i += 16) {  // hd % 16 == 0 (host check); products added in k order per query
+            const i32x4 k0 = *(const i32x4*)(kr + i), k1 = *(const i32x4*)(kr + i + 8);
+            float kf[16];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              kf[2 * u] = h2f((unsigned short)((unsigned)k0[u] & 0xffffu));
+              kf[2 * u + 1] = h2f((unsigned short)((unsigned)k0[u] >> 16));
+              kf[8 + 2 * u] = h2f((unsigned short)((unsigned)k1[u] & 0xffffu));
+              kf[8 + 2 * u + 1] = h2f((unsigned short)((unsigned)k1[u] >> 16));
+            }
+#pragma unroll
+            for (int u = 0; u < QW; u++) {
+              const f32x4* qp = (const f32x4*)(qs + (q0 + u) * hd + i);
+#pragma unroll
+              for (int v4 = 0; v4 < 4; v4++) {
+                const f32x4 qv = qp[v4];
+                acc[u] += qv[0] * kf[4 * v4];
+                acc[u] += qv[1] * kf[4 * v4 + 1];
+                acc[u] += qv[2] * kf[4 * v4 + 2];
+                acc[u] += qv[3] * kf[4 * v4 + 3];
+              }
+            }
+          }
+        } else {
+          const float* kr = (const float*)kc + ((size_t)kvh * seq_cap + t) * hd;
+          for (int i = 0; i < hd; i += 4) {
+            const f32x4 kv = *(const f32x4*)(kr + i);
+#pragma unroll
+            for (int u = 0; u < QW; u++) {
+              const f32x4 qv = *(const f32x4*)(qs + (q0 + u) * hd + i);
+              acc[u] += qv[0] * kv[0];
+              acc[u] += qv[1] * kv[1];
+              acc[u] += qv[2] * kv[2];
+              acc[u] += qv[3] * kv[3];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < QW; u++) sc[(q0 + u) * sstride + t] = acc[u];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      // softmax per query (softmax.rs:36-54; softmax_row with the <= 1024 sequential row sum), by the same wave; the
+      // QW sequential row sums (one dependent v_add chain each) run interleaved
+#pragma unroll
+      for (int u = 0; u < QW; u++) {
+        float* srow = sc + (q0 + u) * sstride;
+        float mx = -INFINITY;
+        for (int t = lane; t < seq; t += 64) mx = fmaxf(mx, srow[t]);
+        mx = wave_max_f32(mx);
+        for (int t = lane; t < seq; t += 64) srow[t] = exp_cached_f(srow[t] - mx, exp_tab);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      float sum[QW];
+#pragma unroll
+      for (int u = 0; u < QW; u++) sum[u] = 0.0f;
+      for (int base = 0; base < seq; base += 64) {
+        float v[QW];
+#pragma unroll
+        for (int u = 0; u < QW; u++) v[u] = base + lane < seq ? sc[(q0 + u) * sstride + base + lane] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+#pragma unroll
+          for (int u = 0; u < QW; u++) sum[u] += rl_f(v[u], i);  // lanes past `seq` add +0.0 (exact)
+      }
+#pragma unroll
+      for (int u = 0; u < QW; u++) {
+        float* srow = sc + (q0 + u) * sstride;
+        for (int t = lane; t < seq; t += 64) {
+          const float pv = srow[t] / sum[u];
+          if (KV16) {  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), stored as the pair {p, p} the PV chains multiply by
+            const unsigned h = (unsigned)f2h(pv);
+            ((unsigned*)srow)[t] = h | (h << 16);
+          } else {
+            srow[t] = pv;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- out[qi][n] = sum_t p[qi][t] * V[t][n].  f16 cache: thread = (pair of columns, query group), the chains run on
+  // v_pk_mul_f16 / v_pk_add_f16 (per half exactly the scalar product-round, sum-round of buf_f16.rs:152-163); a V
+  // pair feeds every chain the thread carries.  f32 cache: thread = (column, query group), plain f32.
+  constexpr int QS = Q / 2 > 0 ? Q / 2 : 1;  // chains per thread (>= 2 query groups); unused slots have lim = 0
+  const int tpg = KV16 ? hd / 2 : hd;      // threads per query group
+  const int ngrp = 256 / tpg;
+  const int n = tid % tpg, grp = tid / tpg;
+  if (grp >= ngrp) return;  // ngrp >= 2 (host check), so Q / 2 chain slots cover the Q queries
+  const int ch = (Q + ngrp - 1) / ngrp;  // consecutive queries per group: normally the heads of ONE row (same length)
+  int lim[QS];
+  const float* prow[QS];
+  int lim_lo = 0x7fffffff, lim_hi = 0;
+#pragma unroll
+  for (int s2 = 0; s2 < QS; s2++) {
+    const int qi = grp * ch + s2;
+    const bool live = s2 < ch && qi < Q && qi / G < rows_here;
+    lim[s2] = live ? pos0 + r0 + qi / G + 1 : 0;
+    prow[s2] = sc + (live ? qi : 0) * sstride;
+    if (live) {
+      lim_lo = lim[s2] < lim_lo ? lim[s2] : lim_lo;
+      lim_hi = lim[s2] > lim_hi ? lim[s2] : lim_hi;
+    }
+  }
+  if (lim_hi == 0) return;
+  if (KV16) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const unsigned* vr = (const unsigned*)((const unsigned short*)vc + (size_t)kvh * seq_cap * hd) + n;
+    const int vs = hd / 2;  // dwords per V row
+    h2v c[QS];
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) c[s2] = h2v{(_Float16)0.0f, (_Float16)0.0f};
+    // the common case: every chain of the thread has the same causal length (one row) and QS / 2 live chains
+    const bool uniform = lim_lo == lim_hi;
+    int t0 = 0;
+    if (uniform) {
+      for (; t0 + 4 <= lim_hi; t0 += 4) {
+        unsigned vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vv[u] = vr[(size_t)(t0 + u) * vs];
+#pragma unroll
+        for (int s2 = 0; s2 < QS; s2++) {
+          if (lim[s2]) {  // thread-constant
+            // four {p, p} pairs, read as scalars (element extraction from a freshly loaded ext-vector feeding
+            // bit_casts was miscompiled here: every element became element 0)
+            const unsigned* pq = (const unsigned*)prow[s2] + t0;
+            unsigned pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pp[u] = pq[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const h2v prod = __builtin_bit_cast(h2v, vv[u]) * __builtin_bit_cast(h2v, pp[u]);
+              c[s2] = c[s2] + prod;
+            }
+          }
+        }
+      }
+    }
+    for (; t0 < lim_hi; t0++) {  // tail / mixed lengths
+      const h2v vp = __builtin_bit_cast(h2v, vr[(size_t)t0 * vs]);
+#pragma unroll
+      for (int s2 = 0; s2 < QS; s2++) {
+        if (t0 < lim[s2]) {
+          const h2v prod = vp * __builtin_bit_cast(h2v, ((const unsigned*)prow[s2])[t0]);
+          c[s2] = c[s2] + prod;
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) {
+      const int qi = grp * ch + s2;
+      if (lim[s2]) {
+        float* o = out + (size_t)(r0 + qi / G) * dim + head_of(qi % G) * hd + 2 * n;
+        o[0] = (float)c[s2][0];
+        o[1] = (float)c[s2][1];
+      }
+    }
+  } else {
+    const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
+    float c[QS];
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) c[s2] = 0.0f;
+    for (int t0 = 0; t0 < lim_hi; t0 += 8) {
+      float vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) vv[u] = t0 + u < lim_hi ? vr[(size_t)(t0 + u) * hd] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + u;
+#pragma unroll
+        for (int s2 = 0; s2 < QS; s2++) {
+          if (t < lim[s2]) c[s2] += prow[s2][t] * vv[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) {
+      const int qi = grp * ch + s2;
+      if (lim[s2]) out[(size_t)(r0 + qi / G) * dim + head_of(qi % G) * hd + n] = c[s2];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_res_epi(const float* __restrict__ tmp, float* __restrict__ x, int m, int add) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) x[i] = add ? tmp[i] + x[i] : tmp[i];
@@ -1849,6 +2075,42 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   return 0;
 }
 
+
+// the row-tiled causal attention of a prefill pass; false = not covered (the caller launches k_attn per (head, row))
+template <bool KV16, int G, int R>
+bool launch_attn_tile_t(crabml_hip_llama* c, int l, int B, int pos0) {
+  const int hd = c->hd, n_heads = c->n_heads_l, n_kv = c->n_kv_l, seq_cap = (int)c->cfg.seq_len;
+  const int sstride = (pos0 + B + 3) & ~3;
+  const size_t lds = (size_t)(G * R) * (size_t)(hd + sstride) * sizeof(float);
+  if (lds > 64 * 1024) return false;
+  k_attn_tile<KV16, G, R><<<dim3(n_kv, (B + R - 1) / R), 256, lds, c->dev->stream>>>(
+      c->pf_qr, c->kc[l], c->vc[l], c->state + 6, (const unsigned short*)c->dev->exp_table, c->pf_attn, n_heads, n_kv, hd, seq_cap, B,
+      sstride);
+  return true;
+}
+bool launch_attn_tile(crabml_hip_llama* c, int l, int B, int pos0) {
+  const int hd = c->hd, g = c->n_heads_l / c->n_kv_l;
+  const bool kv16 = c->cfg.use_f16_kv_cache != 0;
+  if (c->cfg.flags & CRABML_HIP_LLAMA_NO_TILE_ATTENTION) return false;
+  if (pos0 + B > 1024 || hd > (kv16 ? 256 : 128) || hd % (kv16 ? 16 : 4) != 0 || c->n_heads_l % c->n_kv_l != 0) return false;
+  if (kv16) {
+    switch (g) {
+      case 1: return launch_attn_tile_t<true, 1, 4>(c, l, B, pos0);
+      case 2: return launch_attn_tile_t<true, 2, 4>(c, l, B, pos0);
+      case 4: return launch_attn_tile_t<true, 4, 4>(c, l, B, pos0);
+      case 8: return launch_attn_tile_t<true, 8, 2>(c, l, B, pos0);
+      default: return false;
+    }
+  }
+  switch (g) {
+    case 1: return launch_attn_tile_t<false, 1, 4>(c, l, B, pos0);
+    case 2: return launch_attn_tile_t<false, 2, 4>(c, l, B, pos0);
+    case 4: return launch_attn_tile_t<false, 4, 4>(c, l, B, pos0);
+    case 8: return launch_attn_tile_t<false, 8, 2>(c, l, B, pos0);
+    default: return false;
+  }
+}
+
 int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t pos0, bool want_logits) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
@@ -1895,15 +2157,17 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int pairs = (dim + 2 * kv_dim) / 2;
     k_qkv_epi_rows<<<dim3((pairs + 255) / 256, rows), 256, 0, st>>>(c->pf_q, c->pf_k, c->pf_v, e);
-    const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
-    if (kv16)
-      k_attn<true><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
-                                                                c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
-                                                                PrefetchPlan{}, 0);
-    else
-      k_attn<false><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
-                                                                 c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
-                                                                 PrefetchPlan{}, 0);
+    if (!launch_attn_tile(c, l, (int)B, (int)pos0)) {  // long prompts / unusual shapes: one workgroup per (head, row)
+      const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
+      if (kv16)
+        k_attn<true><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
+                                                                  c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
+                                                                  PrefetchPlan{}, 0);
+      else
+        k_attn<false><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
+                                                                   c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
+                                                                   PrefetchPlan{}, 0);
+    }
     a = quant_rows(c->pf_attn, dim, c->pf_act_dim);
     CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp));  // llama2.rs:600
     k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);  // :266
@@ -2286,7 +2550,7 @@ int crabml_hip_llama_prefill(crabml_hip_llama_t* c, const uint32_t* tokens, size
     for (size_t i = 0; i < n; i++) CH_TRY(crabml_hip_llama_forward(c, tokens[i], c->kv_len, i + 1 == n ? logits : nullptr));
     return 0;
   }
-  const size_t chunk = c->cfg.prefill_chunk ? c->cfg.prefill_chunk : 512;  // 8B shape: 9.0k / 11.8k / 15.3k prompt tok/s at 128 / 256 / 512 rows
+  const size_t chunk = c->cfg.prefill_chunk ? c->cfg.prefill_chunk : 512;  // 8B shape: 12.6k / 17.2k prompt tok/s at 256 / 512 rows
   CH_TRY(prefill_alloc(c, chunk));
   for (size_t i = 0; i < n; i += chunk) {
     const size_t B = n - i < chunk ? n - i : chunk;

@@ -126,3 +126,33 @@ def test_prefill_rejects_bad_input(ca):
     assert r.kv_cache_len() == 0
     r.prefill([1, 2, 3])
     assert r.kv_cache_len() == 3
+
+
+@pytest.mark.parametrize("n_heads,n_kv", [(8, 8), (8, 4), (8, 2), (8, 1)])
+@pytest.mark.parametrize("kv_f16", [False, True])
+def test_row_tiled_attention_equals_the_per_row_kernel(ca, n_heads, n_kv, kv_f16):
+    """Prefill attention runs as one workgroup per (kv head, 4-row tile) carrying the G = n_heads / n_kv queries of each
+    row (k_attn_tile); per (row, head) it is k_attn's arithmetic, so the pass is bit-identical to the per-row kernel
+    (flag 2048 = NO_TILE_ATTENTION), for every group size, both cache types, ragged tiles and a non-zero base position."""
+    shape = synth.ModelShape(f"g{n_heads // n_kv}", 512, 1024, 2, n_heads, n_kv, 1024, 64)
+    model = synth.build_model(shape, synth.Q8_0, seed=86)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16)
+    b = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16, extra_flags=2048)
+    for r in (a, b):
+        r.forward(3, 0)
+        r.forward(4, 1)
+    la, lb = a.prefill(PROMPT), b.prefill(PROMPT)  # 23 rows at base position 2: five full tiles + a ragged one
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    la, lb = a.prefill([9, 8, 7]), b.prefill([9, 8, 7])  # a short second pass (one ragged tile)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    s = model.shape
+    es = 2 if kv_f16 else 4
+    filled = a.kv_cache_len() * s.head_dim * es
+    for layer in range(s.n_layers):
+        for which in (False, True):
+            ka, kb = a.debug_kv(layer, which, kv_f16), b.debug_kv(layer, which, kv_f16)
+            for h in range(s.n_kv_heads):
+                lo = h * 64 * s.head_dim * es
+                assert np.array_equal(ka[lo:lo + filled], kb[lo:lo + filled]), (layer, which, h)
