@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-norm-epilogue", action="store_true", help="A/B: keep RMSNorm+quantize as its own launch")
     ap.add_argument("--flags", type=int, default=0, help="extra CRABML_HIP_LLAMA_* flags for A/B runs")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: disable Infinity-Cache weight prefetch")
+    ap.add_argument("--tp", action="store_true",
+                    help="WORLD_SIZE > 1: the ranks form ONE tensor-parallel group (RCCL all-reduce after wo / ffn_down) that "
+                         "decodes a single token stream, instead of independent replicas; meant for --model llama3-70b")
     ap.add_argument("--tp-dry", type=int, default=0,
                     help="measure ONE rank of a tensor-parallel group of this size with its all-reduces skipped "
                          "(per-rank kernel time; not a tokens/s result)")
@@ -197,6 +200,54 @@ def tp_dry_run(args, ca, synth, local):
     }))
 
 
+def tp_group_run(args, ca, synth, dist, rank, world, local):
+    """--tp under torchrun: one tensor-parallel group over all ranks (BASELINE config 5).  Every rank
+    builds the LOCAL shard shapes with the same seed (identical bytes on every rank: a consistent model whose shards
+    happen to be equal, so all ranks sample the same tokens), creates the RCCL communicator from rank 0's unique id
+    (shipped over the torch.distributed group that also provides the barrier) and decodes with 2 all-reduces per layer."""
+    from crabml_amd import tp as tp_mod
+
+    shape = synth.SHAPES[args.model]
+    wtype = synth.TYPE_BY_NAME[args.wtype]
+    tp_mod.check_tp(shape, world, wtype, True)
+    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=world)
+    dev = ca.HipTensorDevice(device_ordinal=local)
+    conf, weights = synth.to_hip(model, dev)
+    comm = tp_mod.init_tp_comm(dev, rank, world, tp_mod.torch_broadcast(rank))
+    seq_len = args.warmup + args.steps + 16
+    r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=world, tp_rank=rank, comm=comm,
+                          extra_flags=args.flags)
+    tok = int(r.decode_greedy(1, args.warmup)[-1]) if args.warmup > 0 else 1
+    dev.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    r.decode_greedy(tok, args.steps)
+    dev.sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, _ = dist.max_sum(elapsed, args.steps)
+    if rank == 0:
+        local_bytes = sum(t.data.nbytes for name, t in model.tensors.items()
+                          if not name.endswith("_norm.weight") and name != "token_embd.weight")
+        tps = args.steps / elapsed_max  # ONE token stream for the whole group
+        print(json.dumps({
+            "metric": f"decode tokens/sec (batch-1 greedy), {shape.name} shape {args.wtype}, tensor-parallel over {world} GPUs",
+            "value": round(tps, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.wtype, "data": "synthetic",
+            "config": {"workload": f"{shape.name}-shape all-{args.wtype} synthetic weights, one batch-1 greedy token stream, f16 KV cache, "
+                                   f"positions {args.warmup}..{args.warmup + args.steps - 1}",
+                       "parallelism": f"tp{world}", "all_reduces_per_token": 2 * conf.n_layers, "all_reduce_bytes": shape.dim * 4,
+                       "rank_weight_bytes_per_token": local_bytes},
+            "roofline": {"bound": "hbm", "achieved": round(tps * local_bytes / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(tps * local_bytes / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "per-rank effective weight bandwidth over the whole step (kernels + all-reduces), not one kernel"},
+        }), flush=True)
+    del r
+    del comm
+    dist.close()
+
+
 def main():
     args = parse()
     if args.selftest_dist:
@@ -211,6 +262,8 @@ def main():
 
     if args.tp_dry > 1:
         return tp_dry_run(args, ca, synth, local)
+    if args.tp and world > 1:
+        return tp_group_run(args, ca, synth, dist, rank, world, local)
     shape = synth.SHAPES[args.model]
     wtype = synth.TYPE_BY_NAME[args.wtype]
     t_build = time.perf_counter()
