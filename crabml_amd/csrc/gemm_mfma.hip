@@ -52,7 +52,23 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
   constexpr int KC = G::KC, APC = G::APC, ARW = G::ARW, BRW = G::BRW, CW = G::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = (blockIdx.x % row_tiles) * 64, c0 = (blockIdx.x / row_tiles) * CW;
+  // Tile order.  Workgroup b runs on XCD b % 8 and the eight L2s do not share: all column tiles of a weight row tile
+  // must sit on ONE XCD, back to back, or every column tile re-fetches the weights (rocprofv3 FETCH_SIZE: 294 MB per
+  // 35 MB gate/up GEMM with column-major tile order).  XCD x owns the row tiles rt = x (mod 8); its j-th workgroup
+  // is (rt = 8 (j / col_tiles) + x, ct = j % col_tiles).  The activation tiles (8 x 295 KB) stay L2-resident.
+  int rt, ct;
+  {
+    const int col_tiles = (int)gridDim.x / row_tiles;
+    if ((row_tiles & 7) == 0) {
+      const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+      ct = j % col_tiles;
+      rt = (j / col_tiles) * 8 + x;
+    } else {
+      rt = (int)blockIdx.x % row_tiles;
+      ct = (int)blockIdx.x / row_tiles;
+    }
+  }
+  const int r0 = rt * 64, c0 = ct * CW;
   const int i = lane & 15, g = lane >> 4;
 
   // staging registers: PF chunks in flight (a k-chunk's global loads are issued PF - 1 iterations before they are
