@@ -1085,13 +1085,145 @@ __device__ __forceinline__ unsigned long long ld_granule(const unsigned long lon
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows); QIN (Q4_K): the rhs is the f32 vector xin
+// The tail of the wo / ffn_down kernels (k_gemv_res_nq, k_ffn): acc[] = this wave's RW row dots.  Publishes the
+// workgroup's rows / sum of squares, takes the one in-launch hop, normalizes + quantizes the rows it owns.
+// wg_index / nwg_all: this workgroup's index among the SPLIT * nchunks workgroups of the stage.
+template <int FMT, int SPLIT>
+__device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
+                                            float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
+                                            void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
+                                            int row, int lane, int wave, int wg_index, int nwg_all) {
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  constexpr bool KQ = FMT == CRABML_HIP_Q4_K;
+  constexpr int RW = 2 / SPLIT;
+  constexpr int ROWS = 32 / SPLIT;
+  // ---- epilogue: publish, one in-launch hop, normalize + quantize -------------------------------------------
+  // every row goes out as a {value, epoch} granule when another workgroup needs it (the partner of a split chunk;
+  // the seven neighbours of a Q8_K super-block), the workgroup's ordered sum of squares as one more
+  constexpr bool ROWG = SPLIT > 1 || KQ;
+#pragma unroll
+  for (int r = 0; r < RW; r++) {
+    const float s = wave_sum_f32(acc[r]);
+    if (lane == 0) hv[part * ROWS + wave * RW + r] = s;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // wave 0 owns the stores: ROWS consecutive rows per instruction (x and the row granules are one or two lines,
+  // not 32 separate partial writes from 16 waves)
+  if (lane < ROWS) {
+    const float xv = hv[part * ROWS + lane] + res;  // x = matmul_out + x (llama2.rs:266 / :636)
+    x[row + lane] = xv;
+    hv[part * ROWS + lane] = xv;
+    if (ROWG)
+      __hip_atomic_store(ng.pair + row + lane, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // sum of squares of a chunk = (rows 0..15 in order) + (rows 16..31 in order): a split chunk's two workgroups
+  // each own one half (norm_quant_block<HALF> computes the same)
+  float cs;
+  {
+    float h0 = -0.0f, h1 = -0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const f32x4 t = ((const f32x4*)hv)[(SPLIT > 1 ? part * 4 : 0) + j];
+      h0 += t[0] * t[0];
+      h0 += t[1] * t[1];
+      h0 += t[2] * t[2];
+      h0 += t[3] * t[3];
+    }
+    if (SPLIT == 1) {
+#pragma unroll
+      for (int j = 4; j < 8; j++) {
+        const f32x4 t = ((const f32x4*)hv)[j];
+        h1 += t[0] * t[0];
+        h1 += t[1] * t[1];
+        h1 += t[2] * t[2];
+        h1 += t[3] * t[3];
+      }
+      cs = h0 + h1;
+    } else {
+      cs = h0;
+    }
+  }
+  if (lane == 0)
+    __hip_atomic_store(ng.slots + wg_index, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granule is on its way before the polls queue up behind it
+  auto poll = [&](const unsigned long long* p) -> float {
+    unsigned long long g = ld_granule(p);
+    int tries = 0;
+    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+      __builtin_amdgcn_s_sleep(2);
+      g = ld_granule(p);
+      tries++;
+    }
+    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+    return __builtin_bit_cast(float, (unsigned)g);
+  };
+  // the rows of other workgroups first (published before their sums; the loads fly while the stragglers arrive) ...
+  const int l32 = lane & 31;
+  const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
+  const int sb = blk >> 3;
+  float v = 0.0f;
+  f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (KQ) {
+    const unsigned long long* p = ng.pair + sb * 256 + lane * 4;
+    unsigned long long g[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) g[i] = ld_granule(p + i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v4[i] = (unsigned)(g[i] >> 32) == epoch ? __builtin_bit_cast(float, (unsigned)g[i]) : poll(p + i);
+  } else if (SPLIT > 1) {
+    if (lane < 32) v = own ? hv[l32] : poll(ng.pair + blk * 32 + l32);
+  } else {
+    v = hv[l32];
+  }
+  // ... then the hop: every workgroup's sum, added strictly in chunk order
+  float sum = 0.0f;
+  const int nwg = nwg_all;
+  for (int base = 0; base < nwg; base += 64) {
+    const int c = base + lane;
+    float cv = c < nwg ? poll(ng.slots + c) : 0.0f;
+    if (SPLIT > 1) cv += dpp_f<0xB1>(cv);  // chunk = its two halves (the same value on both lanes of the pair)
+#pragma unroll
+    for (int i = 0; i < 64; i += SPLIT) sum += rl_f(cv, i);  // lanes past the grid add +0.0
+  }
+  const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
+  if constexpr (!KQ) {
+    const float xn = (v / rms) * wn;
+    const QLane o = quant_lane32<Q81>(xn, true);
+    if (lane < 32 && own) {
+      q[blk * 32 + lane] = o.q;
+      if (lane == 0) {
+        ((unsigned short*)d)[blk] = o.d;
+        store_qaux<Q81>(isum, blk, o.aux);
+      }
+    }
+  } else {
+    // Q8_K (buf_q8_k.rs:84-131): the scale comes from the FIRST element of maximal |x| of the 256-element
+    // super-block = this chunk and its 7 neighbours.  The wave holds the super-block's 256 rows (4 per lane, from
+    // their granules), normalizes them all and runs the whole block's quantizer; it stores the part that is its own.
+    f32x4 xn;
+#pragma unroll
+    for (int i = 0; i < 4; i++) xn[i] = (v4[i] / rms) * wn4[i];
+    const Q8KLane o = q8k_wave_quant(xn, lane);
+    const int l0 = (blk & 7) * 8 + part * (ROWS / 4);
+    if (lane >= l0 && lane < l0 + ROWS / 4) {
+      ((unsigned*)q)[sb * 64 + lane] = o.packed;
+      if ((lane & 3) == 0) ((short*)isum)[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
+    }
+    if (lane == 0 && (blk & 7) == 0 && part == 0) ((float*)d)[sb] = o.d;
+  }
+}
+
 template <int FMT, int SPLIT, bool QIN = false>
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
                                                       signed char* __restrict__ q, void* __restrict__ d,
                                                       void* __restrict__ isum, NormGather ng, int nb) {
-  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
@@ -1170,125 +1302,8 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       }
     }
   }
-  // ---- epilogue: publish, one in-launch hop, normalize + quantize -------------------------------------------
-  // every row goes out as a {value, epoch} granule when another workgroup needs it (the partner of a split chunk;
-  // the seven neighbours of a Q8_K super-block), the workgroup's ordered sum of squares as one more
-  constexpr bool ROWG = SPLIT > 1 || KQ;
-#pragma unroll
-  for (int r = 0; r < RW; r++) {
-    const float s = wave_sum_f32(acc[r]);
-    if (lane == 0) hv[part * ROWS + wave * RW + r] = s;
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  // wave 0 owns the stores: ROWS consecutive rows per instruction (x and the row granules are one or two lines,
-  // not 32 separate partial writes from 16 waves)
-  if (lane < ROWS) {
-    const float xv = hv[part * ROWS + lane] + res;  // x = matmul_out + x (llama2.rs:266 / :636)
-    x[row + lane] = xv;
-    hv[part * ROWS + lane] = xv;
-    if (ROWG)
-      __hip_atomic_store(ng.pair + row + lane, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // sum of squares of a chunk = (rows 0..15 in order) + (rows 16..31 in order): a split chunk's two workgroups
-  // each own one half (norm_quant_block<HALF> computes the same)
-  float cs;
-  {
-    float h0 = -0.0f, h1 = -0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const f32x4 t = ((const f32x4*)hv)[(SPLIT > 1 ? part * 4 : 0) + j];
-      h0 += t[0] * t[0];
-      h0 += t[1] * t[1];
-      h0 += t[2] * t[2];
-      h0 += t[3] * t[3];
-    }
-    if (SPLIT == 1) {
-#pragma unroll
-      for (int j = 4; j < 8; j++) {
-        const f32x4 t = ((const f32x4*)hv)[j];
-        h1 += t[0] * t[0];
-        h1 += t[1] * t[1];
-        h1 += t[2] * t[2];
-        h1 += t[3] * t[3];
-      }
-      cs = h0 + h1;
-    } else {
-      cs = h0;
-    }
-  }
-  if (lane == 0)
-    __hip_atomic_store(ng.slots + blockIdx.x, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granule is on its way before the polls queue up behind it
-  auto poll = [&](const unsigned long long* p) -> float {
-    unsigned long long g = ld_granule(p);
-    int tries = 0;
-    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
-      __builtin_amdgcn_s_sleep(2);
-      g = ld_granule(p);
-      tries++;
-    }
-    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
-    return __builtin_bit_cast(float, (unsigned)g);
-  };
-  // the rows of other workgroups first (published before their sums; the loads fly while the stragglers arrive) ...
-  const int l32 = lane & 31;
-  const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
-  const int sb = blk >> 3;
-  float v = 0.0f;
-  f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (KQ) {
-    const unsigned long long* p = ng.pair + sb * 256 + lane * 4;
-    unsigned long long g[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) g[i] = ld_granule(p + i);
-#pragma unroll
-    for (int i = 0; i < 4; i++) v4[i] = (unsigned)(g[i] >> 32) == epoch ? __builtin_bit_cast(float, (unsigned)g[i]) : poll(p + i);
-  } else if (SPLIT > 1) {
-    if (lane < 32) v = own ? hv[l32] : poll(ng.pair + blk * 32 + l32);
-  } else {
-    v = hv[l32];
-  }
-  // ... then the hop: every workgroup's sum, added strictly in chunk order
-  float sum = 0.0f;
-  const int nwg = (int)gridDim.x;
-  for (int base = 0; base < nwg; base += 64) {
-    const int c = base + lane;
-    float cv = c < nwg ? poll(ng.slots + c) : 0.0f;
-    if (SPLIT > 1) cv += dpp_f<0xB1>(cv);  // chunk = its two halves (the same value on both lanes of the pair)
-#pragma unroll
-    for (int i = 0; i < 64; i += SPLIT) sum += rl_f(cv, i);  // lanes past the grid add +0.0
-  }
-  const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
-  if constexpr (!KQ) {
-    const float xn = (v / rms) * wn;
-    const QLane o = quant_lane32<Q81>(xn, true);
-    if (lane < 32 && own) {
-      q[blk * 32 + lane] = o.q;
-      if (lane == 0) {
-        ((unsigned short*)d)[blk] = o.d;
-        store_qaux<Q81>(isum, blk, o.aux);
-      }
-    }
-  } else {
-    // Q8_K (buf_q8_k.rs:84-131): the scale comes from the FIRST element of maximal |x| of the 256-element
-    // super-block = this chunk and its 7 neighbours.  The wave holds the super-block's 256 rows (4 per lane, from
-    // their granules), normalizes them all and runs the whole block's quantizer; it stores the part that is its own.
-    f32x4 xn;
-#pragma unroll
-    for (int i = 0; i < 4; i++) xn[i] = (v4[i] / rms) * wn4[i];
-    const Q8KLane o = q8k_wave_quant(xn, lane);
-    const int l0 = (blk & 7) * 8 + part * (ROWS / 4);
-    if (lane >= l0 && lane < l0 + ROWS / 4) {
-      ((unsigned*)q)[sb * 64 + lane] = o.packed;
-      if ((lane & 3) == 0) ((short*)isum)[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
-    }
-    if (lane == 0 && (blk & 7) == 0 && part == 0) ((float*)d)[sb] = o.d;
-  }
+  nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
+                          (int)gridDim.x);
 }
 
 // ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
@@ -1381,6 +1396,206 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typenam
     }
   }
 }
+// ---- gate/up + SiLU*mul + quantize + ffn_down + residual + next RMSNorm/quantize in ONE launch ----------------------
+// EXPERIMENT, opt-in (CRABML_HIP_LLAMA_FFN_FUSION): measured 27.5-28.7 us against 12.9 + 0.8 + 10.7 us for the two
+// kernels it replaces on the 8B shape ("measured and rejected"), bit-identical to them.
+// The two halves of the FFN are k_gateup_q and k_gemv_res_nq<FMT, 2> back to back; what the single launch was meant
+// to buy is the boundary between them: ffn_down's first weight loads are requested BEFORE its workgroup waits for h,
+// so the HBM round trip of the stream's head runs under the hand-off instead of after a kernel boundary.  h never touches a
+// plane in global memory: every 32-row block goes out as 8 {4 quants, epoch} granules + 1 {d | aux, epoch} granule
+// (aux = the block's quant sum for Q8_0 -- |sum| <= 4096 fits 16 bits -- or s for Q8_1), and every workgroup polls
+// all of them (hidden/4 + hidden/32 relaxed agent-scope loads, 4 per thread) into its own LDS copy of the planes.
+// Grid = dim/16 workgroups of 1024 threads, all resident (the norm-epilogue condition); workgroup b owns the
+// hidden blocks b and b + grid (the latter when it exists) and, for ffn_down, half of chunk b / 2.
+struct HGather {
+  unsigned long long* hq;  // hidden/4 granules
+  unsigned long long* hs;  // hidden/32 granules
+};
+template <class F, int NB, class ACT>
+__device__ __forceinline__ void ffn_gateup_rows(const Planes& wg, const Planes& wu, const ACT& act, int nb, int lane,
+                                                const int (&row)[NB], float (&g)[NB][2], float (&u2)[NB][2]) {
+#pragma unroll
+  for (int k = 0; k < NB; k++) g[k][0] = g[k][1] = u2[k][0] = u2[k][1] = 0.f;
+  const int nu = nb * F::UNITS;
+  // two units per row in flight (one workgroup per CU: the loads have to supply the parallelism; with one unit per
+  // iteration a wave paid an HBM round trip per iteration and the phase streamed at 3.3 TB/s); terms in block order
+  for (int u = lane; u < nu; u += 128) {
+    const int ub = u + 64;
+    const bool two = ub < nu;
+    const int uu = two ? ub : u;
+    typename F::Blk bg[NB][2][2], bu[NB][2][2];
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        bg[k][r][0] = F::load(wg.q, wg.d, (size_t)(row[k] + r), nb, u);
+        bu[k][r][0] = F::load(wu.q, wu.d, (size_t)(row[k] + r), nb, u);
+        bg[k][r][1] = F::load(wg.q, wg.d, (size_t)(row[k] + r), nb, uu);
+        bu[k][r][1] = F::load(wu.q, wu.d, (size_t)(row[k] + r), nb, uu);
+      }
+    const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        g[k][r] += F::term(bg[k][r][0], xa);
+        u2[k][r] += F::term(bu[k][r][0], xa);
+      }
+    if (two) {
+#pragma unroll
+      for (int k = 0; k < NB; k++)
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          g[k][r] += F::term(bg[k][r][1], xb);
+          u2[k][r] += F::term(bu[k][r][1], xb);
+        }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      g[k][r] = wave_sum_f32(g[k][r]);
+      u2[k][r] = wave_sum_f32(u2[k][r]);
+    }
+}
+template <int FMT>
+__global__ __launch_bounds__(1024) void k_ffn(Planes wg, Planes wu, Planes wdn, typename ActOf<FMT>::type act,
+                                              const unsigned short* __restrict__ exp_tab, float* __restrict__ x,
+                                              const float* __restrict__ wnext, float eps, signed char* __restrict__ q,
+                                              void* __restrict__ d, void* __restrict__ isum, NormGather ng, HGather hg, int nb_in,
+                                              int nblk_h, int off_d, int off_aux) {
+  using F = BlockFmt<FMT>;
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  extern __shared__ i32x4 lds_h[];  // phase B: h's activation planes, act_layout order
+  __shared__ __attribute__((aligned(16))) float hv[64];
+  __shared__ __attribute__((aligned(16))) signed char hqb[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = (int)gridDim.x;
+  const unsigned epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
+  // ---- phase A: gate/up rows of this workgroup's hidden blocks (wave w: rows 2w, 2w + 1 of each block)
+  const int b0 = (int)blockIdx.x, b1 = b0 + G;
+  const bool has0 = b0 < nblk_h, has1 = b1 < nblk_h;
+  if (has0) {
+    if (has1) {
+      const int row[2] = {b0 * 32 + wave * 2, b1 * 32 + wave * 2};
+      float g[2][2], u2[2][2];
+      ffn_gateup_rows<F, 2>(wg, wu, act, nb_in, lane, row, g, u2);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+          for (int r = 0; r < 2; r++) hv[k * 32 + wave * 2 + r] = silu_mul(g[k][r], u2[k][r], exp_tab);
+      }
+    } else {
+      const int row[1] = {b0 * 32 + wave * 2};
+      float g[1][2], u2[1][2];
+      ffn_gateup_rows<F, 1>(wg, wu, act, nb_in, lane, row, g, u2);
+      if (lane == 0) {
+        hv[wave * 2] = silu_mul(g[0][0], u2[0][0], exp_tab);
+        hv[wave * 2 + 1] = silu_mul(g[0][1], u2[0][1], exp_tab);
+      }
+    }
+  }
+  __syncthreads();
+  if ((wave == 0 && has0) || (wave == 1 && has1)) {  // wave k quantizes and publishes block k (buf_q8_0.rs:87-134)
+    const int hb = wave == 0 ? b0 : b1;
+    const QLane o = quant_lane32<Q81>(hv[wave * 32 + (lane & 31)], true);
+    if (lane < 32) hqb[wave * 32 + lane] = o.q;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 8)
+      __hip_atomic_store(hg.hq + hb * 8 + lane, ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)hqb)[wave * 8 + lane],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0)
+      __hip_atomic_store(hg.hs + hb, ((unsigned long long)epoch << 32) | (unsigned long long)((unsigned)o.d | (((unsigned)o.aux & 0xffffu) << 16)),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): on their way before this wave starts polling
+  }
+  // ---- phase B set-up: ffn_down row of this wave, its first weight units requested before the hand-off
+  const int blk = (int)blockIdx.x >> 1, part = (int)blockIdx.x & 1;
+  const int nchunks = G >> 1;
+  const int row = blk * 32 + part * 16 + wave;
+  float res = 0.f, wn = 0.f;
+  const f32x4 wn4 = {0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) {
+    if (lane < 16) res = x[row + lane];
+    wn = wnext[blk * 32 + (lane & 31)];
+  }
+  const int nu = nblk_h * F::UNITS;
+  const int ua = lane < nu ? lane : nu - 1, ub = lane + 64 < nu ? lane + 64 : nu - 1;
+  const typename F::Blk ka0 = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, ua);
+  const typename F::Blk kb0 = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, ub);
+  // ---- the hand-off: all of h into this workgroup's LDS planes
+  char* P = (char*)lds_h;
+  auto poll = [&](const unsigned long long* p) -> unsigned {
+    unsigned long long gq = ld_granule(p);
+    int tries = 0;
+    while ((unsigned)(gq >> 32) != epoch && tries < (1 << 21)) {
+      __builtin_amdgcn_s_sleep(2);
+      gq = ld_granule(p);
+      tries++;
+    }
+    if ((unsigned)(gq >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+    return (unsigned)gq;
+  };
+  // every thread requests its (up to 4) quant granules right away -- for the workgroup that arrives last, which
+  // sets the pace, everything is already published and comes back fresh in the same round trip as the scale
+  // granules; wave 0 alone spins on the scale granules (1024 spinning threads per early workgroup would sit on the
+  // memory path the late workgroups are still streaming weights through); stale quant granules are re-polled after
+  const int nq = nblk_h * 8;
+  unsigned long long gq[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = tid + u * 1024;
+    gq[u] = ld_granule(hg.hq + (i < nq ? i : tid));
+  }
+  if (wave == 0) {
+    for (int i = lane; i < nblk_h; i += 64) {
+      const unsigned v = poll(hg.hs + i);
+      ((unsigned short*)(P + off_d))[i] = (unsigned short)(v & 0xffffu);
+      if constexpr (Q81)
+        ((unsigned short*)(P + off_aux))[i] = (unsigned short)(v >> 16);
+      else
+        ((int*)(P + off_aux))[i] = (int)(short)(v >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = tid + u * 1024;
+    if (i < nq) ((unsigned*)P)[i] = (unsigned)(gq[u] >> 32) == epoch ? (unsigned)gq[u] : poll(hg.hq + i);
+  }
+  for (int i = tid + 4 * 1024; i < nq; i += 1024) ((unsigned*)P)[i] = poll(hg.hq + i);  // hidden > 16384 only
+  __syncthreads();
+  // ---- phase B: the ffn_down row against the LDS planes (terms in block order, as k_gemv_res_nq adds them)
+  typename ActOf<FMT>::type la;
+  la.q = (const i32x4*)P;
+  la.d = (const unsigned short*)(P + off_d);
+  if constexpr (Q81)
+    la.s = (const unsigned short*)(P + off_aux);
+  else
+    la.isum = (const int*)(P + off_aux);
+  float acc[1] = {0.f};
+  {
+    const XUnit xa = F::loadx(la, ua), xb = F::loadx(la, ub);
+    if (lane < nu) acc[0] += F::term(ka0, xa);
+    if (lane + 64 < nu) acc[0] += F::term(kb0, xb);
+  }
+  for (int u = lane + 128; u < nu; u += 128) {
+    const int u2 = u + 64;
+    const bool two = u2 < nu;
+    const int uu = two ? u2 : u;
+    const typename F::Blk ka = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, u);
+    const typename F::Blk kb = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, uu);
+    const XUnit xa = F::loadx(la, u), xb = F::loadx(la, uu);
+    acc[0] += F::term(ka, xa);
+    if (two) acc[0] += F::term(kb, xb);
+  }
+  nq_epilogue<FMT, 2>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row - wave, lane, wave,
+                      (int)blockIdx.x, G);
+}
+
 __global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
                                                     const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1531,6 +1746,8 @@ struct crabml_hip_llama {
   float* rope = nullptr;     // [seq_len][npairs][2]
   int* state = nullptr;      // token, pos, step, sink, serial (never reset), fault
   unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
+  unsigned long long* hgran = nullptr;  // fused FFN: hidden/4 quant granules + hidden/32 scale granules of h
+  bool ffn_fused = false;               // gate/up + ffn_down as one launch (k_ffn)
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
   bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
   bool generic = false;      // per-op launches (strict-order device, or a weight format without fused kernels)
@@ -1766,14 +1983,32 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   } else {
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
     if (!norm_epi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
-    // gate / up + silu * mul (llama2.rs:620-630), local rows
-    CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
-    launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
-             act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
-    CH_TRY(P1(&pr));
-    // down (+ residual, llama2.rs:633-636): k = the local hidden slice
-    CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr,
-                    g.rms_norm_eps));
+    const float* wnext_down = (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr;
+    const int split_down = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
+                           : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
+                           : (hidden_l / 32 >= 256 && dim / 32 <= dev->n_cu) ? 2
+                                                                             : 1;
+    if (c->ffn_fused && norm_epi && split_down == 2 && hidden_l / 32 <= 2 * (dim / 16)) {
+      // gate / up + silu * mul + quantize + down + residual + the next rmsnorm / quantize: one launch (k_ffn)
+      NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg};
+      HGather hg{c->hgran, c->hgran + hidden_l / 4};
+      const ActLayout alh = act_layout(qt, (size_t)hidden_l);
+      if (prof)
+        CH_TRY(prof_begin(dev, &pr, c->wtype, 10,
+                          3.0 * hidden_l * (double)dim * blk_b + 4.0 * dim + 4.0 * (2.0 * hidden_l) + 4.0 * hidden_l + 4.0 * dim));
+      launch_k(st, R, k_ffn<FMT>, dim3(dim / 16), dim3(1024), alh.total, planes_of(c->gate[l]), planes_of(c->up[l]),
+               planes_of(c->down[l]), act_view<FMT>(ad), (const unsigned short*)dev->exp_table, c->x, wnext_down, g.rms_norm_eps, ad.q,
+               (void*)ad.d, ad.isum, ng, hg, dim / 32, hidden_l / 32, (int)alh.off_d, (int)alh.off_aux);
+      CH_TRY(P1(&pr));
+    } else {
+      // gate / up + silu * mul (llama2.rs:620-630), local rows
+      CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
+      launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
+               act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
+      CH_TRY(P1(&pr));
+      // down (+ residual, llama2.rs:633-636): k = the local hidden slice
+      CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps));
+    }
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
@@ -2401,6 +2636,10 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   A((g.embedding_dim / 16 + g.embedding_dim) * 8, (void**)&c->slots);
   c->norm_epi = !generic && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
+  c->ffn_fused = c->norm_epi && (g.flags & CRABML_HIP_LLAMA_FFN_FUSION);  // opt-in: measured slower than the two kernels
+  if (c->ffn_fused) {
+    A((hidden_l / 4 + hidden_l / 32) * 8, (void**)&c->hgran);
+  }
   c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
                   !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) && g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
   c->out_cap = (int)g.seq_len;
@@ -2427,6 +2666,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 8 * sizeof(int), dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (g.embedding_dim / 16 + g.embedding_dim) * 8, dev->stream);
+    if (e == hipSuccess && c->hgran) e = hipMemsetAsync(c->hgran, 0, (hidden_l / 4 + hidden_l / 32) * 8, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) {
       crabml_hip_llama_destroy(c);

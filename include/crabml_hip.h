@@ -192,6 +192,7 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                        (default for tp: eager launches; falls back to eager if capture fails) */
 #define CRABML_HIP_LLAMA_NO_KQUANT_FUSION 256 /* A/B: Q4_K / Q4_1 layers through the per-op segment path */
 #define CRABML_HIP_LLAMA_Q4_1_SEGMENTS 512 /* A/B: Q4_1 layers as 11 launches (separate norm / quantize launches) */
+#define CRABML_HIP_LLAMA_FFN_FUSION 4096 /* experiment (slower, off by default): gate/up + ffn_down as one launch (k_ffn) */
 #define CRABML_HIP_LLAMA_NO_TILE_ATTENTION 2048 /* A/B: prefill attention as one workgroup per (head, row) */
 #define CRABML_HIP_LLAMA_NO_RHS_PROLOGUE 1024 /* A/B: Q4_K layers quantize the rhs of wo / ffn_down in its own launch */
 #define CRABML_HIP_LLAMA_TP_DRY_RUN 128 /* measurement hook: a lone tp rank (tp_comm = NULL) steps with its all-reduces

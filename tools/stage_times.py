@@ -21,7 +21,7 @@ ap.add_argument("--pos0", type=int, default=8)
 ap.add_argument("--model", default="llama3-8b")
 ap.add_argument("--wtype", default="Q4_0")
 a = ap.parse_args()
-NAMES = {1: "qkv", 2: "wo+res", 3: "gateup_q", 4: "down+res", 5: "classifier", 6: "norm_quant", 7: "attn|scores", 8: "attn softmax", 9: "attn pv"}
+NAMES = {1: "qkv", 2: "wo+res", 3: "gateup_q", 4: "down+res", 5: "classifier", 6: "norm_quant", 7: "attn|scores", 8: "attn softmax", 9: "attn pv", 10: "ffn (k_ffn)"}
 shape = synth.SHAPES[a.model]
 if a.hidden:
     shape = synth.ModelShape(**{**shape.__dict__, "hidden": a.hidden})
