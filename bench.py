@@ -265,9 +265,10 @@ def main():
     if args.tp and world > 1:
         return tp_group_run(args, ca, synth, dist, rank, world, local)
     shape = synth.SHAPES[args.model]
-    wtype = synth.TYPE_BY_NAME[args.wtype]
+    k_m = args.wtype.upper() == "Q4_K_M"  # llama.cpp's mix: Q4_K body, attn_v / ffn_down in Q6_K on some layers, Q6_K classifier
+    wtype = synth.Q4_K if k_m else synth.TYPE_BY_NAME[args.wtype]
     t_build = time.perf_counter()
-    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers)
+    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, k_m_mix=k_m)
     dev = ca.HipTensorDevice(device_ordinal=local)
     t_upload = time.perf_counter()
     conf, weights = synth.to_hip(model, dev)

@@ -2525,7 +2525,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   if (qt == 0xffffffffu || out_qt == 0xffffffffu)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama: weight dtype %u / classifier dtype %u has no matmul_vec", wt, out_wt);
   // fused kernels exist for Q4_0 / Q8_0 layers (fast mode); everything else runs the per-op segment path
-  const bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0 && wt != CRABML_HIP_Q4_1) || out_wt != wt;
+  bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0 && wt != CRABML_HIP_Q4_1) || out_wt != wt;
   {
     const size_t be = block_elems(wt) > block_elems(qt) ? block_elems(wt) : block_elems(qt);
     const size_t obe = block_elems(out_wt) > block_elems(out_qt) ? block_elems(out_wt) : block_elems(out_qt);
@@ -2535,15 +2535,27 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   auto check = [&](const crabml_hip_buf* b, size_t m, size_t k, uint32_t t) {
     return b && b->dtype == t && b->n_elems == m * k && (block_elems(t) == 1 || b->k == k);
   };
+  // a layer's matrices may differ in GGML type (llama.cpp's *_K_M files: attn_v / ffn_down in Q6_K on some layers) as
+  // long as they share the rhs type (buf/api.rs:142-159: every K-quant takes Q8_K): such a model runs the per-op
+  // segments, each GEMV picking its kernel by the tensor's own dtype
+  bool mixed = false;
+  auto check_w = [&](const crabml_hip_buf* b, size_t m, size_t k) {
+    if (!b) return false;
+    if (b->dtype != wt) {
+      if (vec_dot_rhs_dtype(b->dtype) != qt || k % block_elems(b->dtype)) return false;
+      mixed = true;
+    }
+    return check(b, m, k, b->dtype);
+  };
   for (size_t l = 0; l < g.n_layers; l++) {
-    if (!check(w->wq[l], dim_l, g.embedding_dim, wt) || !check(w->wk[l], kv_dim_l, g.embedding_dim, wt) ||
-        !check(w->wv[l], kv_dim_l, g.embedding_dim, wt) || !check(w->wo[l], g.embedding_dim, dim_l, wt) ||
-        !check(w->ffn_gate_weight[l], hidden_l, g.embedding_dim, wt) ||
-        !check(w->ffn_up_weight[l], hidden_l, g.embedding_dim, wt) ||
-        !check(w->ffn_down_weight[l], g.embedding_dim, hidden_l, wt) ||
+    if (!check_w(w->wq[l], dim_l, g.embedding_dim) || !check_w(w->wk[l], kv_dim_l, g.embedding_dim) ||
+        !check_w(w->wv[l], kv_dim_l, g.embedding_dim) || !check_w(w->wo[l], g.embedding_dim, dim_l) ||
+        !check_w(w->ffn_gate_weight[l], hidden_l, g.embedding_dim) || !check_w(w->ffn_up_weight[l], hidden_l, g.embedding_dim) ||
+        !check_w(w->ffn_down_weight[l], g.embedding_dim, hidden_l) ||
         !check(w->rms_att_weight[l], 1, g.embedding_dim, CRABML_HIP_F32) ||
         !check(w->rms_ffn_weight[l], 1, g.embedding_dim, CRABML_HIP_F32))
-      CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: layer %zu weights have an unexpected dtype/shape (tp=%d)", l, tp);
+      CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED,
+              "llama fused path: layer %zu weights have an unexpected shape, or dtypes that do not share one rhs dtype (tp=%d)", l, tp);
   }
   if (!check(outw, g.vocab_size, g.embedding_dim, out_wt) || !check(w->rms_final_weight, 1, g.embedding_dim, CRABML_HIP_F32) ||
       w->token_embed->n_elems != g.vocab_size * g.embedding_dim)
@@ -2554,9 +2566,10 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->dev = dev;
   c->cfg = g;
   c->wtype = wt;
+  generic = generic || mixed;
   c->generic = generic;
   // Q4_K always; Q4_1 when it cannot take the 5-kernel path (mixed classifier format) or for the A/B flag
-  c->kfused = !dev->strict_order && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
+  c->kfused = !dev->strict_order && !mixed && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
               (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS))));
   c->qt = qt;
   c->out_qt = out_qt;

@@ -156,12 +156,20 @@ class RawModel:
         return total
 
 
+def use_more_bits(i_layer: int, n_layers: int) -> bool:
+    """llama.cpp's rule for the layers whose attn_v / ffn_down tensors get the wider type in the *_K_M mixes."""
+    return i_layer < n_layers // 8 or i_layer >= 7 * n_layers // 8 or (i_layer - n_layers // 8) % 3 == 2
+
+
 def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional[int] = None,
-                embed_type: Optional[int] = None, tp: int = 1, output_type: Optional[int] = None) -> RawModel:
+                embed_type: Optional[int] = None, tp: int = 1, output_type: Optional[int] = None,
+                k_m_mix: bool = False) -> RawModel:
     """All-`wtype` synthetic Llama weights with GGUF tensor names (model.rs:228-283); norms are F32
     (the loader dequantizes them, model.rs:267-282).  tp > 1: the tensors get one rank's LOCAL shard shapes
     (what crabml_amd.tp.shard_model would cut; random bytes either way -- for timing one rank of a large model
-    without materialising all of it)."""
+    without materialising all of it).  k_m_mix (with wtype = Q4_K): the tensor-type recipe of llama.cpp's Q4_K_M
+    files -- attn_v and ffn_down in Q6_K on the `use_more_bits` layers, output.weight in Q6_K -- i.e. different
+    GGML types inside one layer (all with the Q8_K rhs)."""
     rng = np.random.default_rng(seed)
     L = shape.n_layers if n_layers is None else n_layers
     shp = ModelShape(**{**shape.__dict__, "n_layers": L})
@@ -180,16 +188,17 @@ def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional
     for l in range(L):
         add(f"blk.{l}.attn_q.weight", dim_l, shape.dim, wtype)
         add(f"blk.{l}.attn_k.weight", kv_l, shape.dim, wtype)
-        add(f"blk.{l}.attn_v.weight", kv_l, shape.dim, wtype)
+        wide = Q6_K if (k_m_mix and use_more_bits(l, L)) else wtype
+        add(f"blk.{l}.attn_v.weight", kv_l, shape.dim, wide)
         add(f"blk.{l}.attn_output.weight", shape.dim, dim_l, wtype)
         add(f"blk.{l}.ffn_gate.weight", hid_l, shape.dim, wtype)
-        add(f"blk.{l}.ffn_down.weight", shape.dim, hid_l, wtype)
+        add(f"blk.{l}.ffn_down.weight", shape.dim, hid_l, wide)
         add(f"blk.{l}.ffn_up.weight", hid_l, shape.dim, wtype)
         norm(f"blk.{l}.attn_norm.weight", shape.dim)
         norm(f"blk.{l}.ffn_norm.weight", shape.dim)
     norm("output_norm.weight", shape.dim)
     # llama.cpp's "Q4_0" / "Q4_K_M" files keep output.weight in Q6_K: `output_type` builds that mix
-    add("output.weight", shape.vocab, shape.dim, wtype if output_type is None else output_type)
+    add("output.weight", shape.vocab, shape.dim, (Q6_K if k_m_mix else wtype) if output_type is None else output_type)
     return m
 
 

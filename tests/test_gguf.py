@@ -183,3 +183,22 @@ def test_gguf_f16_norm_weight_is_dequantized_on_load(tmp_path):
     b = ca.HipLlamaRunner(conf_b, w_b, dev, 16, True)
     for i, t in enumerate([1, 365, 400]):
         assert np.array_equal(a.forward(t, i).view(np.uint32), b.forward(t, i).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gguf_q4_k_m_mix_round_trip(tmp_path):
+    """A Q4_K_M-style file (per-tensor types differ inside a layer) through the GGUF loader into the fused step."""
+    shape = synth.ModelShape("tiny-gqa-8l", 512, 1024, 8, 8, 2, 1024, 64)
+    model = synth.build_model(shape, synth.Q4_K, seed=94, k_m_mix=True)
+    path = str(tmp_path / "kmix.gguf")
+    synth.write_gguf(model, path)
+    gf = ca.GGUFFile(path)
+    by_name = {i[0]: i[2] for i in gf.tensor_infos()}
+    assert by_name["blk.0.ffn_down.weight"] == synth.Q6_K and by_name["blk.1.ffn_down.weight"] == synth.Q4_K
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf_a, w_a = synth.to_hip(model, dev)
+    conf_b, w_b = synth.load_gguf_hip(path, dev)
+    a = ca.HipLlamaRunner(conf_a, w_a, dev, 32, True)
+    b = ca.HipLlamaRunner(conf_b, w_b, dev, 32, True)
+    for i, t in enumerate([1, 365, 400, 282]):
+        assert np.array_equal(a.forward(t, i).view(np.uint32), b.forward(t, i).view(np.uint32)), f"step {i}"

@@ -343,3 +343,51 @@ def test_q4_1_five_kernel_layers_equal_the_segment_path(ca):
     for i, t in enumerate(int(v) for v in rng.integers(0, 1024, size=24)):
         a, b = five.forward(t, i), segs.forward(t, i)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+
+
+def test_q4_k_m_mix_mixed_dtypes_inside_a_layer(ca):
+    """llama.cpp's Q4_K_M recipe: a Q4_K body with attn_v / ffn_down in Q6_K on the `use_more_bits` layers and a Q6_K
+    classifier -- different GGML types inside one layer, all with the Q8_K rhs (buf/api.rs:142-159).  The fused step
+    runs it as per-op segments (each GEMV picks its kernel by the tensor's dtype): strict device bit-identical to the
+    oracle for decode AND batched prefill, fast device within tolerance of the oracle and of the trait path."""
+    shape = synth.ModelShape("tiny-gqa-8l", 512, 1024, 8, 8, 2, 1024, 64)  # 8 layers: use_more_bits picks 0, 3, 6, 7
+    model = synth.build_model(shape, synth.Q4_K, seed=65, k_m_mix=True)
+    types = {name: t.typ for name, t in model.tensors.items()}
+    assert types["blk.0.attn_v.weight"] == synth.Q6_K and types["blk.1.attn_v.weight"] == synth.Q4_K
+    assert types["blk.3.ffn_down.weight"] == synth.Q6_K and types["blk.3.ffn_up.weight"] == synth.Q4_K
+    assert types["output.weight"] == synth.Q6_K
+    toks = PROMPT + [7, 9]
+    ref, _ = oracle_logits(model, True, toks)
+    sdev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, sdev)
+    r = ca.HipLlamaRunner(conf, w, sdev, 64, True)
+    for i, t in enumerate(toks):
+        assert np.array_equal(r.forward(t, i).view(np.uint32), ref[i].view(np.uint32)), f"step {i}"
+    p = ca.HipLlamaRunner(conf, w, sdev, 64, True)
+    assert np.array_equal(p.prefill(toks).view(np.uint32), ref[-1].view(np.uint32))
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    fast = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    trait = ca.Llama2Runner(conf, w, dev, 64, True)
+    got = []
+    for i, t in enumerate(toks):
+        a, b = fast.forward(t, i), np.asarray(trait.forward([t], i))
+        # (not bit-equal: the fast step sums the RMSNorm chunks as 16 + 16 halves, the trait op in the reference's order)
+        assert np.max(np.abs(a - b)) <= 3e-2 * np.max(np.abs(b)), f"fused vs trait, step {i}"
+        got.append(a.copy())
+    err = rel_errs(got, ref)
+    assert np.median(err) <= 3e-2 and np.max(err) <= 1e-1, err
+
+
+def test_layer_dtypes_with_different_rhs_types_are_rejected(ca):
+    """Q4_0 (rhs Q8_0) and Q6_K (rhs Q8_K) inside one layer do not share an activation format: loud NOT_IMPLEMENTED."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=66)
+    other = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q6_K, seed=66)
+    model.tensors["blk.1.ffn_down.weight"] = other.tensors["blk.1.ffn_down.weight"]
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    with pytest.raises(Exception):
+        ca.HipLlamaRunner(conf, w, dev, 64, True)
+    # the per-op trait path has no such restriction (every matmul_vec quantizes its own rhs)
+    t = ca.Llama2Runner(conf, w, dev, 64, True)
+    assert np.all(np.isfinite(np.asarray(t.forward([1], 0))))
