@@ -304,9 +304,15 @@ struct Planes {
   const i32x4* q;
   const unsigned short* d;
 };
+// a Q6_K matrix standing in for one of a Q4_K layer's (llama.cpp *_K_M mixes): base = nullptr means "not used"
+struct Planes6 {
+  const char* base;
+  size_t off_qh;
+};
 
 template <int FMT>
-__global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e) {
+__global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e,
+                                             Planes6 wv6) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int row0 = wave * 2;
@@ -324,7 +330,14 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
   QkvPre pre{};
   if (lane == 0) pre = qkv_preload(e, row0);
   float acc[2];
-  rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
+  bool done = false;
+  if constexpr (FMT == CRABML_HIP_Q4_K) {
+    if (wv6.base != nullptr && row0 >= e.dim + e.kv_dim) {  // the V rows of this layer are Q6_K (wave-uniform)
+      rows_partial_q6k<2>(wv6.base, wv6.off_qh, act, local, m, nb, lane, acc);
+      done = true;
+    }
+  }
+  if (!done) rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
   if (lane == 0) qkv_epilogue(e, pre, row0, s0, s1);
 }
@@ -1223,7 +1236,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
                                                       signed char* __restrict__ q, void* __restrict__ d,
-                                                      void* __restrict__ isum, NormGather ng, int nb) {
+                                                      void* __restrict__ isum, NormGather ng, int nb, Planes6 w6) {
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
@@ -1254,6 +1267,14 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     short* sbs = (short*)(sd + nb);
     // the first weight pieces are requested before the prologue (they do not depend on it): its L2 round trip
     // and the quantizer run under the HBM latency of the stream's head
+    if (w6.base != nullptr) {  // this layer's matrix is Q6_K (a *_K_M mix): same rhs, its own inner loop
+      stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
+      const ActQ8_K la6{lds_act, sd, sbs};
+      rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
+      nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
+                              (int)blockIdx.x, (int)gridDim.x);
+      return;
+    }
     constexpr int PRE = 2;
     Q4KPiece<false> pw[PRE][RW];
 #pragma unroll
@@ -1277,7 +1298,10 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     }
     rows_partial_q4k<RW, false>(w.q, (const i32x4*)w.d, la, row, nchunks * 32, nb, lane, acc, PRE * 64);
   } else if constexpr (KQ) {
-    rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
+    if (w6.base != nullptr)
+      rows_partial_q6k<RW>(w6.base, w6.off_qh, act, row, nchunks * 32, nb, lane, acc);
+    else
+      rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
   } else {
     using F = BlockFmt<FMT>;
 #pragma unroll
@@ -1932,11 +1956,11 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32);
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0});
       else
         launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32);
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0});
     } else if (tp) {
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     } else {
@@ -1971,7 +1995,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(&pr, 1, total_rows, dim));
     launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-             planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e);
+             planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;
@@ -2137,6 +2161,10 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   auto planes_k = [&](const crabml_hip_buf* b) {
     return Planes{(const i32x4*)b->ptr, (const unsigned short*)((const char*)b->ptr + b->wl.off_scale)};
   };
+  // a Q6_K tensor inside a Q4_K layer (attn_v / ffn_down of the *_K_M mixes): handed to the kernel beside the planes
+  auto six = [&](const crabml_hip_buf* b) {
+    return b->dtype == CRABML_HIP_Q6_K ? Planes6{(const char*)b->ptr, b->wl.off_scale} : Planes6{nullptr, 0};
+  };
   const size_t norm_lds = norm_lds_bytes(dim);
   // rmsnorm * weight -> xn -> Q8_K planes (buf_q8_k.rs:84-131)
   auto norm_quant = [&](const float* wn, float eps, bool add_pending, uint32_t qt) -> const void* {
@@ -2172,16 +2200,16 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
         if (split == 2 && qin)
           launch_k(st, R, k_gemv_res_nq<FMT, 2, true>, dim3(dim / 16), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE);
+                   od, ob, ng, k / BE, six(w));
         else if (split == 2)
           launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE);
+                   ng, k / BE, six(w));
         else if (qin)
           launch_k(st, R, k_gemv_res_nq<FMT, 1, true>, dim3(dim / 32), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE);
+                   od, ob, ng, k / BE, six(w));
         else
           launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE);
+                   ng, k / BE, six(w));
         return P1();
       }
     }
@@ -2217,7 +2245,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(1, total_rows, dim));
     launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
-             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e);
+             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]));
     CH_TRY(P1());
     enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
     if (!qin) launch_quantize_act(st, QT, c->attn, (size_t)dim_l, c->act_attn);
@@ -2539,19 +2567,22 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   // long as they share the rhs type (buf/api.rs:142-159: every K-quant takes Q8_K): such a model runs the per-op
   // segments, each GEMV picking its kernel by the tensor's own dtype
   bool mixed = false;
-  auto check_w = [&](const crabml_hip_buf* b, size_t m, size_t k) {
+  bool mix_v_down_q6k = true;  // every deviating tensor is an attn_v / ffn_down in Q6_K inside a Q4_K layer (the *_K_M recipe)
+  auto check_w = [&](const crabml_hip_buf* b, size_t m, size_t k, bool v_or_down) {
     if (!b) return false;
     if (b->dtype != wt) {
       if (vec_dot_rhs_dtype(b->dtype) != qt || k % block_elems(b->dtype)) return false;
       mixed = true;
+      if (!(v_or_down && wt == CRABML_HIP_Q4_K && b->dtype == CRABML_HIP_Q6_K)) mix_v_down_q6k = false;
     }
     return check(b, m, k, b->dtype);
   };
   for (size_t l = 0; l < g.n_layers; l++) {
-    if (!check_w(w->wq[l], dim_l, g.embedding_dim) || !check_w(w->wk[l], kv_dim_l, g.embedding_dim) ||
-        !check_w(w->wv[l], kv_dim_l, g.embedding_dim) || !check_w(w->wo[l], g.embedding_dim, dim_l) ||
-        !check_w(w->ffn_gate_weight[l], hidden_l, g.embedding_dim) || !check_w(w->ffn_up_weight[l], hidden_l, g.embedding_dim) ||
-        !check_w(w->ffn_down_weight[l], g.embedding_dim, hidden_l) ||
+    if (!check_w(w->wq[l], dim_l, g.embedding_dim, false) || !check_w(w->wk[l], kv_dim_l, g.embedding_dim, false) ||
+        !check_w(w->wv[l], kv_dim_l, g.embedding_dim, true) || !check_w(w->wo[l], g.embedding_dim, dim_l, false) ||
+        !check_w(w->ffn_gate_weight[l], hidden_l, g.embedding_dim, false) ||
+        !check_w(w->ffn_up_weight[l], hidden_l, g.embedding_dim, false) ||
+        !check_w(w->ffn_down_weight[l], g.embedding_dim, hidden_l, true) ||
         !check(w->rms_att_weight[l], 1, g.embedding_dim, CRABML_HIP_F32) ||
         !check(w->rms_ffn_weight[l], 1, g.embedding_dim, CRABML_HIP_F32))
       CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED,
@@ -2566,10 +2597,15 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->dev = dev;
   c->cfg = g;
   c->wtype = wt;
-  generic = generic || mixed;
+  // the Q4_K fused kernels take a Q6_K attn_v / ffn_down beside the Q4_K planes, but only in the norm-epilogue form
+  const bool nepi_k_possible = !dev->strict_order && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
+                               !(g.flags & (CRABML_HIP_LLAMA_NO_NORM_EPILOGUE | CRABML_HIP_LLAMA_NO_KQUANT_FUSION)) &&
+                               g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
+  const bool mix_fused = mixed && mix_v_down_q6k && nepi_k_possible;
+  generic = generic || (mixed && !mix_fused);
   c->generic = generic;
   // Q4_K always; Q4_1 when it cannot take the 5-kernel path (mixed classifier format) or for the A/B flag
-  c->kfused = !dev->strict_order && !mixed && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
+  c->kfused = !dev->strict_order && (!mixed || mix_fused) && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
               (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS))));
   c->qt = qt;
   c->out_qt = out_qt;

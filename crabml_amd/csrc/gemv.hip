@@ -128,54 +128,8 @@ __global__ __launch_bounds__(256) void k_gemv_q6_k(const char* __restrict__ w, s
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int row0 = wave * R;
   if (row0 >= m) return;
-  const size_t n = off_qh / 128;  // blocks in the tensor
-  const i32x4* wql = (const i32x4*)w;
-  const i32x4* wqh = (const i32x4*)(w + off_qh);
-  const char* wsc = w + off_qh + n * 64;
-  const unsigned short* wd = (const unsigned short*)(w + off_qh + n * 80);
   float acc[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) acc[r] = 0.f;
-  const int npieces = nsb * 8;
-  for (int c = lane; c < npieces; c += 64) {
-    const int sb = c >> 3, h = (c >> 2) & 1, a = (c >> 1) & 1, p = c & 1;
-    const int gi = 8 * h + p + 2 * a;  // scale group of the low nibbles; the high nibbles' group is gi + 4
-    i32x4 qv[R], hv[R];
-    unsigned scw[R];
-    unsigned short dw[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int row = row0 + r < m ? row0 + r : m - 1;
-      const size_t blk = (size_t)row * nsb + sb;
-      qv[r] = __builtin_nontemporal_load(wql + blk * 8 + (c & 7));
-      hv[r] = __builtin_nontemporal_load(wqh + blk * 4 + 2 * h + p);
-      const signed char* sp = (const signed char*)wsc + blk * 16 + gi;
-      scw[r] = (unsigned)(unsigned char)sp[0] | ((unsigned)(unsigned char)sp[4] << 8);
-      dw[r] = wd[blk];
-    }
-    const i32x4* xq = act.q + (size_t)sb * 16 + gi;  // 16 int8 per group
-    const i32x4 xl = xq[0], xh = xq[4];
-    const float d8 = act.d[sb];
-    const short* bs = act.bsums + sb * 16 + gi;
-    const int bs_lo = (int)bs[0], bs_hi = (int)bs[4];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int lo = 0, hi = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const unsigned q = (unsigned)qv[r][i], hb = (unsigned)hv[r][i] >> (2 * a);
-        const unsigned ql4 = (q & 0x0F0F0F0Fu) | ((hb & 0x03030303u) << 4);
-        const unsigned qh4 = ((q >> 4) & 0x0F0F0F0Fu) | (((hb >> 4) & 0x03030303u) << 4);
-        lo = __builtin_amdgcn_sdot4((int)ql4, xl[i], lo, false);
-        hi = __builtin_amdgcn_sdot4((int)qh4, xh[i], hi, false);
-      }
-      lo -= 32 * bs_lo;  // sum (q6 - 32) * q8, exact
-      hi -= 32 * bs_hi;
-      const int sc_lo = (int)(signed char)(scw[r] & 0xffu), sc_hi = (int)(signed char)(scw[r] >> 8);
-      const float dd = h2f(dw[r]) * d8;
-      acc[r] += dd * ((float)(sc_lo * lo) + (float)(sc_hi * hi));
-    }
-  }
+  rows_partial_q6k<R>(w, off_qh, act, row0, m, nsb, lane, acc);  // gemv_core.hpp
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float s = wave_sum_f32(acc[r]);

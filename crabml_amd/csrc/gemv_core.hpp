@@ -260,6 +260,62 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
   }
 }
 
+// Q6_K rows (planes ql[n][128] | qh[n][64] | scales[n][16] | d[n] f16; common.hpp) against a Q8_K activation vector:
+// lane = one 16-byte ql piece of a super-block (8 lanes per super-block), which carries the low nibbles of scale group
+// gi and the high nibbles of group gi + 4 (buf_q6_k.rs:21-48).  6-bit values are rebuilt as bytes for v_dot4; the -32
+// offset is applied as -32 * bsum (exact).  off_qh = byte offset of the qh plane = 128 * blocks in the tensor.
+template <int R>
+__device__ __forceinline__ void rows_partial_q6k(const char* __restrict__ w, size_t off_qh, const ActQ8_K& act, int row0, int m,
+                                                 int nsb, int lane, float acc[R]) {
+  const size_t n = off_qh / 128;  // blocks in the tensor
+  const i32x4* wql = (const i32x4*)w;
+  const i32x4* wqh = (const i32x4*)(w + off_qh);
+  const char* wsc = w + off_qh + n * 64;
+  const unsigned short* wd = (const unsigned short*)(w + off_qh + n * 80);
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int npieces = nsb * 8;
+  for (int c = lane; c < npieces; c += 64) {
+    const int sb = c >> 3, h = (c >> 2) & 1, a = (c >> 1) & 1, p = c & 1;
+    const int gi = 8 * h + p + 2 * a;  // scale group of the low nibbles; the high nibbles' group is gi + 4
+    i32x4 qv[R], hv[R];
+    unsigned scw[R];
+    unsigned short dw[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      const size_t blk = (size_t)row * nsb + sb;
+      qv[r] = __builtin_nontemporal_load(wql + blk * 8 + (c & 7));
+      hv[r] = __builtin_nontemporal_load(wqh + blk * 4 + 2 * h + p);
+      const signed char* sp = (const signed char*)wsc + blk * 16 + gi;
+      scw[r] = (unsigned)(unsigned char)sp[0] | ((unsigned)(unsigned char)sp[4] << 8);
+      dw[r] = wd[blk];
+    }
+    const i32x4* xq = act.q + (size_t)sb * 16 + gi;  // 16 int8 per group
+    const i32x4 xl = xq[0], xh = xq[4];
+    const float d8 = act.d[sb];
+    const short* bs = act.bsums + sb * 16 + gi;
+    const int bs_lo = (int)bs[0], bs_hi = (int)bs[4];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int lo = 0, hi = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = (unsigned)qv[r][i], hb = (unsigned)hv[r][i] >> (2 * a);
+        const unsigned ql4 = (q & 0x0F0F0F0Fu) | ((hb & 0x03030303u) << 4);
+        const unsigned qh4 = ((q >> 4) & 0x0F0F0F0Fu) | (((hb >> 4) & 0x03030303u) << 4);
+        lo = __builtin_amdgcn_sdot4((int)ql4, xl[i], lo, false);
+        hi = __builtin_amdgcn_sdot4((int)qh4, xh[i], hi, false);
+      }
+      lo -= 32 * bs_lo;  // sum (q6 - 32) * q8, exact
+      hi -= 32 * bs_hi;
+      const int sc_lo = (int)(signed char)(scw[r] & 0xffu), sc_hi = (int)(signed char)(scw[r] >> 8);
+      const float dd = h2f(dw[r]) * d8;
+      acc[r] += dd * ((float)(sc_lo * lo) + (float)(sc_hi * hi));
+    }
+  }
+}
+
 // R rows of a weight matrix in format FMT against its activation planes (ActQ8_0 for Q4_0 / Q8_0, ActQ8_K for
 // Q4_K); `wd` is the format's second plane (f16 scales / 16-byte headers), `nu` the blocks per row
 template <int FMT, int R, class ACT>

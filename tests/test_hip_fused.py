@@ -391,3 +391,20 @@ def test_layer_dtypes_with_different_rhs_types_are_rejected(ca):
     # the per-op trait path has no such restriction (every matmul_vec quantizes its own rhs)
     t = ca.Llama2Runner(conf, w, dev, 64, True)
     assert np.all(np.isfinite(np.asarray(t.forward([1], 0))))
+
+
+@pytest.mark.parametrize("flags", [0, 16, 1024])
+def test_q4_k_m_mix_on_the_fused_kernels_equals_the_per_op_segments(ca, flags):
+    """The Q4_K fused kernels take a Q6_K attn_v (inside k_qkv) / ffn_down (inside the norm-epilogue kernel, rhs
+    quantized to Q8_K in its prologue) beside the Q4_K planes: per row the per-op kernel's arithmetic, so the step is
+    bit-identical to the per-op segments (flag 256 = NO_KQUANT_FUSION).  16 = split chunks, 1024 = no rhs prologue."""
+    shape = synth.ModelShape("tiny-gqa-8l", 512, 1024, 8, 8, 2, 1024, 64)
+    model = synth.build_model(shape, synth.Q4_K, seed=67, k_m_mix=True)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    fused = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=flags)
+    per_op = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=256)
+    for i, t in enumerate(PROMPT + [5, 6, 7]):
+        a, b = fused.forward(t, i), per_op.forward(t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+    assert list(fused.decode_greedy(3, 20)) == list(per_op.decode_greedy(3, 20))
