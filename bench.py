@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="llama3-8b", help="shape key in crabml_amd.synth.SHAPES")
     ap.add_argument("--wtype", default="Q4_0")
+    ap.add_argument("--output-type", default=None,
+                    help="GGML type of output.weight when it differs from --wtype (llama.cpp's Q4_0 files: Q6_K)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncate the layer count (INVALID as a result)")
     ap.add_argument("--path", default="auto", choices=["auto", "trait", "fused"],
                     help="trait = one launch per Tensor op (Llama2Runner unchanged); fused = fused decode step")
@@ -268,7 +270,8 @@ def main():
     k_m = args.wtype.upper() == "Q4_K_M"  # llama.cpp's mix: Q4_K body, attn_v / ffn_down in Q6_K on some layers, Q6_K classifier
     wtype = synth.Q4_K if k_m else synth.TYPE_BY_NAME[args.wtype]
     t_build = time.perf_counter()
-    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, k_m_mix=k_m)
+    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, k_m_mix=k_m,
+                              output_type=synth.TYPE_BY_NAME[args.output_type] if args.output_type else None)
     dev = ca.HipTensorDevice(device_ordinal=local)
     t_upload = time.perf_counter()
     conf, weights = synth.to_hip(model, dev)

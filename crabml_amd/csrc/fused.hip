@@ -1971,9 +1971,29 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   };
 
   if (seg == 2 * L) {  // final rmsnorm + classifier (llama2.rs:274-278, 199-208) + greedy sampler
-    if (!norm_epi) norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, plan(nullptr, nullptr, nullptr));
-    CH_TRY(P0(&pr, 5, (double)g.vocab_size, dim));
-    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, c->act_dim, 1, c->logits, R));
+    const void* cls_act = c->act_dim;
+    if (c->out_qt != qt) {
+      // the classifier has its own rhs type (e.g. Q6_K -> Q8_K): normalize the final x to f32 and quantize for it (the
+      // planes the last ffn_down epilogue wrote are in the layers' type and stay unused)
+      const size_t nlds = norm_lds_bytes(dim);
+      const float* addv = tp ? c->partial : nullptr;
+      if (dim <= 4096)
+        k_norm_f32<4><<<1, 1024, nlds, st>>>(c->x, addv, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, 1);
+      else
+        k_norm_f32<12><<<1, 1024, nlds, st>>>(c->x, addv, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, 1);
+      if (c->out_qt == CRABML_HIP_F32) {
+        cls_act = c->xn;
+      } else {
+        launch_quantize_act(st, c->out_qt, c->xn, (size_t)dim, c->act_dim);
+      }
+    } else if (!norm_epi) {
+      norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, plan(nullptr, nullptr, nullptr));
+    }
+    if (prof)
+      CH_TRY(prof_begin(dev, &pr, c->output->dtype, 5,
+                        (double)g.vocab_size * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
+                            4.0 * dim + 4.0 * g.vocab_size));
+    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, cls_act, 1, c->logits, R));
     CH_TRY(P1(&pr));
     k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
     k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
@@ -2553,7 +2573,10 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   if (qt == 0xffffffffu || out_qt == 0xffffffffu)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama: weight dtype %u / classifier dtype %u has no matmul_vec", wt, out_wt);
   // fused kernels exist for Q4_0 / Q8_0 layers (fast mode); everything else runs the per-op segment path
-  bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0 && wt != CRABML_HIP_Q4_1) || out_wt != wt;
+  // (a classifier of another format -- llama.cpp's "Q4_0" files keep output.weight in Q6_K -- does not take the layers
+  // off the fused kernels: the final segment quantizes the normalized row for the classifier's own rhs type)
+  bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0 && wt != CRABML_HIP_Q4_1);
+  const bool out_differs = out_wt != wt;
   {
     const size_t be = block_elems(wt) > block_elems(qt) ? block_elems(wt) : block_elems(qt);
     const size_t obe = block_elems(out_wt) > block_elems(out_qt) ? block_elems(out_wt) : block_elems(out_qt);
@@ -2606,7 +2629,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->generic = generic;
   // Q4_K always; Q4_1 when it cannot take the 5-kernel path (mixed classifier format) or for the A/B flag
   c->kfused = !dev->strict_order && (!mixed || mix_fused) && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
-              (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS))));
+              (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || out_differs || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS))));
   c->qt = qt;
   c->out_qt = out_qt;
   c->tp = tp;
