@@ -202,3 +202,28 @@ def test_gguf_q4_k_m_mix_round_trip(tmp_path):
     b = ca.HipLlamaRunner(conf_b, w_b, dev, 32, True)
     for i, t in enumerate([1, 365, 400, 282]):
         assert np.array_equal(a.forward(t, i).view(np.uint32), b.forward(t, i).view(np.uint32)), f"step {i}"
+
+
+@pytest.mark.gpu
+def test_generate_tool_end_to_end(tmp_path):
+    """tools/generate.py: GGUF file -> C++ loader -> batched prefill -> on-device greedy decode, as one command."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = small_model()
+    path = str(tmp_path / "g.gguf")
+    synth.write_gguf(model, path)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "generate.py"), path, "--steps", "6", "--prompt", "1,2,3,4,5"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("tokens:")][0]
+    ids = [int(t) for t in line.split(":")[1].split(",")]
+    assert len(ids) == 6 and all(0 <= t < model.shape.vocab for t in ids)
+    # the same tokens through the python API
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.load_gguf_hip(path, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 19, True)
+    lg = r.prefill([1, 2, 3, 4, 5])
+    first = int(len(lg) - 1 - lg[::-1].argmax())
+    assert [first] + [int(t) for t in r.decode_greedy(first, 5)] == ids
