@@ -239,13 +239,220 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
   }
 }
 
+// ---- Q4_K weights x Q8_K activation rows (the prompt of a *_K_M file) ------------------------------------------------
+// One chunk = one 256-element super-block.  Per 32-element sub-block j one MFMA per 16 x 16 tile gives the exact integer
+// dots sum q4 * q8 (nibbles are unsigned: Q4_K has no -8 offset), which are folded into the super-block sum with the
+// sub-block's 6-bit scale IN INTEGERS (v_mad_i32_i24; |sum| < 2^24) -- no conversion and no float work per sub-block,
+// which is what bounds the Q4_0 kernel.  The minimum term sum_j m_j * bsum_j is two more MFMAs per tile and
+// super-block: operand A = the row's eight 6-bit minimums, operand B = the column's eight 32-element quant sums split as
+// bsum = 64 a + b with b in [-32, 32), a in [-64, 64] (both fit int8).  Per super-block and output then, as the GEMV
+// does (buf_q4_k.rs:200-262): acc += (d * d8) * isum - (dmin * d8) * msum.
+// Operand layout as above: lane (i, g) supplies bytes [8g, 8g + 8) of the sub-block for row / column i; low nibbles of
+// qs bytes [32p, 32p + 32) are sub-block 2p, high nibbles sub-block 2p + 1 (buf_q4_k.rs:212-217).
+template <int NT>
+struct GemmGeoK {
+  static constexpr int CW = 16 * NT;
+  static constexpr int ASTR = 36;  // words per weight row: 128 B of quants + 16 B pad (16-byte aligned rows)
+  static constexpr int BSTR = 68;  // words per activation row: 256 B + 16 B pad
+  // one buffer, in words: A quants | A scales (8 bytes / row) | A mins | A d f32 | A dmin f32 | B quants | B d8 f32 |
+  // B bsum low parts (8 bytes / column) | B bsum high parts
+  static constexpr int O_ASC = 64 * ASTR, O_AM = O_ASC + 128, O_AD = O_AM + 128, O_ADM = O_AD + 64, O_BQ = O_ADM + 64;
+  static constexpr int O_BD = O_BQ + CW * BSTR, O_BLO = O_BD + CW, O_BHI = O_BLO + 2 * CW, BUF_WORDS = O_BHI + 2 * CW;
+  static constexpr int LDS_BYTES = 2 * BUF_WORDS * 4;
+  static constexpr int A_LOADS = 2, B_LOADS = CW * 16 / 256;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm_mfma_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh,
+                                                       const char* __restrict__ act, size_t act_stride, size_t off_d, size_t off_aux,
+                                                       float* __restrict__ out, int m, int nsb, int b, int row_tiles) {
+  using G = GemmGeoK<NT>;
+  constexpr int CW = G::CW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  int rt, ct;
+  {  // XCD-aware tile order (see k_gemm_mfma)
+    const int col_tiles = (int)gridDim.x / row_tiles;
+    if ((row_tiles & 7) == 0) {
+      const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+      ct = j % col_tiles;
+      rt = (j / col_tiles) * 8 + x;
+    } else {
+      rt = (int)blockIdx.x % row_tiles;
+      ct = (int)blockIdx.x / row_tiles;
+    }
+  }
+  const int r0 = rt * 64, c0 = ct * CW;
+
+  i32x4 ra[G::A_LOADS], rb[G::B_LOADS], rh, rbs;
+  float rd8 = 0.f;
+  auto fetch = [&](int sb) {
+#pragma unroll
+    for (int u = 0; u < G::A_LOADS; u++) {
+      const int t = tid + 256 * u, row = t >> 3, pc = t & 7;
+      const int grow = r0 + row < m ? r0 + row : m - 1;
+      ra[u] = __builtin_nontemporal_load(wq + ((size_t)grow * nsb + sb) * 8 + pc);
+    }
+    if (tid < 64) {
+      const int grow = r0 + tid < m ? r0 + tid : m - 1;
+      rh = __builtin_nontemporal_load(wh + (size_t)grow * nsb + sb);
+    }
+#pragma unroll
+    for (int u = 0; u < G::B_LOADS; u++) {
+      const int t = tid + 256 * u, col = t >> 4, pc = t & 15;
+      const int gcol = c0 + col < b ? c0 + col : b - 1;
+      rb[u] = *((const i32x4*)(act + (size_t)gcol * act_stride) + (size_t)sb * 16 + pc);
+    }
+    if (tid < CW) {
+      const int gcol = c0 + tid < b ? c0 + tid : b - 1;
+      rd8 = ((const float*)(act + (size_t)gcol * act_stride + off_d))[sb];
+    }
+    if (tid < 2 * CW) {
+      const int col = tid >> 1, gcol = c0 + col < b ? c0 + col : b - 1;
+      rbs = *((const i32x4*)(act + (size_t)gcol * act_stride + off_aux) + (size_t)sb * 2 + (tid & 1));  // 8 of the 16 bsums
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned* S = (unsigned*)lds_raw + (size_t)buf * G::BUF_WORDS;
+#pragma unroll
+    for (int u = 0; u < G::A_LOADS; u++) {
+      const int t = tid + 256 * u, row = t >> 3, pc = t & 7;
+      *(i32x4*)(S + row * G::ASTR + pc * 4) = ra[u];
+    }
+    if (tid < 64) {  // unpack the row's header once: 8 scales, 8 mins (6 bits each), d, dmin
+      const unsigned h0 = (unsigned)rh[0], h1 = (unsigned)rh[1], h2 = (unsigned)rh[2], h3 = (unsigned)rh[3];
+      unsigned sc[2] = {0u, 0u}, mn[2] = {0u, 0u};
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const unsigned f = q4k_pair_field(h1, h2, h3, p);
+        const unsigned s2 = (f & 63u) | (((f >> 6) & 63u) << 8), m2 = ((f >> 12) & 63u) | ((f >> 18) << 8);
+        sc[p >> 1] |= s2 << (16 * (p & 1));
+        mn[p >> 1] |= m2 << (16 * (p & 1));
+      }
+      S[G::O_ASC + tid * 2] = sc[0];
+      S[G::O_ASC + tid * 2 + 1] = sc[1];
+      S[G::O_AM + tid * 2] = mn[0];
+      S[G::O_AM + tid * 2 + 1] = mn[1];
+      ((float*)S)[G::O_AD + tid] = h2f((unsigned short)(h0 & 0xffffu));
+      ((float*)S)[G::O_ADM + tid] = h2f((unsigned short)(h0 >> 16));
+    }
+#pragma unroll
+    for (int u = 0; u < G::B_LOADS; u++) {
+      const int t = tid + 256 * u, col = t >> 4, pc = t & 15;
+      *(i32x4*)(S + G::O_BQ + col * G::BSTR + pc * 4) = rb[u];
+    }
+    if (tid < CW) ((float*)S)[G::O_BD + tid] = rd8;
+    if (tid < 2 * CW) {  // four 32-element quant sums -> (b, a) byte pairs: bsum = 64 a + b
+      unsigned lo = 0u, hi = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int w2 = rbs[q];
+        const int bs = (int)(short)(w2 & 0xffff) + (int)(short)((unsigned)w2 >> 16);
+        const int bl = ((bs + 32) & 63) - 32, bh = (bs - bl) >> 6;
+        lo |= ((unsigned)bl & 0xffu) << (8 * q);
+        hi |= ((unsigned)bh & 0xffu) << (8 * q);
+      }
+      S[G::O_BLO + tid] = lo;  // column tid / 2, half tid & 1: words [2 col + half]
+      S[G::O_BHI + tid] = hi;
+    }
+  };
+
+  f32x2 F[NT][2];
+#pragma unroll
+  for (int jt = 0; jt < NT; jt++) F[jt][0] = F[jt][1] = f32x2{0.0f, 0.0f};
+
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int sb = 0; sb < nsb; sb++) {
+    const int buf = sb & 1;
+    fetch(sb + 1 < nsb ? sb + 1 : sb);  // unconditional (the last one re-reads): in flight while this chunk is multiplied
+    const unsigned* S = (const unsigned*)lds_raw + (size_t)buf * G::BUF_WORDS;
+    const unsigned* arow = S + (16 * wave + i) * G::ASTR + 2 * g;
+    // scales / d / dmin of the four rows this lane's accumulators belong to (rows 4g .. 4g + 3 of the wave's 16)
+    unsigned long long sc8[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) sc8[r] = *(const unsigned long long*)(S + G::O_ASC + (16 * wave + 4 * g + r) * 2);
+    const f32x4 dw4 = *(const f32x4*)((const float*)S + G::O_AD + 16 * wave + 4 * g);
+    const f32x4 dm4 = *(const f32x4*)((const float*)S + G::O_ADM + 16 * wave + 4 * g);
+    int iacc[NT][4];
+#pragma unroll
+    for (int jt = 0; jt < NT; jt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) iacc[jt][r] = 0;
+#pragma unroll 2
+    for (int j = 0; j < 8; j++) {  // (fully unrolled the compiler hoists every fragment read: 268 VGPRs)
+      const unsigned long long aw = *(const unsigned long long*)(arow + 8 * (j >> 1));
+      const long A = (long)(((j & 1) ? (aw >> 4) : aw) & 0x0F0F0F0F0F0F0F0Full);
+      i32x4 D[NT];
+#pragma unroll
+      for (int jt = 0; jt < NT; jt++) {
+        const long Bf = *(const long*)(S + G::O_BQ + (16 * jt + i) * G::BSTR + 8 * j + 2 * g);
+        D[jt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bf, i32x4{0, 0, 0, 0}, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int scj = (int)((sc8[r] >> (8 * j)) & 0xffull);
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) iacc[jt][r] += __mul24(D[jt][r], scj);  // v_mad_i32_i24: |D| < 2^17, scj < 64
+      }
+    }
+    // minimum term: (8 mins of row i) x (8 quant-sum parts of column i), in k-slot group 0; the other groups feed zeros
+    const long Am = g == 0 ? *(const long*)(S + G::O_AM + (16 * wave + i) * 2) : 0l;
+    const f32x2 dw01 = {dw4[0], dw4[1]}, dw23 = {dw4[2], dw4[3]}, dm01 = {dm4[0], dm4[1]}, dm23 = {dm4[2], dm4[3]};
+#pragma unroll
+    for (int jt = 0; jt < NT; jt++) {
+      const long Bl = g == 0 ? *(const long*)(S + G::O_BLO + (16 * jt + i) * 2) : 0l;
+      const long Bh = g == 0 ? *(const long*)(S + G::O_BHI + (16 * jt + i) * 2) : 0l;
+      const i32x4 Dl = __builtin_amdgcn_mfma_i32_16x16x32_i8(Am, Bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
+      const i32x4 Dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(Am, Bh, i32x4{0, 0, 0, 0}, 0, 0, 0);
+      const float d8 = ((const float*)S)[G::O_BD + 16 * jt + i];
+      const f32x2 d88 = {d8, d8};
+      const f32x2 i01 = {(float)iacc[jt][0], (float)iacc[jt][1]}, i23 = {(float)iacc[jt][2], (float)iacc[jt][3]};
+      const f32x2 m01 = {(float)(Dl[0] + 64 * Dh[0]), (float)(Dl[1] + 64 * Dh[1])};
+      const f32x2 m23 = {(float)(Dl[2] + 64 * Dh[2]), (float)(Dl[3] + 64 * Dh[3])};
+      F[jt][0] += (dw01 * d88) * i01 - (dm01 * d88) * m01;
+      F[jt][1] += (dw23 * d88) * i23 - (dm23 * d88) * m23;
+    }
+    commit(buf ^ 1);  // the other buffer was last read one iteration ago (barrier below)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int jt = 0; jt < NT; jt++) {
+    const int col = c0 + 16 * jt + i;
+    if (col >= b) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 16 * wave + g * 4 + r;
+      if (row < m) out[(size_t)col * m + row] = F[jt][r >> 1][r & 1];
+    }
+  }
+}
+
 // returns false when the shape / format is not covered (the caller falls back to one GEMV per batch row)
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
                       crabml_hip_device::ProfRec* rec) {
-  if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0) return false;
+  if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K) return false;
   if (b < 16 || m == 0 || k % 32 != 0) return false;
   hipStream_t st = dev->stream;
   const char* wp = (const char*)w->ptr;
+  if (w->dtype == CRABML_HIP_Q4_K) {
+    if (k % 256 != 0) return false;
+    const ActLayout alk = act_layout(CRABML_HIP_Q8_K, k);
+    const int nsb = (int)(k / 256), rtl = (int)((m + 63) / 64);
+    const bool narrow_k = (size_t)rtl * ((b + 63) / 64) < (size_t)4 * dev->n_cu && b > 16;
+    const int cwk = narrow_k ? 32 : 64, ctl = (int)((b + cwk - 1) / cwk);
+    const i32x4* wqk = (const i32x4*)wp;
+    const i32x4* whk = (const i32x4*)(wp + w->wl.off_scale);
+    if (narrow_k)
+      launch_k(st, rec, k_gemm_mfma_q4k<2>, dim3(rtl * ctl), dim3(256), GemmGeoK<2>::LDS_BYTES, wqk, whk, (const char*)act, alk.total,
+               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl);
+    else
+      launch_k(st, rec, k_gemm_mfma_q4k<4>, dim3(rtl * ctl), dim3(256), GemmGeoK<4>::LDS_BYTES, wqk, whk, (const char*)act, alk.total,
+               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl);
+    return true;
+  }
   const ActLayout al = act_layout(CRABML_HIP_Q8_0, k);
   const int nb = (int)(k / 32);
   const int row_tiles = (int)((m + 63) / 64);

@@ -149,6 +149,28 @@ def test_batched_rhs_on_the_matrix_cores_is_bit_exact(ca, hdev, odev, fmt):
         assert np.array_equal(got.export().view(np.uint32), ref.view(np.uint32)), f"{fmt} m={m} k={k} b={b}"
 
 
+def test_batched_rhs_q4_k_on_the_matrix_cores(ca, hdev, odev):
+    """Q4_K weights x >= 16 Q8_K activation rows (the prompt of a *_K_M file): integer MFMA tiles per 32-element
+    sub-block, folded with the 6-bit sub-block scales in integers, the minimum term as two more MFMAs per super-block
+    (gemm_mfma.hip: k_gemm_mfma_q4k).  Same integers as the reference, f32 accumulation per super-block: within the
+    GEMV re-association bound of the oracle (x8 for Q4_K, as for the single-row kernel).  Ragged m / b, 1 .. 16
+    super-blocks, both column-tile widths."""
+    for (m, k, b) in [(16, 256, 16), (37, 512, 17), (100, 1024, 40), (256, 256, 64), (64, 2048, 100), (1000, 4096, 33),
+                      (4096, 512, 64)]:
+        typ, raw, _ = make("Q4_K", m, k, m + k + b)
+        rng = np.random.default_rng(b)
+        x = rng.standard_normal(b * k).astype(np.float32)
+        w = ca.HipTensor.from_cpu(raw, [m, k], ca.GGMLType.Q4K, hdev)
+        got = w.matmul_vec(ca.HipTensor.new(x, [b, k], hdev)).export().reshape(b, m)
+        ref = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(x, [b, k], odev)).export().reshape(b, m)
+        for r in range(b):
+            bound = gemv_order_bound(raw, typ, x[r * k:(r + 1) * k], m, k) * GEMV_REL * 8 + 1e-30
+            assert np.all(np.abs(got[r] - ref[r]) <= bound), f"m={m} k={k} b={b} row {r}: {np.max(np.abs(got[r] - ref[r]) / bound)}"
+        # and equal, within the same bound, to the single-row kernel fed the same rows
+        one = w.matmul_vec(ca.HipTensor.new(x[:k].copy(), [k], hdev)).export()
+        assert np.all(np.abs(got[0] - one) <= gemv_order_bound(raw, typ, x[:k], m, k) * GEMV_REL * 8 + 1e-30)
+
+
 def test_gemv_errors(ca, hdev):
     typ, raw, x = make("Q4_0", 8, 64, 3)
     w = ca.HipTensor.from_cpu(raw, [8, 64], ca.GGMLType.Q4_0, hdev)

@@ -20,7 +20,8 @@ ap.add_argument("--layers", type=int, default=0)
 ap.add_argument("--loop", type=int, default=64, help="tokens of the token-loop baseline")
 a = ap.parse_args()
 shape = synth.SHAPES[a.model]
-model = synth.build_model(shape, synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers or None)
+k_m = a.wtype.upper() == "Q4_K_M"  # llama.cpp's mix: Q4_K body, attn_v / ffn_down in Q6_K on some layers, Q6_K classifier
+model = synth.build_model(shape, synth.Q4_K if k_m else synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers or None, k_m_mix=k_m)
 dev = ca.HipTensorDevice(0)
 conf, w = synth.to_hip(model, dev)
 L = a.layers or shape.n_layers
