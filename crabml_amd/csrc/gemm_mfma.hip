@@ -430,13 +430,223 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q4k(const i32x4* __restrict__
   }
 }
 
+// ---- Q6_K weights x Q8_K activation rows (attn_v / ffn_down / the classifier of the *_K_M mixes) -------------------------
+// A Q6_K scale covers 16 elements, an MFMA 32: every 32-element unit (h, c) = elements 128 h + 32 c + [0, 32) of the
+// super-block is multiplied twice with half of operand A zeroed (k-slot groups 0-1 = the unit's first scale group,
+// 2-3 = the second), giving the two exact integer dots sum q6 * q8 -- the matrix cores have the headroom, the VALU is what
+// is scarce.  6-bit values are rebuilt as bytes from ql (nibble c >> 1 of byte 64 h + 32 (c & 1) + l) and qh (bits 2c,
+// 2c + 1 of byte 32 h + l) (buf_q6_k.rs:21-48).  Folded in integers with the int8 group scales; the -32 offset is
+// -32 * sum_g scale_g * bsum_g, one more pair of MFMAs per tile and super-block (bsum = 64 a + b as for Q4_K).
+// Per super-block and output: acc += (d * d8) * (sum_g scale_g * dot_g - 32 * sum_g scale_g * bsum_g).
+struct GemmGeo6 {
+  static constexpr int NT = 2, CW = 32;
+  static constexpr int QLSTR = 36, QHSTR = 20, BSTR = 68;
+  // words: A ql | A qh | A scales (16 bytes / row) | A d f32 | B quants | B d8 f32 | B bsum low parts (16 bytes / column) | high
+  static constexpr int O_QH = 64 * QLSTR, O_SC = O_QH + 64 * QHSTR, O_D = O_SC + 64 * 4, O_BQ = O_D + 64;
+  static constexpr int O_BD = O_BQ + CW * BSTR, O_BLO = O_BD + CW, O_BHI = O_BLO + 4 * CW, BUF_WORDS = O_BHI + 4 * CW;
+  static constexpr int LDS_BYTES = 2 * BUF_WORDS * 4;
+};
+
+__global__ __launch_bounds__(256) void k_gemm_mfma_q6k(const char* __restrict__ w, size_t off_qh, const char* __restrict__ act,
+                                                       size_t act_stride, size_t off_d, size_t off_aux, float* __restrict__ out,
+                                                       int m, int nsb, int b, int row_tiles) {
+  using G = GemmGeo6;
+  constexpr int NT = G::NT, CW = G::CW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  int rt, ct;
+  {
+    const int col_tiles = (int)gridDim.x / row_tiles;
+    if ((row_tiles & 7) == 0) {
+      const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+      ct = j % col_tiles;
+      rt = (j / col_tiles) * 8 + x;
+    } else {
+      rt = (int)blockIdx.x % row_tiles;
+      ct = (int)blockIdx.x / row_tiles;
+    }
+  }
+  const int r0 = rt * 64, c0 = ct * CW;
+  const size_t nblk = off_qh / 128;  // blocks in the tensor
+  const i32x4* wql = (const i32x4*)w;
+  const i32x4* wqh = (const i32x4*)(w + off_qh);
+  const i32x4* wsc = (const i32x4*)(w + off_qh + nblk * 64);
+  const unsigned short* wd = (const unsigned short*)(w + off_qh + nblk * 80);
+
+  i32x4 rql[2], rqh, rsc, rb[2], rbs;
+  unsigned short rdw = 0;
+  float rd8 = 0.f;
+  auto fetch = [&](int sb) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int t = tid + 256 * u, row = t >> 3, pc = t & 7;
+      const int grow = r0 + row < m ? r0 + row : m - 1;
+      rql[u] = __builtin_nontemporal_load(wql + ((size_t)grow * nsb + sb) * 8 + pc);
+    }
+    {
+      const int row = tid >> 2, pc = tid & 3;
+      const int grow = r0 + row < m ? r0 + row : m - 1;
+      rqh = __builtin_nontemporal_load(wqh + ((size_t)grow * nsb + sb) * 4 + pc);
+    }
+    if (tid < 64) {
+      const int grow = r0 + tid < m ? r0 + tid : m - 1;
+      rsc = __builtin_nontemporal_load(wsc + (size_t)grow * nsb + sb);
+      rdw = wd[(size_t)grow * nsb + sb];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int t = tid + 256 * u, col = t >> 4, pc = t & 15;
+      const int gcol = c0 + col < b ? c0 + col : b - 1;
+      rb[u] = *((const i32x4*)(act + (size_t)gcol * act_stride) + (size_t)sb * 16 + pc);
+    }
+    if (tid < CW) {
+      const int gcol = c0 + tid < b ? c0 + tid : b - 1;
+      rd8 = ((const float*)(act + (size_t)gcol * act_stride + off_d))[sb];
+    }
+    if (tid < 2 * CW) {
+      const int col = tid >> 1, gcol = c0 + col < b ? c0 + col : b - 1;
+      rbs = *((const i32x4*)(act + (size_t)gcol * act_stride + off_aux) + (size_t)sb * 2 + (tid & 1));  // 8 of the 16 bsums
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned* S = (unsigned*)lds_raw + (size_t)buf * G::BUF_WORDS;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int t = tid + 256 * u, row = t >> 3, pc = t & 7;
+      *(i32x4*)(S + row * G::QLSTR + pc * 4) = rql[u];
+    }
+    *(i32x4*)(S + G::O_QH + (tid >> 2) * G::QHSTR + (tid & 3) * 4) = rqh;
+    if (tid < 64) {
+      *(i32x4*)(S + G::O_SC + tid * 4) = rsc;
+      ((float*)S)[G::O_D + tid] = h2f(rdw);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int t = tid + 256 * u, col = t >> 4, pc = t & 15;
+      *(i32x4*)(S + G::O_BQ + col * G::BSTR + pc * 4) = rb[u];
+    }
+    if (tid < CW) ((float*)S)[G::O_BD + tid] = rd8;
+    if (tid < 2 * CW) {  // eight 16-element quant sums -> (b, a) byte pairs: bsum = 64 a + b
+      unsigned lo[2] = {0u, 0u}, hi[2] = {0u, 0u};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int w2 = rbs[q];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int bs = e ? (int)(short)((unsigned)w2 >> 16) : (int)(short)(w2 & 0xffff);
+          const int bl = ((bs + 32) & 63) - 32, bh = (bs - bl) >> 6;
+          const int k = 2 * q + e;  // 0..7 within this half
+          lo[k >> 2] |= ((unsigned)bl & 0xffu) << (8 * (k & 3));
+          hi[k >> 2] |= ((unsigned)bh & 0xffu) << (8 * (k & 3));
+        }
+      }
+      const int col = tid >> 1, half = tid & 1;
+      S[G::O_BLO + col * 4 + half * 2] = lo[0];
+      S[G::O_BLO + col * 4 + half * 2 + 1] = lo[1];
+      S[G::O_BHI + col * 4 + half * 2] = hi[0];
+      S[G::O_BHI + col * 4 + half * 2 + 1] = hi[1];
+    }
+  };
+
+  f32x2 F[NT][2];
+#pragma unroll
+  for (int jt = 0; jt < NT; jt++) F[jt][0] = F[jt][1] = f32x2{0.0f, 0.0f};
+
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int sb = 0; sb < nsb; sb++) {
+    const int buf = sb & 1;
+    fetch(sb + 1 < nsb ? sb + 1 : sb);
+    const unsigned* S = (const unsigned*)lds_raw + (size_t)buf * G::BUF_WORDS;
+    const unsigned* qlrow = S + (16 * wave + i) * G::QLSTR;
+    const unsigned* qhrow = S + G::O_QH + (16 * wave + i) * G::QHSTR;
+    const f32x4 dw4 = *(const f32x4*)((const float*)S + G::O_D + 16 * wave + 4 * g);
+    int iacc[NT][4];
+#pragma unroll
+    for (int jt = 0; jt < NT; jt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) iacc[jt][r] = 0;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {  // half of the super-block: 128 elements, scale groups 8h .. 8h + 7
+      // the 8 group scales of this half for the four rows this lane's accumulators belong to (two words per row)
+      unsigned sc_lo[4], sc_hi[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const unsigned long long t2 = *(const unsigned long long*)(S + G::O_SC + (16 * wave + 4 * g + r) * 4 + 2 * h);
+        sc_lo[r] = (unsigned)t2;
+        sc_hi[r] = (unsigned)(t2 >> 32);
+      }
+      const unsigned long long hw = *(const unsigned long long*)(qhrow + 8 * h + 2 * g);
+#pragma unroll 2
+      for (int c = 0; c < 4; c++) {  // unit (h, c): elements 128 h + 32 c + [0, 32)
+        const unsigned long long lw = *(const unsigned long long*)(qlrow + 16 * h + 8 * (c & 1) + 2 * g);
+        const unsigned long long nib = ((c >> 1) ? (lw >> 4) : lw) & 0x0F0F0F0F0F0F0F0Full;
+        const unsigned long long top = ((hw >> (2 * c)) & 0x0303030303030303ull) << 4;
+        const long A = (long)(nib | top);
+        const long A0 = g < 2 ? A : 0l, A1 = g < 2 ? 0l : A;  // first / second 16-element scale group of the unit
+        const int sh = 16 * (c & 1);  // scales 2c, 2c + 1 of the half: bytes (2c & 3), +1 of word c >> 1
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) {
+          const long Bf = *(const long*)(S + G::O_BQ + (16 * jt + i) * G::BSTR + 32 * h + 8 * c + 2 * g);
+          const i32x4 D0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A0, Bf, i32x4{0, 0, 0, 0}, 0, 0, 0);
+          const i32x4 D1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A1, Bf, i32x4{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const unsigned sw = ((c >> 1) ? sc_hi[r] : sc_lo[r]) >> sh;
+            const int s0 = (int)(signed char)(sw & 0xffu), s1 = (int)(signed char)((sw >> 8) & 0xffu);
+            iacc[jt][r] += __mul24(D0[r], s0) + __mul24(D1[r], s1);
+          }
+        }
+      }
+    }
+    // offset term: (16 scales of row i) x (16 quant-sum parts of column i), k-slot groups 0 and 1; the others feed zeros
+    const long As = g < 2 ? *(const long*)(S + G::O_SC + (16 * wave + i) * 4 + 2 * g) : 0l;
+    const f32x2 dw01 = {dw4[0], dw4[1]}, dw23 = {dw4[2], dw4[3]};
+#pragma unroll
+    for (int jt = 0; jt < NT; jt++) {
+      const long Bl = g < 2 ? *(const long*)(S + G::O_BLO + (16 * jt + i) * 4 + 2 * g) : 0l;
+      const long Bh = g < 2 ? *(const long*)(S + G::O_BHI + (16 * jt + i) * 4 + 2 * g) : 0l;
+      const i32x4 Dl = __builtin_amdgcn_mfma_i32_16x16x32_i8(As, Bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
+      const i32x4 Dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(As, Bh, i32x4{0, 0, 0, 0}, 0, 0, 0);
+      const float d8 = ((const float*)S)[G::O_BD + 16 * jt + i];
+      const f32x2 d88 = {d8, d8};
+      const f32x2 v01 = {(float)(iacc[jt][0] - 32 * (Dl[0] + 64 * Dh[0])), (float)(iacc[jt][1] - 32 * (Dl[1] + 64 * Dh[1]))};
+      const f32x2 v23 = {(float)(iacc[jt][2] - 32 * (Dl[2] + 64 * Dh[2])), (float)(iacc[jt][3] - 32 * (Dl[3] + 64 * Dh[3]))};
+      F[jt][0] += (dw01 * d88) * v01;
+      F[jt][1] += (dw23 * d88) * v23;
+    }
+    commit(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int jt = 0; jt < NT; jt++) {
+    const int col = c0 + 16 * jt + i;
+    if (col >= b) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 16 * wave + g * 4 + r;
+      if (row < m) out[(size_t)col * m + row] = F[jt][r >> 1][r & 1];
+    }
+  }
+}
+
 // returns false when the shape / format is not covered (the caller falls back to one GEMV per batch row)
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
                       crabml_hip_device::ProfRec* rec) {
-  if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K) return false;
+  if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K) return false;
   if (b < 16 || m == 0 || k % 32 != 0) return false;
   hipStream_t st = dev->stream;
   const char* wp = (const char*)w->ptr;
+  if (w->dtype == CRABML_HIP_Q6_K) {
+    if (k % 256 != 0) return false;
+    const ActLayout alk = act_layout(CRABML_HIP_Q8_K, k);
+    const int nsb = (int)(k / 256), rtl = (int)((m + 63) / 64), ctl = (int)((b + GemmGeo6::CW - 1) / GemmGeo6::CW);
+    launch_k(st, rec, k_gemm_mfma_q6k, dim3(rtl * ctl), dim3(256), GemmGeo6::LDS_BYTES, wp, (size_t)w->wl.off_scale, (const char*)act,
+             alk.total, alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl);
+    return true;
+  }
   if (w->dtype == CRABML_HIP_Q4_K) {
     if (k % 256 != 0) return false;
     const ActLayout alk = act_layout(CRABML_HIP_Q8_K, k);

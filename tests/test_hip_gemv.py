@@ -171,6 +171,22 @@ def test_batched_rhs_q4_k_on_the_matrix_cores(ca, hdev, odev):
         assert np.all(np.abs(got[0] - one) <= gemv_order_bound(raw, typ, x[:k], m, k) * GEMV_REL * 8 + 1e-30)
 
 
+def test_batched_rhs_q6_k_on_the_matrix_cores(ca, hdev, odev):
+    """Q6_K weights x >= 16 Q8_K rows (k_gemm_mfma_q6k): every 32-element unit is multiplied twice with half of the weight
+    operand zeroed (a Q6_K scale covers 16 elements), 6-bit values rebuilt from ql + qh, int8 group scales folded in
+    integers, the -32 offset as an MFMA over (scales x quant sums).  Within the GEMV bound of the oracle."""
+    for (m, k, b) in [(16, 256, 16), (37, 512, 17), (100, 1024, 40), (256, 256, 64), (64, 2048, 100), (1000, 4096, 33)]:
+        typ, raw, _ = make("Q6_K", m, k, m + k + b)
+        rng = np.random.default_rng(b)
+        x = rng.standard_normal(b * k).astype(np.float32)
+        w = ca.HipTensor.from_cpu(raw, [m, k], ca.GGMLType.Q6K, hdev)
+        got = w.matmul_vec(ca.HipTensor.new(x, [b, k], hdev)).export().reshape(b, m)
+        ref = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(x, [b, k], odev)).export().reshape(b, m)
+        for r in range(b):
+            bound = gemv_order_bound(raw, typ, x[r * k:(r + 1) * k], m, k) * GEMV_REL * 8 + 1e-30
+            assert np.all(np.abs(got[r] - ref[r]) <= bound), f"m={m} k={k} b={b} row {r}: {np.max(np.abs(got[r] - ref[r]) / bound)}"
+
+
 def test_gemv_errors(ca, hdev):
     typ, raw, x = make("Q4_0", 8, 64, 3)
     w = ca.HipTensor.from_cpu(raw, [8, 64], ca.GGMLType.Q4_0, hdev)
