@@ -1,5 +1,7 @@
-// fused.hip -- the fused Llama decode step (crabml_hip_llama_*): the hot path as 8 kernels per layer,
-// replayed from one hipGraph with token id / position resident in device memory.
+// fused.hip -- the fused Llama decode step (crabml_hip_llama_*): the hot path as 5 kernels per layer, replayed from one
+// hipGraph with token id / position resident in device memory, plus the batched prefill.  This file is the HOST side
+// (context, segment enqueue, graph capture, C entry points); the kernels live in fused_common.hpp (quantizer lanes,
+// norm, q/k/v), fused_attention.hpp and fused_ffn.hpp (wo / ffn_down with the norm epilogue, gate/up, sampler).
 //
 // It serves exactly the op sequence Llama2Runner<T> issues for one token (crabml-llama2/src/llama2.rs):
 //   forward_llama :213-281, forward_multi_query_attention :527-603, forward_ffn :605-638, classifier :184-211
@@ -16,1677 +18,9 @@
 //   k_argmax_step  greedy sampler (last maximum) + token/position advance
 #include <cmath>
 
-#include "dequant.hpp"
-#include "gemv_core.hpp"
-#include "kernels.hpp"
-
-namespace crabml_hip {
-
-// exp_f32_cached (buf_f32.rs:29-35)
-__device__ __forceinline__ float exp_cached_f(float x, const unsigned short* __restrict__ table) {
-  return h2f(table[f2h(x)]);
-}
-
-// ---- the rhs quantizer of matmul_vec, one 32-lane half-wave per 32-element block ------------------------------
-// Q81 = false: Q8_0 (buf_q8_0.rs:87-134: d = max|x| / 127, q = trunc(x / d) with the simd cast's NaN -> 0; aux = the
-// i32 sum of the block's quants -- exact, derived, used for Q4_0's -8 offset).  Q81 = true: Q8_1 (buf_q8_1.rs:90-129:
-// q = trunc(clamp(x / d, -128, 127)) with NaN -> -128, aux = the f16 s = d * sum q).  All 32 lanes of the half-wave
-// call it (dead lanes with live = false and v = 0).
-struct QLane {
-  signed char q;
-  unsigned short d;
-  int aux;
-};
-template <bool Q81>
-__device__ __forceinline__ QLane quant_lane32(float v, bool live) {
-  QLane o;
-  const float amax = half_max_f32(fabsf(v));
-  const float dd = amax / 127.0f;
-  o.d = f2h(dd);
-  if constexpr (!Q81) {
-    const int qi = rs_f32_as_i32(v / dd);
-    o.q = (signed char)(unsigned char)((unsigned)qi & 0xffu);  // `as i8` from i32 wraps
-    o.aux = half_sum_i32(live ? (int)o.q : 0);
-  } else {
-    const float c = fminf(fmaxf(v / dd, -128.0f), 127.0f);  // Rust f32::max / min return the non-NaN operand
-    const int qi = (int)c;
-    o.q = (signed char)qi;
-    const int s = half_sum_i32(live ? qi : 0);
-    o.aux = (int)f2h((float)s * dd);
-  }
-  return o;
-}
-template <bool Q81>
-__device__ __forceinline__ void store_qaux(void* aux, int blk, int v) {
-  if constexpr (Q81)
-    ((unsigned short*)aux)[blk] = (unsigned short)v;
-  else
-    ((int*)aux)[blk] = v;
-}
-
-// ---- weight prefetch into the Infinity Cache ---------------------------------------------------------
-// The norm+quantize and attention stages are latency-bound single-/few-workgroup kernels: HBM idles for
-// ~6-8 us while they run.  Spare workgroups of those launches (one per otherwise idle CU) stream the NEXT
-// GEMV's weights with plain loads and drop them: the lines land in the 256 MiB memory-side Infinity Cache,
-// so the following HBM-bound GEMV starts on warm data.  Pure performance hint: no result depends on it.
-struct PrefetchPlan {
-  const void* p[3];
-  unsigned long long n[3];  // bytes (multiples of 16)
-  int* sink;
-};
-__device__ __forceinline__ void prefetch_wg(const PrefetchPlan& pf, int wg, int nwg) {
-  int acc = 0;
-#pragma unroll 1
-  for (int sp = 0; sp < 3; sp++) {
-    const i32x4* base = (const i32x4*)pf.p[sp];
-    const size_t n16 = pf.n[sp] / 16;
-    if (!base || n16 == 0) continue;
-    const size_t per = (n16 + nwg - 1) / nwg;
-    const size_t lo = (size_t)wg * per, hi = lo + per < n16 ? lo + per : n16;
-    size_t i = lo + threadIdx.x;
-    const size_t st = blockDim.x;
-    for (; i + 3 * st < hi; i += 4 * st) {
-      i32x4 a = base[i], b = base[i + st], c = base[i + 2 * st], d = base[i + 3 * st];
-      acc ^= a[0] ^ b[1] ^ c[2] ^ d[3];
-    }
-    for (; i < hi; i += st) acc ^= base[i][0];
-  }
-  if (acc == 0x7eadbeef) *pf.sink = acc;  // never true in practice; keeps the loads alive
-}
-
-// ---- embedding lookup: copy_rows_from(token_embed, [token]) (llama2.rs:222-223) ----------------------
-__global__ __launch_bounds__(256) void k_embed(const char* __restrict__ w, int dtype, size_t off_scale,
-                                               const int* __restrict__ token_d, int dim, float* __restrict__ x) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= dim) return;
-  // blockIdx.y: row of a prefill batch (token ids and output rows are consecutive); 0 for a decode step
-  x[(size_t)blockIdx.y * dim + i] = dequant_elem(w, dtype, off_scale, (size_t)token_d[blockIdx.y] * dim + i);
-}
-
-// ---- rmsnorm * weight -> Q8_0 planes ------------------------------------------------------------------
-// rms_norm.rs:33-46 (ordered 32-chunk sums, serial chunk accumulation, true division), arithmetic.rs:57-66
-// (x * w), buf_q8_0.rs:87-134 (truncating quantizer).  x itself is left untouched: it is the residual.
-// Executed by ONE 1024-thread workgroup (16 waves: 4 per SIMD, so the two IEEE divisions per element
-// overlap across waves).  It is pure latency, so every global load (x and the norm weight) is issued up
-// front in one batch and kept in registers (NIT values per thread); the ordered chunk sums are taken from
-// an LDS copy.  Outputs (q / d / isum) may live in LDS (GEMV prologue) or in global memory.
-struct NormLds {  // carved from dynamic LDS: xs[cols] f32 | chunk_sums[cols/32] f32
-  float* xs;
-  float* chunk_sums;
-};
-__host__ __device__ inline size_t norm_lds_bytes(int cols) { return (size_t)(cols + cols / 32) * sizeof(float); }
-
-// QUANT = false: the normalized row goes to xn_out as f32 (formats whose rhs is not Q8_0 quantize it afterwards)
-template <int NIT, bool QUANT, bool Q81 = false>  // cols <= NIT * 1024, blockDim.x == 1024; ends with the outputs written
-__device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const float* __restrict__ addv,
-                                                 const float* __restrict__ w, int cols, float eps, NormLds L,
-                                                 float* s_rms, signed char* q, unsigned short* d, void* isum,
-                                                 float* __restrict__ xn_out, int half) {
-  const int nchunks = cols / 32;
-  const int tid = threadIdx.x;
-  float xv[NIT], wv[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    int i = it * 1024 + tid;
-    xv[it] = i < cols ? x[i] : 0.f;
-    wv[it] = i < cols ? w[i] : 0.f;
-    // tensor-parallel: the all-reduced wo / ffn_down output is added to the residual stream here
-    // (x = matmul_out + x, llama2.rs:266 / :636) and written back
-    if (addv != nullptr && i < cols) {
-      xv[it] = addv[i] + xv[it];
-      x[i] = xv[it];
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    int i = it * 1024 + tid;
-    if (i < cols) L.xs[i] = xv[it];
-  }
-  __syncthreads();
-  for (int c = tid; c < nchunks; c += 1024) {
-    const f32x4* p = (const f32x4*)(L.xs + c * 32);
-    float s = -0.0f, s1 = -0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      f32x4 t = p[j];
-      float& a = (half && j >= 4) ? s1 : s;
-      a += t[0] * t[0];
-      a += t[1] * t[1];
-      a += t[2] * t[2];
-      a += t[3] * t[3];
-    }
-    // half (fast mode): chunk = (rows 0..15 in order) + (rows 16..31 in order), the split the wo / ffn_down norm
-    // epilogue uses (two workgroups per chunk); otherwise the reference's 32-element scan (rms_norm.rs:35-38)
-    L.chunk_sums[c] = half ? s + s1 : s;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    // chunk sums are added strictly in chunk order (rms_norm.rs:35-40): wave 0 holds them in registers and
-    // v_readlane feeds a single dependent v_add chain.  Lanes past nchunks contribute +0.0 (exact).
-    float sum = 0.0f;
-    for (int base = 0; base < nchunks; base += 64) {
-      float v = base + tid < nchunks ? L.chunk_sums[base + tid] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < 64; i++) sum += rl_f(v, i);
-    }
-    if (tid == 0) *s_rms = sqrtf(sum / (float)cols + eps);
-  }
-  __syncthreads();
-  const float rms = *s_rms;
-#pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    int i = it * 1024 + tid;
-    if (it * 1024 < cols) {  // wave-uniform; 32-lane halves are entirely in or out of range (cols % 32 == 0)
-      bool live = i < cols;
-      float v = live ? (xv[it] / rms) * wv[it] : 0.f;
-      if constexpr (!QUANT) {
-        if (live) xn_out[i] = v;
-        continue;
-      }
-      const QLane o = quant_lane32<Q81>(v, live);
-      if (live) {
-        q[i] = o.q;
-        if ((tid & 31) == 0) {
-          d[i >> 5] = o.d;
-          store_qaux<Q81>(isum, i >> 5, o.aux);
-        }
-      }
-    }
-  }
-}
-
-template <int NIT, bool Q81>
-__global__ __launch_bounds__(1024) void k_norm_quant(float* __restrict__ x, const float* __restrict__ addv,
-                                                    const float* __restrict__ w, int cols, float eps,
-                                                    signed char* __restrict__ q, unsigned short* __restrict__ d,
-                                                    void* __restrict__ isum, PrefetchPlan pf, int half) {
-  if (blockIdx.x > 0) {  // spare workgroups: warm the Infinity Cache with the next GEMV's weights
-    prefetch_wg(pf, blockIdx.x - 1, gridDim.x - 1);
-    return;
-  }
-  extern __shared__ float lds[];
-  __shared__ float s_rms;
-  NormLds L{lds, lds + cols};
-  norm_quant_block<NIT, true, Q81>(x, addv, w, cols, eps, L, &s_rms, q, d, isum, nullptr, half);
-}
-template <int NIT>
-__global__ __launch_bounds__(1024) void k_norm_f32(float* __restrict__ x, const float* __restrict__ addv,
-                                                  const float* __restrict__ w, int cols, float eps, float* __restrict__ xn, int half) {
-  extern __shared__ float lds[];
-  __shared__ float s_rms;
-  NormLds L{lds, lds + cols};
-  norm_quant_block<NIT, false>(x, addv, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr, xn, half);
-}
-
-// batched prefill: one workgroup per row of x (rows, cols) -> xn (rows, cols)
-template <int NIT>
-__global__ __launch_bounds__(1024) void k_norm_f32_rows(float* __restrict__ x, const float* __restrict__ w, int cols, float eps,
-                                                       float* __restrict__ xn, int half) {
-  extern __shared__ float lds[];
-  __shared__ float s_rms;
-  NormLds L{lds, lds + cols};
-  norm_quant_block<NIT, false>(x + (size_t)blockIdx.x * cols, nullptr, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr,
-                               xn + (size_t)blockIdx.x * cols, half);
-}
-
-// ---- QKV epilogue: rope (rope.rs:47-63) + q scale (llama2.rs:565) + KV append (concatenate.rs:172-204) ---
-struct QkvEpi {
-  float* q_out;       // (n_heads * hd) f32, roped and scaled
-  void* kc;           // K cache of this layer [n_kv][seq_cap][hd]
-  void* vc;
-  const float* rope;  // [seq_cap][npairs][2] (cos, sin)
-  const int* pos_d;
-  float scale;        // 1 / sqrt(hd)
-  int dim, kv_dim, hd, rope_dim, npairs, seq_cap, kv16;
-};
-
-// position + rotation for the pair starting at row0, loaded early (before the weight stream is consumed)
-struct QkvPre {
-  int pos;
-  float c, s;
-  bool rot;
-};
-__device__ __forceinline__ QkvPre qkv_preload(const QkvEpi& e, int row0, int row_of_batch = 0) {
-  QkvPre p;
-  p.pos = *e.pos_d + row_of_batch;
-  p.c = 1.f;
-  p.s = 0.f;
-  p.rot = false;
-  if (row0 < e.dim + e.kv_dim) {
-    const int i = (row0 < e.dim ? row0 : row0 - e.dim) % e.hd;
-    if (i < e.rope_dim) {
-      const float* cs = e.rope + ((size_t)p.pos * e.npairs + (i >> 1)) * 2;
-      p.c = cs[0];
-      p.s = cs[1];
-      p.rot = true;
-    }
-  }
-  return p;
-}
-__device__ __forceinline__ void qkv_epilogue(const QkvEpi& e, const QkvPre& pre, int row0, float s0, float s1) {
-  const int pos = pre.pos;
-  if (row0 < e.dim + e.kv_dim) {  // q or k: rotate the (even, odd) pair
-    const int i = (row0 < e.dim ? row0 : row0 - e.dim) % e.hd;
-    float r0 = s0, r1 = s1;
-    if (pre.rot) {
-      float c = pre.c, s = pre.s;
-      r0 = s0 * c - s1 * s;
-      r1 = s0 * s + s1 * c;
-    }
-    if (row0 < e.dim) {
-      e.q_out[row0] = r0 * e.scale;
-      e.q_out[row0 + 1] = r1 * e.scale;
-    } else {
-      const int kr = row0 - e.dim;
-      const size_t o = ((size_t)(kr / e.hd) * e.seq_cap + pos) * e.hd + i;
-      if (e.kv16) {
-        ((unsigned short*)e.kc)[o] = f2h(r0);
-        ((unsigned short*)e.kc)[o + 1] = f2h(r1);
-      } else {
-        ((float*)e.kc)[o] = r0;
-        ((float*)e.kc)[o + 1] = r1;
-      }
-    }
-  } else {
-    const int vr = row0 - e.dim - e.kv_dim;
-    const size_t o = ((size_t)(vr / e.hd) * e.seq_cap + pos) * e.hd + (vr % e.hd);
-    if (e.kv16) {
-      ((unsigned short*)e.vc)[o] = f2h(s0);
-      ((unsigned short*)e.vc)[o + 1] = f2h(s1);
-    } else {
-      ((float*)e.vc)[o] = s0;
-      ((float*)e.vc)[o + 1] = s1;
-    }
-  }
-}
-
-struct Planes {
-  const i32x4* q;
-  const unsigned short* d;
-};
-// a Q6_K matrix standing in for one of a Q4_K layer's (llama.cpp *_K_M mixes): base = nullptr means "not used"
-struct Planes6 {
-  const char* base;
-  size_t off_qh;
-};
-
-template <int FMT>
-__global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e,
-                                             Planes6 wv6) {
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int row0 = wave * 2;
-  const int total = e.dim + 2 * e.kv_dim;
-  if (row0 >= total) return;
-  Planes w;
-  int local, m;
-  if (row0 < e.dim) {
-    w = wq; local = row0; m = e.dim;
-  } else if (row0 < e.dim + e.kv_dim) {
-    w = wk; local = row0 - e.dim; m = e.kv_dim;
-  } else {
-    w = wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
-  }
-  QkvPre pre{};
-  if (lane == 0) pre = qkv_preload(e, row0);
-  float acc[2];
-  bool done = false;
-  if constexpr (FMT == CRABML_HIP_Q4_K) {
-    if (wv6.base != nullptr && row0 >= e.dim + e.kv_dim) {  // the V rows of this layer are Q6_K (wave-uniform)
-      rows_partial_q6k<2>(wv6.base, wv6.off_qh, act, local, m, nb, lane, acc);
-      done = true;
-    }
-  }
-  if (!done) rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
-  float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
-  if (lane == 0) qkv_epilogue(e, pre, row0, s0, s1);
-}
-// strict mode: the three GEMVs ran in scalar order into tmp[dim + 2 kv_dim]; apply the same epilogue
-__global__ __launch_bounds__(256) void k_qkv_epi(const float* __restrict__ tmp, QkvEpi e) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  int total = (e.dim + 2 * e.kv_dim) / 2;
-  if (p < total) qkv_epilogue(e, qkv_preload(e, 2 * p), 2 * p, tmp[2 * p], tmp[2 * p + 1]);
-}
-
-// batched prefill: the three GEMMs wrote qb (B, dim), kb / vb (B, kv_dim); row r is position *pos_d + r
-__global__ __launch_bounds__(256) void k_qkv_epi_rows(const float* __restrict__ qb, const float* __restrict__ kb,
-                                                     const float* __restrict__ vb, QkvEpi e) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-  if (p >= (e.dim + 2 * e.kv_dim) / 2) return;
-  const int row0 = 2 * p;
-  const float* src = row0 < e.dim              ? qb + (size_t)r * e.dim + row0
-                     : row0 < e.dim + e.kv_dim ? kb + (size_t)r * e.kv_dim + (row0 - e.dim)
-                                               : vb + (size_t)r * e.kv_dim + (row0 - e.dim - e.kv_dim);
-  QkvEpi er = e;
-  er.q_out = e.q_out + (size_t)r * e.dim;
-  qkv_epilogue(er, qkv_preload(e, row0, r), row0, src[0], src[1]);
-}
-
-// softmax.rs:36-54 over scores[0..seq) in LDS, in place, by a 256-thread workgroup: max, exp through the f16 table,
-// row sum sequential up to 1024 positions (bit-exact) and a block tree beyond, true division.  F16: the
-// probabilities are then rounded to f16 (quantize_f32_f16 of the lhs, batch_matmul.rs:39).  Ends with a barrier.
-template <bool F16>
-__device__ __forceinline__ void softmax_row(float* scores, int seq, const unsigned short* __restrict__ exp_tab, float* s_red,
-                                            float* s_val_p) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float mx = -INFINITY;
-  for (int t = tid; t < seq; t += blockDim.x) mx = fmaxf(mx, scores[t]);
-  mx = wave_max_f32(mx);
-  if (lane == 0) s_red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-  __syncthreads();
-  float part = 0.0f;
-  {
-    // the table lookups are independent global gathers: 8 in flight per thread (long rows), summed in t order
-    const int bd = blockDim.x;
-    int t = tid;
-    for (; t + 7 * bd < seq; t += 8 * bd) {
-      float ev[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) ev[u] = exp_cached_f(scores[t + u * bd] - mx, exp_tab);
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        scores[t + u * bd] = ev[u];
-        part += ev[u];
-      }
-    }
-    for (; t < seq; t += bd) {
-      float ev = exp_cached_f(scores[t] - mx, exp_tab);
-      scores[t] = ev;
-      part += ev;
-    }
-  }
-  __syncthreads();
-  if (seq <= 1024) {
-    if (tid < 64) {
-      // sequential row sum (softmax.rs:43-48) without an LDS round trip per add: wave 0 holds 64 values per
-      // pass in registers and v_readlane feeds one dependent v_add chain; lanes past `seq` add +0.0 (exact)
-      float sum = 0.0f;
-      for (int base = 0; base < seq; base += 64) {
-        float v = base + tid < seq ? scores[base + tid] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
-      }
-      if (tid == 0) *s_val_p = sum;
-    }
-  } else {
-    part = wave_sum_f32(part);
-    if (lane == 0) s_red[wave] = part;
-    __syncthreads();
-    if (tid == 0) *s_val_p = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  }
-  __syncthreads();
-  const float sum = *s_val_p;
-  for (int t = tid; t < seq; t += blockDim.x) {
-    float pv = scores[t] / sum;
-    scores[t] = F16 ? h2f(f2h(pv)) : pv;  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), done once
-  }
-  __syncthreads();
-}
-
-// ---- attention: one workgroup per head -------------------------------------------------------------------
-// batch_matmul.rs: f16 cache -> q rounded to f16, f32-accumulated QK^T in k order (buf_f16.rs:83-97),
-// GQA head = h / (n_heads/n_kv); PV accumulated in f16 with a rounding after the product and after the sum
-// (buf_f16.rs:152-163).  f32 cache -> plain f32 loops, kv head = h % n_kv (batch_matmul.rs:61-67).
-// softmax.rs:36-54 with the f16 exp table; the row sum is sequential (bit-exact) up to 1024 positions and a
-// block tree beyond that (documented tolerance 1e-6 relative).
-template <bool KV16>
-__global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const void* __restrict__ kc,
-                                              const void* __restrict__ vc, const int* __restrict__ pos_d,
-                                              const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
-                                              signed char* __restrict__ xq, unsigned short* __restrict__ xd,
-                                              void* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap,
-                                              PrefetchPlan pf, int q81) {
-  if ((int)blockIdx.x >= n_heads) {
-    prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
-    return;
-  }
-  extern __shared__ float lds[];
-  __shared__ float s_red[4];
-  __shared__ float s_val;
-  float* scores = lds;
-  float* qs = lds + seq_cap;
-  const int tid = threadIdx.x;
-  const int head = blockIdx.x;
-  const int kvh = KV16 ? head / (n_heads / n_kv) : head % n_kv;
-  // blockIdx.y: row of a prefill batch = one more cached position per row (causal); 0 for a decode step
-  q += (size_t)blockIdx.y * n_heads * hd;
-  out += (size_t)blockIdx.y * n_heads * hd;
-  // Position-independent loads go out first, so that their (cold, cross-XCD) latency overlaps the q staging
-  // instead of adding two more serial round trips: the first 64 halves of the K row this thread will score
-  // and the first 16 V values of the output column it will accumulate.  Rows past `seq` are read but unused.
-  i32x4 kpre[8];
-  const bool kp = KV16 && hd >= 64 && tid < seq_cap;
-  if (kp) {
-    const unsigned short* kr0 = (const unsigned short*)kc + ((size_t)kvh * seq_cap + tid) * hd;
-#pragma unroll
-    for (int u = 0; u < 8; u++) kpre[u] = *(const i32x4*)(kr0 + 8 * u);
-  }
-  unsigned short vpre[16];
-  const bool vp = KV16 && tid < hd && seq_cap >= 16;
-  if (vp) {
-    const unsigned short* vr0 = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + tid;
-#pragma unroll
-    for (int u = 0; u < 16; u++) vpre[u] = vr0[(size_t)u * hd];
-  }
-  const int seq = *pos_d + 1 + (int)blockIdx.y;
-  for (int i = tid; i < hd; i += blockDim.x) {
-    float v = q[head * hd + i];
-    qs[i] = KV16 ? h2f(f2h(v)) : v;  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
-  }
-  __syncthreads();
-  // ---- scores[t] = q . K[t]
-  for (int t = tid; t < seq; t += blockDim.x) {
-    float acc = 0.0f;
-    if (KV16) {
-      const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
-      int i = 0;
-      for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
-        i32x4 kv[8];
-        if (kp && t == tid && i == 0) {
-#pragma unroll
-          for (int u = 0; u < 8; u++) kv[u] = kpre[u];
-        } else {
-#pragma unroll
-          for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            unsigned w = (unsigned)kv[u][j];
-            acc += qs[i + 8 * u + 2 * j] * h2f((unsigned short)(w & 0xffffu));
-            acc += qs[i + 8 * u + 2 * j + 1] * h2f((unsigned short)(w >> 16));
-          }
-      }
-      for (; i + 8 <= hd; i += 8) {
-        i32x4 kv = *(const i32x4*)(kr + i);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          unsigned w = (unsigned)kv[j];
-          acc += qs[i + 2 * j] * h2f((unsigned short)(w & 0xffffu));
-          acc += qs[i + 2 * j + 1] * h2f((unsigned short)(w >> 16));
-        }
-      }
-      for (; i < hd; i++) acc += qs[i] * h2f(kr[i]);
-    } else {
-      const float* kr = (const float*)kc + ((size_t)kvh * seq_cap + t) * hd;
-      int i = 0;
-      for (; i + 4 <= hd; i += 4) {
-        f32x4 kv = *(const f32x4*)(kr + i);
-        acc += qs[i] * kv[0];
-        acc += qs[i + 1] * kv[1];
-        acc += qs[i + 2] * kv[2];
-        acc += qs[i + 3] * kv[3];
-      }
-      for (; i < hd; i++) acc += qs[i] * kr[i];
-    }
-    scores[t] = acc;
-  }
-  __syncthreads();
-  // ---- softmax (in place; probabilities rounded to f16 for the f16 cache)
-  softmax_row<KV16>(scores, seq, exp_tab, s_red, &s_val);
-  // ---- out[n] = sum_t p[t] * V[t][n]
-  float val = 0.0f;
-  const int n = tid;
-  if (n < hd) {
-    if (KV16) {
-      const unsigned short* vr = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + n;
-      _Float16 c = (_Float16)0.0f;  // native f16 product and sum (devutil.hpp): the chain is one v_add_f16 per position
-      int t = 0;
-      for (; t + 16 <= seq; t += 16) {  // 16 loads in flight, then the (inherently serial) f16 accumulate chain
-        unsigned short vv[16];
-        if (vp && t == 0) {
-#pragma unroll
-          for (int u = 0; u < 16; u++) vv[u] = vpre[u];
-        } else {
-#pragma unroll
-          for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-          const _Float16 prod = hbits(vv[u]) * (_Float16)scores[t + u];  // scores hold f16-representable values
-          c = c + prod;
-        }
-      }
-      for (; t < seq; t++) {
-        const _Float16 prod = hbits(vr[(size_t)t * hd]) * (_Float16)scores[t];
-        c = c + prod;
-      }
-      val = (float)c;
-    } else {
-      const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
-      float c = 0.0f;
-      int t = 0;
-      for (; t + 16 <= seq; t += 16) {
-        float vv[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
-#pragma unroll
-        for (int u = 0; u < 16; u++) c += scores[t + u] * vv[u];
-      }
-      for (; t < seq; t++) c += scores[t] * vr[(size_t)t * hd];
-      val = c;
-    }
-    out[head * hd + n] = val;
-  }
-  // ---- quantize the head's output for wo (only when blocks do not straddle heads)
-  if (xq != nullptr) {
-    const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
-    const float vq = live ? val : 0.f;
-    const QLane o = q81 ? quant_lane32<true>(vq, live) : quant_lane32<false>(vq, live);
-    if (live) {
-      int e = head * hd + n;
-      xq[e] = o.q;
-      if ((n & 31) == 0) {
-        xd[e >> 5] = o.d;
-        if (q81)
-          store_qaux<true>(xisum, e >> 5, o.aux);
-        else
-          store_qaux<false>(xisum, e >> 5, o.aux);
-      }
-    }
-  }
-}
-
-// ---- attention at long context: the same arithmetic over every CU ----------------------------------------------
-// One workgroup per head streams its whole K and V through one CU (~26 GB/s): 223 us per layer at 4000 cached
-// positions.  From `attn_long_from` positions on the step uses three kernels instead (f16 cache, head_dim % 32
-// == 0, n_heads / n_kv in {1, 2, 4, 8}); every rounding point and summation order is unchanged:
-//   k_attn_scores   (kv head, 128-position split): each thread scores ONE cached position against the G q heads
-//                   that share the kv head -- K is read once, f32 accumulation in k order (buf_f16.rs:83-97);
-//   k_attn_softmax  (head): softmax_row over the score row, probabilities rounded to f16;
-//   k_attn_pv       (kv head, 32-dim slice): V tiles are staged through LDS by the whole workgroup (read once for
-//                   the G heads), and G x 16 lanes run the f16 chains, two dims per lane on packed f16 math
-//                   (v_pk_mul_f16 + v_pk_add_f16 = the half crate's product / sum roundings, devutil.hpp).
-template <int G>
-__global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q, const unsigned short* __restrict__ kc,
-                                                     const int* __restrict__ pos_d, float* __restrict__ scores_g,
-                                                     int n_kv, int hd, int seq_cap, int nsplit) {
-  // one thread per (cached position, q head of the group): the G threads of a position sit in adjacent lanes and
-  // read the same K row (one fetch); each runs its own k-ordered f32 accumulation (buf_f16.rs:83-97)
-  extern __shared__ float lds[];  // qs[G][hd]
-  constexpr int TS = 256 / G;     // positions per workgroup
-  const int tid = threadIdx.x;
-  const int j = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
-  const int seq = *pos_d + 1;
-  if (sp * TS >= seq) return;
-  for (int idx = tid; idx < G * hd; idx += 256) {
-    const int g = idx / hd, i = idx - g * hd;
-    lds[idx] = h2f(f2h(q[(size_t)(j * G + g) * hd + i]));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
-  }
-  __syncthreads();
-  const int g = tid % G;
-  const int t = sp * TS + tid / G;
-  if (t >= seq) return;
-  const unsigned short* kr = kc + ((size_t)j * seq_cap + t) * hd;
-  const float* qg = lds + g * hd;
-  float acc = 0.0f;
-  int i = 0;
-  for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
-    i32x4 kv[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-#pragma unroll
-      for (int w4 = 0; w4 < 4; w4++) {
-        const unsigned w = (unsigned)kv[u][w4];
-        acc += qg[i + 8 * u + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
-        acc += qg[i + 8 * u + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
-      }
-  }
-  for (; i + 8 <= hd; i += 8) {
-    const i32x4 kv = *(const i32x4*)(kr + i);
-#pragma unroll
-    for (int w4 = 0; w4 < 4; w4++) {
-      const unsigned w = (unsigned)kv[w4];
-      acc += qg[i + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
-      acc += qg[i + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
-    }
-  }
-  for (; i < hd; i++) acc += qg[i] * h2f(kr[i]);
-  scores_g[(size_t)(j * G + g) * seq_cap + t] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ scores_g, const int* __restrict__ pos_d,
-                                                      const unsigned short* __restrict__ exp_tab,
-                                                      unsigned short* __restrict__ p16, int seq_cap) {
-  extern __shared__ float lds[];
-  __shared__ float s_red[4];
-  __shared__ float s_val;
-  const int head = blockIdx.x, seq = *pos_d + 1;
-  for (int t = threadIdx.x; t < seq; t += blockDim.x) lds[t] = scores_g[(size_t)head * seq_cap + t];
-  __syncthreads();
-  softmax_row<true>(lds, seq, exp_tab, s_red, &s_val);
-  for (int t = threadIdx.x; t < seq; t += blockDim.x) p16[(size_t)head * seq_cap + t] = f2h(lds[t]);  // exact: already f16 values
-}
-
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-#define ATTN_PV_TILE 256
-#define ATTN_PV_ROW (ATTN_PV_TILE + 4)  // words per LDS row: 16-byte aligned rows, shifted by 4 banks from each other
-template <int G>
-__global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restrict__ p16, const unsigned short* __restrict__ vc,
-                                                 const int* __restrict__ pos_d, float* __restrict__ out,
-                                                 signed char* __restrict__ xq, unsigned short* __restrict__ xd,
-                                                 void* __restrict__ xisum, int hd, int seq_cap, int q81) {
-  constexpr int T = ATTN_PV_TILE, ROW = ATTN_PV_ROW;
-  // LDS, two buffers each: V tile transposed to [16 dim pairs][T] words (a chain lane reads 4 consecutive positions
-  // of its dim pair with one ds_read_b128), P tile [G][T] words holding {p, p} (the packed multiplier, ready-made)
-  __shared__ __attribute__((aligned(16))) unsigned vt[2][16 * ROW];
-  __shared__ __attribute__((aligned(16))) unsigned pt[2][G * ROW];
-  const int tid = threadIdx.x;
-  const int nslice = hd / 32;
-  const int j = blockIdx.x / nslice, sl = blockIdx.x % nslice;
-  const int seq = *pos_d + 1;
-  const unsigned short* vbase = vc + (size_t)j * seq_cap * hd + sl * 32;
-  const int ntiles = (seq + T - 1) / T;
-  // loader role (all threads): V piece = 16 B (4 dim pairs) of row (tid / 4) + 64 r, piece tid % 4;
-  // P piece = 16 B = 8 positions of one head
-  i32x4 vreg[4], preg;
-  auto issue = [&](int tile) {
-    const int t0 = tile * T;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      int t = t0 + (tid >> 2) + 64 * r;
-      t = t < seq_cap ? t : seq_cap - 1;  // rows past seq are read (inside the cache allocation) but never used
-      vreg[r] = *(const i32x4*)(vbase + (size_t)t * hd + (tid & 3) * 8);
-    }
-    if (tid < G * (T / 8)) {
-      const int g = tid / (T / 8), c8 = tid % (T / 8);
-      int t = t0 + c8 * 8;
-      t = t + 8 <= seq_cap ? t : seq_cap - 8;  // only past the end of the cache: those positions are never consumed
-      preg = *(const i32x4*)(p16 + (size_t)(j * G + g) * seq_cap + t);
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int tl = (tid >> 2) + 64 * r;
-#pragma unroll
-      for (int i = 0; i < 4; i++) vt[buf][((tid & 3) * 4 + i) * ROW + tl] = (unsigned)vreg[r][i];
-    }
-    if (tid < G * (T / 8)) {
-      const int g = tid / (T / 8), c8 = tid % (T / 8);
-      unsigned pp[8];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const unsigned w = (unsigned)preg[i];
-        const unsigned a = w & 0xffffu, b = w >> 16;
-        pp[2 * i] = a | (a << 16);
-        pp[2 * i + 1] = b | (b << 16);
-      }
-      *(i32x4*)(&pt[buf][g * ROW + c8 * 8]) = i32x4{(int)pp[0], (int)pp[1], (int)pp[2], (int)pp[3]};
-      *(i32x4*)(&pt[buf][g * ROW + c8 * 8 + 4]) = i32x4{(int)pp[4], (int)pp[5], (int)pp[6], (int)pp[7]};
-    }
-  };
-  // chain role: lane c < G * 16 owns dims 2 dp, 2 dp + 1 of head j * G + g
-  const bool chain = tid < G * 16;
-  const int g = tid >> 4, dp = tid & 15;
-  h16x2 c2 = {(_Float16)0.0f, (_Float16)0.0f};
-  issue(0);
-  commit(0);
-  __syncthreads();
-  for (int tile = 0; tile < ntiles; tile++) {
-    const int buf = tile & 1;
-    if (tile + 1 < ntiles) issue(tile + 1);
-    if (chain) {
-      const int nt = seq - tile * T < T ? seq - tile * T : T;
-      const unsigned* vrow = &vt[buf][dp * ROW];
-      const unsigned* prow = &pt[buf][g * ROW];
-      int t = 0;
-      // NB rounds of 8 positions: all the LDS reads of a round go out before its (serial) packed adds, so the LDS
-      // latency is paid once per round
-#define PV_ROUND(NB)                                                                                         \
-  for (; t + 8 * NB <= nt; t += 8 * NB) {                                                                    \
-    i32x4 vq[2 * NB], pq[2 * NB];                                                                            \
-    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) {                                                     \
-      vq[b] = *(const i32x4*)(vrow + t + 4 * b);                                                             \
-      pq[b] = *(const i32x4*)(prow + t + 4 * b);                                                             \
-    }                                                                                                        \
-    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) _Pragma("unroll") for (int u = 0; u < 4; u++) {       \
-      const h16x2 pr = __builtin_bit_cast(h16x2, (unsigned)vq[b][u]) * __builtin_bit_cast(h16x2, (unsigned)pq[b][u]); \
-      c2 = c2 + pr;                                                                                          \
-    }                                                                                                        \
-  }
-      PV_ROUND(4)
-      PV_ROUND(1)
-#undef PV_ROUND
-      for (; t < nt; t++) {
-        const h16x2 pr = __builtin_bit_cast(h16x2, vrow[t]) * __builtin_bit_cast(h16x2, prow[t]);
-        c2 = c2 + pr;
-      }
-    }
-    if (tile + 1 < ntiles) commit(buf ^ 1);  // the other buffer was last read one iteration ago (barrier below)
-    __syncthreads();
-  }
-  if (!chain) return;
-  const float v0 = (float)c2[0], v1 = (float)c2[1];
-  const int head = j * G + g;
-  const int e0 = head * hd + sl * 32 + 2 * dp;
-  out[e0] = v0;
-  out[e0 + 1] = v1;
-  if (xq != nullptr) {  // the rhs block of the 32 dims held by this 16-lane DPP row (quant_lane32's arithmetic)
-    const float amax = row16_max_f32(fmaxf(fabsf(v0), fabsf(v1)));
-    const float dd = amax / 127.0f;
-    int q0, q1;
-    if (q81) {  // Q8_1 (buf_q8_1.rs:90-129)
-      q0 = (int)fminf(fmaxf(v0 / dd, -128.0f), 127.0f);
-      q1 = (int)fminf(fmaxf(v1 / dd, -128.0f), 127.0f);
-    } else {  // Q8_0 (buf_q8_0.rs:87-134)
-      q0 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(v0 / dd) & 0xffu);
-      q1 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(v1 / dd) & 0xffu);
-    }
-    const int qs = row16_sum_i32(q0 + q1);
-    xq[e0] = (signed char)q0;
-    xq[e0 + 1] = (signed char)q1;
-    if (dp == 0) {
-      xd[e0 >> 5] = f2h(dd);
-      if (q81)
-        store_qaux<true>(xisum, e0 >> 5, (int)f2h((float)qs * dd));
-      else
-        store_qaux<false>(xisum, e0 >> 5, qs);
-    }
-  }
-}
-
-// ---- GEMV + residual: x[row] = W[row].xq + x[row]   (matmul_vec, then add_inplace: arithmetic.rs:27-33) ---
-template <int FMT, int R, bool ADD>  // ADD: x[row] += W.xq (residual); else out[row] = W.xq (tensor-parallel partial sum)
-__global__ __launch_bounds__(128) void k_gemv_res(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x, int m, int nb) {
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int row0 = wave * R;
-  if (row0 >= m) return;
-  // the residual is loaded up front (its latency overlaps the weight stream instead of trailing the reduction)
-  float res[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) res[r] = (ADD && lane == 0 && row0 + r < m) ? x[row0 + r] : 0.f;
-  float acc[R];
-  rows_dot<FMT, R>(w.q, w.d, act, row0, m, nb, lane, acc);
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    float s = wave_sum_f32(acc[r]);
-    if (lane == 0 && row0 + r < m) x[row0 + r] = ADD ? s + res[r] : s;
-  }
-}
-
-// ---- batched-prefill attention: one workgroup = one kv head x R consecutive prompt rows x the G q heads of its
-// group (Q = G * R queries).  Per (row, head) the arithmetic is k_attn's, value for value -- f32 dots in k order,
-// softmax_row's table exp / sequential row sum (rows up to 1024 positions; longer prompts use k_attn) / true
-// division, the f16 PV chain in position order -- but a K row is fetched once for the Q queries that score against
-// it and a V element once for the Q / (256 / hd) chains a thread carries, instead of once per (row, head) workgroup:
-// the per-row kernel moved 2.1 GB through L2 per layer for 512 prompt rows of the 8B shape.
-template <bool KV16, int G, int R>
-__global__ __launch_bounds__(256) void k_attn_tile(const float* __restrict__ q, const void* __restrict__ kc,
-                                                   const void* __restrict__ vc, const int* __restrict__ pos_d,
-                                                   const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
-                                                   int n_heads, int n_kv, int hd, int seq_cap, int n_rows, int sstride) {
-  constexpr int Q = G * R;
-  extern __shared__ float lds[];
-  float* qs = lds;            // [Q][hd]: q rows (rounded to f16 for the f16 cache, batch_matmul.rs:39)
-  float* sc = lds + Q * hd;   // [Q][sstride]: scores, then probabilities
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kvh = blockIdx.x, r0 = blockIdx.y * R;
-  const int pos0 = *pos_d;
-  const int dim = n_heads * hd;
-  auto head_of = [&](int j) { return KV16 ? kvh * G + j : kvh + j * n_kv; };  // batch_matmul.rs:61-67 GQA maps
-  const int rows_here = n_rows - r0 < R ? n_rows - r0 : R;
-  for (int e = tid; e < Q * hd; e += 256) {  // query qi = r * G + j
-    const int qi = e / hd, i = e - qi * hd, r = qi / G, j = qi - r * G;
-    const float v = r < rows_here ? q[(size_t)(r0 + r) * dim + head_of(j) * hd + i] : 0.0f;
-    qs[e] = KV16 ? h2f(f2h(v)) : v;
-  }
-  __syncthreads();
-  // ---- scores + softmax: wave w owns the QW = Q / 4 queries w * QW .. (one prompt row: its causal length bounds the
-  // loop), lane = cached position; a K row is fetched once per wave and scored against the wave's queries
-  constexpr int QW = Q / 4;
-  static_assert(Q % 4 == 0 && (G % QW == 0 || QW % G == 0), "a wave's queries belong to one row");
-  {
-    const int q0 = wave * QW, rw = q0 / G;
-    if (rw < rows_here) {
-      const int seq = pos0 + r0 + rw + 1;
-      for (int t = lane; t < seq; t += 64) {
-        float acc[QW];
-#pragma unroll
-        for (int u = 0; u < QW; u++) acc[u] = 0.0f;
-        if (KV16) {
-          const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
-          for (int i = 0; i < hd; i += 16) {  // hd % 16 == 0 (host check); products added in k order per query
-            const i32x4 k0 = *(const i32x4*)(kr + i), k1 = *(const i32x4*)(kr + i + 8);
-            float kf[16];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              kf[2 * u] = h2f((unsigned short)((unsigned)k0[u] & 0xffffu));
-              kf[2 * u + 1] = h2f((unsigned short)((unsigned)k0[u] >> 16));
-              kf[8 + 2 * u] = h2f((unsigned short)((unsigned)k1[u] & 0xffffu));
-              kf[8 + 2 * u + 1] = h2f((unsigned short)((unsigned)k1[u] >> 16));
-            }
-#pragma unroll
-            for (int u = 0; u < QW; u++) {
-              const f32x4* qp = (const f32x4*)(qs + (q0 + u) * hd + i);
-#pragma unroll
-              for (int v4 = 0; v4 < 4; v4++) {
-                const f32x4 qv = qp[v4];
-                acc[u] += qv[0] * kf[4 * v4];
-                acc[u] += qv[1] * kf[4 * v4 + 1];
-                acc[u] += qv[2] * kf[4 * v4 + 2];
-                acc[u] += qv[3] * kf[4 * v4 + 3];
-              }
-            }
-          }
-        } else {
-          const float* kr = (const float*)kc + ((size_t)kvh * seq_cap + t) * hd;
-          for (int i = 0; i < hd; i += 4) {
-            const f32x4 kv = *(const f32x4*)(kr + i);
-#pragma unroll
-            for (int u = 0; u < QW; u++) {
-              const f32x4 qv = *(const f32x4*)(qs + (q0 + u) * hd + i);
-              acc[u] += qv[0] * kv[0];
-              acc[u] += qv[1] * kv[1];
-              acc[u] += qv[2] * kv[2];
-              acc[u] += qv[3] * kv[3];
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < QW; u++) sc[(q0 + u) * sstride + t] = acc[u];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      // softmax per query (softmax.rs:36-54; softmax_row with the <= 1024 sequential row sum), by the same wave; the
-      // QW sequential row sums (one dependent v_add chain each) run interleaved
-#pragma unroll
-      for (int u = 0; u < QW; u++) {
-        float* srow = sc + (q0 + u) * sstride;
-        float mx = -INFINITY;
-        for (int t = lane; t < seq; t += 64) mx = fmaxf(mx, srow[t]);
-        mx = wave_max_f32(mx);
-        for (int t = lane; t < seq; t += 64) srow[t] = exp_cached_f(srow[t] - mx, exp_tab);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      float sum[QW];
-#pragma unroll
-      for (int u = 0; u < QW; u++) sum[u] = 0.0f;
-      for (int base = 0; base < seq; base += 64) {
-        float v[QW];
-#pragma unroll
-        for (int u = 0; u < QW; u++) v[u] = base + lane < seq ? sc[(q0 + u) * sstride + base + lane] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 64; i++)
-#pragma unroll
-          for (int u = 0; u < QW; u++) sum[u] += rl_f(v[u], i);  // lanes past `seq` add +0.0 (exact)
-      }
-#pragma unroll
-      for (int u = 0; u < QW; u++) {
-        float* srow = sc + (q0 + u) * sstride;
-        for (int t = lane; t < seq; t += 64) {
-          const float pv = srow[t] / sum[u];
-          if (KV16) {  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), stored as the pair {p, p} the PV chains multiply by
-            const unsigned h = (unsigned)f2h(pv);
-            ((unsigned*)srow)[t] = h | (h << 16);
-          } else {
-            srow[t] = pv;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- out[qi][n] = sum_t p[qi][t] * V[t][n].  f16 cache: thread = (pair of columns, query group), the chains run on
-  // v_pk_mul_f16 / v_pk_add_f16 (per half exactly the scalar product-round, sum-round of buf_f16.rs:152-163); a V
-  // pair feeds every chain the thread carries.  f32 cache: thread = (column, query group), plain f32.
-  constexpr int QS = Q / 2 > 0 ? Q / 2 : 1;  // chains per thread (>= 2 query groups); unused slots have lim = 0
-  const int tpg = KV16 ? hd / 2 : hd;      // threads per query group
-  const int ngrp = 256 / tpg;
-  const int n = tid % tpg, grp = tid / tpg;
-  if (grp >= ngrp) return;  // ngrp >= 2 (host check), so Q / 2 chain slots cover the Q queries
-  const int ch = (Q + ngrp - 1) / ngrp;  // consecutive queries per group: normally the heads of ONE row (same length)
-  int lim[QS];
-  const float* prow[QS];
-  int lim_lo = 0x7fffffff, lim_hi = 0;
-#pragma unroll
-  for (int s2 = 0; s2 < QS; s2++) {
-    const int qi = grp * ch + s2;
-    const bool live = s2 < ch && qi < Q && qi / G < rows_here;
-    lim[s2] = live ? pos0 + r0 + qi / G + 1 : 0;
-    prow[s2] = sc + (live ? qi : 0) * sstride;
-    if (live) {
-      lim_lo = lim[s2] < lim_lo ? lim[s2] : lim_lo;
-      lim_hi = lim[s2] > lim_hi ? lim[s2] : lim_hi;
-    }
-  }
-  if (lim_hi == 0) return;
-  if (KV16) {
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    const unsigned* vr = (const unsigned*)((const unsigned short*)vc + (size_t)kvh * seq_cap * hd) + n;
-    const int vs = hd / 2;  // dwords per V row
-    h2v c[QS];
-#pragma unroll
-    for (int s2 = 0; s2 < QS; s2++) c[s2] = h2v{(_Float16)0.0f, (_Float16)0.0f};
-    // the common case: every chain of the thread has the same causal length (one row) and QS / 2 live chains
-    const bool uniform = lim_lo == lim_hi;
-    int t0 = 0;
-    if (uniform) {
-      for (; t0 + 4 <= lim_hi; t0 += 4) {
-        unsigned vv[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) vv[u] = vr[(size_t)(t0 + u) * vs];
-#pragma unroll
-        for (int s2 = 0; s2 < QS; s2++) {
-          if (lim[s2]) {  // thread-constant
-            // four {p, p} pairs, read as scalars (element extraction from a freshly loaded ext-vector feeding
-            // bit_casts was miscompiled here: every element became element 0)
-            const unsigned* pq = (const unsigned*)prow[s2] + t0;
-            unsigned pp[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) pp[u] = pq[u];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const h2v prod = __builtin_bit_cast(h2v, vv[u]) * __builtin_bit_cast(h2v, pp[u]);
-              c[s2] = c[s2] + prod;
-            }
-          }
-        }
-      }
-    }
-    for (; t0 < lim_hi; t0++) {  // tail / mixed lengths
-      const h2v vp = __builtin_bit_cast(h2v, vr[(size_t)t0 * vs]);
-#pragma unroll
-      for (int s2 = 0; s2 < QS; s2++) {
-        if (t0 < lim[s2]) {
-          const h2v prod = vp * __builtin_bit_cast(h2v, ((const unsigned*)prow[s2])[t0]);
-          c[s2] = c[s2] + prod;
-        }
-      }
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < QS; s2++) {
-      const int qi = grp * ch + s2;
-      if (lim[s2]) {
-        float* o = out + (size_t)(r0 + qi / G) * dim + head_of(qi % G) * hd + 2 * n;
-        o[0] = (float)c[s2][0];
-        o[1] = (float)c[s2][1];
-      }
-    }
-  } else {
-    const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
-    float c[QS];
-#pragma unroll
-    for (int s2 = 0; s2 < QS; s2++) c[s2] = 0.0f;
-    for (int t0 = 0; t0 < lim_hi; t0 += 8) {
-      float vv[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) vv[u] = t0 + u < lim_hi ? vr[(size_t)(t0 + u) * hd] : 0.0f;
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int t = t0 + u;
-#pragma unroll
-        for (int s2 = 0; s2 < QS; s2++) {
-          if (t < lim[s2]) c[s2] += prow[s2][t] * vv[u];
-        }
-      }
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < QS; s2++) {
-      const int qi = grp * ch + s2;
-      if (lim[s2]) out[(size_t)(r0 + qi / G) * dim + head_of(qi % G) * hd + n] = c[s2];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_res_epi(const float* __restrict__ tmp, float* __restrict__ x, int m, int add) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) x[i] = add ? tmp[i] + x[i] : tmp[i];
-}
-// single-device simulation of the tensor-parallel all-reduce: every rank's partial <- sum over ranks (rank order)
-struct SimPtrs {
-  float* p[8];
-};
-__global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = ptrs.p[0][i];
-  for (int r = 1; r < nranks; r++) s += ptrs.p[r][i];
-  for (int r = 0; r < nranks; r++) ptrs.p[r][i] = s;
-}
-
-// ---- fast mode: GEMV + residual with the NEXT RMSNorm + quantization done in the epilogue ------------------------
-// The separate norm+quantize launch is a single-workgroup latency stage (6 us x 65 per token on Llama-3-8B).  Here
-// the producer of x (wo / ffn_down + residual) finishes the job: a 1024-thread workgroup owns 32 consecutive rows
-// = one rmsnorm chunk = one Q8_0 block (the k_gateup_q shape).  It publishes its ordered chunk sum of squares as
-// one 8-byte {sum, epoch} granule (a single write-through store: data and tag travel together, no fence needed),
-// gathers all dim/32 granules (one wave polls them with relaxed agent-scope loads), adds them in chunk order like
-// rms_norm.rs:35-40, and normalizes + quantizes its own block.  Every bit of the result equals k_norm_quant's:
-// same chunk sums, same serial chain, same divisions.  All dim/32 workgroups are co-resident by construction
-// (<= one per CU, checked at create); the poll is bounded and raises `fault` instead of hanging.
-// Q8_K quantizer of an f32 vector straight into LDS planes (q | d | bsums, as stage_act_q8k lays them out): one
-// wave per super-block.  The Q4_K wo / ffn_down kernels run it as their prologue on the attention output / h,
-// each workgroup for itself (16 KB / 56 KB of L2 reads), instead of a quantizer launch in front of them.
-__device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int nsb, unsigned* sq, float* sd, short* sbs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  // four super-blocks of loads in flight per wave (ffn_down: 56 super-blocks over 16 waves; a round is one L2 latency)
-  for (int sb0 = wave; sb0 < nsb; sb0 += 4 * nw) {
-    f32x4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int sb = sb0 + u * nw;
-      v[u] = ((const f32x4*)x)[(sb < nsb ? sb : sb0) * 64 + lane];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int sb = sb0 + u * nw;
-      if (sb >= nsb) break;  // wave-uniform
-      const Q8KLane o = q8k_wave_quant(v[u], lane);
-      sq[sb * 64 + lane] = o.packed;
-      if ((lane & 3) == 0) sbs[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
-      if (lane == 0) sd[sb] = o.d;
-    }
-  }
-  __syncthreads();
-}
-
-struct NormGather {
-  unsigned long long* slots;  // dim/16 granules: each workgroup's ordered sum of squares over its rows
-  unsigned long long* pair;   // dim row granules (read by a split chunk's partner / a Q8_K super-block's neighbours)
-  const int* serial;          // decode-step serial number (never reset): makes the epoch unique per launch
-  int* fault;
-  int nseg, seg;
-};
-__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows); QIN (Q4_K): the rhs is the f32 vector xin
-// The tail of the wo / ffn_down kernels (k_gemv_res_nq, k_ffn): acc[] = this wave's RW row dots.  Publishes the
-// workgroup's rows / sum of squares, takes the one in-launch hop, normalizes + quantizes the rows it owns.
-// wg_index / nwg_all: this workgroup's index among the SPLIT * nchunks workgroups of the stage.
-template <int FMT, int SPLIT>
-__device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
-                                            float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
-                                            void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
-                                            int row, int lane, int wave, int wg_index, int nwg_all) {
-  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
-  constexpr bool KQ = FMT == CRABML_HIP_Q4_K;
-  constexpr int RW = 2 / SPLIT;
-  constexpr int ROWS = 32 / SPLIT;
-  // ---- epilogue: publish, one in-launch hop, normalize + quantize -------------------------------------------
-  // every row goes out as a {value, epoch} granule when another workgroup needs it (the partner of a split chunk;
-  // the seven neighbours of a Q8_K super-block), the workgroup's ordered sum of squares as one more
-  constexpr bool ROWG = SPLIT > 1 || KQ;
-#pragma unroll
-  for (int r = 0; r < RW; r++) {
-    const float s = wave_sum_f32(acc[r]);
-    if (lane == 0) hv[part * ROWS + wave * RW + r] = s;
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  // wave 0 owns the stores: ROWS consecutive rows per instruction (x and the row granules are one or two lines,
-  // not 32 separate partial writes from 16 waves)
-  if (lane < ROWS) {
-    const float xv = hv[part * ROWS + lane] + res;  // x = matmul_out + x (llama2.rs:266 / :636)
-    x[row + lane] = xv;
-    hv[part * ROWS + lane] = xv;
-    if (ROWG)
-      __hip_atomic_store(ng.pair + row + lane, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // sum of squares of a chunk = (rows 0..15 in order) + (rows 16..31 in order): a split chunk's two workgroups
-  // each own one half (norm_quant_block<HALF> computes the same)
-  float cs;
-  {
-    float h0 = -0.0f, h1 = -0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const f32x4 t = ((const f32x4*)hv)[(SPLIT > 1 ? part * 4 : 0) + j];
-      h0 += t[0] * t[0];
-      h0 += t[1] * t[1];
-      h0 += t[2] * t[2];
-      h0 += t[3] * t[3];
-    }
-    if (SPLIT == 1) {
-#pragma unroll
-      for (int j = 4; j < 8; j++) {
-        const f32x4 t = ((const f32x4*)hv)[j];
-        h1 += t[0] * t[0];
-        h1 += t[1] * t[1];
-        h1 += t[2] * t[2];
-        h1 += t[3] * t[3];
-      }
-      cs = h0 + h1;
-    } else {
-      cs = h0;
-    }
-  }
-  if (lane == 0)
-    __hip_atomic_store(ng.slots + wg_index, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granule is on its way before the polls queue up behind it
-  auto poll = [&](const unsigned long long* p) -> float {
-    unsigned long long g = ld_granule(p);
-    int tries = 0;
-    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
-      __builtin_amdgcn_s_sleep(2);
-      g = ld_granule(p);
-      tries++;
-    }
-    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
-    return __builtin_bit_cast(float, (unsigned)g);
-  };
-  // the rows of other workgroups first (published before their sums; the loads fly while the stragglers arrive) ...
-  const int l32 = lane & 31;
-  const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
-  const int sb = blk >> 3;
-  float v = 0.0f;
-  f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (KQ) {
-    const unsigned long long* p = ng.pair + sb * 256 + lane * 4;
-    unsigned long long g[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) g[i] = ld_granule(p + i);
-#pragma unroll
-    for (int i = 0; i < 4; i++) v4[i] = (unsigned)(g[i] >> 32) == epoch ? __builtin_bit_cast(float, (unsigned)g[i]) : poll(p + i);
-  } else if (SPLIT > 1) {
-    if (lane < 32) v = own ? hv[l32] : poll(ng.pair + blk * 32 + l32);
-  } else {
-    v = hv[l32];
-  }
-  // ... then the hop: every workgroup's sum, added strictly in chunk order
-  float sum = 0.0f;
-  const int nwg = nwg_all;
-  for (int base = 0; base < nwg; base += 64) {
-    const int c = base + lane;
-    float cv = c < nwg ? poll(ng.slots + c) : 0.0f;
-    if (SPLIT > 1) cv += dpp_f<0xB1>(cv);  // chunk = its two halves (the same value on both lanes of the pair)
-#pragma unroll
-    for (int i = 0; i < 64; i += SPLIT) sum += rl_f(cv, i);  // lanes past the grid add +0.0
-  }
-  const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
-  if constexpr (!KQ) {
-    const float xn = (v / rms) * wn;
-    const QLane o = quant_lane32<Q81>(xn, true);
-    if (lane < 32 && own) {
-      q[blk * 32 + lane] = o.q;
-      if (lane == 0) {
-        ((unsigned short*)d)[blk] = o.d;
-        store_qaux<Q81>(isum, blk, o.aux);
-      }
-    }
-  } else {
-    // Q8_K (buf_q8_k.rs:84-131): the scale comes from the FIRST element of maximal |x| of the 256-element
-    // super-block = this chunk and its 7 neighbours.  The wave holds the super-block's 256 rows (4 per lane, from
-    // their granules), normalizes them all and runs the whole block's quantizer; it stores the part that is its own.
-    f32x4 xn;
-#pragma unroll
-    for (int i = 0; i < 4; i++) xn[i] = (v4[i] / rms) * wn4[i];
-    const Q8KLane o = q8k_wave_quant(xn, lane);
-    const int l0 = (blk & 7) * 8 + part * (ROWS / 4);
-    if (lane >= l0 && lane < l0 + ROWS / 4) {
-      ((unsigned*)q)[sb * 64 + lane] = o.packed;
-      if ((lane & 3) == 0) ((short*)isum)[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
-    }
-    if (lane == 0 && (blk & 7) == 0 && part == 0) ((float*)d)[sb] = o.d;
-  }
-}
-
-template <int FMT, int SPLIT, bool QIN = false>
-__global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
-                                                      float* __restrict__ x,
-                                                      const float* __restrict__ wnext, float eps,
-                                                      signed char* __restrict__ q, void* __restrict__ d,
-                                                      void* __restrict__ isum, NormGather ng, int nb, Planes6 w6) {
-  constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
-  constexpr int RW = 2 / SPLIT;         // rows per wave
-  constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
-  __shared__ __attribute__((aligned(16))) float hv[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int blk = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
-  const int nchunks = gridDim.x / SPLIT;
-  const int row = blk * 32 + part * ROWS + wave * RW;
-  float res = 0.f;                         // wave 0: the residual of row (first row of the workgroup) + lane
-  float wn = 0.f;                          // the next RMSNorm's weights for the rows this wave will normalize,
-  f32x4 wn4 = {0.f, 0.f, 0.f, 0.f};        // loaded up front (off the critical path after the hop)
-  unsigned epoch = 0;
-  if (wave == 0) {
-    if (lane < ROWS) res = x[row + lane];
-    if constexpr (KQ)
-      wn4 = ((const f32x4*)wnext)[(blk >> 3) * 64 + lane];
-    else
-      wn = wnext[blk * 32 + (lane & 31)];
-  }
-  if (wave == 0) epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
-  // RW rows x two blocks per lane in flight (one workgroup per CU: the loads have to supply the parallelism);
-  // terms are added in block order, as rows_partial does
-  float acc[RW];
-  if constexpr (KQ && QIN) {
-    // the rhs arrives as f32 (attention output / h): quantize it to Q8_K in LDS first
-    extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
-    float* sd = (float*)(lds_act + nb * 16);
-    short* sbs = (short*)(sd + nb);
-    // the first weight pieces are requested before the prologue (they do not depend on it): its L2 round trip
-    // and the quantizer run under the HBM latency of the stream's head
-    if (w6.base != nullptr) {  // this layer's matrix is Q6_K (a *_K_M mix): same rhs, its own inner loop
-      stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
-      const ActQ8_K la6{lds_act, sd, sbs};
-      rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
-      nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
-                              (int)blockIdx.x, (int)gridDim.x);
-      return;
-    }
-    constexpr int PRE = 2;
-    Q4KPiece<false> pw[PRE][RW];
-#pragma unroll
-    for (int it = 0; it < PRE; it++) {
-      const int c = it * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < RW; r++) pw[it][r] = q4k_load<false>(w.q, (const i32x4*)w.d, (size_t)(row + r), nb, c < nb * 8 ? c : nb * 8 - 1, lane);
-    }
-    stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
-    const ActQ8_K la{lds_act, sd, sbs};
-#pragma unroll
-    for (int r = 0; r < RW; r++) acc[r] = 0.f;
-#pragma unroll
-    for (int it = 0; it < PRE; it++) {
-      const int c = it * 64 + lane;
-      if (c < nb * 8) {
-        const Q4KX xx = q4k_loadx(la, c);
-#pragma unroll
-        for (int r = 0; r < RW; r++) acc[r] += q4k_term<false>(pw[it][r], xx, c);
-      }
-    }
-    rows_partial_q4k<RW, false>(w.q, (const i32x4*)w.d, la, row, nchunks * 32, nb, lane, acc, PRE * 64);
-  } else if constexpr (KQ) {
-    if (w6.base != nullptr)
-      rows_partial_q6k<RW>(w6.base, w6.off_qh, act, row, nchunks * 32, nb, lane, acc);
-    else
-      rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
-  } else {
-    using F = BlockFmt<FMT>;
-#pragma unroll
-    for (int r = 0; r < RW; r++) acc[r] = 0.f;
-    const int nu = nb * F::UNITS;
-    for (int u = lane; u < nu; u += 128) {
-      const int u2 = u + 64;
-      const bool two = u2 < nu;
-      const int uu = two ? u2 : u;
-      typename F::Blk ka[RW], kb[RW];
-#pragma unroll
-      for (int r = 0; r < RW; r++) {
-        ka[r] = F::load(w.q, w.d, (size_t)(row + r), nb, u);
-        kb[r] = F::load(w.q, w.d, (size_t)(row + r), nb, uu);
-      }
-      const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
-#pragma unroll
-      for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], xa);
-      if (two) {
-#pragma unroll
-        for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], xb);
-      }
-    }
-  }
-  nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
-                          (int)gridDim.x);
-}
-
-// ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
-__device__ __forceinline__ float silu_mul(float g, float u, const unsigned short* __restrict__ exp_tab) {
-  float nexp = exp_cached_f(-g, exp_tab);
-  return (g / (1.0f + nexp)) * u;
-}
-template <int FMT>
-__global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename ActOf<FMT>::type act,
-                                                const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m, int nb) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= m) return;
-  float ag[1], au[1];
-  rows_dot<FMT, 1>(wg.q, wg.d, act, row, m, nb, lane, ag);
-  rows_dot<FMT, 1>(wu.q, wu.d, act, row, m, nb, lane, au);
-  const float g = wave_sum_f32(ag[0]), u = wave_sum_f32(au[0]);
-  if (lane == 0) h[row] = silu_mul(g, u, exp_tab);
-}
-// Q4_K gate/up with the Q8_K activation planes staged in LDS once per workgroup (1024 threads = 32 hidden rows x
-// {gate, up}): the per-lane activation reads (2 x 16 B + d + 2 bsums per 16 B of quants) leave the vector-memory
-// path, which the K-quant inner loop otherwise keeps ~57 % busy (rocprofv3 TA_BUSY) while VALU sits at 15 %.
-__global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
-                                                       float* __restrict__ h, int m, int nsb) {
-  extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
-  const int k = nsb * 256;
-  i32x4* sq = lds_act;
-  float* sd = (float*)(sq + k / 16);
-  short* sbs = (short*)(sd + nsb);
-  for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.q[i];
-  for (int i = threadIdx.x; i < nsb; i += 1024) sd[i] = act.d[i];
-  for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
-  __syncthreads();
-  const ActQ8_K la{sq, sd, sbs};
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * 32 + wave * 2;
-  if (row0 >= m) return;
-  float ag[2], au[2];
-  rows_partial_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag);
-  rows_partial_q4k<2, false>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    const float g = wave_sum_f32(ag[r]), u = wave_sum_f32(au[r]);
-    if (lane == 0 && row0 + r < m) h[row0 + r] = silu_mul(g, u, exp_tab);
-  }
-}
-
-// Same, with the Q8_0 quantization of h (the rhs of ffn_down) folded in: a 1024-thread workgroup owns 32
-// consecutive hidden rows = one quant block; each of its 16 waves computes 2 rows (4 weight rows in flight),
-// parks the h values in LDS, and one half-wave quantizes the block (buf_q8_0.rs:87-134).  hidden/32
-// workgroups (448 for Llama-3-8B) are all resident at once (2 per CU).  Saves a launch per layer.
-template <int FMT>
-__global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typename ActOf<FMT>::type act,
-                                                   const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
-                                                   unsigned short* __restrict__ d, void* __restrict__ isum, int nb) {
-  using F = BlockFmt<FMT>;
-  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
-  __shared__ float hv[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int blk = blockIdx.x;
-  const int row = blk * 32 + wave * 2;  // rows row, row+1
-  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
-  const int nu = nb * F::UNITS;
-  for (int u = lane; u < nu; u += 64) {
-    typename F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, u);
-    typename F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, u);
-    typename F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
-    typename F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
-    const XUnit x = F::loadx(act, u);
-    g0 += F::term(bg0, x);
-    u0 += F::term(bu0, x);
-    g1 += F::term(bg1, x);
-    u1 += F::term(bu1, x);
-  }
-  g0 = wave_sum_f32(g0);
-  u0 = wave_sum_f32(u0);
-  g1 = wave_sum_f32(g1);
-  u1 = wave_sum_f32(u1);
-  if (lane == 0) {
-    hv[wave * 2] = silu_mul(g0, u0, exp_tab);
-    hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const QLane o = quant_lane32<Q81>(hv[threadIdx.x], true);
-    q[blk * 32 + threadIdx.x] = o.q;
-    if (threadIdx.x == 0) {
-      d[blk] = o.d;
-      store_qaux<Q81>(isum, blk, o.aux);
-    }
-  }
-}
-// ---- gate/up + SiLU*mul + quantize + ffn_down + residual + next RMSNorm/quantize in ONE launch ----------------------
-// EXPERIMENT, opt-in (CRABML_HIP_LLAMA_FFN_FUSION): measured 27.5-28.7 us against 12.9 + 0.8 + 10.7 us for the two
-// kernels it replaces on the 8B shape ("measured and rejected"), bit-identical to them.
-// The two halves of the FFN are k_gateup_q and k_gemv_res_nq<FMT, 2> back to back; what the single launch was meant
-// to buy is the boundary between them: ffn_down's first weight loads are requested BEFORE its workgroup waits for h,
-// so the HBM round trip of the stream's head runs under the hand-off instead of after a kernel boundary.  h never touches a
-// plane in global memory: every 32-row block goes out as 8 {4 quants, epoch} granules + 1 {d | aux, epoch} granule
-// (aux = the block's quant sum for Q8_0 -- |sum| <= 4096 fits 16 bits -- or s for Q8_1), and every workgroup polls
-// all of them (hidden/4 + hidden/32 relaxed agent-scope loads, 4 per thread) into its own LDS copy of the planes.
-// Grid = dim/16 workgroups of 1024 threads, all resident (the norm-epilogue condition); workgroup b owns the
-// hidden blocks b and b + grid (the latter when it exists) and, for ffn_down, half of chunk b / 2.
-struct HGather {
-  unsigned long long* hq;  // hidden/4 granules
-  unsigned long long* hs;  // hidden/32 granules
-};
-template <class F, int NB, class ACT>
-__device__ __forceinline__ void ffn_gateup_rows(const Planes& wg, const Planes& wu, const ACT& act, int nb, int lane,
-                                                const int (&row)[NB], float (&g)[NB][2], float (&u2)[NB][2]) {
-#pragma unroll
-  for (int k = 0; k < NB; k++) g[k][0] = g[k][1] = u2[k][0] = u2[k][1] = 0.f;
-  const int nu = nb * F::UNITS;
-  // two units per row in flight (one workgroup per CU: the loads have to supply the parallelism; with one unit per
-  // iteration a wave paid an HBM round trip per iteration and the phase streamed at 3.3 TB/s); terms in block order
-  for (int u = lane; u < nu; u += 128) {
-    const int ub = u + 64;
-    const bool two = ub < nu;
-    const int uu = two ? ub : u;
-    typename F::Blk bg[NB][2][2], bu[NB][2][2];
-#pragma unroll
-    for (int k = 0; k < NB; k++)
-#pragma unroll
-      for (int r = 0; r < 2; r++) {
-        bg[k][r][0] = F::load(wg.q, wg.d, (size_t)(row[k] + r), nb, u);
-        bu[k][r][0] = F::load(wu.q, wu.d, (size_t)(row[k] + r), nb, u);
-        bg[k][r][1] = F::load(wg.q, wg.d, (size_t)(row[k] + r), nb, uu);
-        bu[k][r][1] = F::load(wu.q, wu.d, (size_t)(row[k] + r), nb, uu);
-      }
-    const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
-#pragma unroll
-    for (int k = 0; k < NB; k++)
-#pragma unroll
-      for (int r = 0; r < 2; r++) {
-        g[k][r] += F::term(bg[k][r][0], xa);
-        u2[k][r] += F::term(bu[k][r][0], xa);
-      }
-    if (two) {
-#pragma unroll
-      for (int k = 0; k < NB; k++)
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-          g[k][r] += F::term(bg[k][r][1], xb);
-          u2[k][r] += F::term(bu[k][r][1], xb);
-        }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NB; k++)
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      g[k][r] = wave_sum_f32(g[k][r]);
-      u2[k][r] = wave_sum_f32(u2[k][r]);
-    }
-}
-template <int FMT>
-__global__ __launch_bounds__(1024) void k_ffn(Planes wg, Planes wu, Planes wdn, typename ActOf<FMT>::type act,
-                                              const unsigned short* __restrict__ exp_tab, float* __restrict__ x,
-                                              const float* __restrict__ wnext, float eps, signed char* __restrict__ q,
-                                              void* __restrict__ d, void* __restrict__ isum, NormGather ng, HGather hg, int nb_in,
-                                              int nblk_h, int off_d, int off_aux) {
-  using F = BlockFmt<FMT>;
-  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
-  extern __shared__ i32x4 lds_h[];  // phase B: h's activation planes, act_layout order
-  __shared__ __attribute__((aligned(16))) float hv[64];
-  __shared__ __attribute__((aligned(16))) signed char hqb[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = (int)gridDim.x;
-  const unsigned epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
-  // ---- phase A: gate/up rows of this workgroup's hidden blocks (wave w: rows 2w, 2w + 1 of each block)
-  const int b0 = (int)blockIdx.x, b1 = b0 + G;
-  const bool has0 = b0 < nblk_h, has1 = b1 < nblk_h;
-  if (has0) {
-    if (has1) {
-      const int row[2] = {b0 * 32 + wave * 2, b1 * 32 + wave * 2};
-      float g[2][2], u2[2][2];
-      ffn_gateup_rows<F, 2>(wg, wu, act, nb_in, lane, row, g, u2);
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-#pragma unroll
-          for (int r = 0; r < 2; r++) hv[k * 32 + wave * 2 + r] = silu_mul(g[k][r], u2[k][r], exp_tab);
-      }
-    } else {
-      const int row[1] = {b0 * 32 + wave * 2};
-      float g[1][2], u2[1][2];
-      ffn_gateup_rows<F, 1>(wg, wu, act, nb_in, lane, row, g, u2);
-      if (lane == 0) {
-        hv[wave * 2] = silu_mul(g[0][0], u2[0][0], exp_tab);
-        hv[wave * 2 + 1] = silu_mul(g[0][1], u2[0][1], exp_tab);
-      }
-    }
-  }
-  __syncthreads();
-  if ((wave == 0 && has0) || (wave == 1 && has1)) {  // wave k quantizes and publishes block k (buf_q8_0.rs:87-134)
-    const int hb = wave == 0 ? b0 : b1;
-    const QLane o = quant_lane32<Q81>(hv[wave * 32 + (lane & 31)], true);
-    if (lane < 32) hqb[wave * 32 + lane] = o.q;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 8)
-      __hip_atomic_store(hg.hq + hb * 8 + lane, ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)hqb)[wave * 8 + lane],
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane == 0)
-      __hip_atomic_store(hg.hs + hb, ((unsigned long long)epoch << 32) | (unsigned long long)((unsigned)o.d | (((unsigned)o.aux & 0xffffu) << 16)),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): on their way before this wave starts polling
-  }
-  // ---- phase B set-up: ffn_down row of this wave, its first weight units requested before the hand-off
-  const int blk = (int)blockIdx.x >> 1, part = (int)blockIdx.x & 1;
-  const int nchunks = G >> 1;
-  const int row = blk * 32 + part * 16 + wave;
-  float res = 0.f, wn = 0.f;
-  const f32x4 wn4 = {0.f, 0.f, 0.f, 0.f};
-  if (wave == 0) {
-    if (lane < 16) res = x[row + lane];
-    wn = wnext[blk * 32 + (lane & 31)];
-  }
-  const int nu = nblk_h * F::UNITS;
-  const int ua = lane < nu ? lane : nu - 1, ub = lane + 64 < nu ? lane + 64 : nu - 1;
-  const typename F::Blk ka0 = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, ua);
-  const typename F::Blk kb0 = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, ub);
-  // ---- the hand-off: all of h into this workgroup's LDS planes
-  char* P = (char*)lds_h;
-  auto poll = [&](const unsigned long long* p) -> unsigned {
-    unsigned long long gq = ld_granule(p);
-    int tries = 0;
-    while ((unsigned)(gq >> 32) != epoch && tries < (1 << 21)) {
-      __builtin_amdgcn_s_sleep(2);
-      gq = ld_granule(p);
-      tries++;
-    }
-    if ((unsigned)(gq >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
-    return (unsigned)gq;
-  };
-  // every thread requests its (up to 4) quant granules right away -- for the workgroup that arrives last, which
-  // sets the pace, everything is already published and comes back fresh in the same round trip as the scale
-  // granules; wave 0 alone spins on the scale granules (1024 spinning threads per early workgroup would sit on the
-  // memory path the late workgroups are still streaming weights through); stale quant granules are re-polled after
-  const int nq = nblk_h * 8;
-  unsigned long long gq[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int i = tid + u * 1024;
-    gq[u] = ld_granule(hg.hq + (i < nq ? i : tid));
-  }
-  if (wave == 0) {
-    for (int i = lane; i < nblk_h; i += 64) {
-      const unsigned v = poll(hg.hs + i);
-      ((unsigned short*)(P + off_d))[i] = (unsigned short)(v & 0xffffu);
-      if constexpr (Q81)
-        ((unsigned short*)(P + off_aux))[i] = (unsigned short)(v >> 16);
-      else
-        ((int*)(P + off_aux))[i] = (int)(short)(v >> 16);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int i = tid + u * 1024;
-    if (i < nq) ((unsigned*)P)[i] = (unsigned)(gq[u] >> 32) == epoch ? (unsigned)gq[u] : poll(hg.hq + i);
-  }
-  for (int i = tid + 4 * 1024; i < nq; i += 1024) ((unsigned*)P)[i] = poll(hg.hq + i);  // hidden > 16384 only
-  __syncthreads();
-  // ---- phase B: the ffn_down row against the LDS planes (terms in block order, as k_gemv_res_nq adds them)
-  typename ActOf<FMT>::type la;
-  la.q = (const i32x4*)P;
-  la.d = (const unsigned short*)(P + off_d);
-  if constexpr (Q81)
-    la.s = (const unsigned short*)(P + off_aux);
-  else
-    la.isum = (const int*)(P + off_aux);
-  float acc[1] = {0.f};
-  {
-    const XUnit xa = F::loadx(la, ua), xb = F::loadx(la, ub);
-    if (lane < nu) acc[0] += F::term(ka0, xa);
-    if (lane + 64 < nu) acc[0] += F::term(kb0, xb);
-  }
-  for (int u = lane + 128; u < nu; u += 128) {
-    const int u2 = u + 64;
-    const bool two = u2 < nu;
-    const int uu = two ? u2 : u;
-    const typename F::Blk ka = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, u);
-    const typename F::Blk kb = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, uu);
-    const XUnit xa = F::loadx(la, u), xb = F::loadx(la, uu);
-    acc[0] += F::term(ka, xa);
-    if (two) acc[0] += F::term(kb, xb);
-  }
-  nq_epilogue<FMT, 2>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row - wave, lane, wave,
-                      (int)blockIdx.x, G);
-}
-
-__global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
-                                                    const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) h[i] = silu_mul(g[i], u[i], exp_tab);
-}
-
-// ---- greedy sampler + advance: Iterator::max_by keeps the LAST maximum (sampler.rs:109-116) ------------
-// stage 1: ARGMAX_BLOCKS workgroups, each over a contiguous slice; stage 2: one wave combines and advances.
-#define ARGMAX_BLOCKS 128
-__device__ __forceinline__ void argmax_combine(float& cv, int& ci, float ov, int oi) {
-  // keep the later index among equal maxima; an index of -1 means "empty"
-  bool take = oi >= 0 && (ci < 0 || ov > cv || (!(cv > ov) && oi > ci));
-  if (take) {
-    cv = ov;
-    ci = oi;
-  }
-}
-__global__ __launch_bounds__(256) void k_argmax_partial(const float* __restrict__ logits, int n, float* __restrict__ pv,
-                                                        int* __restrict__ pi) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
-  const int per = (n + gridDim.x - 1) / gridDim.x;
-  const int lo = blockIdx.x * per, hi = min(n, lo + per);
-  float bv = -INFINITY;
-  int bi = -1;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) argmax_combine(bv, bi, logits[i], i);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(bv, o, 64);
-    int oi = __shfl_xor(bi, o, 64);
-    argmax_combine(bv, bi, ov, oi);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    sv[threadIdx.x >> 6] = bv;
-    si[threadIdx.x >> 6] = bi;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++) argmax_combine(bv, bi, sv[w], si[w]);
-    pv[blockIdx.x] = bv;
-    pi[blockIdx.x] = bi;
-  }
-}
-__global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
-                                                    int* __restrict__ token_d, int* __restrict__ pos_d,
-                                                    int* __restrict__ step_d, unsigned* __restrict__ out_tokens, int out_cap,
-                                                    int* __restrict__ serial_d) {
-  float bv = -INFINITY;
-  int bi = -1;
-  for (int i = threadIdx.x; i < nparts; i += 64) argmax_combine(bv, bi, pv[i], pi[i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(bv, o, 64);
-    int oi = __shfl_xor(bi, o, 64);
-    argmax_combine(bv, bi, ov, oi);
-  }
-  if (threadIdx.x == 0) {
-    *token_d = bi;
-    int st = *step_d;
-    if (st < out_cap) out_tokens[st] = (unsigned)bi;
-    *step_d = st + 1;
-    *pos_d = *pos_d + 1;
-    *serial_d = *serial_d + 1;
-  }
-}
-
-}  // namespace crabml_hip
+#include "fused_common.hpp"
+#include "fused_attention.hpp"
+#include "fused_ffn.hpp"
 
 
 // ==============================================================================================================

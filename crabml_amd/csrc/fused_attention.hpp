@@ -1,0 +1,599 @@
+// fused_attention.hpp -- attention kernels: one workgroup per head (decode), the long-context split, the row-tiled causal prefill kernel
+// Part of the fused decode step (fused.hip includes the three fused_*.hpp files once, in order; they are not stand-alone
+// translation units: the kernels are launched from fused.hip's host code).
+#pragma once
+#include "fused_common.hpp"
+
+namespace crabml_hip {
+// ---- attention: one workgroup per head -------------------------------------------------------------------
+// batch_matmul.rs: f16 cache -> q rounded to f16, f32-accumulated QK^T in k order (buf_f16.rs:83-97),
+// GQA head = h / (n_heads/n_kv); PV accumulated in f16 with a rounding after the product and after the sum
+// (buf_f16.rs:152-163).  f32 cache -> plain f32 loops, kv head = h % n_kv (batch_matmul.rs:61-67).
+// softmax.rs:36-54 with the f16 exp table; the row sum is sequential (bit-exact) up to 1024 positions and a
+// block tree beyond that (documented tolerance 1e-6 relative).
+template <bool KV16>
+__global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const void* __restrict__ kc,
+                                              const void* __restrict__ vc, const int* __restrict__ pos_d,
+                                              const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
+                                              signed char* __restrict__ xq, unsigned short* __restrict__ xd,
+                                              void* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap,
+                                              PrefetchPlan pf, int q81) {
+  if ((int)blockIdx.x >= n_heads) {
+    prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
+    return;
+  }
+  extern __shared__ float lds[];
+  __shared__ float s_red[4];
+  __shared__ float s_val;
+  float* scores = lds;
+  float* qs = lds + seq_cap;
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x;
+  const int kvh = KV16 ? head / (n_heads / n_kv) : head % n_kv;
+  // blockIdx.y: row of a prefill batch = one more cached position per row (causal); 0 for a decode step
+  q += (size_t)blockIdx.y * n_heads * hd;
+  out += (size_t)blockIdx.y * n_heads * hd;
+  // Position-independent loads go out first, so that their (cold, cross-XCD) latency overlaps the q staging
+  // instead of adding two more serial round trips: the first 64 halves of the K row this thread will score
+  // and the first 16 V values of the output column it will accumulate.  Rows past `seq` are read but unused.
+  i32x4 kpre[8];
+  const bool kp = KV16 && hd >= 64 && tid < seq_cap;
+  if (kp) {
+    const unsigned short* kr0 = (const unsigned short*)kc + ((size_t)kvh * seq_cap + tid) * hd;
+#pragma unroll
+    for (int u = 0; u < 8; u++) kpre[u] = *(const i32x4*)(kr0 + 8 * u);
+  }
+  unsigned short vpre[16];
+  const bool vp = KV16 && tid < hd && seq_cap >= 16;
+  if (vp) {
+    const unsigned short* vr0 = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + tid;
+#pragma unroll
+    for (int u = 0; u < 16; u++) vpre[u] = vr0[(size_t)u * hd];
+  }
+  const int seq = *pos_d + 1 + (int)blockIdx.y;
+  for (int i = tid; i < hd; i += blockDim.x) {
+    float v = q[head * hd + i];
+    qs[i] = KV16 ? h2f(f2h(v)) : v;  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+  }
+  __syncthreads();
+  // ---- scores[t] = q . K[t]
+  for (int t = tid; t < seq; t += blockDim.x) {
+    float acc = 0.0f;
+    if (KV16) {
+      const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
+      int i = 0;
+      for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
+        i32x4 kv[8];
+        if (kp && t == tid && i == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; u++) kv[u] = kpre[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            unsigned w = (unsigned)kv[u][j];
+            acc += qs[i + 8 * u + 2 * j] * h2f((unsigned short)(w & 0xffffu));
+            acc += qs[i + 8 * u + 2 * j + 1] * h2f((unsigned short)(w >> 16));
+          }
+      }
+      for (; i + 8 <= hd; i += 8) {
+        i32x4 kv = *(const i32x4*)(kr + i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          unsigned w = (unsigned)kv[j];
+          acc += qs[i + 2 * j] * h2f((unsigned short)(w & 0xffffu));
+          acc += qs[i + 2 * j + 1] * h2f((unsigned short)(w >> 16));
+        }
+      }
+      for (; i < hd; i++) acc += qs[i] * h2f(kr[i]);
+    } else {
+      const float* kr = (const float*)kc + ((size_t)kvh * seq_cap + t) * hd;
+      int i = 0;
+      for (; i + 4 <= hd; i += 4) {
+        f32x4 kv = *(const f32x4*)(kr + i);
+        acc += qs[i] * kv[0];
+        acc += qs[i + 1] * kv[1];
+        acc += qs[i + 2] * kv[2];
+        acc += qs[i + 3] * kv[3];
+      }
+      for (; i < hd; i++) acc += qs[i] * kr[i];
+    }
+    scores[t] = acc;
+  }
+  __syncthreads();
+  // ---- softmax (in place; probabilities rounded to f16 for the f16 cache)
+  softmax_row<KV16>(scores, seq, exp_tab, s_red, &s_val);
+  // ---- out[n] = sum_t p[t] * V[t][n]
+  float val = 0.0f;
+  const int n = tid;
+  if (n < hd) {
+    if (KV16) {
+      const unsigned short* vr = (const unsigned short*)vc + (size_t)kvh * seq_cap * hd + n;
+      _Float16 c = (_Float16)0.0f;  // native f16 product and sum (devutil.hpp): the chain is one v_add_f16 per position
+      int t = 0;
+      for (; t + 16 <= seq; t += 16) {  // 16 loads in flight, then the (inherently serial) f16 accumulate chain
+        unsigned short vv[16];
+        if (vp && t == 0) {
+#pragma unroll
+          for (int u = 0; u < 16; u++) vv[u] = vpre[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const _Float16 prod = hbits(vv[u]) * (_Float16)scores[t + u];  // scores hold f16-representable values
+          c = c + prod;
+        }
+      }
+      for (; t < seq; t++) {
+        const _Float16 prod = hbits(vr[(size_t)t * hd]) * (_Float16)scores[t];
+        c = c + prod;
+      }
+      val = (float)c;
+    } else {
+      const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
+      float c = 0.0f;
+      int t = 0;
+      for (; t + 16 <= seq; t += 16) {
+        float vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) vv[u] = vr[(size_t)(t + u) * hd];
+#pragma unroll
+        for (int u = 0; u < 16; u++) c += scores[t + u] * vv[u];
+      }
+      for (; t < seq; t++) c += scores[t] * vr[(size_t)t * hd];
+      val = c;
+    }
+    out[head * hd + n] = val;
+  }
+  // ---- quantize the head's output for wo (only when blocks do not straddle heads)
+  if (xq != nullptr) {
+    const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
+    const float vq = live ? val : 0.f;
+    const QLane o = q81 ? quant_lane32<true>(vq, live) : quant_lane32<false>(vq, live);
+    if (live) {
+      int e = head * hd + n;
+      xq[e] = o.q;
+      if ((n & 31) == 0) {
+        xd[e >> 5] = o.d;
+        if (q81)
+          store_qaux<true>(xisum, e >> 5, o.aux);
+        else
+          store_qaux<false>(xisum, e >> 5, o.aux);
+      }
+    }
+  }
+}
+
+// ---- attention at long context: the same arithmetic over every CU ----------------------------------------------
+// One workgroup per head streams its whole K and V through one CU (~26 GB/s): 223 us per layer at 4000 cached
+// positions.  From `attn_long_from` positions on the step uses three kernels instead (f16 cache, head_dim % 32
+// == 0, n_heads / n_kv in {1, 2, 4, 8}); every rounding point and summation order is unchanged:
+//   k_attn_scores   (kv head, 128-position split): each thread scores ONE cached position against the G q heads
+//                   that share the kv head -- K is read once, f32 accumulation in k order (buf_f16.rs:83-97);
+//   k_attn_softmax  (head): softmax_row over the score row, probabilities rounded to f16;
+//   k_attn_pv       (kv head, 32-dim slice): V tiles are staged through LDS by the whole workgroup (read once for
+//                   the G heads), and G x 16 lanes run the f16 chains, two dims per lane on packed f16 math
+//                   (v_pk_mul_f16 + v_pk_add_f16 = the half crate's product / sum roundings, devutil.hpp).
+template <int G>
+__global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q, const unsigned short* __restrict__ kc,
+                                                     const int* __restrict__ pos_d, float* __restrict__ scores_g,
+                                                     int n_kv, int hd, int seq_cap, int nsplit) {
+  // one thread per (cached position, q head of the group): the G threads of a position sit in adjacent lanes and
+  // read the same K row (one fetch); each runs its own k-ordered f32 accumulation (buf_f16.rs:83-97)
+  extern __shared__ float lds[];  // qs[G][hd]
+  constexpr int TS = 256 / G;     // positions per workgroup
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int seq = *pos_d + 1;
+  if (sp * TS >= seq) return;
+  for (int idx = tid; idx < G * hd; idx += 256) {
+    const int g = idx / hd, i = idx - g * hd;
+    lds[idx] = h2f(f2h(q[(size_t)(j * G + g) * hd + i]));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+  }
+  __syncthreads();
+  const int g = tid % G;
+  const int t = sp * TS + tid / G;
+  if (t >= seq) return;
+  const unsigned short* kr = kc + ((size_t)j * seq_cap + t) * hd;
+  const float* qg = lds + g * hd;
+  float acc = 0.0f;
+  int i = 0;
+  for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
+    i32x4 kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int w4 = 0; w4 < 4; w4++) {
+        const unsigned w = (unsigned)kv[u][w4];
+        acc += qg[i + 8 * u + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
+        acc += qg[i + 8 * u + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
+      }
+  }
+  for (; i + 8 <= hd; i += 8) {
+    const i32x4 kv = *(const i32x4*)(kr + i);
+#pragma unroll
+    for (int w4 = 0; w4 < 4; w4++) {
+      const unsigned w = (unsigned)kv[w4];
+      acc += qg[i + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
+      acc += qg[i + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
+    }
+  }
+  for (; i < hd; i++) acc += qg[i] * h2f(kr[i]);
+  scores_g[(size_t)(j * G + g) * seq_cap + t] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ scores_g, const int* __restrict__ pos_d,
+                                                      const unsigned short* __restrict__ exp_tab,
+                                                      unsigned short* __restrict__ p16, int seq_cap) {
+  extern __shared__ float lds[];
+  __shared__ float s_red[4];
+  __shared__ float s_val;
+  const int head = blockIdx.x, seq = *pos_d + 1;
+  for (int t = threadIdx.x; t < seq; t += blockDim.x) lds[t] = scores_g[(size_t)head * seq_cap + t];
+  __syncthreads();
+  softmax_row<true>(lds, seq, exp_tab, s_red, &s_val);
+  for (int t = threadIdx.x; t < seq; t += blockDim.x) p16[(size_t)head * seq_cap + t] = f2h(lds[t]);  // exact: already f16 values
+}
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+#define ATTN_PV_TILE 256
+#define ATTN_PV_ROW (ATTN_PV_TILE + 4)  // words per LDS row: 16-byte aligned rows, shifted by 4 banks from each other
+template <int G>
+__global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restrict__ p16, const unsigned short* __restrict__ vc,
+                                                 const int* __restrict__ pos_d, float* __restrict__ out,
+                                                 signed char* __restrict__ xq, unsigned short* __restrict__ xd,
+                                                 void* __restrict__ xisum, int hd, int seq_cap, int q81) {
+  constexpr int T = ATTN_PV_TILE, ROW = ATTN_PV_ROW;
+  // LDS, two buffers each: V tile transposed to [16 dim pairs][T] words (a chain lane reads 4 consecutive positions
+  // of its dim pair with one ds_read_b128), P tile [G][T] words holding {p, p} (the packed multiplier, ready-made)
+  __shared__ __attribute__((aligned(16))) unsigned vt[2][16 * ROW];
+  __shared__ __attribute__((aligned(16))) unsigned pt[2][G * ROW];
+  const int tid = threadIdx.x;
+  const int nslice = hd / 32;
+  const int j = blockIdx.x / nslice, sl = blockIdx.x % nslice;
+  const int seq = *pos_d + 1;
+  const unsigned short* vbase = vc + (size_t)j * seq_cap * hd + sl * 32;
+  const int ntiles = (seq + T - 1) / T;
+  // loader role (all threads): V piece = 16 B (4 dim pairs) of row (tid / 4) + 64 r, piece tid % 4;
+  // P piece = 16 B = 8 positions of one head
+  i32x4 vreg[4], preg;
+  auto issue = [&](int tile) {
+    const int t0 = tile * T;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int t = t0 + (tid >> 2) + 64 * r;
+      t = t < seq_cap ? t : seq_cap - 1;  // rows past seq are read (inside the cache allocation) but never used
+      vreg[r] = *(const i32x4*)(vbase + (size_t)t * hd + (tid & 3) * 8);
+    }
+    if (tid < G * (T / 8)) {
+      const int g = tid / (T / 8), c8 = tid % (T / 8);
+      int t = t0 + c8 * 8;
+      t = t + 8 <= seq_cap ? t : seq_cap - 8;  // only past the end of the cache: those positions are never consumed
+      preg = *(const i32x4*)(p16 + (size_t)(j * G + g) * seq_cap + t);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int tl = (tid >> 2) + 64 * r;
+#pragma unroll
+      for (int i = 0; i < 4; i++) vt[buf][((tid & 3) * 4 + i) * ROW + tl] = (unsigned)vreg[r][i];
+    }
+    if (tid < G * (T / 8)) {
+      const int g = tid / (T / 8), c8 = tid % (T / 8);
+      unsigned pp[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned w = (unsigned)preg[i];
+        const unsigned a = w & 0xffffu, b = w >> 16;
+        pp[2 * i] = a | (a << 16);
+        pp[2 * i + 1] = b | (b << 16);
+      }
+      *(i32x4*)(&pt[buf][g * ROW + c8 * 8]) = i32x4{(int)pp[0], (int)pp[1], (int)pp[2], (int)pp[3]};
+      *(i32x4*)(&pt[buf][g * ROW + c8 * 8 + 4]) = i32x4{(int)pp[4], (int)pp[5], (int)pp[6], (int)pp[7]};
+    }
+  };
+  // chain role: lane c < G * 16 owns dims 2 dp, 2 dp + 1 of head j * G + g
+  const bool chain = tid < G * 16;
+  const int g = tid >> 4, dp = tid & 15;
+  h16x2 c2 = {(_Float16)0.0f, (_Float16)0.0f};
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile++) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles) issue(tile + 1);
+    if (chain) {
+      const int nt = seq - tile * T < T ? seq - tile * T : T;
+      const unsigned* vrow = &vt[buf][dp * ROW];
+      const unsigned* prow = &pt[buf][g * ROW];
+      int t = 0;
+      // NB rounds of 8 positions: all the LDS reads of a round go out before its (serial) packed adds, so the LDS
+      // latency is paid once per round
+#define PV_ROUND(NB)                                                                                         \
+  for (; t + 8 * NB <= nt; t += 8 * NB) {                                                                    \
+    i32x4 vq[2 * NB], pq[2 * NB];                                                                            \
+    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) {                                                     \
+      vq[b] = *(const i32x4*)(vrow + t + 4 * b);                                                             \
+      pq[b] = *(const i32x4*)(prow + t + 4 * b);                                                             \
+    }                                                                                                        \
+    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) _Pragma("unroll") for (int u = 0; u < 4; u++) {       \
+      const h16x2 pr = __builtin_bit_cast(h16x2, (unsigned)vq[b][u]) * __builtin_bit_cast(h16x2, (unsigned)pq[b][u]); \
+      c2 = c2 + pr;                                                                                          \
+    }                                                                                                        \
+  }
+      PV_ROUND(4)
+      PV_ROUND(1)
+#undef PV_ROUND
+      for (; t < nt; t++) {
+        const h16x2 pr = __builtin_bit_cast(h16x2, vrow[t]) * __builtin_bit_cast(h16x2, prow[t]);
+        c2 = c2 + pr;
+      }
+    }
+    if (tile + 1 < ntiles) commit(buf ^ 1);  // the other buffer was last read one iteration ago (barrier below)
+    __syncthreads();
+  }
+  if (!chain) return;
+  const float v0 = (float)c2[0], v1 = (float)c2[1];
+  const int head = j * G + g;
+  const int e0 = head * hd + sl * 32 + 2 * dp;
+  out[e0] = v0;
+  out[e0 + 1] = v1;
+  if (xq != nullptr) {  // the rhs block of the 32 dims held by this 16-lane DPP row (quant_lane32's arithmetic)
+    const float amax = row16_max_f32(fmaxf(fabsf(v0), fabsf(v1)));
+    const float dd = amax / 127.0f;
+    int q0, q1;
+    if (q81) {  // Q8_1 (buf_q8_1.rs:90-129)
+      q0 = (int)fminf(fmaxf(v0 / dd, -128.0f), 127.0f);
+      q1 = (int)fminf(fmaxf(v1 / dd, -128.0f), 127.0f);
+    } else {  // Q8_0 (buf_q8_0.rs:87-134)
+      q0 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(v0 / dd) & 0xffu);
+      q1 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(v1 / dd) & 0xffu);
+    }
+    const int qs = row16_sum_i32(q0 + q1);
+    xq[e0] = (signed char)q0;
+    xq[e0 + 1] = (signed char)q1;
+    if (dp == 0) {
+      xd[e0 >> 5] = f2h(dd);
+      if (q81)
+        store_qaux<true>(xisum, e0 >> 5, (int)f2h((float)qs * dd));
+      else
+        store_qaux<false>(xisum, e0 >> 5, qs);
+    }
+  }
+}
+
+// ---- batched-prefill attention: one workgroup = one kv head x R consecutive prompt rows x the G q heads of its
+// group (Q = G * R queries).  Per (row, head) the arithmetic is k_attn's, value for value -- f32 dots in k order,
+// softmax_row's table exp / sequential row sum (rows up to 1024 positions; longer prompts use k_attn) / true
+// division, the f16 PV chain in position order -- but a K row is fetched once for the Q queries that score against
+// it and a V element once for the Q / (256 / hd) chains a thread carries, instead of once per (row, head) workgroup:
+// the per-row kernel moved 2.1 GB through L2 per layer for 512 prompt rows of the 8B shape.
+template <bool KV16, int G, int R>
+__global__ __launch_bounds__(256) void k_attn_tile(const float* __restrict__ q, const void* __restrict__ kc,
+                                                   const void* __restrict__ vc, const int* __restrict__ pos_d,
+                                                   const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
+                                                   int n_heads, int n_kv, int hd, int seq_cap, int n_rows, int sstride) {
+  constexpr int Q = G * R;
+  extern __shared__ float lds[];
+  float* qs = lds;            // [Q][hd]: q rows (rounded to f16 for the f16 cache, batch_matmul.rs:39)
+  float* sc = lds + Q * hd;   // [Q][sstride]: scores, then probabilities
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kvh = blockIdx.x, r0 = blockIdx.y * R;
+  const int pos0 = *pos_d;
+  const int dim = n_heads * hd;
+  auto head_of = [&](int j) { return KV16 ? kvh * G + j : kvh + j * n_kv; };  // batch_matmul.rs:61-67 GQA maps
+  const int rows_here = n_rows - r0 < R ? n_rows - r0 : R;
+  for (int e = tid; e < Q * hd; e += 256) {  // query qi = r * G + j
+    const int qi = e / hd, i = e - qi * hd, r = qi / G, j = qi - r * G;
+    const float v = r < rows_here ? q[(size_t)(r0 + r) * dim + head_of(j) * hd + i] : 0.0f;
+    qs[e] = KV16 ? h2f(f2h(v)) : v;
+  }
+  __syncthreads();
+  // ---- scores + softmax: wave w owns the QW = Q / 4 queries w * QW .. (one prompt row: its causal length bounds the
+  // loop), lane = cached position; a K row is fetched once per wave and scored against the wave's queries
+  constexpr int QW = Q / 4;
+  static_assert(Q % 4 == 0 && (G % QW == 0 || QW % G == 0), "a wave's queries belong to one row");
+  {
+    const int q0 = wave * QW, rw = q0 / G;
+    if (rw < rows_here) {
+      const int seq = pos0 + r0 + rw + 1;
+      for (int t = lane; t < seq; t += 64) {
+        float acc[QW];
+#pragma unroll
+        for (int u = 0; u < QW; u++) acc[u] = 0.0f;
+        if (KV16) {
+          const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
+          for (int i = 0; i < hd; i += 16) {  // hd % 16 == 0 (host check); products added in k order per query
+            const i32x4 k0 = *(const i32x4*)(kr + i), k1 = *(const i32x4*)(kr + i + 8);
+            float kf[16];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              kf[2 * u] = h2f((unsigned short)((unsigned)k0[u] & 0xffffu));
+              kf[2 * u + 1] = h2f((unsigned short)((unsigned)k0[u] >> 16));
+              kf[8 + 2 * u] = h2f((unsigned short)((unsigned)k1[u] & 0xffffu));
+              kf[8 + 2 * u + 1] = h2f((unsigned short)((unsigned)k1[u] >> 16));
+            }
+#pragma unroll
+            for (int u = 0; u < QW; u++) {
+              const f32x4* qp = (const f32x4*)(qs + (q0 + u) * hd + i);
+#pragma unroll
+              for (int v4 = 0; v4 < 4; v4++) {
+                const f32x4 qv = qp[v4];
+                acc[u] += qv[0] * kf[4 * v4];
+                acc[u] += qv[1] * kf[4 * v4 + 1];
+                acc[u] += qv[2] * kf[4 * v4 + 2];
+                acc[u] += qv[3] * kf[4 * v4 + 3];
+              }
+            }
+          }
+        } else {
+          const float* kr = (const float*)kc + ((size_t)kvh * seq_cap + t) * hd;
+          for (int i = 0; i < hd; i += 4) {
+            const f32x4 kv = *(const f32x4*)(kr + i);
+#pragma unroll
+            for (int u = 0; u < QW; u++) {
+              const f32x4 qv = *(const f32x4*)(qs + (q0 + u) * hd + i);
+              acc[u] += qv[0] * kv[0];
+              acc[u] += qv[1] * kv[1];
+              acc[u] += qv[2] * kv[2];
+              acc[u] += qv[3] * kv[3];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < QW; u++) sc[(q0 + u) * sstride + t] = acc[u];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      // softmax per query (softmax.rs:36-54; softmax_row with the <= 1024 sequential row sum), by the same wave; the
+      // QW sequential row sums (one dependent v_add chain each) run interleaved
+#pragma unroll
+      for (int u = 0; u < QW; u++) {
+        float* srow = sc + (q0 + u) * sstride;
+        float mx = -INFINITY;
+        for (int t = lane; t < seq; t += 64) mx = fmaxf(mx, srow[t]);
+        mx = wave_max_f32(mx);
+        for (int t = lane; t < seq; t += 64) srow[t] = exp_cached_f(srow[t] - mx, exp_tab);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      float sum[QW];
+#pragma unroll
+      for (int u = 0; u < QW; u++) sum[u] = 0.0f;
+      for (int base = 0; base < seq; base += 64) {
+        float v[QW];
+#pragma unroll
+        for (int u = 0; u < QW; u++) v[u] = base + lane < seq ? sc[(q0 + u) * sstride + base + lane] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+#pragma unroll
+          for (int u = 0; u < QW; u++) sum[u] += rl_f(v[u], i);  // lanes past `seq` add +0.0 (exact)
+      }
+#pragma unroll
+      for (int u = 0; u < QW; u++) {
+        float* srow = sc + (q0 + u) * sstride;
+        for (int t = lane; t < seq; t += 64) {
+          const float pv = srow[t] / sum[u];
+          if (KV16) {  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), stored as the pair {p, p} the PV chains multiply by
+            const unsigned h = (unsigned)f2h(pv);
+            ((unsigned*)srow)[t] = h | (h << 16);
+          } else {
+            srow[t] = pv;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- out[qi][n] = sum_t p[qi][t] * V[t][n].  f16 cache: thread = (pair of columns, query group), the chains run on
+  // v_pk_mul_f16 / v_pk_add_f16 (per half exactly the scalar product-round, sum-round of buf_f16.rs:152-163); a V
+  // pair feeds every chain the thread carries.  f32 cache: thread = (column, query group), plain f32.
+  constexpr int QS = Q / 2 > 0 ? Q / 2 : 1;  // chains per thread (>= 2 query groups); unused slots have lim = 0
+  const int tpg = KV16 ? hd / 2 : hd;      // threads per query group
+  const int ngrp = 256 / tpg;
+  const int n = tid % tpg, grp = tid / tpg;
+  if (grp >= ngrp) return;  // ngrp >= 2 (host check), so Q / 2 chain slots cover the Q queries
+  const int ch = (Q + ngrp - 1) / ngrp;  // consecutive queries per group: normally the heads of ONE row (same length)
+  int lim[QS];
+  const float* prow[QS];
+  int lim_lo = 0x7fffffff, lim_hi = 0;
+#pragma unroll
+  for (int s2 = 0; s2 < QS; s2++) {
+    const int qi = grp * ch + s2;
+    const bool live = s2 < ch && qi < Q && qi / G < rows_here;
+    lim[s2] = live ? pos0 + r0 + qi / G + 1 : 0;
+    prow[s2] = sc + (live ? qi : 0) * sstride;
+    if (live) {
+      lim_lo = lim[s2] < lim_lo ? lim[s2] : lim_lo;
+      lim_hi = lim[s2] > lim_hi ? lim[s2] : lim_hi;
+    }
+  }
+  if (lim_hi == 0) return;
+  if (KV16) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const unsigned* vr = (const unsigned*)((const unsigned short*)vc + (size_t)kvh * seq_cap * hd) + n;
+    const int vs = hd / 2;  // dwords per V row
+    h2v c[QS];
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) c[s2] = h2v{(_Float16)0.0f, (_Float16)0.0f};
+    // the common case: every chain of the thread has the same causal length (one row) and QS / 2 live chains
+    const bool uniform = lim_lo == lim_hi;
+    int t0 = 0;
+    if (uniform) {
+      for (; t0 + 4 <= lim_hi; t0 += 4) {
+        unsigned vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vv[u] = vr[(size_t)(t0 + u) * vs];
+#pragma unroll
+        for (int s2 = 0; s2 < QS; s2++) {
+          if (lim[s2]) {  // thread-constant
+            // four {p, p} pairs, read as scalars (element extraction from a freshly loaded ext-vector feeding
+            // bit_casts was miscompiled here: every element became element 0)
+            const unsigned* pq = (const unsigned*)prow[s2] + t0;
+            unsigned pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pp[u] = pq[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const h2v prod = __builtin_bit_cast(h2v, vv[u]) * __builtin_bit_cast(h2v, pp[u]);
+              c[s2] = c[s2] + prod;
+            }
+          }
+        }
+      }
+    }
+    for (; t0 < lim_hi; t0++) {  // tail / mixed lengths
+      const h2v vp = __builtin_bit_cast(h2v, vr[(size_t)t0 * vs]);
+#pragma unroll
+      for (int s2 = 0; s2 < QS; s2++) {
+        if (t0 < lim[s2]) {
+          const h2v prod = vp * __builtin_bit_cast(h2v, ((const unsigned*)prow[s2])[t0]);
+          c[s2] = c[s2] + prod;
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) {
+      const int qi = grp * ch + s2;
+      if (lim[s2]) {
+        float* o = out + (size_t)(r0 + qi / G) * dim + head_of(qi % G) * hd + 2 * n;
+        o[0] = (float)c[s2][0];
+        o[1] = (float)c[s2][1];
+      }
+    }
+  } else {
+    const float* vr = (const float*)vc + (size_t)kvh * seq_cap * hd + n;
+    float c[QS];
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) c[s2] = 0.0f;
+    for (int t0 = 0; t0 < lim_hi; t0 += 8) {
+      float vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) vv[u] = t0 + u < lim_hi ? vr[(size_t)(t0 + u) * hd] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + u;
+#pragma unroll
+        for (int s2 = 0; s2 < QS; s2++) {
+          if (t < lim[s2]) c[s2] += prow[s2][t] * vv[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < QS; s2++) {
+      const int qi = grp * ch + s2;
+      if (lim[s2]) out[(size_t)(r0 + qi / G) * dim + head_of(qi % G) * hd + n] = c[s2];
+    }
+  }
+}
+
+}  // namespace crabml_hip

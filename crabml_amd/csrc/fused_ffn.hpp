@@ -1,0 +1,678 @@
+// fused_ffn.hpp -- wo / ffn_down GEMV + residual (+ the next RMSNorm / quantize in the epilogue), gate/up + SiLU*mul, the fused-FFN experiment, greedy sampler
+// Part of the fused decode step (fused.hip includes the three fused_*.hpp files once, in order; they are not stand-alone
+// translation units: the kernels are launched from fused.hip's host code).
+#pragma once
+#include "fused_common.hpp"
+
+namespace crabml_hip {
+// ---- GEMV + residual: x[row] = W[row].xq + x[row]   (matmul_vec, then add_inplace: arithmetic.rs:27-33) ---
+template <int FMT, int R, bool ADD>  // ADD: x[row] += W.xq (residual); else out[row] = W.xq (tensor-parallel partial sum)
+__global__ __launch_bounds__(128) void k_gemv_res(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x, int m, int nb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  // the residual is loaded up front (its latency overlaps the weight stream instead of trailing the reduction)
+  float res[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) res[r] = (ADD && lane == 0 && row0 + r < m) ? x[row0 + r] : 0.f;
+  float acc[R];
+  rows_dot<FMT, R>(w.q, w.d, act, row0, m, nb, lane, acc);
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) x[row0 + r] = ADD ? s + res[r] : s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_res_epi(const float* __restrict__ tmp, float* __restrict__ x, int m, int add) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) x[i] = add ? tmp[i] + x[i] : tmp[i];
+}
+// single-device simulation of the tensor-parallel all-reduce: every rank's partial <- sum over ranks (rank order)
+struct SimPtrs {
+  float* p[8];
+};
+__global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = ptrs.p[0][i];
+  for (int r = 1; r < nranks; r++) s += ptrs.p[r][i];
+  for (int r = 0; r < nranks; r++) ptrs.p[r][i] = s;
+}
+
+// ---- fast mode: GEMV + residual with the NEXT RMSNorm + quantization done in the epilogue ------------------------
+// The separate norm+quantize launch is a single-workgroup latency stage (6 us x 65 per token on Llama-3-8B).  Here
+// the producer of x (wo / ffn_down + residual) finishes the job: a 1024-thread workgroup owns 32 consecutive rows
+// = one rmsnorm chunk = one Q8_0 block (the k_gateup_q shape).  It publishes its ordered chunk sum of squares as
+// one 8-byte {sum, epoch} granule (a single write-through store: data and tag travel together, no fence needed),
+// gathers all dim/32 granules (one wave polls them with relaxed agent-scope loads), adds them in chunk order like
+// rms_norm.rs:35-40, and normalizes + quantizes its own block.  Every bit of the result equals k_norm_quant's:
+// same chunk sums, same serial chain, same divisions.  All dim/32 workgroups are co-resident by construction
+// (<= one per CU, checked at create); the poll is bounded and raises `fault` instead of hanging.
+// Q8_K quantizer of an f32 vector straight into LDS planes (q | d | bsums, as stage_act_q8k lays them out): one
+// wave per super-block.  The Q4_K wo / ffn_down kernels run it as their prologue on the attention output / h,
+// each workgroup for itself (16 KB / 56 KB of L2 reads), instead of a quantizer launch in front of them.
+__device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int nsb, unsigned* sq, float* sd, short* sbs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // four super-blocks of loads in flight per wave (ffn_down: 56 super-blocks over 16 waves; a round is one L2 latency)
+  for (int sb0 = wave; sb0 < nsb; sb0 += 4 * nw) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int sb = sb0 + u * nw;
+      v[u] = ((const f32x4*)x)[(sb < nsb ? sb : sb0) * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int sb = sb0 + u * nw;
+      if (sb >= nsb) break;  // wave-uniform
+      const Q8KLane o = q8k_wave_quant(v[u], lane);
+      sq[sb * 64 + lane] = o.packed;
+      if ((lane & 3) == 0) sbs[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
+      if (lane == 0) sd[sb] = o.d;
+    }
+  }
+  __syncthreads();
+}
+
+struct NormGather {
+  unsigned long long* slots;  // dim/16 granules: each workgroup's ordered sum of squares over its rows
+  unsigned long long* pair;   // dim row granules (read by a split chunk's partner / a Q8_K super-block's neighbours)
+  const int* serial;          // decode-step serial number (never reset): makes the epoch unique per launch
+  int* fault;
+  int nseg, seg;
+};
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// SPLIT workgroups share one 32-row chunk (16 waves x 2 / SPLIT rows); QIN (Q4_K): the rhs is the f32 vector xin
+// The tail of the wo / ffn_down kernels (k_gemv_res_nq, k_ffn): acc[] = this wave's RW row dots.  Publishes the
+// workgroup's rows / sum of squares, takes the one in-launch hop, normalizes + quantizes the rows it owns.
+// wg_index / nwg_all: this workgroup's index among the SPLIT * nchunks workgroups of the stage.
+template <int FMT, int SPLIT>
+__device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
+                                            float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
+                                            void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
+                                            int row, int lane, int wave, int wg_index, int nwg_all) {
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  constexpr bool KQ = FMT == CRABML_HIP_Q4_K;
+  constexpr int RW = 2 / SPLIT;
+  constexpr int ROWS = 32 / SPLIT;
+  // ---- epilogue: publish, one in-launch hop, normalize + quantize -------------------------------------------
+  // every row goes out as a {value, epoch} granule when another workgroup needs it (the partner of a split chunk;
+  // the seven neighbours of a Q8_K super-block), the workgroup's ordered sum of squares as one more
+  constexpr bool ROWG = SPLIT > 1 || KQ;
+#pragma unroll
+  for (int r = 0; r < RW; r++) {
+    const float s = wave_sum_f32(acc[r]);
+    if (lane == 0) hv[part * ROWS + wave * RW + r] = s;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // wave 0 owns the stores: ROWS consecutive rows per instruction (x and the row granules are one or two lines,
+  // not 32 separate partial writes from 16 waves)
+  if (lane < ROWS) {
+    const float xv = hv[part * ROWS + lane] + res;  // x = matmul_out + x (llama2.rs:266 / :636)
+    x[row + lane] = xv;
+    hv[part * ROWS + lane] = xv;
+    if (ROWG)
+      __hip_atomic_store(ng.pair + row + lane, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // sum of squares of a chunk = (rows 0..15 in order) + (rows 16..31 in order): a split chunk's two workgroups
+  // each own one half (norm_quant_block<HALF> computes the same)
+  float cs;
+  {
+    float h0 = -0.0f, h1 = -0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const f32x4 t = ((const f32x4*)hv)[(SPLIT > 1 ? part * 4 : 0) + j];
+      h0 += t[0] * t[0];
+      h0 += t[1] * t[1];
+      h0 += t[2] * t[2];
+      h0 += t[3] * t[3];
+    }
+    if (SPLIT == 1) {
+#pragma unroll
+      for (int j = 4; j < 8; j++) {
+        const f32x4 t = ((const f32x4*)hv)[j];
+        h1 += t[0] * t[0];
+        h1 += t[1] * t[1];
+        h1 += t[2] * t[2];
+        h1 += t[3] * t[3];
+      }
+      cs = h0 + h1;
+    } else {
+      cs = h0;
+    }
+  }
+  if (lane == 0)
+    __hip_atomic_store(ng.slots + wg_index, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granule is on its way before the polls queue up behind it
+  auto poll = [&](const unsigned long long* p) -> float {
+    unsigned long long g = ld_granule(p);
+    int tries = 0;
+    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+      __builtin_amdgcn_s_sleep(2);
+      g = ld_granule(p);
+      tries++;
+    }
+    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+    return __builtin_bit_cast(float, (unsigned)g);
+  };
+  // the rows of other workgroups first (published before their sums; the loads fly while the stragglers arrive) ...
+  const int l32 = lane & 31;
+  const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
+  const int sb = blk >> 3;
+  float v = 0.0f;
+  f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (KQ) {
+    const unsigned long long* p = ng.pair + sb * 256 + lane * 4;
+    unsigned long long g[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) g[i] = ld_granule(p + i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v4[i] = (unsigned)(g[i] >> 32) == epoch ? __builtin_bit_cast(float, (unsigned)g[i]) : poll(p + i);
+  } else if (SPLIT > 1) {
+    if (lane < 32) v = own ? hv[l32] : poll(ng.pair + blk * 32 + l32);
+  } else {
+    v = hv[l32];
+  }
+  // ... then the hop: every workgroup's sum, added strictly in chunk order
+  float sum = 0.0f;
+  const int nwg = nwg_all;
+  for (int base = 0; base < nwg; base += 64) {
+    const int c = base + lane;
+    float cv = c < nwg ? poll(ng.slots + c) : 0.0f;
+    if (SPLIT > 1) cv += dpp_f<0xB1>(cv);  // chunk = its two halves (the same value on both lanes of the pair)
+#pragma unroll
+    for (int i = 0; i < 64; i += SPLIT) sum += rl_f(cv, i);  // lanes past the grid add +0.0
+  }
+  const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
+  if constexpr (!KQ) {
+    const float xn = (v / rms) * wn;
+    const QLane o = quant_lane32<Q81>(xn, true);
+    if (lane < 32 && own) {
+      q[blk * 32 + lane] = o.q;
+      if (lane == 0) {
+        ((unsigned short*)d)[blk] = o.d;
+        store_qaux<Q81>(isum, blk, o.aux);
+      }
+    }
+  } else {
+    // Q8_K (buf_q8_k.rs:84-131): the scale comes from the FIRST element of maximal |x| of the 256-element
+    // super-block = this chunk and its 7 neighbours.  The wave holds the super-block's 256 rows (4 per lane, from
+    // their granules), normalizes them all and runs the whole block's quantizer; it stores the part that is its own.
+    f32x4 xn;
+#pragma unroll
+    for (int i = 0; i < 4; i++) xn[i] = (v4[i] / rms) * wn4[i];
+    const Q8KLane o = q8k_wave_quant(xn, lane);
+    const int l0 = (blk & 7) * 8 + part * (ROWS / 4);
+    if (lane >= l0 && lane < l0 + ROWS / 4) {
+      ((unsigned*)q)[sb * 64 + lane] = o.packed;
+      if ((lane & 3) == 0) ((short*)isum)[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
+    }
+    if (lane == 0 && (blk & 7) == 0 && part == 0) ((float*)d)[sb] = o.d;
+  }
+}
+
+template <int FMT, int SPLIT, bool QIN = false>
+__global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
+                                                      float* __restrict__ x,
+                                                      const float* __restrict__ wnext, float eps,
+                                                      signed char* __restrict__ q, void* __restrict__ d,
+                                                      void* __restrict__ isum, NormGather ng, int nb, Planes6 w6) {
+  constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
+  constexpr int RW = 2 / SPLIT;         // rows per wave
+  constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
+  __shared__ __attribute__((aligned(16))) float hv[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+  const int nchunks = gridDim.x / SPLIT;
+  const int row = blk * 32 + part * ROWS + wave * RW;
+  float res = 0.f;                         // wave 0: the residual of row (first row of the workgroup) + lane
+  float wn = 0.f;                          // the next RMSNorm's weights for the rows this wave will normalize,
+  f32x4 wn4 = {0.f, 0.f, 0.f, 0.f};        // loaded up front (off the critical path after the hop)
+  unsigned epoch = 0;
+  if (wave == 0) {
+    if (lane < ROWS) res = x[row + lane];
+    if constexpr (KQ)
+      wn4 = ((const f32x4*)wnext)[(blk >> 3) * 64 + lane];
+    else
+      wn = wnext[blk * 32 + (lane & 31)];
+  }
+  if (wave == 0) epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
+  // RW rows x two blocks per lane in flight (one workgroup per CU: the loads have to supply the parallelism);
+  // terms are added in block order, as rows_partial does
+  float acc[RW];
+  if constexpr (KQ && QIN) {
+    // the rhs arrives as f32 (attention output / h): quantize it to Q8_K in LDS first
+    extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
+    float* sd = (float*)(lds_act + nb * 16);
+    short* sbs = (short*)(sd + nb);
+    // the first weight pieces are requested before the prologue (they do not depend on it): its L2 round trip
+    // and the quantizer run under the HBM latency of the stream's head
+    if (w6.base != nullptr) {  // this layer's matrix is Q6_K (a *_K_M mix): same rhs, its own inner loop
+      stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
+      const ActQ8_K la6{lds_act, sd, sbs};
+      rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
+      nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
+                              (int)blockIdx.x, (int)gridDim.x);
+      return;
+    }
+    constexpr int PRE = 2;
+    Q4KPiece<false> pw[PRE][RW];
+#pragma unroll
+    for (int it = 0; it < PRE; it++) {
+      const int c = it * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < RW; r++) pw[it][r] = q4k_load<false>(w.q, (const i32x4*)w.d, (size_t)(row + r), nb, c < nb * 8 ? c : nb * 8 - 1, lane);
+    }
+    stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
+    const ActQ8_K la{lds_act, sd, sbs};
+#pragma unroll
+    for (int r = 0; r < RW; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < PRE; it++) {
+      const int c = it * 64 + lane;
+      if (c < nb * 8) {
+        const Q4KX xx = q4k_loadx(la, c);
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] += q4k_term<false>(pw[it][r], xx, c);
+      }
+    }
+    rows_partial_q4k<RW, false>(w.q, (const i32x4*)w.d, la, row, nchunks * 32, nb, lane, acc, PRE * 64);
+  } else if constexpr (KQ) {
+    if (w6.base != nullptr)
+      rows_partial_q6k<RW>(w6.base, w6.off_qh, act, row, nchunks * 32, nb, lane, acc);
+    else
+      rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
+  } else {
+    using F = BlockFmt<FMT>;
+#pragma unroll
+    for (int r = 0; r < RW; r++) acc[r] = 0.f;
+    const int nu = nb * F::UNITS;
+    for (int u = lane; u < nu; u += 128) {
+      const int u2 = u + 64;
+      const bool two = u2 < nu;
+      const int uu = two ? u2 : u;
+      typename F::Blk ka[RW], kb[RW];
+#pragma unroll
+      for (int r = 0; r < RW; r++) {
+        ka[r] = F::load(w.q, w.d, (size_t)(row + r), nb, u);
+        kb[r] = F::load(w.q, w.d, (size_t)(row + r), nb, uu);
+      }
+      const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
+#pragma unroll
+      for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], xa);
+      if (two) {
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], xb);
+      }
+    }
+  }
+  nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
+                          (int)gridDim.x);
+}
+
+// ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
+__device__ __forceinline__ float silu_mul(float g, float u, const unsigned short* __restrict__ exp_tab) {
+  float nexp = exp_cached_f(-g, exp_tab);
+  return (g / (1.0f + nexp)) * u;
+}
+template <int FMT>
+__global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename ActOf<FMT>::type act,
+                                                const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m, int nb) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= m) return;
+  float ag[1], au[1];
+  rows_dot<FMT, 1>(wg.q, wg.d, act, row, m, nb, lane, ag);
+  rows_dot<FMT, 1>(wu.q, wu.d, act, row, m, nb, lane, au);
+  const float g = wave_sum_f32(ag[0]), u = wave_sum_f32(au[0]);
+  if (lane == 0) h[row] = silu_mul(g, u, exp_tab);
+}
+// Q4_K gate/up with the Q8_K activation planes staged in LDS once per workgroup (1024 threads = 32 hidden rows x
+// {gate, up}): the per-lane activation reads (2 x 16 B + d + 2 bsums per 16 B of quants) leave the vector-memory
+// path, which the K-quant inner loop otherwise keeps ~57 % busy (rocprofv3 TA_BUSY) while VALU sits at 15 %.
+__global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
+                                                       float* __restrict__ h, int m, int nsb) {
+  extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
+  const int k = nsb * 256;
+  i32x4* sq = lds_act;
+  float* sd = (float*)(sq + k / 16);
+  short* sbs = (short*)(sd + nsb);
+  for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.q[i];
+  for (int i = threadIdx.x; i < nsb; i += 1024) sd[i] = act.d[i];
+  for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
+  __syncthreads();
+  const ActQ8_K la{sq, sd, sbs};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 32 + wave * 2;
+  if (row0 >= m) return;
+  float ag[2], au[2];
+  rows_partial_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag);
+  rows_partial_q4k<2, false>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const float g = wave_sum_f32(ag[r]), u = wave_sum_f32(au[r]);
+    if (lane == 0 && row0 + r < m) h[row0 + r] = silu_mul(g, u, exp_tab);
+  }
+}
+
+// Same, with the Q8_0 quantization of h (the rhs of ffn_down) folded in: a 1024-thread workgroup owns 32
+// consecutive hidden rows = one quant block; each of its 16 waves computes 2 rows (4 weight rows in flight),
+// parks the h values in LDS, and one half-wave quantizes the block (buf_q8_0.rs:87-134).  hidden/32
+// workgroups (448 for Llama-3-8B) are all resident at once (2 per CU).  Saves a launch per layer.
+template <int FMT>
+__global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typename ActOf<FMT>::type act,
+                                                   const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
+                                                   unsigned short* __restrict__ d, void* __restrict__ isum, int nb) {
+  using F = BlockFmt<FMT>;
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  __shared__ float hv[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int row = blk * 32 + wave * 2;  // rows row, row+1
+  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+  const int nu = nb * F::UNITS;
+  for (int u = lane; u < nu; u += 64) {
+    typename F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, u);
+    typename F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, u);
+    typename F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
+    typename F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
+    const XUnit x = F::loadx(act, u);
+    g0 += F::term(bg0, x);
+    u0 += F::term(bu0, x);
+    g1 += F::term(bg1, x);
+    u1 += F::term(bu1, x);
+  }
+  g0 = wave_sum_f32(g0);
+  u0 = wave_sum_f32(u0);
+  g1 = wave_sum_f32(g1);
+  u1 = wave_sum_f32(u1);
+  if (lane == 0) {
+    hv[wave * 2] = silu_mul(g0, u0, exp_tab);
+    hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const QLane o = quant_lane32<Q81>(hv[threadIdx.x], true);
+    q[blk * 32 + threadIdx.x] = o.q;
+    if (threadIdx.x == 0) {
+      d[blk] = o.d;
+      store_qaux<Q81>(isum, blk, o.aux);
+    }
+  }
+}
+// ---- gate/up + SiLU*mul + quantize + ffn_down + residual + next RMSNorm/quantize in ONE launch ----------------------
+// EXPERIMENT, opt-in (CRABML_HIP_LLAMA_FFN_FUSION): measured 27.5-28.7 us against 12.9 + 0.8 + 10.7 us for the two
+// kernels it replaces on the 8B shape ("measured and rejected"), bit-identical to them.
+// The two halves of the FFN are k_gateup_q and k_gemv_res_nq<FMT, 2> back to back; what the single launch was meant
+// to buy is the boundary between them: ffn_down's first weight loads are requested BEFORE its workgroup waits for h,
+// so the HBM round trip of the stream's head runs under the hand-off instead of after a kernel boundary.  h never touches a
+// plane in global memory: every 32-row block goes out as 8 {4 quants, epoch} granules + 1 {d | aux, epoch} granule
+// (aux = the block's quant sum for Q8_0 -- |sum| <= 4096 fits 16 bits -- or s for Q8_1), and every workgroup polls
+// all of them (hidden/4 + hidden/32 relaxed agent-scope loads, 4 per thread) into its own LDS copy of the planes.
+// Grid = dim/16 workgroups of 1024 threads, all resident (the norm-epilogue condition); workgroup b owns the
+// hidden blocks b and b + grid (the latter when it exists) and, for ffn_down, half of chunk b / 2.
+struct HGather {
+  unsigned long long* hq;  // hidden/4 granules
+  unsigned long long* hs;  // hidden/32 granules
+};
+template <class F, int NB, class ACT>
+__device__ __forceinline__ void ffn_gateup_rows(const Planes& wg, const Planes& wu, const ACT& act, int nb, int lane,
+                                                const int (&row)[NB], float (&g)[NB][2], float (&u2)[NB][2]) {
+#pragma unroll
+  for (int k = 0; k < NB; k++) g[k][0] = g[k][1] = u2[k][0] = u2[k][1] = 0.f;
+  const int nu = nb * F::UNITS;
+  // two units per row in flight (one workgroup per CU: the loads have to supply the parallelism; with one unit per
+  // iteration a wave paid an HBM round trip per iteration and the phase streamed at 3.3 TB/s); terms in block order
+  for (int u = lane; u < nu; u += 128) {
+    const int ub = u + 64;
+    const bool two = ub < nu;
+    const int uu = two ? ub : u;
+    typename F::Blk bg[NB][2][2], bu[NB][2][2];
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        bg[k][r][0] = F::load(wg.q, wg.d, (size_t)(row[k] + r), nb, u);
+        bu[k][r][0] = F::load(wu.q, wu.d, (size_t)(row[k] + r), nb, u);
+        bg[k][r][1] = F::load(wg.q, wg.d, (size_t)(row[k] + r), nb, uu);
+        bu[k][r][1] = F::load(wu.q, wu.d, (size_t)(row[k] + r), nb, uu);
+      }
+    const XUnit xa = F::loadx(act, u), xb = F::loadx(act, uu);
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        g[k][r] += F::term(bg[k][r][0], xa);
+        u2[k][r] += F::term(bu[k][r][0], xa);
+      }
+    if (two) {
+#pragma unroll
+      for (int k = 0; k < NB; k++)
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          g[k][r] += F::term(bg[k][r][1], xb);
+          u2[k][r] += F::term(bu[k][r][1], xb);
+        }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      g[k][r] = wave_sum_f32(g[k][r]);
+      u2[k][r] = wave_sum_f32(u2[k][r]);
+    }
+}
+template <int FMT>
+__global__ __launch_bounds__(1024) void k_ffn(Planes wg, Planes wu, Planes wdn, typename ActOf<FMT>::type act,
+                                              const unsigned short* __restrict__ exp_tab, float* __restrict__ x,
+                                              const float* __restrict__ wnext, float eps, signed char* __restrict__ q,
+                                              void* __restrict__ d, void* __restrict__ isum, NormGather ng, HGather hg, int nb_in,
+                                              int nblk_h, int off_d, int off_aux) {
+  using F = BlockFmt<FMT>;
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  extern __shared__ i32x4 lds_h[];  // phase B: h's activation planes, act_layout order
+  __shared__ __attribute__((aligned(16))) float hv[64];
+  __shared__ __attribute__((aligned(16))) signed char hqb[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = (int)gridDim.x;
+  const unsigned epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
+  // ---- phase A: gate/up rows of this workgroup's hidden blocks (wave w: rows 2w, 2w + 1 of each block)
+  const int b0 = (int)blockIdx.x, b1 = b0 + G;
+  const bool has0 = b0 < nblk_h, has1 = b1 < nblk_h;
+  if (has0) {
+    if (has1) {
+      const int row[2] = {b0 * 32 + wave * 2, b1 * 32 + wave * 2};
+      float g[2][2], u2[2][2];
+      ffn_gateup_rows<F, 2>(wg, wu, act, nb_in, lane, row, g, u2);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+          for (int r = 0; r < 2; r++) hv[k * 32 + wave * 2 + r] = silu_mul(g[k][r], u2[k][r], exp_tab);
+      }
+    } else {
+      const int row[1] = {b0 * 32 + wave * 2};
+      float g[1][2], u2[1][2];
+      ffn_gateup_rows<F, 1>(wg, wu, act, nb_in, lane, row, g, u2);
+      if (lane == 0) {
+        hv[wave * 2] = silu_mul(g[0][0], u2[0][0], exp_tab);
+        hv[wave * 2 + 1] = silu_mul(g[0][1], u2[0][1], exp_tab);
+      }
+    }
+  }
+  __syncthreads();
+  if ((wave == 0 && has0) || (wave == 1 && has1)) {  // wave k quantizes and publishes block k (buf_q8_0.rs:87-134)
+    const int hb = wave == 0 ? b0 : b1;
+    const QLane o = quant_lane32<Q81>(hv[wave * 32 + (lane & 31)], true);
+    if (lane < 32) hqb[wave * 32 + lane] = o.q;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 8)
+      __hip_atomic_store(hg.hq + hb * 8 + lane, ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)hqb)[wave * 8 + lane],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0)
+      __hip_atomic_store(hg.hs + hb, ((unsigned long long)epoch << 32) | (unsigned long long)((unsigned)o.d | (((unsigned)o.aux & 0xffffu) << 16)),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): on their way before this wave starts polling
+  }
+  // ---- phase B set-up: ffn_down row of this wave, its first weight units requested before the hand-off
+  const int blk = (int)blockIdx.x >> 1, part = (int)blockIdx.x & 1;
+  const int nchunks = G >> 1;
+  const int row = blk * 32 + part * 16 + wave;
+  float res = 0.f, wn = 0.f;
+  const f32x4 wn4 = {0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) {
+    if (lane < 16) res = x[row + lane];
+    wn = wnext[blk * 32 + (lane & 31)];
+  }
+  const int nu = nblk_h * F::UNITS;
+  const int ua = lane < nu ? lane : nu - 1, ub = lane + 64 < nu ? lane + 64 : nu - 1;
+  const typename F::Blk ka0 = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, ua);
+  const typename F::Blk kb0 = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, ub);
+  // ---- the hand-off: all of h into this workgroup's LDS planes
+  char* P = (char*)lds_h;
+  auto poll = [&](const unsigned long long* p) -> unsigned {
+    unsigned long long gq = ld_granule(p);
+    int tries = 0;
+    while ((unsigned)(gq >> 32) != epoch && tries < (1 << 21)) {
+      __builtin_amdgcn_s_sleep(2);
+      gq = ld_granule(p);
+      tries++;
+    }
+    if ((unsigned)(gq >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+    return (unsigned)gq;
+  };
+  // every thread requests its (up to 4) quant granules right away -- for the workgroup that arrives last, which
+  // sets the pace, everything is already published and comes back fresh in the same round trip as the scale
+  // granules; wave 0 alone spins on the scale granules (1024 spinning threads per early workgroup would sit on the
+  // memory path the late workgroups are still streaming weights through); stale quant granules are re-polled after
+  const int nq = nblk_h * 8;
+  unsigned long long gq[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = tid + u * 1024;
+    gq[u] = ld_granule(hg.hq + (i < nq ? i : tid));
+  }
+  if (wave == 0) {
+    for (int i = lane; i < nblk_h; i += 64) {
+      const unsigned v = poll(hg.hs + i);
+      ((unsigned short*)(P + off_d))[i] = (unsigned short)(v & 0xffffu);
+      if constexpr (Q81)
+        ((unsigned short*)(P + off_aux))[i] = (unsigned short)(v >> 16);
+      else
+        ((int*)(P + off_aux))[i] = (int)(short)(v >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = tid + u * 1024;
+    if (i < nq) ((unsigned*)P)[i] = (unsigned)(gq[u] >> 32) == epoch ? (unsigned)gq[u] : poll(hg.hq + i);
+  }
+  for (int i = tid + 4 * 1024; i < nq; i += 1024) ((unsigned*)P)[i] = poll(hg.hq + i);  // hidden > 16384 only
+  __syncthreads();
+  // ---- phase B: the ffn_down row against the LDS planes (terms in block order, as k_gemv_res_nq adds them)
+  typename ActOf<FMT>::type la;
+  la.q = (const i32x4*)P;
+  la.d = (const unsigned short*)(P + off_d);
+  if constexpr (Q81)
+    la.s = (const unsigned short*)(P + off_aux);
+  else
+    la.isum = (const int*)(P + off_aux);
+  float acc[1] = {0.f};
+  {
+    const XUnit xa = F::loadx(la, ua), xb = F::loadx(la, ub);
+    if (lane < nu) acc[0] += F::term(ka0, xa);
+    if (lane + 64 < nu) acc[0] += F::term(kb0, xb);
+  }
+  for (int u = lane + 128; u < nu; u += 128) {
+    const int u2 = u + 64;
+    const bool two = u2 < nu;
+    const int uu = two ? u2 : u;
+    const typename F::Blk ka = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, u);
+    const typename F::Blk kb = F::load(wdn.q, wdn.d, (size_t)row, nblk_h, uu);
+    const XUnit xa = F::loadx(la, u), xb = F::loadx(la, uu);
+    acc[0] += F::term(ka, xa);
+    if (two) acc[0] += F::term(kb, xb);
+  }
+  nq_epilogue<FMT, 2>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row - wave, lane, wave,
+                      (int)blockIdx.x, G);
+}
+
+__global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g, const float* __restrict__ u,
+                                                    const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) h[i] = silu_mul(g[i], u[i], exp_tab);
+}
+
+// ---- greedy sampler + advance: Iterator::max_by keeps the LAST maximum (sampler.rs:109-116) ------------
+// stage 1: ARGMAX_BLOCKS workgroups, each over a contiguous slice; stage 2: one wave combines and advances.
+#define ARGMAX_BLOCKS 128
+__device__ __forceinline__ void argmax_combine(float& cv, int& ci, float ov, int oi) {
+  // keep the later index among equal maxima; an index of -1 means "empty"
+  bool take = oi >= 0 && (ci < 0 || ov > cv || (!(cv > ov) && oi > ci));
+  if (take) {
+    cv = ov;
+    ci = oi;
+  }
+}
+__global__ __launch_bounds__(256) void k_argmax_partial(const float* __restrict__ logits, int n, float* __restrict__ pv,
+                                                        int* __restrict__ pi) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
+  float bv = -INFINITY;
+  int bi = -1;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) argmax_combine(bv, bi, logits[i], i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    argmax_combine(bv, bi, ov, oi);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = bv;
+    si[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) argmax_combine(bv, bi, sv[w], si[w]);
+    pv[blockIdx.x] = bv;
+    pi[blockIdx.x] = bi;
+  }
+}
+__global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
+                                                    int* __restrict__ token_d, int* __restrict__ pos_d,
+                                                    int* __restrict__ step_d, unsigned* __restrict__ out_tokens, int out_cap,
+                                                    int* __restrict__ serial_d) {
+  float bv = -INFINITY;
+  int bi = -1;
+  for (int i = threadIdx.x; i < nparts; i += 64) argmax_combine(bv, bi, pv[i], pi[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    argmax_combine(bv, bi, ov, oi);
+  }
+  if (threadIdx.x == 0) {
+    *token_d = bi;
+    int st = *step_d;
+    if (st < out_cap) out_tokens[st] = (unsigned)bi;
+    *step_d = st + 1;
+    *pos_d = *pos_d + 1;
+    *serial_d = *serial_d + 1;
+  }
+}
+
+}  // namespace crabml_hip
