@@ -134,6 +134,8 @@ struct crabml_hip_llama {
   float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr, *pf_qr = nullptr, *pf_attn = nullptr,
         *pf_tmp = nullptr, *pf_g = nullptr, *pf_u = nullptr;
   char *pf_act_dim = nullptr, *pf_act_hid = nullptr;
+  float* pf_scores = nullptr;          // long prompts: [PF_LONG_ROWS][n_heads][seq_len] f32 scores
+  unsigned short* pf_p16 = nullptr;    //               and f16 probabilities, allocated on first use
   std::vector<std::pair<void*, size_t>> allocs;
 };
 
@@ -183,11 +185,11 @@ void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned shor
   for (int i = 0; i < 3; i++)
     if (prof) prof_begin(dev, &r[i], CRABML_HIP_F32, 7 + i, 0.0);  // stages 7 / 8 / 9: scores / softmax / pv
   launch_k(st, prof ? &r[0] : nullptr, k_attn_scores<G>, dim3(n_kv * nsplit), dim3(256), (size_t)G * hd * sizeof(float),
-           (const float*)c->qbuf, (const unsigned short*)c->kc[l], pos_d, c->scores_g, n_kv, hd, seq_cap, nsplit);
+           (const float*)c->qbuf, (const unsigned short*)c->kc[l], pos_d, c->scores_g, n_kv, hd, seq_cap, nsplit, 0);
   launch_k(st, prof ? &r[1] : nullptr, k_attn_softmax, dim3(c->n_heads_l), dim3(256), (size_t)seq_cap * sizeof(float),
-           (const float*)c->scores_g, pos_d, (const unsigned short*)dev->exp_table, c->p16, seq_cap);
+           (const float*)c->scores_g, pos_d, (const unsigned short*)dev->exp_table, c->p16, seq_cap, 0);
   launch_k(st, prof ? &r[2] : nullptr, k_attn_pv<G>, dim3(n_kv * (hd / 32)), dim3(256), 0, (const unsigned short*)c->p16,
-           (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap, c->qt == CRABML_HIP_Q8_1 ? 1 : 0);
+           (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, 0);
   for (int i = 0; i < 3; i++)
     if (prof) prof_end(dev, &r[i]);
 }
@@ -728,6 +730,45 @@ bool launch_attn_tile(crabml_hip_llama* c, int l, int B, int pos0) {
   }
 }
 
+// prompts past 1024 positions: the three long-context kernels with a row dimension (grid.y), PF_LONG_ROWS rows at a time
+// (score / probability scratch: rows x n_heads x seq_len x 6 bytes)
+constexpr int PF_LONG_ROWS = 64;
+template <int G>
+int launch_attn_long_rows_t(crabml_hip_llama* c, int l, int B) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const int hd = c->hd, seq_cap = (int)c->cfg.seq_len, n_kv = c->n_kv_l, n_heads = c->n_heads_l;
+  const int* pos_d = c->state + 6;
+  const int ts = 256 / G, nsplit = (seq_cap + ts - 1) / ts;
+  if (!c->pf_scores) {
+    CH_TRY(dalloc(c, (size_t)PF_LONG_ROWS * n_heads * seq_cap * 4, (void**)&c->pf_scores));
+    CH_TRY(dalloc(c, (size_t)PF_LONG_ROWS * n_heads * seq_cap * 2, (void**)&c->pf_p16));
+  }
+  for (int r0 = 0; r0 < B; r0 += PF_LONG_ROWS) {
+    const unsigned rows = (unsigned)(B - r0 < PF_LONG_ROWS ? B - r0 : PF_LONG_ROWS);
+    k_attn_scores<G><<<dim3(n_kv * nsplit, rows), 256, (size_t)G * hd * sizeof(float), st>>>(
+        (const float*)c->pf_qr, (const unsigned short*)c->kc[l], pos_d, c->pf_scores, n_kv, hd, seq_cap, nsplit, r0);
+    k_attn_softmax<<<dim3(n_heads, rows), 256, (size_t)seq_cap * sizeof(float), st>>>(
+        (const float*)c->pf_scores, pos_d, (const unsigned short*)dev->exp_table, c->pf_p16, seq_cap, r0);
+    k_attn_pv<G><<<dim3(n_kv * (hd / 32), rows), 256, 0, st>>>((const unsigned short*)c->pf_p16, (const unsigned short*)c->vc[l], pos_d,
+                                                               c->pf_attn, nullptr, nullptr, nullptr, hd, seq_cap, 0, r0);
+  }
+  return 0;
+}
+// 1 = launched, 0 = not covered, < 0 = error
+int launch_attn_long_rows(crabml_hip_llama* c, int l, int B) {
+  if (!c->attn_long_ok || (c->cfg.flags & CRABML_HIP_LLAMA_NO_TILE_ATTENTION)) return 0;
+  int rc;
+  switch (c->n_heads_l / c->n_kv_l) {
+    case 1: rc = launch_attn_long_rows_t<1>(c, l, B); break;
+    case 2: rc = launch_attn_long_rows_t<2>(c, l, B); break;
+    case 4: rc = launch_attn_long_rows_t<4>(c, l, B); break;
+    case 8: rc = launch_attn_long_rows_t<8>(c, l, B); break;
+    default: return 0;
+  }
+  return rc == 0 ? 1 : -1;
+}
+
 int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t pos0, bool want_logits) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
@@ -774,7 +815,14 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int pairs = (dim + 2 * kv_dim) / 2;
     k_qkv_epi_rows<<<dim3((pairs + 255) / 256, rows), 256, 0, st>>>(c->pf_q, c->pf_k, c->pf_v, e);
-    if (!launch_attn_tile(c, l, (int)B, (int)pos0)) {  // long prompts / unusual shapes: one workgroup per (head, row)
+    int along = 0;
+    if (!launch_attn_tile(c, l, (int)B, (int)pos0)) {
+      along = launch_attn_long_rows(c, l, (int)B);  // past 1024 positions: the long-context kernels, rows in grid.y
+      if (along < 0) return CRABML_HIP_UNEXPECTED;
+    } else {
+      along = 1;
+    }
+    if (!along) {  // unusual shapes (f32 cache past 1024 positions, odd group sizes): one workgroup per (head, row)
       const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
       if (kv16)
         k_attn<true><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,

@@ -183,14 +183,18 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
 template <int G>
 __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q, const unsigned short* __restrict__ kc,
                                                      const int* __restrict__ pos_d, float* __restrict__ scores_g,
-                                                     int n_kv, int hd, int seq_cap, int nsplit) {
+                                                     int n_kv, int hd, int seq_cap, int nsplit, int row0) {
   // one thread per (cached position, q head of the group): the G threads of a position sit in adjacent lanes and
   // read the same K row (one fetch); each runs its own k-ordered f32 accumulation (buf_f16.rs:83-97)
   extern __shared__ float lds[];  // qs[G][hd]
   constexpr int TS = 256 / G;     // positions per workgroup
   const int tid = threadIdx.x;
   const int j = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
-  const int seq = *pos_d + 1;
+  // blockIdx.y: row of a prefill batch (row0 + y: one more cached position per row); a decode step has one row
+  const int rowb = row0 + (int)blockIdx.y;
+  const int seq = *pos_d + 1 + rowb;
+  q += (size_t)rowb * n_kv * G * hd;
+  scores_g += (size_t)blockIdx.y * n_kv * G * seq_cap;
   if (sp * TS >= seq) return;
   for (int idx = tid; idx < G * hd; idx += 256) {
     const int g = idx / hd, i = idx - g * hd;
@@ -232,11 +236,13 @@ __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q
 
 __global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ scores_g, const int* __restrict__ pos_d,
                                                       const unsigned short* __restrict__ exp_tab,
-                                                      unsigned short* __restrict__ p16, int seq_cap) {
+                                                      unsigned short* __restrict__ p16, int seq_cap, int row0) {
   extern __shared__ float lds[];
   __shared__ float s_red[4];
   __shared__ float s_val;
-  const int head = blockIdx.x, seq = *pos_d + 1;
+  const int head = blockIdx.x, seq = *pos_d + 1 + row0 + (int)blockIdx.y;
+  scores_g += (size_t)blockIdx.y * gridDim.x * seq_cap;
+  p16 += (size_t)blockIdx.y * gridDim.x * seq_cap;
   for (int t = threadIdx.x; t < seq; t += blockDim.x) lds[t] = scores_g[(size_t)head * seq_cap + t];
   __syncthreads();
   softmax_row<true>(lds, seq, exp_tab, s_red, &s_val);
@@ -250,7 +256,7 @@ template <int G>
 __global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restrict__ p16, const unsigned short* __restrict__ vc,
                                                  const int* __restrict__ pos_d, float* __restrict__ out,
                                                  signed char* __restrict__ xq, unsigned short* __restrict__ xd,
-                                                 void* __restrict__ xisum, int hd, int seq_cap, int q81) {
+                                                 void* __restrict__ xisum, int hd, int seq_cap, int q81, int row0) {
   constexpr int T = ATTN_PV_TILE, ROW = ATTN_PV_ROW;
   // LDS, two buffers each: V tile transposed to [16 dim pairs][T] words (a chain lane reads 4 consecutive positions
   // of its dim pair with one ds_read_b128), P tile [G][T] words holding {p, p} (the packed multiplier, ready-made)
@@ -259,7 +265,12 @@ __global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restric
   const int tid = threadIdx.x;
   const int nslice = hd / 32;
   const int j = blockIdx.x / nslice, sl = blockIdx.x % nslice;
-  const int seq = *pos_d + 1;
+  const int seq = *pos_d + 1 + row0 + (int)blockIdx.y;
+  {  // blockIdx.y: row of a prefill batch (xq is null there)
+    const size_t n_heads = (size_t)(gridDim.x / nslice) * G;
+    p16 += (size_t)blockIdx.y * n_heads * seq_cap;
+    out += (size_t)(row0 + blockIdx.y) * n_heads * hd;
+  }
   const unsigned short* vbase = vc + (size_t)j * seq_cap * hd + sl * 32;
   const int ntiles = (seq + T - 1) / T;
   // loader role (all threads): V piece = 16 B (4 dim pairs) of row (tid / 4) + 64 r, piece tid % 4;

@@ -156,3 +156,29 @@ def test_row_tiled_attention_equals_the_per_row_kernel(ca, n_heads, n_kv, kv_f16
             for h in range(s.n_kv_heads):
                 lo = h * 64 * s.head_dim * es
                 assert np.array_equal(ka[lo:lo + filled], kb[lo:lo + filled]), (layer, which, h)
+
+
+@pytest.mark.parametrize("n_heads,n_kv", [(8, 2), (8, 8)])
+def test_long_prompt_attention_paths_are_bit_identical(ca, n_heads, n_kv):
+    """A 1100-token prompt in 512-row passes: rows up to position 1024 take the row-tiled kernel, rows beyond it the
+    long-context kernels with a row dimension (scores / softmax with the block-tree row sum / f16 PV chain, 64 rows per
+    launch).  Against the per-(head, row) kernel everywhere (flag 2048): the same logits and the same KV cache, bit for
+    bit; decoding continues identically."""
+    shape = synth.ModelShape("long", 512, 1024, 2, n_heads, n_kv, 1024, 1200)
+    model = synth.build_model(shape, synth.Q8_0, seed=87)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    prompt = [(7 * i + 3) % 1024 for i in range(1100)]
+    a = ca.HipLlamaRunner(conf, w, dev, 1200, True)
+    b = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=2048)
+    la, lb = a.prefill(prompt), b.prefill(prompt)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    nxt = int(np.argmax(la))
+    assert list(a.decode_greedy(nxt, 6)) == list(b.decode_greedy(nxt, 6))
+    filled = a.kv_cache_len() * shape.head_dim * 2
+    for layer in range(shape.n_layers):
+        for which in (False, True):
+            ka, kb = a.debug_kv(layer, which, True), b.debug_kv(layer, which, True)
+            for h in range(n_kv):
+                lo = h * 1200 * shape.head_dim * 2
+                assert np.array_equal(ka[lo:lo + filled], kb[lo:lo + filled]), (layer, which, h)
