@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="llama3-8b", help="shape key in crabml_amd.synth.SHAPES")
     ap.add_argument("--wtype", default="Q4_0")
+    ap.add_argument("--gguf", default=None,
+                    help="decode a llama GGUF FILE instead of synthetic weights (C++ loader, crabml_amd/csrc/host/gguf.hpp); "
+                         "the JSON line then describes that file -- not the BASELINE workload")
     ap.add_argument("--output-type", default=None,
                     help="GGML type of output.weight when it differs from --wtype (llama.cpp's Q4_0 files: Q6_K)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncate the layer count (INVALID as a result)")
@@ -266,20 +269,43 @@ def main():
         return tp_dry_run(args, ca, synth, local)
     if args.tp and world > 1:
         return tp_group_run(args, ca, synth, dist, rank, world, local)
-    shape = synth.SHAPES[args.model]
-    k_m = args.wtype.upper() == "Q4_K_M"  # llama.cpp's mix: Q4_K body, attn_v / ffn_down in Q6_K on some layers, Q6_K classifier
-    wtype = synth.Q4_K if k_m else synth.TYPE_BY_NAME[args.wtype]
     t_build = time.perf_counter()
-    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, k_m_mix=k_m,
-                              output_type=synth.TYPE_BY_NAME[args.output_type] if args.output_type else None)
     dev = ca.HipTensorDevice(device_ordinal=local)
-    t_upload = time.perf_counter()
-    conf, weights = synth.to_hip(model, dev)
+    model = None
+    if args.gguf:
+        gf = ca.GGUFFile(args.gguf)
+        conf = gf.load_config()
+        infos = gf.tensor_infos()
+        by_name = {t[0]: t for t in infos}
+        wtype = by_name["blk.0.attn_q.weight"][2]
+        args.wtype = synth.TYPE_NAMES.get(wtype, str(wtype))
+        shape = synth.ModelShape(os.path.basename(args.gguf), conf.embedding_dim, conf.hidden_dim, conf.n_layers, conf.n_heads,
+                                 conf.n_kv_heads, conf.vocab_size, conf.seq_len, conf.rms_norm_eps, conf.rope_dim)
+
+        def nbytes(t):
+            n = 1
+            for d in t[1]:
+                n *= d
+            return n // synth.BLOCK_ELEMS[t[2]] * synth.BLOCK_BYTES[t[2]]
+
+        gemv_bytes = sum(nbytes(t) for t in infos if not t[0].endswith("_norm.weight") and t[0] != "token_embd.weight")
+        if "output.weight" not in by_name:  # tied classifier
+            gemv_bytes += nbytes(by_name["token_embd.weight"])
+        t_upload = time.perf_counter()
+        weights = gf.load_weights(conf, dev)
+    else:
+        shape = synth.SHAPES[args.model]
+        k_m = args.wtype.upper() == "Q4_K_M"  # llama.cpp's mix: Q4_K body, attn_v / ffn_down in Q6_K on some layers, Q6_K classifier
+        wtype = synth.Q4_K if k_m else synth.TYPE_BY_NAME[args.wtype]
+        model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, k_m_mix=k_m,
+                                  output_type=synth.TYPE_BY_NAME[args.output_type] if args.output_type else None)
+        t_upload = time.perf_counter()
+        conf, weights = synth.to_hip(model, dev)
+        gemv_bytes = model.gemv_weight_bytes_per_token()
     dev.sync()
     t_upload = time.perf_counter() - t_upload
     t_build = time.perf_counter() - t_build
     seq_len = args.warmup + 2 * args.steps + 16
-    gemv_bytes = model.gemv_weight_bytes_per_token()
     trait = ca.Llama2Runner(conf, weights, dev, seq_len, True)  # f16 KV cache = the CLI default (main.rs:250)
     path = args.path
     fused = None
@@ -431,7 +457,10 @@ def main():
             out["roofline"] = roof
         if prefill:
             out["prefill"] = prefill
-        if not args.no_cpu_baseline and args.gpus == 1:
+        if args.gguf:
+            out["data"] = "file: " + args.gguf
+            out["config"]["workload"] = f"GGUF file {os.path.basename(args.gguf)} ({args.wtype} body), batch-1 greedy decode, f16 KV cache"
+        if not args.no_cpu_baseline and args.gpus == 1 and model is not None:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, args.cpu_seconds)
             except Exception as e:  # the baseline must never take the GPU number down with it

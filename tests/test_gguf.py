@@ -227,3 +227,21 @@ def test_generate_tool_end_to_end(tmp_path):
     lg = r.prefill([1, 2, 3, 4, 5])
     first = int(len(lg) - 1 - lg[::-1].argmax())
     assert [first] + [int(t) for t in r.decode_greedy(first, 5)] == ids
+
+
+@pytest.mark.gpu
+def test_bench_runs_from_a_gguf_file(tmp_path):
+    """bench.py --gguf FILE: the decode benchmark on a llama GGUF file (here a synthetic one) instead of in-memory weights."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=95, output_type=synth.Q6_K)
+    path = str(tmp_path / "b.gguf")
+    synth.write_gguf(model, path)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gguf", path, "--steps", "8", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-prefill"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0 and line["data"].startswith("file: ") and line["config"]["gemv_weight_bytes_per_token"] == model.gemv_weight_bytes_per_token()
