@@ -21,11 +21,15 @@ from tests.helpers import to_oracle  # noqa: E402
 
 TOKENS = [1, 365, 400, 282, 7, 9]
 CASES = [(shape, fmt, kv16) for shape in ("tiny-gqa",) for fmt in ("Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q6_K", "Q8_K", "F16", "F32")
-         for kv16 in (True, False)] + [("15m", "Q4_0", True), ("15m", "Q8_0", False)]
+         for kv16 in (True, False)] + [("15m", "Q4_0", True), ("15m", "Q8_0", False),
+                                      # llama.cpp's Q4_K_M recipe: mixed GGML types inside a layer + Q6_K classifier
+                                      ("tiny-gqa", "Q4_K_M", True), ("tiny-gqa", "Q4_K_M", False)]
 
 
 def run(shape, fmt, kv16, avx2=False):
-    model = synth.build_model(synth.SHAPES[shape], synth.TYPE_BY_NAME[fmt], seed=20250103, n_layers=2)
+    k_m = fmt == "Q4_K_M"
+    model = synth.build_model(synth.SHAPES[shape], synth.Q4_K if k_m else synth.TYPE_BY_NAME[fmt], seed=20250103,
+                              n_layers=8 if k_m else 2, k_m_mix=k_m)
     odev = o.OracleDevice(thread_num=2, use_avx2=avx2)
     conf, w = to_oracle(model, odev)
     r = o.OracleLlamaRunner(conf, w, odev, 32, kv16)
