@@ -245,3 +245,21 @@ def test_bench_runs_from_a_gguf_file(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["value"] > 0 and line["data"].startswith("file: ") and line["config"]["gemv_weight_bytes_per_token"] == model.gemv_weight_bytes_per_token()
+
+
+def test_q4_k_m_recipe_layers_and_container_types(tmp_path):
+    """CPU: the llama.cpp `use_more_bits` rule (first and last eighth of the layers, every third in between) and its
+    round trip through the GGUF writer / reader (per-tensor ggml types)."""
+    assert [i for i in range(32) if synth.use_more_bits(i, 32)] == [0, 1, 2, 3, 6, 9, 12, 15, 18, 21, 24, 27, 28, 29, 30, 31]
+    assert [i for i in range(8) if synth.use_more_bits(i, 8)] == [0, 3, 6, 7]
+    shape = synth.ModelShape("tiny-gqa-8l", 512, 1024, 8, 8, 2, 1024, 64)
+    model = synth.build_model(shape, synth.Q4_K, seed=96, k_m_mix=True)
+    path = str(tmp_path / "k.gguf")
+    synth.write_gguf(model, path)
+    types = {i[0]: i[2] for i in ca.GGUFFile(path).tensor_infos()}
+    for l in range(8):
+        wide = synth.Q6_K if synth.use_more_bits(l, 8) else synth.Q4_K
+        assert types[f"blk.{l}.attn_v.weight"] == wide and types[f"blk.{l}.ffn_down.weight"] == wide
+        assert types[f"blk.{l}.attn_q.weight"] == synth.Q4_K and types[f"blk.{l}.ffn_up.weight"] == synth.Q4_K
+        assert types[f"blk.{l}.attn_norm.weight"] == synth.F32
+    assert types["output.weight"] == synth.Q6_K and types["token_embd.weight"] == synth.Q4_K
