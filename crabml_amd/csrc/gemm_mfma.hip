@@ -33,8 +33,8 @@ template <int FMT, int NT>  // NT column tiles of 16 batch rows per workgroup (4
 struct GemmGeo {
   static constexpr int CW = 16 * NT;                               // batch rows per workgroup
   static constexpr int KC = 4;                                     // blocks per chunk (37 KB of LDS per workgroup: 4 workgroups per CU)
-  static constexpr int APC = FMT == CRABML_HIP_Q4_0 ? 1 : 2;       // 16-byte pieces per weight block
-  static constexpr int ARW = FMT == CRABML_HIP_Q4_0 ? 4 : 12;      // LDS words per weight block row
+  static constexpr int APC = (FMT == CRABML_HIP_Q4_0 || FMT == CRABML_HIP_Q4_1) ? 1 : 2;       // 16-byte pieces per weight block
+  static constexpr int ARW = (FMT == CRABML_HIP_Q4_0 || FMT == CRABML_HIP_Q4_1) ? 4 : 12;      // LDS words per weight block row
   static constexpr int BRW = 12;                                   // LDS words per activation block row
   static constexpr int A_WORDS = KC * 64 * ARW, B_WORDS = KC * CW * BRW;
   // one buffer: A quants | B quants | A scales f32 [KC][64] | B scales f32 [KC][64] (converted from f16 once, by the
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
   constexpr int PF = 2;
   struct Stage {
     i32x4 ra[G::A_LOADS], rb[G::B_LOADS];
-    unsigned short rad[G::S_LOADS], rbd[G::S_LOADS];
+    unsigned rad[G::S_LOADS], rbd[G::S_LOADS];  // f16 scale bits; Q4_1: (d | m << 16) and the Q8_1 row's (d | s << 16)
   };
   Stage stg[PF];
   auto fetch = [&](auto SET, int kb0) {
@@ -105,8 +105,13 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
       const int grow = r0 + rc < m ? r0 + rc : m - 1, gcol = c0 + rc < b ? c0 + rc : b - 1;
       const int gkb = kb0 + kb < nb ? kb0 + kb : nb - 1;
       const char* ap = act + (size_t)gcol * act_stride;
-      rad[u] = wd[(size_t)grow * nb + gkb];
-      rbd[u] = ((const unsigned short*)(ap + off_d))[gkb];
+      if constexpr (FMT == CRABML_HIP_Q4_1) {
+        rad[u] = ((const unsigned*)wd)[(size_t)grow * nb + gkb];
+        rbd[u] = (unsigned)((const unsigned short*)(ap + off_d))[gkb] | ((unsigned)((const unsigned short*)(ap + off_aux))[gkb] << 16);
+      } else {
+        rad[u] = wd[(size_t)grow * nb + gkb];
+        rbd[u] = ((const unsigned short*)(ap + off_d))[gkb];
+      }
     }
   };
   auto commit = [&](auto SET, int buf) {
@@ -131,16 +136,26 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
 #pragma unroll
     for (int u = 0; u < G::S_LOADS; u++) {
       const int t = tid + 256 * u, rc = t / KC, kb = t % KC;
-      sAd[kb * 64 + rc] = h2f(rad[u]);
-      sBd[kb * 64 + rc] = h2f(rbd[u]);
+      if constexpr (FMT == CRABML_HIP_Q4_1) {  // raw f16 pairs: the products are taken in f16 (buf_q4_1.rs:276)
+        ((unsigned*)sAd)[kb * 64 + rc] = rad[u];
+        ((unsigned*)sBd)[kb * 64 + rc] = rbd[u];
+      } else {
+        sAd[kb * 64 + rc] = h2f((unsigned short)rad[u]);
+        sBd[kb * 64 + rc] = h2f((unsigned short)rbd[u]);
+      }
     }
   };
 
   // accumulators as f32 pairs: the block scaling runs on v_pk_mul_f32 / v_pk_add_f32 (same IEEE operations, two
   // rows per instruction)
   f32x2 F[NT][2];
+  float Fq[NT][4];  // Q4_1 only: scalar accumulators (element-wise updates of the ext-vector ones were miscompiled)
 #pragma unroll
-  for (int jt = 0; jt < NT; jt++) F[jt][0] = F[jt][1] = f32x2{0.0f, 0.0f};
+  for (int jt = 0; jt < NT; jt++) {
+    F[jt][0] = F[jt][1] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 4; r++) Fq[jt][r] = 0.0f;
+  }
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
   if constexpr (PF == 3) fetch(S2{}, 2 * KC < last ? 2 * KC : last);
   __syncthreads();
   // per-lane LDS offsets (words), constant over the k loop: the block index only adds immediates
-  const int a_off = (16 * wave + i) * ARW + (FMT == CRABML_HIP_Q4_0 ? g : 2 * g);
+  const int a_off = (16 * wave + i) * ARW + ((FMT == CRABML_HIP_Q4_0 || FMT == CRABML_HIP_Q4_1) ? g : 2 * g);
   const int ad_off = 16 * wave + 4 * g;
   // iteration c: request chunk c + PF into the set chunk c used, multiply chunk c (LDS buffer c & 1), commit chunk
   // c + 1 (requested two iterations ago) to the other buffer, barrier
@@ -170,6 +185,31 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
     const float* sAd = (const float*)(sB + G::B_WORDS);
     const float* sBd = sAd + KC * 64;
     auto mul_block = [&](int kb) {
+      if constexpr (FMT == CRABML_HIP_Q4_1) {
+        // Q4_1 x Q8_1 (buf_q4_1.rs:270-280): unsigned nibbles, per block sumf += f16(d_w * d_x) * sumi + f16(m_w * s_x)
+        // with both products rounded to f16 -- in block order, i.e. the scalar reference bit for bit
+        const unsigned w = sA[kb * 64 * ARW + a_off];
+        const long A1 = (long)(((unsigned long long)((w >> 4) & 0x0F0F0F0Fu) << 32) | (unsigned long long)(w & 0x0F0F0F0Fu));
+        const i32x4 dm4 = *(const i32x4*)((const unsigned*)sAd + kb * 64 + ad_off);
+        unsigned dmr[4] = {(unsigned)dm4[0], (unsigned)dm4[1], (unsigned)dm4[2], (unsigned)dm4[3]};
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) {
+          const int col = 16 * jt + i;
+          const unsigned* brow = sB + (kb * CW + col) * BRW;
+          const long Bf1 = (long)(((unsigned long long)brow[4 + g] << 32) | (unsigned long long)brow[g]);
+          const unsigned ds = ((const unsigned*)sBd)[kb * 64 + col];
+          const i32x4 D1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A1, Bf1, i32x4{0, 0, 0, 0}, 0, 0, 0);
+          const unsigned short dxh = (unsigned short)(ds & 0xffffu), sxh = (unsigned short)(ds >> 16);
+          const int Dr[4] = {D1[0], D1[1], D1[2], D1[3]};
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float a = h2f(h_mul((unsigned short)(dmr[r] & 0xffffu), dxh));
+            const float bm = h2f(h_mul((unsigned short)(dmr[r] >> 16), sxh));
+            Fq[jt][r] += a * (float)Dr[r] + bm;
+          }
+        }
+        return;
+      }
       long A;
       if (FMT == CRABML_HIP_Q4_0) {
         // nibbles to signed bytes v - 8 without carries between bytes: ((v | 0x80) - 8) ^ 0x80 per byte, so the
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = r0 + 16 * wave + g * 4 + r;
-      if (row < m) out[(size_t)col * m + row] = F[jt][r >> 1][r & 1];
+      if (row < m) out[(size_t)col * m + row] = FMT == CRABML_HIP_Q4_1 ? Fq[jt][r] : F[jt][r >> 1][r & 1];
     }
   }
 }
@@ -635,7 +675,9 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q6k(const char* __restrict__ 
 // returns false when the shape / format is not covered (the caller falls back to one GEMV per batch row)
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
                       crabml_hip_device::ProfRec* rec) {
-  if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K) return false;
+  if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K &&
+      w->dtype != CRABML_HIP_Q4_1)
+    return false;
   if (b < 16 || m == 0 || k % 32 != 0) return false;
   hipStream_t st = dev->stream;
   const char* wp = (const char*)w->ptr;
@@ -663,7 +705,7 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
                alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl);
     return true;
   }
-  const ActLayout al = act_layout(CRABML_HIP_Q8_0, k);
+  const ActLayout al = act_layout(w->dtype == CRABML_HIP_Q4_1 ? CRABML_HIP_Q8_1 : CRABML_HIP_Q8_0, k);
   const int nb = (int)(k / 32);
   const int row_tiles = (int)((m + 63) / 64);
   // 64-column tiles amortize a weight tile over more batch rows; when that grid leaves the chip under-occupied
@@ -680,6 +722,11 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
       CRABML_GEMM_LAUNCH(CRABML_HIP_Q4_0, 2);
     else
       CRABML_GEMM_LAUNCH(CRABML_HIP_Q4_0, 4);
+  } else if (w->dtype == CRABML_HIP_Q4_1) {
+    if (narrow)
+      CRABML_GEMM_LAUNCH(CRABML_HIP_Q4_1, 2);
+    else
+      CRABML_GEMM_LAUNCH(CRABML_HIP_Q4_1, 4);
   } else {
     if (narrow)
       CRABML_GEMM_LAUNCH(CRABML_HIP_Q8_0, 2);

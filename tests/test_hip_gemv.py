@@ -132,7 +132,7 @@ def test_gemv_batched_rhs_and_quant_cache(ca, hdev, odev):
     assert not np.array_equal(got3, got2)
 
 
-@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0"])
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1"])
 def test_batched_rhs_on_the_matrix_cores_is_bit_exact(ca, hdev, odev, fmt):
     """b >= 16 activation rows take the MFMA skinny-GEMM path (gemm_mfma.hip): exact integer tiles from
     v_mfma_i32_16x16x32_i8, scaled block by block like the reference's scalar loop -- every output equals the
