@@ -804,7 +804,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     if (!strict) return launch_gemv(dev, w, m, k, act, B, out, nullptr);
     // strict order: the Q4_0 / Q8_0 / Q4_1 MFMA GEMM scales its exact integer tiles block by block in the reference's scalar
     // order, i.e. it IS the strict result (bit for bit) -- the other formats take the scalar-order GEMV row by row
-    if ((w->dtype == CRABML_HIP_Q4_0 || w->dtype == CRABML_HIP_Q8_0 || w->dtype == CRABML_HIP_Q4_1) && B >= 16 &&
+    if ((w->dtype == CRABML_HIP_Q4_0 || w->dtype == CRABML_HIP_Q8_0 || w->dtype == CRABML_HIP_Q4_1 || w->dtype == CRABML_HIP_Q8_K) && B >= 16 &&
         launch_gemm_mfma(dev, w, m, k, act, B, out, nullptr))
       return 0;
     return launch_gemv_strict(dev, w, m, k, act, B, out);

@@ -672,15 +672,140 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q6k(const char* __restrict__ 
   }
 }
 
+// ---- Q8_K weights x Q8_K activation rows (buf_q8_k.rs:205-222) -----------------------------------------------------------
+// The cheapest member of the family: one f32 scale per 256-element super-block on either side, so the eight MFMAs of a
+// super-block chain into ONE integer accumulator (|sum| <= 256 * 127^2 < 2^23) and the scaling -- sumf += (sumi as f32 *
+// d_w) * d_x, in super-block order: the scalar reference bit for bit -- happens once per 256 elements.
+struct GemmGeo8K {
+  static constexpr int NT = 2, CW = 32, STR = 68;  // 256 B + 16 B pad per row / column
+  static constexpr int O_B = 64 * STR, O_AD = O_B + CW * STR, O_BD = O_AD + 64, BUF_WORDS = O_BD + CW;
+  static constexpr int LDS_BYTES = 2 * BUF_WORDS * 4;
+};
+__global__ __launch_bounds__(256) void k_gemm_mfma_q8k(const i32x4* __restrict__ wq, const float* __restrict__ wd,
+                                                       const char* __restrict__ act, size_t act_stride, size_t off_d,
+                                                       float* __restrict__ out, int m, int nsb, int b, int row_tiles) {
+  using G = GemmGeo8K;
+  constexpr int NT = G::NT, CW = G::CW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  int rt, ct;
+  {
+    const int col_tiles = (int)gridDim.x / row_tiles;
+    if ((row_tiles & 7) == 0) {
+      const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+      ct = j % col_tiles;
+      rt = (j / col_tiles) * 8 + x;
+    } else {
+      rt = (int)blockIdx.x % row_tiles;
+      ct = (int)blockIdx.x / row_tiles;
+    }
+  }
+  const int r0 = rt * 64, c0 = ct * CW;
+  i32x4 ra[4], rb[2];
+  float rdw = 0.f, rd8 = 0.f;
+  auto fetch = [&](int sb) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = tid + 256 * u, row = t >> 4, pc = t & 15;
+      const int grow = r0 + row < m ? r0 + row : m - 1;
+      ra[u] = __builtin_nontemporal_load(wq + ((size_t)grow * nsb + sb) * 16 + pc);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int t = tid + 256 * u, col = t >> 4, pc = t & 15;
+      const int gcol = c0 + col < b ? c0 + col : b - 1;
+      rb[u] = *((const i32x4*)(act + (size_t)gcol * act_stride) + (size_t)sb * 16 + pc);
+    }
+    if (tid < 64) {
+      const int grow = r0 + tid < m ? r0 + tid : m - 1;
+      rdw = wd[(size_t)grow * nsb + sb];
+    }
+    if (tid < CW) {
+      const int gcol = c0 + tid < b ? c0 + tid : b - 1;
+      rd8 = ((const float*)(act + (size_t)gcol * act_stride + off_d))[sb];
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned* S = (unsigned*)lds_raw + (size_t)buf * G::BUF_WORDS;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = tid + 256 * u;
+      *(i32x4*)(S + (t >> 4) * G::STR + (t & 15) * 4) = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int t = tid + 256 * u;
+      *(i32x4*)(S + G::O_B + (t >> 4) * G::STR + (t & 15) * 4) = rb[u];
+    }
+    if (tid < 64) ((float*)S)[G::O_AD + tid] = rdw;
+    if (tid < CW) ((float*)S)[G::O_BD + tid] = rd8;
+  };
+  f32x2 F[NT][2];
+#pragma unroll
+  for (int jt = 0; jt < NT; jt++) F[jt][0] = F[jt][1] = f32x2{0.0f, 0.0f};
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int sb = 0; sb < nsb; sb++) {
+    const int buf = sb & 1;
+    fetch(sb + 1 < nsb ? sb + 1 : sb);
+    const unsigned* S = (const unsigned*)lds_raw + (size_t)buf * G::BUF_WORDS;
+    const unsigned* arow = S + (16 * wave + i) * G::STR + 2 * g;
+    i32x4 D[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; jt++) D[jt] = i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const long A = *(const long*)(arow + 8 * j);
+#pragma unroll
+      for (int jt = 0; jt < NT; jt++) {
+        const long Bf = *(const long*)(S + G::O_B + (16 * jt + i) * G::STR + 8 * j + 2 * g);
+        D[jt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bf, D[jt], 0, 0, 0);
+      }
+    }
+    const f32x4 dw4 = *(const f32x4*)((const float*)S + G::O_AD + 16 * wave + 4 * g);
+    const f32x2 dw01 = {dw4[0], dw4[1]}, dw23 = {dw4[2], dw4[3]};
+#pragma unroll
+    for (int jt = 0; jt < NT; jt++) {
+      const float d8 = ((const float*)S)[G::O_BD + 16 * jt + i];
+      const f32x2 d88 = {d8, d8};
+      const f32x2 c01 = {(float)D[jt][0], (float)D[jt][1]}, c23 = {(float)D[jt][2], (float)D[jt][3]};
+      F[jt][0] += (c01 * dw01) * d88;
+      F[jt][1] += (c23 * dw23) * d88;
+    }
+    commit(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int jt = 0; jt < NT; jt++) {
+    const int col = c0 + 16 * jt + i;
+    if (col >= b) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 16 * wave + g * 4 + r;
+      if (row < m) out[(size_t)col * m + row] = F[jt][r >> 1][r & 1];
+    }
+  }
+}
+
 // returns false when the shape / format is not covered (the caller falls back to one GEMV per batch row)
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
                       crabml_hip_device::ProfRec* rec) {
   if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K &&
-      w->dtype != CRABML_HIP_Q4_1)
+      w->dtype != CRABML_HIP_Q4_1 && w->dtype != CRABML_HIP_Q8_K)
     return false;
   if (b < 16 || m == 0 || k % 32 != 0) return false;
   hipStream_t st = dev->stream;
   const char* wp = (const char*)w->ptr;
+  if (w->dtype == CRABML_HIP_Q8_K) {
+    if (k % 256 != 0) return false;
+    const ActLayout alk = act_layout(CRABML_HIP_Q8_K, k);
+    const int nsb = (int)(k / 256), rtl = (int)((m + 63) / 64), ctl = (int)((b + GemmGeo8K::CW - 1) / GemmGeo8K::CW);
+    launch_k(st, rec, k_gemm_mfma_q8k, dim3(rtl * ctl), dim3(256), GemmGeo8K::LDS_BYTES, (const i32x4*)wp,
+             (const float*)(wp + w->wl.off_scale), (const char*)act, alk.total, alk.off_d, out, (int)m, nsb, (int)b, rtl);
+    return true;
+  }
   if (w->dtype == CRABML_HIP_Q6_K) {
     if (k % 256 != 0) return false;
     const ActLayout alk = act_layout(CRABML_HIP_Q8_K, k);

@@ -132,13 +132,15 @@ def test_gemv_batched_rhs_and_quant_cache(ca, hdev, odev):
     assert not np.array_equal(got3, got2)
 
 
-@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1"])
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q8_K"])
 def test_batched_rhs_on_the_matrix_cores_is_bit_exact(ca, hdev, odev, fmt):
     """b >= 16 activation rows take the MFMA skinny-GEMM path (gemm_mfma.hip): exact integer tiles from
     v_mfma_i32_16x16x32_i8, scaled block by block like the reference's scalar loop -- every output equals the
     scalar-order oracle BIT FOR BIT (stronger than the single-row fast GEMV, which re-associates).  Ragged shapes:
     m not a multiple of 16, b not a multiple of 16 / 64, k with 1 and 9 blocks."""
     for (m, k, b) in [(16, 32, 16), (37, 288, 17), (100, 1024, 40), (288, 288, 64), (64, 2048, 100), (1000, 4096, 33)]:
+        if fmt == "Q8_K":
+            k = max(256, k // 256 * 256)  # super-blocks of 256
         typ, raw, _ = make(fmt, m, k, m + k + b)
         rng = np.random.default_rng(b)
         x = rng.standard_normal(b * k).astype(np.float32)

@@ -39,7 +39,7 @@ def kv_equal(runner, orr, model, n_pos, kv_f16, seq_len=64):
     return True
 
 
-@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "F32"])
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q8_K", "F32"])
 @pytest.mark.parametrize("kv_f16", [False, True])
 @pytest.mark.parametrize("chunk", [0, 5])
 def test_prefill_strict_equals_the_oracle_token_loop(ca, fmt, kv_f16, chunk):
@@ -88,7 +88,7 @@ def test_prefill_in_two_calls_and_after_decode_steps(ca):
     assert kv_equal(r, orr, model, len(toks), True)
 
 
-@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q6_K", "Q8_K"])
 def test_prefill_fast_on_the_matrix_cores(ca, fmt):
     """23 rows >= 16: q/k/v, wo, gate/up, down run as MFMA GEMMs.  Logits within the fast-mode tolerance of the oracle;
     the greedy continuation equals the one after a fast token loop over the same prompt."""
