@@ -139,6 +139,7 @@ struct crabml_hip_buf {
     uint32_t qtype = 0xffffffffu;
     uint64_t version = 0;
     size_t n = 0;
+    size_t k = 0;  // row length the planes were laid out for (act_layout depends on k, not only on b * k)
     void* ptr = nullptr;
     size_t cap = 0;
   } qc;
@@ -153,6 +154,15 @@ int hip_fail(crabml_hip_device* dev, hipError_t e, const char* what, const char*
   do {                                                                                           \
     hipError_t e__ = (expr);                                                                     \
     if (e__ != hipSuccess) return ::crabml_hip::hip_fail((dev), e__, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+// Every entry point that allocates or launches selects its device first: hipMalloc / kernel launches / hipGraphLaunch go
+// to the CALLING THREAD's current device, which is device 0 on a fresh thread and whatever torch (or a second
+// HipTensorDevice) left behind otherwise.  hipSetDevice on the already-current device is a thread-local compare.
+#define CH_USE(dev)                                                                                        \
+  do {                                                                                                     \
+    hipError_t e__ = hipSetDevice((dev)->ordinal);                                                         \
+    if (e__ != hipSuccess) return ::crabml_hip::hip_fail((dev), e__, "hipSetDevice", __FILE__, __LINE__); \
   } while (0)
 
 #define CH_BAIL(dev, status, ...) return ::crabml_hip::set_error((dev), (status), __VA_ARGS__)

@@ -282,4 +282,27 @@ void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t
   k_q4k_pack_scales<<<(unsigned)((n_blocks + 255) / 256), 256, 0, st>>>((unsigned char*)hdr_plane, blk0, n_blocks);
 }
 
+// ---- read ceiling: what a plain streaming kernel reads per second on this box (the practical HBM ceiling) ----------
+// 16-byte non-temporal loads, 8 in flight per lane, grid-stride; the xor keeps the loads alive.
+__global__ __launch_bounds__(256) void k_stream_read(const i32x4* __restrict__ p, size_t n16, int* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int acc = 0;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    i32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+  }
+  for (; i < n16; i += stride) {
+    const i32x4 v = __builtin_nontemporal_load(p + i);
+    acc ^= v[0] ^ v[3];
+  }
+  if (acc == 0x7eadbeef) *sink = acc;
+}
+void launch_stream_read(hipStream_t st, const void* buf, size_t bytes, int* sink, hipEvent_t e0, hipEvent_t e1) {
+  hipExtLaunchKernelGGL(k_stream_read, dim3(8192), dim3(256), 0, st, e0, e1, 0, (const i32x4*)buf, bytes / 16, sink);
+}
+
 }  // namespace crabml_hip

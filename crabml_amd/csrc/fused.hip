@@ -137,6 +137,11 @@ struct crabml_hip_llama {
   float* pf_scores = nullptr;          // long prompts: [PF_LONG_ROWS][n_heads][seq_len] f32 scores
   unsigned short* pf_p16 = nullptr;    //               and f16 probabilities, allocated on first use
   std::vector<std::pair<void*, size_t>> allocs;
+  // token / pos / step of the next step are staged in pinned host memory owned by the context (a ring, one slot per
+  // set_state): the async copy reads it when the stream gets there, long after the caller's stack frame is gone
+  int* h_state = nullptr;
+  unsigned h_state_next = 0;
+  static constexpr unsigned H_STATE_SLOTS = 256;
 };
 
 namespace {
@@ -871,8 +876,15 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
 }
 
 int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step) {
-  int st[3] = {(int)token, (int)pos, step};
-  CH_HIP(c->dev, hipMemcpyAsync(c->state, st, sizeof st, hipMemcpyHostToDevice, c->dev->stream));
+  if (c->h_state_next == crabml_hip_llama::H_STATE_SLOTS) {  // every slot may still be waiting for its copy: drain, start over
+    CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
+    c->h_state_next = 0;
+  }
+  int* st = c->h_state + 4 * c->h_state_next++;
+  st[0] = (int)token;
+  st[1] = (int)pos;
+  st[2] = step;
+  CH_HIP(c->dev, hipMemcpyAsync(c->state, st, 3 * sizeof(int), hipMemcpyHostToDevice, c->dev->stream));
   return 0;
 }
 
@@ -892,7 +904,7 @@ int crabml_hip_tp_comm_create(crabml_hip_device_t* dev, const void* id128, int n
   *out = nullptr;
   Rccl* r = rccl();
   if (!r) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "librccl.so could not be loaded");
-  (void)hipSetDevice(dev->ordinal);
+  CH_USE(dev);
   Rccl::IdT id;
   memcpy(&id, id128, sizeof id);
   void* comm = nullptr;
@@ -920,6 +932,7 @@ int crabml_hip_tp_comm_destroy(crabml_hip_tp_comm_t* comm) {
 int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, size_t n) {
   if (!comm || !buf) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = comm->dev;
+  CH_USE(dev);
   if (buf->dtype != CRABML_HIP_F32 || n > buf->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: needs an f32 buffer of >= n elements");
   Rccl* r = rccl();
   if (!r) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "librccl.so could not be loaded");
@@ -1003,9 +1016,13 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       w->token_embed->n_elems != g.vocab_size * g.embedding_dim)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: classifier / final norm / embedding dtype or shape");
 
-  (void)hipSetDevice(dev->ordinal);
+  CH_USE(dev);
   crabml_hip_llama* c = new crabml_hip_llama();
   c->dev = dev;
+  if (hipHostMalloc((void**)&c->h_state, crabml_hip_llama::H_STATE_SLOTS * 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    delete c;
+    CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: hipHostMalloc of the state staging ring failed");
+  }
   c->cfg = g;
   c->wtype = wt;
   // the Q4_K fused kernels take a Q6_K attn_v / ffn_down beside the Q4_K planes, but only in the norm-epilogue form
@@ -1179,6 +1196,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
 
 int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
   if (!c) return 0;
+  (void)hipSetDevice(c->dev->ordinal);
   (void)hipStreamSynchronize(c->dev->stream);
   for (int v = 0; v < 2; v++) {
     if (c->exec[v]) (void)hipGraphExecDestroy(c->exec[v]);
@@ -1186,6 +1204,7 @@ int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
   }
   for (auto& a : c->allocs) pool_free(c->dev, a.first, a.second);
   for (auto* b : c->held) crabml_hip_buf_release(b);
+  if (c->h_state) (void)hipHostFree(c->h_state);
   delete c;
   return 0;
 }
@@ -1201,6 +1220,7 @@ static int check_step(crabml_hip_llama* c, size_t token, size_t pos) {
 int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, float* logits) {
   if (!c) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
+  CH_USE(dev);
   if (c->tp > 1 && !c->comm && !c->tp_dry)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   CH_TRY(check_step(c, token, pos));
@@ -1220,6 +1240,7 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, fl
 int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n_steps, uint32_t* out_tokens) {
   if (!c || (!out_tokens && n_steps)) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
+  CH_USE(dev);
   if (c->tp > 1 && !c->comm && !c->tp_dry)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
@@ -1241,6 +1262,7 @@ int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n
 int crabml_hip_llama_prefill(crabml_hip_llama_t* c, const uint32_t* tokens, size_t n, float* logits) {
   if (!c || (!tokens && n)) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
+  CH_USE(dev);
   if (n == 0) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama prefill: expected at least 1 prompt token");  // llama2.rs:117-122
   for (size_t i = 0; i < n; i++)
     if (tokens[i] >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %u out of range", tokens[i]);
@@ -1270,6 +1292,7 @@ int crabml_hip_llama_prefill(crabml_hip_llama_t* c, const uint32_t* tokens, size
 int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, size_t token, size_t pos, float* logits) {
   if (!ranks || n < 1 || n > 8 || !ranks[0]) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = ranks[0]->dev;
+  CH_USE(dev);
   for (int r = 0; r < n; r++) {
     if (!ranks[r] || ranks[r]->dev != dev || ranks[r]->tp != n || ranks[r]->tp_rank != r || ranks[r]->comm)
       CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_sim: rank %d is not a communicator-less rank %d of %d on this device", r, r, n);
@@ -1303,6 +1326,7 @@ int crabml_hip_llama_reset(crabml_hip_llama_t* c) {
 
 int crabml_hip_llama_debug_kv(crabml_hip_llama_t* c, size_t layer, int32_t which_v, void* dst, size_t nbytes) {
   if (!c || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_USE(c->dev);
   if (layer >= c->cfg.n_layers || nbytes > c->kv_bytes) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: bad layer/size");
   CH_HIP(c->dev, hipMemcpyAsync(dst, which_v ? c->vc[layer] : c->kc[layer], nbytes, hipMemcpyDeviceToHost, c->dev->stream));
   CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));

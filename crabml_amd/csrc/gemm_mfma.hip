@@ -305,7 +305,7 @@ struct GemmGeoK {
 template <int NT>
 __global__ __launch_bounds__(256) void k_gemm_mfma_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh,
                                                        const char* __restrict__ act, size_t act_stride, size_t off_d, size_t off_aux,
-                                                       float* __restrict__ out, int m, int nsb, int b, int row_tiles) {
+                                                       float* __restrict__ out, int m, int nsb, int b, int row_tiles, int* __restrict__ dbg) {
   using G = GemmGeoK<NT>;
   constexpr int CW = G::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -452,6 +452,18 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q4k(const i32x4* __restrict__
       const f32x2 i01 = {(float)iacc[jt][0], (float)iacc[jt][1]}, i23 = {(float)iacc[jt][2], (float)iacc[jt][3]};
       const f32x2 m01 = {(float)(Dl[0] + 64 * Dh[0]), (float)(Dl[1] + 64 * Dh[1])};
       const f32x2 m23 = {(float)(Dl[2] + 64 * Dh[2]), (float)(Dl[3] + 64 * Dh[3])};
+      if (dbg != nullptr) {  // parity hook (crabml_hip_debug_gemm_ints; NULL in every product launch): this super-block's
+        const int col = c0 + 16 * jt + i;  // (isum, msum) per output, exactly as the float part below consumes them
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = r0 + 16 * wave + g * 4 + r;
+          if (col < b && row < m) {
+            int* o = dbg + (((size_t)col * m + row) * nsb + sb) * 2;
+            o[0] = iacc[jt][r];
+            o[1] = Dl[r] + 64 * Dh[r];
+          }
+        }
+      }
       F[jt][0] += (dw01 * d88) * i01 - (dm01 * d88) * m01;
       F[jt][1] += (dw23 * d88) * i23 - (dm23 * d88) * m23;
     }
@@ -489,7 +501,7 @@ struct GemmGeo6 {
 
 __global__ __launch_bounds__(256) void k_gemm_mfma_q6k(const char* __restrict__ w, size_t off_qh, const char* __restrict__ act,
                                                        size_t act_stride, size_t off_d, size_t off_aux, float* __restrict__ out,
-                                                       int m, int nsb, int b, int row_tiles) {
+                                                       int m, int nsb, int b, int row_tiles, int* __restrict__ dbg) {
   using G = GemmGeo6;
   constexpr int NT = G::NT, CW = G::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -654,6 +666,18 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q6k(const char* __restrict__ 
       const f32x2 d88 = {d8, d8};
       const f32x2 v01 = {(float)(iacc[jt][0] - 32 * (Dl[0] + 64 * Dh[0])), (float)(iacc[jt][1] - 32 * (Dl[1] + 64 * Dh[1]))};
       const f32x2 v23 = {(float)(iacc[jt][2] - 32 * (Dl[2] + 64 * Dh[2])), (float)(iacc[jt][3] - 32 * (Dl[3] + 64 * Dh[3]))};
+      if (dbg != nullptr) {  // parity hook (NULL in every product launch): sum_g scale_g * dot_g and sum_g scale_g * bsum_g
+        const int col = c0 + 16 * jt + i;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = r0 + 16 * wave + g * 4 + r;
+          if (col < b && row < m) {
+            int* o = dbg + (((size_t)col * m + row) * nsb + sb) * 2;
+            o[0] = iacc[jt][r];
+            o[1] = Dl[r] + 64 * Dh[r];
+          }
+        }
+      }
       F[jt][0] += (dw01 * d88) * v01;
       F[jt][1] += (dw23 * d88) * v23;
     }
@@ -791,7 +815,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q8k(const i32x4* __restrict__
 
 // returns false when the shape / format is not covered (the caller falls back to one GEMV per batch row)
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
-                      crabml_hip_device::ProfRec* rec) {
+                      crabml_hip_device::ProfRec* rec, int* dbg) {
   if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K &&
       w->dtype != CRABML_HIP_Q4_1 && w->dtype != CRABML_HIP_Q8_K)
     return false;
@@ -811,7 +835,7 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
     const ActLayout alk = act_layout(CRABML_HIP_Q8_K, k);
     const int nsb = (int)(k / 256), rtl = (int)((m + 63) / 64), ctl = (int)((b + GemmGeo6::CW - 1) / GemmGeo6::CW);
     launch_k(st, rec, k_gemm_mfma_q6k, dim3(rtl * ctl), dim3(256), GemmGeo6::LDS_BYTES, wp, (size_t)w->wl.off_scale, (const char*)act,
-             alk.total, alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl);
+             alk.total, alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl, dbg);
     return true;
   }
   if (w->dtype == CRABML_HIP_Q4_K) {
@@ -824,10 +848,10 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
     const i32x4* whk = (const i32x4*)(wp + w->wl.off_scale);
     if (narrow_k)
       launch_k(st, rec, k_gemm_mfma_q4k<2>, dim3(rtl * ctl), dim3(256), GemmGeoK<2>::LDS_BYTES, wqk, whk, (const char*)act, alk.total,
-               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl);
+               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl, dbg);
     else
       launch_k(st, rec, k_gemm_mfma_q4k<4>, dim3(rtl * ctl), dim3(256), GemmGeoK<4>::LDS_BYTES, wqk, whk, (const char*)act, alk.total,
-               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl);
+               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl, dbg);
     return true;
   }
   const ActLayout al = act_layout(w->dtype == CRABML_HIP_Q4_1 ? CRABML_HIP_Q8_1 : CRABML_HIP_Q8_0, k);

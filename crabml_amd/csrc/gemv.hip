@@ -377,6 +377,50 @@ __global__ void k_block_dots_q6k(const char* __restrict__ w, size_t off_qh, ActQ
   out[sb * 16 + gi + 4] = hi - 32 * (int)act.bsums[sb * 16 + gi + 4];
 }
 
+// ---- parity hook: the integers of the PRODUCTION K-quant loops (rows_partial_q4k / rows_partial_q6k, DBG instantiation) --
+// One wave walks row `row` exactly as k_gemv_q4_k<1> / k_gemv_q6_k<1> do; out[2 c], out[2 c + 1] = the two integers piece c
+// hands to its float part (Q4_K: isum, msum; Q6_K: scale_lo * dot_lo, scale_hi * dot_hi, the -32 offset included).
+__global__ __launch_bounds__(64) void k_piece_ints_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, ActQ8_K act, int row,
+                                                       int m, int nsb, int* __restrict__ out, float* __restrict__ fout) {
+  float acc[1];
+  rows_partial_q4k<1, true, true>(wq, wh, act, row, m, nsb, (int)threadIdx.x, acc, 0, out);
+  const float s = wave_sum_f32(acc[0]);
+  if (threadIdx.x == 0) *fout = s;
+}
+__global__ __launch_bounds__(64) void k_piece_ints_q4k_lds(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, ActQ8_K act, int row,
+                                                           int m, int nsb, int* __restrict__ out, float* __restrict__ fout) {
+  float acc[1];  // the whole-header form the LDS-staged kernels use (HDR_DPP = false)
+  rows_partial_q4k<1, false, true>(wq, wh, act, row, m, nsb, (int)threadIdx.x, acc, 0, out);
+  const float s = wave_sum_f32(acc[0]);
+  if (threadIdx.x == 0) *fout = s;
+}
+__global__ __launch_bounds__(64) void k_piece_ints_q6k(const char* __restrict__ w, size_t off_qh, ActQ8_K act, int row, int m, int nsb,
+                                                       int* __restrict__ out, float* __restrict__ fout) {
+  float acc[1];
+  rows_partial_q6k<1, true>(w, off_qh, act, row, m, nsb, (int)threadIdx.x, acc, out);
+  const float s = wave_sum_f32(acc[0]);
+  if (threadIdx.x == 0) *fout = s;
+}
+int launch_piece_ints(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, size_t row, const void* act, int variant,
+                      int32_t* out, float* fout) {
+  const char* wp = (const char*)w->ptr;
+  const char* ap = (const char*)act;
+  const ActLayout al = act_layout(CRABML_HIP_Q8_K, k);
+  ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+  const int nsb = (int)(k / 256);
+  if (w->dtype == CRABML_HIP_Q4_K) {
+    if (variant == 0)
+      k_piece_ints_q4k<<<1, 64, 0, dev->stream>>>((const i32x4*)wp, (const i32x4*)(wp + w->wl.off_scale), a, (int)row, (int)m, nsb, out, fout);
+    else
+      k_piece_ints_q4k_lds<<<1, 64, 0, dev->stream>>>((const i32x4*)wp, (const i32x4*)(wp + w->wl.off_scale), a, (int)row, (int)m, nsb, out, fout);
+  } else if (w->dtype == CRABML_HIP_Q6_K) {
+    k_piece_ints_q6k<<<1, 64, 0, dev->stream>>>(wp, w->wl.off_scale, a, (int)row, (int)m, nsb, out, fout);
+  } else {
+    return set_error(dev, CRABML_HIP_TENSOR_ERROR, "debug_superblock_ints: Q4_K / Q6_K weights only");
+  }
+  return 0;
+}
+
 void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out) {
   const char* wp = (const char*)w->ptr;
   const char* ap = (const char*)act;

@@ -209,10 +209,13 @@ __device__ __forceinline__ Q4KX q4k_loadx(const ActQ8_K& act, int c) {
   x.bs_hi = (int)bs[2];
   return x;
 }
+// The exact integer part of piece c (buf_q4_k.rs:212-263): isum = sc_lo * sum(q4 q8 | low nibbles) + sc_hi * sum(q4 q8 | high
+// nibbles), msum = m_lo * bsum_lo + m_hi * bsum_hi; h0 = the header's first dword (d | dmin << 16).  Every Q4_K GEMV kernel
+// (k_gemv_q4_k, k_qkv, k_gemv_res_nq, k_gateup_k_lds) gets its integers from here; crabml_hip_debug_superblock_ints dumps them.
 template <bool HDR_DPP>
-__device__ __forceinline__ float q4k_term(const Q4KPiece<HDR_DPP>& w, const Q4KX& x, int c) {
+__device__ __forceinline__ void q4k_ints(const Q4KPiece<HDR_DPP>& w, const Q4KX& x, int c, int& isum, int& msum, unsigned& h0) {
   const int p = (c & 7) >> 1;
-  unsigned h0, h1, h2, h3;
+  unsigned h1, h2, h3;
   if constexpr (HDR_DPP) {  // quad_perm broadcasts of dword 0..3
     h0 = (unsigned)dpp_i<0x00>((int)w.hw);
     h1 = (unsigned)dpp_i<0x55>((int)w.hw);
@@ -233,15 +236,25 @@ __device__ __forceinline__ float q4k_term(const Q4KPiece<HDR_DPP>& w, const Q4KX
     lo = __builtin_amdgcn_sdot4(w.qv[i] & 0x0F0F0F0F, x.xl[i], lo, false);
     hi = __builtin_amdgcn_sdot4((w.qv[i] >> 4) & 0x0F0F0F0F, x.xh[i], hi, false);
   }
-  const int isum = sc_lo * lo + sc_hi * hi;          // exact (the reference's aux32 lanes hold integers < 2^24)
-  const int msum = m_lo * x.bs_lo + m_hi * x.bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
+  isum = sc_lo * lo + sc_hi * hi;          // exact (the reference's aux32 lanes hold integers < 2^24)
+  msum = m_lo * x.bs_lo + m_hi * x.bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
+}
+template <bool HDR_DPP>
+__device__ __forceinline__ float q4k_term(const Q4KPiece<HDR_DPP>& w, const Q4KX& x, int c, int* dbg = nullptr) {
+  int isum, msum;
+  unsigned h0;
+  q4k_ints<HDR_DPP>(w, x, c, isum, msum, h0);
+  if (dbg != nullptr) {  // parity hook (DBG instantiations only): this piece's integers, as the float part consumes them
+    dbg[0] = isum;
+    dbg[1] = msum;
+  }
   const float dd = h2f((unsigned short)(h0 & 0xffff)) * x.d8;
   const float dmin = h2f((unsigned short)(h0 >> 16)) * x.d8;
   return dd * (float)isum - dmin * (float)msum;
 }
-template <int R, bool HDR_DPP = true>
+template <int R, bool HDR_DPP = true, bool DBG = false>
 __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act,
-                                                 int row0, int m, int nsb, int lane, float acc[R], int c0 = 0) {
+                                                 int row0, int m, int nsb, int lane, float acc[R], int c0 = 0, int* dbg = nullptr) {
   if (c0 == 0) {
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.f;
@@ -256,7 +269,12 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
     }
     const Q4KX x = q4k_loadx(act, c);
 #pragma unroll
-    for (int r = 0; r < R; r++) acc[r] += q4k_term<HDR_DPP>(w[r], x, c);
+    for (int r = 0; r < R; r++) {
+      if constexpr (DBG)
+        acc[r] += q4k_term<HDR_DPP>(w[r], x, c, dbg + ((size_t)r * nchunks + c) * 2);
+      else
+        acc[r] += q4k_term<HDR_DPP>(w[r], x, c);
+    }
   }
 }
 
@@ -264,9 +282,9 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
 // lane = one 16-byte ql piece of a super-block (8 lanes per super-block), which carries the low nibbles of scale group
 // gi and the high nibbles of group gi + 4 (buf_q6_k.rs:21-48).  6-bit values are rebuilt as bytes for v_dot4; the -32
 // offset is applied as -32 * bsum (exact).  off_qh = byte offset of the qh plane = 128 * blocks in the tensor.
-template <int R>
+template <int R, bool DBG = false>
 __device__ __forceinline__ void rows_partial_q6k(const char* __restrict__ w, size_t off_qh, const ActQ8_K& act, int row0, int m,
-                                                 int nsb, int lane, float acc[R]) {
+                                                 int nsb, int lane, float acc[R], int* dbg = nullptr) {
   const size_t n = off_qh / 128;  // blocks in the tensor
   const i32x4* wql = (const i32x4*)w;
   const i32x4* wqh = (const i32x4*)(w + off_qh);
@@ -310,6 +328,10 @@ __device__ __forceinline__ void rows_partial_q6k(const char* __restrict__ w, siz
       lo -= 32 * bs_lo;  // sum (q6 - 32) * q8, exact
       hi -= 32 * bs_hi;
       const int sc_lo = (int)(signed char)(scw[r] & 0xffu), sc_hi = (int)(signed char)(scw[r] >> 8);
+      if constexpr (DBG) {  // parity hook: the two scaled group sums of this piece, as the float part consumes them
+        dbg[((size_t)r * npieces + c) * 2] = sc_lo * lo;
+        dbg[((size_t)r * npieces + c) * 2 + 1] = sc_hi * hi;
+      }
       const float dd = h2f(dw[r]) * d8;
       acc[r] += dd * ((float)(sc_lo * lo) + (float)(sc_hi * hi));
     }

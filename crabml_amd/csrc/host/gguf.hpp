@@ -6,7 +6,9 @@
 //   * the data of tensor i runs from its offset to the NEXT tensor's offset (the last one to the end of the file), so it
 //     includes the alignment padding (gguf.rs:737-759);
 //   * `general.alignment` may be any integer type, default 32 (gguf.rs:575-587); the data section starts at
-//     position - position % alignment + alignment (gguf.rs:722-724: a full extra block when already aligned);
+//     position - position % alignment + alignment in the reference (gguf.rs:722-724: a full extra block when the infos
+//     already end aligned -- which disagrees with the GGUF spec for 1 file in `alignment`; decode() resolves that case
+//     from the file itself and falls back to the spec, see there);
 //   * load_config reads `<arch>.*` keys and takes vocab_size from tokenizer.ggml.tokens (model.rs:565-625);
 //   * load_weights reverses the on-disk dimensions (model.rs:473-475) and uploads every tensor in its stored type
 //     (the CPU-side F32-only gate of GpuLlamaModel::from_cpu is what the hip backend lifts).
@@ -55,7 +57,8 @@ struct GGUFTensorInfo {  // gguf.rs:648-689
 
 class GGUFFile {
  public:
-  explicit GGUFFile(const std::string& path) {
+  // GGUFFileLoader::new(path, mlock) (gguf.rs:793-826): mmap + madvise(WILLNEED) + optional mlock
+  explicit GGUFFile(const std::string& path, bool mlock = false) {
     fd_ = ::open(path.c_str(), O_RDONLY);
     if (fd_ < 0) throw Error(ErrorKind::IOError, "failed to open the file: " + path);
     struct stat st {};
@@ -70,6 +73,16 @@ class GGUFFile {
       throw Error(ErrorKind::IOError, "failed to mmap the file: " + path);
     }
     base_ = (const uint8_t*)p;
+    if (madvise(p, len_, MADV_WILLNEED) != 0) {  // gguf.rs:811-817
+      munmap(p, len_);
+      ::close(fd_);
+      throw Error(ErrorKind::IOError, "failed to advise the mmap: " + path);
+    }
+    if (mlock && ::mlock(p, len_) != 0) {  // gguf.rs:819-825
+      munmap(p, len_);
+      ::close(fd_);
+      throw Error(ErrorKind::IOError, "failed to lock the mmap: " + path);
+    }
     try {
       decode();
     } catch (...) {
@@ -90,6 +103,8 @@ class GGUFFile {
   const std::map<std::string, GGUFValue>& metadata() const { return kv_; }
   const std::vector<GGUFTensorInfo>& tensor_infos() const { return tensors_; }
   size_t tensor_data_offset() const { return data_off_; }
+  // 0: data starts where the GGUF spec puts it; 1: the reference's always-skip convention was detected (see decode())
+  int data_start_convention() const { return data_start_convention_; }
 
   uint64_t alignment() const {  // gguf.rs:575-587
     auto it = kv_.find("general.alignment");
@@ -158,7 +173,21 @@ class GGUFFile {
     if (t > 12) throw Error(ErrorKind::FormatError, "failed to decode the value type for " + std::to_string(t));
     return (GGUFValueType)t;
   }
-  GGUFValue rd_scalar(GGUFValueType t) {
+  // nesting depth of array-of-array values: a crafted file with 200k levels (12 bytes each) would otherwise overflow
+  // the stack instead of raising FormatError; real files nest at most once
+  static constexpr int MAX_ARRAY_DEPTH = 4;
+  static size_t min_value_bytes(GGUFValueType t, uint32_t version) {
+    switch (t) {
+      case GGUFValueType::U8: case GGUFValueType::I8: case GGUFValueType::Bool: return 1;
+      case GGUFValueType::U16: case GGUFValueType::I16: return 2;
+      case GGUFValueType::U32: case GGUFValueType::I32: case GGUFValueType::F32: return 4;
+      case GGUFValueType::U64: case GGUFValueType::I64: case GGUFValueType::F64: return 8;
+      case GGUFValueType::String: return version == 1 ? 4 : 8;             // the length prefix
+      case GGUFValueType::Array: return 4 + (version == 1 ? 4 : 8);        // element type + length
+    }
+    return 1;
+  }
+  GGUFValue rd_scalar(GGUFValueType t, int depth = 0) {
     GGUFValue x;
     x.type = t;
     switch (t) {
@@ -174,17 +203,21 @@ class GGUFFile {
       case GGUFValueType::U64: x.v = rd<uint64_t>(); break;
       case GGUFValueType::I64: x.v = rd<int64_t>(); break;
       case GGUFValueType::F64: x.v = rd<double>(); break;
-      case GGUFValueType::Array: x.v = rd_array(); break;
+      case GGUFValueType::Array: x.v = rd_array(depth + 1); break;
     }
     return x;
   }
-  GGUFArray rd_array() {  // gguf.rs:341-371 (nested arrays included)
+  GGUFArray rd_array(int depth = 1) {  // gguf.rs:341-371 (nested arrays included)
+    if (depth > MAX_ARRAY_DEPTH)
+      throw Error(ErrorKind::FormatError, "metadata arrays nest deeper than " + std::to_string(MAX_ARRAY_DEPTH) + " levels");
     GGUFArray a;
     a.elem_type = value_type(rd<uint32_t>());
     size_t n = rd_len();
-    if (n > len_) throw Error(ErrorKind::FormatError, "array length " + std::to_string(n) + " exceeds the file");
+    // every element occupies at least min_value_bytes in the file: bounds the reserve() below by the bytes that are left
+    if (n > (len_ - pos_) / min_value_bytes(a.elem_type, version_))
+      throw Error(ErrorKind::FormatError, "array length " + std::to_string(n) + " exceeds the file");
     a.items.reserve(n);
-    for (size_t i = 0; i < n; i++) a.items.push_back(rd_scalar(a.elem_type));
+    for (size_t i = 0; i < n; i++) a.items.push_back(rd_scalar(a.elem_type, depth));
     return a;
   }
   void decode() {
@@ -213,7 +246,33 @@ class GGUFFile {
     }
     const size_t al = (size_t)alignment();
     if (al == 0) throw Error(ErrorKind::FormatError, "general.alignment is 0");
-    const size_t next = pos_ - (pos_ % al) + al;  // gguf.rs:722-724
+    // Where the tensor data starts.  The reference always skips to the NEXT multiple of the alignment
+    // (`position - position % alignment + alignment`, gguf.rs:722-724), i.e. a whole extra block when the tensor infos
+    // already end on a boundary; the GGUF spec (and every llama.cpp / gguf-py writer) pads only when misaligned.  The two
+    // agree unless pos % al == 0 (1 file in `al`).  In that case the file itself decides: under the right convention the
+    // data section ends exactly where the last tensor (plus its padding) ends.  Spec wins when the file does not tell.
+    size_t next = pos_ - (pos_ % al) + al;
+    if (pos_ % al == 0) {
+      size_t max_end = 0;
+      bool sized = true;
+      for (const auto& t : tensors_) {
+        size_t bb = 0, be = 0, n = 1;
+        if (!ggml_block_geometry_(t.ggml_type, &bb, &be)) { sized = false; break; }
+        for (size_t d : t.dimensions)
+          if (__builtin_mul_overflow(n, d, &n)) { sized = false; break; }
+        if (!sized) break;
+        const size_t end = (size_t)t.offset + n / be * bb;
+        if (end > max_end) max_end = end;
+      }
+      auto fits = [&](size_t start) {
+        if (!sized || start > len_) return false;
+        const size_t have = len_ - start;
+        return have == max_end || have == align_up_(max_end, al);
+      };
+      const bool spec_ok = fits(pos_), ref_ok = fits(pos_ + al);
+      if (spec_ok || !ref_ok) next = pos_;  // spec convention (also the default when neither or both match)
+      data_start_convention_ = (spec_ok || !ref_ok) ? 0 : 1;
+    }
     (void)take(next - pos_);
     data_off_ = pos_;
     const size_t data_len = len_ - data_off_;
@@ -226,6 +285,9 @@ class GGUFFile {
     }
   }
 
+  static size_t align_up_(size_t v, size_t a) { return (v + a - 1) / a * a; }
+  static bool ggml_block_geometry_(uint32_t t, size_t* bb, size_t* be);
+  int data_start_convention_ = 0;  // 0 = GGUF spec (pad only when misaligned), 1 = the reference's always-skip (detected)
   int fd_ = -1;
   const uint8_t* base_ = nullptr;
   size_t len_ = 0, pos_ = 0, data_off_ = 0;
@@ -250,6 +312,7 @@ inline bool ggml_block_geometry(uint32_t t, size_t* block_bytes, size_t* block_e
     default: return false;
   }
 }
+inline bool GGUFFile::ggml_block_geometry_(uint32_t t, size_t* bb, size_t* be) { return ggml_block_geometry(t, bb, be); }
 
 // CpuLlamaModelLoader::load_config (model.rs:545-625), llama architecture
 inline LlamaConfig load_llama_config(const GGUFFile& gf) {
@@ -287,7 +350,9 @@ inline HipTensor load_gguf_tensor(const GGUFFile& gf, const std::string& name, c
   if (!ggml_block_geometry(info->ggml_type, &bb, &be))
     throw Error(ErrorKind::NotImplemented, "tensor " + name + ": ggml type " + std::to_string(info->ggml_type) + " is not supported by the hip backend");
   size_t n = 1;
-  for (size_t d : dims) n *= d;
+  for (size_t d : dims)
+    if (__builtin_mul_overflow(n, d, &n))
+      throw Error(ErrorKind::FormatError, "tensor " + name + " " + fmt_dims(dims) + ": element count overflows");
   if (dims.empty() || n % be != 0 || dims.back() % be != 0)
     throw Error(ErrorKind::TensorError, "tensor " + name + " " + fmt_dims(dims) + " is not a whole number of blocks per row");
   const size_t nbytes = n / be * bb;

@@ -332,6 +332,22 @@ class HipTensor {
     device_->check(crabml_hip_debug_block_dots(device_->raw(), buf_.get(), m, k, row, x.buf_.get(), out.data()));
     return out;
   }
+  // the production K-quant loops' integers per super-block: (isum, msum) pairs + the kernel's own f32 value
+  std::pair<std::vector<int32_t>, float> debug_superblock_ints(size_t row, const HipTensor& x, int variant) const {
+    size_t m = shape()[0], k = shape()[1];
+    std::vector<int32_t> out(k / 256 * 2);
+    float v = 0.f;
+    device_->check(crabml_hip_debug_superblock_ints(device_->raw(), buf_.get(), m, k, row, x.buf_.get(), variant, out.data(), &v));
+    return {out, v};
+  }
+  // the same out of the matrix-core GEMM: x = (b, k) rows; returns ints[b][m][k/256][2] and the GEMM's f32 (b, m)
+  std::pair<std::vector<int32_t>, std::vector<float>> debug_gemm_ints(const HipTensor& x, size_t b) const {
+    size_t m = shape()[0], k = shape()[1];
+    std::vector<int32_t> ints(b * m * (k / 256) * 2);
+    std::vector<float> out(b * m);
+    device_->check(crabml_hip_debug_gemm_ints(device_->raw(), buf_.get(), m, k, x.buf_.get(), b, ints.data(), out.data()));
+    return {ints, out};
+  }
 
  private:
   HipTensor(BufRef buf, GGMLType dtype, TensorStrider strider, DeviceRef device)

@@ -77,6 +77,14 @@ PYBIND11_MODULE(_host, m) {
       .def("stream", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(crabml_hip_device_stream(d.raw())); })
       .def("raw_handle", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(d.raw()); })
       .def("prof_enable", [](HipTensorDevice& d, bool on) { d.check(crabml_hip_prof_enable(d.raw(), on ? 1 : 0)); })
+      .def("read_ceiling_gbps",
+           [](HipTensorDevice& d, size_t bytes, int reps) {
+             double v = 0.0;
+             py::gil_scoped_release rel;
+             d.check(crabml_hip_debug_read_ceiling(d.raw(), bytes, reps, &v));
+             return v;
+           },
+           py::arg("bytes") = (size_t)1 << 30, py::arg("reps") = 5)
       .def("prof_read_launches",
            [](HipTensorDevice& d, size_t cap) {
              std::vector<float> ms(cap);
@@ -170,6 +178,17 @@ PYBIND11_MODULE(_host, m) {
              std::vector<uint8_t> v = t.debug_quantize(q);
              return py::array_t<uint8_t>(v.size(), v.data());
            })
+      .def("debug_superblock_ints",
+           [](const HipTensor& w, size_t row, const HipTensor& x, int variant) {
+             auto r = w.debug_superblock_ints(row, x, variant);
+             return py::make_tuple(py::array_t<int32_t>(r.first.size(), r.first.data()), r.second);
+           },
+           py::arg("row"), py::arg("x"), py::arg("variant") = 0)
+      .def("debug_gemm_ints",
+           [](const HipTensor& w, const HipTensor& x, size_t b) {
+             auto r = w.debug_gemm_ints(x, b);
+             return py::make_tuple(py::array_t<int32_t>(r.first.size(), r.first.data()), py::array_t<float>(r.second.size(), r.second.data()));
+           })
       .def("debug_block_dots", [](const HipTensor& w, size_t row, const HipTensor& x) {
         std::vector<int32_t> v = w.debug_block_dots(row, x);
         return py::array_t<int32_t>(v.size(), v.data());
@@ -251,7 +270,9 @@ PYBIND11_MODULE(_host, m) {
     }
   };
   py::class_<GGUFFile, std::shared_ptr<GGUFFile>>(m, "GGUFFile")
-      .def(py::init([](const std::string& path) { return std::make_shared<GGUFFile>(path); }))
+      .def(py::init([](const std::string& path, bool mlock) { return std::make_shared<GGUFFile>(path, mlock); }), py::arg("path"),
+           py::arg("mlock") = false)
+      .def_property_readonly("data_start_convention", &GGUFFile::data_start_convention)
       .def_property_readonly("version", &GGUFFile::version)
       .def_property_readonly("architecture", &GGUFFile::architecture)
       .def_property_readonly("alignment", &GGUFFile::alignment)

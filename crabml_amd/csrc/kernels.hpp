@@ -39,7 +39,11 @@ void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, siz
 void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t n_blocks);
 // batched rhs on the matrix cores (gemm_mfma.hip); false = not covered
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
-                      crabml_hip_device::ProfRec* rec);
+                      crabml_hip_device::ProfRec* rec, int* dbg = nullptr);
+int launch_piece_ints(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, size_t row, const void* act, int variant,
+                      int32_t* out, float* fout);
+// elementwise.hip: plain streaming read of `bytes` bytes (crabml_hip_debug_read_ceiling), timed by the event pair
+void launch_stream_read(hipStream_t st, const void* buf, size_t bytes, int* sink, hipEvent_t e0, hipEvent_t e1);
 void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out);
 
 // ---- elementwise.hip

@@ -100,6 +100,7 @@ int pool_alloc(crabml_hip_device* dev, size_t bytes, void** out, size_t* cap) {
     }
   }
   void* p = nullptr;
+  (void)hipSetDevice(dev->ordinal);  // hipMalloc allocates on the calling thread's current device
   hipError_t e = hipMalloc(&p, cls);
   if (e != hipSuccess) {
     // give pooled blocks back to the driver once, then retry
@@ -194,7 +195,7 @@ static int ensure_act(crabml_hip_device* dev, const crabml_hip_buf* x_, size_t b
   }
   ActLayout al = act_layout(qt, k);
   size_t need = al.total * b;
-  if (x->qc.qtype == qt && x->qc.version == x->version && x->qc.n == b * k && x->qc.ptr) {
+  if (x->qc.qtype == qt && x->qc.version == x->version && x->qc.n == b * k && x->qc.k == k && x->qc.ptr) {
     *act = x->qc.ptr;
     return 0;
   }
@@ -208,6 +209,7 @@ static int ensure_act(crabml_hip_device* dev, const crabml_hip_buf* x_, size_t b
   x->qc.qtype = qt;
   x->qc.version = x->version;
   x->qc.n = b * k;
+  x->qc.k = k;
   *act = x->qc.ptr;
   return 0;
 }
@@ -277,6 +279,7 @@ int crabml_hip_device_destroy(crabml_hip_device_t* dev) {
 
 int crabml_hip_device_sync(crabml_hip_device_t* dev) {
   if (!dev) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
   return 0;
 }
@@ -309,7 +312,9 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
   if (be == 0 || t == CRABML_HIP_Q8_1)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "unsupported tensor type on hip %u", t);
   size_t n_elems = 1;
-  for (int i = 0; i < ndim; i++) n_elems *= shape[i];
+  for (int i = 0; i < ndim; i++)
+    if (__builtin_mul_overflow(n_elems, shape[i], &n_elems))
+      CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "shape overflows the element count");
   size_t k = shape[ndim - 1];
   size_t m = k ? n_elems / k : 0;
   if (be > 1 && k % be != 0)
@@ -317,7 +322,7 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
   size_t expect = n_elems / be * bb;
   if (nbytes < expect)  // GGUF slices may carry trailing alignment padding (gguf.rs:743-748): >= is accepted
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "data length %zu too small for shape (need %zu)", nbytes, expect);
-  (void)hipSetDevice(dev->ordinal);
+  CH_USE(dev);
   WeightLayout wl = weight_layout(t, n_elems);
   crabml_hip_buf* b = nullptr;
   CH_TRY(buf_new(dev, t, n_elems, wl.total, &b));
@@ -399,7 +404,7 @@ int crabml_hip_buf_alloc(crabml_hip_device_t* dev, size_t n_elems, uint32_t t, c
   if (!dev || !out) return CRABML_HIP_BAD_INPUT;
   *out = nullptr;
   if (t != CRABML_HIP_F32 && t != CRABML_HIP_F16) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 is supported");
-  (void)hipSetDevice(dev->ordinal);
+  CH_USE(dev);
   size_t bytes = n_elems * (t == CRABML_HIP_F32 ? 4 : 2);
   crabml_hip_buf* b = nullptr;
   CH_TRY(buf_new(dev, t, n_elems, bytes, &b));
@@ -437,6 +442,7 @@ size_t crabml_hip_buf_len(const crabml_hip_buf_t* b) { return b ? b->n_elems : 0
 // ---- data movement -----------------------------------------------------------------------------------
 int crabml_hip_export(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, float* dst, size_t n) {
   if (!dev || !b || (!dst && n)) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   if (b->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: not f32, but got %u", b->dtype);
   if (n > b->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: %zu elements requested, buffer holds %zu", n, b->n_elems);
   if (n) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, n * 4, hipMemcpyDeviceToHost, dev->stream));
@@ -446,6 +452,7 @@ int crabml_hip_export(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, float
 
 int crabml_hip_export_raw(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, void* dst, size_t nbytes) {
   if (!dev || !b || (!dst && nbytes)) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   if (b->dtype != CRABML_HIP_F32 && b->dtype != CRABML_HIP_F16)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export_raw: only f32/f16 buffers");
   size_t have = b->n_elems * (b->dtype == CRABML_HIP_F32 ? 4 : 2);
@@ -457,6 +464,7 @@ int crabml_hip_export_raw(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, v
 
 int crabml_hip_dup(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, crabml_hip_buf_t** out) {
   if (!dev || !src || !out) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   *out = nullptr;
   if (src->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "dup: not f32, but got %u", src->dtype);
   crabml_hip_buf* b = nullptr;
@@ -482,6 +490,7 @@ static void pad3(const size_t* v, int ndim, size_t fill, size_t out[3]) {
 int crabml_hip_contiguous(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, const size_t* shape,
                           const size_t* strides, int ndim, crabml_hip_buf_t** out) {
   if (!dev || !src || !out || !shape || !strides) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   *out = nullptr;
   if (ndim != 2 && ndim != 3) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "contiguous: only 2-d / 3-d tensors");
   if (src->dtype != CRABML_HIP_F32 && src->dtype != CRABML_HIP_F16)
@@ -507,6 +516,7 @@ int crabml_hip_concatenate(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, cons
                            const size_t* dstrides, const crabml_hip_buf_t* rhs, const size_t* rshape,
                            const size_t* rstrides, int ndim, int axis) {
   if (!dev || !dst || !rhs || !dshape || !dstrides || !rshape || !rstrides) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   if (ndim < 1 || ndim > 3 || axis < 0 || axis >= ndim) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "concatenate: bad ndim/axis");
   if (dst->dtype != CRABML_HIP_F32 && dst->dtype != CRABML_HIP_F16)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 is supported on concatenate");
@@ -541,6 +551,7 @@ int crabml_hip_concatenate(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, cons
 int crabml_hip_copy_rows_from(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, const crabml_hip_buf_t* src, size_t cols,
                               const size_t* rows, size_t n_rows) {
   if (!dev || !dst || !src || (!rows && n_rows)) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   if (dst->dtype != CRABML_HIP_F32 && dst->dtype != CRABML_HIP_F16)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 can be copied to");
   size_t be = block_elems(src->dtype);
@@ -568,6 +579,7 @@ static int need_f32(crabml_hip_device* dev, const crabml_hip_buf* b, size_t n, c
 int crabml_hip_rope_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n_batch, size_t bi_stride,
                             size_t head_dim, uint32_t mode, size_t pos, size_t rope_dims) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, x, n_batch * bi_stride, "rope"));
   if (head_dim == 0 || rope_dims > head_dim || (mode != 0 && mode != 1))
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rope: bad head_dim/rope_dims/mode");
@@ -604,6 +616,7 @@ int crabml_hip_rope_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_
 
 int crabml_hip_rms_norm_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols, float eps) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, x, rows * cols, "rms_norm"));
   if (cols % 32 != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rms_norm: row length %zu is not a multiple of 32", cols);
   if (cols / 32 * 4 > 64 * 1024) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "rms_norm: row too long");
@@ -614,6 +627,7 @@ int crabml_hip_rms_norm_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, s
 
 int crabml_hip_softmax_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, x, rows * cols, "softmax"));
   launch_softmax(dev->stream, (float*)x->ptr, rows, cols, dev->exp_table);
   touch(x);
@@ -622,6 +636,7 @@ int crabml_hip_softmax_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, si
 
 int crabml_hip_silu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, x, n, "silu"));
   launch_silu(dev->stream, (float*)x->ptr, n, dev->exp_table);
   touch(x);
@@ -630,6 +645,7 @@ int crabml_hip_silu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_
 
 int crabml_hip_gelu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, x, n, "gelu"));
   if (!dev->gelu_table) {  // OnceLock<Vec<f16>> (cpu_device.rs:117-124)
     std::vector<uint16_t> tab(65536);
@@ -645,6 +661,7 @@ int crabml_hip_gelu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_
 
 static int binary(crabml_hip_device* dev, int op, crabml_hip_buf* a, size_t na, const crabml_hip_buf* b, size_t nb) {
   if (!dev || !a || !b) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, a, na, op ? "mul" : "add"));
   CH_TRY(need_f32(dev, b, nb, op ? "mul" : "add"));
   if (nb == 0 || na % nb != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "%s: lhs len %zu is not a multiple of rhs len %zu", op ? "mul" : "add", na, nb);
@@ -660,6 +677,7 @@ int crabml_hip_add_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t
 }
 int crabml_hip_scale_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, float f) {
   if (!dev || !a) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, a, na, "scale"));
   launch_scale(dev->stream, (float*)a->ptr, na, f);
   touch(a);
@@ -669,6 +687,7 @@ int crabml_hip_scale_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size
 int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k,
                           const crabml_hip_buf_t* x, size_t b, crabml_hip_buf_t** out) {
   if (!dev || !w || !x || !out) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   *out = nullptr;
   uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (qt == 0xffffffffu) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
@@ -685,12 +704,20 @@ int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, s
   CH_TRY(buf_new(dev, CRABML_HIP_F32, b * m, b * m * 4, &o));
   o->wl = weight_layout(CRABML_HIP_F32, b * m);
   crabml_hip_device::ProfRec rec{};
-  if (dev->prof_on)
+  const bool prof = dev->prof_on && !dev->strict_order;  // the strict-order kernels carry no events: take none
+  if (prof)
     CH_TRY(prof_begin(dev, &rec, w->dtype, 0,
                       (double)b * ((double)m * (double)(k / block_elems(w->dtype)) * (double)block_bytes(w->dtype) + 4.0 * k + 4.0 * m)));
   int rc = dev->strict_order ? launch_gemv_strict(dev, w, m, k, act, b, (float*)o->ptr)
-                             : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr, dev->prof_on ? &rec : nullptr);
-  if (dev->prof_on && !dev->strict_order) CH_TRY(prof_end(dev, &rec));
+                             : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr, prof ? &rec : nullptr);
+  if (prof) {
+    if (rc == 0) {
+      CH_TRY(prof_end(dev, &rec));
+    } else {  // nothing was recorded: hand the pair back
+      dev->prof_free_events.push_back(rec.e0);
+      dev->prof_free_events.push_back(rec.e1);
+    }
+  }
   if (rc != 0) {
     crabml_hip_buf_release(o);
     return rc;
@@ -703,6 +730,7 @@ int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a,
                             const crabml_hip_buf_t* b, size_t bb, size_t n, size_t sb0, size_t sb1, size_t sb2,
                             crabml_hip_buf_t** out) {
   if (!dev || !a || !b || !out) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   *out = nullptr;
   CH_TRY(need_f32(dev, a, ba * m * k, "batch_matmul lhs"));
   if (b->dtype != CRABML_HIP_F32 && b->dtype != CRABML_HIP_F16)
@@ -726,6 +754,7 @@ int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a,
 int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* x, size_t n, uint32_t qt, void* dst,
                               size_t dst_bytes) {
   if (!dev || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_TRY(need_f32(dev, x, n, "debug_quantize"));
   if (qt != CRABML_HIP_Q8_0 && qt != CRABML_HIP_Q8_1 && qt != CRABML_HIP_Q8_K)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_quantize: unsupported target %u", qt);
@@ -764,6 +793,7 @@ int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* 
 int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
                                 const crabml_hip_buf_t* x, int32_t* dst) {
   if (!dev || !w || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (block_elems(w->dtype) <= 1 || qt == 0xffffffffu)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_block_dots: quantized weights only");
@@ -783,6 +813,113 @@ int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t
   return 0;
 }
 
+int crabml_hip_debug_superblock_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
+                                     const crabml_hip_buf_t* x, int32_t variant, int32_t* dst, float* value) {
+  if (!dev || !w || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
+  if (w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_superblock_ints: Q4_K / Q6_K weights only");
+  if (row >= m || w->k != k || m * k > w->n_elems || k % 256 != 0)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_superblock_ints: bad row/shape");
+  CH_TRY(need_f32(dev, x, k, "debug_superblock_ints rhs"));
+  const void* act = nullptr;
+  CH_TRY(ensure_act(dev, x, 1, k, CRABML_HIP_Q8_K, &act));
+  const size_t nsb = k / 256, npieces = nsb * 8;
+  void* d = nullptr;
+  size_t cap = 0;
+  CH_TRY(pool_alloc(dev, npieces * 8 + 16, &d, &cap));
+  float* fout = (float*)((char*)d + npieces * 8);
+  int rc = launch_piece_ints(dev, w, m, k, row, act, variant, (int32_t*)d, fout);
+  std::vector<int32_t> h(npieces * 2);
+  float fv = 0.f;
+  hipError_t e = rc == 0 ? hipMemcpyAsync(h.data(), d, npieces * 8, hipMemcpyDeviceToHost, dev->stream) : hipSuccess;
+  if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(&fv, fout, 4, hipMemcpyDeviceToHost, dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  pool_free(dev, d, cap);
+  if (rc != 0) return rc;
+  if (e != hipSuccess) return hip_fail(dev, e, "debug_superblock_ints", __FILE__, __LINE__);
+  for (size_t sb = 0; sb < nsb; sb++) {  // the 8 pieces of a super-block: plain integer sums
+    long long a = 0, b = 0;
+    for (size_t j = 0; j < 8; j++) {
+      a += h[(sb * 8 + j) * 2];
+      b += h[(sb * 8 + j) * 2 + 1];
+    }
+    if (w->dtype == CRABML_HIP_Q6_K) {  // both halves are scaled group sums
+      a += b;
+      b = 0;
+    }
+    dst[2 * sb] = (int32_t)a;
+    dst[2 * sb + 1] = (int32_t)b;
+  }
+  if (value) *value = fv;
+  return 0;
+}
+
+int crabml_hip_debug_gemm_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, const crabml_hip_buf_t* x,
+                               size_t b, int32_t* dst, float* out) {
+  if (!dev || !w || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
+  if (w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K)
+    CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_gemm_ints: Q4_K / Q6_K weights only");
+  if (b < 16 || w->k != k || m * k > w->n_elems || k % 256 != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_gemm_ints: needs b >= 16 rows and a matching shape");
+  CH_TRY(need_f32(dev, x, b * k, "debug_gemm_ints rhs"));
+  const void* act = nullptr;
+  CH_TRY(ensure_act(dev, x, b, k, CRABML_HIP_Q8_K, &act));
+  const size_t n = b * m * (k / 256) * 2;
+  void *d = nullptr, *o = nullptr;
+  size_t cap = 0, ocap = 0;
+  CH_TRY(pool_alloc(dev, n * 4, &d, &cap));
+  int rc = pool_alloc(dev, b * m * 4, &o, &ocap);
+  if (rc != 0) {
+    pool_free(dev, d, cap);
+    return rc;
+  }
+  hipError_t e = hipMemsetAsync(d, 0xff, n * 4, dev->stream);
+  const bool ran = e == hipSuccess && launch_gemm_mfma(dev, w, m, k, act, b, (float*)o, nullptr, (int*)d);
+  if (ran) e = hipMemcpyAsync(dst, d, n * 4, hipMemcpyDeviceToHost, dev->stream);
+  if (ran && e == hipSuccess && out) e = hipMemcpyAsync(out, o, b * m * 4, hipMemcpyDeviceToHost, dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  pool_free(dev, d, cap);
+  pool_free(dev, o, ocap);
+  if (e != hipSuccess) return hip_fail(dev, e, "debug_gemm_ints", __FILE__, __LINE__);
+  if (!ran) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "debug_gemm_ints: the matrix-core GEMM did not take this shape");
+  return 0;
+}
+
+int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_t reps, double* gbytes_per_s) {
+  if (!dev || !gbytes_per_s || reps < 1) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
+  bytes = bytes / 4096 * 4096;
+  if (bytes < ((size_t)1 << 20)) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "debug_read_ceiling: at least 1 MiB");
+  void *buf = nullptr, *sink = nullptr;
+  size_t cap = 0, scap = 0;
+  CH_TRY(pool_alloc(dev, bytes, &buf, &cap));
+  int rc = pool_alloc(dev, 256, &sink, &scap);
+  if (rc != 0) {
+    pool_free(dev, buf, cap);
+    return rc;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipMemsetAsync(buf, 1, bytes, dev->stream);
+  float best = 0.f;
+  for (int i = 0; i < reps + 1 && e == hipSuccess; i++) {  // first launch = warm-up
+    launch_stream_read(dev->stream, buf, bytes, (int*)sink, e0, e1);
+    e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (i > 0 && e == hipSuccess && (best == 0.f || ms < best)) best = ms;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  pool_free(dev, buf, cap);
+  pool_free(dev, sink, scap);
+  if (e != hipSuccess) return hip_fail(dev, e, "debug_read_ceiling", __FILE__, __LINE__);
+  *gbytes_per_s = best > 0.f ? (double)bytes / ((double)best * 1e-3) / 1e9 : 0.0;
+  return 0;
+}
+
 int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on) {
   if (!dev) return CRABML_HIP_BAD_INPUT;
   dev->prof_on = on != 0;
@@ -791,6 +928,7 @@ int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on) {
 
 int crabml_hip_prof_read_launches(crabml_hip_device_t* dev, float* ms_out, size_t cap, size_t* n) {
   if (!dev || !n || (!ms_out && cap)) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
   size_t i = 0;
   for (auto& r : dev->prof_recs) {
@@ -807,6 +945,7 @@ int crabml_hip_prof_read_launches(crabml_hip_device_t* dev, float* ms_out, size_
 
 int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n) {
   if (!dev || !n || (!out && cap)) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
   std::map<uint64_t, crabml_hip_prof_entry_t> agg;
   for (auto& r : dev->prof_recs) {

@@ -169,6 +169,25 @@ int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* 
  * bit-exact gate for the nibble unpack + integer dot. */
 int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
                                 const crabml_hip_buf_t* x, int32_t* dst);
+/* The integers of the PRODUCTION K-quant loops, per super-block (Q4_K / Q6_K weights, Q8_K rhs; north_star: "bit-exactly
+ * at the integer unpack level").  The single-row kernels' own inner loops (rows_partial_q4k / rows_partial_q6k in their
+ * debug instantiation: the same code k_gemv_q4_k / k_qkv / k_gemv_res_nq / k_gateup_k_lds run) walk row `row` and hand out
+ * what their float part consumes: dst[2 sb] = isum = sum_j scale_j * sum(q * q8) and dst[2 sb + 1] = msum = sum_j min_j *
+ * bsum_j for Q4_K (buf_q4_k.rs:212-263; variant 0 = quad-exchanged header dwords, 1 = whole-header loads, the form the
+ * LDS-staged kernels use); dst[2 sb] = sum_g scale_g * sum((q6 - 32) * q8), dst[2 sb + 1] = 0 for Q6_K
+ * (buf_q6_k.rs:183-234).  k / 256 pairs.  *value (optional) = the kernel's own f32 result for the row. */
+int crabml_hip_debug_superblock_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
+                                     const crabml_hip_buf_t* x, int32_t variant, int32_t* dst, float* value);
+/* The same integers out of the matrix-core GEMM (k_gemm_mfma_q4k / k_gemm_mfma_q6k themselves, run with their dump
+ * pointer set): x holds b >= 16 rows of k; dst[((bi * m + row) * (k / 256) + sb) * 2 + {0, 1}] = (isum, msum) for Q4_K and
+ * (sum_g scale_g * sum(q6 * q8), sum_g scale_g * bsum_g) for Q6_K -- the -32 offset is applied as isum - 32 * that.
+ * out (optional, b * m floats) receives the GEMM's f32 result. */
+int crabml_hip_debug_gemm_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k,
+                               const crabml_hip_buf_t* x, size_t b, int32_t* dst, float* out);
+/* Sustained HBM read rate of this device as a plain streaming kernel reaches it (16-byte non-temporal loads over `bytes`
+ * bytes, best of `reps` launches, HIP events on the device stream): the practical ceiling bench.py quotes next to the
+ * 8 TB/s datasheet peak. */
+int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_t reps, double* gbytes_per_s);
 
 /* ---- fused Llama decode step (extension of the hot path) ------------------------------------------
  * The trait above costs ~31 launches per layer (one per Tensor call of crabml-llama2/src/llama2.rs:226-271),

@@ -44,3 +44,105 @@ def gemv_order_bound(w_raw, wtyp, x, m, k):
 
 
 GEMV_REL = 2e-5  # f32 re-association bound factor: |gpu - oracle| <= GEMV_REL * sum_i |w_i x_i| + tiny
+
+# End-to-end tolerance of the FAST kernels PER WEIGHT FORMAT: (median, max) over the tested steps of
+# max|hip - oracle| / max|oracle logit|, teacher-forced on the oracle's tokens.  Set to a small multiple (~3x) of what
+# MI355X shows on the test seeds; every fast-path test records what it observed in gpurun_out/fast_path_errors.json
+# (tests/golden/fast_path_errors_observed.json keeps the last committed copy).  The formats with a TRUNCATING rhs quantizer
+# (Q8_0 / Q8_1 rhs: buf_q8_0.rs:119-124) amplify 1-ulp GEMV differences into +-1 quant flips -- the reference's own
+# scalar-vs-AVX2 spread on Q8_0 models is 1.5-2.7e-2 (tests/test_oracle_runner.py) --, the K-quants round to nearest
+# (buf_q8_k.rs:84-131), F32 / F16 weights have no activation quantizer at all.
+FAST_TOL = {"Q4_0": (3e-2, 1e-1), "Q8_0": (3e-2, 1e-1), "Q4_1": (3e-2, 1e-1), "Q4_K": (3e-2, 1e-1), "Q6_K": (3e-2, 1e-1),
+            "Q8_K": (3e-2, 1e-1), "F32": (1e-4, 1e-3), "F16": (1e-4, 1e-3)}
+_OBSERVED = {}
+
+
+def check_fast(key, fmt, err):
+    """records the observed per-step errors under `key` and asserts the format's tolerance"""
+    import json
+    import os
+
+    err = np.asarray(err, dtype=np.float64)
+    _OBSERVED[key] = {"median": float(np.median(err)), "max": float(np.max(err)), "steps": int(err.size)}
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        path = os.path.join("gpurun_out", "fast_path_errors.json")
+        prev = {}
+        if os.path.exists(path):
+            try:
+                prev = json.load(open(path))
+            except ValueError:
+                prev = {}
+        prev.update(_OBSERVED)
+        with open(path, "w") as f:
+            json.dump(prev, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    med, mx = FAST_TOL[fmt]
+    assert np.median(err) <= med and np.max(err) <= mx, (key, err)
+
+
+# ---- an independent (pure Python) GGUF reader for the checker side ------------------------------------------------------
+# The product parses GGUF in C++ (crabml_amd/csrc/host/gguf.hpp); the oracle side of a real-file test must not lean on
+# it, so this is a second, minimal reader written from the format description in crabml-core/src/gguf.rs:499-566
+# (header + metadata), :632-646 (tensor infos) and the GGUF spec's data-section rule (pad to the alignment only when
+# misaligned).  Returns a synth.RawModel whose tensors are views of the file's bytes.
+def read_gguf_py(path):
+    import struct
+
+    buf = open(path, "rb").read()
+    pos = 0
+
+    def rd(fmt):
+        nonlocal pos
+        v = struct.unpack_from(fmt, buf, pos)
+        pos += struct.calcsize(fmt)
+        return v[0]
+
+    magic, version = rd("<I"), rd("<I")
+    assert magic == 0x46554747 and version in (1, 2, 3)
+    ln = (lambda: rd("<I")) if version == 1 else (lambda: rd("<Q"))
+
+    def rstr():
+        nonlocal pos
+        n = ln()
+        s = buf[pos:pos + n]
+        pos += n
+        return s.decode("utf-8", "replace")
+
+    scalar = {0: "<B", 1: "<b", 2: "<H", 3: "<h", 4: "<I", 5: "<i", 6: "<f", 7: "<B", 10: "<Q", 11: "<q", 12: "<d"}
+
+    def rval(t):
+        if t == 8:
+            return rstr()
+        if t == 9:
+            et = rd("<I")
+            return [rval(et) for _ in range(ln())]
+        return rd(scalar[t])
+
+    n_tensors, n_kv = ln(), ln()
+    kv = {}
+    for _ in range(n_kv):
+        k = rstr()
+        kv[k] = rval(rd("<I"))
+    infos = []
+    for _ in range(n_tensors):
+        name = rstr()
+        nd = rd("<I")
+        dims = [ln() for _ in range(nd)]
+        typ, off = rd("<I"), rd("<Q")
+        infos.append((name, dims[::-1], typ, off))  # stored innermost-first (model.rs:473-475 reverses them)
+    al = int(kv.get("general.alignment", 32))
+    start = pos + (al - pos % al) % al
+    arch = kv["general.architecture"]
+    shape = synth.ModelShape(kv.get("general.name", "gguf"), kv[f"{arch}.embedding_length"], kv[f"{arch}.feed_forward_length"],
+                             kv[f"{arch}.block_count"], kv[f"{arch}.attention.head_count"], kv[f"{arch}.attention.head_count_kv"],
+                             len(kv["tokenizer.ggml.tokens"]), kv[f"{arch}.context_length"],
+                             kv[f"{arch}.attention.layer_norm_rms_epsilon"], kv.get(f"{arch}.rope.dimension_count"))
+    model = synth.RawModel(shape, infos[1][2])
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    for name, dims, typ, off in infos:
+        n = int(np.prod(dims))
+        nbytes = n // synth.BLOCK_ELEMS[typ] * synth.BLOCK_BYTES[typ]
+        model.tensors[name] = synth.RawTensor(raw[start + off:start + off + nbytes], dims, typ)
+    return model, kv

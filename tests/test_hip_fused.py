@@ -11,7 +11,7 @@ import pytest
 
 from crabml_amd import synth
 from oracle import oracle as o
-from tests.helpers import to_oracle
+from tests.helpers import check_fast, to_oracle
 
 pytestmark = pytest.mark.gpu
 PROMPT = [1, 365, 400, 282]
@@ -82,7 +82,7 @@ def test_decode_step_other_formats_fast(ca, fmt):
     r = ca.HipLlamaRunner(conf, w, dev, 64, True)
     got = [r.forward(t, i).copy() for i, t in enumerate(toks)]
     err = rel_errs(got, ref)
-    assert np.median(err) <= 3e-2 and np.max(err) <= 1e-1, err
+    check_fast(f"fused/tiny-gqa/{fmt}", fmt, err)
     # greedy continuation on the device = host argmax (last maximum) over the exported logits
     ids = r.decode_greedy(int(o.argmax_last(got[-1])), 4)
     assert len(ids) == 4 and r.kv_cache_len() == len(toks) + 4
@@ -111,8 +111,8 @@ def test_fused_fast_matches_oracle_and_trait_path(ca, shape, fmt):
         assert np.array_equal(split_chunks.forward(t, i).view(np.uint32), lf[i].view(np.uint32)), f"split chunks, step {i}"
     lt = [trait.forward([t], i).copy() for i, t in enumerate(toks)]
     ef, et = rel_errs(lf, ref), rel_errs(lt, ref)
-    assert np.median(ef) <= 3e-2 and np.max(ef) <= 1e-1, ef
-    assert np.median(et) <= 3e-2 and np.max(et) <= 1e-1, et
+    check_fast(f"fused/{shape}/{fmt}", fmt, ef)
+    check_fast(f"trait12/{shape}/{fmt}", fmt, et)
     # step 0 (empty cache, before anything can amplify) is tight for both
     assert ef[0] <= 2e-2 and et[0] <= 2e-2
 

@@ -35,7 +35,9 @@ def test_reference_own_order_sensitivity():
         r = o.OracleLlamaRunner(conf, w, odev, 32, False)
         logits.append(r.forward([7], 0).copy())
     spread = np.max(np.abs(logits[0] - logits[1])) / np.max(np.abs(logits[0]))
-    assert spread <= 3e-2, spread
+    # both sides of the claim: the two builds of the reference DO differ at the 1e-2 level (1.5e-2 here; 2.0-2.7e-2 on
+    # the 15M shape) -- a lower bound, so that the statement cannot pass vacuously -- and not by more than 3e-2
+    assert 5e-3 <= spread <= 3e-2, spread
 
 
 def test_gemv_weight_bytes_formula_matches_survey():

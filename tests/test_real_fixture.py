@@ -1,0 +1,106 @@
+"""Config C1 on the only real model weights in reach: the reference's own fixture
+`testdata/tinyllamas-stories-260k-f32.gguf` (copied to tests/golden/; gguf.rs:841 / :918 parse it in the reference's
+tests).  100 greedy steps from BOS, the pattern of llama2.rs:738-797 (same weights, CPU path vs device path).
+
+CPU tests (no GPU): the oracle's restatement of Llama2Runner<CpuTensor> decodes the file deterministically and -- with
+the CLI's default f16 KV cache (main.rs:250) -- produces fluent TinyStories English, which is the end-to-end evidence
+that the oracle's forward pass is the model's forward pass; the token stream is pinned as a golden.
+GPU tests: the file goes through the product's C++ loader (GGUFFile.load_config / load_weights -> from_cpu) and the
+STRICT-order device must reproduce the oracle's logits bit for bit at every one of the 100 steps; the fast kernels must
+produce the same 100 tokens."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from tests.helpers import read_gguf_py, to_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "tinyllamas-stories-260k-f32.gguf")
+GOLD = os.path.join(HERE, "golden", "tinyllamas_260k_greedy.json")
+STEPS = 100
+BOS = 1
+
+
+def oracle_decode(kv_f16, steps=STEPS, threads=2):
+    model, kv = read_gguf_py(FIXTURE)
+    odev = o.OracleDevice(thread_num=threads, use_avx2=False)
+    conf, w = to_oracle(model, odev)
+    r = o.OracleLlamaRunner(conf, w, odev, 256, kv_f16)
+    tok, ids, logits = BOS, [], []
+    for pos in range(steps):
+        lg = r.forward([tok], pos).copy()
+        logits.append(lg)
+        tok = o.argmax_last(lg)
+        ids.append(tok)
+    return ids, logits, kv["tokenizer.ggml.tokens"]
+
+
+def detok(ids, vocab):
+    return "".join(vocab[i] for i in ids).replace("▁", " ")
+
+
+def test_fixture_is_the_reference_file():
+    """1 182 656 bytes, the size of /root/reference/testdata/tinyllamas-stories-260k-f32.gguf; sha256 pinned."""
+    raw = open(FIXTURE, "rb").read()
+    assert len(raw) == 1182656
+    assert hashlib.sha256(raw).hexdigest() == json.load(open(GOLD))["fixture_sha256"]
+
+
+@pytest.mark.parametrize("kv_f16", [True, False])
+def test_oracle_100_greedy_steps_are_deterministic_and_pinned(kv_f16):
+    ids_a, lg_a, vocab = oracle_decode(kv_f16, threads=1)
+    ids_b, lg_b, _ = oracle_decode(kv_f16, threads=3)  # thread count must not change a bit (row-split pool)
+    assert ids_a == ids_b
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(lg_a, lg_b))
+    gold = json.load(open(GOLD))["f16kv" if kv_f16 else "f32kv"]
+    assert ids_a == gold["tokens"]
+    assert hashlib.sha256(b"".join(x.tobytes() for x in lg_a)).hexdigest() == gold["logits_sha256"]
+    if kv_f16:
+        # real weights, real English: the oracle's forward pass is the model's
+        text = detok(ids_a, vocab)
+        assert text.startswith(" Once upon a time, there was a little girl named Lily. She loved to play outside in the park.")
+        assert text == gold["text"]
+
+
+def _hip_runner(ca, strict, kv_f16):
+    dev = ca.HipTensorDevice(0, False, 0, strict)
+    gf = ca.GGUFFile(FIXTURE)
+    conf = gf.load_config()
+    w = gf.load_weights(conf, dev)
+    return dev, ca.Llama2Runner(conf, w, dev, 256, kv_f16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv_f16", [True, False])
+def test_strict_device_equals_the_oracle_bit_for_bit_on_the_real_file(ca, kv_f16):
+    ids_o, lg_o, _ = oracle_decode(kv_f16)
+    _, r = _hip_runner(ca, True, kv_f16)
+    tok, ids = BOS, []
+    for pos in range(STEPS):
+        lg = r.forward([tok], pos)
+        assert np.array_equal(lg.view(np.uint32), lg_o[pos].view(np.uint32)), f"logits differ at step {pos}"
+        tok = o.argmax_last(lg)
+        ids.append(tok)
+    assert ids == ids_o
+
+
+@pytest.mark.gpu
+def test_fast_device_decodes_the_same_100_tokens_on_the_real_file(ca):
+    """F32 weights: the fast GEMV differs from the scalar order only by f32 re-association (no activation quantizer to
+    amplify it), so the logits stay within 1e-4 * max|logit| and the greedy stream is the oracle's."""
+    ids_o, lg_o, _ = oracle_decode(True)
+    _, r = _hip_runner(ca, False, True)
+    tok, ids, worst = BOS, [], 0.0
+    for pos in range(STEPS):
+        lg = r.forward([tok], pos)
+        worst = max(worst, float(np.max(np.abs(lg - lg_o[pos])) / np.max(np.abs(lg_o[pos]))))
+        tok = ids_o[pos]  # teacher-forced, so every step is compared
+        ids.append(o.argmax_last(lg))
+    assert worst <= 1e-4, worst
+    assert ids == ids_o
+    ids2 = _hip_runner(ca, False, True)[1].generate_greedy([BOS], STEPS)
+    assert list(ids2) == ids_o
