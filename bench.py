@@ -31,10 +31,30 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the achievable copy rate
 # HBM bytes per GEMV launch from rocprofv3 --pmc (FETCH_SIZE x2 correction for gfx950), see profiles/; None until measured
+KERNEL_SOURCES = ("fused_ffn.hpp", "fused_common.hpp", "gemv_core.hpp", "devutil.hpp")  # what k_gateup_q is made of
+
+
+def kernel_code_hash():
+    """sha256 over the sources of the dominant kernel: profiles/pmc_traffic.json is stamped with it when the PMC pass is
+    taken (tools/pmc_traffic.py), so a traffic figure measured on other code is never quoted."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "crabml_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass -- or None when that pass was
+    taken on different kernel code (hash mismatch)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)
+            pmc = json.load(f)
+        if pmc.get("kernel_code_hash") != kernel_code_hash():
+            return {"stale": True, "source": pmc.get("source"), "measured_on": pmc.get("kernel_code_hash")}
+        return pmc
     except Exception:
         return None
 
@@ -65,7 +85,10 @@ def parse():
                          "(per-rank kernel time; not a tokens/s result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the batched-prefill measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated this many times (same positions)")
+    ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-context", action="store_true", help="skip the long-context decode points")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self test of the rank aggregation")
     return ap.parse_args()
 
@@ -145,14 +168,14 @@ def cpu_baseline(model, steps_budget_s):
 
     ncpu = os.cpu_count() or 1
     results = []
-    for threads in sorted({2, min(ncpu, 32)}):
+    for threads in sorted({2, min(ncpu, 32), ncpu}):  # crabml's CLI default (-T 2, main.rs:49-50), 32, every host CPU
         odev = o.OracleDevice(thread_num=threads, use_avx2=True)
         conf, w = to_oracle(model, odev)
         r = o.OracleLlamaRunner(conf, w, odev, 64, True)
         r.forward([1], 0)  # touch all pages once (untimed)
         tok, pos, n = o.argmax_last(r.logits), 1, 0
         t0 = time.perf_counter()
-        budget = steps_budget_s / 2
+        budget = steps_budget_s / 3
         while True:
             r.forward([tok], pos)
             tok = o.argmax_last(r.logits)
@@ -171,6 +194,53 @@ def cpu_baseline(model, steps_budget_s):
             f"T={t}: {n} tokens in {el:.2f}s = {v:.2f} tok/s" for v, t, n, el in results),
         "note": "reference is Rust nightly (no rustc here): its AVX2 CPU path restated in C (oracle/crabml_oracle.c)",
     }
+
+
+def parity_check(ca, synth, model, conf, weights, dev, ordinal, n_pos=4):
+    """The benchmarked path against the oracle, on the benchmarked model: teacher-forced on fixed tokens, (a) the fast fused
+    step (hipGraph, 5-kernel layers -- what `value` times) -> max relative logit error and greedy-token agreement, (b) a
+    STRICT-order device (CRABML_HIP_FLAG_STRICT_ORDER) -> bit-identical logits, with its tokens/s.  The oracle is the
+    reference's scalar-order CPU path (oracle/, test infrastructure; checker only, outside every timed region)."""
+    import numpy as np
+
+    from oracle import oracle as o
+    from tests.helpers import to_oracle
+
+    toks = [1, 365, 400, 282, 9906, 7, 9, 11][:n_pos]
+    ncpu = os.cpu_count() or 1
+    odev = o.OracleDevice(thread_num=max(2, min(ncpu, 64)), use_avx2=False)
+    oconf, ow = to_oracle(model, odev)
+    orr = o.OracleLlamaRunner(oconf, ow, odev, 64, True)
+    t0 = time.perf_counter()
+    ref = [orr.forward([t], i).copy() for i, t in enumerate(toks)]
+    t_oracle = time.perf_counter() - t0
+    fast = ca.HipLlamaRunner(conf, weights, dev, 64, True)
+    errs, equal = [], []
+    for i, t in enumerate(toks):
+        lg = fast.forward(t, i)
+        errs.append(float(np.max(np.abs(lg - ref[i])) / np.max(np.abs(ref[i]))))
+        equal.append(bool(o.argmax_last(lg) == o.argmax_last(ref[i])))
+    del fast
+    out = {"tokens_compared": len(toks), "fast_max_rel_logit_err": round(max(errs), 6), "fast_rel_logit_err_per_pos": [round(e, 6) for e in errs],
+           "fast_tokens_equal": equal, "oracle": "scalar-order restatement of the reference CPU path", "oracle_s": round(t_oracle, 2)}
+    try:
+        sdev = ca.HipTensorDevice(ordinal, False, 0, True)
+        sconf, sw = synth.to_hip(model, sdev)
+        strict = ca.HipLlamaRunner(sconf, sw, sdev, 64, True)
+        ident = []
+        for i, t in enumerate(toks):
+            lg = strict.forward(t, i)
+            ident.append(bool(np.array_equal(lg.view(np.uint32), ref[i].view(np.uint32))))
+        sdev.sync()
+        t0 = time.perf_counter()
+        strict.decode_greedy(1, 8)
+        sdev.sync()
+        out["strict_bit_identical"] = ident
+        out["strict_tokens_per_s"] = round(8 / (time.perf_counter() - t0), 2)
+        del strict, sw
+    except Exception as e:  # pragma: no cover
+        out["strict_error"] = repr(e)
+    return out
 
 
 def tp_dry_run(args, ca, synth, local):
@@ -325,16 +395,26 @@ def main():
             return int(fused.decode_greedy(tok, n)[-1])
         return int(trait.timed_decode(tok, n)[0][-1])
 
-    # ---- warm-up (untimed), then the timed region -------------------------------------------------
-    tok = decode(1, args.warmup) if args.warmup > 0 else 1
-    dev.sync()
-    dist.barrier()
-    t0 = time.perf_counter()
-    tok = decode(tok, args.steps)
-    dev.sync()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed_max, total_tokens = dist.max_sum(elapsed, args.steps)
+    # ---- warm-up (untimed), then the timed region: EXACTLY K steps between barrier + synchronize ------------------
+    # The region is repeated `--repeats` times over the SAME positions (the sequence is rewound: kv length back to 0,
+    # W warm-up steps, K timed steps), so the repeats are comparable; `value` is the MEDIAN region, all of them are listed.
+    regions = []
+    for rep in range(max(1, args.repeats)):
+        if rep > 0:
+            if path == "fused":
+                fused.reset()
+            else:
+                trait = ca.Llama2Runner(conf, weights, dev, seq_len, True)
+        tok = decode(1, args.warmup) if args.warmup > 0 else 1
+        dev.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        tok = decode(tok, args.steps)
+        dev.sync()
+        dist.barrier()
+        regions.append(dist.max_sum(time.perf_counter() - t0, args.steps))
+    regions.sort()
+    elapsed_max, total_tokens = regions[len(regions) // 2]
 
     # the per-op trait path (Llama2Runner<HipTensor> unchanged) is always reported next to the fused number
     trait_tps = None
@@ -378,11 +458,20 @@ def main():
             d_us = dom["kernel_ms"] * 1e3 / dom["launches"]
             gbs = d_bytes / (d_us * 1e-6) / 1e9
             pmc = _pmc_traffic()
+            pmc_ok = bool(pmc) and not pmc.get("stale") and path == "fused" and args.wtype == "Q4_0" and args.model == "llama3-8b"
+            try:  # what a plain streaming-read kernel reaches on THIS box, right now (1 GiB, best of 5)
+                ceiling = dev.read_ceiling_gbps(1 << 30, 5)
+            except Exception:
+                ceiling = None
             roof = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": pmc["hbm_bytes_per_launch"] if pmc and path == "fused" and args.wtype == "Q4_0" and args.model == "llama3-8b" else None,
-                "traffic_source": pmc["source"] if pmc else None,
+                "measured_read_ceiling": round(ceiling, 1) if ceiling else None,
+                "frac_of_measured": round(gbs / ceiling, 4) if ceiling else None,
+                "traffic": pmc["hbm_bytes_per_launch"] if pmc_ok else None,
+                "traffic_source": (pmc["source"] if pmc_ok else ("stale: PMC pass was taken on other kernel code (" + str(pmc.get("measured_on")) + " vs " +
+                                                                kernel_code_hash() + ")" if pmc and pmc.get("stale") else None)),
+                "kernel_code_hash": kernel_code_hash(),
                 "kernel": STAGES.get(dom["stage"], "?"),
                 "avg_launch_us": round(d_us, 3),
                 "algo_bytes_per_launch": round(d_bytes, 1),
@@ -428,6 +517,26 @@ def main():
         except Exception as e:
             prefill = {"error": repr(e)}
 
+    # ---- decode at longer contexts: the prompt is prefilled (batched pass), then 32 greedy steps are timed ------------------
+    context = None
+    if rank == 0 and path == "fused" and not args.no_context and not args.gguf:
+        context = {}
+        for ctx_len in (1024, 4096):
+            try:
+                if ctx_len + 64 > shape.seq_len:
+                    continue
+                cr = ca.HipLlamaRunner(conf, weights, dev, ctx_len + 64, True)
+                cr.prefill([(7 * i + 1) % shape.vocab for i in range(ctx_len)])
+                ctok = int(cr.decode_greedy(1, 4)[-1])
+                dev.sync()
+                tc = time.perf_counter()
+                cr.decode_greedy(ctok, 32)
+                dev.sync()
+                context[str(ctx_len)] = round(32 / (time.perf_counter() - tc), 2)
+                del cr
+            except Exception as e:
+                context[str(ctx_len)] = repr(e)
+
     out = None
     if rank == 0:
         tps = total_tokens / elapsed_max
@@ -448,7 +557,16 @@ def main():
             "frac_of_hbm_roofline_tokens": round(tps / args.gpus / (HBM_PEAK_GBS * 1e9 / gemv_bytes), 4),
             "effective_weight_GBps_per_gpu": round(tps / args.gpus * gemv_bytes / 1e9, 1),
             "setup_s": round(t_build, 1), "upload_s": round(t_upload, 2),
+            "timed_regions": {"repeats": len(regions), "steps_each": args.steps,
+                              "tokens_per_s": [round(u / t, 2) for t, u in regions][::-1],  # fastest first
+                              "median": round(tps, 2),
+                              "p10": round(regions[min(len(regions) - 1, int(0.9 * len(regions)))][1] / regions[min(len(regions) - 1, int(0.9 * len(regions)))][0], 2),
+                              "p90": round(regions[int(0.1 * len(regions))][1] / regions[int(0.1 * len(regions))][0], 2),
+                              "note": "every region = the same W warm-up + K timed steps from an empty KV cache; value = the median region"},
         }
+        if context:
+            out["context"] = {"tokens_per_s_at_position": context,
+                              "note": "prompt of that length prefilled in batched passes, then 32 timed greedy steps"}
         if trait_tps is not None:
             out["trait_path_tokens_per_s"] = round(trait_tps, 2)
         if args.layers is not None:
@@ -460,6 +578,11 @@ def main():
         if args.gguf:
             out["data"] = "file: " + args.gguf
             out["config"]["workload"] = f"GGUF file {os.path.basename(args.gguf)} ({args.wtype} body), batch-1 greedy decode, f16 KV cache"
+        if not args.no_parity_check and args.gpus == 1 and model is not None and path == "fused":
+            try:
+                out["parity_check"] = parity_check(ca, synth, model, conf, weights, dev, local)
+            except Exception as e:
+                out["parity_check"] = {"error": repr(e)}
         if not args.no_cpu_baseline and args.gpus == 1 and model is not None:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, args.cpu_seconds)

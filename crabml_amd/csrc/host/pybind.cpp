@@ -302,6 +302,9 @@ PYBIND11_MODULE(_host, m) {
              if (!t) throw Error(ErrorKind::TensorNotFound, "failed to find tensor " + name);
              return py::bytes((const char*)t->data, t->data_len);
            })
+      .def("load_tensor", [](const GGUFFile& g, const std::string& name, std::shared_ptr<HipTensorDevice> dev) {
+        return load_gguf_tensor(g, name, dev);  // model.rs:462-495 for one tensor
+      })
       .def("load_config", [](const GGUFFile& g) { return load_llama_config(g); })
       .def("load_weights", [](const GGUFFile& g, const LlamaConfig& conf, std::shared_ptr<HipTensorDevice> dev) {
         py::gil_scoped_release rel;

@@ -244,10 +244,13 @@ _GGUF_FMT = {"u8": "<B", "i8": "<b", "u16": "<H", "i16": "<h", "u32": "<I", "i32
 
 
 def write_gguf(model: RawModel, path: str, version: int = 3, alignment: int = 32, write_alignment_key=None,
-               extra_kv=None, tensor_order=None) -> None:
+               extra_kv=None, tensor_order=None, data_start: str = "reference", pad_header_to_alignment: bool = False) -> None:
     """Serialize a RawModel as a llama-architecture GGUF file.  write_alignment_key: None = omit general.alignment
     (readers assume 32), or a value-type name ("u32", "u64", "i32", ...) to store `alignment` under that type.
-    extra_kv: list of (key, type_name, value); arrays as (key, "arr", (elem_type_name, [values]))."""
+    extra_kv: list of (key, type_name, value); arrays as (key, "arr", (elem_type_name, [values])).
+    data_start: "reference" = always skip to the NEXT multiple of the alignment (gguf.rs:722-724: a whole extra block when
+    the tensor infos already end aligned), "spec" = pad only when misaligned (llama.cpp / gguf-py writers).  The two differ
+    only when the header ends on a boundary; pad_header_to_alignment forces that case (a filler string key sized so)."""
     import struct
 
     s = model.shape
@@ -281,9 +284,24 @@ def write_gguf(model: RawModel, path: str, version: int = 3, alignment: int = 32
         kv.append(("general.alignment", write_alignment_key, alignment))
     kv += list(extra_kv or [])
     names = tensor_order or list(model.tensors.keys())
-    out = struct.pack("<II", 0x46554747, version) + wlen(len(names)) + wlen(len(kv))
-    for k, t, v in kv:
-        out += wstr(k) + struct.pack("<I", _GGUF_T[t]) + wval(t, v)
+
+    def header(kvs):
+        h = struct.pack("<II", 0x46554747, version) + wlen(len(names)) + wlen(len(kvs))
+        for k, t, v in kvs:
+            h += wstr(k) + struct.pack("<I", _GGUF_T[t]) + wval(t, v)
+        return h
+
+    def infos_len():
+        n = 0
+        for nm in names:
+            t = model.tensors[nm]
+            n += len(wstr(nm)) + 4 + len(t.shape) * (4 if version == 1 else 8) + 12
+        return n
+
+    if pad_header_to_alignment:  # a filler key whose string length makes header + tensor infos end on a boundary
+        base = len(header(kv + [("x.filler", "str", "")])) + infos_len()
+        kv.append(("x.filler", "str", "." * ((alignment - base % alignment) % alignment)))
+    out = header(kv)
     infos = b""
     off = 0
     offsets = []
@@ -297,7 +315,12 @@ def write_gguf(model: RawModel, path: str, version: int = 3, alignment: int = 32
         off += (len(t.data) + alignment - 1) // alignment * alignment
     out += infos
     pos = len(out)
-    pad = pos - (pos % alignment) + alignment - pos  # gguf.rs:722-724: a whole extra block when already aligned
+    if data_start == "spec":
+        pad = (alignment - pos % alignment) % alignment
+    else:
+        pad = pos - (pos % alignment) + alignment - pos  # gguf.rs:722-724: a whole extra block when already aligned
+    if pad_header_to_alignment:
+        assert pos % alignment == 0, pos
     with open(path, "wb") as f:
         f.write(out)
         f.write(b"\0" * pad)

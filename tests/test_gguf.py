@@ -263,3 +263,97 @@ def test_q4_k_m_recipe_layers_and_container_types(tmp_path):
         assert types[f"blk.{l}.attn_q.weight"] == synth.Q4_K and types[f"blk.{l}.ffn_up.weight"] == synth.Q4_K
         assert types[f"blk.{l}.attn_norm.weight"] == synth.F32
     assert types["output.weight"] == synth.Q6_K and types["token_embd.weight"] == synth.Q4_K
+
+
+# ---- robustness against crafted / unusual files -------------------------------------------------------------
+def test_deeply_nested_arrays_raise_instead_of_overflowing_the_stack(tmp_path):
+    """array-of-array-of-... 200k levels deep is 2.4 MB of file; the recursive reader used to die with SIGSEGV."""
+    head = struct.pack("<II", 0x46554747, 3) + struct.pack("<QQ", 0, 1)
+    key = b"x.deep"
+    body = struct.pack("<Q", len(key)) + key + struct.pack("<I", 9)  # value type: array
+    body += (struct.pack("<I", 9) + struct.pack("<Q", 1)) * 200000   # each level: elem type = array, length 1
+    body += struct.pack("<I", 0) + struct.pack("<Q", 0)
+    p = tmp_path / "deep.gguf"
+    p.write_bytes(head + body)
+    with pytest.raises(Exception) as ei:
+        ca.GGUFFile(str(p))
+    assert "nest" in str(ei.value)
+    # four levels are fine (real files nest at most once)
+    model = small_model()
+    path = str(tmp_path / "ok.gguf")
+    synth.write_gguf(model, path, extra_kv=[("x.n3", "arr", ("arr", [("arr", [("u8", [7])])]))])
+    assert ca.GGUFFile(path).metadata()["x.n3"] == [[[7]]]
+
+
+def test_array_length_is_bounded_by_the_bytes_that_are_left(tmp_path):
+    head = struct.pack("<II", 0x46554747, 3) + struct.pack("<QQ", 0, 1)
+    key = b"x.big"
+    body = struct.pack("<Q", len(key)) + key + struct.pack("<I", 9) + struct.pack("<I", 10) + struct.pack("<Q", 1 << 40)  # 2^40 u64s
+    p = tmp_path / "big.gguf"
+    p.write_bytes(head + body + b"\0" * 64)
+    with pytest.raises(Exception) as ei:
+        ca.GGUFFile(str(p))
+    assert "exceeds the file" in str(ei.value)
+
+
+def _evil_file(tmp_path):
+    """one F32 tensor whose dims (2^33, 2^33) multiply to 0 mod 2^64"""
+    name = b"evil.weight"
+    head = struct.pack("<II", 0x46554747, 3) + struct.pack("<QQ", 1, 1)
+    k = b"general.architecture"
+    head += struct.pack("<Q", len(k)) + k + struct.pack("<I", 8) + struct.pack("<Q", 5) + b"llama"
+    head += struct.pack("<Q", len(name)) + name + struct.pack("<I", 2) + struct.pack("<QQ", 1 << 33, 1 << 33) + struct.pack("<IQ", 0, 0)
+    pad = (32 - len(head) % 32) % 32
+    p = tmp_path / "evil.gguf"
+    p.write_bytes(head + b"\0" * pad + b"\0" * 64)
+    return str(p)
+
+
+def test_container_with_overflowing_dims_still_parses(tmp_path):
+    gf = ca.GGUFFile(_evil_file(tmp_path))  # the container itself is well formed; the tensor is refused at load time
+    assert gf.tensor_infos()[0][0] == "evil.weight"
+
+
+@pytest.mark.gpu
+def test_tensor_dims_whose_product_overflows_are_rejected_at_load(tmp_path):
+    gf = ca.GGUFFile(_evil_file(tmp_path))
+    dev = ca.HipTensorDevice(0)
+    with pytest.raises(Exception) as ei:
+        gf.load_tensor("evil.weight", dev)  # used to wrap to n = 0 and upload a 0-byte buffer carrying that shape
+    assert "overflow" in str(ei.value)
+    with pytest.raises(Exception) as ei:
+        ca.HipTensor.from_cpu(np.zeros(16, np.uint8), [1 << 33, 1 << 33], ca.GGMLType.F32, dev)  # the C ABI checks, too
+    assert "overflow" in str(ei.value)
+
+
+@pytest.mark.parametrize("convention", ["spec", "reference"])
+def test_header_that_ends_on_an_alignment_boundary(tmp_path, convention):
+    """1 file in `alignment` ends its tensor infos exactly on a boundary.  The reference then skips a whole extra block
+    (gguf.rs:722-724), the GGUF spec / llama.cpp writers do not pad at all: the reader resolves the case from the file
+    (the data section must end where the last tensor ends) and reads the right bytes under BOTH conventions."""
+    model = small_model()
+    path = str(tmp_path / f"aligned-{convention}.gguf")
+    synth.write_gguf(model, path, data_start=convention, pad_header_to_alignment=True)
+    gf = ca.GGUFFile(path)
+    assert gf.data_start_convention == (0 if convention == "spec" else 1)
+    for name, t in model.tensors.items():
+        assert gf.tensor_data(name)[:len(t.data)] == t.data.tobytes(), name
+    # the independent python reader of the tests follows the spec
+    if convention == "spec":
+        from tests.helpers import read_gguf_py
+
+        m2, _ = read_gguf_py(path)
+        for name, t in model.tensors.items():
+            assert np.array_equal(m2.tensors[name].data, t.data), name
+
+
+def test_mlock_flag_and_madvise(tmp_path):
+    model = small_model()
+    path = str(tmp_path / "m.gguf")
+    synth.write_gguf(model, path)
+    try:
+        gf = ca.GGUFFile(path, mlock=True)  # GGUFFileLoader::new(path, true) (gguf.rs:819-825)
+    except Exception as e:  # RLIMIT_MEMLOCK may forbid it in a container: the error must say so
+        assert "lock" in str(e)
+    else:
+        assert gf.load_config().n_layers == model.shape.n_layers

@@ -1,0 +1,635 @@
+// dma_lab.hip -- design lab (round 2): LDS-DMA weight streaming for the decode GEMV stages on MI355X (gfx950).
+//
+// Not part of the product.  Questions it answers by measurement (profiles/r02_dma_lab.log):
+//   Q1  does a GEMV whose waves stream their rows through a private LDS ring (global_load_lds_dwordx4, 1 KiB per
+//       wave-instruction, D chunks in flight per wave = 16 x D KiB per CU) beat the register-load GEMV at the decode
+//       shapes (wo 4096x4096, q|k|v 6144x4096, ffn_down 4096x14336, gate|up 28672x4096)?
+//   Q2  is an RMSNorm + Q8_0 quantizer prologue, repeated by every workgroup, hidden under that stream (the weights are
+//       requested before the activation is touched)?  If so the norm epilogue's in-launch hop can go.
+//   Q3  do two kernels launched with hipExtAnyOrderLaunch overlap on gfx950?
+//   Q4  LDS-DMA destinations beyond 64 KiB.
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o dma_lab tools/dma_lab.hip && ./dma_lab
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                                \
+  do {                                                                                       \
+    hipError_t e_ = (x);                                                                     \
+    if (e_ != hipSuccess) {                                                                  \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                               \
+    }                                                                                        \
+  } while (0)
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float h2f(unsigned short h) {
+  _Float16 x;
+  __builtin_memcpy(&x, &h, 2);
+  return (float)x;
+}
+__device__ __forceinline__ unsigned short f2h(float f) {
+  asm("" : "+v"(f));
+  _Float16 x = (_Float16)f;
+  unsigned short h;
+  __builtin_memcpy(&h, &x, 2);
+  return h;
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float rl_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float row16_sum_f32(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v = row16_sum_f32(v);
+  return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
+}
+__device__ __forceinline__ float row16_max_f32(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float half_max_f32(float v) {
+  v = row16_max_f32(v);
+  float lo = fmaxf(rl_f(v, 0), rl_f(v, 16)), hi = fmaxf(rl_f(v, 32), rl_f(v, 48));
+  return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ int row16_sum_i32(int v) {
+  v += dpp_i<0xB1>(v);
+  v += dpp_i<0x4E>(v);
+  v += dpp_i<0x141>(v);
+  v += dpp_i<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ int half_sum_i32(int v) {
+  v = row16_sum_i32(v);
+  int lo = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
+  int hi = __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+  return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ int dot_q4_0(i32x4 q, i32x4 xlo, i32x4 xhi, int xsum) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int w = q[i];
+    s = __builtin_amdgcn_sdot4(w & 0x0F0F0F0F, xlo[i], s, false);
+    s = __builtin_amdgcn_sdot4((w >> 4) & 0x0F0F0F0F, xhi[i], s, false);
+  }
+  return s - 8 * xsum;
+}
+
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; expcnt / lgkmcnt fields left at "no wait")
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void wait_vm_n(int n) {  // n is wave-uniform, 0..15
+  switch (n) {
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<1>(); break;
+    case 2: wait_vm<2>(); break;
+    case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;
+    case 6: wait_vm<6>(); break;
+    case 7: wait_vm<7>(); break;
+    case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;
+    case 10: wait_vm<10>(); break;
+    case 11: wait_vm<11>(); break;
+    case 12: wait_vm<12>(); break;
+    case 13: wait_vm<13>(); break;
+    case 14: wait_vm<14>(); break;
+    default: wait_vm<15>(); break;
+  }
+}
+// workgroup barrier that does NOT drain the LDS-DMA queue: __syncthreads() carries a workgroup release, which the
+// compiler lowers to s_waitcnt vmcnt(0) while global_load_lds requests are in flight (cdna_hip_programming.md section 3);
+// LDS stores of this wave are complete at lgkmcnt(0), DMA'd pieces are waited for by their issuer with a counted vmcnt
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// one wave-instruction of LDS-DMA: lane l copies 16 bytes from its own global address to lds_wave_base + 16 l
+__device__ __forceinline__ void dma16(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(gsrc_lane, LDSP(lds_wave_base), 16, 0, 0);
+}
+__device__ __forceinline__ void dma16_nt(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(gsrc_lane, LDSP(lds_wave_base), 16, 0, 2);  // aux = 2: nt
+}
+
+// =====================================================================================================================
+// V0: the register-load GEMV (production mapping, gemv.hip): 128-thread workgroups, R rows per wave, x from global
+// =====================================================================================================================
+template <int R>
+__global__ __launch_bounds__(128) void k_plain(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
+                                               const char* __restrict__ act, int off_d, int off_s, float* __restrict__ out, int m,
+                                               int nb) {
+  const i32x4* xq = (const i32x4*)act;
+  const unsigned short* xd = (const unsigned short*)(act + off_d);
+  const int* xs = (const int*)(act + off_s);
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 2 + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    i32x4 q[R];
+    unsigned short dw[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      size_t idx = (size_t)row * nb + b;
+      q[r] = __builtin_nontemporal_load(wq + idx);
+      dw[r] = __builtin_nontemporal_load(wd + idx);
+    }
+    i32x4 xlo = xq[2 * b], xhi = xq[2 * b + 1];
+    float dx = h2f(xd[b]);
+    int s = xs[b];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] += ((float)dot_q4_0(q[r], xlo, xhi, s) * h2f(dw[r])) * dx;
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
+// V0b: 256 workgroups x 1024 threads (the k_gemv_res_nq geometry): wave w of workgroup b owns rows b * rpw + w, + 16, ...
+// two units per row in flight, x from global
+__global__ __launch_bounds__(1024) void k_fat(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
+                                              const char* __restrict__ act, int off_d, int off_s, float* __restrict__ out, int m, int nb,
+                                              int rpw) {
+  const i32x4* xq = (const i32x4*)act;
+  const unsigned short* xd = (const unsigned short*)(act + off_d);
+  const int* xs = (const int*)(act + off_s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < rpw; j += 16) {
+    const int row = blockIdx.x * rpw + j;
+    if (row >= m) break;
+    float acc = 0.f;
+    for (int u = lane; u < nb; u += 128) {
+      const int u2 = u + 64 < nb ? u + 64 : u;
+      i32x4 qa = __builtin_nontemporal_load(wq + (size_t)row * nb + u);
+      i32x4 qb = __builtin_nontemporal_load(wq + (size_t)row * nb + u2);
+      unsigned short da = __builtin_nontemporal_load(wd + (size_t)row * nb + u);
+      unsigned short db = __builtin_nontemporal_load(wd + (size_t)row * nb + u2);
+      acc += ((float)dot_q4_0(qa, xq[2 * u], xq[2 * u + 1], xs[u]) * h2f(da)) * h2f(xd[u]);
+      if (u + 64 < nb) acc += ((float)dot_q4_0(qb, xq[2 * u2], xq[2 * u2 + 1], xs[u2]) * h2f(db)) * h2f(xd[u2]);
+    }
+    float s = wave_sum_f32(acc);
+    if (lane == 0) out[row] = s;
+  }
+}
+
+// =====================================================================================================================
+// V1: LDS-DMA ring.  256 workgroups x 1024 threads, one per CU.  Wave w owns rows b * rpw + w, + 16, ... ; its weight
+// stream is the sequence of 1 KiB chunks (64 units) of those rows; D chunks are kept in flight in the wave's private ring
+// (each lane reads back exactly the 16 bytes it requested: no barrier, only vmcnt).  The rows' f16 scales are requested
+// first (one masked wave-instruction per row).  The activation planes arrive by DMA as well (all VMEM traffic of the
+// kernel is LDS-DMA, so every s_waitcnt vmcnt is written by hand and exact).
+// MODE 0: x = Q8_0 planes (q | d | isum) from global.  MODE 1: x = f32 row; every workgroup runs RMSNorm * weight +
+// the truncating Q8_0 quantizer itself (the k_norm_quant arithmetic, fast-mode chunk sums), under the weight stream.
+// =====================================================================================================================
+struct DmaArgs {
+  const i32x4* wq;
+  const unsigned short* wd;
+  const char* act;   // MODE 0: planes;  MODE 1: f32 x
+  const float* wn;   // MODE 1: norm weights
+  int off_d, off_s;  // plane offsets (bytes), also the LDS layout of the planes
+  int act_bytes;     // MODE 0: total bytes of the planes (multiple of 16)
+  float* out;
+  int m, nb, rpw;    // rows, blocks per row, rows per workgroup
+  float eps;
+  int nt;
+};
+
+template <int D, int MODE>
+__global__ __launch_bounds__(1024) void k_dma(DmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = a.nb, nc = nb >> 6;  // chunks per row
+  const int k = nb * 32;
+  // LDS map: [planes: k + ...][f32 x (MODE 1): 4 k][chunk sums: k/32 * 4][per wave: scales rows_w * nb * 2 | ring D KiB]
+  const int planes_bytes = a.off_s + nb * 4;
+  unsigned char* P = lds;
+  float* XF = (float*)(lds + ((planes_bytes + 255) & ~255));
+  float* WN = XF + (MODE == 1 ? k : 0);
+  float* CS = WN + (MODE == 1 ? k : 0);
+  unsigned char* WB = (unsigned char*)(CS + (MODE == 1 ? nb : 0));
+  const int rows_w_max = (a.rpw + 15) >> 4;
+  const int scale_bytes = ((rows_w_max * nb * 2) + 255) & ~255;
+  unsigned char* my = WB + (size_t)wave * (scale_bytes + D * 1024);
+  unsigned short* SD = (unsigned short*)my;
+  unsigned char* RING = my + scale_bytes;
+
+  // ---- this wave's rows
+  int nrows = 0;
+  for (int j = wave; j < a.rpw; j += 16)
+    if (blockIdx.x * a.rpw + j < a.m) nrows++;
+  const int T = nrows * nc;
+  int n_issued_vm = 0;  // VMEM ops this wave has issued so far (wave-uniform)
+
+  // ---- 1. the activation goes first (oldest requests)
+  if (MODE == 0) {
+    const int npieces = (a.act_bytes + 1023) >> 10;
+    for (int p = wave; p < npieces; p += 16) {
+      const int off = p * 1024 + lane * 16;
+      if (off < a.act_bytes) dma16(a.act + off, P + p * 1024);
+      n_issued_vm++;
+    }
+  } else {
+    const int npieces = (k * 4) >> 10;
+    for (int p = wave; p < npieces; p += 16) {
+      dma16(a.act + p * 1024 + lane * 16, (unsigned char*)XF + p * 1024);
+      dma16((const char*)a.wn + p * 1024 + lane * 16, (unsigned char*)WN + p * 1024);
+      n_issued_vm += 2;
+    }
+  }
+  const int n_act_vm = n_issued_vm;
+  // ---- 2. scales of all my rows, then the first D chunks
+  for (int r = 0; r < nrows; r++) {
+    const size_t row = (size_t)blockIdx.x * a.rpw + wave + 16 * r;
+    if (lane * 8 < nb) dma16((const char*)(a.wd + row * nb) + lane * 16, (unsigned char*)(SD + r * nb));
+    n_issued_vm++;
+  }
+  auto issue = [&](int t) {
+    const int r = t / nc, c = t - r * nc;
+    const size_t row = (size_t)blockIdx.x * a.rpw + wave + 16 * r;
+    const i32x4* src = a.wq + row * nb + c * 64 + lane;
+    if (a.nt)
+      dma16_nt(src, RING + (t % D) * 1024);
+    else
+      dma16(src, RING + (t % D) * 1024);
+  };
+  const int pre = T < D ? T : D;
+  for (int t = 0; t < pre; t++) issue(t);
+  n_issued_vm += pre;
+
+  // ---- 3. wait for the activation (everything issued after it may still be in flight), make it visible to the workgroup
+  wait_vm_n(n_issued_vm - n_act_vm > 15 ? 15 : n_issued_vm - n_act_vm);
+  wg_barrier();
+  if (MODE == 1) {
+    // RMSNorm (rms_norm.rs:33-46, fast-mode chunk = 16 + 16 halves) * weight -> truncating Q8_0 (buf_q8_0.rs:87-134)
+    __shared__ float s_rms;
+    for (int c = tid; c < nb; c += 1024) {
+      const f32x4* p = (const f32x4*)(XF + c * 32);
+      float s = -0.0f, s1 = -0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        f32x4 t = p[j];
+        float& ac = j >= 4 ? s1 : s;
+        ac += t[0] * t[0];
+        ac += t[1] * t[1];
+        ac += t[2] * t[2];
+        ac += t[3] * t[3];
+      }
+      CS[c] = s + s1;
+    }
+    wg_barrier();
+    if (tid < 64) {
+      float sum = 0.0f;
+      for (int base = 0; base < nb; base += 64) {
+        float v = base + tid < nb ? CS[base + tid] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
+      }
+      if (tid == 0) s_rms = sqrtf(sum / (float)k + a.eps);
+    }
+    wg_barrier();
+    const float rms = s_rms;
+    for (int i = tid; i < k; i += 1024) {  // k % 1024 == 0 here: every 32-lane half is one block
+      const float v = (XF[i] / rms) * WN[i];
+      const float amax = half_max_f32(fabsf(v));
+      const float dd = amax / 127.0f;
+      const float qf = v / dd;
+      int qi = (qf != qf) ? 0 : (int)qf;
+      const signed char q = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+      const int sum = half_sum_i32((int)q);
+      ((signed char*)P)[i] = q;
+      if ((tid & 31) == 0) {
+        ((unsigned short*)(P + a.off_d))[i >> 5] = f2h(dd);
+        ((int*)(P + a.off_s))[i >> 5] = sum;
+      }
+    }
+    wg_barrier();
+  }
+  const i32x4* xq = (const i32x4*)P;
+  const unsigned short* xd = (const unsigned short*)(P + a.off_d);
+  const int* xs = (const int*)(P + a.off_s);
+
+  // ---- 4. consume the ring in order, refilling behind
+  float acc = 0.f;
+  for (int t = 0; t < T; t++) {
+    const int younger = (T - 1 - t) < (D - 1) ? (T - 1 - t) : (D - 1);  // chunk DMAs issued after chunk t
+    wait_vm_n(younger);
+    const int r = t / nc, c = t - r * nc;
+    const int u = c * 64 + lane;
+    const i32x4 q = *(const i32x4*)(RING + (t % D) * 1024 + lane * 16);
+    const unsigned short dw = SD[r * nb + u];
+    acc += ((float)dot_q4_0(q, xq[2 * u], xq[2 * u + 1], xs[u]) * h2f(dw)) * h2f(xd[u]);
+    if (t + D < T) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read before it is overwritten
+      issue(t + D);
+    }
+    if (c == nc - 1) {
+      const float s = wave_sum_f32(acc);
+      if (lane == 0) a.out[(size_t)blockIdx.x * a.rpw + wave + 16 * r] = s;
+      acc = 0.f;
+    }
+  }
+}
+
+// =====================================================================================================================
+// Q3: any-order launch.  A spins (bounded) until B's flag store becomes visible.
+// =====================================================================================================================
+__global__ void k_spin(int* flag, int* seen, long long max_cycles) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = __builtin_readcyclecounter();
+  int v = 0;
+  while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+    if (__builtin_readcyclecounter() - t0 > max_cycles) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  seen[blockIdx.x] = v;
+}
+__global__ void k_set(int* flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Q4: DMA to a high LDS address
+__global__ __launch_bounds__(64) void k_dma_high(const i32x4* src, i32x4* dst, int lds_off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  dma16(src + threadIdx.x, lds + lds_off);
+  wait_vm<0>();
+  dst[threadIdx.x] = *(const i32x4*)(lds + lds_off + threadIdx.x * 16);
+}
+
+// =====================================================================================================================
+// host
+// =====================================================================================================================
+static uint32_t rng_state = 12345;
+static uint32_t rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 17;
+  rng_state ^= rng_state << 5;
+  return rng_state;
+}
+static uint16_t f2h_host(float f) {
+  _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+static float h2f_host(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Shape {
+  const char* name;
+  int m, k;
+};
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  printf("# device %s CUs=%d maxLDS/block=%zu\n", prop.gcnArchName, prop.multiProcessorCount, (size_t)prop.sharedMemPerBlock);
+  hipStream_t st;
+  CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+
+  // ---- Q4
+  {
+    std::vector<int> h(256);
+    for (int i = 0; i < 256; i++) h[i] = i * 7 + 1;
+    int *s, *d;
+    CK(hipMalloc(&s, 1024));
+    CK(hipMalloc(&d, 1024));
+    CK(hipMemcpy(s, h.data(), 1024, hipMemcpyHostToDevice));
+    for (int off : {0, 60 * 1024, 100 * 1024, 150 * 1024}) {
+      CK(hipMemset(d, 0, 1024));
+      CK(hipFuncSetAttribute((const void*)k_dma_high, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      k_dma_high<<<1, 64, 160 * 1024, st>>>((const i32x4*)s, (i32x4*)d, off);
+      CK(hipStreamSynchronize(st));
+      std::vector<int> g(256);
+      CK(hipMemcpy(g.data(), d, 1024, hipMemcpyDeviceToHost));
+      printf("Q4 dma to lds offset %6d: %s\n", off, memcmp(g.data(), h.data(), 1024) == 0 ? "ok" : "WRONG");
+    }
+  }
+  // ---- Q3
+  {
+    int *flag, *seen;
+    CK(hipMalloc(&flag, 4));
+    CK(hipMalloc(&seen, 256 * 4));
+    for (int mode = 0; mode < 2; mode++) {
+      CK(hipMemset(flag, 0, 4));
+      CK(hipMemset(seen, 0xff, 256 * 4));
+      CK(hipStreamSynchronize(st));
+      hipExtLaunchKernelGGL(k_spin, dim3(256), dim3(64), 0, st, nullptr, nullptr, 0, flag, seen, (long long)2400 * 300);  // <= 300 us
+      hipExtLaunchKernelGGL(k_set, dim3(1), dim3(64), 0, st, nullptr, nullptr, mode ? hipExtAnyOrderLaunch : 0, flag);
+      hipError_t e = hipStreamSynchronize(st);
+      std::vector<int> g(256);
+      CK(hipMemcpy(g.data(), seen, 1024, hipMemcpyDeviceToHost));
+      int n1 = 0;
+      for (int v : g) n1 += v == 1;
+      printf("Q3 spin-then-set, second launch flags=%s: %d of 256 spinners saw the flag (launch status %s)\n", mode ? "AnyOrder" : "0", n1,
+             hipGetErrorString(e));
+    }
+  }
+
+  // ---- GEMV variants
+  const Shape shapes[] = {{"wo 4096x4096", 4096, 4096}, {"qkv 6144x4096", 6144, 4096}, {"down 4096x14336", 4096, 14336},
+                          {"gate|up 28672x4096", 28672, 4096}};
+  const size_t POOL = (size_t)720 << 20;
+  char* pool;
+  CK(hipMalloc(&pool, POOL));
+  for (const Shape& sh : shapes) {
+    const int m = sh.m, k = sh.k, nb = k / 32;
+    const size_t qbytes = (size_t)m * nb * 16, dbytes = (size_t)m * nb * 2;
+    const size_t copy_bytes = align_up(qbytes, 4096) + align_up(dbytes, 4096);
+    const int ncopies = (int)std::min<size_t>(64, POOL / copy_bytes);
+    // host weights (one copy, replicated)
+    std::vector<uint32_t> hq(qbytes / 4);
+    for (auto& v : hq) v = rnd();
+    std::vector<uint16_t> hd((size_t)m * nb);
+    for (auto& v : hd) v = f2h_host(2e-3f + (rnd() % 1000) * 1.8e-5f);
+    for (int c = 0; c < ncopies; c++) {
+      CK(hipMemcpy(pool + c * copy_bytes, hq.data(), qbytes, hipMemcpyHostToDevice));
+      CK(hipMemcpy(pool + c * copy_bytes + align_up(qbytes, 4096), hd.data(), dbytes, hipMemcpyHostToDevice));
+    }
+    // activation: f32 x, norm weights, and the host-side norm + quantizer (same arithmetic as the device prologue)
+    std::vector<float> x(k), wn(k);
+    for (int i = 0; i < k; i++) {
+      x[i] = ((int)(rnd() % 20001) - 10000) * 1e-4f;
+      wn[i] = 1.0f + ((int)(rnd() % 201) - 100) * 1e-4f;
+    }
+    const float eps = 1e-5f;
+    std::vector<float> xn(k);
+    {
+      float sum = 0.0f;
+      for (int c = 0; c < nb; c++) {
+        float s = -0.0f, s1 = -0.0f;
+        for (int j = 0; j < 32; j++) (j >= 16 ? s1 : s) += x[c * 32 + j] * x[c * 32 + j];
+        sum += s + s1;
+      }
+      const float rms = sqrtf(sum / (float)k + eps);
+      for (int i = 0; i < k; i++) xn[i] = (x[i] / rms) * wn[i];
+    }
+    const int off_d = (int)align_up(k, 256), off_s = off_d + (int)align_up(nb * 2, 256);
+    const int act_bytes = off_s + nb * 4;
+    std::vector<char> planes(align_up(act_bytes, 1024), 0);
+    for (int b = 0; b < nb; b++) {
+      float amax = 0.f;
+      for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(xn[b * 32 + j]));
+      const float dd = amax / 127.0f;
+      int s = 0;
+      for (int j = 0; j < 32; j++) {
+        const float qf = xn[b * 32 + j] / dd;
+        int qi = (qf != qf) ? 0 : (int)qf;
+        planes[b * 32 + j] = (char)(signed char)qi;
+        s += (signed char)qi;
+      }
+      ((uint16_t*)(planes.data() + off_d))[b] = f2h_host(dd);
+      ((int*)(planes.data() + off_s))[b] = s;
+    }
+    // host reference (double)
+    std::vector<double> ref(m);
+    for (int r = 0; r < m; r++) {
+      double acc = 0;
+      for (int b = 0; b < nb; b++) {
+        const uint8_t* q = (const uint8_t*)hq.data() + ((size_t)r * nb + b) * 16;
+        int si = 0;
+        for (int j = 0; j < 16; j++) {
+          si += ((int)(q[j] & 15) - 8) * (int)(signed char)planes[b * 32 + j];
+          si += ((int)(q[j] >> 4) - 8) * (int)(signed char)planes[b * 32 + j + 16];
+        }
+        acc += (double)si * h2f_host(hd[(size_t)r * nb + b]) * h2f_host(((uint16_t*)(planes.data() + off_d))[b]);
+      }
+      ref[r] = acc;
+    }
+    char *d_planes, *d_xf, *d_wn;
+    float* d_out;
+    CK(hipMalloc(&d_planes, planes.size()));
+    CK(hipMalloc(&d_xf, (size_t)k * 4));
+    CK(hipMalloc(&d_wn, (size_t)k * 4));
+    CK(hipMalloc(&d_out, (size_t)m * 4));
+    CK(hipMemcpy(d_planes, planes.data(), planes.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_xf, x.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_wn, wn.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+
+    auto check = [&]() -> double {
+      std::vector<float> o(m);
+      CK(hipMemcpy(o.data(), d_out, (size_t)m * 4, hipMemcpyDeviceToHost));
+      double worst = 0;
+      for (int r = 0; r < m; r++) worst = fmax(worst, fabs(o[r] - ref[r]) / (fabs(ref[r]) + 1.0));
+      return worst;
+    };
+    const double MB = (qbytes + dbytes) / 1e6;
+    auto bench = [&](const char* label, auto launch) {
+      CK(hipMemset(d_out, 0, (size_t)m * 4));
+      launch(0);
+      hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess) {
+        printf("%-22s %-44s launch failed: %s\n", sh.name, label, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return;
+      }
+      const double err = check();
+      const int N = 240;
+      for (int i = 0; i < 16; i++) launch(i % ncopies);
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      double best = 1e30;
+      for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < N; i++) launch((i + 1) % ncopies);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = fmin(best, ms * 1e3 / N);
+      }
+      printf("%-22s %-44s %7.2f us/launch  %7.1f GB/s  %s (maxrel %.1e)\n", sh.name, label, best, MB / best * 1e3,
+             err < 1e-4 ? "ok" : "WRONG", err);
+      fflush(stdout);
+    };
+    auto wq_of = [&](int c) { return (const i32x4*)(pool + (size_t)c * copy_bytes); };
+    auto wd_of = [&](int c) { return (const unsigned short*)(pool + (size_t)c * copy_bytes + align_up(qbytes, 4096)); };
+
+    bench("plain R=1 tpb=128 (regs)", [&](int c) {
+      k_plain<1><<<(m + 1) / 2, 128, 0, st>>>(wq_of(c), wd_of(c), d_planes, off_d, off_s, d_out, m, nb);
+    });
+    bench("plain R=2 tpb=128 (regs)", [&](int c) {
+      k_plain<2><<<((m + 1) / 2 + 1) / 2, 128, 0, st>>>(wq_of(c), wd_of(c), d_planes, off_d, off_s, d_out, m, nb);
+    });
+    const int rpw = (m + 255) / 256;
+    bench("fat 256x1024 (regs, 2 units in flight)", [&](int c) {
+      k_fat<<<256, 1024, 0, st>>>(wq_of(c), wd_of(c), d_planes, off_d, off_s, d_out, m, nb, rpw);
+    });
+    auto lds_bytes = [&](int D, int mode) {
+      const int planes_b = (int)align_up(off_s + nb * 4, 256);
+      const int rows_w_max = (rpw + 15) / 16;
+      const int scale_b = (int)align_up((size_t)rows_w_max * nb * 2, 256);
+      return (size_t)planes_b + (mode ? (size_t)k * 8 + nb * 4 : 0) + 16 * ((size_t)scale_b + D * 1024);
+    };
+    auto run_dma = [&](auto kern, int D, int mode, int nt, const char* label) {
+      const size_t lb = lds_bytes(D, mode);
+      if (lb > 160 * 1024) {
+        printf("%-22s %-44s skipped: %zu bytes of LDS\n", sh.name, label, lb);
+        return;
+      }
+      CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      bench(label, [&](int c) {
+        DmaArgs a{wq_of(c), wd_of(c), mode ? d_xf : d_planes, (const float*)d_wn, off_d, off_s, (int)align_up(act_bytes, 16), d_out, m, nb, rpw, eps, nt};
+        kern<<<256, 1024, lb, st>>>(a);
+      });
+    };
+    run_dma(k_dma<4, 0>, 4, 0, 0, "dma ring D=4  planes");
+    run_dma(k_dma<7, 0>, 7, 0, 0, "dma ring D=7  planes");
+    run_dma(k_dma<7, 0>, 7, 0, 1, "dma ring D=7  planes nt");
+    run_dma(k_dma<8, 0>, 8, 0, 1, "dma ring D=8  planes nt");
+    if (k <= 4096) {
+      run_dma(k_dma<4, 1>, 4, 1, 1, "dma ring D=4  f32 x: norm+quant prologue nt");
+      run_dma(k_dma<5, 1>, 5, 1, 1, "dma ring D=5  f32 x: norm+quant prologue nt");
+      run_dma(k_dma<7, 1>, 7, 1, 1, "dma ring D=7  f32 x: norm+quant prologue nt");
+    }
+    CK(hipFree(d_planes));
+    CK(hipFree(d_xf));
+    CK(hipFree(d_wn));
+    CK(hipFree(d_out));
+  }
+  return 0;
+}
