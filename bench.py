@@ -439,7 +439,7 @@ def main():
         n_prof = min(args.steps, 16)
         if path == "fused":
             eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch,
-                                      norm_epilogue=not args.no_norm_epilogue)
+                                      norm_epilogue=not args.no_norm_epilogue, extra_flags=args.flags)
             eager.decode_greedy(1, 4)  # warm
             dev.sync()
             dev.prof_enable(True)
