@@ -52,8 +52,11 @@ GEMV_REL = 2e-5  # f32 re-association bound factor: |gpu - oracle| <= GEMV_REL *
 # (Q8_0 / Q8_1 rhs: buf_q8_0.rs:119-124) amplify 1-ulp GEMV differences into +-1 quant flips -- the reference's own
 # scalar-vs-AVX2 spread on Q8_0 models is 1.5-2.7e-2 (tests/test_oracle_runner.py) --, the K-quants round to nearest
 # (buf_q8_k.rs:84-131), F32 / F16 weights have no activation quantizer at all.
-FAST_TOL = {"Q4_0": (3e-2, 1e-1), "Q8_0": (3e-2, 1e-1), "Q4_1": (3e-2, 1e-1), "Q4_K": (3e-2, 1e-1), "Q6_K": (3e-2, 1e-1),
-            "Q8_K": (3e-2, 1e-1), "F32": (1e-4, 1e-3), "F16": (1e-4, 1e-3)}
+# Observed on MI355X (round 2, tests/golden/fast_path_errors_observed.json), worst (median, max) over all test models:
+#   Q4_0 3.0e-3 / 7.5e-3   Q8_0 2.7e-2 / 3.7e-2   Q4_1 4.1e-4 / 5.1e-4   Q4_K, Q6_K, Q8_K 1.9e-7 / 2.8e-7
+#   F32 1.1e-4 / 2.6e-4    F16 4.1e-4 / 5.6e-4     (full 8B shape, Q4_0 and Q4_K: 6e-5 / 5e-4, tests/test_hip_headline.py)
+FAST_TOL = {"Q4_0": (1e-2, 2.5e-2), "Q8_0": (6e-2, 1e-1), "Q4_1": (1.5e-3, 2e-3), "Q4_K": (1e-6, 2e-6), "Q6_K": (1e-6, 2e-6),
+            "Q8_K": (1e-6, 2e-6), "F32": (5e-4, 1e-3), "F16": (1.5e-3, 2e-3)}
 _OBSERVED = {}
 
 

@@ -25,9 +25,10 @@ pytestmark = pytest.mark.gpu
 
 TOKENS = [1, 365, 400, 282, 9906]  # teacher-forced positions 0..4
 SEQ = 32
-# max over the steps of max|hip - oracle| / max|oracle logit| that the FAST path may show, per weight format: ~4x the
-# largest value observed on MI355X for this seed (recorded by the test itself in gpurun_out/headline_parity.json)
-FAST_TOL = {"Q4_0": 2e-2, "Q4_K": 2e-2}
+# max over the steps of max|hip - oracle| / max|oracle logit| that the FAST path may show, per weight format: 4x the
+# largest value observed on MI355X for this seed (4.9e-4 for Q4_0, 5.0e-4 for Q4_K; the test records what it sees in
+# gpurun_out/headline_parity.json, last committed copy: tests/golden/headline_parity_observed.json)
+FAST_TOL = {"Q4_0": 2e-3, "Q4_K": 2e-3}
 _RESULTS = {}
 
 

@@ -372,6 +372,113 @@ __global__ __launch_bounds__(1024) void k_dma(DmaArgs a) {
 }
 
 // =====================================================================================================================
+// V2: register prefetch + redundant prologue.  256 x 1024; the f32 x row and the norm weights are requested first, then
+// ALL of the wave's weight units (ROWS rows x 2 units per lane for k = 4096) -- plain loads, so the compiler's own
+// vmcnt(N) lets the prologue run on x while the weights are still in flight.  MODE 1: RMSNorm + quantize prologue
+// (every workgroup repeats it); MODE 0: the planes come from global memory (no prologue), for the A/B.
+// =====================================================================================================================
+template <int ROWS, int MODE>
+__global__ __launch_bounds__(1024) void k_regs(DmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __shared__ float s_rms;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = a.nb, k = nb * 32;  // k == 4096: two units per lane and row
+  unsigned char* P = lds;
+  float* XF = (float*)(lds + ((a.off_s + nb * 4 + 255) & ~255));
+  float* CS = XF + k;
+  float xv[4], wv[4];
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      xv[j] = ((const float*)a.act)[tid + 1024 * j];
+      wv[j] = a.wn[tid + 1024 * j];
+    }
+  }
+  i32x4 q[ROWS][2];
+  unsigned short dw[ROWS][2];
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const int j = wave + 16 * r;
+    const size_t row = (size_t)blockIdx.x * a.rpw + (j < a.rpw ? j : wave);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      q[r][c] = __builtin_nontemporal_load(a.wq + row * nb + c * 64 + lane);
+      dw[r][c] = __builtin_nontemporal_load(a.wd + row * nb + c * 64 + lane);
+    }
+  }
+  const i32x4* xq;
+  const unsigned short* xd;
+  const int* xs;
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) XF[tid + 1024 * j] = xv[j];
+    __syncthreads();
+    for (int c = tid; c < nb; c += 1024) {
+      const f32x4* p = (const f32x4*)(XF + c * 32);
+      float s = -0.0f, s1 = -0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        f32x4 t = p[j];
+        float& ac = j >= 4 ? s1 : s;
+        ac += t[0] * t[0];
+        ac += t[1] * t[1];
+        ac += t[2] * t[2];
+        ac += t[3] * t[3];
+      }
+      CS[c] = s + s1;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float sum = 0.0f;
+      for (int base = 0; base < nb; base += 64) {
+        float v = base + tid < nb ? CS[base + tid] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
+      }
+      if (tid == 0) s_rms = sqrtf(sum / (float)k + a.eps);
+    }
+    __syncthreads();
+    const float rms = s_rms;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = tid + 1024 * j;
+      const float v = (xv[j] / rms) * wv[j];
+      const float amax = half_max_f32(fabsf(v));
+      const float dd = amax / 127.0f;
+      const float qf = v / dd;
+      int qi = (qf != qf) ? 0 : (int)qf;
+      const signed char qq = (signed char)(unsigned char)((unsigned)qi & 0xffu);
+      const int sum = half_sum_i32((int)qq);
+      ((signed char*)P)[i] = qq;
+      if ((tid & 31) == 0) {
+        ((unsigned short*)(P + a.off_d))[i >> 5] = f2h(dd);
+        ((int*)(P + a.off_s))[i >> 5] = sum;
+      }
+    }
+    __syncthreads();
+    xq = (const i32x4*)P;
+    xd = (const unsigned short*)(P + a.off_d);
+    xs = (const int*)(P + a.off_s);
+  } else {
+    xq = (const i32x4*)a.act;
+    xd = (const unsigned short*)(a.act + a.off_d);
+    xs = (const int*)(a.act + a.off_s);
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const int j = wave + 16 * r;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int u = c * 64 + lane;
+      acc += ((float)dot_q4_0(q[r][c], xq[2 * u], xq[2 * u + 1], xs[u]) * h2f(dw[r][c])) * h2f(xd[u]);
+    }
+    const float s = wave_sum_f32(acc);
+    if (lane == 0 && j < a.rpw) a.out[(size_t)blockIdx.x * a.rpw + j] = s;
+  }
+}
+
+// =====================================================================================================================
 // Q3: any-order launch.  A spins (bounded) until B's flag store becomes visible.
 // =====================================================================================================================
 __global__ void k_spin(int* flag, int* seen, long long max_cycles) {
@@ -448,24 +555,46 @@ int main(int argc, char** argv) {
       printf("Q4 dma to lds offset %6d: %s\n", off, memcmp(g.data(), h.data(), 1024) == 0 ? "ok" : "WRONG");
     }
   }
-  // ---- Q3
+  // ---- Q3: any-order launch.  A = 256 spinners (<= 200 us each), B = one store.  Everything on `st`.
   {
     int *flag, *seen;
     CK(hipMalloc(&flag, 4));
     CK(hipMalloc(&seen, 256 * 4));
-    for (int mode = 0; mode < 2; mode++) {
-      CK(hipMemset(flag, 0, 4));
-      CK(hipMemset(seen, 0xff, 256 * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto run_pair = [&](unsigned fl) {
+      hipExtLaunchKernelGGL(k_spin, dim3(256), dim3(64), 0, st, nullptr, nullptr, 0, flag, seen, (long long)2400 * 200);
+      hipExtLaunchKernelGGL(k_set, dim3(1), dim3(64), 0, st, nullptr, nullptr, fl, flag);
+    };
+    for (int mode = 0; mode < 3; mode++) {
+      CK(hipMemsetAsync(flag, 0, 4, st));
+      CK(hipMemsetAsync(seen, 0xff, 256 * 4, st));
       CK(hipStreamSynchronize(st));
-      hipExtLaunchKernelGGL(k_spin, dim3(256), dim3(64), 0, st, nullptr, nullptr, 0, flag, seen, (long long)2400 * 300);  // <= 300 us
-      hipExtLaunchKernelGGL(k_set, dim3(1), dim3(64), 0, st, nullptr, nullptr, mode ? hipExtAnyOrderLaunch : 0, flag);
+      const char* what = mode == 0 ? "flags=0" : mode == 1 ? "AnyOrder" : "AnyOrder, captured into a hipGraph";
+      float ms = 0.f;
+      if (mode < 2) {
+        CK(hipEventRecord(e0, st));
+        run_pair(mode ? hipExtAnyOrderLaunch : 0);
+        CK(hipEventRecord(e1, st));
+      } else {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        run_pair(hipExtAnyOrderLaunch);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipEventRecord(e0, st));
+        CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e1, st));
+      }
       hipError_t e = hipStreamSynchronize(st);
+      CK(hipEventElapsedTime(&ms, e0, e1));
       std::vector<int> g(256);
       CK(hipMemcpy(g.data(), seen, 1024, hipMemcpyDeviceToHost));
       int n1 = 0;
       for (int v : g) n1 += v == 1;
-      printf("Q3 spin-then-set, second launch flags=%s: %d of 256 spinners saw the flag (launch status %s)\n", mode ? "AnyOrder" : "0", n1,
-             hipGetErrorString(e));
+      printf("Q3 spin-then-set (%s): %d of 256 spinners saw the flag, pair took %.1f us (%s)\n", what, n1, ms * 1e3, hipGetErrorString(e));
     }
   }
 
@@ -607,11 +736,11 @@ int main(int argc, char** argv) {
     };
     auto run_dma = [&](auto kern, int D, int mode, int nt, const char* label) {
       const size_t lb = lds_bytes(D, mode);
-      if (lb > 160 * 1024) {
+      if (lb > 160 * 1024 - 64) {
         printf("%-22s %-44s skipped: %zu bytes of LDS\n", sh.name, label, lb);
         return;
       }
-      CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
       bench(label, [&](int c) {
         DmaArgs a{wq_of(c), wd_of(c), mode ? d_xf : d_planes, (const float*)d_wn, off_d, off_s, (int)align_up(act_bytes, 16), d_out, m, nb, rpw, eps, nt};
         kern<<<256, 1024, lb, st>>>(a);
@@ -621,6 +750,25 @@ int main(int argc, char** argv) {
     run_dma(k_dma<7, 0>, 7, 0, 0, "dma ring D=7  planes");
     run_dma(k_dma<7, 0>, 7, 0, 1, "dma ring D=7  planes nt");
     run_dma(k_dma<8, 0>, 8, 0, 1, "dma ring D=8  planes nt");
+    if (k == 4096) {
+      auto run_regs = [&](auto kern, int mode, const char* label) {
+        const size_t lb = align_up(off_s + nb * 4, 256) + (size_t)k * 4 + nb * 4;
+        bench(label, [&](int c) {
+          DmaArgs a{wq_of(c), wd_of(c), mode ? d_xf : d_planes, (const float*)d_wn, off_d, off_s, (int)align_up(act_bytes, 16), d_out, m, nb, rpw, eps, 1};
+          kern<<<256, 1024, lb, st>>>(a);
+        });
+      };
+      if (rpw <= 16) {
+        run_regs(k_regs<1, 0>, 0, "regs all-in-flight 256x1024  planes");
+        run_regs(k_regs<1, 1>, 1, "regs all-in-flight 256x1024  norm+quant prologue");
+      } else if (rpw <= 32) {
+        run_regs(k_regs<2, 0>, 0, "regs all-in-flight 256x1024  planes");
+        run_regs(k_regs<2, 1>, 1, "regs all-in-flight 256x1024  norm+quant prologue");
+      } else {
+        run_regs(k_regs<7, 0>, 0, "regs all-in-flight 256x1024  planes");
+        run_regs(k_regs<7, 1>, 1, "regs all-in-flight 256x1024  norm+quant prologue");
+      }
+    }
     if (k <= 4096) {
       run_dma(k_dma<4, 1>, 4, 1, 1, "dma ring D=4  f32 x: norm+quant prologue nt");
       run_dma(k_dma<5, 1>, 5, 1, 1, "dma ring D=5  f32 x: norm+quant prologue nt");
