@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--tp", action="store_true",
                     help="WORLD_SIZE > 1: the ranks form ONE tensor-parallel group (RCCL all-reduce after wo / ffn_down) that "
                          "decodes a single token stream, instead of independent replicas; meant for --model llama3-70b")
+    ap.add_argument("--tp-rccl", action="store_true",
+                    help="with --tp: all-reduce through RCCL (ncclAllReduce per segment, the baseline) instead of the one-shot "
+                         "P2P collective fused into the wo / ffn_down kernels")
     ap.add_argument("--tp-dry", type=int, default=0,
                     help="measure ONE rank of a tensor-parallel group of this size with its all-reduces skipped "
                          "(per-rank kernel time; not a tokens/s result)")
@@ -271,7 +274,10 @@ def tp_dry_run(args, ca, synth, local):
         "rank_weight_bytes_per_token": local_bytes,
         "rank_effective_GBps": round(local_bytes / ms / 1e6, 1),
         "all_reduces_per_token": 2 * conf.n_layers, "all_reduce_bytes": shape.dim * 4,
-        "note": "not tokens/s: add 2 x n_layers all-reduces of dim x 4 bytes over xGMI (not measurable on one GPU)",
+        "launches_per_layer": 5,
+        "note": "not tokens/s: the rank runs the fused-collective layer (5 launches: q|k|v, attention, wo + exchange + norm, gate|up, "
+                "down + exchange + norm) with the exchange itself skipped; add 2 x n_layers one-shot exchanges of dim x 8 bytes "
+                "per peer over xGMI (not measurable on one GPU)",
     }))
 
 
@@ -288,7 +294,10 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
     model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=world)
     dev = ca.HipTensorDevice(device_ordinal=local)
     conf, weights = synth.to_hip(model, dev)
-    comm = tp_mod.init_tp_comm(dev, rank, world, tp_mod.torch_broadcast(rank))
+    if args.tp_rccl:
+        comm = tp_mod.init_tp_comm(dev, rank, world, tp_mod.torch_broadcast(rank))
+    else:  # the production collective: peers' inboxes mapped over hipIpc (xGMI between GPUs), no RCCL on the data path
+        comm = tp_mod.init_tp_p2p(dev, rank, world, shape.dim, tp_mod.torch_all_gather(world))
     seq_len = args.warmup + args.steps + 16
     r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=world, tp_rank=rank, comm=comm,
                           extra_flags=args.flags)
@@ -313,6 +322,8 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
             "config": {"workload": f"{shape.name}-shape all-{args.wtype} synthetic weights, one batch-1 greedy token stream, f16 KV cache, "
                                    f"positions {args.warmup}..{args.warmup + args.steps - 1}",
                        "parallelism": f"tp{world}", "all_reduces_per_token": 2 * conf.n_layers, "all_reduce_bytes": shape.dim * 4,
+                       "collective": "RCCL ncclAllReduce per segment" if args.tp_rccl else
+                                     "one-shot P2P all-reduce over hipIpc-mapped inboxes, fused into the wo / ffn_down epilogue",
                        "rank_weight_bytes_per_token": local_bytes},
             "roofline": {"bound": "hbm", "achieved": round(tps * local_bytes / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(tps * local_bytes / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

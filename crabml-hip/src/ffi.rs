@@ -150,6 +150,10 @@ extern "C" {
     pub fn crabml_hip_tp_comm_create(dev: *mut crabml_hip_device_t, id128: *const c_void, nranks: i32, rank: i32, out: *mut *mut crabml_hip_tp_comm_t) -> i32;
     pub fn crabml_hip_tp_comm_destroy(comm: *mut crabml_hip_tp_comm_t) -> i32;
     pub fn crabml_hip_tp_all_reduce(comm: *mut crabml_hip_tp_comm_t, buf: *mut crabml_hip_buf_t, n: usize) -> i32;
+    pub fn crabml_hip_tp_p2p_create(dev: *mut crabml_hip_device_t, nranks: i32, rank: i32, max_elems: usize, out: *mut *mut crabml_hip_tp_comm_t) -> i32;
+    pub fn crabml_hip_tp_p2p_export(comm: *mut crabml_hip_tp_comm_t, handle64: *mut c_void) -> i32;
+    pub fn crabml_hip_tp_p2p_connect(comm: *mut crabml_hip_tp_comm_t, handles: *const c_void) -> i32;
+    pub fn crabml_hip_tp_p2p_connect_local(comms: *const *mut crabml_hip_tp_comm_t, n: i32) -> i32;
     pub fn crabml_hip_llama_tp_sim_forward(ranks: *const *mut crabml_hip_llama_t, n: i32, token: usize, pos: usize, logits: *mut f32) -> i32;
     pub fn crabml_hip_llama_debug_kv(ctx: *mut crabml_hip_llama_t, layer: usize, which_v: i32, dst: *mut c_void, nbytes: usize) -> i32;
 

@@ -38,8 +38,19 @@ using namespace crabml_hip;
 // ---- RCCL, bound at run time (the single-GPU product path never needs it) ------------------------------------
 struct crabml_hip_tp_comm {
   crabml_hip_device* dev = nullptr;
-  void* nccl = nullptr;  // ncclComm_t
+  void* nccl = nullptr;  // ncclComm_t (RCCL kind)
   int nranks = 1, rank = 0;
+  // P2P kind (crabml_hip_tp_p2p_*): the one-shot all-reduce over peer-mapped inboxes (fused_ffn.hpp, TpP2P)
+  bool p2p = false;
+  bool connected = false;
+  unsigned long long* inbox = nullptr;   // this rank's inbox: 2 slots x nranks rows x cap granules
+  size_t inbox_bytes = 0;
+  unsigned cap = 0;                      // granules per row
+  bool finegrained = false;
+  void* peer[8] = {nullptr};             // peers' inboxes as mapped here (peer[rank] = inbox)
+  int* fault = nullptr;                  // device word raised by a poll that timed out
+  unsigned host_epoch = 0;               // crabml_hip_tp_all_reduce outside a decode step
+  unsigned sessions = 0;                 // decode contexts created on this group so far (every rank creates them in the same order)
 };
 namespace {
 struct NcclId {  // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
@@ -106,6 +117,7 @@ struct crabml_hip_llama {
   unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
   unsigned long long* hgran = nullptr;  // fused FFN: hidden/4 quant granules + hidden/32 scale granules of h
   bool ffn_fused = false;               // gate/up + ffn_down as one launch (k_ffn)
+  unsigned tp_salt = 0;      // P2P group: epoch salt of this context (see TpP2P::salt)
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
   bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
   bool generic = false;      // per-op launches (strict-order device, or a weight format without fused kernels)
@@ -145,6 +157,16 @@ struct crabml_hip_llama {
 };
 
 namespace {
+
+TpP2P p2p_view(const crabml_hip_tp_comm* m);
+// the inbox view a decode-step kernel gets: empty (n = 0) unless this context runs the fused collective; timeouts raise the
+// context's own fault word, which forward / decode_greedy check at their sync
+TpP2P tp_view(const crabml_hip_llama* c, bool fused_collective) {
+  TpP2P t = p2p_view(fused_collective && c->comm && c->comm->p2p ? c->comm : nullptr);  // dry run: no comm, n = 0
+  t.fault = c->state + 5;
+  t.salt = c->tp_salt;
+  return t;
+}
 
 int dalloc(crabml_hip_llama* c, size_t bytes, void** out) {
   size_t cap = 0;
@@ -297,11 +319,11 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0});
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tp_view(c, tp));
       else
         launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0});
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tp_view(c, tp));
     } else if (tp) {
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     } else {
@@ -317,7 +339,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       // the classifier has its own rhs type (e.g. Q6_K -> Q8_K): normalize the final x to f32 and quantize for it (the
       // planes the last ffn_down epilogue wrote are in the layers' type and stay unused)
       const size_t nlds = norm_lds_bytes(dim);
-      const float* addv = tp ? c->partial : nullptr;
+      const float* addv = tp && !norm_epi ? c->partial : nullptr;  // (fused collective: x is already final)
       if (dim <= 4096)
         k_norm_f32<4><<<1, 1024, nlds, st>>>(c->x, addv, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, 1);
       else
@@ -561,16 +583,16 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
         if (split == 2 && qin)
           launch_k(st, R, k_gemv_res_nq<FMT, 2, true>, dim3(dim / 16), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE, six(w));
+                   od, ob, ng, k / BE, six(w), TpP2P{});
         else if (split == 2)
           launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE, six(w));
+                   ng, k / BE, six(w), TpP2P{});
         else if (qin)
           launch_k(st, R, k_gemv_res_nq<FMT, 1, true>, dim3(dim / 32), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE, six(w));
+                   od, ob, ng, k / BE, six(w), TpP2P{});
         else
           launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE, six(w));
+                   ng, k / BE, six(w), TpP2P{});
         return P1();
       }
     }
@@ -640,9 +662,28 @@ int enqueue_segment(crabml_hip_llama* c, int seg) {
                                        : enqueue_segment_t<CRABML_HIP_Q4_1>(c, seg);
 }
 
-int allreduce(crabml_hip_llama* c) {
+TpP2P p2p_view(const crabml_hip_tp_comm* m) {
+  TpP2P t{};
+  if (m && m->p2p) {
+    for (int i = 0; i < 8; i++) t.peer[i] = (unsigned long long*)m->peer[i];
+    t.n = m->nranks;
+    t.me = m->rank;
+    t.cap = m->cap;
+    t.fault = m->fault;
+  }
+  return t;
+}
+
+int allreduce(crabml_hip_llama* c, int seg) {
   crabml_hip_device* dev = c->dev;
   if (c->tp_dry) return 0;  // timing-only rank: the partial sums are left as they are
+  if (c->comm && c->comm->p2p) {  // one-shot P2P all-reduce as its own launch (per-op segment path)
+    if (c->norm_epi) return 0;    // fast path: the collective is fused into the wo / ffn_down epilogue
+    const int n = (int)c->cfg.embedding_dim;
+    k_tp_allreduce<<<(n + 255) / 256, 256, 0, dev->stream>>>(c->partial, n, tp_view(c, true), c->state + 4, n_segments(c), seg, 0u);
+    CH_HIP(dev, hipGetLastError());
+    return 0;
+  }
   Rccl* r = rccl();
   if (!r || !c->comm || !c->comm->nccl) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama tp: no RCCL communicator");
   int rc = r->AllReduce(c->partial, c->partial, c->cfg.embedding_dim, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm->nccl, dev->stream);
@@ -654,7 +695,7 @@ int enqueue_step(crabml_hip_llama* c) {
   const int n = n_segments(c);
   for (int s = 0; s < n; s++) {
     CH_TRY(enqueue_segment(c, s));
-    if (c->tp > 1 && s + 1 < n) CH_TRY(allreduce(c));
+    if (c->tp > 1 && s + 1 < n) CH_TRY(allreduce(c, s));
   }
   return 0;
 }
@@ -921,6 +962,20 @@ int crabml_hip_tp_comm_create(crabml_hip_device_t* dev, const void* id128, int n
 
 int crabml_hip_tp_comm_destroy(crabml_hip_tp_comm_t* comm) {
   if (!comm) return 0;
+  if (comm->p2p) {
+    (void)hipSetDevice(comm->dev->ordinal);
+    (void)hipStreamSynchronize(comm->dev->stream);
+    for (int r = 0; r < comm->nranks; r++) {
+      if (r == comm->rank || !comm->peer[r]) continue;
+      // mapped through IPC (another process): close the mapping; same-process peers are plain pointers owned by their rank
+      hipPointerAttribute_t at{};
+      if (hipPointerGetAttributes(&at, comm->peer[r]) == hipSuccess) (void)hipIpcCloseMemHandle(comm->peer[r]);
+      (void)hipGetLastError();
+    }
+    if (comm->inbox) (void)hipFree(comm->inbox);
+    delete comm;
+    return 0;
+  }
   Rccl* r = rccl();
   if (r && comm->nccl) r->CommDestroy(comm->nccl);
   delete comm;
@@ -934,11 +989,116 @@ int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, 
   crabml_hip_device* dev = comm->dev;
   CH_USE(dev);
   if (buf->dtype != CRABML_HIP_F32 || n > buf->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: needs an f32 buffer of >= n elements");
+  if (comm->p2p) {
+    if (!comm->connected) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_all_reduce: the p2p group is not connected");
+    if (n > comm->cap) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: %zu elements exceed the inbox rows (%u)", n, comm->cap);
+    const unsigned k = comm->host_epoch++;  // every rank issues the same sequence of calls
+    k_tp_allreduce<<<(unsigned)((n + 255) / 256), 256, 0, dev->stream>>>((float*)buf->ptr, (int)n, p2p_view(comm), nullptr, 1, (int)(k & 1u),
+                                                                       0x40000000u + k);
+    CH_HIP(dev, hipGetLastError());
+    int fault = 0;
+    CH_HIP(dev, hipMemcpyAsync(&fault, comm->fault, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+    CH_HIP(dev, hipStreamSynchronize(dev->stream));
+    if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "tp_all_reduce: a peer's partial never arrived (poll timed out)");
+    touch(buf);
+    return 0;
+  }
   Rccl* r = rccl();
   if (!r) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "librccl.so could not be loaded");
   int rc = r->AllReduce(buf->ptr, buf->ptr, n, 7, 0, comm->nccl, dev->stream);
   if (rc != 0) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "ncclAllReduce failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
   touch(buf);
+  return 0;
+}
+
+// ---- one-shot P2P all-reduce group (the production collective of SURVEY.md 8e; device side: fused_ffn.hpp, TpP2P) --------
+int crabml_hip_tp_p2p_create(crabml_hip_device_t* dev, int nranks, int rank, size_t max_elems, crabml_hip_tp_comm_t** out) {
+  if (!dev || !out || nranks < 1 || nranks > 8 || rank < 0 || rank >= nranks || max_elems == 0 || max_elems > (1u << 24))
+    return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  CH_USE(dev);
+  crabml_hip_tp_comm* c = new crabml_hip_tp_comm();
+  c->dev = dev;
+  c->nranks = nranks;
+  c->rank = rank;
+  c->p2p = true;
+  c->cap = (unsigned)((max_elems + 31) / 32 * 32);
+  c->inbox_bytes = (size_t)2 * nranks * c->cap * 8 + 256;  // + the fault word
+  // fine-grained device memory: stores from a peer GPU become visible to a kernel that is already running (the coarse-
+  // grained default only promises that at kernel boundaries); plain hipMalloc is the fallback where the flag is refused
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, c->inbox_bytes, hipDeviceMallocFinegrained);
+  c->finegrained = e == hipSuccess;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc(&p, c->inbox_bytes);
+  }
+  if (e == hipSuccess) e = hipMemsetAsync(p, 0, c->inbox_bytes, dev->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  if (e != hipSuccess) {
+    if (p) (void)hipFree(p);
+    delete c;
+    return hip_fail(dev, e, "tp_p2p_create", __FILE__, __LINE__);
+  }
+  c->inbox = (unsigned long long*)p;
+  c->fault = (int*)((char*)p + (size_t)2 * nranks * c->cap * 8);
+  c->peer[rank] = p;
+  c->connected = nranks == 1;
+  *out = c;
+  return 0;
+}
+
+// 64 bytes = hipIpcMemHandle_t of this rank's inbox; ship it to every peer (any side channel), then connect
+int crabml_hip_tp_p2p_export(crabml_hip_tp_comm_t* comm, void* handle64) {
+  if (!comm || !comm->p2p || !handle64) return CRABML_HIP_BAD_INPUT;
+  crabml_hip_device* dev = comm->dev;
+  CH_USE(dev);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t h;
+  CH_HIP(dev, hipIpcGetMemHandle(&h, comm->inbox));
+  memcpy(handle64, &h, 64);
+  return 0;
+}
+
+// handles: nranks x 64 bytes in rank order (this rank's own entry is ignored)
+int crabml_hip_tp_p2p_connect(crabml_hip_tp_comm_t* comm, const void* handles) {
+  if (!comm || !comm->p2p || !handles) return CRABML_HIP_BAD_INPUT;
+  crabml_hip_device* dev = comm->dev;
+  CH_USE(dev);
+  if (comm->connected && comm->nranks > 1) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_p2p_connect: already connected");
+  for (int r = 0; r < comm->nranks; r++) {
+    if (r == comm->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + (size_t)r * 64, 64);
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return hip_fail(dev, e, "hipIpcOpenMemHandle (peer inbox)", __FILE__, __LINE__);
+    comm->peer[r] = p;
+  }
+  comm->connected = true;
+  return 0;
+}
+
+// the same wiring for ranks that live in ONE process (one HipTensorDevice / stream per rank, possibly on the same GPU):
+// the inboxes are plain device pointers, no IPC handle is involved
+int crabml_hip_tp_p2p_connect_local(crabml_hip_tp_comm_t* const* comms, int n) {
+  if (!comms || n < 1 || n > 8) return CRABML_HIP_BAD_INPUT;
+  for (int r = 0; r < n; r++)
+    if (!comms[r] || !comms[r]->p2p || comms[r]->nranks != n || comms[r]->rank != r || comms[r]->cap != comms[0]->cap)
+      return CRABML_HIP_BAD_INPUT;
+  for (int r = 0; r < n; r++) {
+    for (int p = 0; p < n; p++) {
+      if (p == r) continue;
+      if (comms[p]->dev->ordinal != comms[r]->dev->ordinal) {  // another GPU of this process: map it
+        (void)hipSetDevice(comms[r]->dev->ordinal);
+        hipError_t e = hipDeviceEnablePeerAccess(comms[p]->dev->ordinal, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_fail(comms[r]->dev, e, "hipDeviceEnablePeerAccess", __FILE__, __LINE__);
+        (void)hipGetLastError();
+      }
+      comms[r]->peer[p] = comms[p]->inbox;
+    }
+    comms[r]->connected = true;
+  }
   return 0;
 }
 
@@ -952,6 +1112,12 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: inconsistent head configuration");
   if (tp > 8 || g.tp_rank < 0 || g.tp_rank >= tp || g.n_kv_heads % tp || g.hidden_dim % tp)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: tp_size %d must divide n_kv_heads and hidden_dim (and be <= 8)", tp);
+  if (g.tp_comm) {
+    const crabml_hip_tp_comm* m = (const crabml_hip_tp_comm*)g.tp_comm;
+    if (m->p2p && (!m->connected || m->nranks != tp || m->rank != g.tp_rank || m->cap < g.embedding_dim || m->dev != dev))
+      CH_BAIL(dev, CRABML_HIP_BAD_INPUT,
+              "llama: the p2p group must be connected, match tp_size / tp_rank, live on this device and hold rows of >= embedding_dim");
+  }
   // the F32 KV cache pairs head h with kv head h % n_kv (the batch_matmul broadcast quirk): those sets are not
   // contiguous head slices, so a GQA model shards by heads only with the F16 cache (h / (n_heads / n_kv))
   if (tp > 1 && !g.use_f16_kv_cache && g.n_heads != g.n_kv_heads)
@@ -1041,6 +1207,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->tp_rank = g.tp_rank;
   c->comm = (crabml_hip_tp_comm*)g.tp_comm;
   c->tp_dry = tp > 1 && !g.tp_comm && (g.flags & CRABML_HIP_LLAMA_TP_DRY_RUN);
+  if (c->comm && c->comm->p2p) c->tp_salt = (++c->comm->sessions) * 0x9E3779B1u;
   c->hd = (int)hd;
   c->npairs = (int)(g.rope_dim / 2);
   c->n_heads_l = (int)n_heads_l;
@@ -1111,7 +1278,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   }
   A(8 * sizeof(int), (void**)&c->state);
   A((g.embedding_dim / 16 + g.embedding_dim) * 8, (void**)&c->slots);
-  c->norm_epi = !generic && tp == 1 && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
+  // tp > 1: the epilogue also hosts the collective when the group is the P2P kind (or in the collective-free dry run)
+  const bool p2p_comm = c->comm != nullptr && c->comm->p2p;
+  c->norm_epi = !generic && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->ffn_fused = c->norm_epi && (g.flags & CRABML_HIP_LLAMA_FFN_FUSION);  // opt-in: measured slower than the two kernels
   if (c->ffn_fused) {
@@ -1154,7 +1323,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   // tp > 1 without a communicator = a rank of the single-device simulation: driven segment by segment, no graph.
   // tp > 1 over RCCL launches eagerly unless CRABML_HIP_LLAMA_TP_GRAPH asks for the collectives to be captured too.
   const bool want_graph = !(g.flags & CRABML_HIP_LLAMA_NO_GRAPH) &&
-                          (tp == 1 || c->tp_dry || (c->comm != nullptr && (g.flags & CRABML_HIP_LLAMA_TP_GRAPH)));
+                          (tp == 1 || c->tp_dry || p2p_comm || (c->comm != nullptr && (g.flags & CRABML_HIP_LLAMA_TP_GRAPH)));
   if (want_graph) {
     const int nvar = c->attn_long_ok ? 2 : 1;
     bool ok = true;

@@ -41,6 +41,70 @@ __global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks,
   for (int r = 0; r < nranks; r++) ptrs.p[r][i] = s;
 }
 
+// ---- one-shot all-reduce over peer-mapped inboxes (the production collective) -----------------------------
+// Tensor-parallel decode exchanges 2 x dim f32 per layer and token: latency, not bandwidth.  Every rank owns an INBOX
+// (device memory, exported with hipIpcGetMemHandle and mapped by its peers with hipIpcOpenMemHandle -- the same mapping
+// reaches a peer GPU's HBM over xGMI or another process's buffer on the same GPU): two slots (segment parity) x nranks
+// rows of `cap` granules.  A granule is ONE naturally aligned 8-byte {f32 partial, u32 epoch}: data and tag travel in one
+// system-scope store, so there is no flag, no fence and no ordering between a producer's rows (MI355X_MICROARCH.md, "R2
+// granule").  Rank r writes its partial row into slot[seg & 1][r] of EVERY peer's inbox and then reads the nranks rows of
+// its own inbox, polling a granule until its tag is this step's epoch; the partials are added in rank order
+// (p0 + p1) + p2 ..., so every rank computes the same bits (= OracleTpLlamaRunner._sum_in_rank_order).  Two slots are
+// enough: a rank cannot finish all-reduce k + 1 before every peer has consumed all-reduce k.
+struct TpP2P {
+  unsigned long long* peer[8];  // peer[p] = rank p's inbox as mapped in THIS process (peer[me] = the local allocation)
+  int n, me;
+  unsigned cap;                 // granules per row
+  unsigned salt;                // per decode context (the n-th context created on this group): added to the epoch, so that the
+                                // granules a previous context left in the inboxes can never carry a matching tag
+  int* fault;
+};
+__device__ __forceinline__ unsigned long long* tp_row(const TpP2P& t, int owner, int slot, int src) {
+  return t.peer[owner] + ((size_t)slot * t.n + src) * t.cap;
+}
+__device__ __forceinline__ void tp_put(unsigned long long* p, float v, unsigned epoch) {
+  __hip_atomic_store(p, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float tp_get(const TpP2P& t, const unsigned long long* p, unsigned epoch) {
+  unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int tries = 0;
+  while ((unsigned)(g >> 32) != epoch && tries < (1 << 24)) {  // bounded: a peer that never arrives raises a fault, not a hang
+    __builtin_amdgcn_s_sleep(4);
+    g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    tries++;
+  }
+  if ((unsigned)(g >> 32) != epoch) *t.fault = 2;
+  return __builtin_bit_cast(float, (unsigned)g);
+}
+// element i of this rank's partial -> the all-reduced value (every lane calls it for its own i; i < cap)
+__device__ __forceinline__ float tp_allreduce_elem(const TpP2P& t, float part, int i, unsigned epoch, int slot) {
+#pragma unroll
+  for (int p = 0; p < 8; p++)  // (static indices into the kernel-argument array; n <= 8 ranks = one xGMI node)
+    if (p < t.n && p != t.me) tp_put(tp_row(t, p, slot, t.me) + i, part, epoch);
+  float sum = 0.f;
+  unsigned long long* mine = nullptr;
+#pragma unroll
+  for (int p = 0; p < 8; p++)
+    if (p == t.me) mine = t.peer[p];
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    if (s >= t.n) break;
+    const float v = s == t.me ? part : tp_get(t, mine + ((size_t)slot * t.n + s) * t.cap + i, epoch);
+    sum = s == 0 ? v : sum + v;
+  }
+  return sum;
+}
+// the collective as its own launch (replaces ncclAllReduce on the per-op segment path and in crabml_hip_tp_all_reduce):
+// buf[i] <- sum over ranks, in place.  epoch_d != NULL: epoch = *epoch_d * nseg + seg + 1 (decode step, graph-safe)
+__global__ __launch_bounds__(256) void k_tp_allreduce(float* __restrict__ buf, int n, TpP2P t, const int* __restrict__ serial_d, int nseg, int seg,
+                                                      unsigned epoch_host) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned epoch = serial_d ? (unsigned)(*serial_d) * (unsigned)nseg + (unsigned)seg + 1u + t.salt : epoch_host;
+  buf[i] = tp_allreduce_elem(t, buf[i], i, epoch, seg & 1);
+}
+
 // ---- fast mode: GEMV + residual with the NEXT RMSNorm + quantization done in the epilogue ------------------------
 // The separate norm+quantize launch is a single-workgroup latency stage (6 us x 65 per token on Llama-3-8B).  Here
 // the producer of x (wo / ffn_down + residual) finishes the job: a 1024-thread workgroup owns 32 consecutive rows
@@ -94,7 +158,7 @@ template <int FMT, int SPLIT>
 __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
                                             float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
                                             void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
-                                            int row, int lane, int wave, int wg_index, int nwg_all) {
+                                            int row, int lane, int wave, int wg_index, int nwg_all, const TpP2P* tp = nullptr) {
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;
   constexpr int RW = 2 / SPLIT;
@@ -113,7 +177,11 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
   // wave 0 owns the stores: ROWS consecutive rows per instruction (x and the row granules are one or two lines,
   // not 32 separate partial writes from 16 waves)
   if (lane < ROWS) {
-    const float xv = hv[part * ROWS + lane] + res;  // x = matmul_out + x (llama2.rs:266 / :636)
+    float mo = hv[part * ROWS + lane];
+    // tensor parallel: this rank's rows are PARTIAL sums over its k slice -- exchange them with the peers' (one-shot
+    // all-reduce through the inboxes, rank-order sum) before the residual is added; every rank then holds the same x rows
+    if (tp != nullptr) mo = tp_allreduce_elem(*tp, mo, row + lane, epoch + tp->salt, ng.seg & 1);
+    const float xv = mo + res;  // x = matmul_out + x (llama2.rs:266 / :636)
     x[row + lane] = xv;
     hv[part * ROWS + lane] = xv;
     if (ROWG)
@@ -225,8 +293,9 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
                                                       signed char* __restrict__ q, void* __restrict__ d,
-                                                      void* __restrict__ isum, NormGather ng, int nb, Planes6 w6) {
+                                                      void* __restrict__ isum, NormGather ng, int nb, Planes6 w6, TpP2P tpx) {
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
+  const TpP2P* tp = tpx.n > 1 ? &tpx : nullptr;
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
   __shared__ __attribute__((aligned(16))) float hv[32];
@@ -261,7 +330,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       const ActQ8_K la6{lds_act, sd, sbs};
       rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
       nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
-                              (int)blockIdx.x, (int)gridDim.x);
+                              (int)blockIdx.x, (int)gridDim.x, tp);
       return;
     }
     constexpr int PRE = 2;
@@ -316,7 +385,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     }
   }
   nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
-                          (int)gridDim.x);
+                          (int)gridDim.x, tp);
 }
 
 // ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---

@@ -23,6 +23,26 @@ class TpComm {
     if (id.size() != 128) throw Error(ErrorKind::BadInput, "a ncclUniqueId is 128 bytes");
     device_->check(crabml_hip_tp_comm_create(device_->raw(), id.data(), nranks, rank, &comm_));
   }
+  // the one-shot P2P group (crabml_hip_tp_p2p_*): create -> export_handle -> (ship handles) -> connect
+  struct P2P {};
+  TpComm(P2P, HipTensorDeviceRef device, int nranks, int rank, size_t max_elems) : device_(std::move(device)), nranks_(nranks), rank_(rank) {
+    device_->check(crabml_hip_tp_p2p_create(device_->raw(), nranks, rank, max_elems, &comm_));
+  }
+  std::vector<uint8_t> export_handle() const {
+    std::vector<uint8_t> h(64);
+    device_->check(crabml_hip_tp_p2p_export(comm_, h.data()));
+    return h;
+  }
+  void connect(const std::vector<uint8_t>& handles) {
+    if (handles.size() != (size_t)nranks_ * 64) throw Error(ErrorKind::BadInput, "connect: expected nranks x 64 bytes of handles");
+    device_->check(crabml_hip_tp_p2p_connect(comm_, handles.data()));
+  }
+  static void connect_local(const std::vector<std::shared_ptr<TpComm>>& comms) {
+    std::vector<crabml_hip_tp_comm_t*> raw;
+    for (const auto& c : comms) raw.push_back(c->raw());
+    if (raw.empty()) throw Error(ErrorKind::BadInput, "connect_local: no ranks");
+    comms[0]->device_->check(crabml_hip_tp_p2p_connect_local(raw.data(), (int)raw.size()));
+  }
   ~TpComm() {
     if (comm_) crabml_hip_tp_comm_destroy(comm_);
   }

@@ -323,9 +323,25 @@ PYBIND11_MODULE(_host, m) {
              return std::make_shared<TpComm>(std::move(dev), std::vector<uint8_t>(s.begin(), s.end()), nranks, rank);
            }),
            py::arg("device"), py::arg("unique_id"), py::arg("nranks"), py::arg("rank"))
+      .def_static("p2p",
+                  [](std::shared_ptr<HipTensorDevice> dev, int nranks, int rank, size_t max_elems) {
+                    return std::make_shared<TpComm>(TpComm::P2P{}, std::move(dev), nranks, rank, max_elems);
+                  },
+                  py::arg("device"), py::arg("nranks"), py::arg("rank"), py::arg("max_elems"))
+      .def("export_handle",
+           [](const TpComm& c) {
+             std::vector<uint8_t> h = c.export_handle();
+             return py::bytes((const char*)h.data(), h.size());
+           })
+      .def("connect",
+           [](TpComm& c, py::bytes handles) {
+             std::string s = handles;
+             c.connect(std::vector<uint8_t>(s.begin(), s.end()));
+           })
+      .def_static("connect_local", &TpComm::connect_local)
       .def_property_readonly("nranks", &TpComm::nranks)
       .def_property_readonly("rank", &TpComm::rank)
-      .def("all_reduce", &TpComm::all_reduce);
+      .def("all_reduce", &TpComm::all_reduce, py::call_guard<py::gil_scoped_release>());
 
   py::class_<HipLlamaRunner>(m, "HipLlamaRunner")
       .def(py::init([](const LlamaConfig& conf, std::shared_ptr<Weights> w, std::shared_ptr<HipTensorDevice> dev,

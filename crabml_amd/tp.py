@@ -98,6 +98,57 @@ def init_tp_comm(device, rank: int, world: int, broadcast_bytes):
     return ca.TpComm(device, bytes(uid), world, rank)
 
 
+def init_tp_p2p(device, rank: int, world: int, max_elems: int, all_gather_bytes):
+    """Create this rank's one-shot P2P all-reduce group (crabml_hip_tp_p2p_*: the production collective, no RCCL on the
+    data path).  `all_gather_bytes(b: bytes) -> list[bytes]` returns every rank's 64-byte inbox handle in rank order over
+    any side channel (torch.distributed all_gather_object, files, MPI ...)."""
+    import crabml_amd as ca
+
+    comm = ca.TpComm.p2p(device, world, rank, max_elems)
+    if world > 1:
+        handles = all_gather_bytes(comm.export_handle())
+        if len(handles) != world or any(len(h) != 64 for h in handles):
+            raise ValueError("init_tp_p2p: the all-gather did not deliver one 64-byte handle per rank")
+        comm.connect(b"".join(bytes(h) for h in handles))
+    return comm
+
+
+def torch_all_gather(world: int):
+    """all_gather_bytes for init_tp_p2p over an initialised torch.distributed process group."""
+    import torch.distributed as dist
+
+    def gather(b):
+        box = [None] * world
+        dist.all_gather_object(box, b)
+        return box
+
+    return gather
+
+
+def file_all_gather(directory: str, rank: int, world: int, timeout_s: float = 120.0):
+    """all_gather_bytes over a shared directory (no torch): every rank drops its handle as a file and waits for the rest."""
+    import os
+    import time
+
+    def gather(b):
+        tmp = os.path.join(directory, f"handle.{rank}.tmp")
+        with open(tmp, "wb") as f:
+            f.write(b)
+        os.replace(tmp, os.path.join(directory, f"handle.{rank}"))
+        out, t0 = [], time.time()
+        for r in range(world):
+            path = os.path.join(directory, f"handle.{r}")
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError(f"rank {rank}: no handle from rank {r}")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                out.append(f.read())
+        return out
+
+    return gather
+
+
 def torch_broadcast(rank: int):
     """broadcast_bytes for init_tp_comm over an initialised torch.distributed process group."""
     import torch.distributed as dist

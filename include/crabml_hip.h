@@ -276,6 +276,20 @@ int crabml_hip_tp_get_unique_id(void* id128);
 int crabml_hip_tp_comm_create(crabml_hip_device_t* dev, const void* id128, int nranks, int rank, crabml_hip_tp_comm_t** out);
 int crabml_hip_tp_comm_destroy(crabml_hip_tp_comm_t* comm);
 int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, size_t n); /* in-place f32 sum */
+/* ---- the production collective: one-shot all-reduce over peer-mapped inboxes (no RCCL call on the data path) ----
+ * A decode step all-reduces 2 x dim f32 per layer: pure latency.  Every rank allocates an INBOX; its peers map it
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle: a peer GPU's HBM over xGMI, or another process's buffer on the same GPU) and
+ * write their partial rows straight into it as 8-byte {f32, epoch} granules; the reader polls its own inbox and adds the
+ * rows in rank order, so every rank computes the same bits.  With such a group in crabml_hip_llama_config_t.tp_comm the
+ * fast step runs the collective INSIDE the wo / ffn_down kernels (scatter -> gather -> residual -> RMSNorm -> quantize in
+ * their epilogue: 5 launches per layer, like one GPU); the per-op segment path (strict order, K-quants) runs it as one small
+ * launch where the RCCL group runs ncclAllReduce.  Usage: create on every rank, export the 64-byte handle, ship the handles
+ * to every rank (any side channel), connect.  max_elems >= embedding_dim. */
+int crabml_hip_tp_p2p_create(crabml_hip_device_t* dev, int nranks, int rank, size_t max_elems, crabml_hip_tp_comm_t** out);
+int crabml_hip_tp_p2p_export(crabml_hip_tp_comm_t* comm, void* handle64);
+int crabml_hip_tp_p2p_connect(crabml_hip_tp_comm_t* comm, const void* handles /* nranks x 64 bytes, rank order */);
+/* ranks living in ONE process (one device object / stream per rank): wires the inboxes as plain device pointers */
+int crabml_hip_tp_p2p_connect_local(crabml_hip_tp_comm_t* const* comms, int n);
 /* single-device simulation of a tp group (ranks created on ONE device with tp_comm = NULL): same kernels, same
  * sharding, the all-reduce replaced by a local sum -- validates everything but the RCCL transport itself */
 int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, size_t token, size_t pos, float* logits);

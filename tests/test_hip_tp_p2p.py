@@ -1,0 +1,163 @@
+"""The production collective of the tensor-parallel step: the one-shot all-reduce over peer-mapped inboxes
+(crabml_hip_tp_p2p_*; device side: fused_ffn.hpp `TpP2P`), on the ONE GPU a test box has.
+
+  * ranks in one process (one device object / stream per rank, inboxes wired as plain pointers): the collective kernel
+    itself, the strict step == OracleTpLlamaRunner bit for bit, and the fast step -- collective INSIDE the wo / ffn_down
+    epilogue, 5 launches per layer -- == the single-device simulation bit for bit;
+  * ranks in SEPARATE PROCESSES sharing device 0, inboxes mapped with hipIpcGetMemHandle / hipIpcOpenMemHandle -- the very
+    mechanism that maps a peer GPU's HBM over xGMI: strict logits == the oracle's tensor-parallel restatement bit for bit
+    on every rank (rank-order sums keep it exact), for 2 and 4 processes.
+No scaling curve comes out of this (one GPU); what is established is that the collective is correct across processes."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from crabml_amd import synth, tp as tp_mod
+from tests.test_hip_tp import TOKS, hip_tp_ranks, oracle_tp_logits
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def local_group(ca, n, dim, strict):
+    devs = [ca.HipTensorDevice(0, False, 0, strict) for _ in range(n)]  # one stream per rank
+    comms = [ca.TpComm.p2p(devs[r], n, r, dim) for r in range(n)]
+    ca.TpComm.connect_local(comms)
+    return devs, comms
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_one_shot_all_reduce_rank_order_sum(ca, n):
+    dim = 1024
+    devs, comms = local_group(ca, n, dim, False)
+    rng = np.random.default_rng(n)
+    for it in range(4):  # consecutive collectives alternate the two inbox slots
+        xs = [rng.standard_normal(dim).astype(np.float32) for _ in range(n)]
+        ts = [ca.HipTensor.from_cpu(xs[r].view(np.uint8), [dim], ca.GGMLType.F32, devs[r]) for r in range(n)]
+        errs = []
+
+        def run(r):
+            try:
+                comms[r].all_reduce(ts[r])
+            except Exception as e:  # surfaced below
+                errs.append(e)
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        want = xs[0].copy()
+        for r in range(1, n):
+            want = want + xs[r]  # (p0 + p1) + p2 ...: f32, rank order
+        for r in range(n):
+            assert np.array_equal(ts[r].export().view(np.uint32), want.view(np.uint32)), (it, r)
+
+
+def run_group(ca, runners, toks):
+    """one token stream through n ranks that live in this process: ranks 1.. only enqueue, rank 0 blocks for the logits"""
+    out = []
+    for i, t in enumerate(toks):
+        for r in runners[1:]:
+            r.forward_async(t, i)
+        out.append(runners[0].forward(t, i).copy())
+    return out
+
+
+@pytest.mark.parametrize("shape,n,fmt", [("tiny-gqa", 2, "Q4_0"), ("15m", 3, "Q8_0"), ("tiny-gqa", 2, "Q4_K")])
+def test_strict_step_over_the_p2p_group_equals_the_oracle(ca, shape, n, fmt):
+    model = synth.build_model(synth.SHAPES[shape], synth.TYPE_BY_NAME[fmt], seed=31)
+    ref = oracle_tp_logits(model, n, True, TOKS)
+    devs, comms = local_group(ca, n, model.shape.dim, True)
+    runners = []
+    for r in range(n):
+        conf, w = synth.to_hip(tp_mod.shard_model(model, n, r, True), devs[r])
+        runners.append(ca.HipLlamaRunner(conf, w, devs[r], 64, True, True, True, n, r, comms[r]))
+    got = run_group(ca, runners, TOKS)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+
+
+@pytest.mark.parametrize("fmt,n", [("Q4_0", 2), ("Q8_0", 2), ("Q4_1", 2), ("Q4_0", 4)])
+def test_fast_step_with_the_collective_in_the_epilogue_equals_the_simulation(ca, fmt, n):
+    """fast kernels: wo / ffn_down scatter their partial rows, gather the peers', add the residual and run RMSNorm +
+    quantize in the same launch (5 launches per layer and rank).  Same arithmetic as the single-device simulation
+    (per-rank GEMV + rank-order sum + norm launch): bit-identical logits."""
+    shape = synth.ModelShape("tp4", 512, 1024, 2, 8, 4, 1024, 64, 1e-5, None) if n == 4 else synth.SHAPES["tiny-gqa"]
+    model = synth.build_model(shape, synth.TYPE_BY_NAME[fmt], seed=32)
+    sim_dev = ca.HipTensorDevice(0)
+    sim = hip_tp_ranks(ca, model, n, True, sim_dev)
+    want = [ca.HipLlamaRunner.tp_sim_forward(sim, t, i).copy() for i, t in enumerate(TOKS)]
+    devs, comms = local_group(ca, n, model.shape.dim, False)
+    runners = []
+    for r in range(n):
+        conf, w = synth.to_hip(tp_mod.shard_model(model, n, r, True), devs[r])
+        runners.append(ca.HipLlamaRunner(conf, w, devs[r], 64, True, True, True, n, r, comms[r]))
+    got = run_group(ca, runners, TOKS)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{fmt}: step {i}"
+
+
+def spawn(tmp_path, world, shape, fmt, strict, mode):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "tp_p2p_worker.py"), str(tmp_path), str(r), str(world), shape, fmt,
+                               "1" if strict else "0", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_all_reduce_across_processes_over_hip_ipc(tmp_path, world):
+    spawn(tmp_path, world, "tiny-gqa", "Q4_0", False, "allreduce")
+    dim = synth.SHAPES["tiny-gqa"].dim
+    for it in range(5):
+        want = None
+        for r in range(world):
+            x = (np.arange(dim, dtype=np.float32) * (r + 1) + it).astype(np.float32)
+            want = x if want is None else want + x
+        for r in range(world):
+            got = np.load(tmp_path / f"out.{r}.npy")[it]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (it, r)
+
+
+@pytest.mark.parametrize("world,shape,fmt", [(2, "tiny-gqa", "Q4_0"), (2, "tiny-gqa", "Q4_K")])
+def test_strict_tp_step_across_processes_equals_the_oracle(tmp_path, world, shape, fmt):
+    model = synth.build_model(synth.SHAPES[shape], synth.TYPE_BY_NAME[fmt], seed=31)
+    ref = np.stack(oracle_tp_logits(model, world, True, TOKS))
+    spawn(tmp_path, world, shape, fmt, True, "step")
+    for r in range(world):  # every rank holds the same (replicated) logits
+        got = np.load(tmp_path / f"out.{r}.npy")
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"rank {r}"
+    ids = [np.load(tmp_path / f"ids.{r}.npy") for r in range(world)]
+    assert all(np.array_equal(ids[0], i) for i in ids)
+
+
+def test_fast_tp_step_across_four_processes(tmp_path):
+    """4 processes, fast kernels (the collective inside the wo / ffn_down epilogue, hipGraph replay): every rank's logits
+    equal the single-device simulation's bit for bit."""
+    # tiny-gqa has 2 kv heads: a 4-way split needs 4 -- same dims, 4 kv heads
+    shape = synth.ModelShape("tp4", 512, 1024, 2, 8, 4, 1024, 64, 1e-5, None)
+    synth.SHAPES["tp4"] = shape
+    import crabml_amd as ca
+
+    model = synth.build_model(shape, synth.Q4_0, seed=31)
+    sim = hip_tp_ranks(ca, model, 4, True, ca.HipTensorDevice(0))
+    want = np.stack([ca.HipLlamaRunner.tp_sim_forward(sim, t, i).copy() for i, t in enumerate(TOKS)])
+    del sim
+    spawn(tmp_path, 4, "tp4", "Q4_0", False, "step")
+    for r in range(4):
+        got = np.load(tmp_path / f"out.{r}.npy")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"rank {r}"
