@@ -999,7 +999,10 @@ int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, 
     int fault = 0;
     CH_HIP(dev, hipMemcpyAsync(&fault, comm->fault, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
     CH_HIP(dev, hipStreamSynchronize(dev->stream));
-    if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "tp_all_reduce: a peer's partial never arrived (poll timed out)");
+    if (fault) {
+      (void)hipMemsetAsync(comm->fault, 0, sizeof(int), dev->stream);  // the group stays usable once the peer shows up
+      CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "tp_all_reduce: a peer's partial never arrived (poll timed out)");
+    }
     touch(buf);
     return 0;
   }
@@ -1401,6 +1404,7 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, fl
     CH_HIP(dev, hipMemcpyAsync(logits, c->logits, c->cfg.vocab_size * 4, hipMemcpyDeviceToHost, dev->stream));
     CH_HIP(dev, hipMemcpyAsync(&fault, c->state + 5, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
     CH_HIP(dev, hipStreamSynchronize(dev->stream));
+    if (fault == 2) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: a tensor-parallel peer's partial sums never arrived (poll timed out)");
     if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: a norm-epilogue gather timed out (workgroups not co-resident?)");
   }
   return 0;
@@ -1423,6 +1427,7 @@ int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n
   CH_HIP(dev, hipMemcpyAsync(out_tokens, c->out_tokens, n_steps * 4, hipMemcpyDeviceToHost, dev->stream));
   CH_HIP(dev, hipMemcpyAsync(&fault, c->state + 5, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  if (fault == 2) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: a tensor-parallel peer's partial sums never arrived (poll timed out)");
   if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: a norm-epilogue gather timed out (workgroups not co-resident?)");
   return 0;
 }

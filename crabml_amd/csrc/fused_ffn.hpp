@@ -69,7 +69,7 @@ __device__ __forceinline__ void tp_put(unsigned long long* p, float v, unsigned 
 __device__ __forceinline__ float tp_get(const TpP2P& t, const unsigned long long* p, unsigned epoch) {
   unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   int tries = 0;
-  while ((unsigned)(g >> 32) != epoch && tries < (1 << 24)) {  // bounded: a peer that never arrives raises a fault, not a hang
+  while ((unsigned)(g >> 32) != epoch && tries < (1 << 22)) {  // bounded (seconds): a peer that never arrives raises a fault, not a hang
     __builtin_amdgcn_s_sleep(4);
     g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     tries++;
