@@ -138,6 +138,8 @@ struct crabml_hip_llama {
   int attn_variant = 0;         // which of the two the next enqueue emits
   bool attn_long_ok = false;    // f16 cache, head_dim % 32 == 0, group size in {1, 2, 4, 8}, seq_len % 8 == 0
   size_t attn_long_from = 0;    // cached positions (pos + 1) from which variant 1 is used
+  int attn_s_rows = 0;          // > 0: variant 0 runs k_attn_s (K / V staged through LDS) with room for this many cached rows
+  size_t attn_s_lds = 0;
   float* scores_g = nullptr;    // [n_heads_l][seq_len] f32
   unsigned short* p16 = nullptr;  // [n_heads_l][seq_len] f16 probabilities
   // batched prefill (crabml_hip_llama_prefill): row buffers for pf_cap prompt rows, allocated on first use
@@ -240,14 +242,18 @@ void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned sho
   crabml_hip_device::ProfRec ar{};
   crabml_hip_device::ProfRec* AR = prof ? &ar : nullptr;
   if (prof) prof_begin(dev, &ar, CRABML_HIP_F32, 7, 0.0);
-  if (c->cfg.use_f16_kv_cache)
+  if (c->attn_s_rows > 0)
+    launch_k(st, AR, k_attn_s<false>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
+             (const unsigned short*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd, seq_cap,
+             c->attn_s_rows, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
+  else if (c->cfg.use_f16_kv_cache)
     launch_k(st, AR, k_attn<true>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
              (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
-             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0);
+             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
   else
     launch_k(st, AR, k_attn<false>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
              (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
-             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0);
+             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
   if (prof) prof_end(dev, &ar);
 }
 
@@ -316,14 +322,22 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
                         : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
                         : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
                                                                           : 1;
-      if (split == 2)
+      const TpP2P tpv = tp_view(c, tp);
+      if (tpv.n > 1) {  // tensor parallel over a P2P group: the collective runs inside this launch
+        if (split == 2)
+          launch_k(st, R, k_gemv_res_nq<FMT, 2, false, true>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
+                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
+        else
+          launch_k(st, R, k_gemv_res_nq<FMT, 1, false, true>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
+                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
+      } else if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tp_view(c, tp));
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
       else
         launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tp_view(c, tp));
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
     } else if (tp) {
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     } else {
@@ -583,16 +597,16 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
         if (split == 2 && qin)
           launch_k(st, R, k_gemv_res_nq<FMT, 2, true>, dim3(dim / 16), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE, six(w), TpP2P{});
+                   od, ob, ng, k / BE, six(w), NoTp{});
         else if (split == 2)
           launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE, six(w), TpP2P{});
+                   ng, k / BE, six(w), NoTp{});
         else if (qin)
           launch_k(st, R, k_gemv_res_nq<FMT, 1, true>, dim3(dim / 32), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE, six(w), TpP2P{});
+                   od, ob, ng, k / BE, six(w), NoTp{});
         else
           launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE, six(w), TpP2P{});
+                   ng, k / BE, six(w), NoTp{});
         return P1();
       }
     }
@@ -1277,6 +1291,17 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     if (c->attn_long_ok) {
       A(n_heads_l * g.seq_len * 4, (void**)&c->scores_g);
       A(n_heads_l * g.seq_len * 2, (void**)&c->p16);
+    }
+    // short-context attention with K / V staged through LDS (f16 cache): variant 0 serves positions < S
+    if (g.use_f16_kv_cache && hd % 8 == 0 && !(g.flags & CRABML_HIP_LLAMA_NO_STAGED_ATTENTION)) {
+      const size_t S = c->attn_long_ok && c->attn_long_from < g.seq_len ? c->attn_long_from : g.seq_len;
+      const size_t lds = attn_s_lds_bytes((int)S, (int)hd);
+      if (lds <= 150 * 1024 &&
+          hipFuncSetAttribute((const void*)k_attn_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+        c->attn_s_rows = (int)S;
+        c->attn_s_lds = lds;
+      }
+      (void)hipGetLastError();
     }
   }
   A(8 * sizeof(int), (void**)&c->state);

@@ -11,17 +11,24 @@ namespace crabml_hip {
 // (buf_f16.rs:152-163).  f32 cache -> plain f32 loops, kv head = h % n_kv (batch_matmul.rs:61-67).
 // softmax.rs:36-54 with the f16 exp table; the row sum is sequential (bit-exact) up to 1024 positions and a
 // block tree beyond that (documented tolerance 1e-6 relative).
-template <bool KV16>
+// STAMP (tools/attn_lab.hip only): workgroup 0 records s_memtime at its phase boundaries into `stamps`
+template <bool KV16, bool STAMP = false>
 __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const void* __restrict__ kc,
                                               const void* __restrict__ vc, const int* __restrict__ pos_d,
                                               const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
                                               signed char* __restrict__ xq, unsigned short* __restrict__ xd,
                                               void* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap,
-                                              PrefetchPlan pf, int q81) {
+                                              PrefetchPlan pf, int q81, long long* __restrict__ stamps = nullptr) {
   if ((int)blockIdx.x >= n_heads) {
     prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
     return;
   }
+  auto stamp = [&](int i) {
+    if constexpr (STAMP) {
+      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = (long long)__builtin_readcyclecounter();
+    }
+  };
+  stamp(0);
   extern __shared__ float lds[];
   __shared__ float s_red[4];
   __shared__ float s_val;
@@ -56,6 +63,7 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
     qs[i] = KV16 ? h2f(f2h(v)) : v;  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
   }
   __syncthreads();
+  stamp(1);
   // ---- scores[t] = q . K[t]
   for (int t = tid; t < seq; t += blockDim.x) {
     float acc = 0.0f;
@@ -105,8 +113,10 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
     scores[t] = acc;
   }
   __syncthreads();
+  stamp(2);
   // ---- softmax (in place; probabilities rounded to f16 for the f16 cache)
   softmax_row<KV16>(scores, seq, exp_tab, s_red, &s_val);
+  stamp(3);
   // ---- out[n] = sum_t p[t] * V[t][n]
   float val = 0.0f;
   const int n = tid;
@@ -151,6 +161,7 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
     }
     out[head * hd + n] = val;
   }
+  stamp(4);
   // ---- quantize the head's output for wo (only when blocks do not straddle heads)
   if (xq != nullptr) {
     const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
@@ -168,6 +179,170 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
       }
     }
   }
+  stamp(5);
+}
+
+// ---- attention at short context with K / V staged through LDS ---------------------------------------------------------
+// k_attn above lets every thread fetch "its" K row / V column straight from the cache: 16-byte pieces at a 256-byte stride,
+// in batches that each cost a memory round trip, all queued in order behind one another (s_memtime stamps at position 39 of
+// the 8B shape, tools/attn_lab.hip: q staged 1.7 us | scores 2.2 | softmax 1.2 | PV 3.1 | quantize 0.4).  Here the
+// workgroup copies the head's K and V rows [0, seq) into LDS with coalesced 16-byte loads that are ALL in flight at once --
+// the first 64 rows are requested before the position is even known (rows past `seq` are allocated cache memory: read,
+// never used) -- and the score / PV loops then run out of LDS.  Same arithmetic, element for element, as k_attn:
+// q rounded to f16, f32 accumulation in k order (buf_f16.rs:83-97), softmax_row, f16-accumulated PV in position order
+// (buf_f16.rs:152-163).  f16 cache, head_dim % 8 == 0; serves positions < S (the rows the launch has LDS for).
+// K rows are padded by 16 bytes: a 16-lane group of ds_read_b128 then covers all 64 banks once (272 B = 68 dwords = 4 mod 64).
+template <bool STAMP = false>
+__global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, const unsigned short* __restrict__ kc,
+                                                const unsigned short* __restrict__ vc, const int* __restrict__ pos_d,
+                                                const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
+                                                signed char* __restrict__ xq, unsigned short* __restrict__ xd,
+                                                void* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap, int S,
+                                                PrefetchPlan pf, int q81, long long* __restrict__ stamps) {
+  if ((int)blockIdx.x >= n_heads) {
+    prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
+    return;
+  }
+  auto stamp = [&](int i) {
+    if constexpr (STAMP) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = (long long)__builtin_readcyclecounter();
+    }
+  };
+  stamp(0);
+  extern __shared__ float lds[];
+  __shared__ float s_red[4];
+  __shared__ float s_val;
+  const int S4 = (S + 3) & ~3, kstr = hd + 8;
+  float* scores = lds;
+  float* qs = lds + S4;
+  unsigned short* Ks = (unsigned short*)(qs + hd);
+  unsigned short* Vs = Ks + (size_t)S * kstr;
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x;
+  const int kvh = head / (n_heads / n_kv);
+  const int ppr = hd >> 3;  // 16-byte pieces per row
+  const i32x4* Kg = (const i32x4*)(kc + (size_t)kvh * seq_cap * hd);
+  const i32x4* Vg = (const i32x4*)(vc + (size_t)kvh * seq_cap * hd);
+  // ---- requests that do not depend on the position: q, and the first rows of K and V (4 pieces per thread each)
+  constexpr int P0 = 4;
+  const float qv = tid < hd ? q[head * hd + tid] : 0.f;
+  const int spec = min(S * ppr, P0 * 256);
+  i32x4 k0[P0], v0[P0];
+#pragma unroll
+  for (int j = 0; j < P0; j++) {
+    const int p = tid + 256 * j;
+    if (p < spec) {
+      k0[j] = Kg[p];
+      v0[j] = Vg[p];
+    }
+  }
+  int seq = *pos_d + 1;
+  seq = seq < S ? seq : S;  // (the host only launches this kernel for positions < S)
+  if (tid < hd) qs[tid] = h2f(f2h(qv));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+  // ---- the rest of the rows, now that seq is known (none at the short contexts this kernel is for): 4 + 4 in flight
+  const int need = seq * ppr;
+  for (int p0 = spec; p0 < need; p0 += P0 * 256) {
+    i32x4 k1[P0], v1[P0];
+#pragma unroll
+    for (int j = 0; j < P0; j++) {
+      const int p = p0 + tid + 256 * j;
+      if (p < need) {
+        k1[j] = Kg[p];
+        v1[j] = Vg[p];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < P0; j++) {
+      const int p = p0 + tid + 256 * j;
+      if (p < need) {
+        const int row = p / ppr, c = p - row * ppr;
+        *(i32x4*)(Ks + (size_t)row * kstr + c * 8) = k1[j];
+        *(i32x4*)(Vs + (size_t)row * hd + c * 8) = v1[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < P0; j++) {
+    const int p = tid + 256 * j;
+    if (p < spec) {
+      const int row = p / ppr, c = p - row * ppr;
+      *(i32x4*)(Ks + (size_t)row * kstr + c * 8) = k0[j];
+      *(i32x4*)(Vs + (size_t)row * hd + c * 8) = v0[j];
+    }
+  }
+  __syncthreads();
+  stamp(1);
+  // ---- scores[t] = q . K[t], f32 accumulation in k order
+  for (int t = tid; t < seq; t += 256) {
+    const unsigned short* kr = Ks + (size_t)t * kstr;
+    float acc = 0.0f;
+    for (int i = 0; i < hd; i += 8) {
+      const i32x4 kv = *(const i32x4*)(kr + i);
+      const f32x4 qa = *(const f32x4*)(qs + i), qb = *(const f32x4*)(qs + i + 4);
+      acc += qa[0] * h2f((unsigned short)((unsigned)kv[0] & 0xffffu));
+      acc += qa[1] * h2f((unsigned short)((unsigned)kv[0] >> 16));
+      acc += qa[2] * h2f((unsigned short)((unsigned)kv[1] & 0xffffu));
+      acc += qa[3] * h2f((unsigned short)((unsigned)kv[1] >> 16));
+      acc += qb[0] * h2f((unsigned short)((unsigned)kv[2] & 0xffffu));
+      acc += qb[1] * h2f((unsigned short)((unsigned)kv[2] >> 16));
+      acc += qb[2] * h2f((unsigned short)((unsigned)kv[3] & 0xffffu));
+      acc += qb[3] * h2f((unsigned short)((unsigned)kv[3] >> 16));
+    }
+    scores[t] = acc;
+  }
+  __syncthreads();
+  stamp(2);
+  softmax_row<true>(scores, seq, exp_tab, s_red, &s_val);
+  stamp(3);
+  // ---- out[n] = sum_t p[t] * V[t][n]: f16 product and f16 sum per position, in position order
+  float val = 0.0f;
+  const int n = tid;
+  if (n < hd) {
+    const unsigned short* vr = Vs + n;
+    _Float16 c = (_Float16)0.0f;
+    int t = 0;
+    for (; t + 8 <= seq; t += 8) {
+      unsigned short vv[8];
+      float pp[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        vv[u] = vr[(size_t)(t + u) * hd];
+        pp[u] = scores[t + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const _Float16 prod = hbits(vv[u]) * (_Float16)pp[u];  // scores hold f16-representable values
+        c = c + prod;
+      }
+    }
+    for (; t < seq; t++) {
+      const _Float16 prod = hbits(vr[(size_t)t * hd]) * (_Float16)scores[t];
+      c = c + prod;
+    }
+    val = (float)c;
+    out[head * hd + n] = val;
+  }
+  stamp(4);
+  if (xq != nullptr) {
+    const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
+    const float vq = live ? val : 0.f;
+    const QLane o = q81 ? quant_lane32<true>(vq, live) : quant_lane32<false>(vq, live);
+    if (live) {
+      int e = head * hd + n;
+      xq[e] = o.q;
+      if ((n & 31) == 0) {
+        xd[e >> 5] = o.d;
+        if (q81)
+          store_qaux<true>(xisum, e >> 5, o.aux);
+        else
+          store_qaux<false>(xisum, e >> 5, o.aux);
+      }
+    }
+  }
+  stamp(5);
+}
+__host__ __device__ inline size_t attn_s_lds_bytes(int S, int hd) {
+  return (size_t)(((S + 3) & ~3) + hd) * sizeof(float) + (size_t)S * (hd + 8) * 2 + (size_t)S * hd * 2;
 }
 
 // ---- attention at long context: the same arithmetic over every CU ----------------------------------------------

@@ -77,6 +77,17 @@ __device__ __forceinline__ float tp_get(const TpP2P& t, const unsigned long long
   if ((unsigned)(g >> 32) != epoch) *t.fault = 2;
   return __builtin_bit_cast(float, (unsigned)g);
 }
+// kernels that host the collective take a TpP2P by value; every other instantiation takes an empty struct (no kernel
+// argument bytes, no code: the single-GPU kernels are exactly what they were)
+struct NoTp {};
+template <bool TP>
+struct TpArg {
+  typedef NoTp type;
+};
+template <>
+struct TpArg<true> {
+  typedef TpP2P type;
+};
 // element i of this rank's partial -> the all-reduced value (every lane calls it for its own i; i < cap)
 __device__ __forceinline__ float tp_allreduce_elem(const TpP2P& t, float part, int i, unsigned epoch, int slot) {
 #pragma unroll
@@ -154,11 +165,12 @@ __device__ __forceinline__ unsigned long long ld_granule(const unsigned long lon
 // The tail of the wo / ffn_down kernels (k_gemv_res_nq, k_ffn): acc[] = this wave's RW row dots.  Publishes the
 // workgroup's rows / sum of squares, takes the one in-launch hop, normalizes + quantizes the rows it owns.
 // wg_index / nwg_all: this workgroup's index among the SPLIT * nchunks workgroups of the stage.
-template <int FMT, int SPLIT>
+template <int FMT, int SPLIT, bool TP = false>
 __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
                                             float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
                                             void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
-                                            int row, int lane, int wave, int wg_index, int nwg_all, const TpP2P* tp = nullptr) {
+                                            int row, int lane, int wave, int wg_index, int nwg_all,
+                                            const typename TpArg<TP>::type& tp = typename TpArg<TP>::type{}) {
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;
   constexpr int RW = 2 / SPLIT;
@@ -180,7 +192,7 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     float mo = hv[part * ROWS + lane];
     // tensor parallel: this rank's rows are PARTIAL sums over its k slice -- exchange them with the peers' (one-shot
     // all-reduce through the inboxes, rank-order sum) before the residual is added; every rank then holds the same x rows
-    if (tp != nullptr) mo = tp_allreduce_elem(*tp, mo, row + lane, epoch + tp->salt, ng.seg & 1);
+    if constexpr (TP) mo = tp_allreduce_elem(tp, mo, row + lane, epoch + tp.salt, ng.seg & 1);
     const float xv = mo + res;  // x = matmul_out + x (llama2.rs:266 / :636)
     x[row + lane] = xv;
     hv[part * ROWS + lane] = xv;
@@ -288,14 +300,14 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
   }
 }
 
-template <int FMT, int SPLIT, bool QIN = false>
+template <int FMT, int SPLIT, bool QIN = false, bool TP = false>
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
                                                       signed char* __restrict__ q, void* __restrict__ d,
-                                                      void* __restrict__ isum, NormGather ng, int nb, Planes6 w6, TpP2P tpx) {
+                                                      void* __restrict__ isum, NormGather ng, int nb, Planes6 w6,
+                                                      typename TpArg<TP>::type tp) {
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
-  const TpP2P* tp = tpx.n > 1 ? &tpx : nullptr;
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
   __shared__ __attribute__((aligned(16))) float hv[32];
@@ -329,8 +341,8 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
       const ActQ8_K la6{lds_act, sd, sbs};
       rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
-      nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
-                              (int)blockIdx.x, (int)gridDim.x, tp);
+      nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
+                                  (int)blockIdx.x, (int)gridDim.x, tp);
       return;
     }
     constexpr int PRE = 2;
@@ -384,8 +396,8 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       }
     }
   }
-  nq_epilogue<FMT, SPLIT>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
-                          (int)gridDim.x, tp);
+  nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
+                              (int)gridDim.x, tp);
 }
 
 // ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
