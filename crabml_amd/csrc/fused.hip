@@ -242,8 +242,12 @@ void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned sho
   crabml_hip_device::ProfRec ar{};
   crabml_hip_device::ProfRec* AR = prof ? &ar : nullptr;
   if (prof) prof_begin(dev, &ar, CRABML_HIP_F32, 7, 0.0);
-  if (c->attn_s_rows > 0)
-    launch_k(st, AR, k_attn_s<false>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
+  if (c->attn_s_rows > 0 && hd == 128)
+    launch_k(st, AR, k_attn_s<128>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
+             (const unsigned short*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd, seq_cap,
+             c->attn_s_rows, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
+  else if (c->attn_s_rows > 0)
+    launch_k(st, AR, k_attn_s<0>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
              (const unsigned short*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd, seq_cap,
              c->attn_s_rows, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
   else if (c->cfg.use_f16_kv_cache)
@@ -1297,7 +1301,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       const size_t S = c->attn_long_ok && c->attn_long_from < g.seq_len ? c->attn_long_from : g.seq_len;
       const size_t lds = attn_s_lds_bytes((int)S, (int)hd);
       if (lds <= 150 * 1024 &&
-          hipFuncSetAttribute((const void*)k_attn_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+          hipFuncSetAttribute((const void*)k_attn_s<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_attn_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
         c->attn_s_rows = (int)S;
         c->attn_s_lds = lds;
       }

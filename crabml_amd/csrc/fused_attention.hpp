@@ -192,12 +192,12 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
 // q rounded to f16, f32 accumulation in k order (buf_f16.rs:83-97), softmax_row, f16-accumulated PV in position order
 // (buf_f16.rs:152-163).  f16 cache, head_dim % 8 == 0; serves positions < S (the rows the launch has LDS for).
 // K rows are padded by 16 bytes: a 16-lane group of ds_read_b128 then covers all 64 banks once (272 B = 68 dwords = 4 mod 64).
-template <bool STAMP = false>
+template <int HD, bool STAMP = false>  // HD: head_dim when known at compile time (128: the score loop is fully unrolled), 0 = run time
 __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, const unsigned short* __restrict__ kc,
                                                 const unsigned short* __restrict__ vc, const int* __restrict__ pos_d,
                                                 const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
                                                 signed char* __restrict__ xq, unsigned short* __restrict__ xd,
-                                                void* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap, int S,
+                                                void* __restrict__ xisum, int n_heads, int n_kv, int hd_rt, int seq_cap, int S,
                                                 PrefetchPlan pf, int q81, long long* __restrict__ stamps) {
   if ((int)blockIdx.x >= n_heads) {
     prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
@@ -212,39 +212,40 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
   extern __shared__ float lds[];
   __shared__ float s_red[4];
   __shared__ float s_val;
+  const int hd = HD ? HD : hd_rt;
   const int S4 = (S + 3) & ~3, kstr = hd + 8;
   float* scores = lds;
   float* qs = lds + S4;
   unsigned short* Ks = (unsigned short*)(qs + hd);
   unsigned short* Vs = Ks + (size_t)S * kstr;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x;
   const int kvh = head / (n_heads / n_kv);
   const int ppr = hd >> 3;  // 16-byte pieces per row
   const i32x4* Kg = (const i32x4*)(kc + (size_t)kvh * seq_cap * hd);
   const i32x4* Vg = (const i32x4*)(vc + (size_t)kvh * seq_cap * hd);
   // ---- requests that do not depend on the position: q, and the first rows of K and V (4 pieces per thread each)
-  constexpr int P0 = 4;
+  constexpr int P0 = 4, P1 = 10;  // P0 * 256 pieces speculative (64 rows at head_dim 128), up to P1 * 256 more once seq is known
   const float qv = tid < hd ? q[head * hd + tid] : 0.f;
   const int spec = min(S * ppr, P0 * 256);
-  i32x4 k0[P0], v0[P0];
+  i32x4 k0[P0], vb0[P0];
 #pragma unroll
   for (int j = 0; j < P0; j++) {
     const int p = tid + 256 * j;
     if (p < spec) {
       k0[j] = Kg[p];
-      v0[j] = Vg[p];
+      vb0[j] = Vg[p];
     }
   }
   int seq = *pos_d + 1;
   seq = seq < S ? seq : S;  // (the host only launches this kernel for positions < S)
   if (tid < hd) qs[tid] = h2f(f2h(qv));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
-  // ---- the rest of the rows, now that seq is known (none at the short contexts this kernel is for): 4 + 4 in flight
+  // ---- the rest of the rows, now that seq is known (none at the short contexts this kernel is for): all in flight at once
   const int need = seq * ppr;
-  for (int p0 = spec; p0 < need; p0 += P0 * 256) {
-    i32x4 k1[P0], v1[P0];
+  for (int p0 = spec; p0 < need; p0 += P1 * 256) {
+    i32x4 k1[P1], v1[P1];
 #pragma unroll
-    for (int j = 0; j < P0; j++) {
+    for (int j = 0; j < P1; j++) {
       const int p = p0 + tid + 256 * j;
       if (p < need) {
         k1[j] = Kg[p];
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
       }
     }
 #pragma unroll
-    for (int j = 0; j < P0; j++) {
+    for (int j = 0; j < P1; j++) {
       const int p = p0 + tid + 256 * j;
       if (p < need) {
         const int row = p / ppr, c = p - row * ppr;
@@ -267,16 +268,17 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
     if (p < spec) {
       const int row = p / ppr, c = p - row * ppr;
       *(i32x4*)(Ks + (size_t)row * kstr + c * 8) = k0[j];
-      *(i32x4*)(Vs + (size_t)row * hd + c * 8) = v0[j];
+      *(i32x4*)(Vs + (size_t)row * hd + c * 8) = vb0[j];
     }
   }
   __syncthreads();
   stamp(1);
-  // ---- scores[t] = q . K[t], f32 accumulation in k order
-  for (int t = tid; t < seq; t += 256) {
+  // ---- scores[t] = q . K[t], f32 accumulation in k order (one cached position per thread)
+  auto score_of = [&](int t) -> float {
     const unsigned short* kr = Ks + (size_t)t * kstr;
     float acc = 0.0f;
-    for (int i = 0; i < hd; i += 8) {
+#pragma unroll
+    for (int i = 0; i < (HD ? HD : 0); i += 8) {  // compile-time head_dim: straight-line, the LDS reads run ahead of the chain
       const i32x4 kv = *(const i32x4*)(kr + i);
       const f32x4 qa = *(const f32x4*)(qs + i), qb = *(const f32x4*)(qs + i + 4);
       acc += qa[0] * h2f((unsigned short)((unsigned)kv[0] & 0xffffu));
@@ -288,54 +290,108 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
       acc += qb[2] * h2f((unsigned short)((unsigned)kv[3] & 0xffffu));
       acc += qb[3] * h2f((unsigned short)((unsigned)kv[3] >> 16));
     }
-    scores[t] = acc;
+    if constexpr (HD == 0) {
+      for (int i = 0; i < hd; i += 8) {
+        const i32x4 kv = *(const i32x4*)(kr + i);
+        const f32x4 qa = *(const f32x4*)(qs + i), qb = *(const f32x4*)(qs + i + 4);
+        acc += qa[0] * h2f((unsigned short)((unsigned)kv[0] & 0xffffu));
+        acc += qa[1] * h2f((unsigned short)((unsigned)kv[0] >> 16));
+        acc += qa[2] * h2f((unsigned short)((unsigned)kv[1] & 0xffffu));
+        acc += qa[3] * h2f((unsigned short)((unsigned)kv[1] >> 16));
+        acc += qb[0] * h2f((unsigned short)((unsigned)kv[2] & 0xffffu));
+        acc += qb[1] * h2f((unsigned short)((unsigned)kv[2] >> 16));
+        acc += qb[2] * h2f((unsigned short)((unsigned)kv[3] & 0xffffu));
+        acc += qb[3] * h2f((unsigned short)((unsigned)kv[3] >> 16));
+      }
+    }
+    return acc;
+  };
+  if (seq <= 64) {
+    // one wave holds the whole row: softmax.rs:36-54 without a barrier or an LDS round trip -- the same maximum, the same
+    // table lookups, the same sequential sum (lanes past seq add +0.0), the same division and f16 rounding as softmax_row
+    if (wave == 0) {
+      const float sc = lane < seq ? score_of(lane) : -INFINITY;
+      stamp(2);
+      const float mx = wave_max_f32(sc);
+      const float e = lane < seq ? exp_cached_f(sc - mx, exp_tab) : 0.0f;
+      float sum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 64; i++) sum += rl_f(e, i);
+      const float pv = e / sum;
+      if (lane < seq) scores[lane] = h2f(f2h(pv));  // quantize_f32_f16 of the lhs (batch_matmul.rs:39)
+    }
+    __syncthreads();
+  } else {
+    for (int t = tid; t < seq; t += 256) scores[t] = score_of(t);
+    __syncthreads();
+    stamp(2);
+    softmax_row<true>(scores, seq, exp_tab, s_red, &s_val);
   }
-  __syncthreads();
-  stamp(2);
-  softmax_row<true>(scores, seq, exp_tab, s_red, &s_val);
   stamp(3);
-  // ---- out[n] = sum_t p[t] * V[t][n]: f16 product and f16 sum per position, in position order
-  float val = 0.0f;
-  const int n = tid;
-  if (n < hd) {
-    const unsigned short* vr = Vs + n;
-    _Float16 c = (_Float16)0.0f;
+  // ---- out[n] = sum_t p[t] * V[t][n]: f16 product and f16 sum per position, in position order (buf_f16.rs:152-163).
+  // A lane carries the chains of TWO adjacent output columns on packed f16 math (v_pk_mul_f16 + v_pk_add_f16 = the half
+  // crate's product / sum roundings, one instruction pair per position for both columns): hd / 2 lanes, one LDS dword of V
+  // and one broadcast probability per position.
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  const int npair = hd >> 1;
+  float v0 = 0.0f, v1 = 0.0f;
+  if (tid < npair) {
+    const unsigned* vr = (const unsigned*)Vs + tid;  // row stride hd / 2 dwords
+    h2v c = {(_Float16)0.0f, (_Float16)0.0f};
     int t = 0;
     for (; t + 8 <= seq; t += 8) {
-      unsigned short vv[8];
+      unsigned vv[8];
       float pp[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        vv[u] = vr[(size_t)(t + u) * hd];
+        vv[u] = vr[(size_t)(t + u) * npair];
         pp[u] = scores[t + u];
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const _Float16 prod = hbits(vv[u]) * (_Float16)pp[u];  // scores hold f16-representable values
+        const _Float16 ph = (_Float16)pp[u];  // scores hold f16-representable values
+        const h2v p2 = {ph, ph};
+        const h2v prod = __builtin_bit_cast(h2v, vv[u]) * p2;
         c = c + prod;
       }
     }
     for (; t < seq; t++) {
-      const _Float16 prod = hbits(vr[(size_t)t * hd]) * (_Float16)scores[t];
+      const _Float16 ph = (_Float16)scores[t];
+      const h2v p2 = {ph, ph};
+      const h2v prod = __builtin_bit_cast(h2v, vr[(size_t)t * npair]) * p2;
       c = c + prod;
     }
-    val = (float)c;
-    out[head * hd + n] = val;
+    v0 = (float)c[0];
+    v1 = (float)c[1];
+    *(f32x2*)(out + head * hd + 2 * tid) = f32x2{v0, v1};
   }
   stamp(4);
-  if (xq != nullptr) {
-    const bool live = n < hd;  // hd % 32 == 0 here, so 32-lane groups are all-live or all-dead
-    const float vq = live ? val : 0.f;
-    const QLane o = q81 ? quant_lane32<true>(vq, live) : quant_lane32<false>(vq, live);
+  // ---- quantize the head's output for wo: a 32-element block = the 16 lanes of one DPP row (two columns each)
+  if (xq != nullptr && wave * 64 < npair) {  // whole waves (hd % 32 == 0 here: rows of 16 lanes are all-live or all-dead)
+    const bool live = tid < npair;
+    const float a0 = live ? v0 : 0.f, a1 = live ? v1 : 0.f;
+    const float amax = row16_max_f32(fmaxf(fabsf(a0), fabsf(a1)));
+    const float dd = amax / 127.0f;
+    int q0, q1, aux;
+    if (!q81) {  // buf_q8_0.rs:87-134: q = trunc(x / d) (`as i8` of the i32 wraps), aux = the block's quant sum
+      q0 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(a0 / dd) & 0xffu);
+      q1 = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(a1 / dd) & 0xffu);
+      aux = row16_sum_i32(live ? q0 + q1 : 0);
+    } else {  // buf_q8_1.rs:90-129: clamp, NaN -> -128, s = f16(d * sum q)
+      q0 = (int)fminf(fmaxf(a0 / dd, -128.0f), 127.0f);
+      q1 = (int)fminf(fmaxf(a1 / dd, -128.0f), 127.0f);
+      const int sum = row16_sum_i32(live ? q0 + q1 : 0);
+      aux = (int)f2h((float)sum * dd);
+    }
     if (live) {
-      int e = head * hd + n;
-      xq[e] = o.q;
-      if ((n & 31) == 0) {
-        xd[e >> 5] = o.d;
+      const int e = head * hd + 2 * tid;
+      *(unsigned short*)(xq + e) = (unsigned short)(((unsigned)q0 & 0xffu) | (((unsigned)q1 & 0xffu) << 8));
+      if ((tid & 15) == 0) {
+        xd[e >> 5] = f2h(dd);
         if (q81)
-          store_qaux<true>(xisum, e >> 5, o.aux);
+          store_qaux<true>(xisum, e >> 5, aux);
         else
-          store_qaux<false>(xisum, e >> 5, o.aux);
+          store_qaux<false>(xisum, e >> 5, aux);
       }
     }
   }

@@ -26,7 +26,9 @@ int hip_fail(crabml_hip_device*, hipError_t, const char*, const char*, int) { re
 }  // namespace crabml_hip
 
 int main() {
-  const int n_heads = 32, n_kv = 8, hd = 128, seq_cap = 8192, L = 24;  // L cache copies: every launch touches cold-ish rows
+  const int n_heads = 32, n_kv = 8, hd = 128, seq_cap = 8192;
+  const int L = getenv("ATTN_LAB_L") ? atoi(getenv("ATTN_LAB_L")) : 24;  // L cache copies: every launch touches cold-ish rows (L = 1: warm)
+  printf("# %d KV-cache copies\n", L);
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   const size_t kvb = (size_t)n_kv * seq_cap * hd * 2;
@@ -95,12 +97,12 @@ int main() {
     {  // the LDS-staged kernel (k_attn_s), same stamps
       const int S = 224;
       const size_t lds_s = attn_s_lds_bytes(S, hd);
-      CK(hipFuncSetAttribute((const void*)k_attn_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-      CK(hipFuncSetAttribute((const void*)k_attn_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      CK(hipFuncSetAttribute((const void*)k_attn_s<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      CK(hipFuncSetAttribute((const void*)k_attn_s<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
       std::vector<std::vector<long long>> runs2;
       for (int it = 0; it < 9; it++) {
         const int l = it % L;
-        k_attn_s<true><<<dim3(n_heads), 256, lds_s, st>>>(q, (const unsigned short*)(kc + l * kvb), (const unsigned short*)(vc + l * kvb), pos_d, d_tab,
+        k_attn_s<128, true><<<dim3(n_heads), 256, lds_s, st>>>(q, (const unsigned short*)(kc + l * kvb), (const unsigned short*)(vc + l * kvb), pos_d, d_tab,
                                                           out, xq, xd, (void*)xs, n_heads, n_kv, hd, seq_cap, S, PrefetchPlan{}, 0, stamps);
         CK(hipStreamSynchronize(st));
         std::vector<long long> s2(6);
@@ -116,7 +118,7 @@ int main() {
         CK(hipEventRecord(e0, st));
         for (int it = 0; it < 96; it++) {
           const int l = it % L;
-          k_attn_s<false><<<dim3(n_heads), 256, lds_s, st>>>(q, (const unsigned short*)(kc + l * kvb), (const unsigned short*)(vc + l * kvb), pos_d, d_tab,
+          k_attn_s<128, false><<<dim3(n_heads), 256, lds_s, st>>>(q, (const unsigned short*)(kc + l * kvb), (const unsigned short*)(vc + l * kvb), pos_d, d_tab,
                                                              out, xq, xd, (void*)xs, n_heads, n_kv, hd, seq_cap, S, PrefetchPlan{}, 0, nullptr);
         }
         CK(hipEventRecord(e1, st));
