@@ -814,8 +814,14 @@ int launch_attn_long_rows_t(crabml_hip_llama* c, int l, int B) {
         (const float*)c->pf_qr, (const unsigned short*)c->kc[l], pos_d, c->pf_scores, n_kv, hd, seq_cap, nsplit, r0);
     k_attn_softmax<<<dim3(n_heads, rows), 256, (size_t)seq_cap * sizeof(float), st>>>(
         (const float*)c->pf_scores, pos_d, (const unsigned short*)dev->exp_table, c->pf_p16, seq_cap, r0);
-    k_attn_pv<G><<<dim3(n_kv * (hd / 32), rows), 256, 0, st>>>((const unsigned short*)c->pf_p16, (const unsigned short*)c->vc[l], pos_d,
-                                                               c->pf_attn, nullptr, nullptr, nullptr, hd, seq_cap, 0, r0);
+    // PV for R prompt rows per workgroup (one V fetch for R x G chains); G = 8 fills the lanes with two rows
+    constexpr int PR = G == 8 ? 2 : 4;
+    if (c->cfg.flags & CRABML_HIP_LLAMA_NO_PV_ROW_TILES)
+      k_attn_pv<G><<<dim3(n_kv * (hd / 32), rows), 256, 0, st>>>((const unsigned short*)c->pf_p16, (const unsigned short*)c->vc[l], pos_d,
+                                                                 c->pf_attn, nullptr, nullptr, nullptr, hd, seq_cap, 0, r0);
+    else
+      k_attn_pv_rows<G, PR><<<dim3(n_kv * (hd / 32), (rows + PR - 1) / PR), 256, 0, st>>>(
+          (const unsigned short*)c->pf_p16, (const unsigned short*)c->vc[l], pos_d, c->pf_attn, hd, seq_cap, r0, (int)rows);
   }
   return 0;
 }

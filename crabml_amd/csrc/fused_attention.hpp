@@ -613,6 +613,126 @@ __global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restric
   }
 }
 
+
+// The same PV pass for R consecutive prompt rows per workgroup (batched prefill past 1024 positions): row r of the tile
+// sees seq0 + r cached positions.  The V tile is fetched and transposed ONCE for the R rows x G heads -- every lane of the
+// workgroup carries a chain (R * G * 16 = 256 for Llama-3's G = 4, R = 4) instead of 64 of 256, and V is read R times less
+// often (a 4096-token prompt re-read V once per row: 340 of 582 ms).  Per (row, head, column) the arithmetic and its order
+// are k_attn_pv's: bit-identical (test_long_prompt_attention_paths_are_bit_identical).
+template <int G, int R>
+__global__ __launch_bounds__(256) void k_attn_pv_rows(const unsigned short* __restrict__ p16, const unsigned short* __restrict__ vc,
+                                                      const int* __restrict__ pos_d, float* __restrict__ out, int hd, int seq_cap,
+                                                      int row0, int nrows) {
+  static_assert(R * G * 16 <= 256, "one chain per lane");
+  constexpr int T = ATTN_PV_TILE, ROW = ATTN_PV_ROW;
+  __shared__ __attribute__((aligned(16))) unsigned vt[2][16 * ROW];
+  __shared__ __attribute__((aligned(16))) unsigned pt[2][R * G * ROW];
+  const int tid = threadIdx.x;
+  const int nslice = hd / 32;
+  const int j = blockIdx.x / nslice, sl = blockIdx.x % nslice;
+  const int rt0 = (int)blockIdx.y * R;                       // first row of this tile within the launch
+  const int rows_here = nrows - rt0 < R ? nrows - rt0 : R;   // >= 1
+  const int seq0 = *pos_d + 1 + row0 + rt0;                  // cached positions of the tile's first row
+  const int seq_max = seq0 + rows_here - 1;
+  const size_t n_heads = (size_t)(gridDim.x / nslice) * G;
+  p16 += (size_t)rt0 * n_heads * seq_cap;
+  out += (size_t)(row0 + rt0) * n_heads * hd;
+  const unsigned short* vbase = vc + (size_t)j * seq_cap * hd + sl * 32;
+  const int ntiles = (seq_max + T - 1) / T;
+  constexpr int PP = (R * G * (T / 8) + 255) / 256;  // probability pieces (8 positions of one (row, head)) per thread
+  i32x4 vreg[4], preg[PP];
+  auto issue = [&](int tile) {
+    const int t0 = tile * T;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int t = t0 + (tid >> 2) + 64 * r;
+      t = t < seq_cap ? t : seq_cap - 1;
+      vreg[r] = *(const i32x4*)(vbase + (size_t)t * hd + (tid & 3) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < PP; u++) {
+      const int pc = tid + 256 * u;
+      if (pc < R * G * (T / 8)) {
+        const int rg = pc / (T / 8), c8 = pc % (T / 8), r = rg / G, g = rg % G;
+        const int rr = r < rows_here ? r : rows_here - 1;  // rows past the batch: re-read the last row (never consumed)
+        int t = t0 + c8 * 8;
+        t = t + 8 <= seq_cap ? t : seq_cap - 8;
+        preg[u] = *(const i32x4*)(p16 + ((size_t)rr * n_heads + (j * G + g)) * seq_cap + t);
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int tl = (tid >> 2) + 64 * r;
+#pragma unroll
+      for (int i = 0; i < 4; i++) vt[buf][((tid & 3) * 4 + i) * ROW + tl] = (unsigned)vreg[r][i];
+    }
+#pragma unroll
+    for (int u = 0; u < PP; u++) {
+      const int pc = tid + 256 * u;
+      if (pc < R * G * (T / 8)) {
+        const int rg = pc / (T / 8), c8 = pc % (T / 8);
+        unsigned pp[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const unsigned w = (unsigned)preg[u][i];
+          const unsigned a = w & 0xffffu, b = w >> 16;
+          pp[2 * i] = a | (a << 16);
+          pp[2 * i + 1] = b | (b << 16);
+        }
+        *(i32x4*)(&pt[buf][rg * ROW + c8 * 8]) = i32x4{(int)pp[0], (int)pp[1], (int)pp[2], (int)pp[3]};
+        *(i32x4*)(&pt[buf][rg * ROW + c8 * 8 + 4]) = i32x4{(int)pp[4], (int)pp[5], (int)pp[6], (int)pp[7]};
+      }
+    }
+  };
+  // chain role: lane = (row r, head g, dim pair dp)
+  const int rg = tid >> 4, dp = tid & 15, r = rg / G, g = rg % G;
+  const bool chain = tid < R * G * 16 && r < rows_here;
+  const int seq = seq0 + r;
+  h16x2 c2 = {(_Float16)0.0f, (_Float16)0.0f};
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile++) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles) issue(tile + 1);
+    if (chain && tile * T < seq) {
+      const int nt = seq - tile * T < T ? seq - tile * T : T;
+      const unsigned* vrow = &vt[buf][dp * ROW];
+      const unsigned* prow = &pt[buf][rg * ROW];
+      int t = 0;
+#define PV_ROUND(NB)                                                                                         \
+  for (; t + 8 * NB <= nt; t += 8 * NB) {                                                                    \
+    i32x4 vq[2 * NB], pq[2 * NB];                                                                            \
+    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) {                                                     \
+      vq[b] = *(const i32x4*)(vrow + t + 4 * b);                                                             \
+      pq[b] = *(const i32x4*)(prow + t + 4 * b);                                                             \
+    }                                                                                                        \
+    _Pragma("unroll") for (int b = 0; b < 2 * NB; b++) _Pragma("unroll") for (int u = 0; u < 4; u++) {       \
+      const h16x2 pr = __builtin_bit_cast(h16x2, (unsigned)vq[b][u]) * __builtin_bit_cast(h16x2, (unsigned)pq[b][u]); \
+      c2 = c2 + pr;                                                                                          \
+    }                                                                                                        \
+  }
+      PV_ROUND(4)
+      PV_ROUND(1)
+#undef PV_ROUND
+      for (; t < nt; t++) {
+        const h16x2 pr = __builtin_bit_cast(h16x2, vrow[t]) * __builtin_bit_cast(h16x2, prow[t]);
+        c2 = c2 + pr;
+      }
+    }
+    if (tile + 1 < ntiles) commit(buf ^ 1);
+    __syncthreads();
+  }
+  if (!chain) return;
+  const int head = j * G + g;
+  const int e0 = head * hd + sl * 32 + 2 * dp;
+  float* o = out + (size_t)r * n_heads * hd;
+  o[e0] = (float)c2[0];
+  o[e0 + 1] = (float)c2[1];
+}
+
 // ---- batched-prefill attention: one workgroup = one kv head x R consecutive prompt rows x the G q heads of its
 // group (Q = G * R queries).  Per (row, head) the arithmetic is k_attn's, value for value -- f32 dots in k order,
 // softmax_row's table exp / sequential row sum (rows up to 1024 positions; longer prompts use k_attn) / true

@@ -217,6 +217,7 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
 #define CRABML_HIP_LLAMA_TP_DRY_RUN 128 /* measurement hook: a lone tp rank (tp_comm = NULL) steps with its all-reduces
                                           skipped -- per-rank kernel time of a tp group; the logits are meaningless */
 #define CRABML_HIP_LLAMA_NO_LONG_ATTENTION 64 /* A/B: one attention workgroup per head at every context length */
+#define CRABML_HIP_LLAMA_NO_PV_ROW_TILES 16384 /* A/B: long-prompt prefill runs the PV pass one prompt row per workgroup */
 #define CRABML_HIP_LLAMA_NO_STAGED_ATTENTION 8192 /* A/B: short-context attention without the LDS staging of K / V (k_attn) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */

@@ -173,6 +173,9 @@ def test_long_prompt_attention_paths_are_bit_identical(ca, n_heads, n_kv):
     b = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=2048)
     la, lb = a.prefill(prompt), b.prefill(prompt)
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    # ... and the PV pass with one prompt row per workgroup (flag 16384) instead of the row tiles
+    c = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=16384)
+    assert np.array_equal(c.prefill(prompt).view(np.uint32), la.view(np.uint32))
     nxt = int(np.argmax(la))
     assert list(a.decode_greedy(nxt, 6)) == list(b.decode_greedy(nxt, 6))
     filled = a.kv_cache_len() * shape.head_dim * 2
