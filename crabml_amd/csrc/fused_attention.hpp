@@ -229,17 +229,24 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
   const float qv = tid < hd ? q[head * hd + tid] : 0.f;
   const int spec = min(S * ppr, P0 * 256);
   i32x4 k0[P0], vb0[P0];
+  // (unconditional, index clamped: a load inside a divergent branch gets its own s_waitcnt from the compiler -- four serial
+  // round trips, ~4000 cycles, where all eight requests should be in flight together)
 #pragma unroll
   for (int j = 0; j < P0; j++) {
     const int p = tid + 256 * j;
-    if (p < spec) {
-      k0[j] = Kg[p];
-      vb0[j] = Vg[p];
-    }
+    const int pc = p < spec ? p : spec - 1;
+    k0[j] = Kg[pc];
+    vb0[j] = Vg[pc];
   }
+  stamp(6);  // loads issued
   int seq = *pos_d + 1;
   seq = seq < S ? seq : S;  // (the host only launches this kernel for positions < S)
+  if constexpr (STAMP) {
+    if (seq < 0) stamps[15] = 0;  // (forces the wait for the scalar load here)
+  }
+  stamp(7);  // position known
   if (tid < hd) qs[tid] = h2f(f2h(qv));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+  stamp(8);  // q arrived and staged
   // ---- the rest of the rows, now that seq is known (none at the short contexts this kernel is for): all in flight at once
   const int need = seq * ppr;
   for (int p0 = spec; p0 < need; p0 += P1 * 256) {
@@ -247,10 +254,9 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
 #pragma unroll
     for (int j = 0; j < P1; j++) {
       const int p = p0 + tid + 256 * j;
-      if (p < need) {
-        k1[j] = Kg[p];
-        v1[j] = Vg[p];
-      }
+      const int pc = p < need ? p : need - 1;  // clamped, not branched (see above)
+      k1[j] = Kg[pc];
+      v1[j] = Vg[pc];
     }
 #pragma unroll
     for (int j = 0; j < P1; j++) {
@@ -271,26 +277,37 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
       *(i32x4*)(Vs + (size_t)row * hd + c * 8) = vb0[j];
     }
   }
+  stamp(9);  // K / V pieces arrived and written to LDS (this wave)
   __syncthreads();
   stamp(1);
   // ---- scores[t] = q . K[t], f32 accumulation in k order (one cached position per thread)
+  // HD = 128: q lives in two registers per lane (lane l: q[l] and q[64 + l], rounded to f16 as the reference does) and is
+  // handed to the multiply as a scalar by v_readlane; the thread's K row comes out of LDS with 16 reads that are all issued
+  // before the chain starts.  (Reading q from LDS inside the loop cost one LDS round trip per 8 elements: 3600 cycles for
+  // the 128-element dot; the products are the same q[i] * k[i], added in the same k order.)
+  float q_lo = 0.f, q_hi = 0.f;
+  if constexpr (HD == 128) {
+    q_lo = h2f(f2h(q[head * 128 + lane]));
+    q_hi = h2f(f2h(q[head * 128 + 64 + lane]));
+  }
   auto score_of = [&](int t) -> float {
     const unsigned short* kr = Ks + (size_t)t * kstr;
     float acc = 0.0f;
+    if constexpr (HD == 128) {
+      i32x4 kv[16];
 #pragma unroll
-    for (int i = 0; i < (HD ? HD : 0); i += 8) {  // compile-time head_dim: straight-line, the LDS reads run ahead of the chain
-      const i32x4 kv = *(const i32x4*)(kr + i);
-      const f32x4 qa = *(const f32x4*)(qs + i), qb = *(const f32x4*)(qs + i + 4);
-      acc += qa[0] * h2f((unsigned short)((unsigned)kv[0] & 0xffffu));
-      acc += qa[1] * h2f((unsigned short)((unsigned)kv[0] >> 16));
-      acc += qa[2] * h2f((unsigned short)((unsigned)kv[1] & 0xffffu));
-      acc += qa[3] * h2f((unsigned short)((unsigned)kv[1] >> 16));
-      acc += qb[0] * h2f((unsigned short)((unsigned)kv[2] & 0xffffu));
-      acc += qb[1] * h2f((unsigned short)((unsigned)kv[2] >> 16));
-      acc += qb[2] * h2f((unsigned short)((unsigned)kv[3] & 0xffffu));
-      acc += qb[3] * h2f((unsigned short)((unsigned)kv[3] >> 16));
-    }
-    if constexpr (HD == 0) {
+      for (int i = 0; i < 16; i++) kv[i] = *(const i32x4*)(kr + 8 * i);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned w = (unsigned)kv[i][j];
+          const int e = 8 * i + 2 * j;
+          acc += rl_f(e < 64 ? q_lo : q_hi, e & 63) * h2f((unsigned short)(w & 0xffffu));
+          acc += rl_f(e + 1 < 64 ? q_lo : q_hi, (e + 1) & 63) * h2f((unsigned short)(w >> 16));
+        }
+      }
+    } else {
       for (int i = 0; i < hd; i += 8) {
         const i32x4 kv = *(const i32x4*)(kr + i);
         const f32x4 qa = *(const f32x4*)(qs + i), qb = *(const f32x4*)(qs + i + 4);

@@ -67,7 +67,7 @@ int main() {
   int* pos_d;
   CK(hipMalloc(&pos_d, 4));
   long long* stamps;
-  CK(hipMalloc(&stamps, 64));
+  CK(hipMalloc(&stamps, 256));
   char* wo;
   const size_t wo_bytes = (size_t)9437184 + 1048576;
   CK(hipMalloc(&wo, wo_bytes * 8));
@@ -105,8 +105,8 @@ int main() {
         k_attn_s<128, true><<<dim3(n_heads), 256, lds_s, st>>>(q, (const unsigned short*)(kc + l * kvb), (const unsigned short*)(vc + l * kvb), pos_d, d_tab,
                                                           out, xq, xd, (void*)xs, n_heads, n_kv, hd, seq_cap, S, PrefetchPlan{}, 0, stamps);
         CK(hipStreamSynchronize(st));
-        std::vector<long long> s2(6);
-        CK(hipMemcpy(s2.data(), stamps, 48, hipMemcpyDeviceToHost));
+        std::vector<long long> s2(10);
+        CK(hipMemcpy(s2.data(), stamps, 80, hipMemcpyDeviceToHost));
         runs2.push_back(s2);
       }
       std::sort(runs2.begin(), runs2.end(), [](const auto& a, const auto& b) { return a[5] - a[0] < b[5] - b[0]; });
@@ -127,6 +127,8 @@ int main() {
         CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, ms * 1e3f / 96);
       }
+      printf("pos %3d  STAGED  inside `staged`: loads issued %5lld | position known %5lld | q staged %5lld | K,V in LDS %5lld | barrier %5lld\n", pos,
+             s2[6] - s2[0], s2[7] - s2[6], s2[8] - s2[7], s2[9] - s2[8], s2[1] - s2[9]);
       printf("pos %3d  launch STAGED 32 workgroups            : %.2f us\n", pos, best);
     }
     // launch time: back-to-back launches over different layers' caches, with and without the prefetch workgroups
