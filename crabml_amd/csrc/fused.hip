@@ -116,6 +116,9 @@ struct crabml_hip_llama {
   int* state = nullptr;      // token, pos, step, sink, serial (never reset), fault
   unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
   unsigned long long* hgran = nullptr;  // fused FFN: hidden/4 quant granules + hidden/32 scale granules of h
+  unsigned long long* a8gran = nullptr;  // Q4_K layers: granules of the attention output (dim_l) and of h (hidden_l), through which
+  unsigned long long* h8gran = nullptr;  // the producing kernels assemble Q8_K super-blocks (q8k_exchange_store)
+  bool q8k_producers = false;            // attention / gate-up emit the Q8_K planes of wo's / ffn_down's rhs themselves
   bool ffn_fused = false;               // gate/up + ffn_down as one launch (k_ffn)
   unsigned tp_salt = 0;      // P2P group: epoch salt of this context (see TpP2P::salt)
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
@@ -224,7 +227,7 @@ void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned shor
 }
 
 void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, void* xisum, const PrefetchPlan& pf,
-                       int spare, bool prof) {
+                       int spare, bool prof, const AttnQ8K* k8 = nullptr) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
   const int hd = c->hd, seq_cap = (int)c->cfg.seq_len, n_heads = c->n_heads_l, n_kv = c->n_kv_l;
@@ -245,11 +248,11 @@ void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned sho
   if (c->attn_s_rows > 0 && hd == 128)
     launch_k(st, AR, k_attn_s<128>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
              (const unsigned short*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd, seq_cap,
-             c->attn_s_rows, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
+             c->attn_s_rows, pf, k8 ? 2 : c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr, k8 ? *k8 : AttnQ8K{});
   else if (c->attn_s_rows > 0)
     launch_k(st, AR, k_attn_s<0>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
              (const unsigned short*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd, seq_cap,
-             c->attn_s_rows, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
+             c->attn_s_rows, pf, k8 ? 2 : c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr, k8 ? *k8 : AttnQ8K{});
   else if (c->cfg.use_f16_kv_cache)
     launch_k(st, AR, k_attn<true>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
              (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
@@ -583,9 +586,11 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
   // the rhs of wo / ffn_down quantized by the consuming kernel itself (no quantizer launch)
   const bool qin = nepi && !(g.flags & CRABML_HIP_LLAMA_NO_RHS_PROLOGUE) && dim_l % 256 == 0 && hidden_l % 256 == 0;
+  const bool qout = qin && c->q8k_producers;  // attention / gate-up write the planes, wo / ffn_down copy them
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only); xin: the f32 rhs
+  // qmode: 0 = rhs planes from global memory, 1 = quantize the f32 rhs in the kernel's prologue, 2 = copy finished planes
   auto gemv_out = [&](const crabml_hip_buf* w, const Act& a, const float* xin, int k, uint32_t stage, const float* wnext,
-                      float eps_next) -> int {
+                      float eps_next, int qmode) -> int {
     CH_TRY(P0(stage, dim, k));
     if constexpr (FMT == CRABML_HIP_Q4_K) {
       if (nepi) {
@@ -599,18 +604,22 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
                           : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
                                                                             : 1;
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
-        if (split == 2 && qin)
-          launch_k(st, R, k_gemv_res_nq<FMT, 2, true>, dim3(dim / 16), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE, six(w), NoTp{});
+#define CRABML_NQ_K(SPLIT_, QIN_, GRID_, LDS_)                                                                                          \
+  launch_k(st, R, k_gemv_res_nq<FMT, SPLIT_, QIN_>, dim3(GRID_), dim3(1024), LDS_, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob, \
+           ng, k / BE, six(w), NoTp{})
+        if (split == 2 && qmode == 2)
+          CRABML_NQ_K(2, 2, dim / 16, lds);
+        else if (split == 2 && qmode == 1)
+          CRABML_NQ_K(2, 1, dim / 16, lds);
         else if (split == 2)
-          launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE, six(w), NoTp{});
-        else if (qin)
-          launch_k(st, R, k_gemv_res_nq<FMT, 1, true>, dim3(dim / 32), dim3(1024), lds, planes_k(w), a, xin, c->x, wnext, eps_next, oq,
-                   od, ob, ng, k / BE, six(w), NoTp{});
+          CRABML_NQ_K(2, 0, dim / 16, 0);
+        else if (qmode == 2)
+          CRABML_NQ_K(1, 2, dim / 32, lds);
+        else if (qmode == 1)
+          CRABML_NQ_K(1, 1, dim / 32, lds);
         else
-          launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob,
-                   ng, k / BE, six(w), NoTp{});
+          CRABML_NQ_K(1, 0, dim / 32, 0);
+#undef CRABML_NQ_K
         return P1();
       }
     }
@@ -648,16 +657,37 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
              planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]));
     CH_TRY(P1());
-    enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
+    // Q8_K producers: the (short-context) attention kernel assembles the planes of wo's rhs itself; wo copies them
+    const bool aq8 = qout && (g.flags & CRABML_HIP_LLAMA_Q8K_ATTN_PRODUCER) && c->attn_variant == 0 && c->attn_s_rows > 0;
+    if constexpr (FMT == CRABML_HIP_Q4_K) {
+      if (aq8) {
+        const ActLayout ala = act_layout(QT, (size_t)dim_l);
+        const AttnQ8K k8{Q8KExchange{c->a8gran, c->state + 4, c->state + 5, n_segments(c), seg}, (float*)(c->act_attn + ala.off_d),
+                         (short*)(c->act_attn + ala.off_aux)};
+        enqueue_attention(c, l, (signed char*)c->act_attn, nullptr, nullptr, PrefetchPlan{}, 0, prof, &k8);
+      } else {
+        enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
+      }
+    } else {
+      enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
+    }
     if (!qin) launch_quantize_act(st, QT, c->attn, (size_t)dim_l, c->act_attn);
-    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), c->attn, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
+    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), c->attn, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f, aq8 ? 2 : qin ? 1 : 0));
   } else {
     if (!nepi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, QT);  // llama2.rs:611
     CH_TRY(P0(3, 2.0 * hidden_l, dim));
     if constexpr (FMT == CRABML_HIP_Q4_K) {
       const size_t lds = (size_t)dim + (size_t)(dim / 256) * 4 + (size_t)(dim / 16) * 2;
-      launch_k(st, R, k_gateup_k_lds, dim3((hidden_l + 31) / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
-               act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256);
+      const ActLayout alh = act_layout(QT, (size_t)hidden_l);
+      const Q8KExchange hx{c->h8gran, c->state + 4, c->state + 5, n_segments(c), seg};
+      if (qout)
+        launch_k(st, R, k_gateup_k_lds<true>, dim3(hidden_l / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
+                 act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
+                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux));
+      else
+        launch_k(st, R, k_gateup_k_lds<false>, dim3((hidden_l + 31) / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
+                 act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)nullptr,
+                 (float*)nullptr, (short*)nullptr);
     } else {
       launch_k(st, R, k_gateup<FMT>, dim3((hidden_l + 1) / 2), dim3(128), 0, planes_k(c->gate[l]), planes_k(c->up[l]),
                act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / BE);
@@ -665,7 +695,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     CH_TRY(P1());
     if (!qin) launch_quantize_act(st, QT, c->h, (size_t)hidden_l, c->act_hid);
     CH_TRY(gemv_out(c->down[l], act_k(c->act_hid, hidden_l), c->h, hidden_l, 4,
-                    (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr, g.rms_norm_eps));
+                    (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr, g.rms_norm_eps, qout ? 2 : qin ? 1 : 0));
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
@@ -1327,6 +1357,12 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   }
   c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
                   !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) && g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
+  c->q8k_producers = c->norm_epi_k && !(g.flags & (CRABML_HIP_LLAMA_NO_RHS_PROLOGUE | CRABML_HIP_LLAMA_NO_Q8K_PRODUCERS)) && dim_l % 256 == 0 &&
+                     hidden_l % 256 == 0 && (hd == 64 || hd == 128 || hd == 256) && (int)(hidden_l / 32) <= 2 * dev->n_cu;
+  if (c->q8k_producers) {
+    A(dim_l * 8, (void**)&c->a8gran);
+    A(hidden_l * 8, (void**)&c->h8gran);
+  }
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);
@@ -1352,6 +1388,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 8 * sizeof(int), dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (g.embedding_dim / 16 + g.embedding_dim) * 8, dev->stream);
     if (e == hipSuccess && c->hgran) e = hipMemsetAsync(c->hgran, 0, (hidden_l / 4 + hidden_l / 32) * 8, dev->stream);
+    if (e == hipSuccess && c->a8gran) e = hipMemsetAsync(c->a8gran, 0, dim_l * 8, dev->stream);
+    if (e == hipSuccess && c->h8gran) e = hipMemsetAsync(c->h8gran, 0, hidden_l * 8, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) {
       crabml_hip_llama_destroy(c);

@@ -192,13 +192,20 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
 // q rounded to f16, f32 accumulation in k order (buf_f16.rs:83-97), softmax_row, f16-accumulated PV in position order
 // (buf_f16.rs:152-163).  f16 cache, head_dim % 8 == 0; serves positions < S (the rows the launch has LDS for).
 // K rows are padded by 16 bytes: a 16-lane group of ds_read_b128 then covers all 64 banks once (272 B = 68 dwords = 4 mod 64).
+// q81 = 2: the output leaves as Q8_K planes (xq = quants, k8.d / k8.bs = scales / 16-element sums): the heads of a 256-element
+// super-block exchange their columns as granules (q8k_exchange_store); head_dim in {64, 128, 256}.
+struct AttnQ8K {
+  Q8KExchange ex;
+  float* d;
+  short* bs;
+};
 template <int HD, bool STAMP = false>  // HD: head_dim when known at compile time (128: the score loop is fully unrolled), 0 = run time
 __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, const unsigned short* __restrict__ kc,
                                                 const unsigned short* __restrict__ vc, const int* __restrict__ pos_d,
                                                 const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
                                                 signed char* __restrict__ xq, unsigned short* __restrict__ xd,
                                                 void* __restrict__ xisum, int n_heads, int n_kv, int hd_rt, int seq_cap, int S,
-                                                PrefetchPlan pf, int q81, long long* __restrict__ stamps) {
+                                                PrefetchPlan pf, int q81, long long* __restrict__ stamps, AttnQ8K k8) {
   if ((int)blockIdx.x >= n_heads) {
     prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
     return;
@@ -383,8 +390,17 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
     *(f32x2*)(out + head * hd + 2 * tid) = f32x2{v0, v1};
   }
   stamp(4);
-  // ---- quantize the head's output for wo: a 32-element block = the 16 lanes of one DPP row (two columns each)
-  if (xq != nullptr && wave * 64 < npair) {  // whole waves (hd % 32 == 0 here: rows of 16 lanes are all-live or all-dead)
+  if (xq != nullptr && q81 == 2) {
+    // Q8_K rhs for wo (Q4_K layers): the head's columns go to LDS (the q staging area is free by now), wave 0 exchanges
+    // them with the other heads of the super-block and stores this head's share of the planes
+    if (tid < npair) {
+      qs[2 * tid] = v0;
+      qs[2 * tid + 1] = v1;
+    }
+    __syncthreads();
+    if (wave == 0) q8k_exchange_store(k8.ex, qs, head * hd, hd, lane, xq, k8.d, k8.bs);
+  } else if (xq != nullptr && wave * 64 < npair) {
+  // ---- quantize the head's output for wo: a 32-element block = the 16 lanes of one DPP row (two columns each)  // whole waves (hd % 32 == 0 here: rows of 16 lanes are all-live or all-dead)
     const bool live = tid < npair;
     const float a0 = live ? v0 : 0.f, a1 = live ? v1 : 0.f;
     const float amax = row16_max_f32(fmaxf(fabsf(a0), fabsf(a1)));

@@ -50,6 +50,61 @@ __device__ __forceinline__ void store_qaux(void* aux, int blk, int v) {
     ((int*)aux)[blk] = v;
 }
 
+// ---- Q8_K planes straight from the kernels that produce the vector ------------------------------------------------------
+// A Q8_K super-block is 256 elements and its scale comes from the FIRST element of maximal |x| among them
+// (buf_q8_k.rs:84-131), but the producers own less: an attention workgroup one head (head_dim values), a gate/up workgroup
+// 32 rows.  Every producer publishes its values as 8-byte {f32, epoch} granules (one write-through store carries data and
+// tag), gathers the rest of its super-block from its neighbours' granules (bounded polls), runs the whole block's quantizer
+// (q8k_wave_quant: the arithmetic of the stand-alone quantizer launch, bit for bit) and stores the part that is its own.
+// The consuming GEMV then only copies finished planes into LDS instead of quantizing the f32 vector in its prologue
+// (56 super-blocks per workgroup for ffn_down).  All producers of a super-block are co-resident by construction.
+struct Q8KExchange {
+  unsigned long long* gran;  // one granule per element of the vector
+  const int* serial;         // decode-step serial number (never reset): epoch = serial * nseg + seg + 1
+  int* fault;
+  int nseg, seg;
+};
+// called by ONE whole wave.  own: this workgroup's n_own consecutive values (LDS), the first of which is element `first` of
+// the vector; n_own divides 256 and is a multiple of 16.  oq / od / obs: the Q8_K planes of the vector (q | d | bsums).
+__device__ __forceinline__ void q8k_exchange_store(const Q8KExchange& ex, const float* own, int first, int n_own, int lane,
+                                                   signed char* __restrict__ oq, float* __restrict__ od, short* __restrict__ obs) {
+  const unsigned epoch = (unsigned)(*ex.serial) * (unsigned)ex.nseg + (unsigned)ex.seg + 1u;
+  if (n_own < 256) {
+    for (int i = lane; i < n_own; i += 64)
+      __hip_atomic_store(ex.gran + first + i, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, own[i]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granules are on their way before the polls queue up behind them
+  }
+  const int sb = first >> 8, e0 = sb * 256 + 4 * lane;  // this lane's four elements of the super-block
+  const bool mine = e0 >= first && e0 < first + n_own;
+  f32x4 v;
+  if (mine) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = own[e0 - first + i];
+  } else {
+    unsigned long long g[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) g[i] = __hip_atomic_load(ex.gran + e0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int tries = 0;
+      while ((unsigned)(g[i] >> 32) != epoch && tries < (1 << 21)) {
+        __builtin_amdgcn_s_sleep(2);
+        g[i] = __hip_atomic_load(ex.gran + e0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tries++;
+      }
+      if ((unsigned)(g[i] >> 32) != epoch) *ex.fault = 1;  // a neighbour never arrived: flagged, not hung
+      v[i] = __builtin_bit_cast(float, (unsigned)g[i]);
+    }
+  }
+  const Q8KLane o = q8k_wave_quant(v, lane);
+  if (mine) {
+    ((unsigned*)oq)[sb * 64 + lane] = o.packed;
+    if ((lane & 3) == 0) obs[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
+  }
+  if (lane == 0 && first == sb * 256) od[sb] = o.d;
+}
+
 // ---- weight prefetch into the Infinity Cache ---------------------------------------------------------
 // The norm+quantize and attention stages are latency-bound single-/few-workgroup kernels: HBM idles for
 // ~6-8 us while they run.  Spare workgroups of those launches (one per otherwise idle CU) stream the NEXT

@@ -151,6 +151,15 @@ __device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int
   __syncthreads();
 }
 
+// the finished Q8_K planes of a vector (written by the kernel that produced it: q8k_exchange_store) copied into LDS:
+// coalesced 16-byte pieces, one round trip
+__device__ __forceinline__ void stage_copy_q8k(const ActQ8_K& act, int nsb, i32x4* sq, float* sd, short* sbs) {
+  for (int i = threadIdx.x; i < nsb * 16; i += blockDim.x) sq[i] = act.q[i];
+  for (int i = threadIdx.x; i < nsb; i += blockDim.x) sd[i] = act.d[i];
+  for (int i = threadIdx.x; i < nsb * 2; i += blockDim.x) ((i32x4*)sbs)[i] = ((const i32x4*)act.bsums)[i];
+  __syncthreads();
+}
+
 struct NormGather {
   unsigned long long* slots;  // dim/16 granules: each workgroup's ordered sum of squares over its rows
   unsigned long long* pair;   // dim row granules (read by a split chunk's partner / a Q8_K super-block's neighbours)
@@ -300,7 +309,9 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
   }
 }
 
-template <int FMT, int SPLIT, bool QIN = false, bool TP = false>
+// QIN (Q4_K): 0 = the rhs planes are read from global memory; 1 = the rhs arrives as f32 (xin) and is quantized into LDS
+// by this workgroup; 2 = the finished planes (act) are copied into LDS
+template <int FMT, int SPLIT, int QIN = 0, bool TP = false>
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
@@ -338,7 +349,10 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     // the first weight pieces are requested before the prologue (they do not depend on it): its L2 round trip
     // and the quantizer run under the HBM latency of the stream's head
     if (w6.base != nullptr) {  // this layer's matrix is Q6_K (a *_K_M mix): same rhs, its own inner loop
-      stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
+      if constexpr (QIN == 2)
+        stage_copy_q8k(act, nb, lds_act, sd, sbs);
+      else
+        stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
       const ActQ8_K la6{lds_act, sd, sbs};
       rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
       nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
@@ -353,7 +367,10 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
 #pragma unroll
       for (int r = 0; r < RW; r++) pw[it][r] = q4k_load<false>(w.q, (const i32x4*)w.d, (size_t)(row + r), nb, c < nb * 8 ? c : nb * 8 - 1, lane);
     }
-    stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
+    if constexpr (QIN == 2)
+      stage_copy_q8k(act, nb, lds_act, sd, sbs);
+    else
+      stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
     const ActQ8_K la{lds_act, sd, sbs};
 #pragma unroll
     for (int r = 0; r < RW; r++) acc[r] = 0.f;
@@ -420,8 +437,12 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename A
 // Q4_K gate/up with the Q8_K activation planes staged in LDS once per workgroup (1024 threads = 32 hidden rows x
 // {gate, up}): the per-lane activation reads (2 x 16 B + d + 2 bsums per 16 B of quants) leave the vector-memory
 // path, which the K-quant inner loop otherwise keeps ~57 % busy (rocprofv3 TA_BUSY) while VALU sits at 15 %.
+// QOUT: h leaves the kernel as Q8_K planes (the rhs of ffn_down) as well: the eight workgroups of a 256-row super-block exchange
+// their rows as granules (q8k_exchange_store); hidden % 256 == 0.
+template <bool QOUT>
 __global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
-                                                       float* __restrict__ h, int m, int nsb) {
+                                                       float* __restrict__ h, int m, int nsb, Q8KExchange ex, signed char* __restrict__ oq,
+                                                       float* __restrict__ od, short* __restrict__ obs) {
   extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
   const int k = nsb * 256;
   i32x4* sq = lds_act;
@@ -438,10 +459,19 @@ __global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, Act
   float ag[2], au[2];
   rows_partial_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag);
   rows_partial_q4k<2, false>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
+  __shared__ float hv[32];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const float g = wave_sum_f32(ag[r]), u = wave_sum_f32(au[r]);
-    if (lane == 0 && row0 + r < m) h[row0 + r] = silu_mul(g, u, exp_tab);
+    if (lane == 0 && row0 + r < m) {
+      const float hval = silu_mul(g, u, exp_tab);
+      h[row0 + r] = hval;
+      if (QOUT) hv[wave * 2 + r] = hval;
+    }
+  }
+  if constexpr (QOUT) {
+    __syncthreads();
+    if (wave == 0) q8k_exchange_store(ex, hv, (int)blockIdx.x * 32, 32, lane, oq, od, obs);
   }
 }
 

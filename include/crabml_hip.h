@@ -217,6 +217,10 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
 #define CRABML_HIP_LLAMA_TP_DRY_RUN 128 /* measurement hook: a lone tp rank (tp_comm = NULL) steps with its all-reduces
                                           skipped -- per-rank kernel time of a tp group; the logits are meaningless */
 #define CRABML_HIP_LLAMA_NO_LONG_ATTENTION 64 /* A/B: one attention workgroup per head at every context length */
+#define CRABML_HIP_LLAMA_NO_Q8K_PRODUCERS 32768 /* A/B: Q4_K layers quantize the rhs of wo / ffn_down in those kernels' prologues instead
+                                                  of receiving finished Q8_K planes from attention / gate-up (bit-identical) */
+#define CRABML_HIP_LLAMA_Q8K_ATTN_PRODUCER 65536 /* A/B, opt-in: the staged attention kernel also assembles wo's Q8_K planes (pairs of heads
+                                                   exchange their outputs); measured slower than wo's own 4096-element prologue */
 #define CRABML_HIP_LLAMA_NO_PV_ROW_TILES 16384 /* A/B: long-prompt prefill runs the PV pass one prompt row per workgroup */
 #define CRABML_HIP_LLAMA_NO_STAGED_ATTENTION 8192 /* A/B: short-context attention without the LDS staging of K / V (k_attn) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */

@@ -248,8 +248,10 @@ def test_q4_k_fused_kernels_equal_the_per_op_segments(ca, fmt):
 
 
 # 16 = SPLIT_CHUNKS_ALWAYS: the two-workgroup chunk hand-off; 1024 = NO_RHS_PROLOGUE: wo / ffn_down read Q8_K planes
-# from a quantizer launch instead of quantizing the f32 attention output / h themselves
-@pytest.mark.parametrize("flags", [0, 16, 1024, 1024 + 16])
+# from a quantizer launch instead of quantizing the f32 attention output / h themselves; 32768 = NO_Q8K_PRODUCERS: ffn_down
+# quantizes h in its prologue instead of copying the planes the gate/up kernel assembled; 65536 = Q8K_ATTN_PRODUCER: the
+# staged attention kernel assembles wo's planes as well
+@pytest.mark.parametrize("flags", [0, 16, 1024, 1024 + 16, 32768, 32768 + 16, 65536, 65536 + 16])
 def test_q4_k_norm_epilogue_equals_the_quantizer_launches(ca, flags):
     """Q4_K layers: RMSNorm + the Q8_K quantizer of the next GEMV run in the wo / ffn_down epilogue.  A Q8_K
     super-block (buf_q8_k.rs:84-131: scale from the FIRST element of maximal |x| of 256) spans eight 32-row
@@ -279,6 +281,12 @@ def test_q4_k_hand_offs_under_load_llama3_8b_shape(ca):
     assert list(ta) == list(tb)
     la, lb = a.forward(int(ta[-1]), 300), b.forward(int(tb[-1]), 300)
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    # the Q8_K planes of ffn_down's rhs assembled by gate/up (default), by ffn_down itself (32768), and wo's by the
+    # attention kernel (65536): the same bits at 448 / 32 exchanging workgroups
+    for fl in (32768, 65536):
+        c = ca.HipLlamaRunner(conf, w, dev, 320, True, extra_flags=fl)
+        assert list(c.decode_greedy(1, 300)) == list(ta), fl
+        assert np.array_equal(c.forward(int(ta[-1]), 300).view(np.uint32), la.view(np.uint32)), fl
 
 
 @pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1"])
@@ -311,6 +319,12 @@ def test_fused_ffn_under_load_llama3_8b_shape(ca):
     assert list(ta) == list(tb)
     la, lb = a.forward(int(ta[-1]), 300), b.forward(int(tb[-1]), 300)
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    # the Q8_K planes of ffn_down's rhs assembled by gate/up (default), by ffn_down itself (32768), and wo's by the
+    # attention kernel (65536): the same bits at 448 / 32 exchanging workgroups
+    for fl in (32768, 65536):
+        c = ca.HipLlamaRunner(conf, w, dev, 320, True, extra_flags=fl)
+        assert list(c.decode_greedy(1, 300)) == list(ta), fl
+        assert np.array_equal(c.forward(int(ta[-1]), 300).view(np.uint32), la.view(np.uint32)), fl
 
 
 def test_in_launch_hand_offs_under_load_llama3_8b_shape(ca):

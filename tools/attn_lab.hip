@@ -103,7 +103,7 @@ int main() {
       for (int it = 0; it < 9; it++) {
         const int l = it % L;
         k_attn_s<128, true><<<dim3(n_heads), 256, lds_s, st>>>(q, (const unsigned short*)(kc + l * kvb), (const unsigned short*)(vc + l * kvb), pos_d, d_tab,
-                                                          out, xq, xd, (void*)xs, n_heads, n_kv, hd, seq_cap, S, PrefetchPlan{}, 0, stamps);
+                                                          out, xq, xd, (void*)xs, n_heads, n_kv, hd, seq_cap, S, PrefetchPlan{}, 0, stamps, AttnQ8K{});
         CK(hipStreamSynchronize(st));
         std::vector<long long> s2(10);
         CK(hipMemcpy(s2.data(), stamps, 80, hipMemcpyDeviceToHost));
@@ -119,7 +119,7 @@ int main() {
         for (int it = 0; it < 96; it++) {
           const int l = it % L;
           k_attn_s<128, false><<<dim3(n_heads), 256, lds_s, st>>>(q, (const unsigned short*)(kc + l * kvb), (const unsigned short*)(vc + l * kvb), pos_d, d_tab,
-                                                             out, xq, xd, (void*)xs, n_heads, n_kv, hd, seq_cap, S, PrefetchPlan{}, 0, nullptr);
+                                                             out, xq, xd, (void*)xs, n_heads, n_kv, hd, seq_cap, S, PrefetchPlan{}, 0, nullptr, AttnQ8K{});
         }
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
