@@ -141,6 +141,7 @@ struct crabml_hip_llama {
   int attn_variant = 0;         // which of the two the next enqueue emits
   bool attn_long_ok = false;    // f16 cache, head_dim % 32 == 0, group size in {1, 2, 4, 8}, seq_len % 8 == 0
   size_t attn_long_from = 0;    // cached positions (pos + 1) from which variant 1 is used
+  bool pv_split = false;        // variant 1: k_attn_pv_split (products by producer waves) instead of k_attn_pv
   int attn_s_rows = 0;          // > 0: variant 0 runs k_attn_s (K / V staged through LDS) with room for this many cached rows
   size_t attn_s_lds = 0;
   float* scores_g = nullptr;    // [n_heads_l][seq_len] f32
@@ -218,10 +219,15 @@ void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned shor
     if (prof) prof_begin(dev, &r[i], CRABML_HIP_F32, 7 + i, 0.0);  // stages 7 / 8 / 9: scores / softmax / pv
   launch_k(st, prof ? &r[0] : nullptr, k_attn_scores<G>, dim3(n_kv * nsplit), dim3(256), (size_t)G * hd * sizeof(float),
            (const float*)c->qbuf, (const unsigned short*)c->kc[l], pos_d, c->scores_g, n_kv, hd, seq_cap, nsplit, 0);
-  launch_k(st, prof ? &r[1] : nullptr, k_attn_softmax, dim3(c->n_heads_l), dim3(256), (size_t)seq_cap * sizeof(float),
+  launch_k(st, prof ? &r[1] : nullptr, k_attn_softmax<16>, dim3(c->n_heads_l), dim3(1024), (size_t)seq_cap * sizeof(float),
            (const float*)c->scores_g, pos_d, (const unsigned short*)dev->exp_table, c->p16, seq_cap, 0);
-  launch_k(st, prof ? &r[2] : nullptr, k_attn_pv<G>, dim3(n_kv * (hd / 32)), dim3(256), 0, (const unsigned short*)c->p16,
-           (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, 0);
+  if (c->pv_split)
+    launch_k(st, prof ? &r[2] : nullptr, k_attn_pv_split<G>, dim3(n_kv * (hd / 32) * PvSplit<G>::NSUB), dim3(PvSplit<G>::THREADS), PvSplit<G>::LDS,
+             (const unsigned short*)c->p16, (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap,
+             c->qt == CRABML_HIP_Q8_1 ? 1 : 0, 0);
+  else
+    launch_k(st, prof ? &r[2] : nullptr, k_attn_pv<G>, dim3(n_kv * (hd / 32)), dim3(256), 0, (const unsigned short*)c->p16,
+             (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, 0);
   for (int i = 0; i < 3; i++)
     if (prof) prof_end(dev, &r[i]);
 }
@@ -842,7 +848,7 @@ int launch_attn_long_rows_t(crabml_hip_llama* c, int l, int B) {
     const unsigned rows = (unsigned)(B - r0 < PF_LONG_ROWS ? B - r0 : PF_LONG_ROWS);
     k_attn_scores<G><<<dim3(n_kv * nsplit, rows), 256, (size_t)G * hd * sizeof(float), st>>>(
         (const float*)c->pf_qr, (const unsigned short*)c->kc[l], pos_d, c->pf_scores, n_kv, hd, seq_cap, nsplit, r0);
-    k_attn_softmax<<<dim3(n_heads, rows), 256, (size_t)seq_cap * sizeof(float), st>>>(
+    k_attn_softmax<4><<<dim3(n_heads, rows), 256, (size_t)seq_cap * sizeof(float), st>>>(
         (const float*)c->pf_scores, pos_d, (const unsigned short*)dev->exp_table, c->pf_p16, seq_cap, r0);
     // PV for R prompt rows per workgroup (one V fetch for R x G chains); G = 8 fills the lanes with two rows
     constexpr int PR = G == 8 ? 2 : 4;
@@ -1331,6 +1337,17 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     if (c->attn_long_ok) {
       A(n_heads_l * g.seq_len * 4, (void**)&c->scores_g);
       A(n_heads_l * g.seq_len * 2, (void**)&c->p16);
+      if (!(g.flags & CRABML_HIP_LLAMA_NO_PV_PRODUCER_WAVES) && g.seq_len % 4 == 0) {
+        hipError_t e = hipErrorInvalidValue;
+        switch (grp) {
+          case 1: e = hipFuncSetAttribute((const void*)k_attn_pv_split<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<1>::LDS); break;
+          case 2: e = hipFuncSetAttribute((const void*)k_attn_pv_split<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<2>::LDS); break;
+          case 4: e = hipFuncSetAttribute((const void*)k_attn_pv_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<4>::LDS); break;
+          default: e = hipFuncSetAttribute((const void*)k_attn_pv_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<8>::LDS); break;
+        }
+        c->pv_split = e == hipSuccess;
+        (void)hipGetLastError();
+      }
     }
     // short-context attention with K / V staged through LDS (f16 cache): variant 0 serves positions < S
     if (g.use_f16_kv_cache && hd % 8 == 0 && !(g.flags & CRABML_HIP_LLAMA_NO_STAGED_ATTENTION)) {

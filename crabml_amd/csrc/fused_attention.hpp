@@ -498,19 +498,20 @@ __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q
   scores_g[(size_t)(j * G + g) * seq_cap + t] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ scores_g, const int* __restrict__ pos_d,
-                                                      const unsigned short* __restrict__ exp_tab,
-                                                      unsigned short* __restrict__ p16, int seq_cap, int row0) {
+template <int NW>  // waves per workgroup: 4, or 16 for the decode step's one row per head
+__global__ __launch_bounds__(NW * 64) void k_attn_softmax(const float* __restrict__ scores_g, const int* __restrict__ pos_d,
+                                                         const unsigned short* __restrict__ exp_tab,
+                                                         unsigned short* __restrict__ p16, int seq_cap, int row0) {
   extern __shared__ float lds[];
-  __shared__ float s_red[4];
+  __shared__ float s_red[NW];
   __shared__ float s_val;
   const int head = blockIdx.x, seq = *pos_d + 1 + row0 + (int)blockIdx.y;
   scores_g += (size_t)blockIdx.y * gridDim.x * seq_cap;
   p16 += (size_t)blockIdx.y * gridDim.x * seq_cap;
-  for (int t = threadIdx.x; t < seq; t += blockDim.x) lds[t] = scores_g[(size_t)head * seq_cap + t];
+  for (int t = threadIdx.x; t < seq; t += NW * 64) lds[t] = scores_g[(size_t)head * seq_cap + t];
   __syncthreads();
-  softmax_row<true>(lds, seq, exp_tab, s_red, &s_val);
-  for (int t = threadIdx.x; t < seq; t += blockDim.x) p16[(size_t)head * seq_cap + t] = f2h(lds[t]);  // exact: already f16 values
+  softmax_row<true, NW>(lds, seq, exp_tab, s_red, &s_val);
+  for (int t = threadIdx.x; t < seq; t += NW * 64) p16[(size_t)head * seq_cap + t] = f2h(lds[t]);  // exact: already f16 values
 }
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -642,6 +643,177 @@ __global__ __launch_bounds__(256) void k_attn_pv(const unsigned short* __restric
         store_qaux<true>(xisum, e0 >> 5, (int)f2h((float)qs * dd));
       else
         store_qaux<false>(xisum, e0 >> 5, qs);
+    }
+  }
+}
+
+
+// ---- the PV pass with the products made by other waves ------------------------------------------------------------------
+// A column's value is ONE f16 chain over the cached positions: c <- fl16(c + fl16(p_t * v_t)) (the half crate's product and
+// sum roundings, in t order); that order is the result, so the pass cannot be split over positions, and its floor is the
+// dependent-issue latency of the add: 10.4 cycles for v_pk_add_f16, 6-7 for v_add_f16 (tools/valu_chain_lab.hip).
+// k_attn_pv's chain wave multiplies, adds packed pairs and waits for its own LDS reads: 21 cycles per position (37 us per
+// layer at 4096 positions, Llama-3-8B).  Here a chain lane owns ONE column and only adds (v_add_f16, the high halves through
+// SDWA selects): four producer waves read V and P straight from global memory (three tiles ahead, in registers), round the
+// packed products and lay them out in LDS per column -- prod[column][t], rows of 2 T + 16 bytes so that the lanes'
+// ds_read_b128 (eight positions) are conflict-free -- and the chain wave reads 64 positions ahead of its adds.  A workgroup
+// carries two heads x 32 columns (64 chains = one wave; fewer chains per workgroup = less LDS traffic per position, which is
+// what bounded the four-head version): grid = kv heads x 32-column slices x G / 2.  Measured 8-9 cycles per position + 5 us
+// (profiles/r02_pv_lab_chain_breakdown.log).  Same products, same order as k_attn_pv: bit-identical (tests).
+template <int G>
+struct PvSplit {
+  static constexpr int HG = G >= 2 ? 2 : 1;         // heads per workgroup
+  static constexpr int NSUB = G / HG;
+  static constexpr int T = 256;                     // positions per tile
+  static constexpr int ROWB = T * 2 + 16;           // bytes per chain row
+  static constexpr int CHAINS = HG * 32;
+  static constexpr int THREADS = 5 * 64;            // one chain wave + four producer waves
+  static constexpr int D = 3;                       // tiles of loads in flight per producer thread
+  static constexpr size_t LDS = (size_t)2 * CHAINS * ROWB;
+};
+template <int G>
+__global__ __launch_bounds__(320) void k_attn_pv_split(const unsigned short* __restrict__ p16, const unsigned short* __restrict__ vc,
+                                                       const int* __restrict__ pos_d, float* __restrict__ out,
+                                                       signed char* __restrict__ xq, unsigned short* __restrict__ xd,
+                                                       void* __restrict__ xisum, int hd, int seq_cap, int q81, int row0) {
+  typedef PvSplit<G> C;
+  constexpr int T = C::T, ROWB = C::ROWB, CH = C::CHAINS, D = C::D, HG = C::HG, NSUB = C::NSUB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char prodb[];  // [2][CH][ROWB]
+  const int tid = threadIdx.x;
+  const int nslice = hd / 32;
+  const int hsub = blockIdx.x % NSUB;
+  const int j = blockIdx.x / NSUB / nslice, sl = blockIdx.x / NSUB % nslice;
+  const int seq = *pos_d + 1 + row0 + (int)blockIdx.y;
+  {  // blockIdx.y: row of a prefill batch (xq is null there)
+    const size_t n_heads = (size_t)(gridDim.x / NSUB / nslice) * G;
+    p16 += (size_t)blockIdx.y * n_heads * seq_cap;
+    out += (size_t)(row0 + blockIdx.y) * n_heads * hd;
+  }
+  const int ntiles = (seq + T - 1) / T;
+  // Both roles run `nround` tile slots (a multiple of D) so that the producer loop is branch-free: a conditional issue or
+  // commit makes the compiler's wait-count analysis assume the shortest path and drain ALL loads before every commit
+  // (measured: one memory round trip per tile).  Tiles past the last one are clamped reads inside the cache and products
+  // written to the buffer nobody reads any more.
+  const int nround = (ntiles + D - 1) / D * D;
+  if (tid >= 64) {
+    // ---- producer: work item = (8-column piece q of the slice, four consecutive positions) of each tile
+    const int pt = tid - 64;
+    const int q = pt & 3, tg = pt >> 2;
+    const unsigned short* vbase = vc + (size_t)j * seq_cap * hd + sl * 32 + q * 8;
+    const unsigned short* pbase = p16 + (size_t)(j * G + hsub * HG) * seq_cap;
+    i32x4 vr[D][4];
+    unsigned long long pr[D][HG];
+    auto issue = [&](int tile, int s) {
+      long long t0 = (long long)tile * T + 4 * tg;
+      t0 = t0 + 4 <= seq_cap ? t0 : seq_cap - 4;  // past the end of the cache: never consumed
+#pragma unroll
+      for (int r = 0; r < 4; r++) vr[s][r] = *(const i32x4*)(vbase + (size_t)(t0 + r) * hd);
+#pragma unroll
+      for (int g = 0; g < HG; g++) pr[s][g] = *(const unsigned long long*)(pbase + (size_t)g * seq_cap + t0);
+    };
+    auto commit = [&](int buf, int s) {
+      unsigned char* pb = prodb + (size_t)buf * CH * ROWB + 8 * tg;
+#pragma unroll
+      for (int g = 0; g < HG; g++) {
+        unsigned pp[4];  // {p, p} of the four positions
+        const unsigned lo = (unsigned)pr[s][g], hi = (unsigned)(pr[s][g] >> 32);
+        pp[0] = (lo & 0xffffu) | (lo << 16);
+        pp[1] = (lo >> 16) | (lo & 0xffff0000u);
+        pp[2] = (hi & 0xffffu) | (hi << 16);
+        pp[3] = (hi >> 16) | (hi & 0xffff0000u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          unsigned o[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            o[r] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h16x2, (unsigned)vr[s][r][i]) * __builtin_bit_cast(h16x2, pp[r]));
+          // column 2 i (low halves) and column 2 i + 1 (high halves) of the four positions
+          const unsigned l0 = __builtin_amdgcn_perm(o[1], o[0], 0x05040100u), l1 = __builtin_amdgcn_perm(o[3], o[2], 0x05040100u);
+          const unsigned h0 = __builtin_amdgcn_perm(o[1], o[0], 0x07060302u), h1 = __builtin_amdgcn_perm(o[3], o[2], 0x07060302u);
+          const int rowi = g * 32 + q * 8 + 2 * i;
+          *(unsigned long long*)(pb + (size_t)rowi * ROWB) = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+          *(unsigned long long*)(pb + (size_t)(rowi + 1) * ROWB) = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    commit(0, 0);
+    issue(D, 0);
+    __syncthreads();
+    // tile k is consumed between barrier k and barrier k + 1 while tile k + 1 is committed into the other buffer
+    for (int base = 0; base < nround; base += D) {
+#pragma unroll
+      for (int u = 0; u < D; u++) {
+        const int tile = base + u;  // the chain wave consumes `tile`
+        commit((tile + 1) & 1, (u + 1) % D);
+        issue(tile + 1 + D, (u + 1) % D);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  // ---- chain wave: lane c owns column sl * 32 + (c & 31) of head j * G + hsub * HG + (c >> 5)
+  const bool chain = tid < CH;
+  _Float16 c = (_Float16)0.0f;
+  __syncthreads();
+#define PV_ADD8(w)                                                  \
+  _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                \
+    const h16x2 p_ = __builtin_bit_cast(h16x2, (unsigned)(w)[r_]);  \
+    c = c + p_[0];                                                  \
+    c = c + p_[1];                                                  \
+  }
+  for (int tile = 0; tile < nround; tile++) {
+    if (chain && tile < ntiles) {
+      const int nt = seq - tile * T < T ? seq - tile * T : T;
+      const unsigned char* row = prodb + (size_t)(tile & 1) * CH * ROWB + (size_t)tid * ROWB;
+      int t = 0;
+      if (nt >= 64) {
+        i32x4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = *(const i32x4*)(row + 16 * u);
+        for (; t + 128 <= nt; t += 128) {
+#pragma unroll
+          for (int u = 0; u < 8; u++) b[u] = *(const i32x4*)(row + 2 * (t + 64) + 16 * u);
+#pragma unroll
+          for (int u = 0; u < 8; u++) PV_ADD8(a[u])
+          {  // unconditional (a branch here makes the waits for `b` drain these reads too); only used when t + 192 <= nt
+            const int ta = t + 128 <= T - 64 ? t + 128 : T - 64;
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = *(const i32x4*)(row + 2 * ta + 16 * u);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) PV_ADD8(b[u])
+        }
+        if (t + 64 <= nt) {  // `a` holds positions t .. t + 63
+#pragma unroll
+          for (int u = 0; u < 8; u++) PV_ADD8(a[u])
+          t += 64;
+        }
+      }
+      for (; t + 8 <= nt; t += 8) {
+        const i32x4 v = *(const i32x4*)(row + 2 * t);
+        PV_ADD8(v)
+      }
+      for (; t < nt; t++) c = c + *(const _Float16*)(row + 2 * t);
+    }
+    __syncthreads();
+  }
+#undef PV_ADD8
+  if (!chain) return;
+  const float v = (float)c;
+  const int head = j * G + hsub * HG + (tid >> 5);
+  const int e = head * hd + sl * 32 + (tid & 31);
+  out[e] = v;
+  if (xq != nullptr) {  // the rhs block of the 32 columns held by this half-wave (k_attn_pv's epilogue: quant_lane32's arithmetic)
+    const QLane o = q81 ? quant_lane32<true>(v, true) : quant_lane32<false>(v, true);
+    xq[e] = o.q;
+    if ((tid & 31) == 0) {
+      xd[e >> 5] = o.d;
+      if (q81)
+        store_qaux<true>(xisum, e >> 5, o.aux);
+      else
+        store_qaux<false>(xisum, e >> 5, o.aux);
     }
   }
 }

@@ -403,36 +403,51 @@ __global__ __launch_bounds__(256) void k_qkv_epi_rows(const float* __restrict__ 
   qkv_epilogue(er, qkv_preload(e, row0, r), row0, src[0], src[1]);
 }
 
-// softmax.rs:36-54 over scores[0..seq) in LDS, in place, by a 256-thread workgroup: max, exp through the f16 table,
-// row sum sequential up to 1024 positions (bit-exact) and a block tree beyond, true division.  F16: the
+// softmax.rs:36-54 over scores[0..seq) in LDS, in place, by a workgroup of NW waves (4 or 16): max, exp through the f16
+// table, row sum sequential up to 1024 positions (bit-exact) and a block tree beyond, true division.  F16: the
 // probabilities are then rounded to f16 (quantize_f32_f16 of the lhs, batch_matmul.rs:39).  Ends with a barrier.
-template <bool F16>
+// The tree is defined on 256 partial sums (partial v = positions v, v + 256, ... in order) whatever NW is: 16 waves share
+// the max / exp / division passes (the long-context softmax kernel), the sums are the 4-wave kernel's bit for bit.
+// s_red: NW floats.
+template <bool F16, int NW = 4>
 __device__ __forceinline__ void softmax_row(float* scores, int seq, const unsigned short* __restrict__ exp_tab, float* s_red,
                                             float* s_val_p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int BD = NW * 64;
   float mx = -INFINITY;
-  for (int t = tid; t < seq; t += blockDim.x) mx = fmaxf(mx, scores[t]);
+  for (int t = tid; t < seq; t += BD) mx = fmaxf(mx, scores[t]);
   mx = wave_max_f32(mx);
   if (lane == 0) s_red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  mx = s_red[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_red[w]);
   __syncthreads();
   float part = 0.0f;
   {
-    // the table lookups are independent global gathers: 8 in flight per thread (long rows), summed in t order
-    const int bd = blockDim.x;
+    // the table lookups are independent global gathers: 8 (4) in flight per thread (long rows), summed in t order
     int t = tid;
-    for (; t + 7 * bd < seq; t += 8 * bd) {
+    for (; t + 7 * BD < seq; t += 8 * BD) {
       float ev[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) ev[u] = exp_cached_f(scores[t + u * bd] - mx, exp_tab);
+      for (int u = 0; u < 8; u++) ev[u] = exp_cached_f(scores[t + u * BD] - mx, exp_tab);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        scores[t + u * bd] = ev[u];
+        scores[t + u * BD] = ev[u];
         part += ev[u];
       }
     }
-    for (; t < seq; t += bd) {
+    for (; t + 3 * BD < seq; t += 4 * BD) {
+      float ev[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ev[u] = exp_cached_f(scores[t + u * BD] - mx, exp_tab);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        scores[t + u * BD] = ev[u];
+        part += ev[u];
+      }
+    }
+    for (; t < seq; t += BD) {
       float ev = exp_cached_f(scores[t] - mx, exp_tab);
       scores[t] = ev;
       part += ev;
@@ -452,14 +467,21 @@ __device__ __forceinline__ void softmax_row(float* scores, int seq, const unsign
       if (tid == 0) *s_val_p = sum;
     }
   } else {
-    part = wave_sum_f32(part);
-    if (lane == 0) s_red[wave] = part;
+    if constexpr (NW != 4) {  // the 256 partial sums of the 4-wave tree, from the exponentials in LDS
+      part = 0.0f;
+      if (tid < 256)
+        for (int t = tid; t < seq; t += 256) part += scores[t];
+    }
+    if (NW == 4 || tid < 256) {
+      part = wave_sum_f32(part);
+      if (lane == 0) s_red[wave] = part;
+    }
     __syncthreads();
     if (tid == 0) *s_val_p = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   }
   __syncthreads();
   const float sum = *s_val_p;
-  for (int t = tid; t < seq; t += blockDim.x) {
+  for (int t = tid; t < seq; t += BD) {
     float pv = scores[t] / sum;
     scores[t] = F16 ? h2f(f2h(pv)) : pv;  // quantize_f32_f16 of the lhs (batch_matmul.rs:39), done once
   }

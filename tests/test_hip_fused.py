@@ -173,6 +173,45 @@ def test_fused_errors(ca):
         r.decode_greedy(1, 1)  # cache full
 
 
+@pytest.mark.parametrize("n_kv", [8, 4, 2, 1])
+def test_pv_with_producer_waves_equals_the_single_wave_pass(ca, n_kv):
+    """Long-context decode: k_attn_pv_split (four producer waves round the packed f16 products into LDS, the chain wave only
+    adds) against k_attn_pv (flag 131072: the chain wave multiplies and adds) -- the same f16 chain per column, so every
+    logit is bit-identical, at group sizes 1 / 2 / 4 / 8, across tile boundaries (256 / 128 positions) and every tail
+    length (positions 1 .. 700, logits compared at each step)."""
+    s = synth.ModelShape(f"g{8 // n_kv}", 512, 1024, 2, 8, n_kv, 1024, 64, 1e-5, None)
+    model = synth.build_model(s, synth.Q4_0, seed=43)
+    rng = np.random.default_rng(6)
+    toks = [int(t) for t in rng.integers(0, s.vocab, size=700)]
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    new = ca.HipLlamaRunner(conf, w, dev, 704, True, attn_long_from=1)
+    old = ca.HipLlamaRunner(conf, w, dev, 704, True, attn_long_from=1, extra_flags=131072)
+    for i, t in enumerate(toks):
+        a, b = new.forward(t, i), old.forward(t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"group {8 // n_kv}, step {i}"
+
+
+def test_long_context_kernels_beyond_1024_positions_equal_the_one_workgroup_kernel(ca):
+    """Past 1024 cached positions the softmax row sum is a block tree over 256 partial sums (softmax_row); the decode step's
+    16-wave softmax kernel and the 4-wave one-workgroup-per-head kernel (flag 64) must build the same tree, and the PV pass
+    with producer waves the same f16 chains over five tiles: logits bit-identical at positions 1050 .. 1061."""
+    shape = synth.ModelShape("long", 512, 1024, 2, 8, 2, 1024, 1200)
+    model = synth.build_model(shape, synth.Q8_0, seed=88)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    prompt = [(5 * i + 1) % 1024 for i in range(1050)]
+    runners = [ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=f) for f in (0, 64, 131072)]
+    first = [r.prefill(prompt) for r in runners]
+    assert all(np.array_equal(first[0].view(np.uint32), x.view(np.uint32)) for x in first[1:])
+    tok = int(np.argmax(first[0]))
+    for i in range(12):
+        lg = [r.forward(tok, 1050 + i) for r in runners]
+        for k in (1, 2):
+            assert np.array_equal(lg[0].view(np.uint32), lg[k].view(np.uint32)), (i, k)
+        tok = int(np.argmax(lg[0]))
+
+
 @pytest.mark.parametrize("shape,group", [("tiny-gqa", 4), ("15m", 1)])
 def test_long_context_attention_kernels_are_bit_identical(ca, shape, group):
     """From `attn_long_from` cached positions the step switches to the multi-workgroup attention kernels (scores per
