@@ -18,6 +18,7 @@ ap.add_argument("--n", type=int, default=512)
 ap.add_argument("--chunks", default="64,128,256,512")
 ap.add_argument("--layers", type=int, default=0)
 ap.add_argument("--loop", type=int, default=64, help="tokens of the token-loop baseline")
+ap.add_argument("--flags", type=int, default=0, help="extra CRABML_HIP_LLAMA_* flags (A/B runs)")
 a = ap.parse_args()
 shape = synth.SHAPES[a.model]
 k_m = a.wtype.upper() == "Q4_K_M"  # llama.cpp's mix: Q4_K body, attn_v / ffn_down in Q6_K on some layers, Q6_K classifier
@@ -29,7 +30,7 @@ hd = shape.dim // shape.n_heads
 ops_per_row = 2.0 * L * (shape.dim * shape.dim * 2 + 2 * shape.dim * hd * shape.n_kv_heads + 3 * shape.dim * shape.hidden)
 toks = [(7 * i + 1) % shape.vocab for i in range(a.n)]
 for chunk in [int(c) for c in a.chunks.split(",")]:
-    r = ca.HipLlamaRunner(conf, w, dev, a.n + 8, True, prefill_chunk=chunk)
+    r = ca.HipLlamaRunner(conf, w, dev, a.n + 8, True, prefill_chunk=chunk, extra_flags=a.flags)
     best = None
     for rep in range(2):
         r.reset()
