@@ -207,8 +207,15 @@ __device__ __forceinline__ void norm_quant_block(float* __restrict__ x, const fl
     float sum = 0.0f;
     for (int base = 0; base < nchunks; base += 64) {
       float v = base + tid < nchunks ? L.chunk_sums[base + tid] : 0.0f;
+      if (half) {
+        // fast mode: 64 chunk sums per round through the DPP tree (wave_sum_f32), rounds added in order -- the order of the
+        // wo / ffn_down norm epilogue, where a 128-step dependent v_add chain sat between the last arriving granule and the
+        // quantizer (0.4 us per hop on MI355X: a dependent f32 add issues every ~8 cycles)
+        sum += wave_sum_f32(v);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 64; i++) sum += rl_f(v, i);
+        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
+      }
     }
     if (tid == 0) *s_rms = sqrtf(sum / (float)cols + eps);
   }

@@ -272,15 +272,22 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     v = hv[l32];
   }
   // ... then the hop: every workgroup's sum, added strictly in chunk order
+  // (fast-mode order, shared with norm_quant_block: 64 chunks per round through the DPP tree, rounds added in order)
   float sum = 0.0f;
   const int nwg = nwg_all;
-  for (int base = 0; base < nwg; base += 64) {
-    const int c = base + lane;
-    float cv = c < nwg ? poll(ng.slots + c) : 0.0f;
-    if (SPLIT > 1) cv += dpp_f<0xB1>(cv);  // chunk = its two halves (the same value on both lanes of the pair)
-#pragma unroll
-    for (int i = 0; i < 64; i += SPLIT) sum += rl_f(cv, i);  // lanes past the grid add +0.0
+  for (int base = 0; base < nchunks; base += 64) {
+    const int c = base + lane;  // this lane's chunk
+    float cv;
+    if (SPLIT > 1) {
+      const float h0 = c < nchunks ? poll(ng.slots + 2 * c) : 0.0f;
+      const float h1 = c < nchunks ? poll(ng.slots + 2 * c + 1) : 0.0f;
+      cv = h0 + h1;  // chunk = its two halves
+    } else {
+      cv = c < nchunks ? poll(ng.slots + c) : 0.0f;
+    }
+    sum += wave_sum_f32(cv);  // lanes past the grid add +0.0
   }
+  (void)nwg;
   const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
   if constexpr (!KQ) {
     const float xn = (v / rms) * wn;
