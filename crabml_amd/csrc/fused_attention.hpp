@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
     if (seq < 0) stamps[15] = 0;  // (forces the wait for the scalar load here)
   }
   stamp(7);  // position known
-  if (tid < hd) qs[tid] = h2f(f2h(qv));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+  // quantize_f32_f16(bufa) (batch_matmul.rs:39): q is staged as f16 -- the score chain multiplies f16 by f16 (v_fma_mix_f32)
+  unsigned short* q16 = (unsigned short*)qs;
+  if (tid < hd) q16[tid] = f2h(qv);
   stamp(8);  // q arrived and staged
   // ---- the rest of the rows, now that seq is known (none at the short contexts this kernel is for): all in flight at once
   const int need = seq * ppr;
@@ -288,44 +290,41 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
   __syncthreads();
   stamp(1);
   // ---- scores[t] = q . K[t], f32 accumulation in k order (one cached position per thread)
-  // HD = 128: q lives in two registers per lane (lane l: q[l] and q[64 + l], rounded to f16 as the reference does) and is
-  // handed to the multiply as a scalar by v_readlane; the thread's K row comes out of LDS with 16 reads that are all issued
-  // before the chain starts.  (Reading q from LDS inside the loop cost one LDS round trip per 8 elements: 3600 cycles for
-  // the 128-element dot; the products are the same q[i] * k[i], added in the same k order.)
-  float q_lo = 0.f, q_hi = 0.f;
-  if constexpr (HD == 128) {
-    q_lo = h2f(f2h(q[head * 128 + lane]));
-    q_hi = h2f(f2h(q[head * 128 + 64 + lane]));
-  }
+  // One v_fma_mix_f32 per element: acc <- fl32(q[i] * k[i] + acc) with both factors taken as f16 straight from packed
+  // registers.  That IS the reference's `acc += q[i] * k[i]` bit for bit: q (rounded to f16, batch_matmul.rs:39) and k carry
+  // 11-bit significands, so the f32 product is exact and the fused operation rounds once where the separate multiply would
+  // not have rounded at all.  (v_readlane + v_cvt + v_mul + v_add per element made the 128-element dot 3500 cycles of
+  // instruction issue -- a lone wave per SIMD issues one instruction per ~5 cycles; the chain of 128 dependent operations is
+  // ~1000.)  q comes out of LDS as broadcast 16-byte reads issued together with the K row's.
+  typedef _Float16 h2q __attribute__((ext_vector_type(2)));
   auto score_of = [&](int t) -> float {
     const unsigned short* kr = Ks + (size_t)t * kstr;
     float acc = 0.0f;
     if constexpr (HD == 128) {
-      i32x4 kv[16];
+      i32x4 kv[16], qq[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) kv[i] = *(const i32x4*)(kr + 8 * i);
+      for (int i = 0; i < 16; i++) {
+        kv[i] = *(const i32x4*)(kr + 8 * i);
+        qq[i] = *(const i32x4*)(q16 + 8 * i);
+      }
 #pragma unroll
       for (int i = 0; i < 16; i++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const unsigned w = (unsigned)kv[i][j];
-          const int e = 8 * i + 2 * j;
-          acc += rl_f(e < 64 ? q_lo : q_hi, e & 63) * h2f((unsigned short)(w & 0xffffu));
-          acc += rl_f(e + 1 < 64 ? q_lo : q_hi, (e + 1) & 63) * h2f((unsigned short)(w >> 16));
+          const h2q kh = __builtin_bit_cast(h2q, (unsigned)kv[i][j]), qh = __builtin_bit_cast(h2q, (unsigned)qq[i][j]);
+          acc = __builtin_fmaf((float)qh[0], (float)kh[0], acc);
+          acc = __builtin_fmaf((float)qh[1], (float)kh[1], acc);
         }
       }
     } else {
       for (int i = 0; i < hd; i += 8) {
-        const i32x4 kv = *(const i32x4*)(kr + i);
-        const f32x4 qa = *(const f32x4*)(qs + i), qb = *(const f32x4*)(qs + i + 4);
-        acc += qa[0] * h2f((unsigned short)((unsigned)kv[0] & 0xffffu));
-        acc += qa[1] * h2f((unsigned short)((unsigned)kv[0] >> 16));
-        acc += qa[2] * h2f((unsigned short)((unsigned)kv[1] & 0xffffu));
-        acc += qa[3] * h2f((unsigned short)((unsigned)kv[1] >> 16));
-        acc += qb[0] * h2f((unsigned short)((unsigned)kv[2] & 0xffffu));
-        acc += qb[1] * h2f((unsigned short)((unsigned)kv[2] >> 16));
-        acc += qb[2] * h2f((unsigned short)((unsigned)kv[3] & 0xffffu));
-        acc += qb[3] * h2f((unsigned short)((unsigned)kv[3] >> 16));
+        const i32x4 kv = *(const i32x4*)(kr + i), qq = *(const i32x4*)(q16 + i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const h2q kh = __builtin_bit_cast(h2q, (unsigned)kv[j]), qh = __builtin_bit_cast(h2q, (unsigned)qq[j]);
+          acc = __builtin_fmaf((float)qh[0], (float)kh[0], acc);
+          acc = __builtin_fmaf((float)qh[1], (float)kh[1], acc);
+        }
       }
     }
     return acc;
@@ -460,41 +459,48 @@ __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q
   q += (size_t)rowb * n_kv * G * hd;
   scores_g += (size_t)blockIdx.y * n_kv * G * seq_cap;
   if (sp * TS >= seq) return;
+  // q staged as f16 (quantize_f32_f16(bufa), batch_matmul.rs:39): the dot is one v_fma_mix_f32 per element -- the f32
+  // product of two f16 values is exact, so fl32(q k + acc) is the reference's `acc += q * k` bit for bit (k_attn_s)
+  unsigned short* q16 = (unsigned short*)lds;
   for (int idx = tid; idx < G * hd; idx += 256) {
     const int g = idx / hd, i = idx - g * hd;
-    lds[idx] = h2f(f2h(q[(size_t)(j * G + g) * hd + i]));  // quantize_f32_f16(bufa) (batch_matmul.rs:39)
+    q16[idx] = f2h(q[(size_t)(j * G + g) * hd + i]);
   }
   __syncthreads();
   const int g = tid % G;
   const int t = sp * TS + tid / G;
   if (t >= seq) return;
   const unsigned short* kr = kc + ((size_t)j * seq_cap + t) * hd;
-  const float* qg = lds + g * hd;
+  const unsigned short* qg = q16 + g * hd;
+  typedef _Float16 h2q __attribute__((ext_vector_type(2)));
   float acc = 0.0f;
   int i = 0;
   for (; i + 64 <= hd; i += 64) {  // 8 x 16-byte loads in flight; products still added in k order
-    i32x4 kv[8];
+    i32x4 kv[8], qq[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) kv[u] = *(const i32x4*)(kr + i + 8 * u);
+    for (int u = 0; u < 8; u++) {
+      kv[u] = *(const i32x4*)(kr + i + 8 * u);
+      qq[u] = *(const i32x4*)(qg + i + 8 * u);
+    }
 #pragma unroll
     for (int u = 0; u < 8; u++)
 #pragma unroll
       for (int w4 = 0; w4 < 4; w4++) {
-        const unsigned w = (unsigned)kv[u][w4];
-        acc += qg[i + 8 * u + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
-        acc += qg[i + 8 * u + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
+        const h2q kh = __builtin_bit_cast(h2q, (unsigned)kv[u][w4]), qh = __builtin_bit_cast(h2q, (unsigned)qq[u][w4]);
+        acc = __builtin_fmaf((float)qh[0], (float)kh[0], acc);
+        acc = __builtin_fmaf((float)qh[1], (float)kh[1], acc);
       }
   }
   for (; i + 8 <= hd; i += 8) {
-    const i32x4 kv = *(const i32x4*)(kr + i);
+    const i32x4 kv = *(const i32x4*)(kr + i), qq = *(const i32x4*)(qg + i);
 #pragma unroll
     for (int w4 = 0; w4 < 4; w4++) {
-      const unsigned w = (unsigned)kv[w4];
-      acc += qg[i + 2 * w4] * h2f((unsigned short)(w & 0xffffu));
-      acc += qg[i + 2 * w4 + 1] * h2f((unsigned short)(w >> 16));
+      const h2q kh = __builtin_bit_cast(h2q, (unsigned)kv[w4]), qh = __builtin_bit_cast(h2q, (unsigned)qq[w4]);
+      acc = __builtin_fmaf((float)qh[0], (float)kh[0], acc);
+      acc = __builtin_fmaf((float)qh[1], (float)kh[1], acc);
     }
   }
-  for (; i < hd; i++) acc += qg[i] * h2f(kr[i]);
+  for (; i < hd; i++) acc = __builtin_fmaf(h2f(qg[i]), h2f(kr[i]), acc);
   scores_g[(size_t)(j * G + g) * seq_cap + t] = acc;
 }
 
