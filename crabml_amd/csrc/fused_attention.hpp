@@ -968,7 +968,10 @@ __global__ __launch_bounds__(256) void k_attn_tile(const float* __restrict__ q, 
   for (int e = tid; e < Q * hd; e += 256) {  // query qi = r * G + j
     const int qi = e / hd, i = e - qi * hd, r = qi / G, j = qi - r * G;
     const float v = r < rows_here ? q[(size_t)(r0 + r) * dim + head_of(j) * hd + i] : 0.0f;
-    qs[e] = KV16 ? h2f(f2h(v)) : v;
+    if (KV16)
+      ((unsigned short*)qs)[e] = f2h(v);  // f16 cache: q staged as f16, the dots run on v_fma_mix_f32 (exact: see k_attn_s)
+    else
+      qs[e] = v;
   }
   __syncthreads();
   // ---- scores + softmax: wave w owns the QW = Q / 4 queries w * QW .. (one prompt row: its causal length bounds the
@@ -985,26 +988,24 @@ __global__ __launch_bounds__(256) void k_attn_tile(const float* __restrict__ q, 
         for (int u = 0; u < QW; u++) acc[u] = 0.0f;
         if (KV16) {
           const unsigned short* kr = (const unsigned short*)kc + ((size_t)kvh * seq_cap + t) * hd;
+          typedef _Float16 h2q __attribute__((ext_vector_type(2)));
+          const unsigned short* q16 = (const unsigned short*)qs;
           for (int i = 0; i < hd; i += 16) {  // hd % 16 == 0 (host check); products added in k order per query
             const i32x4 k0 = *(const i32x4*)(kr + i), k1 = *(const i32x4*)(kr + i + 8);
-            float kf[16];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              kf[2 * u] = h2f((unsigned short)((unsigned)k0[u] & 0xffffu));
-              kf[2 * u + 1] = h2f((unsigned short)((unsigned)k0[u] >> 16));
-              kf[8 + 2 * u] = h2f((unsigned short)((unsigned)k1[u] & 0xffffu));
-              kf[8 + 2 * u + 1] = h2f((unsigned short)((unsigned)k1[u] >> 16));
-            }
 #pragma unroll
             for (int u = 0; u < QW; u++) {
-              const f32x4* qp = (const f32x4*)(qs + (q0 + u) * hd + i);
+              const i32x4 qa = *(const i32x4*)(q16 + (q0 + u) * hd + i), qb = *(const i32x4*)(q16 + (q0 + u) * hd + i + 8);
 #pragma unroll
-              for (int v4 = 0; v4 < 4; v4++) {
-                const f32x4 qv = qp[v4];
-                acc[u] += qv[0] * kf[4 * v4];
-                acc[u] += qv[1] * kf[4 * v4 + 1];
-                acc[u] += qv[2] * kf[4 * v4 + 2];
-                acc[u] += qv[3] * kf[4 * v4 + 3];
+              for (int w4 = 0; w4 < 4; w4++) {
+                const h2q kh = __builtin_bit_cast(h2q, (unsigned)k0[w4]), qh = __builtin_bit_cast(h2q, (unsigned)qa[w4]);
+                acc[u] = __builtin_fmaf((float)qh[0], (float)kh[0], acc[u]);
+                acc[u] = __builtin_fmaf((float)qh[1], (float)kh[1], acc[u]);
+              }
+#pragma unroll
+              for (int w4 = 0; w4 < 4; w4++) {
+                const h2q kh = __builtin_bit_cast(h2q, (unsigned)k1[w4]), qh = __builtin_bit_cast(h2q, (unsigned)qb[w4]);
+                acc[u] = __builtin_fmaf((float)qh[0], (float)kh[0], acc[u]);
+                acc[u] = __builtin_fmaf((float)qh[1], (float)kh[1], acc[u]);
               }
             }
           }
