@@ -1334,6 +1334,16 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     c->attn_long_ok = g.use_f16_kv_cache && hd % 32 == 0 && g.seq_len % 8 == 0 && (grp == 1 || grp == 2 || grp == 4 || grp == 8) &&
                       !(g.flags & CRABML_HIP_LLAMA_NO_LONG_ATTENTION);
     c->attn_long_from = g.attn_long_from ? g.attn_long_from : 224;  // measured crossover on MI355X (Llama-3-8B shape): ~200-220
+    if (c->attn_long_ok && g.seq_len * 4 > 64 * 1024) {
+      // the softmax kernels keep a head's score row in LDS: rows past 16384 positions need the raised dynamic-LDS limit,
+      // rows past ~38000 do not fit at all (the step then stays on the one-workgroup-per-head kernel)
+      const int lds = (int)(g.seq_len * 4);
+      if (lds > 150 * 1024 ||
+          hipFuncSetAttribute((const void*)k_attn_softmax<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_attn_softmax<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        c->attn_long_ok = false;
+      (void)hipGetLastError();
+    }
     if (c->attn_long_ok) {
       A(n_heads_l * g.seq_len * 4, (void**)&c->scores_g);
       A(n_heads_l * g.seq_len * 2, (void**)&c->p16);
