@@ -6,7 +6,7 @@
     epilogue, 5 launches per layer -- == the single-device simulation bit for bit;
   * ranks in SEPARATE PROCESSES sharing device 0, inboxes mapped with hipIpcGetMemHandle / hipIpcOpenMemHandle -- the very
     mechanism that maps a peer GPU's HBM over xGMI: strict logits == the oracle's tensor-parallel restatement bit for bit
-    on every rank (rank-order sums keep it exact), for 2 and 4 processes.
+    on every rank (rank-order sums keep it exact); the stand-alone collective and the fast fused step up to 8 processes.
 No scaling curve comes out of this (one GPU); what is established is that the collective is correct across processes."""
 import os
 import subprocess
@@ -135,7 +135,7 @@ def spawn(tmp_path, world, shape, fmt, strict, mode):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_all_reduce_across_processes_over_hip_ipc(tmp_path, world):
     spawn(tmp_path, world, "tiny-gqa", "Q4_0", False, "allreduce")
     dim = synth.SHAPES["tiny-gqa"].dim
@@ -175,5 +175,23 @@ def test_fast_tp_step_across_four_processes(tmp_path):
     del sim
     spawn(tmp_path, 4, "tp4", "Q4_0", False, "step")
     for r in range(4):
+        got = np.load(tmp_path / f"out.{r}.npy")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"rank {r}"
+
+
+def test_fast_tp_step_across_eight_processes(tmp_path):
+    """The node size the collective is built for: 8 ranks = 8 processes (here sharing one GPU), fast kernels, the one-shot
+    all-reduce inside the wo / ffn_down epilogue with seven peers per rank: every rank's logits equal the single-device
+    simulation's bit for bit."""
+    shape = synth.ModelShape("tp8", 512, 2048, 2, 8, 8, 1024, 64, 1e-5, None)
+    synth.SHAPES["tp8"] = shape
+    import crabml_amd as ca
+
+    model = synth.build_model(shape, synth.Q4_0, seed=31)
+    sim = hip_tp_ranks(ca, model, 8, True, ca.HipTensorDevice(0))
+    want = np.stack([ca.HipLlamaRunner.tp_sim_forward(sim, t, i).copy() for i, t in enumerate(TOKS)])
+    del sim
+    spawn(tmp_path, 8, "tp8", "Q4_0", False, "step")
+    for r in range(8):
         got = np.load(tmp_path / f"out.{r}.npy")
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"rank {r}"

@@ -15,6 +15,7 @@ from crabml_amd import synth, tp as tp_mod  # noqa: E402
 
 TOKS = [1, 365, 400, 282, 7, 9]
 synth.SHAPES["tp4"] = synth.ModelShape("tp4", 512, 1024, 2, 8, 4, 1024, 64, 1e-5, None)  # tiny-gqa with 4 kv heads
+synth.SHAPES["tp8"] = synth.ModelShape("tp8", 512, 2048, 2, 8, 8, 1024, 64, 1e-5, None)  # 8 kv heads, 256 hidden columns per rank
 
 
 def main():
