@@ -917,9 +917,41 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
   };
   k_embed<<<dim3((dim + 255) / 256, rows), 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
                                                          c->token_embed->wl.off_scale, c->pf_tokens, dim, c->pf_x);
+  // Q8_0 / Q8_1 rhs: residual add + RMSNorm + quantize as one launch per row (k_norm_quant_rows), SiLU * mul + quantize as one
+  // (k_gateup_epi_quant): the (rows, dim) / (rows, hidden) f32 intermediates make one trip through memory instead of three
+  const bool fuse_rows = (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1) && !(g.flags & CRABML_HIP_LLAMA_NO_PREFILL_ROW_FUSION);
+  const ActLayout ald = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)dim);
+  const ActLayout alh = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)hidden);
+  // pending = the wo / ffn_down output that has not been added to x yet (folded into the next norm)
+  auto norm_quant_rows = [&](const float* wn, float eps, const float* pending) -> const void* {
+    const bool q81 = c->qt == CRABML_HIP_Q8_1;
+#define CRABML_NQR(NIT_, Q_)                                                                                                    \
+  k_norm_quant_rows<NIT_, Q_><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d, \
+                                                            ald.off_aux, half)
+    if (dim <= 4096) {
+      if (q81)
+        CRABML_NQR(4, true);
+      else
+        CRABML_NQR(4, false);
+    } else {
+      if (q81)
+        CRABML_NQR(12, true);
+      else
+        CRABML_NQR(12, false);
+    }
+#undef CRABML_NQR
+    return c->pf_act_dim;
+  };
+  bool pending_down = false;  // (fuse_rows) the previous layer's ffn_down output sits in pf_tmp, not yet added to pf_x
   for (int l = 0; l < L; l++) {
-    norm_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);  // llama2.rs:230-234
-    const void* a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+    const void* a;
+    if (fuse_rows) {
+      a = norm_quant_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, pending_down ? c->pf_tmp : nullptr);
+      pending_down = false;
+    } else {
+      norm_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);  // llama2.rs:230-234
+      a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+    }
     CH_TRY(gemm(c->wq[l], dim, dim, a, c->pf_q));  // llama2.rs:244-246
     CH_TRY(gemm(c->wk[l], kv_dim, dim, a, c->pf_k));
     CH_TRY(gemm(c->wv[l], kv_dim, dim, a, c->pf_v));
@@ -947,16 +979,34 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     }
     a = quant_rows(c->pf_attn, dim, c->pf_act_dim);
     CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp));  // llama2.rs:600
-    k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);  // :266
-    norm_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f);  // llama2.rs:611
-    a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+    if (fuse_rows) {
+      a = norm_quant_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f, c->pf_tmp);  // x += wo out (:266), FFN norm (:611), quantize
+    } else {
+      k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);  // :266
+      norm_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f);  // llama2.rs:611
+      a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+    }
     CH_TRY(gemm(c->gate[l], hidden, dim, a, c->pf_g));  // llama2.rs:620-630
     CH_TRY(gemm(c->up[l], hidden, dim, a, c->pf_u));
-    k_gateup_epi<<<(unsigned)(((size_t)B * hidden + 255) / 256), 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table,
-                                                                               c->pf_g, (int)(B * hidden));
-    a = quant_rows(c->pf_g, hidden, c->pf_act_hid);
+    if (fuse_rows) {
+      const dim3 gq((unsigned)((hidden + 255) / 256), rows);
+      if (c->qt == CRABML_HIP_Q8_1)
+        k_gateup_epi_quant<true><<<gq, 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table, hidden, c->pf_act_hid, alh.total,
+                                                     alh.off_d, alh.off_aux);
+      else
+        k_gateup_epi_quant<false><<<gq, 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table, hidden, c->pf_act_hid, alh.total,
+                                                      alh.off_d, alh.off_aux);
+      a = c->pf_act_hid;
+    } else {
+      k_gateup_epi<<<(unsigned)(((size_t)B * hidden + 255) / 256), 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table,
+                                                                                 c->pf_g, (int)(B * hidden));
+      a = quant_rows(c->pf_g, hidden, c->pf_act_hid);
+    }
     CH_TRY(gemm(c->down[l], dim, hidden, a, c->pf_tmp));  // llama2.rs:633-636
-    k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);
+    if (fuse_rows && l + 1 < L)
+      pending_down = true;  // added by the next layer's norm launch
+    else
+      k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);
   }
   if (want_logits) {  // final rmsnorm + classifier of the last row only (llama2.rs:274-278, 199-208)
     CH_HIP(dev, hipMemcpyAsync(c->x, c->pf_x + (B - 1) * (size_t)dim, (size_t)dim * 4, hipMemcpyDeviceToDevice, st));

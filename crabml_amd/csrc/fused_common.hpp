@@ -266,6 +266,22 @@ __global__ __launch_bounds__(1024) void k_norm_f32(float* __restrict__ x, const 
   norm_quant_block<NIT, false>(x, addv, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr, xn, half);
 }
 
+// batched prefill, Q8_0 / Q8_1 rhs: x[row] (+= addv[row]: the pending wo / ffn_down output, llama2.rs:266 / :636) -> RMSNorm ->
+// the row's quantized planes, one workgroup per row.  Replaces residual-add, norm and quantize launches (three passes over
+// the (rows, cols) activations) by one; per row the arithmetic is norm_quant_block's, i.e. the decode step's.
+template <int NIT, bool Q81>
+__global__ __launch_bounds__(1024) void k_norm_quant_rows(float* __restrict__ x, const float* __restrict__ addv, const float* __restrict__ w,
+                                                         int cols, float eps, char* __restrict__ planes, size_t row_stride, size_t off_d,
+                                                         size_t off_aux, int half) {
+  extern __shared__ float lds[];
+  __shared__ float s_rms;
+  NormLds L{lds, lds + cols};
+  const size_t r = blockIdx.x;
+  char* p = planes + r * row_stride;
+  norm_quant_block<NIT, true, Q81>(x + r * cols, addv ? addv + r * cols : nullptr, w, cols, eps, L, &s_rms, (signed char*)p,
+                                   (unsigned short*)(p + off_d), (void*)(p + off_aux), nullptr, half);
+}
+
 // batched prefill: one workgroup per row of x (rows, cols) -> xn (rows, cols)
 template <int NIT>
 __global__ __launch_bounds__(1024) void k_norm_f32_rows(float* __restrict__ x, const float* __restrict__ w, int cols, float eps,

@@ -733,6 +733,26 @@ __global__ __launch_bounds__(256) void k_gateup_epi(const float* __restrict__ g,
   if (i < m) h[i] = silu_mul(g[i], u[i], exp_tab);
 }
 
+// batched prefill, Q8_0 / Q8_1 rhs: h = silu(g) * u quantized straight into the rows' planes (one 32-lane half-wave per block:
+// quant_lane32 = the quantizer launch's arithmetic) -- the (rows, hidden) f32 h never goes to memory and back
+template <bool Q81>
+__global__ __launch_bounds__(256) void k_gateup_epi_quant(const float* __restrict__ g, const float* __restrict__ u,
+                                                          const unsigned short* __restrict__ exp_tab, int hidden, char* __restrict__ planes,
+                                                          size_t row_stride, size_t off_d, size_t off_aux) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // hidden % 32 == 0: half-waves are all-live or all-dead
+  const size_t r = blockIdx.y;
+  const bool live = i < hidden;
+  const float h = live ? silu_mul(g[r * hidden + i], u[r * hidden + i], exp_tab) : 0.0f;
+  const QLane o = quant_lane32<Q81>(h, live);
+  if (!live) return;
+  char* p = planes + r * row_stride;
+  ((signed char*)p)[i] = o.q;
+  if ((threadIdx.x & 31) == 0) {
+    ((unsigned short*)(p + off_d))[i >> 5] = o.d;
+    store_qaux<Q81>((void*)(p + off_aux), i >> 5, o.aux);
+  }
+}
+
 // ---- greedy sampler + advance: Iterator::max_by keeps the LAST maximum (sampler.rs:109-116) ------------
 // stage 1: ARGMAX_BLOCKS workgroups, each over a contiguous slice; stage 2: one wave combines and advances.
 #define ARGMAX_BLOCKS 128

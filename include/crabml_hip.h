@@ -223,6 +223,8 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                                    exchange their outputs); measured slower than wo's own 4096-element prologue */
 #define CRABML_HIP_LLAMA_NO_PV_PRODUCER_WAVES 131072 /* A/B: long-context decode runs k_attn_pv (the chain wave multiplies and adds)
                                                        instead of k_attn_pv_split (producer waves multiply); bit-identical */
+#define CRABML_HIP_LLAMA_NO_PREFILL_ROW_FUSION 262144 /* A/B: the prompt pass keeps residual-add / RMSNorm / quantize and SiLU * mul / quantize as
+                                                        separate launches (bit-identical) */
 #define CRABML_HIP_LLAMA_NO_PV_ROW_TILES 16384 /* A/B: long-prompt prefill runs the PV pass one prompt row per workgroup */
 #define CRABML_HIP_LLAMA_NO_STAGED_ATTENTION 8192 /* A/B: short-context attention without the LDS staging of K / V (k_attn) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */

@@ -185,3 +185,22 @@ def test_long_prompt_attention_paths_are_bit_identical(ca, n_heads, n_kv):
             for h in range(n_kv):
                 lo = h * 1200 * shape.head_dim * 2
                 assert np.array_equal(ka[lo:lo + filled], kb[lo:lo + filled]), (layer, which, h)
+
+
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1"])
+def test_prefill_row_fusion_equals_the_separate_launches(ca, fmt):
+    """Residual add + RMSNorm + quantize as one launch per prompt row and SiLU * mul + quantize as one (the default for Q8_0 /
+    Q8_1 rhs formats) against the separate launches (flag 262144): same logits and the same decoding afterwards, bit for
+    bit, in fast and in strict mode, in one and in several passes."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=83)
+    prompt = [(3 * i + 1) % 1000 for i in range(45)]
+    for strict in (False, True):
+        dev = ca.HipTensorDevice(0, False, 0, strict)
+        conf, w = synth.to_hip(model, dev)
+        for chunk in (0, 16):
+            a = ca.HipLlamaRunner(conf, w, dev, 64, True, prefill_chunk=chunk)
+            b = ca.HipLlamaRunner(conf, w, dev, 64, True, prefill_chunk=chunk, extra_flags=262144)
+            la, lb = a.prefill(prompt), b.prefill(prompt)
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), (fmt, strict, chunk)
+            nxt = int(np.argmax(la))
+            assert list(a.decode_greedy(nxt, 5)) == list(b.decode_greedy(nxt, 5))
