@@ -461,3 +461,31 @@ def test_q4_k_m_mix_on_the_fused_kernels_equals_the_per_op_segments(ca, flags):
         a, b = fused.forward(t, i), per_op.forward(t, i)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
     assert list(fused.decode_greedy(3, 20)) == list(per_op.decode_greedy(3, 20))
+
+
+def test_three_thousand_token_decode_across_every_attention_regime(ca):
+    """A soak over the regimes of the decode step: short-context staged attention, the switch to the long-context kernels at
+    224 positions, the block-tree softmax past 1024, a dozen PV tiles -- 3000 greedy tokens through the hipGraph path
+    (default kernels) against the one-workgroup-per-head kernel (flag 64): the same token at every step, bit-identical
+    logits at sampled steps, no fault flag raised (a raised flag surfaces as an error from the next blocking call)."""
+    shape = synth.ModelShape("soak", 512, 1024, 2, 8, 2, 1024, 3072, 1e-5, None)
+    model = synth.build_model(shape, synth.Q4_0, seed=91)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, 3072, True)
+    b = ca.HipLlamaRunner(conf, w, dev, 3072, True, extra_flags=64)
+    ta = list(a.decode_greedy(1, 3000))
+    tb = list(b.decode_greedy(1, 3000))
+    assert ta == tb
+    # teacher-forced replay of a fresh pair: logits at sampled positions in every regime
+    a2 = ca.HipLlamaRunner(conf, w, dev, 3072, True)
+    b2 = ca.HipLlamaRunner(conf, w, dev, 3072, True, extra_flags=64)
+    toks = [1] + ta
+    check = {0, 1, 63, 64, 65, 222, 223, 224, 225, 255, 256, 257, 511, 512, 1023, 1024, 1025, 1535, 1536, 2047, 2048, 2999}
+    for i in range(3000):
+        if i in check:
+            la, lb = a2.forward(toks[i], i), b2.forward(toks[i], i)
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), f"position {i}"
+        else:
+            a2.forward_async(toks[i], i)
+            b2.forward_async(toks[i], i)
