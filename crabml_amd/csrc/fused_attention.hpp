@@ -696,11 +696,9 @@ __global__ __launch_bounds__(320) void k_attn_pv_split(const unsigned short* __r
     out += (size_t)(row0 + blockIdx.y) * n_heads * hd;
   }
   const int ntiles = (seq + T - 1) / T;
-  // Both roles run `nround` tile slots (a multiple of D) so that the producer loop is branch-free: a conditional issue or
-  // commit makes the compiler's wait-count analysis assume the shortest path and drain ALL loads before every commit
-  // (measured: one memory round trip per tile).  Tiles past the last one are clamped reads inside the cache and products
-  // written to the buffer nobody reads any more.
-  const int nround = (ntiles + D - 1) / D * D;
+  // The producer loop is branch-free for whole groups of D tiles: a conditional issue or commit makes the compiler's
+  // wait-count analysis assume the shortest path and drain ALL loads before every commit (measured: one memory round trip
+  // per tile).  Loads for tiles past the last one are clamped reads inside the cache, never consumed.
   if (tid >= 64) {
     // ---- producer: work item = (8-column piece q of the slice, four consecutive positions) of each tile
     const int pt = tid - 64;
@@ -747,8 +745,12 @@ __global__ __launch_bounds__(320) void k_attn_pv_split(const unsigned short* __r
     commit(0, 0);
     issue(D, 0);
     __syncthreads();
-    // tile k is consumed between barrier k and barrier k + 1 while tile k + 1 is committed into the other buffer
-    for (int base = 0; base < nround; base += D) {
+    // tile k is consumed between barrier k and barrier k + 1 while tile k + 1 is committed into the other buffer.
+    // Whole groups of D tiles run branch-free; the last ntiles % D tiles run guarded (a conditional commit makes the
+    // compiler drain every outstanding load first -- harmless in the last one or two rounds, where nothing is left to fetch,
+    // and it saves the one or two rounds of products nobody would read)
+    int base = 0;
+    for (; base + D <= ntiles; base += D) {
 #pragma unroll
       for (int u = 0; u < D; u++) {
         const int tile = base + u;  // the chain wave consumes `tile`
@@ -756,6 +758,13 @@ __global__ __launch_bounds__(320) void k_attn_pv_split(const unsigned short* __r
         issue(tile + 1 + D, (u + 1) % D);
         __syncthreads();
       }
+    }
+#pragma unroll
+    for (int u = 0; u < D - 1; u++) {
+      const int tile = base + u;
+      if (tile >= ntiles) break;
+      if (tile + 1 < ntiles) commit((tile + 1) & 1, (u + 1) % D);
+      __syncthreads();
     }
     return;
   }
@@ -769,8 +778,8 @@ __global__ __launch_bounds__(320) void k_attn_pv_split(const unsigned short* __r
     c = c + p_[0];                                                  \
     c = c + p_[1];                                                  \
   }
-  for (int tile = 0; tile < nround; tile++) {
-    if (chain && tile < ntiles) {
+  for (int tile = 0; tile < ntiles; tile++) {
+    if (chain) {
       const int nt = seq - tile * T < T ? seq - tile * T : T;
       const unsigned char* row = prodb + (size_t)(tile & 1) * CH * ROWB + (size_t)tid * ROWB;
       int t = 0;
