@@ -462,15 +462,21 @@ __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q
   // q staged as f16 (quantize_f32_f16(bufa), batch_matmul.rs:39): the dot is one v_fma_mix_f32 per element -- the f32
   // product of two f16 values is exact, so fl32(q k + acc) is the reference's `acc += q * k` bit for bit (k_attn_s)
   unsigned short* q16 = (unsigned short*)lds;
-  for (int idx = tid; idx < G * hd; idx += 256) {
-    const int g = idx / hd, i = idx - g * hd;
-    q16[idx] = f2h(q[(size_t)(j * G + g) * hd + i]);
-  }
-  __syncthreads();
   const int g = tid % G;
   const int t = sp * TS + tid / G;
+  // the thread's K row does not depend on q: its first 128 bytes are requested before q is staged (rows past seq: clamped)
+  const unsigned short* kr = kc + ((size_t)j * seq_cap + (t < seq ? t : seq - 1)) * hd;
+  i32x4 kv0[8];
+  if (hd >= 64) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) kv0[u] = *(const i32x4*)(kr + 8 * u);
+  }
+  for (int idx = tid; idx < G * hd; idx += 256) {
+    const int gq = idx / hd, i = idx - gq * hd;
+    q16[idx] = f2h(q[(size_t)(j * G + gq) * hd + i]);
+  }
+  __syncthreads();
   if (t >= seq) return;
-  const unsigned short* kr = kc + ((size_t)j * seq_cap + t) * hd;
   const unsigned short* qg = q16 + g * hd;
   typedef _Float16 h2q __attribute__((ext_vector_type(2)));
   float acc = 0.0f;
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q
     i32x4 kv[8], qq[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      kv[u] = *(const i32x4*)(kr + i + 8 * u);
+      kv[u] = i == 0 ? kv0[u] : *(const i32x4*)(kr + i + 8 * u);
       qq[u] = *(const i32x4*)(qg + i + 8 * u);
     }
 #pragma unroll
