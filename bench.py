@@ -92,6 +92,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated this many times (same positions)")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-context", action="store_true", help="skip the long-context decode points")
+    ap.add_argument("--no-gemv-points", action="store_true", help="skip the single-kernel GEMV points (SURVEY.md 8d)")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self test of the rank aggregation")
     return ap.parse_args()
 
@@ -197,6 +198,43 @@ def cpu_baseline(model, steps_budget_s):
             f"T={t}: {n} tokens in {el:.2f}s = {v:.2f} tok/s" for v, t, n, el in results),
         "note": "reference is Rust nightly (no rustc here): its AVX2 CPU path restated in C (oracle/crabml_oracle.c)",
     }
+
+
+def gemv_points(ca, synth, dev, fname="Q4_0"):
+    """SURVEY.md 8(d), the second half of BASELINE's metric ("Q4_0 GEMV GB/s vs HBM roofline"): crabml_hip_matmul_vec alone on the
+    four Llama-3-8B shapes.  Every launch reads a DIFFERENT weight buffer out of >= 512 MB of distinct copies (cycled, so the
+    256 MB Infinity Cache never holds the next one), 20 warm-up + 200 timed launches, kernel time from the dispatch's own
+    start / stop events: median, p10, p90, algorithmic GB/s = (m k / 32 * 18 + 4 k + 4 m) / median, fraction of 8 TB/s."""
+    import numpy as np
+
+    typ = synth.TYPE_BY_NAME[fname]
+    gt = {synth.Q4_0: ca.GGMLType.Q4_0, synth.Q8_0: ca.GGMLType.Q8_0, synth.Q4_1: ca.GGMLType.Q4_1}[typ]
+    rng = np.random.default_rng(3)
+    pts = {}
+    for (m, k) in [(4096, 4096), (14336, 4096), (4096, 14336), (128256, 4096)]:
+        wbytes = m * k // synth.BLOCK_ELEMS[typ] * synth.BLOCK_BYTES[typ]
+        algo = wbytes + 4 * k + 4 * m
+        ncopies = max(2, -(-536_870_912 // wbytes))
+        raw = synth.random_blocks(rng, m * k, typ)
+        ws = [ca.HipTensor.from_cpu(np.roll(raw, 4096 * c), [m, k], gt, dev) for c in range(ncopies)]
+        x = ca.HipTensor.new(rng.standard_normal(k).astype(np.float32), [k], dev)
+        for i in range(20):
+            ws[i % ncopies].matmul_vec(x)
+        dev.sync()
+        dev.prof_enable(True)
+        for i in range(200):
+            ws[i % ncopies].matmul_vec(x)
+        ms = dev.prof_read_launches()
+        dev.prof_enable(False)
+        us = np.sort(ms.astype(np.float64) * 1e3)
+        med, p10, p90 = float(np.median(us)), float(us[len(us) // 10]), float(us[len(us) * 9 // 10])
+        pts[f"{m}x{k}"] = {"algo_MB": round(algo / 1e6, 2), "distinct_weight_MB": round(ncopies * wbytes / 1e6), "launches": int(len(us)),
+                           "median_us": round(med, 2), "p10_us": round(p10, 2), "p90_us": round(p90, 2),
+                           "GBps": round(algo / med / 1e3, 1), "frac_of_peak": round(algo / med / 1e3 / HBM_PEAK_GBS, 4)}
+        del ws, x
+    return {"format": fname, "kernel": "crabml_hip_matmul_vec (k_gemv, one launch per call)", "peak_GBps": HBM_PEAK_GBS, "points": pts,
+            "method": "200 timed launches per shape after 20 warm-ups, each on a different weight buffer (cycling >= 512 MB), "
+                      "hipExtLaunchKernelGGL start/stop events"}
 
 
 def parity_check(ca, synth, model, conf, weights, dev, ordinal, n_pos=4):
@@ -446,7 +484,9 @@ def main():
         STAGES = {0: "matmul_vec (per-op path)", 1: "k_qkv (wq|wk|wv + rope + KV append)", 2: "wo GEMV + residual (+ next rmsnorm/quantize epilogue)",
                   3: "k_gateup_q (gate|up + silu*mul + quantize)", 4: "ffn_down GEMV + residual (+ next rmsnorm/quantize epilogue)",
                   5: "k_gemv (classifier)",
-                  10: "k_ffn (gate|up + silu*mul + quantize + ffn_down + residual + next rmsnorm/quantize, one launch)"}
+                  10: "k_ffn (gate|up + silu*mul + quantize + ffn_down + residual + next rmsnorm/quantize, one launch)",
+                  11: "k_engine (wo + residual + rmsnorm/quantize + gate|up + silu*mul + quantize + ffn_down + residual + next rmsnorm/quantize: "
+                      "one persistent launch, LDS-DMA weight stream)"}
         n_prof = min(args.steps, 16)
         if path == "fused":
             eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch,
@@ -586,6 +626,11 @@ def main():
             out["roofline"] = roof
         if prefill:
             out["prefill"] = prefill
+        if not args.no_gemv_points and args.gpus == 1 and args.wtype in ("Q4_0", "Q8_0", "Q4_1"):
+            try:
+                out["gemv_points"] = gemv_points(ca, synth, dev, args.wtype)
+            except Exception as e:
+                out["gemv_points"] = {"error": repr(e)}
         if args.gguf:
             out["data"] = "file: " + args.gguf
             out["config"]["workload"] = f"GGUF file {os.path.basename(args.gguf)} ({args.wtype} body), batch-1 greedy decode, f16 KV cache"

@@ -283,7 +283,12 @@ void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t
 }
 
 // ---- read ceiling: what a plain streaming kernel reads per second on this box (the practical HBM ceiling) ----------
-// 16-byte non-temporal loads, 8 in flight per lane, grid-stride; the xor keeps the loads alive.
+// 16-byte non-temporal loads; the xor keeps the loads alive.  Three access patterns, the caller keeps the best (round-2 verdict:
+// the grid-stride pattern alone read 6.2 TB/s on a box where the product's own classifier GEMV streamed 7.05 TB/s -- not a ceiling):
+//   0  grid-stride, 8 loads in flight per lane (each lane's loads are gridDim x 4 KiB apart)
+//   1  the GEMV's pattern: short-lived 128-thread workgroups, every wave reads ONE contiguous 4 KiB span (4 x 1 KiB requests,
+//      all in flight) and exits -- what k_gemv_q4_0<2> does with two 2304-byte rows per wave
+//   2  persistent: 2048 workgroups x 256 threads, every wave walks contiguous 8 KiB spans, 8 requests in flight
 __global__ __launch_bounds__(256) void k_stream_read(const i32x4* __restrict__ p, size_t n16, int* __restrict__ sink) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,8 +306,38 @@ __global__ __launch_bounds__(256) void k_stream_read(const i32x4* __restrict__ p
   }
   if (acc == 0x7eadbeef) *sink = acc;
 }
-void launch_stream_read(hipStream_t st, const void* buf, size_t bytes, int* sink, hipEvent_t e0, hipEvent_t e1) {
-  hipExtLaunchKernelGGL(k_stream_read, dim3(8192), dim3(256), 0, st, e0, e1, 0, (const i32x4*)buf, bytes / 16, sink);
+__global__ __launch_bounds__(128) void k_stream_read_spans(const i32x4* __restrict__ p, size_t n16, int* __restrict__ sink) {
+  const size_t wave = (size_t)blockIdx.x * 2 + (threadIdx.x >> 6);
+  const size_t i = wave * 256 + (threadIdx.x & 63);  // 256 16-byte units = 4 KiB per wave
+  if (i + 192 >= n16) return;
+  i32x4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(p + i + u * 64);
+  int acc = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+  if (acc == 0x7eadbeef) *sink = acc;
+}
+__global__ __launch_bounds__(256) void k_stream_read_persistent(const i32x4* __restrict__ p, size_t n16, int* __restrict__ sink) {
+  const size_t nwaves = (size_t)gridDim.x * 4, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int acc = 0;
+  for (size_t s = wave * 512; s + 512 <= n16; s += nwaves * 512) {  // 512 units = 8 KiB per wave and step
+    i32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(p + s + u * 64 + (threadIdx.x & 63));
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+  }
+  if (acc == 0x7eadbeef) *sink = acc;
+}
+void launch_stream_read(hipStream_t st, const void* buf, size_t bytes, int* sink, hipEvent_t e0, hipEvent_t e1, int pattern) {
+  const size_t n16 = bytes / 16;
+  if (pattern == 1)
+    hipExtLaunchKernelGGL(k_stream_read_spans, dim3((unsigned)(n16 / 512)), dim3(128), 0, st, e0, e1, 0, (const i32x4*)buf, n16, sink);
+  else if (pattern == 2)
+    hipExtLaunchKernelGGL(k_stream_read_persistent, dim3(2048), dim3(256), 0, st, e0, e1, 0, (const i32x4*)buf, n16, sink);
+  else
+    hipExtLaunchKernelGGL(k_stream_read, dim3(8192), dim3(256), 0, st, e0, e1, 0, (const i32x4*)buf, n16, sink);
 }
 
 }  // namespace crabml_hip

@@ -21,6 +21,7 @@
 #include "fused_common.hpp"
 #include "fused_attention.hpp"
 #include "fused_ffn.hpp"
+#include "engine.hpp"
 
 
 // ==============================================================================================================
@@ -120,6 +121,15 @@ struct crabml_hip_llama {
   unsigned long long* h8gran = nullptr;  // the producing kernels assemble Q8_K super-blocks (q8k_exchange_store)
   bool q8k_producers = false;            // attention / gate-up emit the Q8_K planes of wo's / ffn_down's rhs themselves
   bool ffn_fused = false;               // gate/up + ffn_down as one launch (k_ffn)
+  // the engine (engine.hpp): wo + norm + gate/up + ffn_down + norm of a layer as ONE persistent launch over a CU-major weight stream
+  bool engine = false;
+  EngGeom eng_g{};
+  int eng_D = 0, eng_nc = 3, eng_flags = 0;
+  size_t eng_lds = 0, eng_layer_bytes = 0;
+  unsigned char* eng_stream = nullptr;          // n_layers x eng_layer_bytes
+  unsigned long long* eng_cu_off = nullptr;     // [G + 1]
+  unsigned long long* xqgran = nullptr;         // dim / 4 + dim / 32 granules of the normalized residual (rhs of gate/up)
+  EngArgs* eng_args = nullptr;                  // [n_layers] kernel arguments of the layers' launches (device memory, static)
   unsigned tp_salt = 0;      // P2P group: epoch salt of this context (see TpP2P::salt)
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
   bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
@@ -220,7 +230,7 @@ void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned shor
   launch_k(st, prof ? &r[0] : nullptr, k_attn_scores<G>, dim3(n_kv * nsplit), dim3(256), (size_t)G * hd * sizeof(float),
            (const float*)c->qbuf, (const unsigned short*)c->kc[l], pos_d, c->scores_g, n_kv, hd, seq_cap, nsplit, 0);
   launch_k(st, prof ? &r[1] : nullptr, k_attn_softmax<16>, dim3(c->n_heads_l), dim3(1024), (size_t)seq_cap * sizeof(float),
-           (const float*)c->scores_g, pos_d, (const unsigned short*)dev->exp_table, c->p16, seq_cap, 0);
+           (const float*)c->scores_g, pos_d, (const unsigned short*)dev->exp_table, c->p16, seq_cap, 0, dev->strict_order ? 1 : 0);
   if (c->pv_split)
     launch_k(st, prof ? &r[2] : nullptr, k_attn_pv_split<G>, dim3(n_kv * (hd / 32) * PvSplit<G>::NSUB), dim3(PvSplit<G>::THREADS), PvSplit<G>::LDS,
              (const unsigned short*)c->p16, (const unsigned short*)c->vc[l], pos_d, c->attn, xq, xd, xisum, hd, seq_cap,
@@ -248,25 +258,26 @@ void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned sho
     return;
   }
   const size_t attn_lds = (size_t)(seq_cap + hd) * sizeof(float);
+  const int sbit = dev->strict_order ? 256 : 0;  // strict device: sequential softmax row sums at any length (softmax.rs:43-48)
   crabml_hip_device::ProfRec ar{};
   crabml_hip_device::ProfRec* AR = prof ? &ar : nullptr;
   if (prof) prof_begin(dev, &ar, CRABML_HIP_F32, 7, 0.0);
   if (c->attn_s_rows > 0 && hd == 128)
     launch_k(st, AR, k_attn_s<128>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
              (const unsigned short*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd, seq_cap,
-             c->attn_s_rows, pf, k8 ? 2 : c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr, k8 ? *k8 : AttnQ8K{});
+             c->attn_s_rows, pf, (k8 ? 2 : c->qt == CRABML_HIP_Q8_1 ? 1 : 0) | sbit, (long long*)nullptr, k8 ? *k8 : AttnQ8K{});
   else if (c->attn_s_rows > 0)
     launch_k(st, AR, k_attn_s<0>, dim3(n_heads + spare), dim3(256), c->attn_s_lds, (const float*)c->qbuf, (const unsigned short*)c->kc[l],
              (const unsigned short*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd, seq_cap,
-             c->attn_s_rows, pf, k8 ? 2 : c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr, k8 ? *k8 : AttnQ8K{});
+             c->attn_s_rows, pf, (k8 ? 2 : c->qt == CRABML_HIP_Q8_1 ? 1 : 0) | sbit, (long long*)nullptr, k8 ? *k8 : AttnQ8K{});
   else if (c->cfg.use_f16_kv_cache)
     launch_k(st, AR, k_attn<true>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
              (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
-             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
+             seq_cap, pf, (c->qt == CRABML_HIP_Q8_1 ? 1 : 0) | sbit, (long long*)nullptr);
   else
     launch_k(st, AR, k_attn<false>, dim3(n_heads + spare), dim3(256), attn_lds, (const float*)c->qbuf, (const void*)c->kc[l],
              (const void*)c->vc[l], pos_d, (const unsigned short*)dev->exp_table, c->attn, xq, xd, xisum, n_heads, n_kv, hd,
-             seq_cap, pf, c->qt == CRABML_HIP_Q8_1 ? 1 : 0, (long long*)nullptr);
+             seq_cap, pf, (c->qt == CRABML_HIP_Q8_1 ? 1 : 0) | sbit, (long long*)nullptr);
   if (prof) prof_end(dev, &ar);
 }
 
@@ -412,12 +423,24 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     const int attn_spare = do_pf && dev->n_cu > n_heads_l ? dev->n_cu - n_heads_l : 0;
     enqueue_attention(c, l, attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, plan(c->wo[l], nullptr, nullptr), attn_spare, prof);
     if (!attn_quant) launch_quantize_act(st, qt, c->attn, (size_t)dim_l, c->act_attn);
-    // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
-    CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
+    // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice (engine: part of the odd segment's launch)
+    if (!c->engine) CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
   } else {
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
     if (!norm_epi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
     const float* wnext_down = (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr;
+    if (c->engine) {
+      // wo + residual + ffn norm + gate/up + silu * mul + down + residual + the next norm: one persistent launch (engine.hpp)
+      if constexpr (FMT == CRABML_HIP_Q4_0) {
+        if (prof)
+          CH_TRY(prof_begin(dev, &pr, c->wtype, 11,
+                            ((double)dim * dim_l + 3.0 * hidden_l * (double)dim) * blk_b + 4.0 * dim_l + 4.0 * dim + 4.0 * hidden_l + 8.0 * dim));
+        launch_k(st, R, k_engine<CRABML_HIP_Q4_0>, dim3(c->eng_g.G), dim3(64 * (1 + c->eng_nc)), c->eng_lds, (const EngArgs*)(c->eng_args + l));
+        CH_TRY(P1(&pr));
+      }
+      CH_HIP(dev, hipGetLastError());
+      return 0;
+    }
     const int split_down = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
                            : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
                            : (hidden_l / 32 >= 256 && dim / 32 <= dev->n_cu) ? 2
@@ -849,7 +872,7 @@ int launch_attn_long_rows_t(crabml_hip_llama* c, int l, int B) {
     k_attn_scores<G><<<dim3(n_kv * nsplit, rows), 256, (size_t)G * hd * sizeof(float), st>>>(
         (const float*)c->pf_qr, (const unsigned short*)c->kc[l], pos_d, c->pf_scores, n_kv, hd, seq_cap, nsplit, r0);
     k_attn_softmax<4><<<dim3(n_heads, rows), 256, (size_t)seq_cap * sizeof(float), st>>>(
-        (const float*)c->pf_scores, pos_d, (const unsigned short*)dev->exp_table, c->pf_p16, seq_cap, r0);
+        (const float*)c->pf_scores, pos_d, (const unsigned short*)dev->exp_table, c->pf_p16, seq_cap, r0, dev->strict_order ? 1 : 0);
     // PV for R prompt rows per workgroup (one V fetch for R x G chains); G = 8 fills the lanes with two rows
     constexpr int PR = G == 8 ? 2 : 4;
     if (c->cfg.flags & CRABML_HIP_LLAMA_NO_PV_ROW_TILES)
@@ -971,11 +994,11 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       if (kv16)
         k_attn<true><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
                                                                   c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
-                                                                  PrefetchPlan{}, 0);
+                                                                  PrefetchPlan{}, dev->strict_order ? 256 : 0);
       else
         k_attn<false><<<dim3(n_heads, rows), 256, attn_lds, st>>>(c->pf_qr, c->kc[l], c->vc[l], pos_d, (const unsigned short*)dev->exp_table,
                                                                    c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
-                                                                   PrefetchPlan{}, 0);
+                                                                   PrefetchPlan{}, dev->strict_order ? 256 : 0);
     }
     a = quant_rows(c->pf_attn, dim, c->pf_act_dim);
     CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp));  // llama2.rs:600
@@ -1023,6 +1046,160 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
                   : launch_gemv(dev, c->output, g.vocab_size, dim, act, 1, c->logits, nullptr));
   }
   CH_HIP(dev, hipGetLastError());
+  return 0;
+}
+
+// ---- the engine (engine.hpp): geometry, LDS budget, the CU-major weight stream -----------------------------------------------
+// Opt-in / opt-out through the config flags; silently stays off (the 5-launch layer runs) when the shape does not fit:
+// Q4_0 layers, fast mode, one GPU, the norm-epilogue conditions, head_dim % 32 == 0 (the attention launch emits wo's rhs planes),
+// wo / ffn_down rows = 16 per CU (two CUs share a norm chunk) or 32, gate/up rows in (gate, up) pairs.
+template <class T>
+ENG_G T* eng_g(T* p) {  // EngArgs declares its pointers global (engine.hpp)
+  return (ENG_G T*)p;
+}
+int engine_setup(crabml_hip_llama* c) {
+  crabml_hip_device* dev = c->dev;
+  const auto& g = c->cfg;
+  c->engine = false;
+  if (!(g.flags & CRABML_HIP_LLAMA_ENGINE)) return 0;
+  if (c->generic || c->kfused || c->wtype != CRABML_HIP_Q4_0 || c->tp != 1 || !c->norm_epi || (c->hd % 32) != 0) return 0;
+  const int dim = (int)g.embedding_dim, dim_l = c->dim_l, hidden_l = c->hidden_l;
+  EngGeom eg{};
+  eg.nblk_h = hidden_l / 32;
+  const int want = dim / 16 > eg.nblk_h ? dim / 16 : eg.nblk_h;
+  eg.G = want < dev->n_cu ? want : dev->n_cu;
+  if (dim / 16 <= eg.G) {
+    eg.rpc = 16;
+    eg.n_row_cus = dim / 16;
+  } else if (dim == 32 * eg.G) {
+    eg.rpc = 32;
+    eg.n_row_cus = eg.G;
+  } else {
+    return 0;
+  }
+  if ((eg.nblk_h + eg.G - 1) / eg.G > ENG_MAX_BLK) return 0;
+  eg.nb[0] = dim_l / 32;
+  eg.nb[1] = dim / 32;
+  eg.nb[2] = hidden_l / 32;
+  for (int op = 0; op < 3; op++) {
+    const int row_bytes = eg.nb[op] * 18;
+    int R = 8;
+    while (R > 1 && R * row_bytes > ENG_SLOT) R >>= 1;
+    if (R * row_bytes > ENG_SLOT) return 0;
+    if (op == 1 && R < 2) return 0;
+    if (op != 1 && eg.rpc % R) return 0;
+    eg.R[op] = R;
+    eg.ni[op] = (R * row_bytes + 1023) / 1024;
+  }
+  size_t act = act_layout(c->qt, (size_t)dim_l).total;
+  if (act_layout(c->qt, (size_t)dim).total > act) act = act_layout(c->qt, (size_t)dim).total;
+  if (act_layout(c->qt, (size_t)hidden_l).total > act) act = act_layout(c->qt, (size_t)hidden_l).total;
+  const size_t lds_max = 160 * 1024 - 4096;  // static LDS of k_engine (EngShared) stays below 4 KiB
+  if (act + 3 * (size_t)ENG_SLOT > lds_max) return 0;
+  int D = (int)((lds_max - act) / ENG_SLOT);
+  if (D > ENG_MAX_D) D = ENG_MAX_D;
+  if (const char* e = getenv("CRABML_HIP_ENGINE_D")) {
+    const int v = atoi(e);
+    if (v >= 3 && v <= D) D = v;
+  }
+  c->eng_nc = 3;
+  if (const char* e = getenv("CRABML_HIP_ENGINE_NC")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 7) c->eng_nc = v;
+  }
+  c->eng_flags = 0;
+  if (const char* e = getenv("CRABML_HIP_ENGINE_THIN")) c->eng_flags |= atoi(e) ? 1 : 0;
+  c->eng_D = D;
+  c->eng_lds = (size_t)D * ENG_SLOT + act;
+  if (hipFuncSetAttribute((const void*)k_engine<CRABML_HIP_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->eng_lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  // per-CU stream offsets inside a layer
+  auto nslots = [&](int op, int cu) {
+    if (op == 1) return cu < eg.nblk_h ? ((eg.nblk_h - cu + eg.G - 1) / eg.G) * (64 / eg.R[1]) : 0;
+    return cu < eg.n_row_cus ? eg.rpc / eg.R[op] : 0;
+  };
+  std::vector<unsigned long long> off(eg.G + 1, 0);
+  int nmax[3] = {0, 0, 0};
+  for (int cu = 0; cu < eg.G; cu++) {
+    unsigned long long b = 0;
+    for (int op = 0; op < 3; op++) {
+      const int n = nslots(op, cu);
+      if (n > nmax[op]) nmax[op] = n;
+      b += (unsigned long long)n * eg.ni[op] * 1024ull;
+    }
+    off[cu + 1] = off[cu] + b;
+  }
+  c->eng_layer_bytes = (size_t)off[eg.G];
+  const size_t total = c->eng_layer_bytes * g.n_layers;
+  CH_TRY(dalloc(c, total, (void**)&c->eng_stream));
+  CH_TRY(dalloc(c, (size_t)(eg.G + 1) * 8, (void**)&c->eng_cu_off));
+  CH_TRY(dalloc(c, (size_t)(dim / 4 + dim / 32) * 8, (void**)&c->xqgran));
+  if (!c->hgran) CH_TRY(dalloc(c, (size_t)(hidden_l / 4 + hidden_l / 32) * 8, (void**)&c->hgran));
+  hipStream_t st = dev->stream;
+  CH_HIP(dev, hipMemcpyAsync(c->eng_cu_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, st));
+  CH_HIP(dev, hipMemsetAsync(c->eng_stream, 0, total, st));
+  CH_HIP(dev, hipMemsetAsync(c->xqgran, 0, (size_t)(dim / 4 + dim / 32) * 8, st));
+  CH_HIP(dev, hipMemsetAsync(c->hgran, 0, (size_t)(hidden_l / 4 + hidden_l / 32) * 8, st));
+  for (size_t l = 0; l < g.n_layers; l++) {
+    unsigned char* dst = c->eng_stream + l * c->eng_layer_bytes;
+    for (int op = 0; op < 3; op++) {
+      const size_t n = (size_t)eg.G * nmax[op] * eg.R[op] * eg.nb[op];
+      if (n == 0) continue;
+      const Planes w0 = planes_of(op == 0 ? c->wo[l] : op == 1 ? c->gate[l] : c->down[l]);
+      const Planes w1 = planes_of(op == 1 ? c->up[l] : c->wo[l]);
+      k_eng_pack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(dst, c->eng_cu_off, eg, op, nmax[op], w0, w1);
+    }
+  }
+  // the layers' kernel arguments
+  const int L = (int)g.n_layers;
+  CH_TRY(dalloc(c, (size_t)L * sizeof(EngArgs), (void**)&c->eng_args));
+  std::vector<EngArgs> args((size_t)L);
+  const ActLayout ala = act_layout(c->qt, (size_t)dim_l), ald = act_layout(c->qt, (size_t)dim), alh = act_layout(c->qt, (size_t)hidden_l);
+  const ActPtrs ad = act_ptrs(c->act_dim, (size_t)dim, c->qt);
+  for (int l = 0; l < L; l++) {
+    EngArgs& ea = args[(size_t)l];
+    ea = EngArgs{};
+    ea.stream = eng_g(c->eng_stream + (size_t)l * c->eng_layer_bytes);
+    ea.cu_off = eng_g(c->eng_cu_off);
+    ea.G = eg.G;
+    ea.D = D;
+    ea.dim = dim;
+    ea.nblk_h = eg.nblk_h;
+    ea.nb_wo = eg.nb[0]; ea.nb_gu = eg.nb[1]; ea.nb_dn = eg.nb[2];
+    ea.R_wo = eg.R[0]; ea.R_gu = eg.R[1]; ea.R_dn = eg.R[2];
+    ea.ni_wo = eg.ni[0]; ea.ni_gu = eg.ni[1]; ea.ni_dn = eg.ni[2];
+    ea.rpc = eg.rpc;
+    ea.n_row_cus = eg.n_row_cus;
+    ea.attn_bytes = (int)ala.total; ea.attn_off_d = (int)ala.off_d; ea.attn_off_aux = (int)ala.off_aux;
+    ea.dim_off_d = (int)ald.off_d; ea.dim_off_aux = (int)ald.off_aux;
+    ea.hid_off_d = (int)alh.off_d; ea.hid_off_aux = (int)alh.off_aux;
+    ea.act_attn = eng_g((const unsigned char*)c->act_attn);
+    ea.x = eng_g(c->x);
+    ea.wn_ffn = eng_g((const float*)c->rms_ffn[l]->ptr);
+    ea.wn_next = eng_g((const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr);
+    ea.eps_ffn = 1e-5f;  // the literal of llama2.rs:611
+    ea.eps_next = g.rms_norm_eps;
+    ea.exp_tab = eng_g((const unsigned short*)dev->exp_table);
+    ea.oq = eng_g(ad.q); ea.od = eng_g(ad.d); ea.oisum = eng_g((int*)ad.isum);
+    ea.slots = eng_g(c->slots);
+    ea.pair = eng_g(c->slots + dim / 16);
+    ea.xq_g = eng_g(c->xqgran);
+    ea.xs_g = eng_g(c->xqgran + dim / 4);
+    ea.hq_g = eng_g(c->hgran);
+    ea.hs_g = eng_g(c->hgran + hidden_l / 4);
+    ea.serial = eng_g(c->state + 4);
+    ea.fault = eng_g(c->state + 5);
+    ea.nseg = n_segments(c);
+    ea.seg0 = 2 * l;  // the wo edge carries the even segment's epoch, the gate/up and down edges the odd segment's
+    ea.flags = c->eng_flags;
+  }
+  CH_HIP(dev, hipMemcpyAsync(c->eng_args, args.data(), args.size() * sizeof(EngArgs), hipMemcpyHostToDevice, st));
+  CH_HIP(dev, hipGetLastError());
+  CH_HIP(dev, hipStreamSynchronize(st));  // `off` and `args` leave scope
+  c->eng_g = eg;
+  c->engine = true;
   return 0;
 }
 
@@ -1426,7 +1603,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   A((g.embedding_dim / 16 + g.embedding_dim) * 8, (void**)&c->slots);
   // tp > 1: the epilogue also hosts the collective when the group is the P2P kind (or in the collective-free dry run)
   const bool p2p_comm = c->comm != nullptr && c->comm->p2p;
-  c->norm_epi = !generic && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
+  // (not for the K-quant segment path -- a Q4_1 body with a classifier of another format runs it: its wo / ffn_down launches
+  // host neither the norm epilogue nor the collective, so over a P2P group the stand-alone all-reduce launch must run)
+  c->norm_epi = !generic && !c->kfused && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->ffn_fused = c->norm_epi && (g.flags & CRABML_HIP_LLAMA_FFN_FUSION);  // opt-in: measured slower than the two kernels
   if (c->ffn_fused) {
@@ -1440,6 +1619,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     A(dim_l * 8, (void**)&c->a8gran);
     A(hidden_l * 8, (void**)&c->h8gran);
   }
+  if (rc == 0) rc = engine_setup(c);
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);

@@ -18,7 +18,10 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
                                               const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
                                               signed char* __restrict__ xq, unsigned short* __restrict__ xd,
                                               void* __restrict__ xisum, int n_heads, int n_kv, int hd, int seq_cap,
-                                              PrefetchPlan pf, int q81, long long* __restrict__ stamps = nullptr) {
+                                              PrefetchPlan pf, int q81_in, long long* __restrict__ stamps = nullptr) {
+  // q81_in: bits 0-7 = the output quantizer (0 Q8_0, 1 Q8_1), bit 8 = sequential softmax row sum at any length (strict device)
+  const int q81 = q81_in & 255;
+  const bool strict_sum = (q81_in & 256) != 0;
   if ((int)blockIdx.x >= n_heads) {
     prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
     return;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
   __syncthreads();
   stamp(2);
   // ---- softmax (in place; probabilities rounded to f16 for the f16 cache)
-  softmax_row<KV16>(scores, seq, exp_tab, s_red, &s_val);
+  softmax_row<KV16>(scores, seq, exp_tab, s_red, &s_val, strict_sum);
   stamp(3);
   // ---- out[n] = sum_t p[t] * V[t][n]
   float val = 0.0f;
@@ -205,7 +208,9 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
                                                 const unsigned short* __restrict__ exp_tab, float* __restrict__ out,
                                                 signed char* __restrict__ xq, unsigned short* __restrict__ xd,
                                                 void* __restrict__ xisum, int n_heads, int n_kv, int hd_rt, int seq_cap, int S,
-                                                PrefetchPlan pf, int q81, long long* __restrict__ stamps, AttnQ8K k8) {
+                                                PrefetchPlan pf, int q81_in, long long* __restrict__ stamps, AttnQ8K k8) {
+  const int q81 = q81_in & 255;  // bit 8: sequential softmax row sum at any length (strict device), as in k_attn
+  const bool strict_sum = (q81_in & 256) != 0;
   if ((int)blockIdx.x >= n_heads) {
     prefetch_wg(pf, blockIdx.x - n_heads, gridDim.x - n_heads);
     return;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
     for (int t = tid; t < seq; t += 256) scores[t] = score_of(t);
     __syncthreads();
     stamp(2);
-    softmax_row<true>(scores, seq, exp_tab, s_red, &s_val);
+    softmax_row<true>(scores, seq, exp_tab, s_red, &s_val, strict_sum);
   }
   stamp(3);
   // ---- out[n] = sum_t p[t] * V[t][n]: f16 product and f16 sum per position, in position order (buf_f16.rs:152-163).
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q
 template <int NW>  // waves per workgroup: 4, or 16 for the decode step's one row per head
 __global__ __launch_bounds__(NW * 64) void k_attn_softmax(const float* __restrict__ scores_g, const int* __restrict__ pos_d,
                                                          const unsigned short* __restrict__ exp_tab,
-                                                         unsigned short* __restrict__ p16, int seq_cap, int row0) {
+                                                         unsigned short* __restrict__ p16, int seq_cap, int row0, int strict_sum) {
   extern __shared__ float lds[];
   __shared__ float s_red[NW];
   __shared__ float s_val;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_softmax(const float* __restric
   p16 += (size_t)blockIdx.y * gridDim.x * seq_cap;
   for (int t = threadIdx.x; t < seq; t += NW * 64) lds[t] = scores_g[(size_t)head * seq_cap + t];
   __syncthreads();
-  softmax_row<true, NW>(lds, seq, exp_tab, s_red, &s_val);
+  softmax_row<true, NW>(lds, seq, exp_tab, s_red, &s_val, strict_sum != 0);
   for (int t = threadIdx.x; t < seq; t += NW * 64) p16[(size_t)head * seq_cap + t] = f2h(lds[t]);  // exact: already f16 values
 }
 

@@ -427,14 +427,17 @@ __global__ __launch_bounds__(256) void k_qkv_epi_rows(const float* __restrict__ 
 }
 
 // softmax.rs:36-54 over scores[0..seq) in LDS, in place, by a workgroup of NW waves (4 or 16): max, exp through the f16
-// table, row sum sequential up to 1024 positions (bit-exact) and a block tree beyond, true division.  F16: the
+// table, row sum sequential up to 1024 positions (bit-exact; at every length when seq_sum is set) and a block tree beyond,
+// true division.  F16: the
 // probabilities are then rounded to f16 (quantize_f32_f16 of the lhs, batch_matmul.rs:39).  Ends with a barrier.
 // The tree is defined on 256 partial sums (partial v = positions v, v + 256, ... in order) whatever NW is: 16 waves share
 // the max / exp / division passes (the long-context softmax kernel), the sums are the 4-wave kernel's bit for bit.
 // s_red: NW floats.
+// seq_sum: the row sum stays sequential at ANY length (the strict-order device: softmax.rs:43-48 is one scalar loop; the block
+// tree beyond 1024 positions is the fast kernels' re-association, pinned in tests/helpers.FAST_TOL)
 template <bool F16, int NW = 4>
 __device__ __forceinline__ void softmax_row(float* scores, int seq, const unsigned short* __restrict__ exp_tab, float* s_red,
-                                            float* s_val_p) {
+                                            float* s_val_p, bool seq_sum = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int BD = NW * 64;
   float mx = -INFINITY;
@@ -477,7 +480,7 @@ __device__ __forceinline__ void softmax_row(float* scores, int seq, const unsign
     }
   }
   __syncthreads();
-  if (seq <= 1024) {
+  if (seq <= 1024 || seq_sum) {
     if (tid < 64) {
       // sequential row sum (softmax.rs:43-48) without an LDS round trip per add: wave 0 holds 64 values per
       // pass in registers and v_readlane feeds one dependent v_add chain; lanes past `seq` add +0.0 (exact)

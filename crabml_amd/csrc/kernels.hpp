@@ -43,7 +43,7 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
 int launch_piece_ints(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, size_t row, const void* act, int variant,
                       int32_t* out, float* fout);
 // elementwise.hip: plain streaming read of `bytes` bytes (crabml_hip_debug_read_ceiling), timed by the event pair
-void launch_stream_read(hipStream_t st, const void* buf, size_t bytes, int* sink, hipEvent_t e0, hipEvent_t e1);
+void launch_stream_read(hipStream_t st, const void* buf, size_t bytes, int* sink, hipEvent_t e0, hipEvent_t e1, int pattern);
 void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t row, const void* act, int32_t* out);
 
 // ---- elementwise.hip

@@ -193,15 +193,24 @@ int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_
  * The trait above costs ~31 launches per layer (one per Tensor call of crabml-llama2/src/llama2.rs:226-271),
  * which makes batch-1 decode launch-bound on MI355X (profiles/r01_trait_path_kernel_trace.md).  This entry
  * point serves the SAME op sequence -- Llama2Runner::forward for the Llama architecture, n_batch = 1
- * (llama2.rs:184-281, 527-638) -- as 8 fused kernels per layer replayed from one hipGraph:
- *   rmsnorm*w+quantize | QKV GEMV + RoPE + scale + KV append | attention (QK^T, softmax, PV, quantize) |
- *   wo GEMV + residual | rmsnorm*w+quantize | gate/up GEMV + SiLU*mul | quantize | down GEMV + residual
- * with token id and position living in device memory (greedy argmax on device, sampler.rs:109-116).
+ * (llama2.rs:184-281, 527-638) -- as FIVE kernels per layer replayed from one hipGraph:
+ *   q/k/v GEMV + RoPE + scale + KV append | attention (QK^T, softmax, PV, quantize for wo) |
+ *   wo GEMV + residual + the ffn RMSNorm + quantize | gate/up GEMV + SiLU*mul + quantize |
+ *   ffn_down GEMV + residual + the next layer's RMSNorm + quantize
+ * (the norms run in the producing GEMV's epilogue through one in-launch gather; attention switches to three
+ * multi-workgroup kernels from `attn_long_from` cached positions), or as THREE with CRABML_HIP_LLAMA_ENGINE
+ * (q/k/v | attention | one persistent launch for wo .. ffn_down fed by an LDS-DMA weight stream), with token id
+ * and position living in device memory (greedy argmax on device, sampler.rs:109-116).
  * Arithmetic is the reference's (same rounding points; RoPE cos/sin tabulated on the host with the same
- * libm + iterated-theta recurrence); only GEMV block terms are summed wave-parallel, exactly like
- * crabml_hip_matmul_vec.  With CRABML_HIP_FLAG_STRICT_ORDER the GEMVs run in scalar order and the step
- * is bit-identical to the reference.  Weights: wq..ffn_* and output must share one dtype in
- * {Q4_0, Q8_0}; norm weights F32; otherwise CRABML_HIP_NOT_IMPLEMENTED (use the per-op trait path). */
+ * libm + iterated-theta recurrence); only GEMV block terms (and, fast mode, the RMSNorm chunk sums and softmax
+ * row sums past 1024 positions) are summed wave-parallel, exactly like crabml_hip_matmul_vec.  With
+ * CRABML_HIP_FLAG_STRICT_ORDER every sum runs in the reference's scalar order and the step is bit-identical
+ * to the reference at every context length.
+ * Weights: layer matrices in any matmul_vec format (Q4_0, Q8_0, Q4_1 and Q4_K run fused kernels, Q4_K also
+ * with attn_v / ffn_down in Q6_K -- llama.cpp's *_K_M mixes; Q6_K, Q8_K, F16, F32 and any other mix sharing
+ * one rhs dtype run as per-op segments inside the same graph); the classifier may have another format; norm
+ * weights F32.  Tensor types whose rhs dtypes differ inside a layer: CRABML_HIP_NOT_IMPLEMENTED (use the
+ * per-op trait path). */
 typedef struct crabml_hip_llama crabml_hip_llama_t;
 #define CRABML_HIP_LLAMA_NO_GRAPH 1 /* launch the kernels eagerly instead of replaying a hipGraph */
 #define CRABML_HIP_LLAMA_NO_PREFETCH 2 /* do not warm the Infinity Cache from the latency-bound stages */
@@ -227,6 +236,10 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                                         separate launches (bit-identical) */
 #define CRABML_HIP_LLAMA_NO_PV_ROW_TILES 16384 /* A/B: long-prompt prefill runs the PV pass one prompt row per workgroup */
 #define CRABML_HIP_LLAMA_NO_STAGED_ATTENTION 8192 /* A/B: short-context attention without the LDS staging of K / V (k_attn) */
+#define CRABML_HIP_LLAMA_ENGINE 524288 /* Q4_0 layers, fast mode, one GPU: wo + RMSNorm + gate/up + SiLU*mul + ffn_down + RMSNorm of a
+                                          layer as ONE persistent launch fed by an LDS-DMA loader over a CU-major copy of the
+                                          weights (crabml_amd/csrc/engine.hpp); bit-identical to the 5-launch layer; ignored
+                                          (5 launches) when the shape does not fit */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */

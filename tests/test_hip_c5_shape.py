@@ -1,0 +1,112 @@
+"""BASELINE config C5 at ITS OWN widths (round-2 verdict: nothing on the device had been compared with the oracle at dim 8192).
+
+Llama-3-70B's layer shapes -- dim 8192, hidden 28672, 64 query / 8 kv heads, head_dim 128, vocab 128256 (llama2.rs:244-246, 600,
+620-633) -- with two layers (the oracle decodes that at a few tokens/s; the widths, not the depth, select the kernels):
+k_norm_quant<12>, 256 co-resident workgroups in the wo norm gather, 512 in ffn_down's split chunks (hidden / 32 = 896 blocks), the
+k_gateup_q grid of 896 workgroups, 4608-byte weight rows.
+
+  * one GPU, tp = 1: the STRICT device (fused step, per-op trait path, batched prefill) is bit-identical to OracleLlamaRunner;
+    the FAST device stays inside the tolerance pinned for the 8B shape and reproduces the oracle's greedy tokens;
+  * tp = 8 at the real per-rank shapes (8 query heads + 1 kv head, 1024 wo columns, 3584 hidden rows / ffn_down columns per
+    rank): 8 ranks as 8 PROCESSES sharing this GPU over hipIpc, strict mode, every rank's logits bit-identical to
+    OracleTpLlamaRunner; the fast kernels at the same per-rank shapes through the single-device simulation (collective replaced by
+    the rank-order sum) inside the fast tolerance.  (The fused-collective kernels cannot run as 8 ranks on ONE GPU at this width:
+    a rank's ffn_down launch alone fills all 256 CUs, so its peers' launches -- whose partial sums it polls for -- cannot
+    become resident; they are validated across 8 processes at small widths in tests/test_hip_tp_p2p.py.)"""
+import os
+
+import numpy as np
+import pytest
+
+from crabml_amd import synth, tp as tp_mod
+from oracle import oracle as o
+from tests.helpers import to_oracle
+from tests.test_hip_tp_p2p import spawn
+
+pytestmark = pytest.mark.gpu
+SHAPE = synth.ModelShape("Llama-3-70B (2 layers)", 8192, 28672, 2, 64, 8, 128256, 64, 1e-5, None)
+TOKS = [1, 365, 9906]
+FAST_TOL = 2e-3  # = the 8B shape's (tests/test_hip_headline.py)
+
+
+def _threads():
+    return max(16, min(64, os.cpu_count() or 16))
+
+
+@pytest.fixture(scope="module")
+def c5():
+    model = synth.build_model(SHAPE, synth.Q4_0, seed=31)
+    odev = o.OracleDevice(thread_num=_threads(), use_avx2=False)
+    oconf, ow = to_oracle(model, odev)
+    orr = o.OracleLlamaRunner(oconf, ow, odev, 64, True)
+    ref = [orr.forward([t], i).copy() for i, t in enumerate(TOKS)]
+    del orr
+    yield model, ref
+
+
+def test_c5_shape_strict_is_bit_identical_to_the_oracle(ca, c5):
+    model, ref = c5
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, dev)
+    f = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    for i, t in enumerate(TOKS):
+        assert np.array_equal(f.forward(t, i).view(np.uint32), ref[i].view(np.uint32)), f"strict fused step, position {i}"
+    r = ca.Llama2Runner(conf, w, dev, 64, True)
+    assert np.array_equal(r.forward([TOKS[0]], 0).view(np.uint32), ref[0].view(np.uint32)), "strict per-op trait path, position 0"
+    p = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    assert np.array_equal(p.prefill(TOKS).view(np.uint32), ref[-1].view(np.uint32)), "strict batched prefill"
+
+
+def test_c5_shape_fast_path_against_the_oracle(ca, c5):
+    model, ref = c5
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    f = ca.HipLlamaRunner(conf, w, dev, 64, True)  # hipGraph, norm epilogue (256 / 512 co-resident workgroups)
+    errs = []
+    for i, t in enumerate(TOKS):
+        lg = f.forward(t, i)
+        scale = float(np.max(np.abs(ref[i])))
+        errs.append(float(np.max(np.abs(lg.astype(np.float64) - ref[i].astype(np.float64)))) / scale)
+        a_h, a_o = o.argmax_last(lg), o.argmax_last(ref[i])
+        assert a_h == a_o or float(ref[i][a_o] - ref[i][a_h]) / scale <= 2 * errs[-1], (i, errs)
+    assert max(errs) <= FAST_TOL, errs
+    # without the norm epilogue (k_norm_quant<12> as its own launch) and with split chunks forced: same bits
+    for kw in ({"norm_epilogue": False}, {"extra_flags": 16}, {"extra_flags": 32}):
+        g = ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, **kw)
+        h = ca.HipLlamaRunner(conf, w, dev, 64, True)
+        for i, t in enumerate(TOKS[:2]):
+            assert np.array_equal(g.forward(t, i).view(np.uint32), h.forward(t, i).view(np.uint32)), (kw, i)
+
+
+def _oracle_tp(model, tp):
+    odev = o.OracleDevice(thread_num=_threads(), use_avx2=False)
+    rank_w = []
+    for r in range(tp):
+        conf, w = to_oracle(tp_mod.shard_model(model, tp, r, True), odev)
+        rank_w.append(w)
+    runner = o.OracleTpLlamaRunner(conf, rank_w, odev, 64, True)
+    return [runner.forward([t], i).copy() for i, t in enumerate(TOKS)]
+
+
+def test_c5_shape_tp8_strict_across_eight_processes_equals_the_oracle(ca, c5, tmp_path):
+    model, _ = c5
+    ref = np.stack(_oracle_tp(model, 8))
+    spawn(tmp_path, 8, "c5-2l", "Q4_0", True, "step", timeout=900)
+    for r in range(8):
+        got = np.load(tmp_path / f"out.{r}.npy")
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"rank {r}"
+
+
+def test_c5_shape_tp8_fast_kernels_at_the_per_rank_shapes(ca, c5):
+    model, ref1 = c5
+    dev = ca.HipTensorDevice(0)
+    ranks = []
+    for r in range(8):
+        conf, w = synth.to_hip(tp_mod.shard_model(model, 8, r, True), dev)
+        ranks.append(ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, 8, r))
+    errs = []
+    for i, t in enumerate(TOKS):
+        lg = ca.HipLlamaRunner.tp_sim_forward(ranks, t, i)
+        errs.append(float(np.max(np.abs(lg - ref1[i])) / np.max(np.abs(ref1[i]))))
+    # against the single-GPU oracle: the rank-order sum re-associates the k dimension of wo / ffn_down, nothing else
+    assert max(errs) <= 4 * FAST_TOL, errs

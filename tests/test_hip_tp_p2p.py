@@ -117,7 +117,7 @@ def test_fast_step_with_the_collective_in_the_epilogue_equals_the_simulation(ca,
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{fmt}: step {i}"
 
 
-def spawn(tmp_path, world, shape, fmt, strict, mode):
+def spawn(tmp_path, world, shape, fmt, strict, mode, timeout=240):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "tp_p2p_worker.py"), str(tmp_path), str(r), str(world), shape, fmt,
                                "1" if strict else "0", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -125,7 +125,7 @@ def spawn(tmp_path, world, shape, fmt, strict, mode):
     outs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=240)
+            o, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -195,3 +195,20 @@ def test_fast_tp_step_across_eight_processes(tmp_path):
     for r in range(8):
         got = np.load(tmp_path / f"out.{r}.npy")
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"rank {r}"
+
+
+def test_q4_1_body_with_a_q6_k_classifier_over_the_p2p_group(ca):
+    """Round-2 review finding: a Q4_1 model whose classifier has another format runs the K-quant segment path, whose wo /
+    ffn_down launches host no collective -- the stand-alone all-reduce launch must run over a P2P group (it was skipped:
+    every rank added only its own partial sums).  tp = 2 over the P2P group == the single-device simulation, bit for bit."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_1, seed=35, embed_type=synth.Q6_K, output_type=synth.Q6_K)
+    sim = hip_tp_ranks(ca, model, 2, True, ca.HipTensorDevice(0))
+    want = [ca.HipLlamaRunner.tp_sim_forward(sim, t, i).copy() for i, t in enumerate(TOKS)]
+    devs, comms = local_group(ca, 2, model.shape.dim, False)
+    runners = []
+    for r in range(2):
+        conf, w = synth.to_hip(tp_mod.shard_model(model, 2, r, True), devs[r])
+        runners.append(ca.HipLlamaRunner(conf, w, devs[r], 64, True, True, True, 2, r, comms[r]))
+    got = run_group(ca, runners, TOKS)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"

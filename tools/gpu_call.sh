@@ -1,20 +1,21 @@
 #!/bin/bash
-# One GPU-box visit (gpurun): GPU test suite, the DMA lab, the default bench line, A/B bench lines.  Logs under gpurun_out/.
-# usage: gpurun --timeout 1500 -- 'bash tools/gpu_call.sh TAG [tests] [lab] [bench] [ab]'
-TAG=${1:-r2}; shift
-WHAT="${*:-tests lab bench ab}"
+# One GPU-box visit (gpurun).  Logs under gpurun_out/.
+# usage: gpurun --timeout 1800 -- 'bash tools/gpu_call.sh TAG [engtests] [newtests] [tests] [ab] [bench] [engbench] [fault]'
+TAG=${1:-r3}; shift
+WHAT="${*:-engtests newtests tests ab bench}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+PT="python -m pytest -q -p no:cacheprovider"
 for w in $WHAT; do
   case $w in
-    tests) timeout 1100 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider > gpurun_out/gpu_tests_$TAG.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/gpu_tests_$TAG.log ;;
-    lab) timeout 300 ./build/dma_lab > gpurun_out/dma_lab_$TAG.log 2>&1; echo "lab rc=$?"; cat gpurun_out/dma_lab_$TAG.log ;;
-    bench) timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"; cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err ;;
-    ab) for f in 16 32; do timeout 300 python bench.py --flags $f --steps 48 --repeats 3 --no-cpu-baseline --no-parity-check --no-context --no-prefill > gpurun_out/bench_${TAG}_flags$f.json 2>> gpurun_out/bench_$TAG.err; python - <<PY
-import json
-d=json.load(open("gpurun_out/bench_${TAG}_flags$f.json"))
-print("flags $f:", d["value"], {k:v["avg_us"] for k,v in d["roofline"]["per_stage"].items()})
-PY
-    done ;;
+    engtests) timeout 600 $PT tests/test_hip_engine.py -x > gpurun_out/eng_tests_$TAG.log 2>&1; echo "engtests rc=$?"; tail -15 gpurun_out/eng_tests_$TAG.log ;;
+    newtests) timeout 1500 $PT tests/test_hip_long_context_oracle.py tests/test_hip_c5_shape.py "tests/test_hip_tp_p2p.py::test_q4_1_body_with_a_q6_k_classifier_over_the_p2p_group" > gpurun_out/new_tests_$TAG.log 2>&1; echo "newtests rc=$?"; tail -25 gpurun_out/new_tests_$TAG.log ;;
+    tests) timeout 1500 $PT tests -m gpu --maxfail=25 --deselect tests/test_hip_long_context_oracle.py --deselect tests/test_hip_c5_shape.py --deselect tests/test_hip_engine.py > gpurun_out/gpu_tests_$TAG.log 2>&1; echo "tests rc=$?"; tail -8 gpurun_out/gpu_tests_$TAG.log ;;
+    alltests) timeout 2400 $PT tests -m gpu --maxfail=25 > gpurun_out/gpu_tests_all_$TAG.log 2>&1; echo "alltests rc=$?"; tail -8 gpurun_out/gpu_tests_all_$TAG.log ;;
+    ab) timeout 900 python tools/engine_ab.py --check ${ENGINE_AB_ARGS:-} > gpurun_out/engine_ab_$TAG.log 2>&1; echo "ab rc=$?"; cat gpurun_out/engine_ab_$TAG.log ;;
+    bench) timeout 900 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"; cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err ;;
+    engbench) timeout 900 python bench.py --flags 524288 > gpurun_out/bench_eng_$TAG.json 2> gpurun_out/bench_eng_$TAG.err; echo "engbench rc=$?"; cat gpurun_out/bench_eng_$TAG.json; tail -3 gpurun_out/bench_eng_$TAG.err ;;
+    fault) timeout 900 $PT tests/test_hip_fault_paths.py > gpurun_out/fault_tests_$TAG.log 2>&1; echo "fault rc=$?"; tail -15 gpurun_out/fault_tests_$TAG.log ;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke_$TAG.log ;;
   esac
 done
