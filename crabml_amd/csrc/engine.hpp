@@ -78,7 +78,17 @@ struct EngArgs {
   ENG_G int* fault;
   int nseg, seg0;                     // epochs: serial * nseg + seg0 + 1 (wo edge), + 2 (gate/up and down edges)
   int flags;                          // 1: thin the loader (one slot in flight) while this CU gathers
+  ENG_G unsigned long long* stamps;   // profiling hook (CRABML_HIP_ENGINE_STAMPS=1; NULL otherwise): ENG_STAMPS words per workgroup,
+                                      // s_memrealtime (100 MHz) at the phase boundaries + accumulated wait times (tools/engine_stamps.py)
 };
+constexpr int ENG_STAMPS = 64;
+__device__ __forceinline__ unsigned long long eng_now() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void eng_stamp(const EngArgs& a, int c, int i, int lane) {
+  if (a.stamps != nullptr && lane == 0) a.stamps[(size_t)c * ENG_STAMPS + i] = eng_now();
+}
+__device__ __forceinline__ void eng_stamp_val(const EngArgs& a, int c, int i, int lane, unsigned long long v) {
+  if (a.stamps != nullptr && lane == 0) a.stamps[(size_t)c * ENG_STAMPS + i] = v;
+}
 
 // ---- LDS words shared by the waves of a workgroup -----------------------------------------------------------------------
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -160,10 +170,12 @@ __device__ __forceinline__ void eng_slot_dots(const unsigned char* slot, int nb,
 struct EngShared {
   unsigned filled[ENG_MAX_D];  // filled[p] = s + 1 once slot s (s % D == p) has landed
   unsigned freed[ENG_MAX_D];   // freed[p]  = s + 1 once slot s has been read
-  unsigned phase;              // rhs vectors staged so far: 1 attention output, 2 normalized x, 3 h
+  unsigned phase;              // rhs vectors gathered so far: 2 normalized x, 3 h
   unsigned giveup;             // a wave hit a bound
   unsigned gathering;          // the edge wave is polling granules
   unsigned cnt_wo, cnt_gu, cnt_dn;       // slots finished per op
+  unsigned staged;                       // consumer waves that have copied their share of the attention output's planes
+  unsigned edge1, sweeps;                // the wo edge has published this CU's chunk; sweep shares finished (NC per vector)
   unsigned cnt_blk[ENG_MAX_BLK];         // slots finished per gate/up block
   float xrow[32];                        // this CU's wo / ffn_down row dots
   __attribute__((aligned(16))) float hv[32];              // the edge wave's chunk (nq_epilogue's hv)
@@ -192,12 +204,22 @@ __device__ __forceinline__ void eng_bail(EngCtx& k, ENG_G int* fault) {
 template <int FMT, int R, int OP>
 __device__ __forceinline__ bool eng_consume(EngCtx& k, const EngArgs& a, int s0, int n, int nb, const ActQ8_0& act, unsigned epoch) {
   EngShared* S = k.S;
+  const bool st = a.stamps != nullptr;
+  unsigned long long tw = 0, tb = 0, t0 = 0, t1 = 0;
+  int nslots = 0;
   for (int s = eng_first(s0, k.cw, k.NC); s < s0 + n; s += k.NC) {
     const int p = s % k.D;
+    if (st) t0 = eng_now();
     if (!lds_wait_ge(&S->filled[p], (unsigned)s + 1u, &S->giveup)) return false;
+    if (st) t1 = eng_now();
     float out[R];
     eng_slot_dots<FMT, R>(k.ring + (size_t)p * ENG_SLOT, nb, act, k.lane, out);
     if (k.lane == 0) lds_st_release(&S->freed[p], (unsigned)s + 1u);  // the slot's bytes are in registers (the sums depend on them)
+    if (st) {
+      tw += t1 - t0;
+      tb += eng_now() - t1;
+      nslots++;
+    }
     const int j = s - s0;
     if constexpr (OP == 1) {
       // slot j of the CU's gate/up stream: block ordinal t, rows [jj R, jj R + R) of the block's 64 interleaved rows
@@ -238,6 +260,12 @@ __device__ __forceinline__ bool eng_consume(EngCtx& k, const EngArgs& a, int s0,
       }
     }
   }
+  if (st && k.cw < 3) {  // per op and consumer wave (the first three): time waiting for slots, time computing, slots
+    const int base = 32 + (OP * 3 + k.cw) * 3;
+    eng_stamp_val(a, k.c, base, k.lane, tw);
+    eng_stamp_val(a, k.c, base + 1, k.lane, tb);
+    eng_stamp_val(a, k.c, base + 2, k.lane, (unsigned long long)nslots);
+  }
   return true;
 }
 template <int FMT, int OP>
@@ -277,26 +305,35 @@ __device__ __forceinline__ unsigned eng_poll(const ENG_G unsigned long long* p, 
   }
   return (unsigned)g;
 }
-// one wave sweeps `count` granules (16 per lane and pass, every granule re-read until the whole chunk carries the epoch:
-// MI355X_MICROARCH.md "allgather", cdna_hip_programming.md Guideline 16 R2) and hands each payload to `put(index, payload)`
-template <class PUT>
-__device__ __forceinline__ bool eng_sweep(const ENG_G unsigned long long* g, int count, unsigned epoch, int lane, EngShared* S, ENG_G int* fault, PUT put) {
-  for (int base = 0; base < count; base += 1024) {
-    unsigned v[16];
+// The all-to-all edges: every CU takes a whole quantized vector of n elements -- n / 4 {4 quants, epoch} granules and n / 32
+// {d | aux, epoch} granules -- into its LDS planes q | d | isum.  ALL consumer waves of the workgroup sweep (they have nothing
+// else to do until the vector is there), each a contiguous share of the granules with every load of a batch in flight at once:
+// under the weight stream a granule round trip costs 1 - 3 us (MI355X_MICROARCH.md "handoff-1to1" L->L), so what is paid per
+// edge is ROUND TRIPS, not bytes -- the first engine swept 16 granules per lane and pass from one wave: five dependent round
+// trips for h (35 KB) where one suffices.  A batch is re-read until every granule carries the epoch (Guideline 16 R2).
+constexpr int ENG_SWEEP_B = 24;  // granules per lane and batch (48 VGPRs)
+__device__ __forceinline__ bool eng_sweep_part(const ENG_G unsigned long long* qg, const ENG_G unsigned long long* sg, int n, unsigned epoch,
+                                               unsigned char* P, int off_d, int off_aux, int lane, int part, int nparts, EngShared* S,
+                                               ENG_G int* fault) {
+  unsigned* pq = (unsigned*)P;
+  unsigned short* pd = (unsigned short*)(P + off_d);
+  int* pa = (int*)(P + off_aux);
+  const int nq = n / 4, count = nq + n / 32;
+  const int per = ((count + nparts - 1) / nparts + 63) & ~63;
+  const int lo = part * per, hi = lo + per < count ? lo + per : count;
+  for (int base = lo; base < hi; base += 64 * ENG_SWEEP_B) {
+    unsigned long long x[ENG_SWEEP_B];
     int spins = 0;
     for (;;) {
       bool ok = true;
-      unsigned long long x[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
+      for (int i = 0; i < ENG_SWEEP_B; i++) {
         const int idx = base + i * 64 + lane;
-        x[i] = eng_ldg(g + (idx < count ? idx : base));
+        const int j = idx < hi ? idx : base;  // (base < hi: a valid granule)
+        x[i] = eng_ldg(j < nq ? qg + j : sg + (j - nq));
       }
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        v[i] = (unsigned)x[i];
-        ok &= (unsigned)(x[i] >> 32) == epoch;
-      }
+      for (int i = 0; i < ENG_SWEEP_B; i++) ok &= (unsigned)(x[i] >> 32) == epoch;
       if (__all(ok)) break;
       if (++spins > (1 << 19) || lds_ld(&S->giveup)) {
         if (lane == 0) {
@@ -308,25 +345,20 @@ __device__ __forceinline__ bool eng_sweep(const ENG_G unsigned long long* g, int
       __builtin_amdgcn_s_sleep(2);
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < ENG_SWEEP_B; i++) {
       const int idx = base + i * 64 + lane;
-      if (idx < count) put(idx, v[i]);
+      if (idx < hi) {
+        const unsigned v = (unsigned)x[i];
+        if (idx < nq) {
+          pq[idx] = v;
+        } else {
+          pd[idx - nq] = (unsigned short)(v & 0xffffu);
+          pa[idx - nq] = (int)(short)(v >> 16);  // |sum of 32 quants| <= 4064 fits 16 bits
+        }
+      }
     }
   }
   return true;
-}
-// sweep the quantized vector of n elements (n / 4 quant granules, n / 32 {d | aux} granules) into LDS planes q | d | isum
-__device__ __forceinline__ bool eng_gather_planes(const ENG_G unsigned long long* qg, const ENG_G unsigned long long* sg, int n, unsigned epoch,
-                                                  unsigned char* P, int off_d, int off_aux, int lane, EngShared* S, ENG_G int* fault) {
-  unsigned* pq = (unsigned*)P;
-  unsigned short* pd = (unsigned short*)(P + off_d);
-  int* pa = (int*)(P + off_aux);
-  if (!eng_sweep(sg, n / 32, epoch, lane, S, fault, [&](int i, unsigned v) {
-        pd[i] = (unsigned short)(v & 0xffffu);
-        pa[i] = (int)(short)(v >> 16);  // |sum of 32 quants| <= 4064 fits 16 bits
-      }))
-    return false;
-  return eng_sweep(qg, n / 4, epoch, lane, S, fault, [&](int i, unsigned v) { pq[i] = v; });
 }
 
 // The tail of wo / ffn_down for this CU's rows (nq_epilogue<FMT, SPLIT> restated for one wave per CU): xrow[] + residual -> x,
@@ -383,23 +415,41 @@ __device__ __forceinline__ float eng_edge(EngCtx& k, const EngArgs& a, unsigned 
   if (a.flags & 1) lds_st(&S->gathering, 1u);
   const int l32 = lane & 31;
   const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
+  // the hop: the partner's rows (split chunks) and EVERY workgroup's sum are requested at once -- one round trip when they are all
+  // there, which is the rule for all but the last workgroups to arrive; stale granules are polled individually afterwards.
+  // Up to 4 x 64 chunks (dim <= 8192), two halves each.
+  const int NB = (nchunks + 63) >> 6;
+  unsigned long long gr = 0, gs[8];
+  const bool need_row = split > 1 && lane < 32 && !own;
+  if (need_row) gr = eng_ldg(a.pair + blk * 32 + l32);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int b = j >> 1, h = j & 1, ch = b * 64 + lane;
+    const bool valid = b < NB && ch < nchunks && h < split;
+    gs[j] = valid ? eng_ldg(a.slots + (split > 1 ? 2 * ch + h : ch)) : 0ull;
+  }
   float v = 0.0f;
   if (split > 1) {
-    if (lane < 32) v = own ? S->hv[l32] : __builtin_bit_cast(float, eng_poll(a.pair + blk * 32 + l32, epoch, S, a.fault));
+    if (lane < 32)
+      v = own ? S->hv[l32]
+              : __builtin_bit_cast(float, (unsigned)(gr >> 32) == epoch ? (unsigned)gr : eng_poll(a.pair + blk * 32 + l32, epoch, S, a.fault));
   } else {
     v = S->hv[l32];
   }
   float sum = 0.0f;
-  for (int base = 0; base < nchunks; base += 64) {
-    const int ch = base + lane;
-    float cv;
-    if (split > 1) {
-      const float h0 = ch < nchunks ? __builtin_bit_cast(float, eng_poll(a.slots + 2 * ch, epoch, S, a.fault)) : 0.0f;
-      const float h1 = ch < nchunks ? __builtin_bit_cast(float, eng_poll(a.slots + 2 * ch + 1, epoch, S, a.fault)) : 0.0f;
-      cv = h0 + h1;
-    } else {
-      cv = ch < nchunks ? __builtin_bit_cast(float, eng_poll(a.slots + ch, epoch, S, a.fault)) : 0.0f;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    if (b >= NB) break;  // wave-uniform
+    const int ch = b * 64 + lane;
+    float hh[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (h < split && ch < nchunks) {
+        const unsigned long long g = gs[b * 2 + h];
+        hh[h] = __builtin_bit_cast(float, (unsigned)(g >> 32) == epoch ? (unsigned)g : eng_poll(a.slots + (split > 1 ? 2 * ch + h : ch), epoch, S, a.fault));
+      }
     }
+    const float cv = split > 1 ? hh[0] + hh[1] : hh[0];  // chunk = its two halves (lanes past the grid add +0.0)
     sum += wave_sum_f32(cv);
   }
   const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
@@ -451,6 +501,7 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
     S.giveup = 0;
     S.gathering = 0;
     S.cnt_wo = S.cnt_gu = S.cnt_dn = 0;
+    S.edge1 = S.sweeps = S.staged = 0;
   }
   __syncthreads();  // the only workgroup barrier: no DMA is in flight yet
   // this CU's share: rows [c rpc, (c + 1) rpc) of wo and ffn_down, gate/up blocks c, c + G, ...
@@ -469,17 +520,22 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
     int published = 0;  // slots [0, published) carry their filled word
     int ni_prev = 0;
     bool dead = false;
+    const bool st = a.stamps != nullptr;
+    unsigned long long t_full = 0, t_vm = 0, t0 = 0;
+    eng_stamp(a, c, 16, lane);
     for (int s = 0; s < total && !dead; s++) {
       const int ni = s < n_wo ? a.ni_wo : s < n_wo + n_gu ? a.ni_gu : a.ni_dn;
       const int p = s % D;
       if (s >= D && lds_ld(&S.freed[p]) < (unsigned)(s - D) + 1u) {
         // the ring is full: let everything land and hand it over, then wait for the slot
+        if (st) t0 = eng_now();
         eng_wait_vm<0>();
         for (; published < s; published++) lds_st(&S.filled[published % D], (unsigned)published + 1u);
         if (!lds_wait_ge(&S.freed[p], (unsigned)(s - D) + 1u, &S.giveup)) {
           dead = true;
           break;
         }
+        if (st) t_full += eng_now() - t0;
       }
       const bool thin = (a.flags & 1) && lds_ld(&S.gathering) != 0;
       const unsigned dst = ring_base + (unsigned)p * ENG_SLOT;
@@ -491,10 +547,18 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
       src += (size_t)ni * 1024;
       // slot s - 2 has landed once at most ni(s) + ni(s - 1) younger pieces are outstanding
       if (s >= 2 && published <= s - 2) {
+        if (st) t0 = eng_now();
         eng_wait_vm_le(ni + ni_prev);
+        if (st) t_vm += eng_now() - t0;
         for (; published <= s - 2; published++) lds_st(&S.filled[published % D], (unsigned)published + 1u);
       }
       ni_prev = ni;
+      if (st) {
+        if (s == 0) eng_stamp(a, c, 17, lane);
+        if (s == n_wo - 1) eng_stamp(a, c, 20, lane);
+        if (s == n_wo + n_gu - 1) eng_stamp(a, c, 21, lane);
+        if (s == total - 1) eng_stamp(a, c, 22, lane);
+      }
     }
     if (!dead) {
       if (total >= 2 && published <= total - 2) {
@@ -510,6 +574,9 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
       }
     }
     eng_wait_vm<0>();
+    eng_stamp(a, c, 23, lane);
+    eng_stamp_val(a, c, 24, lane, t_full);
+    eng_stamp_val(a, c, 25, lane, t_vm);
     return;
   }
 
@@ -529,27 +596,49 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
       wn1 = a.wn_ffn[blk * 32 + (lane & 31)];
       wn2 = a.wn_next[blk * 32 + (lane & 31)];
     }
-    for (int i = lane; i < a.attn_bytes / 16; i += 64) ((i32x4*)ACT)[i] = ((const i32x4*)a.act_attn)[i];
-    if (lane == 0) lds_st_release(&S.phase, 1u);
+    eng_stamp(a, c, 0, lane);
+  }
+  {
+    // (every consumer wave copies a share: 16-byte pieces, up to four requests in flight per lane)
+    const int n16 = a.attn_bytes / 16, step = NC * 64;
+    for (int i0 = k.cw * 64 + lane; i0 < n16; i0 += 4 * step) {
+      i32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) t[u] = ((const ENG_G i32x4*)a.act_attn)[i0 + u * step < n16 ? i0 + u * step : i0];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i0 + u * step < n16) ((i32x4*)ACT)[i0 + u * step] = t[u];
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&S.staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   // ---- wo
   {
-    if (!lds_wait_ge(&S.phase, 1u, &S.giveup)) return eng_bail(k, a.fault);
+    if (!lds_wait_ge(&S.staged, (unsigned)NC, &S.giveup)) return eng_bail(k, a.fault);
+    if (edge_wave) eng_stamp(a, c, 1, lane);
     const ActQ8_0 act{(const i32x4*)ACT, (const unsigned short*)(ACT + a.attn_off_d), (const int*)(ACT + a.attn_off_aux)};
     if (!eng_consume_r<FMT, 0>(k, a, a.R_wo, 0, n_wo, a.nb_wo, act, e1)) return eng_bail(k, a.fault);
   }
   if (edge_wave) {
     if (has_rows) {
       if (!lds_wait_ge(&S.cnt_wo, (unsigned)n_wo, &S.giveup)) return eng_bail(k, a.fault);
+      eng_stamp(a, c, 2, lane);
       res = eng_edge<false>(k, a, e1, res, wn1, a.eps_ffn);  // x2 = wo . attn + x; its norm chunk goes out as granules
+      eng_stamp(a, c, 3, lane);
     } else if (a.flags & 1) {
       lds_st(&S.gathering, 1u);
     }
-    // every CU takes the whole normalized vector (rhs of gate/up); the planes region is free: the wo slots of this CU are done
-    if (!eng_gather_planes(a.xq_g, a.xs_g, a.dim, e1, ACT, a.dim_off_d, a.dim_off_aux, lane, &S, a.fault)) return;
-    if (lane == 0) {
+    if (lane == 0) lds_st_release(&S.edge1, 1u);
+  }
+  // every CU takes the whole normalized vector (rhs of gate/up), all consumer waves sweeping; the planes region is free once
+  // this CU's wo slots have been read (edge1 is set after cnt_wo was seen)
+  if (!lds_wait_ge(&S.edge1, 1u, &S.giveup)) return eng_bail(k, a.fault);
+  if (!eng_sweep_part(a.xq_g, a.xs_g, a.dim, e1, ACT, a.dim_off_d, a.dim_off_aux, lane, k.cw, NC, &S, a.fault)) return;
+  if (lane == 0) {
+    const unsigned done = __hip_atomic_fetch_add(&S.sweeps, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+    if (done == (unsigned)NC) {
       lds_st(&S.gathering, 0u);
       lds_st_release(&S.phase, 2u);
+      eng_stamp(a, c, 4, lane);
     }
   }
   // ---- gate / up
@@ -558,14 +647,19 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
     const ActQ8_0 act{(const i32x4*)ACT, (const unsigned short*)(ACT + a.dim_off_d), (const int*)(ACT + a.dim_off_aux)};
     if (!eng_consume_r<FMT, 1>(k, a, a.R_gu, n_wo, n_gu, a.nb_gu, act, e2)) return eng_bail(k, a.fault);
   }
+  // all of h (rhs of ffn_down) -- once this CU's own gate/up slots have been read (they use the planes region)
+  if (!lds_wait_ge(&S.cnt_gu, (unsigned)n_gu, &S.giveup)) return eng_bail(k, a.fault);
   if (edge_wave) {
-    // all of h (rhs of ffn_down) -- once this CU's own gate/up slots have been read (they use the planes region)
-    if (!lds_wait_ge(&S.cnt_gu, (unsigned)n_gu, &S.giveup)) return eng_bail(k, a.fault);
-    if (a.flags & 1) lds_st(&S.gathering, 1u);
-    if (!eng_gather_planes(a.hq_g, a.hs_g, a.nblk_h * 32, e2, ACT, a.hid_off_d, a.hid_off_aux, lane, &S, a.fault)) return;
-    if (lane == 0) {
+    eng_stamp(a, c, 5, lane);
+    if ((a.flags & 1) && lane == 0) lds_st(&S.gathering, 1u);
+  }
+  if (!eng_sweep_part(a.hq_g, a.hs_g, a.nblk_h * 32, e2, ACT, a.hid_off_d, a.hid_off_aux, lane, k.cw, NC, &S, a.fault)) return;
+  if (lane == 0) {
+    const unsigned done = __hip_atomic_fetch_add(&S.sweeps, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+    if (done == 2u * (unsigned)NC) {
       lds_st(&S.gathering, 0u);
       lds_st_release(&S.phase, 3u);
+      eng_stamp(a, c, 6, lane);
     }
   }
   // ---- ffn_down
@@ -576,8 +670,10 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
   }
   if (edge_wave && has_rows) {
     if (!lds_wait_ge(&S.cnt_dn, (unsigned)n_dn, &S.giveup)) return eng_bail(k, a.fault);
+    eng_stamp(a, c, 7, lane);
     (void)eng_edge<true>(k, a, e2, res, wn2, a.eps_next);  // x3 = down . h + x2; the next norm's planes in global memory
     if (lane == 0) lds_st(&S.gathering, 0u);
+    eng_stamp(a, c, 8, lane);
   }
 }
 

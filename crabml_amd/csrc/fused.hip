@@ -44,7 +44,8 @@ struct crabml_hip_tp_comm {
   // P2P kind (crabml_hip_tp_p2p_*): the one-shot all-reduce over peer-mapped inboxes (fused_ffn.hpp, TpP2P)
   bool p2p = false;
   bool connected = false;
-  unsigned long long* inbox = nullptr;   // this rank's inbox: 2 slots x nranks rows x cap granules
+  unsigned long long* inbox = nullptr;   // this rank's inbox: TP_SLOTS slots x nranks rows x cap granules
+  bool via_ipc[8] = {false};             // peer[r] was mapped with hipIpcOpenMemHandle (closed at destroy; plain pointers are not)
   size_t inbox_bytes = 0;
   unsigned cap = 0;                      // granules per row
   bool finegrained = false;
@@ -130,6 +131,7 @@ struct crabml_hip_llama {
   unsigned long long* eng_cu_off = nullptr;     // [G + 1]
   unsigned long long* xqgran = nullptr;         // dim / 4 + dim / 32 granules of the normalized residual (rhs of gate/up)
   EngArgs* eng_args = nullptr;                  // [n_layers] kernel arguments of the layers' launches (device memory, static)
+  unsigned long long* eng_stamps = nullptr;     // CRABML_HIP_ENGINE_STAMPS=1: [n_layers][G][ENG_STAMPS] profiling words
   unsigned tp_salt = 0;      // P2P group: epoch salt of this context (see TpP2P::salt)
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
   bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
@@ -142,6 +144,10 @@ struct crabml_hip_llama {
   int out_cap = 0;
   float* am_val = nullptr;  // argmax partials
   int* am_idx = nullptr;
+  // CRABML_HIP_LLAMA_TP_SPLIT_VOCAB: this rank's classifier rows [vocab_off, vocab_off + vocab_l) (otherwise 0 / vocab_size)
+  bool split_vocab = false;
+  int vocab_l = 0, vocab_off = 0;
+  int* am_best = nullptr;   // {max bits, index} of this rank's shard (single-device simulation: combined by the driver)
   size_t kv_len = 0;
   // [0]: one attention workgroup per head; [1]: the long-context attention kernels (from attn_long_from positions)
   hipGraph_t graph[2] = {nullptr, nullptr};
@@ -281,6 +287,30 @@ void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned sho
   if (prof) prof_end(dev, &ar);
 }
 
+// the tail of the final segment: classifier GEMV over this rank's rows (all of them unless the vocabulary is split,
+// llama2.rs:199-208) + greedy sampler + advance
+int enqueue_classifier_and_sampler(crabml_hip_llama* c, const void* cls_act, crabml_hip_device::ProfRec* R) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const auto& g = c->cfg;
+  const int dim = (int)g.embedding_dim;
+  int *token_d = c->state, *pos_d = c->state + 1, *step_d = c->state + 2;
+  float* out = c->logits + c->vocab_off;
+  if (dev->strict_order)
+    CH_TRY(launch_gemv_strict(dev, c->output, (size_t)c->vocab_l, dim, cls_act, 1, out));
+  else
+    CH_TRY(launch_gemv(dev, c->output, (size_t)c->vocab_l, dim, cls_act, 1, out, R));
+  k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(out, c->vocab_l, c->am_val, c->am_idx, c->vocab_off);
+  if (c->split_vocab && c->comm && c->comm->p2p)
+    k_argmax_step_tp<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap, c->state + 4,
+                                       tp_view(c, true), n_segments(c));
+  else
+    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap, c->state + 4,
+                                    c->split_vocab ? c->am_best : (int*)nullptr);
+  CH_HIP(dev, hipGetLastError());
+  return 0;
+}
+
 // enqueue segment `seg` of one decode step on the device stream (see the banner above): the fused kernels
 // (fast mode, Q4_0 / Q8_0 weights)
 template <int FMT>
@@ -296,7 +326,6 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   const int L = (int)g.n_layers;
   int* token_d = c->state;
   int* pos_d = c->state + 1;
-  int* step_d = c->state + 2;
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   const uint32_t qt = c->qt;
   ActPtrs ad = act_ptrs(c->act_dim, dim, qt), aa = act_ptrs(c->act_attn, dim_l, qt), ah = act_ptrs(c->act_hid, hidden_l, qt);
@@ -392,14 +421,10 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     }
     if (prof)
       CH_TRY(prof_begin(dev, &pr, c->output->dtype, 5,
-                        (double)g.vocab_size * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
-                            4.0 * dim + 4.0 * g.vocab_size));
-    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, cls_act, 1, c->logits, R));
+                        (double)c->vocab_l * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
+                            4.0 * dim + 4.0 * c->vocab_l));
+    CH_TRY(enqueue_classifier_and_sampler(c, cls_act, R));
     CH_TRY(P1(&pr));
-    k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
-    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
-                                    c->state + 4);
-    CH_HIP(dev, hipGetLastError());
     return 0;
   }
   const int l = seg / 2;
@@ -487,7 +512,6 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
   const int L = (int)g.n_layers;
   int* token_d = c->state;
   int* pos_d = c->state + 1;
-  int* step_d = c->state + 2;
   const bool prof = dev->prof_on && !c->use_graph && !c->capturing && !strict;
   crabml_hip_device::ProfRec pr{};
   auto gemv = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out, uint32_t stage) -> int {
@@ -518,11 +542,12 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
   if (seg == 2 * L) {
     norm((const float*)c->rms_final->ptr, g.rms_norm_eps, tp);
     const void* act = quant(c->xn, dim, c->out_qt, c->act_dim);
-    CH_TRY(gemv(c->output, (int)g.vocab_size, dim, act, c->logits, 5));
-    k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
-    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
-                                    c->state + 4);
-    CH_HIP(dev, hipGetLastError());
+    if (prof)
+      CH_TRY(prof_begin(dev, &pr, c->output->dtype, 5,
+                        (double)c->vocab_l * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) + 4.0 * dim +
+                            4.0 * c->vocab_l));
+    CH_TRY(enqueue_classifier_and_sampler(c, act, prof ? &pr : nullptr));
+    if (prof) CH_TRY(prof_end(dev, &pr));
     return 0;
   }
   const int l = seg / 2;
@@ -575,7 +600,6 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   const int L = (int)g.n_layers;
   int* token_d = c->state;
   int* pos_d = c->state + 1;
-  int* step_d = c->state + 2;
   const bool prof = dev->prof_on && !c->use_graph && !c->capturing;
   crabml_hip_device::ProfRec pr{};
   crabml_hip_device::ProfRec* R = prof ? &pr : nullptr;
@@ -663,14 +687,10 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     const void* act = nepi ? (const void*)c->act_dim : norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, c->out_qt);
     if (prof)
       CH_TRY(prof_begin(dev, &pr, c->output->dtype, 5,
-                        (double)g.vocab_size * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
-                            4.0 * dim + 4.0 * g.vocab_size));
-    CH_TRY(launch_gemv(dev, c->output, g.vocab_size, dim, act, 1, c->logits, R));
+                        (double)c->vocab_l * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
+                            4.0 * dim + 4.0 * c->vocab_l));
+    CH_TRY(enqueue_classifier_and_sampler(c, act, R));
     CH_TRY(P1());
-    k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(c->logits, (int)g.vocab_size, c->am_val, c->am_idx);
-    k_argmax_step<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap,
-                                    c->state + 4);
-    CH_HIP(dev, hipGetLastError());
     return 0;
   }
   const int l = seg / 2;
@@ -757,7 +777,7 @@ int allreduce(crabml_hip_llama* c, int seg) {
   if (c->comm && c->comm->p2p) {  // one-shot P2P all-reduce as its own launch (per-op segment path)
     if (c->norm_epi) return 0;    // fast path: the collective is fused into the wo / ffn_down epilogue
     const int n = (int)c->cfg.embedding_dim;
-    k_tp_allreduce<<<(n + 255) / 256, 256, 0, dev->stream>>>(c->partial, n, tp_view(c, true), c->state + 4, n_segments(c), seg, 0u);
+    k_tp_allreduce<<<(n + 255) / 256, 256, 0, dev->stream>>>(c->partial, n, tp_view(c, true), c->state + 4, n_segments(c), seg, 0u, 0);
     CH_HIP(dev, hipGetLastError());
     return 0;
   }
@@ -1154,6 +1174,13 @@ int engine_setup(crabml_hip_llama* c) {
   }
   // the layers' kernel arguments
   const int L = (int)g.n_layers;
+  if (const char* e = getenv("CRABML_HIP_ENGINE_STAMPS")) {
+    if (atoi(e)) {
+      const size_t nb = (size_t)L * eg.G * ENG_STAMPS * 8;
+      CH_TRY(dalloc(c, nb, (void**)&c->eng_stamps));
+      CH_HIP(dev, hipMemsetAsync(c->eng_stamps, 0, nb, st));
+    }
+  }
   CH_TRY(dalloc(c, (size_t)L * sizeof(EngArgs), (void**)&c->eng_args));
   std::vector<EngArgs> args((size_t)L);
   const ActLayout ala = act_layout(c->qt, (size_t)dim_l), ald = act_layout(c->qt, (size_t)dim), alh = act_layout(c->qt, (size_t)hidden_l);
@@ -1194,6 +1221,7 @@ int engine_setup(crabml_hip_llama* c) {
     ea.nseg = n_segments(c);
     ea.seg0 = 2 * l;  // the wo edge carries the even segment's epoch, the gate/up and down edges the odd segment's
     ea.flags = c->eng_flags;
+    ea.stamps = c->eng_stamps ? eng_g(c->eng_stamps + (size_t)l * eg.G * ENG_STAMPS) : nullptr;
   }
   CH_HIP(dev, hipMemcpyAsync(c->eng_args, args.data(), args.size() * sizeof(EngArgs), hipMemcpyHostToDevice, st));
   CH_HIP(dev, hipGetLastError());
@@ -1254,9 +1282,9 @@ int crabml_hip_tp_comm_destroy(crabml_hip_tp_comm_t* comm) {
     (void)hipStreamSynchronize(comm->dev->stream);
     for (int r = 0; r < comm->nranks; r++) {
       if (r == comm->rank || !comm->peer[r]) continue;
-      // mapped through IPC (another process): close the mapping; same-process peers are plain pointers owned by their rank
-      hipPointerAttribute_t at{};
-      if (hipPointerGetAttributes(&at, comm->peer[r]) == hipSuccess) (void)hipIpcCloseMemHandle(comm->peer[r]);
+      // mapped through IPC (another process): close the mapping; same-process peers (connect_local) are plain pointers owned
+      // by their rank and are left alone.  Destroy order: contexts before their group, every rank quiesced.
+      if (comm->via_ipc[r]) (void)hipIpcCloseMemHandle(comm->peer[r]);
       (void)hipGetLastError();
     }
     if (comm->inbox) (void)hipFree(comm->inbox);
@@ -1281,7 +1309,7 @@ int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, 
     if (n > comm->cap) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: %zu elements exceed the inbox rows (%u)", n, comm->cap);
     const unsigned k = comm->host_epoch++;  // every rank issues the same sequence of calls
     k_tp_allreduce<<<(unsigned)((n + 255) / 256), 256, 0, dev->stream>>>((float*)buf->ptr, (int)n, p2p_view(comm), nullptr, 1, (int)(k & 1u),
-                                                                       0x40000000u + k);
+                                                                       0x40000000u + k, 2);
     CH_HIP(dev, hipGetLastError());
     int fault = 0;
     CH_HIP(dev, hipMemcpyAsync(&fault, comm->fault, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
@@ -1312,8 +1340,8 @@ int crabml_hip_tp_p2p_create(crabml_hip_device_t* dev, int nranks, int rank, siz
   c->nranks = nranks;
   c->rank = rank;
   c->p2p = true;
-  c->cap = (unsigned)((max_elems + 31) / 32 * 32);
-  c->inbox_bytes = (size_t)2 * nranks * c->cap * 8 + 256;  // + the fault word
+  c->cap = (unsigned)((max_elems + 2 + 31) / 32 * 32);  // + the two granules of the vocabulary-split sampler (k_argmax_step_tp)
+  c->inbox_bytes = (size_t)TP_SLOTS * nranks * c->cap * 8 + 256;  // + the fault word
   // fine-grained device memory: stores from a peer GPU become visible to a kernel that is already running (the coarse-
   // grained default only promises that at kernel boundaries); plain hipMalloc is the fallback where the flag is refused
   void* p = nullptr;
@@ -1331,7 +1359,7 @@ int crabml_hip_tp_p2p_create(crabml_hip_device_t* dev, int nranks, int rank, siz
     return hip_fail(dev, e, "tp_p2p_create", __FILE__, __LINE__);
   }
   c->inbox = (unsigned long long*)p;
-  c->fault = (int*)((char*)p + (size_t)2 * nranks * c->cap * 8);
+  c->fault = (int*)((char*)p + (size_t)TP_SLOTS * nranks * c->cap * 8);
   c->peer[rank] = p;
   c->connected = nranks == 1;
   *out = c;
@@ -1364,6 +1392,7 @@ int crabml_hip_tp_p2p_connect(crabml_hip_tp_comm_t* comm, const void* handles) {
     hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) return hip_fail(dev, e, "hipIpcOpenMemHandle (peer inbox)", __FILE__, __LINE__);
     comm->peer[r] = p;
+    comm->via_ipc[r] = true;
   }
   comm->connected = true;
   return 0;
@@ -1468,7 +1497,16 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED,
               "llama fused path: layer %zu weights have an unexpected shape, or dtypes that do not share one rhs dtype (tp=%d)", l, tp);
   }
-  if (!check(outw, g.vocab_size, g.embedding_dim, out_wt) || !check(w->rms_final_weight, 1, g.embedding_dim, CRABML_HIP_F32) ||
+  // the classifier split by vocabulary: this rank holds rows [tp_rank V / tp, (tp_rank + 1) V / tp)
+  const bool split_vocab = tp > 1 && (g.flags & CRABML_HIP_LLAMA_TP_SPLIT_VOCAB) != 0;
+  if (split_vocab) {
+    if (!w->output_weight || g.vocab_size % tp)
+      CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: the vocabulary split needs an untied output.weight and vocab_size %% tp_size == 0");
+    if (g.tp_comm && !((const crabml_hip_tp_comm*)g.tp_comm)->p2p)
+      CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama: the vocabulary split exchanges its arg-max pairs through a P2P group (crabml_hip_tp_p2p_*)");
+  }
+  const size_t vocab_l = split_vocab ? g.vocab_size / tp : g.vocab_size;
+  if (!check(outw, vocab_l, g.embedding_dim, out_wt) || !check(w->rms_final_weight, 1, g.embedding_dim, CRABML_HIP_F32) ||
       w->token_embed->n_elems != g.vocab_size * g.embedding_dim)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: classifier / final norm / embedding dtype or shape");
 
@@ -1498,6 +1536,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->comm = (crabml_hip_tp_comm*)g.tp_comm;
   c->tp_dry = tp > 1 && !g.tp_comm && (g.flags & CRABML_HIP_LLAMA_TP_DRY_RUN);
   if (c->comm && c->comm->p2p) c->tp_salt = (++c->comm->sessions) * 0x9E3779B1u;
+  c->split_vocab = split_vocab;
+  c->vocab_l = (int)vocab_l;
+  c->vocab_off = split_vocab ? (int)(vocab_l * (size_t)g.tp_rank) : 0;
   c->hd = (int)hd;
   c->npairs = (int)(g.rope_dim / 2);
   c->n_heads_l = (int)n_heads_l;
@@ -1624,6 +1665,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_idx);
+  A(2 * sizeof(int), (void**)&c->am_best);
   if (rc != 0) {
     crabml_hip_llama_destroy(c);
     return rc;
@@ -1643,6 +1685,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     }
     hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 8 * sizeof(int), dev->stream);
+    // vocabulary split: the entries of the other ranks' shards read -inf (an element-wise max over the ranks is the all-gather)
+    if (e == hipSuccess && c->split_vocab) e = hipMemsetD32Async((hipDeviceptr_t)c->logits, (int)0xff800000u, g.vocab_size, dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (g.embedding_dim / 16 + g.embedding_dim) * 8, dev->stream);
     if (e == hipSuccess && c->hgran) e = hipMemsetAsync(c->hgran, 0, (hidden_l / 4 + hidden_l / 32) * 8, dev->stream);
     if (e == hipSuccess && c->a8gran) e = hipMemsetAsync(c->a8gran, 0, dim_l * 8, dev->stream);
@@ -1814,8 +1858,27 @@ int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, siz
     if (n > 1 && s + 1 < nseg) k_sim_allreduce<<<(dim + 255) / 256, 256, 0, dev->stream>>>(ptrs, n, dim);
   }
   for (int r = 0; r < n; r++) ranks[r]->kv_len++;
+  if (ranks[0]->split_vocab) {
+    // every rank sampled from its own shard: the group's token is the rank-order combination of the pairs
+    SimBest sb{};
+    for (int r = 0; r < n; r++) {
+      if (!ranks[r]->split_vocab) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_sim: rank %d does not split the vocabulary like rank 0", r);
+      sb.best[r] = ranks[r]->am_best;
+      sb.token[r] = ranks[r]->state;
+      sb.step[r] = ranks[r]->state + 2;
+      sb.out_tokens[r] = ranks[r]->out_tokens;
+    }
+    k_sim_argmax_combine<<<1, 64, 0, dev->stream>>>(sb, n, ranks[0]->out_cap);
+    CH_HIP(dev, hipGetLastError());
+  }
   if (logits) {
-    CH_HIP(dev, hipMemcpyAsync(logits, ranks[0]->logits, ranks[0]->cfg.vocab_size * 4, hipMemcpyDeviceToHost, dev->stream));
+    if (ranks[0]->split_vocab) {
+      for (int r = 0; r < n; r++)
+        CH_HIP(dev, hipMemcpyAsync(logits + ranks[r]->vocab_off, ranks[r]->logits + ranks[r]->vocab_off, (size_t)ranks[r]->vocab_l * 4,
+                                   hipMemcpyDeviceToHost, dev->stream));
+    } else {
+      CH_HIP(dev, hipMemcpyAsync(logits, ranks[0]->logits, ranks[0]->cfg.vocab_size * 4, hipMemcpyDeviceToHost, dev->stream));
+    }
     CH_HIP(dev, hipStreamSynchronize(dev->stream));
   }
   return 0;
@@ -1832,6 +1895,13 @@ int crabml_hip_llama_reset(crabml_hip_llama_t* c) {
 int crabml_hip_llama_debug_kv(crabml_hip_llama_t* c, size_t layer, int32_t which_v, void* dst, size_t nbytes) {
   if (!c || !dst) return CRABML_HIP_BAD_INPUT;
   CH_USE(c->dev);
+  if (which_v == 2) {  // profiling hook of the engine (CRABML_HIP_ENGINE_STAMPS=1): the layer's [G][ENG_STAMPS] words
+    const size_t have = c->eng_stamps ? (size_t)c->eng_g.G * ENG_STAMPS * 8 : 0;
+    if (layer >= c->cfg.n_layers || nbytes > have) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: no engine stamps of that size");
+    CH_HIP(c->dev, hipMemcpyAsync(dst, c->eng_stamps + layer * (size_t)c->eng_g.G * ENG_STAMPS, nbytes, hipMemcpyDeviceToHost, c->dev->stream));
+    CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
+    return 0;
+  }
   if (layer >= c->cfg.n_layers || nbytes > c->kv_bytes) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: bad layer/size");
   CH_HIP(c->dev, hipMemcpyAsync(dst, which_v ? c->vc[layer] : c->kc[layer], nbytes, hipMemcpyDeviceToHost, c->dev->stream));
   CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));

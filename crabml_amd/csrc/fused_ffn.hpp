@@ -44,13 +44,15 @@ __global__ __launch_bounds__(256) void k_sim_allreduce(SimPtrs ptrs, int nranks,
 // ---- one-shot all-reduce over peer-mapped inboxes (the production collective) -----------------------------
 // Tensor-parallel decode exchanges 2 x dim f32 per layer and token: latency, not bandwidth.  Every rank owns an INBOX
 // (device memory, exported with hipIpcGetMemHandle and mapped by its peers with hipIpcOpenMemHandle -- the same mapping
-// reaches a peer GPU's HBM over xGMI or another process's buffer on the same GPU): two slots (segment parity) x nranks
-// rows of `cap` granules.  A granule is ONE naturally aligned 8-byte {f32 partial, u32 epoch}: data and tag travel in one
+// reaches a peer GPU's HBM over xGMI or another process's buffer on the same GPU): TP_SLOTS slots (0 / 1: the step's
+// collectives by segment parity, 2 / 3: host-issued all-reduces, 4 / 5: the vocabulary-split sampler) x nranks rows of `cap`
+// granules.  A granule is ONE naturally aligned 8-byte {f32 partial, u32 epoch}: data and tag travel in one
 // system-scope store, so there is no flag, no fence and no ordering between a producer's rows (MI355X_MICROARCH.md, "R2
 // granule").  Rank r writes its partial row into slot[seg & 1][r] of EVERY peer's inbox and then reads the nranks rows of
 // its own inbox, polling a granule until its tag is this step's epoch; the partials are added in rank order
 // (p0 + p1) + p2 ..., so every rank computes the same bits (= OracleTpLlamaRunner._sum_in_rank_order).  Two slots are
 // enough: a rank cannot finish all-reduce k + 1 before every peer has consumed all-reduce k.
+#define TP_SLOTS 6
 struct TpP2P {
   unsigned long long* peer[8];  // peer[p] = rank p's inbox as mapped in THIS process (peer[me] = the local allocation)
   int n, me;
@@ -108,12 +110,15 @@ __device__ __forceinline__ float tp_allreduce_elem(const TpP2P& t, float part, i
 }
 // the collective as its own launch (replaces ncclAllReduce on the per-op segment path and in crabml_hip_tp_all_reduce):
 // buf[i] <- sum over ranks, in place.  epoch_d != NULL: epoch = *epoch_d * nseg + seg + 1 (decode step, graph-safe)
+// slot_base: 0 for the decode step's collectives (slots 0 / 1 by segment parity), 2 for crabml_hip_tp_all_reduce issued by the
+// host (slots 2 / 3 by call parity): a host collective between two steps can then never land in the slot a step's first segment
+// polls next (round-2 review finding); slots 4 / 5 belong to the vocabulary-split sampler (k_argmax_step_tp)
 __global__ __launch_bounds__(256) void k_tp_allreduce(float* __restrict__ buf, int n, TpP2P t, const int* __restrict__ serial_d, int nseg, int seg,
-                                                      unsigned epoch_host) {
+                                                      unsigned epoch_host, int slot_base) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned epoch = serial_d ? (unsigned)(*serial_d) * (unsigned)nseg + (unsigned)seg + 1u + t.salt : epoch_host;
-  buf[i] = tp_allreduce_elem(t, buf[i], i, epoch, seg & 1);
+  buf[i] = tp_allreduce_elem(t, buf[i], i, epoch, slot_base + (seg & 1));
 }
 
 // ---- fast mode: GEMV + residual with the NEXT RMSNorm + quantization done in the epilogue ------------------------
@@ -764,15 +769,16 @@ __device__ __forceinline__ void argmax_combine(float& cv, int& ci, float ov, int
     ci = oi;
   }
 }
+// base: global index of logits[0] (a vocabulary shard of a tensor-parallel classifier; 0 otherwise)
 __global__ __launch_bounds__(256) void k_argmax_partial(const float* __restrict__ logits, int n, float* __restrict__ pv,
-                                                        int* __restrict__ pi) {
+                                                        int* __restrict__ pi, int base) {
   __shared__ float sv[4];
   __shared__ int si[4];
   const int per = (n + gridDim.x - 1) / gridDim.x;
   const int lo = blockIdx.x * per, hi = min(n, lo + per);
   float bv = -INFINITY;
   int bi = -1;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) argmax_combine(bv, bi, logits[i], i);
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) argmax_combine(bv, bi, logits[i], base + i);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     float ov = __shfl_xor(bv, o, 64);
@@ -790,10 +796,12 @@ __global__ __launch_bounds__(256) void k_argmax_partial(const float* __restrict_
     pi[blockIdx.x] = bi;
   }
 }
+// best: nullable; {max as f32 bits, index} of THIS context's logits (a tensor-parallel rank's shard: the single-device
+// simulation combines the ranks' pairs afterwards, k_sim_argmax_combine)
 __global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
                                                     int* __restrict__ token_d, int* __restrict__ pos_d,
                                                     int* __restrict__ step_d, unsigned* __restrict__ out_tokens, int out_cap,
-                                                    int* __restrict__ serial_d) {
+                                                    int* __restrict__ serial_d, int* __restrict__ best) {
   float bv = -INFINITY;
   int bi = -1;
   for (int i = threadIdx.x; i < nparts; i += 64) argmax_combine(bv, bi, pv[i], pi[i]);
@@ -804,6 +812,10 @@ __global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv
     argmax_combine(bv, bi, ov, oi);
   }
   if (threadIdx.x == 0) {
+    if (best != nullptr) {
+      best[0] = __builtin_bit_cast(int, bv);
+      best[1] = bi;
+    }
     *token_d = bi;
     int st = *step_d;
     if (st < out_cap) out_tokens[st] = (unsigned)bi;
@@ -811,6 +823,82 @@ __global__ __launch_bounds__(64) void k_argmax_step(const float* __restrict__ pv
     *pos_d = *pos_d + 1;
     *serial_d = *serial_d + 1;
   }
+}
+
+// the same step for a rank of a P2P group whose classifier is split by vocabulary: the rank's {max, index} pair goes to every
+// peer as two granules (slots 4 / 5 of the inbox, alternating by step: the wo / ffn_down collectives own slots 0 / 1, the host
+// all-reduce 2 / 3), the n pairs are combined in rank order -- shards ascend with the rank, so "the later index wins a tie"
+// (sampler.rs:109-116) holds across shards as inside one -- and every rank advances with the same token.
+__global__ __launch_bounds__(64) void k_argmax_step_tp(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
+                                                       int* __restrict__ token_d, int* __restrict__ pos_d, int* __restrict__ step_d,
+                                                       unsigned* __restrict__ out_tokens, int out_cap, int* __restrict__ serial_d, TpP2P t,
+                                                       int nseg) {
+  const int lane = threadIdx.x;
+  float bv = -INFINITY;
+  int bi = -1;
+  for (int i = lane; i < nparts; i += 64) argmax_combine(bv, bi, pv[i], pi[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    argmax_combine(bv, bi, ov, oi);
+  }
+  const unsigned serial = (unsigned)(*serial_d);
+  const unsigned epoch = serial * (unsigned)nseg + (unsigned)nseg + t.salt;  // segment nseg - 1, + 1
+  const int slot = 4 + (int)(serial & 1u);
+  const unsigned base = t.cap - 2;  // the last two granules of a row
+  if (lane < t.n && lane != t.me) {
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+      if (p == lane) {
+        tp_put(tp_row(t, p, slot, t.me) + base, bv, epoch);
+        tp_put(tp_row(t, p, slot, t.me) + base + 1, __builtin_bit_cast(float, bi), epoch);
+      }
+  }
+  unsigned long long* mine = nullptr;
+#pragma unroll
+  for (int p = 0; p < 8; p++)
+    if (p == t.me) mine = t.peer[p];
+  float rv = bv;
+  int ri = bi;
+  if (lane < t.n && lane != t.me) {
+    rv = tp_get(t, mine + ((size_t)slot * t.n + lane) * t.cap + base, epoch);
+    ri = __builtin_bit_cast(int, tp_get(t, mine + ((size_t)slot * t.n + lane) * t.cap + base + 1, epoch));
+  }
+  float cv = -INFINITY;
+  int ci = -1;
+  for (int s = 0; s < t.n; s++) argmax_combine(cv, ci, rl_f(rv, s), __builtin_amdgcn_readlane(ri, s));
+  if (lane == 0) {
+    *token_d = ci;
+    int st = *step_d;
+    if (st < out_cap) out_tokens[st] = (unsigned)ci;
+    *step_d = st + 1;
+    *pos_d = *pos_d + 1;
+    *serial_d = *serial_d + 1;
+  }
+}
+// single-device simulation: the ranks' {max, index} pairs (k_argmax_step's `best`) combined in rank order; every rank's token
+// word and the last entry of its token list are overwritten with the group's arg-max
+struct SimBest {
+  const int* best[8];
+  int* token[8];
+  int* step[8];
+  unsigned* out_tokens[8];
+};
+__global__ __launch_bounds__(64) void k_sim_argmax_combine(SimBest b, int n, int out_cap) {
+  if (threadIdx.x != 0) return;
+  float cv = -INFINITY;
+  int ci = -1;
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (r < n) argmax_combine(cv, ci, __builtin_bit_cast(float, b.best[r][0]), b.best[r][1]);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (r < n) {
+      *b.token[r] = ci;
+      const int st = *b.step[r] - 1;  // k_argmax_step has advanced it
+      if (st >= 0 && st < out_cap) b.out_tokens[r][st] = (unsigned)ci;
+    }
 }
 
 }  // namespace crabml_hip

@@ -4,7 +4,9 @@ Megatron-style split of the per-layer GEMVs over `tp` ranks, one process per GPU
 
   column-parallel (rows of W):   attn_q / attn_k / attn_v by heads, ffn_gate / ffn_up by rows
   row-parallel    (k of W):      attn_output by the local heads' columns, ffn_down by the local hidden columns
-  replicated:                    token_embd, norms, output (classifier)
+  replicated:                    token_embd, norms; output (classifier) unless split_vocab
+  split_vocab:    output.weight by rows -- rank r scores vocabulary [r V / tp, (r + 1) V / tp), takes the arg-max of
+                                 its shard and the ranks exchange 8-byte {max, index} pairs (CRABML_HIP_LLAMA_TP_SPLIT_VOCAB)
 
 Both splits cut GGML block rows on block boundaries (k_local % block_elems == 0), so a shard is a plain
 byte slice of the GGUF tensor: no re-quantization, and the activation blocks each rank quantizes are the
@@ -50,15 +52,22 @@ def _cols(t: RawTensor, lo: int, hi: int) -> RawTensor:
     return RawTensor(np.ascontiguousarray(blocks[:, lo // be:hi // be]).reshape(-1), [rows, hi - lo], t.typ)
 
 
-def shard_model(model: RawModel, tp: int, rank: int, kv_f16: bool = True) -> RawModel:
+TP_SPLIT_VOCAB = 1048576  # CRABML_HIP_LLAMA_TP_SPLIT_VOCAB (include/crabml_hip.h)
+
+
+def shard_model(model: RawModel, tp: int, rank: int, kv_f16: bool = True, split_vocab: bool = False) -> RawModel:
     """Rank `rank`'s shard of `model`.  `.shape` stays the GLOBAL ModelShape (the runner derives the local
-    geometry from tp_size); the sharded tensors carry their local [rows, cols]."""
+    geometry from tp_size); the sharded tensors carry their local [rows, cols].  split_vocab: output.weight is cut by rows
+    (the runner must then be created with the TP_SPLIT_VOCAB flag)."""
     s = model.shape
     check_tp(s, tp, model.wtype, kv_f16)
     if not 0 <= rank < tp:
         raise ValueError(f"rank {rank} outside 0..{tp - 1}")
     if tp == 1:
         return model
+    if split_vocab and (s.vocab % tp or "output.weight" not in model.tensors):
+        raise ValueError(f"split_vocab: vocab {s.vocab} must be a multiple of tp={tp} and output.weight must not be tied")
+    v_lo, v_hi = rank * (s.vocab // tp), (rank + 1) * (s.vocab // tp)
     hd = s.head_dim
     q_lo, q_hi = rank * (s.n_heads // tp) * hd, (rank + 1) * (s.n_heads // tp) * hd
     kv_lo, kv_hi = rank * (s.n_kv_heads // tp) * hd, (rank + 1) * (s.n_kv_heads // tp) * hd
@@ -75,6 +84,8 @@ def shard_model(model: RawModel, tp: int, rank: int, kv_f16: bool = True) -> Raw
             out.tensors[name] = _rows(t, h_lo, h_hi)
         elif name.endswith("ffn_down.weight"):
             out.tensors[name] = _cols(t, h_lo, h_hi)
+        elif name == "output.weight" and split_vocab:
+            out.tensors[name] = _rows(t, v_lo, v_hi)
         else:
             out.tensors[name] = t  # replicated
     return out

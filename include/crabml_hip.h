@@ -240,6 +240,14 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                           layer as ONE persistent launch fed by an LDS-DMA loader over a CU-major copy of the
                                           weights (crabml_amd/csrc/engine.hpp); bit-identical to the 5-launch layer; ignored
                                           (5 launches) when the shape does not fit */
+#define CRABML_HIP_LLAMA_TP_SPLIT_VOCAB 1048576 /* tp_size > 1 (P2P group, or the single-device simulation): the classifier is split by
+                                          vocabulary -- weights.output_weight holds rows [tp_rank V / tp_size,
+                                          (tp_rank + 1) V / tp_size) of output.weight (V % tp_size == 0, not tied to token_embed);
+                                          every rank streams 1 / tp_size of the classifier, takes the arg-max of its shard (last
+                                          maximum, sampler.rs:109-116) and the ranks exchange 8-byte {max, index} pairs through the
+                                          inboxes (rank order; the later index wins a tie across shards as it does inside one).
+                                          Logits copied out by forward(): this rank's shard at its global offsets, -inf elsewhere
+                                          (an element-wise max over the ranks' buffers is the all-gather) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */

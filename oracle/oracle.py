@@ -757,5 +757,10 @@ class OracleTpLlamaRunner:
         x_final = T.alloc([c.embedding_dim], F32, self.device)
         x_final.copy_rows_from(x, [0])
         ow = w0.output_weight if w0.output_weight is not None else w0.token_embed
-        self.logits = ow.matmul_vec(x_final).export()
+        if w0.output_weight is not None and ow.shape()[0] * self.tp == c.vocab_size and self.tp > 1:
+            # the classifier split by vocabulary: rank r scores rows [r V / tp, (r + 1) V / tp) with the
+            # reference's matmul_vec; the logits are the concatenation (every row dot is the unsplit classifier's)
+            self.logits = np.concatenate([r.weights.output_weight.matmul_vec(x_final).export() for r in self.ranks])
+        else:
+            self.logits = ow.matmul_vec(x_final).export()
         return self.logits

@@ -86,3 +86,40 @@ def test_rccl_binding_single_rank_all_reduce(ca):
     t = ca.HipTensor.from_cpu(x.view(np.uint8), [4096], ca.GGMLType.F32, dev)
     comm.all_reduce(t)  # sum over one rank: identity, but goes through ncclAllReduce on the device stream
     assert np.array_equal(t.export(), x)
+
+
+@pytest.mark.parametrize("fmt,tp,strict", [("Q4_0", 2, True), ("Q4_0", 2, False), ("Q4_K", 2, True), ("Q8_0", 2, False)])
+def test_tp_sim_with_the_classifier_split_by_vocabulary(ca, fmt, tp, strict):
+    """output.weight split by rows, per-shard arg-max (last maximum, sampler.rs:109-116), {max, index} pairs
+    combined in rank order.  Logits (gathered shard by shard) equal the replicated classifier's bit for bit -- every row dot is
+    the same dot -- and on the strict device the oracle's; the sampled tokens equal the replicated run's."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=36)
+    dev = ca.HipTensorDevice(0, False, 0, strict)
+    rep = hip_tp_ranks(ca, model, tp, True, dev)
+    split = []
+    for r in range(tp):
+        conf, w = synth.to_hip(tp_mod.shard_model(model, tp, r, True, split_vocab=True), dev)
+        split.append(ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, tp, r, extra_flags=tp_mod.TP_SPLIT_VOCAB))
+    ref = None
+    if strict:
+        odev = o.OracleDevice(thread_num=4)
+        rank_w = [to_oracle(tp_mod.shard_model(model, tp, r, True, split_vocab=True), odev) for r in range(tp)]
+        orr = o.OracleTpLlamaRunner(rank_w[0][0], [w for _, w in rank_w], odev, 64, True)
+        ref = [orr.forward([t], i).copy() for i, t in enumerate(TOKS)]
+    for i, t in enumerate(TOKS):
+        a = ca.HipLlamaRunner.tp_sim_forward(rep, t, i)
+        b = ca.HipLlamaRunner.tp_sim_forward(split, t, i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+        if ref is not None:
+            assert np.array_equal(b.view(np.uint32), ref[i].view(np.uint32)), f"oracle, step {i}"
+
+
+def test_the_vocabulary_split_is_validated_at_create(ca):
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=37)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(tp_mod.shard_model(model, 2, 0, True), dev)  # replicated classifier, flag set: wrong row count
+    with pytest.raises(ca.CrabmlError):
+        ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, 2, 0, extra_flags=tp_mod.TP_SPLIT_VOCAB)
+    conf, w = synth.to_hip(tp_mod.shard_model(model, 2, 0, True, split_vocab=True), dev)  # split shard without the flag
+    with pytest.raises(ca.CrabmlError):
+        ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, 2, 0)

@@ -212,3 +212,44 @@ def test_q4_1_body_with_a_q6_k_classifier_over_the_p2p_group(ca):
     got = run_group(ca, runners, TOKS)
     for i, (a, b) in enumerate(zip(got, want)):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+
+
+def test_vocabulary_split_over_the_p2p_group_samples_the_same_tokens(ca):
+    """tp = 2 over the P2P group, classifier split by vocabulary: each rank scores its half, the {max, index} pairs cross the
+    inboxes (k_argmax_step_tp), every rank advances with the same token -- the greedy continuation equals the replicated
+    classifier's, and the gathered logits (element-wise max of the ranks' buffers: -inf outside the own shard) are its logits."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=38)
+    devs, comms = local_group(ca, 2, model.shape.dim, False)
+    rep = []
+    for r in range(2):
+        conf, w = synth.to_hip(tp_mod.shard_model(model, 2, r, True), devs[r])
+        rep.append(ca.HipLlamaRunner(conf, w, devs[r], 64, True, True, True, 2, r, comms[r]))
+    want = run_group(ca, rep, TOKS)
+    devs2, comms2 = local_group(ca, 2, model.shape.dim, False)
+    split = []
+    for r in range(2):
+        conf, w = synth.to_hip(tp_mod.shard_model(model, 2, r, True, split_vocab=True), devs2[r])
+        split.append(ca.HipLlamaRunner(conf, w, devs2[r], 64, True, True, True, 2, r, comms2[r], extra_flags=tp_mod.TP_SPLIT_VOCAB))
+    half = model.shape.vocab // 2
+    for i, t in enumerate(TOKS):
+        split[1].forward_async(t, i)
+        lg0 = split[0].forward(t, i).copy()
+        assert np.all(np.isneginf(lg0[half:])) and np.array_equal(lg0[:half].view(np.uint32), want[i][:half].view(np.uint32)), f"step {i}"
+    # greedy continuation: both groups decode 6 more tokens; rank 0 of each group reports them
+    def greedy(group, first):
+        out = [None, None]
+
+        def run(r):
+            out[r] = group[r].decode_greedy(first, 6)
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        return out
+
+    for r in rep:
+        r.reset()
+    for r in split:
+        r.reset()
+    a, b = greedy(rep, 5), greedy(split, 5)
+    assert list(a[0]) == list(a[1]) == list(b[0]) == list(b[1]), (a, b)

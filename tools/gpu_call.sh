@@ -16,6 +16,8 @@ for w in $WHAT; do
     bench) timeout 900 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"; cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err ;;
     engbench) timeout 900 python bench.py --flags 524288 > gpurun_out/bench_eng_$TAG.json 2> gpurun_out/bench_eng_$TAG.err; echo "engbench rc=$?"; cat gpurun_out/bench_eng_$TAG.json; tail -3 gpurun_out/bench_eng_$TAG.err ;;
     fault) timeout 900 $PT tests/test_hip_fault_paths.py > gpurun_out/fault_tests_$TAG.log 2>&1; echo "fault rc=$?"; tail -15 gpurun_out/fault_tests_$TAG.log ;;
+    stamps) timeout 600 python tools/engine_stamps.py ${ENGINE_STAMPS_ARGS:-} > gpurun_out/engine_stamps_$TAG.log 2>&1; echo "stamps rc=$?"; cat gpurun_out/engine_stamps_$TAG.log ;;
+    tptests) timeout 900 $PT tests/test_hip_tp.py tests/test_hip_tp_p2p.py > gpurun_out/tp_tests_$TAG.log 2>&1; echo "tptests rc=$?"; tail -15 gpurun_out/tp_tests_$TAG.log ;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke_$TAG.log ;;
   esac
 done
