@@ -78,6 +78,7 @@ struct EngArgs {
   ENG_G int* fault;
   int nseg, seg0;                     // epochs: serial * nseg + seg0 + 1 (wo edge), + 2 (gate/up and down edges)
   int flags;                          // 1: thin the loader (one slot in flight) while this CU gathers
+  int lag;                            // a slot is handed to the consumers once `lag` younger slots have been issued (1..3)
   ENG_G unsigned long long* stamps;   // profiling hook (CRABML_HIP_ENGINE_STAMPS=1; NULL otherwise): ENG_STAMPS words per workgroup,
                                       // s_memrealtime (100 MHz) at the phase boundaries + accumulated wait times (tools/engine_stamps.py)
 };
@@ -122,6 +123,35 @@ __device__ __forceinline__ void eng_dma16(const ENG_G void* gsrc, unsigned lds_d
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// a whole slot of NI pieces as ONE statement: M0 is saved / restored once, the global address is SGPR base + a 32-bit VGPR offset
+// that advances by 1 KiB per piece, the M0 write is separated from the DMA by the v_add (the one wait state an M0 write needs
+// before an LDS-DMA instruction).  Three instructions per piece: the first loader spent ~120 cycles per piece in a compiled loop
+// of twelve (0.8 us per 18 KiB slot = 21 GB/s per CU, issue-bound: profiles/r03_engine_stamps_v2.log).
+#define ENG_P1 "s_addk_i32 m0, 0x400\n\tv_add_u32_e32 %1, 0x400, %1\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
+#define ENG_P2 ENG_P1 ENG_P1
+#define ENG_P4 ENG_P2 ENG_P2
+#define ENG_P8 ENG_P4 ENG_P4
+#define ENG_P16 ENG_P8 ENG_P8
+#define ENG_T1 "s_addk_i32 m0, 0x400\n\tv_add_u32_e32 %1, 0x400, %1\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_waitcnt vmcnt(16)\n\t"
+#define ENG_T2 ENG_T1 ENG_T1
+#define ENG_T4 ENG_T2 ENG_T2
+#define ENG_T8 ENG_T4 ENG_T4
+#define ENG_T16 ENG_T8 ENG_T8
+#define ENG_SLOT_ASM(BODY)                                                                                                     \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t" BODY "s_mov_b32 m0, %0" \
+               : "=&s"(keep), "+v"(voff)                                                                                       \
+               : "s"(base), "s"(lds_dst)                                                                                       \
+               : "memory", "scc")
+// NI = 18 or 16 pieces; base: wave-uniform; voff: this lane's byte offset of the slot's first piece; THIN: at most 17 pieces
+// outstanding (the loader thinned while its CU gathers)
+template <int NI, bool THIN>
+__device__ __forceinline__ void eng_dma_slot(const ENG_G unsigned char* base, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (NI == 18 && !THIN) ENG_SLOT_ASM(ENG_P16 ENG_P1);
+  if constexpr (NI == 18 && THIN) ENG_SLOT_ASM(ENG_T16 ENG_T1);
+  if constexpr (NI == 16 && !THIN) ENG_SLOT_ASM(ENG_P8 ENG_P4 ENG_P2 ENG_P1);
+  if constexpr (NI == 16 && THIN) ENG_SLOT_ASM(ENG_T8 ENG_T4 ENG_T2 ENG_T1);
+}
 template <int N>
 __device__ __forceinline__ void eng_wait_vm() {  // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4)
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
@@ -130,11 +160,13 @@ __device__ __forceinline__ void eng_wait_vm() {  // s_waitcnt vmcnt(N) only (gfx
 __device__ __forceinline__ void eng_wait_vm_le(int n) {
 #define ENG_W(N_) \
   case N_: eng_wait_vm<N_>(); break;
-  switch (n < 0 ? 0 : n > 36 ? 36 : n) {
+  switch (n < 0 ? 0 : n > 54 ? 54 : n) {
     ENG_W(0) ENG_W(1) ENG_W(2) ENG_W(3) ENG_W(4) ENG_W(5) ENG_W(6) ENG_W(7) ENG_W(8) ENG_W(9) ENG_W(10) ENG_W(11) ENG_W(12)
     ENG_W(13) ENG_W(14) ENG_W(15) ENG_W(16) ENG_W(17) ENG_W(18) ENG_W(19) ENG_W(20) ENG_W(21) ENG_W(22) ENG_W(23) ENG_W(24)
-    ENG_W(25) ENG_W(26) ENG_W(27) ENG_W(28) ENG_W(29) ENG_W(30) ENG_W(31) ENG_W(32) ENG_W(33) ENG_W(34) ENG_W(35)
-    default: eng_wait_vm<36>(); break;
+    ENG_W(25) ENG_W(26) ENG_W(27) ENG_W(28) ENG_W(29) ENG_W(30) ENG_W(31) ENG_W(32) ENG_W(33) ENG_W(34) ENG_W(35) ENG_W(36)
+    ENG_W(37) ENG_W(38) ENG_W(39) ENG_W(40) ENG_W(41) ENG_W(42) ENG_W(43) ENG_W(44) ENG_W(45) ENG_W(46) ENG_W(47) ENG_W(48)
+    ENG_W(49) ENG_W(50) ENG_W(51) ENG_W(52) ENG_W(53)
+    default: eng_wait_vm<54>(); break;
   }
 #undef ENG_W
 }
@@ -180,7 +212,7 @@ struct EngShared {
   float xrow[32];                        // this CU's wo / ffn_down row dots
   __attribute__((aligned(16))) float hv[32];              // the edge wave's chunk (nq_epilogue's hv)
   __attribute__((aligned(16))) float hblk[ENG_MAX_BLK][64];  // (gate, up) row dots of the CU's gate/up blocks, interleaved
-  __attribute__((aligned(4))) signed char qb[8][32];      // quants of a block on their way into granules (one row per wave)
+  __attribute__((aligned(4))) signed char qb[16][32];     // quants of a block on their way into granules (one row per wave)
 };
 
 struct EngCtx {  // per-wave view (registers)
@@ -240,12 +272,12 @@ __device__ __forceinline__ bool eng_consume(EngCtx& k, const EngArgs& a, int s0,
         const int hb = k.c + t * a.G;
         const f32x2 gu = ((const f32x2*)S->hblk[t])[k.lane & 31];
         const QLane o = quant_lane32<false>(silu_mul(gu[0], gu[1], eng_flat(a.exp_tab)), true);
-        if (k.lane < 32) S->qb[k.cw & 7][k.lane] = o.q;
+        if (k.lane < 32) S->qb[k.cw & 15][k.lane] = o.q;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (k.lane < 8)
           __hip_atomic_store(a.hq_g + hb * 8 + k.lane,
-                             ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)S->qb[k.cw & 7])[k.lane], __ATOMIC_RELAXED,
+                             ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)S->qb[k.cw & 15])[k.lane], __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
         if (k.lane == 0)
           __hip_atomic_store(a.hs_g + hb, ((unsigned long long)epoch << 32) | (unsigned long long)((unsigned)o.d | (((unsigned)o.aux & 0xffffu) << 16)),
@@ -464,11 +496,11 @@ __device__ __forceinline__ float eng_edge(EngCtx& k, const EngArgs& a, unsigned 
       }
     }
   } else if (part == 0) {
-    if (lane < 32) S->qb[k.cw & 7][lane] = o.q;
+    if (lane < 32) S->qb[k.cw & 15][lane] = o.q;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (lane < 8)
-      __hip_atomic_store(a.xq_g + blk * 8 + lane, ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)S->qb[k.cw & 7])[lane],
+      __hip_atomic_store(a.xq_g + blk * 8 + lane, ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)S->qb[k.cw & 15])[lane],
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0)
       __hip_atomic_store(a.xs_g + blk, ((unsigned long long)epoch << 32) | (unsigned long long)((unsigned)o.d | (((unsigned)o.aux & 0xffffu) << 16)),
@@ -483,7 +515,7 @@ __device__ __forceinline__ float eng_edge(EngCtx& k, const EngArgs& a, unsigned 
 // and pointers as by-value kernel arguments cost the kernel ~100 live SGPRs and spills; through the pointer they are scalar
 // loads where they are used
 template <int FMT>
-__global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) {
+__global__ __launch_bounds__(1024) void k_engine(const EngArgs* __restrict__ ap) {
   const EngArgs& a = *ap;
   extern __shared__ __attribute__((aligned(16))) unsigned char eng_lds[];
   __shared__ EngShared S;
@@ -514,11 +546,18 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
 
   if (wave == 0) {
     // ================= loader =================
+    __builtin_amdgcn_s_setprio(3);  // the loader's few instructions go first on the SIMD it shares with consumer waves
     const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)eng_lds;
-    const ENG_G unsigned char* src = a.stream + a.cu_off[c] + lane * 16;
+    // wave-uniform: an SGPR pair (readfirstlane: the offset comes through a vector load, which the compiler cannot prove uniform)
+    const unsigned long long ba = (unsigned long long)(size_t)(a.stream + a.cu_off[c]);
+    const ENG_G unsigned char* base = (const ENG_G unsigned char*)(size_t)(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba));
+    unsigned voff = (unsigned)lane * 16u;                      // this lane's byte offset inside the CU's stream
+    const int lag = a.lag;
     const int total = n_wo + n_gu + n_dn;
     int published = 0;  // slots [0, published) carry their filled word
-    int ni_prev = 0;
+    int ni_prev = 0, ni_prev2 = 0;
     bool dead = false;
     const bool st = a.stamps != nullptr;
     unsigned long long t_full = 0, t_vm = 0, t0 = 0;
@@ -539,19 +578,36 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
       }
       const bool thin = (a.flags & 1) && lds_ld(&S.gathering) != 0;
       const unsigned dst = ring_base + (unsigned)p * ENG_SLOT;
+      if (ni == 18) {
+        if (thin)
+          eng_dma_slot<18, true>(base, voff, dst);
+        else
+          eng_dma_slot<18, false>(base, voff, dst);
+      } else if (ni == 16) {
+        if (thin)
+          eng_dma_slot<16, true>(base, voff, dst);
+        else
+          eng_dma_slot<16, false>(base, voff, dst);
+      } else {
 #pragma unroll 2
-      for (int i = 0; i < ni; i++) {
-        eng_dma16(src + (size_t)i * 1024, dst + (unsigned)i * 1024);
-        if (thin) eng_wait_vm<16>();
+        for (int i = 0; i < ni; i++) {
+          eng_dma16(base + voff + (size_t)i * 1024, dst + (unsigned)i * 1024);
+          if (thin) eng_wait_vm<16>();
+        }
       }
-      src += (size_t)ni * 1024;
-      // slot s - 2 has landed once at most ni(s) + ni(s - 1) younger pieces are outstanding
-      if (s >= 2 && published <= s - 2) {
-        if (st) t0 = eng_now();
-        eng_wait_vm_le(ni + ni_prev);
-        if (st) t_vm += eng_now() - t0;
-        for (; published <= s - 2; published++) lds_st(&S.filled[published % D], (unsigned)published + 1u);
+      voff += (unsigned)ni * 1024u;
+      // slot s - lag has landed once at most the pieces of the `lag` younger slots are outstanding (lag 1: ni(s); 2: + ni(s - 1);
+      // 3: + ni(s - 2)).  The first slots (wo: the head of the critical path) are handed over with lag 1.
+      {
+        const int lg = s < n_wo + 1 ? 1 : lag;
+        if (s >= lg && published <= s - lg) {
+          if (st) t0 = eng_now();
+          eng_wait_vm_le(lg == 1 ? ni : lg == 2 ? ni + ni_prev : ni + ni_prev + ni_prev2);
+          if (st) t_vm += eng_now() - t0;
+          for (; published <= s - lg; published++) lds_st(&S.filled[published % D], (unsigned)published + 1u);
+        }
       }
+      ni_prev2 = ni_prev;
       ni_prev = ni;
       if (st) {
         if (s == 0) eng_stamp(a, c, 17, lane);
@@ -562,7 +618,7 @@ __global__ __launch_bounds__(512) void k_engine(const EngArgs* __restrict__ ap) 
     }
     if (!dead) {
       if (total >= 2 && published <= total - 2) {
-        eng_wait_vm_le(ni_prev);
+        eng_wait_vm_le(ni_prev);  // everything but the last slot
         for (; published <= total - 2; published++) lds_st(&S.filled[published % D], (unsigned)published + 1u);
       }
       eng_wait_vm<0>();

@@ -125,7 +125,7 @@ struct crabml_hip_llama {
   // the engine (engine.hpp): wo + norm + gate/up + ffn_down + norm of a layer as ONE persistent launch over a CU-major weight stream
   bool engine = false;
   EngGeom eng_g{};
-  int eng_D = 0, eng_nc = 3, eng_flags = 0;
+  int eng_D = 0, eng_nc = 3, eng_flags = 0, eng_lag = 2;
   size_t eng_lds = 0, eng_layer_bytes = 0;
   unsigned char* eng_stream = nullptr;          // n_layers x eng_layer_bytes
   unsigned long long* eng_cu_off = nullptr;     // [G + 1]
@@ -1125,10 +1125,15 @@ int engine_setup(crabml_hip_llama* c) {
   c->eng_nc = 3;
   if (const char* e = getenv("CRABML_HIP_ENGINE_NC")) {
     const int v = atoi(e);
-    if (v >= 1 && v <= 7) c->eng_nc = v;
+    if (v >= 1 && v <= 15) c->eng_nc = v;
   }
   c->eng_flags = 0;
   if (const char* e = getenv("CRABML_HIP_ENGINE_THIN")) c->eng_flags |= atoi(e) ? 1 : 0;
+  c->eng_lag = 2;
+  if (const char* e = getenv("CRABML_HIP_ENGINE_LAG")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 3) c->eng_lag = v;
+  }
   c->eng_D = D;
   c->eng_lds = (size_t)D * ENG_SLOT + act;
   if (hipFuncSetAttribute((const void*)k_engine<CRABML_HIP_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->eng_lds) != hipSuccess) {
@@ -1221,6 +1226,7 @@ int engine_setup(crabml_hip_llama* c) {
     ea.nseg = n_segments(c);
     ea.seg0 = 2 * l;  // the wo edge carries the even segment's epoch, the gate/up and down edges the odd segment's
     ea.flags = c->eng_flags;
+    ea.lag = c->eng_lag;
     ea.stamps = c->eng_stamps ? eng_g(c->eng_stamps + (size_t)l * eg.G * ENG_STAMPS) : nullptr;
   }
   CH_HIP(dev, hipMemcpyAsync(c->eng_args, args.data(), args.size() * sizeof(EngArgs), hipMemcpyHostToDevice, st));

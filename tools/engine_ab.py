@@ -42,8 +42,8 @@ for cfg in a.configs.split(","):
             prefetch = False
             continue
         k, v = p.split("=")
-        env[{"nc": "CRABML_HIP_ENGINE_NC", "d": "CRABML_HIP_ENGINE_D", "thin": "CRABML_HIP_ENGINE_THIN"}[k]] = v
-    for k in ("CRABML_HIP_ENGINE_NC", "CRABML_HIP_ENGINE_D", "CRABML_HIP_ENGINE_THIN"):
+        env[{"nc": "CRABML_HIP_ENGINE_NC", "d": "CRABML_HIP_ENGINE_D", "thin": "CRABML_HIP_ENGINE_THIN", "lag": "CRABML_HIP_ENGINE_LAG"}[k]] = v
+    for k in ("CRABML_HIP_ENGINE_NC", "CRABML_HIP_ENGINE_D", "CRABML_HIP_ENGINE_THIN", "CRABML_HIP_ENGINE_LAG"):
         os.environ.pop(k, None)
     os.environ.update(env)
     try:
