@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--tp-dry", type=int, default=0,
                     help="measure ONE rank of a tensor-parallel group of this size with its all-reduces skipped "
                          "(per-rank kernel time; not a tokens/s result)")
+    ap.add_argument("--tp-split-vocab", action="store_true",
+                    help="with --tp-dry / --tp: the classifier split by vocabulary (each rank streams 1 / tp of output.weight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the batched-prefill measurement")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
@@ -293,11 +295,12 @@ def tp_dry_run(args, ca, synth, local):
     wtype = synth.TYPE_BY_NAME[args.wtype]
     n = args.tp_dry
     tp_mod.check_tp(shape, n, wtype, True)
-    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=n)
+    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=n, tp_split_vocab=args.tp_split_vocab)
     dev = ca.HipTensorDevice(device_ordinal=local)
     conf, weights = synth.to_hip(model, dev)
     seq_len = args.warmup + args.steps + 16
-    r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=n, tp_rank=0, extra_flags=128)
+    r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=n, tp_rank=0,
+                          extra_flags=128 | (1048576 if args.tp_split_vocab else 0) | args.flags)
     r.decode_greedy(1, args.warmup)
     dev.sync()
     t0 = time.perf_counter()
@@ -312,7 +315,7 @@ def tp_dry_run(args, ca, synth, local):
         "rank_weight_bytes_per_token": local_bytes,
         "rank_effective_GBps": round(local_bytes / ms / 1e6, 1),
         "all_reduces_per_token": 2 * conf.n_layers, "all_reduce_bytes": shape.dim * 4,
-        "launches_per_layer": 5,
+        "launches_per_layer": 5, "classifier": "split by vocabulary (1 / tp of output.weight per rank)" if args.tp_split_vocab else "replicated",
         "note": "not tokens/s: the rank runs the fused-collective layer (5 launches: q|k|v, attention, wo + exchange + norm, gate|up, "
                 "down + exchange + norm) with the exchange itself skipped; add 2 x n_layers one-shot exchanges of dim x 8 bytes "
                 "per peer over xGMI (not measurable on one GPU)",
@@ -329,7 +332,8 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
     shape = synth.SHAPES[args.model]
     wtype = synth.TYPE_BY_NAME[args.wtype]
     tp_mod.check_tp(shape, world, wtype, True)
-    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=world)
+    split_vocab = args.tp_split_vocab and not args.tp_rccl
+    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=world, tp_split_vocab=split_vocab)
     dev = ca.HipTensorDevice(device_ordinal=local)
     conf, weights = synth.to_hip(model, dev)
     if args.tp_rccl:
@@ -337,8 +341,9 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
     else:  # the production collective: peers' inboxes mapped over hipIpc (xGMI between GPUs), no RCCL on the data path
         comm = tp_mod.init_tp_p2p(dev, rank, world, shape.dim, tp_mod.torch_all_gather(world))
     seq_len = args.warmup + args.steps + 16
+    xflags = args.flags | (1048576 if split_vocab else 0)
     r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=world, tp_rank=rank, comm=comm,
-                          extra_flags=args.flags)
+                          extra_flags=xflags)
     tok = int(r.decode_greedy(1, args.warmup)[-1]) if args.warmup > 0 else 1
     dev.sync()
     dist.barrier()
@@ -348,6 +353,18 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
     dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed_max, _ = dist.max_sum(elapsed, args.steps)
+    # the same rank with its exchanges skipped (same weights, same kernels, TP_DRY_RUN): step time minus this = what the
+    # collectives (2 per layer + the sampler's pair exchange) cost per token on this node -- one run reports both
+    dry = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=world, tp_rank=rank,
+                            extra_flags=xflags | 128)
+    dry.decode_greedy(1, args.warmup)
+    dev.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dry.decode_greedy(1, args.steps)
+    dev.sync()
+    dry_max, _ = dist.max_sum(time.perf_counter() - t0, args.steps)
+    del dry
     if rank == 0:
         local_bytes = sum(t.data.nbytes for name, t in model.tensors.items()
                           if not name.endswith("_norm.weight") and name != "token_embd.weight")
@@ -355,13 +372,17 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
         print(json.dumps({
             "metric": f"decode tokens/sec (batch-1 greedy), {shape.name} shape {args.wtype}, tensor-parallel over {world} GPUs",
             "value": round(tps, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+            "rank_kernels_ms_per_step": round(dry_max / args.steps * 1e3, 4),
+            "exchange_ms_per_step": round((elapsed_max - dry_max) / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.wtype, "data": "synthetic",
             "config": {"workload": f"{shape.name}-shape all-{args.wtype} synthetic weights, one batch-1 greedy token stream, f16 KV cache, "
                                    f"positions {args.warmup}..{args.warmup + args.steps - 1}",
                        "parallelism": f"tp{world}", "all_reduces_per_token": 2 * conf.n_layers, "all_reduce_bytes": shape.dim * 4,
                        "collective": "RCCL ncclAllReduce per segment" if args.tp_rccl else
                                      "one-shot P2P all-reduce over hipIpc-mapped inboxes, fused into the wo / ffn_down epilogue",
+                       "classifier": "split by vocabulary, per-shard arg-max + 8-byte pair exchange" if split_vocab else "replicated",
                        "rank_weight_bytes_per_token": local_bytes},
             "roofline": {"bound": "hbm", "achieved": round(tps * local_bytes / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(tps * local_bytes / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

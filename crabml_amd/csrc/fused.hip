@@ -190,6 +190,20 @@ TpP2P tp_view(const crabml_hip_llama* c, bool fused_collective) {
   return t;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel in this PROCESS, not of a context: a second context
+// with a shorter sequence must not lower the limit an earlier context's launches (and captured graphs) were sized for.
+// Only ever raise it, per device.
+hipError_t raise_dyn_lds(const crabml_hip_device* dev, const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> have;
+  std::lock_guard<std::mutex> g(mu);
+  int& cur = have[{dev->ordinal, fn}];
+  if (bytes <= cur) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) cur = bytes;
+  return e;
+}
+
 int dalloc(crabml_hip_llama* c, size_t bytes, void** out) {
   size_t cap = 0;
   CH_TRY(pool_alloc(c->dev, bytes, out, &cap));
@@ -1071,8 +1085,9 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
 
 // ---- the engine (engine.hpp): geometry, LDS budget, the CU-major weight stream -----------------------------------------------
 // Opt-in / opt-out through the config flags; silently stays off (the 5-launch layer runs) when the shape does not fit:
-// Q4_0 layers, fast mode, one GPU, the norm-epilogue conditions, head_dim % 32 == 0 (the attention launch emits wo's rhs planes),
-// wo / ffn_down rows = 16 per CU (two CUs share a norm chunk) or 32, gate/up rows in (gate, up) pairs.
+// Q4_0 layers, fast mode, one GPU, the norm-epilogue conditions, wo / ffn_down rows = 16 per CU (two CUs share a norm chunk) or 32,
+// gate/up rows in (gate, up) pairs.  (wo's rhs planes come from the attention launch, or from the quantizer launch behind it
+// when head_dim % 32 != 0.)
 template <class T>
 ENG_G T* eng_g(T* p) {  // EngArgs declares its pointers global (engine.hpp)
   return (ENG_G T*)p;
@@ -1082,7 +1097,7 @@ int engine_setup(crabml_hip_llama* c) {
   const auto& g = c->cfg;
   c->engine = false;
   if (!(g.flags & CRABML_HIP_LLAMA_ENGINE)) return 0;
-  if (c->generic || c->kfused || c->wtype != CRABML_HIP_Q4_0 || c->tp != 1 || !c->norm_epi || (c->hd % 32) != 0) return 0;
+  if (c->generic || c->kfused || c->wtype != CRABML_HIP_Q4_0 || c->tp != 1 || !c->norm_epi) return 0;
   const int dim = (int)g.embedding_dim, dim_l = c->dim_l, hidden_l = c->hidden_l;
   EngGeom eg{};
   eg.nblk_h = hidden_l / 32;
@@ -1136,7 +1151,7 @@ int engine_setup(crabml_hip_llama* c) {
   }
   c->eng_D = D;
   c->eng_lds = (size_t)D * ENG_SLOT + act;
-  if (hipFuncSetAttribute((const void*)k_engine<CRABML_HIP_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->eng_lds) != hipSuccess) {
+  if (raise_dyn_lds(dev, (const void*)k_engine<CRABML_HIP_Q4_0>, (int)c->eng_lds) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -1613,8 +1628,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       // rows past ~38000 do not fit at all (the step then stays on the one-workgroup-per-head kernel)
       const int lds = (int)(g.seq_len * 4);
       if (lds > 150 * 1024 ||
-          hipFuncSetAttribute((const void*)k_attn_softmax<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_attn_softmax<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+          raise_dyn_lds(dev, (const void*)k_attn_softmax<16>, lds) != hipSuccess ||
+          raise_dyn_lds(dev, (const void*)k_attn_softmax<4>, lds) != hipSuccess)
         c->attn_long_ok = false;
       (void)hipGetLastError();
     }
@@ -1624,10 +1639,10 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       if (!(g.flags & CRABML_HIP_LLAMA_NO_PV_PRODUCER_WAVES) && g.seq_len % 4 == 0) {
         hipError_t e = hipErrorInvalidValue;
         switch (grp) {
-          case 1: e = hipFuncSetAttribute((const void*)k_attn_pv_split<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<1>::LDS); break;
-          case 2: e = hipFuncSetAttribute((const void*)k_attn_pv_split<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<2>::LDS); break;
-          case 4: e = hipFuncSetAttribute((const void*)k_attn_pv_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<4>::LDS); break;
-          default: e = hipFuncSetAttribute((const void*)k_attn_pv_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PvSplit<8>::LDS); break;
+          case 1: e = raise_dyn_lds(dev, (const void*)k_attn_pv_split<1>, (int)PvSplit<1>::LDS); break;
+          case 2: e = raise_dyn_lds(dev, (const void*)k_attn_pv_split<2>, (int)PvSplit<2>::LDS); break;
+          case 4: e = raise_dyn_lds(dev, (const void*)k_attn_pv_split<4>, (int)PvSplit<4>::LDS); break;
+          default: e = raise_dyn_lds(dev, (const void*)k_attn_pv_split<8>, (int)PvSplit<8>::LDS); break;
         }
         c->pv_split = e == hipSuccess;
         (void)hipGetLastError();
@@ -1638,8 +1653,8 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       const size_t S = c->attn_long_ok && c->attn_long_from < g.seq_len ? c->attn_long_from : g.seq_len;
       const size_t lds = attn_s_lds_bytes((int)S, (int)hd);
       if (lds <= 150 * 1024 &&
-          hipFuncSetAttribute((const void*)k_attn_s<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-          hipFuncSetAttribute((const void*)k_attn_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+          raise_dyn_lds(dev, (const void*)k_attn_s<128>, (int)lds) == hipSuccess &&
+          raise_dyn_lds(dev, (const void*)k_attn_s<0>, (int)lds) == hipSuccess) {
         c->attn_s_rows = (int)S;
         c->attn_s_lds = lds;
       }

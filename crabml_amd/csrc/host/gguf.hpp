@@ -270,7 +270,14 @@ class GGUFFile {
         return have == max_end || have == align_up_(max_end, al);
       };
       const bool spec_ok = fits(pos_), ref_ok = fits(pos_ + al);
-      if (spec_ok || !ref_ok) next = pos_;  // spec convention (also the default when neither or both match)
+      // Neither convention puts the last tensor's end at the end of the file (trailing bytes, loosely packed tensors) AND the
+      // tensor sizes are known: the file does not say where its data starts, and guessing wrong shifts EVERY tensor by one
+      // alignment block without any error downstream.  Refuse it (round-2 review finding) instead of defaulting silently.
+      if (sized && !spec_ok && !ref_ok)
+        throw Error(ErrorKind::FormatError,
+                    "the tensor infos end on an alignment boundary and neither the GGUF spec's data start (no padding) nor the "
+                    "reference's (one more block, gguf.rs:722-724) makes the data section end with the last tensor: ambiguous file");
+      if (spec_ok || !ref_ok) next = pos_;  // spec convention (also when both fit, or when tensor sizes are unknown)
       data_start_convention_ = (spec_ok || !ref_ok) ? 0 : 1;
     }
     (void)take(next - pos_);

@@ -241,6 +241,12 @@ int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev->ordinal) == hipSuccess) dev->n_cu = prop.multiProcessorCount;
+  // test hook (tests/test_hip_fault_paths.py): claim this many CUs whatever the device reports, so that a CU-masked process
+  // (HSA_CU_MASK) loses the co-residency the in-launch hand-offs rely on -- their bounded polls must raise, not hang
+  if (const char* e = getenv("CRABML_HIP_ASSUME_CUS")) {
+    const int v = atoi(e);
+    if (v > 0 && v <= 1024) dev->n_cu = v;
+  }
   if (opts && opts->stream) {
     dev->stream = (hipStream_t)opts->stream;
     dev->own_stream = false;

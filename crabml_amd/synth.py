@@ -163,7 +163,7 @@ def use_more_bits(i_layer: int, n_layers: int) -> bool:
 
 def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional[int] = None,
                 embed_type: Optional[int] = None, tp: int = 1, output_type: Optional[int] = None,
-                k_m_mix: bool = False) -> RawModel:
+                k_m_mix: bool = False, tp_split_vocab: bool = False) -> RawModel:
     """All-`wtype` synthetic Llama weights with GGUF tensor names (model.rs:228-283); norms are F32
     (the loader dequantizes them, model.rs:267-282).  tp > 1: the tensors get one rank's LOCAL shard shapes
     (what crabml_amd.tp.shard_model would cut; random bytes either way -- for timing one rank of a large model
@@ -198,7 +198,9 @@ def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional
         norm(f"blk.{l}.ffn_norm.weight", shape.dim)
     norm("output_norm.weight", shape.dim)
     # llama.cpp's "Q4_0" / "Q4_K_M" files keep output.weight in Q6_K: `output_type` builds that mix
-    add("output.weight", shape.vocab, shape.dim, (Q6_K if k_m_mix else wtype) if output_type is None else output_type)
+    # tp_split_vocab (with tp > 1): one rank's vocabulary shard of the classifier (CRABML_HIP_LLAMA_TP_SPLIT_VOCAB)
+    add("output.weight", shape.vocab // tp if tp_split_vocab else shape.vocab, shape.dim,
+        (Q6_K if k_m_mix else wtype) if output_type is None else output_type)
     return m
 
 

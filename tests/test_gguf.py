@@ -357,3 +357,17 @@ def test_mlock_flag_and_madvise(tmp_path):
         assert "lock" in str(e)
     else:
         assert gf.load_config().n_layers == model.shape.n_layers
+
+
+def test_aligned_header_with_trailing_bytes_is_refused_not_guessed(tmp_path):
+    """Round-2 review finding: when the tensor infos end on an alignment boundary AND neither data-start convention makes the data
+    section end with the last tensor (here: trailing bytes appended), the reader used to fall back to the spec offset silently --
+    for a file written in the reference's convention every tensor would then be read one block early.  It must refuse instead."""
+    model = small_model()
+    path = str(tmp_path / "aligned-trailing.gguf")
+    synth.write_gguf(model, path, data_start="reference", pad_header_to_alignment=True)
+    with open(path, "ab") as f:
+        f.write(b"\0" * 7)
+    with pytest.raises(Exception) as ei:
+        ca.GGUFFile(path)
+    assert "ambiguous" in str(ei.value)

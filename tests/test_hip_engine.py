@@ -27,6 +27,8 @@ SHAPES = {
     "rows<cus": synth.ModelShape("rows<cus", 512, 1536, 2, 8, 2, 1024, 64, 1e-5, None),
     # 288 blocks over 256 CUs: CUs 0..31 carry two gate/up blocks; 224 CUs own no rows at all
     "two-blocks": synth.ModelShape("two-blocks", 512, 9216, 2, 8, 4, 1024, 64, 1e-5, None),
+    # head_dim 48 (the attention launch does not quantize its output: a quantizer launch feeds the engine), 18 CUs with rows, 24 blocks
+    "15m": synth.SHAPES["15m"],
     # long ffn_down rows: 1152 blocks = 20736 bytes per row -> does not fit a slot -> the engine must decline, not break
     "row>slot": synth.ModelShape("row>slot", 256, 36864, 1, 4, 4, 512, 32, 1e-5, None),
 }
@@ -39,7 +41,7 @@ def run(ca, model, flags, toks, use_graph=True, seq_len=64):
     return [r.forward(t, i).copy() for i, t in enumerate(toks)], r
 
 
-@pytest.mark.parametrize("shape", ["tiny-gqa", "rows<cus", "two-blocks", "row>slot"])
+@pytest.mark.parametrize("shape", ["tiny-gqa", "rows<cus", "two-blocks", "15m", "row>slot"])
 def test_engine_equals_the_five_launch_layer(ca, shape):
     model = synth.build_model(SHAPES[shape], synth.TYPE_BY_NAME["Q4_0"], seed=31)
     base, _ = run(ca, model, 0, TOKS)

@@ -1,0 +1,51 @@
+"""Fault path of the single-GPU in-launch hand-offs (round-2 verdict, item 7): the norm-epilogue gathers of wo / ffn_down and
+the engine's edges rely on all of their workgroups being resident at once (checked against the device's CU count at create).
+When that is lost behind the library's back -- here: the process is confined to 32 CUs with HSA_CU_MASK while the library is
+told to assume 256 (CRABML_HIP_ASSUME_CUS, a test hook) -- the polls are BOUNDED: the step must raise CrabmlError ("gather
+timed out") within seconds, not hang, and the device must stay usable afterwards.  The P2P collective has the same test
+(tests/test_hip_tp_p2p.py::test_a_peer_that_never_arrives_raises_instead_of_hanging).
+
+Runs in a subprocess (the CU mask is read when the runtime starts).  If the runtime does not honour the mask (every workgroup
+stays resident and the step simply succeeds) the test is skipped: the condition cannot be produced on that box."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import crabml_amd as ca
+from crabml_amd import synth
+flags = int(sys.argv[1])
+model = synth.build_model(synth.SHAPES["llama3-8b"], synth.Q4_0, seed=5, n_layers=1)
+dev = ca.HipTensorDevice(0)
+conf, w = synth.to_hip(model, dev)
+r = ca.HipLlamaRunner(conf, w, dev, 32, True, True, True, extra_flags=flags)
+t0 = time.time()
+try:
+    r.forward(1, 0)
+    print("NOFAULT", flush=True)
+except ca.CrabmlError as e:
+    print("FAULT %%.1fs %%s" %% (time.time() - t0, e), flush=True)
+x = np.arange(256, dtype=np.float32)
+y = ca.HipTensor.from_cpu(x.view(np.uint8), [256], ca.GGMLType.F32, dev).scale_inplace(2.0).export()
+print("USABLE" if np.array_equal(y, 2 * x) else "BROKEN", flush=True)
+""" % ROOT
+
+
+@pytest.mark.parametrize("flags,name", [(0, "norm-epilogue gathers"), (524288, "engine edges")])
+def test_lost_co_residency_raises_instead_of_hanging(flags, name):
+    env = dict(os.environ, HSA_CU_MASK="0:0-31", ROC_GLOBAL_CU_MASK="0xffffffff", CRABML_HIP_ASSUME_CUS="256")
+    p = subprocess.run([sys.executable, "-c", SCRIPT, str(flags)], env=env, capture_output=True, text=True, timeout=600)
+    out = p.stdout
+    assert p.returncode == 0, (out[-2000:], p.stderr[-2000:])
+    if "NOFAULT" in out:
+        pytest.skip("the runtime did not confine the process to 32 CUs (mask not honoured): the condition cannot be produced here")
+    assert "FAULT" in out and "timed out" in out, out
+    assert "USABLE" in out, out
