@@ -122,6 +122,7 @@ struct crabml_hip_llama {
   unsigned long long* h8gran = nullptr;  // the producing kernels assemble Q8_K super-blocks (q8k_exchange_store)
   bool q8k_producers = false;            // attention / gate-up emit the Q8_K planes of wo's / ffn_down's rhs themselves
   bool ffn_fused = false;               // gate/up + ffn_down as one launch (k_ffn)
+  bool qkv_tail = false;                // the next layer's q/k/v rows ride the ffn_down launch (QkvTail, fused_ffn.hpp)
   // the engine (engine.hpp): wo + norm + gate/up + ffn_down + norm of a layer as ONE persistent launch over a CU-major weight stream
   bool engine = false;
   EngGeom eng_g{};
@@ -379,7 +380,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
   const bool norm_epi = c->norm_epi;
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
-  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next) -> int {
+  // tail_layer >= 0: the launch also computes layer `tail_layer`'s q/k/v rows (QkvTail; ffn_down of the layer before it)
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next, int tail_layer = -1) -> int {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
     if (norm_epi) {
@@ -393,18 +395,29 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       if (tpv.n > 1) {  // tensor parallel over a P2P group: the collective runs inside this launch
         if (split == 2)
           launch_k(st, R, k_gemv_res_nq<FMT, 2, false, true>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
-                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
+                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv, NoQkv{});
         else
           launch_k(st, R, k_gemv_res_nq<FMT, 1, false, true>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
-                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
+                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv, NoQkv{});
+      } else if (split == 2 && tail_layer >= 0) {
+        if constexpr (FMT == CRABML_HIP_Q4_0) {
+          const int tl = tail_layer;
+          const ActLayout ald = act_layout(qt, (size_t)dim);
+          QkvTail tq{planes_of(c->wq[tl]), planes_of(c->wk[tl]), planes_of(c->wv[tl]),
+                     QkvEpi{c->qbuf, c->kc[tl], c->vc[tl], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd, (int)g.rope_dim,
+                            c->npairs, seq_cap, kv16 ? 1 : 0},
+                     c->xqgran, c->xqgran + dim / 4, ((dim_l + 2 * kv_dim_l) / 2 + dim / 16 - 1) / (dim / 16), (int)ald.off_d, (int)ald.off_aux};
+          launch_k(st, R, k_gemv_res_nq<FMT, 2, 0, false, true>, dim3(dim / 16), dim3(1024), ald.total, planes_of(w), act_view<FMT>(a),
+                   (const float*)nullptr, c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{}, tq);
+        }
       } else if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{}, NoQkv{});
       else
         launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{}, NoQkv{});
     } else if (tp) {
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     } else {
@@ -453,10 +466,12 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
-    CH_TRY(P0(&pr, 1, total_rows, dim));
-    launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-             planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
-    CH_TRY(P1(&pr));
+    if (!(c->qkv_tail && l > 0)) {  // (qkv_tail: layer l's rows were the tail of layer l - 1's ffn_down launch)
+      CH_TRY(P0(&pr, 1, total_rows, dim));
+      launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
+               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
+      CH_TRY(P1(&pr));
+    }
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;
     const int attn_spare = do_pf && dev->n_cu > n_heads_l ? dev->n_cu - n_heads_l : 0;
@@ -503,7 +518,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
                act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
       CH_TRY(P1(&pr));
       // down (+ residual, llama2.rs:633-636): k = the local hidden slice
-      CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps));
+      CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps, c->qkv_tail && l + 1 < L ? l + 1 : -1));
     }
   }
   CH_HIP(dev, hipGetLastError());
@@ -673,7 +688,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
 #define CRABML_NQ_K(SPLIT_, QIN_, GRID_, LDS_)                                                                                          \
   launch_k(st, R, k_gemv_res_nq<FMT, SPLIT_, QIN_>, dim3(GRID_), dim3(1024), LDS_, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob, \
-           ng, k / BE, six(w), NoTp{})
+           ng, k / BE, six(w), NoTp{}, NoQkv{})
         if (split == 2 && qmode == 2)
           CRABML_NQ_K(2, 2, dim / 16, lds);
         else if (split == 2 && qmode == 1)
@@ -1682,6 +1697,22 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     A(hidden_l * 8, (void**)&c->h8gran);
   }
   if (rc == 0) rc = engine_setup(c);
+  {
+    // the q/k/v tail of the ffn_down launch (QkvTail): the split-chunk launch must be the one every layer takes, with ONE
+    // workgroup per CU (the tail's registers do not leave room for two), and a wave per row pair
+    const int split_down = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
+                           : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
+                           : (hidden_l / 32 >= 256 && (int)(g.embedding_dim / 32) <= dev->n_cu) ? 2
+                                                                                                 : 1;
+    const size_t nwg = g.embedding_dim / 16, npairs = (dim_l + 2 * kv_dim_l) / 2;
+    c->qkv_tail = (g.flags & CRABML_HIP_LLAMA_QKV_TAIL) && !generic && !c->kfused && wt == CRABML_HIP_Q4_0 && tp == 1 && c->norm_epi &&
+                  !c->ffn_fused && !c->engine && split_down == 2 && (int)nwg <= dev->n_cu && (npairs + nwg - 1) / nwg <= 16 &&
+                  g.embedding_dim <= 8192 && g.n_layers > 1;
+    if (c->qkv_tail && !c->xqgran) {
+      A((g.embedding_dim / 4 + g.embedding_dim / 32) * 8, (void**)&c->xqgran);
+      if (rc == 0 && hipMemsetAsync(c->xqgran, 0, (g.embedding_dim / 4 + g.embedding_dim / 32) * 8, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
+    }
+  }
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
   A(ARGMAX_BLOCKS * 4, (void**)&c->am_val);

@@ -165,6 +165,79 @@ __device__ __forceinline__ void stage_copy_q8k(const ActQ8_K& act, int nsb, i32x
   __syncthreads();
 }
 
+// ---- the NEXT layer's q/k/v GEMV as the tail of the ffn_down launch ---------------------------------------------------------
+// k_qkv streams 14 MB in 4.6 us on the 8B shape: 2.2 us of stream and a launch's ramp (a GEMV stage costs
+// bytes / 6.2 TB/s + 2.6 us).  Its weights do not depend on anything, so the ffn_down launch can hold them: every workgroup
+// requests the rows of (up to) 16 (even, odd) row pairs -- 55 KB per workgroup, 4 x 16 bytes + scales per lane -- right before
+// its norm hop and keeps them in REGISTERS; the normalized, quantized residual then crosses the workgroups as granules (the
+// engine's format: 8 {4 quants, epoch} + 1 {d | aux, epoch} per block, swept by all 16 waves in one round trip: the chip has
+// drained its weight stream by then, so the hop is cheap), and the dots run from registers.  Same lane -> block mapping and
+// order as k_qkv (rows_partial<FMT, 2>), same epilogue: bit-identical to the separate launch.
+struct QkvTail {
+  Planes wq, wk, wv;
+  QkvEpi e;
+  unsigned long long* xq_g;  // dim / 4 quant granules
+  unsigned long long* xs_g;  // dim / 32 scale granules
+  int pairs_per_wg;          // row pairs per workgroup (<= 16: one per wave)
+  int off_d, off_aux;        // act_layout of the dim-sized rhs planes (LDS copy)
+};
+struct NoQkv {};
+template <bool Q>
+struct QkvArg {
+  typedef NoQkv type;
+};
+template <>
+struct QkvArg<true> {
+  typedef QkvTail type;
+};
+// one wave's share of the sweep of a quantized vector's granules (n / 4 quant + n / 32 scale granules) into LDS planes
+// q | d | isum; every load of the share is in flight at once, the share is re-read until each granule carries the epoch
+// (bounded: a workgroup that never publishes raises the fault word)
+template <int B>
+__device__ __forceinline__ void sweep_planes_share(const unsigned long long* qg, const unsigned long long* sg, int n, unsigned epoch,
+                                                   unsigned char* P, int off_d, int off_aux, int lane, int part, int nparts, int* fault) {
+  unsigned* pq = (unsigned*)P;
+  unsigned short* pd = (unsigned short*)(P + off_d);
+  int* pa = (int*)(P + off_aux);
+  const int nq = n / 4, count = nq + n / 32;
+  const int per = ((count + nparts - 1) / nparts + 63) & ~63;
+  const int lo = part * per, hi = lo + per < count ? lo + per : count;
+  for (int base = lo; base < hi; base += 64 * B) {
+    unsigned long long x[B];
+    int spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < B; i++) {
+        const int idx = base + i * 64 + lane;
+        const int j = idx < hi ? idx : base;
+        x[i] = __hip_atomic_load(j < nq ? qg + j : sg + (j - nq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int i = 0; i < B; i++) ok &= (unsigned)(x[i] >> 32) == epoch;
+      if (__all(ok)) break;
+      if (++spins > (1 << 19)) {
+        if (lane == 0) *fault = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+      const int idx = base + i * 64 + lane;
+      if (idx < hi) {
+        const unsigned v = (unsigned)x[i];
+        if (idx < nq) {
+          pq[idx] = v;
+        } else {
+          pd[idx - nq] = (unsigned short)(v & 0xffffu);
+          pa[idx - nq] = (int)(short)(v >> 16);
+        }
+      }
+    }
+  }
+}
+
 struct NormGather {
   unsigned long long* slots;  // dim/16 granules: each workgroup's ordered sum of squares over its rows
   unsigned long long* pair;   // dim row granules (read by a split chunk's partner / a Q8_K super-block's neighbours)
@@ -179,12 +252,14 @@ __device__ __forceinline__ unsigned long long ld_granule(const unsigned long lon
 // The tail of the wo / ffn_down kernels (k_gemv_res_nq, k_ffn): acc[] = this wave's RW row dots.  Publishes the
 // workgroup's rows / sum of squares, takes the one in-launch hop, normalizes + quantizes the rows it owns.
 // wg_index / nwg_all: this workgroup's index among the SPLIT * nchunks workgroups of the stage.
+// pubq / pubs (nullable): the chunk's quantized block also goes out as granules (8 quant dwords + {d | aux}: the q/k/v tail)
 template <int FMT, int SPLIT, bool TP = false>
 __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
                                             float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
                                             void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
                                             int row, int lane, int wave, int wg_index, int nwg_all,
-                                            const typename TpArg<TP>::type& tp = typename TpArg<TP>::type{}) {
+                                            const typename TpArg<TP>::type& tp = typename TpArg<TP>::type{},
+                                            unsigned long long* pubq = nullptr, unsigned long long* pubs = nullptr) {
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;
   constexpr int RW = 2 / SPLIT;
@@ -304,6 +379,19 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
         store_qaux<Q81>(isum, blk, o.aux);
       }
     }
+    if (pubq != nullptr && part == 0) {  // (both parts of a split chunk hold the whole block: part 0 publishes it)
+      signed char* qb = (signed char*)hv;  // hv is done with: 32 bytes of it carry the quants into dwords
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 32) qb[lane] = o.q;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 8)
+        __hip_atomic_store(pubq + blk * 8 + lane, ((unsigned long long)epoch << 32) | (unsigned long long)((const unsigned*)qb)[lane], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0)
+        __hip_atomic_store(pubs + blk, ((unsigned long long)epoch << 32) | (unsigned long long)((unsigned)o.d | (((unsigned)o.aux & 0xffffu) << 16)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else {
     // Q8_K (buf_q8_k.rs:84-131): the scale comes from the FIRST element of maximal |x| of the 256-element
     // super-block = this chunk and its 7 neighbours.  The wave holds the super-block's 256 rows (4 per lane, from
@@ -323,13 +411,14 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
 
 // QIN (Q4_K): 0 = the rhs planes are read from global memory; 1 = the rhs arrives as f32 (xin) and is quantized into LDS
 // by this workgroup; 2 = the finished planes (act) are copied into LDS
-template <int FMT, int SPLIT, int QIN = 0, bool TP = false>
+// QKV (Q4_0 weights, SPLIT = 2): the launch ends with the next layer's q/k/v rows (QkvTail above)
+template <int FMT, int SPLIT, int QIN = 0, bool TP = false, bool QKV = false>
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
                                                       signed char* __restrict__ q, void* __restrict__ d,
                                                       void* __restrict__ isum, NormGather ng, int nb, Planes6 w6,
-                                                      typename TpArg<TP>::type tp) {
+                                                      typename TpArg<TP>::type tp, typename QkvArg<QKV>::type qt = typename QkvArg<QKV>::type{}) {
   constexpr bool KQ = FMT == CRABML_HIP_Q4_K;  // Q4_K weights: nb counts super-blocks, the output is Q8_K
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
@@ -425,8 +514,63 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       }
     }
   }
-  nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
-                              (int)gridDim.x, tp);
+  if constexpr (!QKV) {
+    nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
+                                (int)gridDim.x, tp);
+  } else {
+    static_assert(FMT == CRABML_HIP_Q4_0 && !TP && SPLIT == 2, "the q/k/v tail rides the split-chunk ffn_down launch of Q4_0 layers");
+    using F = BlockFmt<FMT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_planes[];
+    // ---- the tail's weights: this wave's row pair of the next layer's wq | wk | wv, requested NOW (they depend on nothing) and
+    // held in registers across the norm hop and the sweep.  Up to 4 blocks per lane and row (dim <= 8192).
+    const QkvEpi& e = qt.e;
+    const int total = e.dim + 2 * e.kv_dim, nbq = nchunks;  // blocks per q/k/v row = dim / 32
+    const int pair = (int)blockIdx.x * qt.pairs_per_wg + wave, row0 = 2 * pair;
+    const bool have = wave < qt.pairs_per_wg && row0 < total;
+    Planes wsel = qt.wq;
+    int local = row0, m = e.dim;
+    if (row0 >= e.dim + e.kv_dim) {
+      wsel = qt.wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
+    } else if (row0 >= e.dim) {
+      wsel = qt.wk; local = row0 - e.dim; m = e.kv_dim;
+    }
+    typename F::Blk tb[2][4];
+    QkvPre pre{};
+    if (have) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int u = lane + 64 * i;
+        const int uu = u < nbq ? u : lane;  // (lane < nbq whenever the row has a block for this lane; clamped loads are not used)
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const int rr = local + r < m ? local + r : m - 1;
+          tb[r][i] = F::load(wsel.q, wsel.d, (size_t)rr, nbq, uu < nbq ? uu : 0);
+        }
+      }
+      if (lane == 0) pre = qkv_preload(e, row0);
+    }
+    const unsigned ep_all = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
+    nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
+                                (int)gridDim.x, tp, qt.xq_g, qt.xs_g);
+    // ---- every workgroup takes the whole normalized, quantized vector (16 waves, one round trip when it is all there)
+    sweep_planes_share<2>(qt.xq_g, qt.xs_g, nchunks * 32, ep_all, tail_planes, qt.off_d, qt.off_aux, lane, wave, 16, ng.fault);
+    __syncthreads();
+    if (have) {
+      const ActQ8_0 la{(const i32x4*)tail_planes, (const unsigned short*)(tail_planes + qt.off_d), (const int*)(tail_planes + qt.off_aux)};
+      float a2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int u = lane + 64 * i;
+        if (u < nbq) {  // ascending blocks per lane: rows_partial's order
+          const XUnit xu = F::loadx(la, u);
+          a2[0] += F::term(tb[0][i], xu);
+          a2[1] += F::term(tb[1][i], xu);
+        }
+      }
+      const float s0 = wave_sum_f32(a2[0]), s1 = wave_sum_f32(a2[1]);
+      if (lane == 0) qkv_epilogue(e, pre, row0, s0, s1);
+    }
+  }
 }
 
 // ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---

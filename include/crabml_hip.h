@@ -248,6 +248,10 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                           inboxes (rank order; the later index wins a tie across shards as it does inside one).
                                           Logits copied out by forward(): this rank's shard at its global offsets, -inf elsewhere
                                           (an element-wise max over the ranks' buffers is the all-gather) */
+#define CRABML_HIP_LLAMA_QKV_TAIL 2097152 /* Q4_0 layers, fast mode, one GPU: the NEXT layer's q/k/v GEMV (+ RoPE + KV append) runs as the
+                                          tail of the ffn_down launch -- its weights are requested into registers before the norm hop, the
+                                          quantized residual crosses the workgroups as granules -- instead of its own launch: 4 launches
+                                          per layer, bit-identical to 5 */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */

@@ -18,6 +18,7 @@ for w in $WHAT; do
     fault) timeout 900 $PT tests/test_hip_fault_paths.py > gpurun_out/fault_tests_$TAG.log 2>&1; echo "fault rc=$?"; tail -15 gpurun_out/fault_tests_$TAG.log ;;
     stamps) timeout 600 python tools/engine_stamps.py ${ENGINE_STAMPS_ARGS:-} > gpurun_out/engine_stamps_$TAG.log 2>&1; echo "stamps rc=$?"; cat gpurun_out/engine_stamps_$TAG.log ;;
     tptests) timeout 900 $PT tests/test_hip_tp.py tests/test_hip_tp_p2p.py > gpurun_out/tp_tests_$TAG.log 2>&1; echo "tptests rc=$?"; tail -15 gpurun_out/tp_tests_$TAG.log ;;
+    tailtests) timeout 600 $PT tests/test_hip_qkv_tail.py > gpurun_out/tail_tests_$TAG.log 2>&1; echo "tailtests rc=$?"; tail -15 gpurun_out/tail_tests_$TAG.log ;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke_$TAG.log ;;
   esac
 done
