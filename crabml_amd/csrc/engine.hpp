@@ -354,6 +354,13 @@ __device__ __forceinline__ bool eng_sweep_part(const ENG_G unsigned long long* q
   const int per = ((count + nparts - 1) / nparts + 63) & ~63;
   const int lo = part * per, hi = lo + per < count ? lo + per : count;
   for (int base = lo; base < hi; base += 64 * ENG_SWEEP_B) {
+    // a sentinel first: lane l spins on granule base + 64 * (ENG_SWEEP_B - 1) + l of the batch (clamped) -- the batch itself is
+    // requested once those are in, when it is likely to be complete (a batch requested early comes back stale and is paid twice)
+    {
+      int j = base + 64 * (ENG_SWEEP_B - 1) + lane;
+      if (j >= hi) j = hi - 1 - (lane % (hi - base < 64 ? hi - base : 64));
+      (void)eng_poll(j < nq ? qg + j : sg + (j - nq), epoch, S, fault);
+    }
     unsigned long long x[ENG_SWEEP_B];
     int spins = 0;
     for (;;) {
@@ -447,41 +454,26 @@ __device__ __forceinline__ float eng_edge(EngCtx& k, const EngArgs& a, unsigned 
   if (a.flags & 1) lds_st(&S->gathering, 1u);
   const int l32 = lane & 31;
   const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
-  // the hop: the partner's rows (split chunks) and EVERY workgroup's sum are requested at once -- one round trip when they are all
-  // there, which is the rule for all but the last workgroups to arrive; stale granules are polled individually afterwards.
-  // Up to 4 x 64 chunks (dim <= 8192), two halves each.
-  const int NB = (nchunks + 63) >> 6;
-  unsigned long long gr = 0, gs[8];
-  const bool need_row = split > 1 && lane < 32 && !own;
-  if (need_row) gr = eng_ldg(a.pair + blk * 32 + l32);
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int b = j >> 1, h = j & 1, ch = b * 64 + lane;
-    const bool valid = b < NB && ch < nchunks && h < split;
-    gs[j] = valid ? eng_ldg(a.slots + (split > 1 ? 2 * ch + h : ch)) : 0ull;
-  }
+  // the hop, polled in nq_epilogue's order: the partner's rows first, then every workgroup's sum in chunk order -- the wait for
+  // the first straggler covers the arrival of the rest (requesting everything at once was measured slower: most granules come
+  // back stale and are fetched twice; profiles/r03_engine_stamps_v3_nc7.log vs v2)
   float v = 0.0f;
   if (split > 1) {
-    if (lane < 32)
-      v = own ? S->hv[l32]
-              : __builtin_bit_cast(float, (unsigned)(gr >> 32) == epoch ? (unsigned)gr : eng_poll(a.pair + blk * 32 + l32, epoch, S, a.fault));
+    if (lane < 32) v = own ? S->hv[l32] : __builtin_bit_cast(float, eng_poll(a.pair + blk * 32 + l32, epoch, S, a.fault));
   } else {
     v = S->hv[l32];
   }
   float sum = 0.0f;
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    if (b >= NB) break;  // wave-uniform
-    const int ch = b * 64 + lane;
-    float hh[2] = {0.0f, 0.0f};
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      if (h < split && ch < nchunks) {
-        const unsigned long long g = gs[b * 2 + h];
-        hh[h] = __builtin_bit_cast(float, (unsigned)(g >> 32) == epoch ? (unsigned)g : eng_poll(a.slots + (split > 1 ? 2 * ch + h : ch), epoch, S, a.fault));
-      }
+  for (int base = 0; base < nchunks; base += 64) {
+    const int ch = base + lane;
+    float cv;
+    if (split > 1) {
+      const float h0 = ch < nchunks ? __builtin_bit_cast(float, eng_poll(a.slots + 2 * ch, epoch, S, a.fault)) : 0.0f;
+      const float h1 = ch < nchunks ? __builtin_bit_cast(float, eng_poll(a.slots + 2 * ch + 1, epoch, S, a.fault)) : 0.0f;
+      cv = h0 + h1;  // chunk = its two halves (lanes past the grid add +0.0)
+    } else {
+      cv = ch < nchunks ? __builtin_bit_cast(float, eng_poll(a.slots + ch, epoch, S, a.fault)) : 0.0f;
     }
-    const float cv = split > 1 ? hh[0] + hh[1] : hh[0];  // chunk = its two halves (lanes past the grid add +0.0)
     sum += wave_sum_f32(cv);
   }
   const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);

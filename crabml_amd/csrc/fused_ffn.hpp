@@ -334,6 +334,9 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     return __builtin_bit_cast(float, (unsigned)g);
   };
   // the rows of other workgroups first (published before their sums; the loads fly while the stragglers arrive) ...
+  // (Round 3 measured the alternative -- every granule of the hop requested at once, stale ones polled afterwards: ffn_down
+  // 9.5 -> 10.3 us, profiles/r03_batched_epilogue_polls_ab.log.  Requested early, most granules come back stale and are
+  // fetched twice; polled in this order, the wait for the first straggler covers the arrival of the rest.)
   const int l32 = lane & 31;
   const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
   const int sb = blk >> 3;

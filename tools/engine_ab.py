@@ -34,7 +34,7 @@ seq = a.warmup + a.steps + 40
 ref = None
 for cfg in a.configs.split(","):
     parts = cfg.split(":")
-    flags = ENGINE if parts[0] == "eng" else 2097152 if parts[0] == "tail" else 0
+    flags = ENGINE if parts[0] == "eng" else 2097152 if parts[0] == "tail" else int(parts[0][5:]) if parts[0].startswith("flags") else 0
     env = {}
     prefetch = True
     for p in parts[1:]:
