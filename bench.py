@@ -309,8 +309,28 @@ def tp_dry_run(args, ca, synth, local):
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
     local_bytes = sum(t.data.nbytes for name, t in model.tensors.items()
                       if not name.endswith("_norm.weight") and name != "token_embd.weight")
+    # per-stage kernel times of the same rank (eager replay, dispatch-timestamp events)
+    stage_names = {1: "qkv", 2: "wo", 3: "gate|up", 4: "ffn_down", 5: "classifier", 6: "norm", 7: "attention", 8: "softmax", 9: "pv"}
+    per_stage = None
+    try:
+        del r
+        e = ca.HipLlamaRunner(conf, weights, dev, 64, True, False, not args.no_prefetch, tp_size=n, tp_rank=0,
+                              extra_flags=128 | (1048576 if args.tp_split_vocab else 0) | args.flags)
+        e.decode_greedy(1, args.warmup)
+        dev.sync()
+        dev.prof_enable(True)
+        e.decode_greedy(1, 8)
+        recs = dev.prof_read()
+        dev.prof_enable(False)
+        per_stage = {stage_names.get(x["stage"], str(x["stage"])): {"avg_us": round(x["kernel_ms"] * 1e3 / x["launches"], 2),
+                                                                     "launches_per_token": x["launches"] / 8,
+                                                                     "algo_MB": round(x["algo_bytes"] / x["launches"] / 1e6, 2)}
+                     for x in sorted(recs, key=lambda x: x["stage"])}
+    except Exception as ex:
+        per_stage = {"error": repr(ex)}
     print(json.dumps({
         "measurement": "tensor-parallel dry run: one rank's kernels per token, all-reduces skipped",
+        "per_stage": per_stage,
         "model": shape.name, "wtype": args.wtype, "tp_size": n, "ms_per_token_rank_kernels": round(ms, 4),
         "rank_weight_bytes_per_token": local_bytes,
         "rank_effective_GBps": round(local_bytes / ms / 1e6, 1),

@@ -451,7 +451,7 @@ __device__ __forceinline__ float eng_edge(EngCtx& k, const EngArgs& a, unsigned 
     __hip_atomic_store(a.slots + c, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granules are on their way before the polls queue up behind them
-  if (a.flags & 1) lds_st(&S->gathering, 1u);
+  if (a.flags & 3) lds_st(&S->gathering, 1u);
   const int l32 = lane & 31;
   const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
   // the hop, polled in nq_epilogue's order: the partner's rows first, then every workgroup's sum in chunk order -- the wait for
@@ -568,6 +568,15 @@ __global__ __launch_bounds__(1024) void k_engine(const EngArgs* __restrict__ ap)
         }
         if (st) t_full += eng_now() - t0;
       }
+      if ((a.flags & 2) && lds_ld(&S.gathering) != 0) {
+        // pause: while this CU's edge wave polls granules the loader issues nothing (every byte in flight queues ahead of the
+        // granule loads in the CU's memory pipeline); what is in flight lands and is handed over meanwhile
+        if (st) t0 = eng_now();
+        eng_wait_vm<0>();
+        for (; published < s; published++) lds_st(&S.filled[published % D], (unsigned)published + 1u);
+        for (int tries = 0; tries < ENG_SPIN && lds_ld(&S.gathering) != 0 && !lds_ld(&S.giveup); tries++) __builtin_amdgcn_s_sleep(1);
+        if (st) t_full += eng_now() - t0;
+      }
       const bool thin = (a.flags & 1) && lds_ld(&S.gathering) != 0;
       const unsigned dst = ring_base + (unsigned)p * ENG_SLOT;
       if (ni == 18) {
@@ -667,12 +676,13 @@ __global__ __launch_bounds__(1024) void k_engine(const EngArgs* __restrict__ ap)
     if (!eng_consume_r<FMT, 0>(k, a, a.R_wo, 0, n_wo, a.nb_wo, act, e1)) return eng_bail(k, a.fault);
   }
   if (edge_wave) {
+    if ((a.flags & 2) && lane == 0) lds_st(&S.gathering, 1u);  // pause mode: the loader stops before the hop starts
     if (has_rows) {
       if (!lds_wait_ge(&S.cnt_wo, (unsigned)n_wo, &S.giveup)) return eng_bail(k, a.fault);
       eng_stamp(a, c, 2, lane);
       res = eng_edge<false>(k, a, e1, res, wn1, a.eps_ffn);  // x2 = wo . attn + x; its norm chunk goes out as granules
       eng_stamp(a, c, 3, lane);
-    } else if (a.flags & 1) {
+    } else if (a.flags & 3) {
       lds_st(&S.gathering, 1u);
     }
     if (lane == 0) lds_st_release(&S.edge1, 1u);
@@ -699,7 +709,7 @@ __global__ __launch_bounds__(1024) void k_engine(const EngArgs* __restrict__ ap)
   if (!lds_wait_ge(&S.cnt_gu, (unsigned)n_gu, &S.giveup)) return eng_bail(k, a.fault);
   if (edge_wave) {
     eng_stamp(a, c, 5, lane);
-    if ((a.flags & 1) && lane == 0) lds_st(&S.gathering, 1u);
+    if ((a.flags & 3) && lane == 0) lds_st(&S.gathering, 1u);
   }
   if (!eng_sweep_part(a.hq_g, a.hs_g, a.nblk_h * 32, e2, ACT, a.hid_off_d, a.hid_off_aux, lane, k.cw, NC, &S, a.fault)) return;
   if (lane == 0) {

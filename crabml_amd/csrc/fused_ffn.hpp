@@ -638,6 +638,8 @@ __global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, Act
 // consecutive hidden rows = one quant block; each of its 16 waves computes 2 rows (4 weight rows in flight),
 // parks the h values in LDS, and one half-wave quantizes the block (buf_q8_0.rs:87-134).  hidden/32
 // workgroups (448 for Llama-3-8B) are all resident at once (2 per CU).  Saves a launch per layer.
+// (Round 3: two units per row in flight -- 8 weight loads per lane and step -- measured slower on the full grid, 12.9 -> 14.6 us,
+// and on a tensor-parallel rank's 112 workgroups, 10.65 -> 11.35 us: a CU's ~26 GB/s is not a matter of bytes in flight.)
 template <int FMT>
 __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typename ActOf<FMT>::type act,
                                                    const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,

@@ -51,9 +51,9 @@ def test_engine_equals_the_five_launch_layer(ca, shape):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{shape} graph={use_graph} step {i}"
 
 
-@pytest.mark.parametrize("nc,depth,thin", [(1, 3, 0), (2, 4, 1), (3, 5, 1), (7, 0, 0)])
+@pytest.mark.parametrize("nc,depth,thin", [(1, 3, 0), (2, 4, 1), (3, 5, 2), (7, 0, 0), (15, 0, 3)])
 def test_engine_wave_counts_and_ring_depths(ca, nc, depth, thin):
-    """1..7 consumer waves, shallow rings (a slot is reused after 3 fills), the thinned loader: same bits."""
+    """1..15 consumer waves, shallow rings (a slot is reused after 3 fills), the thinned / paused loader: same bits."""
     model = synth.build_model(SHAPES["two-blocks"], synth.TYPE_BY_NAME["Q4_0"], seed=32)
     base, _ = run(ca, model, 0, TOKS[:6])
     env = {"CRABML_HIP_ENGINE_NC": str(nc), "CRABML_HIP_ENGINE_D": str(depth), "CRABML_HIP_ENGINE_THIN": str(thin)}
