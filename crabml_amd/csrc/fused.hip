@@ -1158,7 +1158,7 @@ int engine_setup(crabml_hip_llama* c) {
     if (v >= 1 && v <= 15) c->eng_nc = v;
   }
   c->eng_flags = 0;
-  if (const char* e = getenv("CRABML_HIP_ENGINE_THIN")) c->eng_flags |= atoi(e) ? 1 : 0;
+  if (const char* e = getenv("CRABML_HIP_ENGINE_THIN")) c->eng_flags |= atoi(e) & 3;  // 1: thin, 2: pause the loader while the CU gathers
   c->eng_lag = 2;
   if (const char* e = getenv("CRABML_HIP_ENGINE_LAG")) {
     const int v = atoi(e);
