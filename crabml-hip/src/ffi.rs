@@ -19,6 +19,11 @@ pub const CRABML_HIP_LLAMA_NO_GRAPH: i32 = 1;
 pub const CRABML_HIP_LLAMA_NO_PREFETCH: i32 = 2;
 pub const CRABML_HIP_LLAMA_NO_NORM_EPILOGUE: i32 = 4;
 pub const CRABML_HIP_LLAMA_TP_GRAPH: i32 = 8;
+/// opt-in decode-step variants (bit-identical, measured slower on MI355X: DESIGN.md section 4, "Round 3")
+pub const CRABML_HIP_LLAMA_ENGINE: i32 = 524288;
+pub const CRABML_HIP_LLAMA_QKV_TAIL: i32 = 2097152;
+/// tensor parallelism: `output_weight` is the rank's vocabulary shard of the classifier (P2P group)
+pub const CRABML_HIP_LLAMA_TP_SPLIT_VOCAB: i32 = 1048576;
 
 #[repr(C)]
 pub struct crabml_hip_device_t {
