@@ -2,9 +2,15 @@
 // gate/up GEMV + SiLU * mul + quantize -> ffn_down GEMV + residual + the next RMSNorm + quantize.
 // Part of the fused decode step (fused.hip includes it after the three fused_*.hpp files).
 //
-// Why: as three launches (k_gemv_res_nq, k_gateup_q, k_gemv_res_nq) every GEMV pays a dependent-kernel boundary and the ramp of
-// its weight stream (T ~ bytes / 6.2 TB/s + 2.6 us), and the two in-launch norm gathers run with HBM idle.
-// Here one workgroup per CU stays resident for the three GEMVs and the weights never stop streaming:
+// STATUS (round 3, measured on MI355X): correct -- bit-identical to the three launches it replaces at every tested shape -- and
+// SLOWER: 37-39 us per launch against 5.2 + 12.8 + 9.5 = 27.5 us (600-616 vs 747 tok/s on the Llama-3-8B shape).  It is therefore
+// opt-in (CRABML_HIP_LLAMA_ENGINE), kept with its tests and its profiling stamps as the measured answer to "what does the
+// persistent layer of MI355X_MICROARCH.md buy on THIS path": an in-launch all-to-all edge costs ~3 us (five of them here), a
+// kernel boundary ~0.6 us of gap plus a ramp, and the run-ahead is capped at the 33 MB of LDS.  DESIGN.md section 4, "Round 3".
+//
+// Why it was built: as three launches (k_gemv_res_nq, k_gateup_q, k_gemv_res_nq) every GEMV pays a dependent-kernel boundary and
+// the ramp of its weight stream (T ~ bytes / 6.2 TB/s + 2.6 us), and the two in-launch norm gathers run with
+// HBM idle.  Here one workgroup per CU stays resident for the three GEMVs and the weights never stop streaming:
 //   * wave 0 is the LOADER: it copies the CU's weight stream (a contiguous, CU-major re-layout of wo | gate/up | down made once
 //     at create: k_eng_pack) into an LDS ring of D slots with LDS-DMA (global_load_lds_dwordx4 ... nt, 1 KiB per instruction),
 //     up to D slots (129 KiB per CU, 33 MB per chip = ~5 us of stream) ahead of the consumers -- across the two all-to-all
@@ -35,7 +41,6 @@
 namespace crabml_hip {
 
 constexpr int ENG_SLOT = 18432;  // ring slot stride: 18 KiB = 8 rows of a 4096-column Q4_0 matrix (8 x 128 x 18 bytes)
-constexpr int ENG_MAX_NI = 18;   // 1 KiB DMA pieces per slot
 constexpr int ENG_MAX_D = 8;     // ring depth (slots)
 constexpr int ENG_MAX_BLK = 8;   // gate/up 32-row blocks per CU
 constexpr int ENG_SPIN = 1 << 20;
@@ -319,9 +324,6 @@ __device__ __forceinline__ bool eng_consume_r(EngCtx& k, const EngArgs& a, int R
 // remaining waits fall through quickly)
 __device__ __forceinline__ unsigned long long eng_ldg(const ENG_G unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void eng_stg(ENG_G unsigned long long* p, unsigned epoch, unsigned payload) {
-  __hip_atomic_store(p, ((unsigned long long)epoch << 32) | (unsigned long long)payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned eng_poll(const ENG_G unsigned long long* p, unsigned epoch, EngShared* S, ENG_G int* fault) {
   unsigned long long g = eng_ldg(p);
