@@ -93,3 +93,27 @@ def test_engine_llama3_8b_shape_two_layers(ca):
     got, _ = run(ca, model, ENGINE, toks, seq_len=128)
     for i, (a, b) in enumerate(zip(got, base)):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
+
+
+def test_engine_after_a_batched_prefill(ca):
+    """prompt through crabml_hip_llama_prefill (the engine plays no part in it), then decode steps through the engine: tokens and
+    logits equal the 5-launch step's, and a reset + second sequence reuses the same weight stream."""
+    model = synth.build_model(SHAPES["rows<cus"], synth.TYPE_BY_NAME["Q4_0"], seed=35)
+    prompt = [(11 * i + 3) % 1024 for i in range(24)]
+    out = []
+    for flags in (0, ENGINE):
+        dev = ca.HipTensorDevice(0)
+        conf, w = synth.to_hip(model, dev)
+        r = ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, extra_flags=flags)
+        first = r.prefill(prompt).copy()
+        steps = [r.forward(t, len(prompt) + i).copy() for i, t in enumerate(TOKS[:5])]
+        ids = list(r.decode_greedy(7, 6))
+        r.reset()
+        again = r.prefill(prompt[:9]).copy()
+        out.append((first, steps, ids, again))
+    a, b = out
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    for x, y in zip(a[1], b[1]):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert a[2] == b[2]
+    assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
