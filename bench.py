@@ -524,10 +524,7 @@ def main():
     if rank == 0:
         STAGES = {0: "matmul_vec (per-op path)", 1: "k_qkv (wq|wk|wv + rope + KV append)", 2: "wo GEMV + residual (+ next rmsnorm/quantize epilogue)",
                   3: "k_gateup_q (gate|up + silu*mul + quantize)", 4: "ffn_down GEMV + residual (+ next rmsnorm/quantize epilogue)",
-                  5: "k_gemv (classifier)",
-                  10: "k_ffn (gate|up + silu*mul + quantize + ffn_down + residual + next rmsnorm/quantize, one launch)",
-                  11: "k_engine (wo + residual + rmsnorm/quantize + gate|up + silu*mul + quantize + ffn_down + residual + next rmsnorm/quantize: "
-                      "one persistent launch, LDS-DMA weight stream)"}
+                  5: "k_gemv (classifier)"}
         n_prof = min(args.steps, 16)
         if path == "fused":
             eager = ca.HipLlamaRunner(conf, weights, dev, n_prof + 8, True, False, not args.no_prefetch,

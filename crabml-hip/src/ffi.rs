@@ -1,4 +1,5 @@
-//! Raw bindings of include/crabml_hip.h (ABI version 1), written by hand: the header is small, plain C
+//! Raw bindings of include/crabml_hip.h (ABI version 1; the parity / measurement hooks of crabml_hip_debug.h are test
+//! infrastructure of the backend repository and are not bound), written by hand: the header is small, plain C
 //! (opaque handles, pointers, sizes, fixed-width integers), and a checked-in binding keeps `bindgen` / libclang out
 //! of the build.  tests/test_rust_crate.py (backend repository) parses this `extern "C"` block and the header and
 //! fails when a name, an arity or an integer width differs.
@@ -17,11 +18,9 @@ pub const CRABML_HIP_FLAG_STRICT_ORDER: i32 = 1;
 
 pub const CRABML_HIP_LLAMA_NO_GRAPH: i32 = 1;
 pub const CRABML_HIP_LLAMA_NO_PREFETCH: i32 = 2;
-pub const CRABML_HIP_LLAMA_NO_NORM_EPILOGUE: i32 = 4;
 pub const CRABML_HIP_LLAMA_TP_GRAPH: i32 = 8;
-/// opt-in decode-step variants (bit-identical, measured slower on MI355X: DESIGN.md section 4, "Round 3")
-pub const CRABML_HIP_LLAMA_ENGINE: i32 = 524288;
-pub const CRABML_HIP_LLAMA_QKV_TAIL: i32 = 2097152;
+/// fast mode at long context: keep the reference's f16-accumulated PV chain instead of the f32 split-KV kernels
+pub const CRABML_HIP_LLAMA_EXACT_ATTENTION: i32 = 4194304;
 /// tensor parallelism: `output_weight` is the rank's vocabulary shard of the classifier (P2P group)
 pub const CRABML_HIP_LLAMA_TP_SPLIT_VOCAB: i32 = 1048576;
 
@@ -87,15 +86,6 @@ pub struct crabml_hip_llama_weights_t {
     pub output_weight: *const crabml_hip_buf_t,
 }
 
-#[repr(C)]
-pub struct crabml_hip_prof_entry_t {
-    pub dtype: u32,
-    pub reserved: u32,
-    pub launches: u64,
-    pub kernel_ms: f64,
-    pub algo_bytes: f64,
-}
-
 extern "C" {
     // ---- device
     pub fn crabml_hip_abi_version() -> i32;
@@ -134,13 +124,6 @@ extern "C" {
     pub fn crabml_hip_matmul_vec(dev: *mut crabml_hip_device_t, w: *const crabml_hip_buf_t, m: usize, k: usize, x: *const crabml_hip_buf_t, b: usize, out: *mut *mut crabml_hip_buf_t) -> i32;
     pub fn crabml_hip_batch_matmul(dev: *mut crabml_hip_device_t, a: *const crabml_hip_buf_t, ba: usize, m: usize, k: usize, b: *const crabml_hip_buf_t, bb: usize, n: usize, sb0: usize, sb1: usize, sb2: usize, out: *mut *mut crabml_hip_buf_t) -> i32;
 
-    // ---- parity / debug hooks
-    pub fn crabml_hip_debug_quantize(dev: *mut crabml_hip_device_t, x: *const crabml_hip_buf_t, n: usize, qtype: u32, dst: *mut c_void, dst_bytes: usize) -> i32;
-    pub fn crabml_hip_debug_block_dots(dev: *mut crabml_hip_device_t, w: *const crabml_hip_buf_t, m: usize, k: usize, row: usize, x: *const crabml_hip_buf_t, dst: *mut i32) -> i32;
-    pub fn crabml_hip_debug_superblock_ints(dev: *mut crabml_hip_device_t, w: *const crabml_hip_buf_t, m: usize, k: usize, row: usize, x: *const crabml_hip_buf_t, variant: i32, dst: *mut i32, value: *mut f32) -> i32;
-    pub fn crabml_hip_debug_gemm_ints(dev: *mut crabml_hip_device_t, w: *const crabml_hip_buf_t, m: usize, k: usize, x: *const crabml_hip_buf_t, b: usize, dst: *mut i32, out: *mut f32) -> i32;
-    pub fn crabml_hip_debug_read_ceiling(dev: *mut crabml_hip_device_t, bytes: usize, reps: i32, gbytes_per_s: *mut f64) -> i32;
-
     // ---- fused Llama decode step
     pub fn crabml_hip_llama_create(dev: *mut crabml_hip_device_t, cfg: *const crabml_hip_llama_config_t, w: *const crabml_hip_llama_weights_t, out: *mut *mut crabml_hip_llama_t) -> i32;
     pub fn crabml_hip_llama_destroy(ctx: *mut crabml_hip_llama_t) -> i32;
@@ -160,10 +143,5 @@ extern "C" {
     pub fn crabml_hip_tp_p2p_connect(comm: *mut crabml_hip_tp_comm_t, handles: *const c_void) -> i32;
     pub fn crabml_hip_tp_p2p_connect_local(comms: *const *mut crabml_hip_tp_comm_t, n: i32) -> i32;
     pub fn crabml_hip_llama_tp_sim_forward(ranks: *const *mut crabml_hip_llama_t, n: i32, token: usize, pos: usize, logits: *mut f32) -> i32;
-    pub fn crabml_hip_llama_debug_kv(ctx: *mut crabml_hip_llama_t, layer: usize, which_v: i32, dst: *mut c_void, nbytes: usize) -> i32;
 
-    // ---- measurement hook
-    pub fn crabml_hip_prof_enable(dev: *mut crabml_hip_device_t, on: i32) -> i32;
-    pub fn crabml_hip_prof_read(dev: *mut crabml_hip_device_t, out: *mut crabml_hip_prof_entry_t, cap: usize, n: *mut usize) -> i32;
-    pub fn crabml_hip_prof_read_launches(dev: *mut crabml_hip_device_t, ms: *mut f32, cap: usize, n: *mut usize) -> i32;
 }

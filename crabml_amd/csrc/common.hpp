@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/crabml_hip.h"
+#include "../../include/crabml_hip_debug.h"  // parity / measurement hooks and A/B flag bits (not the drop-in surface)
 
 namespace crabml_hip {
 

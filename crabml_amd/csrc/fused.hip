@@ -21,7 +21,6 @@
 #include "fused_common.hpp"
 #include "fused_attention.hpp"
 #include "fused_ffn.hpp"
-#include "engine.hpp"
 
 
 // ==============================================================================================================
@@ -117,22 +116,9 @@ struct crabml_hip_llama {
   float* rope = nullptr;     // [seq_len][npairs][2]
   int* state = nullptr;      // token, pos, step, sink, serial (never reset), fault
   unsigned long long* slots = nullptr;  // dim/32 {chunk sum, epoch} granules of the norm epilogue
-  unsigned long long* hgran = nullptr;  // fused FFN: hidden/4 quant granules + hidden/32 scale granules of h
   unsigned long long* a8gran = nullptr;  // Q4_K layers: granules of the attention output (dim_l) and of h (hidden_l), through which
   unsigned long long* h8gran = nullptr;  // the producing kernels assemble Q8_K super-blocks (q8k_exchange_store)
   bool q8k_producers = false;            // attention / gate-up emit the Q8_K planes of wo's / ffn_down's rhs themselves
-  bool ffn_fused = false;               // gate/up + ffn_down as one launch (k_ffn)
-  bool qkv_tail = false;                // the next layer's q/k/v rows ride the ffn_down launch (QkvTail, fused_ffn.hpp)
-  // the engine (engine.hpp): wo + norm + gate/up + ffn_down + norm of a layer as ONE persistent launch over a CU-major weight stream
-  bool engine = false;
-  EngGeom eng_g{};
-  int eng_D = 0, eng_nc = 3, eng_flags = 0, eng_lag = 2;
-  size_t eng_lds = 0, eng_layer_bytes = 0;
-  unsigned char* eng_stream = nullptr;          // n_layers x eng_layer_bytes
-  unsigned long long* eng_cu_off = nullptr;     // [G + 1]
-  unsigned long long* xqgran = nullptr;         // dim / 4 + dim / 32 granules of the normalized residual (rhs of gate/up)
-  EngArgs* eng_args = nullptr;                  // [n_layers] kernel arguments of the layers' launches (device memory, static)
-  unsigned long long* eng_stamps = nullptr;     // CRABML_HIP_ENGINE_STAMPS=1: [n_layers][G][ENG_STAMPS] profiling words
   unsigned tp_salt = 0;      // P2P group: epoch salt of this context (see TpP2P::salt)
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
   bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
@@ -380,8 +366,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
   const bool norm_epi = c->norm_epi;
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
-  // tail_layer >= 0: the launch also computes layer `tail_layer`'s q/k/v rows (QkvTail; ffn_down of the layer before it)
-  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next, int tail_layer = -1) -> int {
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next) -> int {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
     if (norm_epi) {
@@ -395,29 +380,18 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       if (tpv.n > 1) {  // tensor parallel over a P2P group: the collective runs inside this launch
         if (split == 2)
           launch_k(st, R, k_gemv_res_nq<FMT, 2, false, true>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
-                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv, NoQkv{});
+                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
         else
           launch_k(st, R, k_gemv_res_nq<FMT, 1, false, true>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
-                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv, NoQkv{});
-      } else if (split == 2 && tail_layer >= 0) {
-        if constexpr (FMT == CRABML_HIP_Q4_0) {
-          const int tl = tail_layer;
-          const ActLayout ald = act_layout(qt, (size_t)dim);
-          QkvTail tq{planes_of(c->wq[tl]), planes_of(c->wk[tl]), planes_of(c->wv[tl]),
-                     QkvEpi{c->qbuf, c->kc[tl], c->vc[tl], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd, (int)g.rope_dim,
-                            c->npairs, seq_cap, kv16 ? 1 : 0},
-                     c->xqgran, c->xqgran + dim / 4, ((dim_l + 2 * kv_dim_l) / 2 + dim / 16 - 1) / (dim / 16), (int)ald.off_d, (int)ald.off_aux};
-          launch_k(st, R, k_gemv_res_nq<FMT, 2, 0, false, true>, dim3(dim / 16), dim3(1024), ald.total, planes_of(w), act_view<FMT>(a),
-                   (const float*)nullptr, c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{}, tq);
-        }
+                   c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
       } else if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{}, NoQkv{});
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
       else
         launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
-                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{}, NoQkv{});
+                 ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
     } else if (tp) {
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     } else {
@@ -466,60 +440,28 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
-    if (!(c->qkv_tail && l > 0)) {  // (qkv_tail: layer l's rows were the tail of layer l - 1's ffn_down launch)
-      CH_TRY(P0(&pr, 1, total_rows, dim));
-      launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
-      CH_TRY(P1(&pr));
-    }
+    CH_TRY(P0(&pr, 1, total_rows, dim));
+    launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
+             planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
+    CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;
     const int attn_spare = do_pf && dev->n_cu > n_heads_l ? dev->n_cu - n_heads_l : 0;
     enqueue_attention(c, l, attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, plan(c->wo[l], nullptr, nullptr), attn_spare, prof);
     if (!attn_quant) launch_quantize_act(st, qt, c->attn, (size_t)dim_l, c->act_attn);
-    // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice (engine: part of the odd segment's launch)
-    if (!c->engine) CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
+    // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
+    CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
   } else {
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
     if (!norm_epi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
     const float* wnext_down = (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr;
-    if (c->engine) {
-      // wo + residual + ffn norm + gate/up + silu * mul + down + residual + the next norm: one persistent launch (engine.hpp)
-      if constexpr (FMT == CRABML_HIP_Q4_0) {
-        if (prof)
-          CH_TRY(prof_begin(dev, &pr, c->wtype, 11,
-                            ((double)dim * dim_l + 3.0 * hidden_l * (double)dim) * blk_b + 4.0 * dim_l + 4.0 * dim + 4.0 * hidden_l + 8.0 * dim));
-        launch_k(st, R, k_engine<CRABML_HIP_Q4_0>, dim3(c->eng_g.G), dim3(64 * (1 + c->eng_nc)), c->eng_lds, (const EngArgs*)(c->eng_args + l));
-        CH_TRY(P1(&pr));
-      }
-      CH_HIP(dev, hipGetLastError());
-      return 0;
-    }
-    const int split_down = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
-                           : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
-                           : (hidden_l / 32 >= 256 && dim / 32 <= dev->n_cu) ? 2
-                                                                             : 1;
-    if (c->ffn_fused && norm_epi && split_down == 2 && hidden_l / 32 <= 2 * (dim / 16)) {
-      // gate / up + silu * mul + quantize + down + residual + the next rmsnorm / quantize: one launch (k_ffn)
-      NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg};
-      HGather hg{c->hgran, c->hgran + hidden_l / 4};
-      const ActLayout alh = act_layout(qt, (size_t)hidden_l);
-      if (prof)
-        CH_TRY(prof_begin(dev, &pr, c->wtype, 10,
-                          3.0 * hidden_l * (double)dim * blk_b + 4.0 * dim + 4.0 * (2.0 * hidden_l) + 4.0 * hidden_l + 4.0 * dim));
-      launch_k(st, R, k_ffn<FMT>, dim3(dim / 16), dim3(1024), alh.total, planes_of(c->gate[l]), planes_of(c->up[l]),
-               planes_of(c->down[l]), act_view<FMT>(ad), (const unsigned short*)dev->exp_table, c->x, wnext_down, g.rms_norm_eps, ad.q,
-               (void*)ad.d, ad.isum, ng, hg, dim / 32, hidden_l / 32, (int)alh.off_d, (int)alh.off_aux);
-      CH_TRY(P1(&pr));
-    } else {
-      // gate / up + silu * mul (llama2.rs:620-630), local rows
-      CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
-      launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
-               act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
-      CH_TRY(P1(&pr));
-      // down (+ residual, llama2.rs:633-636): k = the local hidden slice
-      CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps, c->qkv_tail && l + 1 < L ? l + 1 : -1));
-    }
+    // gate / up + silu * mul (llama2.rs:620-630), local rows
+    CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
+    launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
+             act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
+    CH_TRY(P1(&pr));
+    // down (+ residual, llama2.rs:633-636): k = the local hidden slice
+    CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps));
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
@@ -688,7 +630,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
 #define CRABML_NQ_K(SPLIT_, QIN_, GRID_, LDS_)                                                                                          \
   launch_k(st, R, k_gemv_res_nq<FMT, SPLIT_, QIN_>, dim3(GRID_), dim3(1024), LDS_, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob, \
-           ng, k / BE, six(w), NoTp{}, NoQkv{})
+           ng, k / BE, six(w), NoTp{})
         if (split == 2 && qmode == 2)
           CRABML_NQ_K(2, 2, dim / 16, lds);
         else if (split == 2 && qmode == 1)
@@ -1095,175 +1037,6 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
                   : launch_gemv(dev, c->output, g.vocab_size, dim, act, 1, c->logits, nullptr));
   }
   CH_HIP(dev, hipGetLastError());
-  return 0;
-}
-
-// ---- the engine (engine.hpp): geometry, LDS budget, the CU-major weight stream -----------------------------------------------
-// Opt-in / opt-out through the config flags; silently stays off (the 5-launch layer runs) when the shape does not fit:
-// Q4_0 layers, fast mode, one GPU, the norm-epilogue conditions, wo / ffn_down rows = 16 per CU (two CUs share a norm chunk) or 32,
-// gate/up rows in (gate, up) pairs.  (wo's rhs planes come from the attention launch, or from the quantizer launch behind it
-// when head_dim % 32 != 0.)
-template <class T>
-ENG_G T* eng_g(T* p) {  // EngArgs declares its pointers global (engine.hpp)
-  return (ENG_G T*)p;
-}
-int engine_setup(crabml_hip_llama* c) {
-  crabml_hip_device* dev = c->dev;
-  const auto& g = c->cfg;
-  c->engine = false;
-  if (!(g.flags & CRABML_HIP_LLAMA_ENGINE)) return 0;
-  if (c->generic || c->kfused || c->wtype != CRABML_HIP_Q4_0 || c->tp != 1 || !c->norm_epi) return 0;
-  const int dim = (int)g.embedding_dim, dim_l = c->dim_l, hidden_l = c->hidden_l;
-  EngGeom eg{};
-  eg.nblk_h = hidden_l / 32;
-  const int want = dim / 16 > eg.nblk_h ? dim / 16 : eg.nblk_h;
-  eg.G = want < dev->n_cu ? want : dev->n_cu;
-  if (dim / 16 <= eg.G) {
-    eg.rpc = 16;
-    eg.n_row_cus = dim / 16;
-  } else if (dim == 32 * eg.G) {
-    eg.rpc = 32;
-    eg.n_row_cus = eg.G;
-  } else {
-    return 0;
-  }
-  if ((eg.nblk_h + eg.G - 1) / eg.G > ENG_MAX_BLK) return 0;
-  eg.nb[0] = dim_l / 32;
-  eg.nb[1] = dim / 32;
-  eg.nb[2] = hidden_l / 32;
-  for (int op = 0; op < 3; op++) {
-    const int row_bytes = eg.nb[op] * 18;
-    int R = 8;
-    while (R > 1 && R * row_bytes > ENG_SLOT) R >>= 1;
-    if (R * row_bytes > ENG_SLOT) return 0;
-    if (op == 1 && R < 2) return 0;
-    if (op != 1 && eg.rpc % R) return 0;
-    eg.R[op] = R;
-    eg.ni[op] = (R * row_bytes + 1023) / 1024;
-  }
-  size_t act = act_layout(c->qt, (size_t)dim_l).total;
-  if (act_layout(c->qt, (size_t)dim).total > act) act = act_layout(c->qt, (size_t)dim).total;
-  if (act_layout(c->qt, (size_t)hidden_l).total > act) act = act_layout(c->qt, (size_t)hidden_l).total;
-  const size_t lds_max = 160 * 1024 - 4096;  // static LDS of k_engine (EngShared) stays below 4 KiB
-  if (act + 3 * (size_t)ENG_SLOT > lds_max) return 0;
-  int D = (int)((lds_max - act) / ENG_SLOT);
-  if (D > ENG_MAX_D) D = ENG_MAX_D;
-  if (const char* e = getenv("CRABML_HIP_ENGINE_D")) {
-    const int v = atoi(e);
-    if (v >= 3 && v <= D) D = v;
-  }
-  c->eng_nc = 3;
-  if (const char* e = getenv("CRABML_HIP_ENGINE_NC")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= 15) c->eng_nc = v;
-  }
-  c->eng_flags = 0;
-  if (const char* e = getenv("CRABML_HIP_ENGINE_THIN")) c->eng_flags |= atoi(e) & 3;  // 1: thin, 2: pause the loader while the CU gathers
-  c->eng_lag = 2;
-  if (const char* e = getenv("CRABML_HIP_ENGINE_LAG")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= 3) c->eng_lag = v;
-  }
-  c->eng_D = D;
-  c->eng_lds = (size_t)D * ENG_SLOT + act;
-  if (raise_dyn_lds(dev, (const void*)k_engine<CRABML_HIP_Q4_0>, (int)c->eng_lds) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  // per-CU stream offsets inside a layer
-  auto nslots = [&](int op, int cu) {
-    if (op == 1) return cu < eg.nblk_h ? ((eg.nblk_h - cu + eg.G - 1) / eg.G) * (64 / eg.R[1]) : 0;
-    return cu < eg.n_row_cus ? eg.rpc / eg.R[op] : 0;
-  };
-  std::vector<unsigned long long> off(eg.G + 1, 0);
-  int nmax[3] = {0, 0, 0};
-  for (int cu = 0; cu < eg.G; cu++) {
-    unsigned long long b = 0;
-    for (int op = 0; op < 3; op++) {
-      const int n = nslots(op, cu);
-      if (n > nmax[op]) nmax[op] = n;
-      b += (unsigned long long)n * eg.ni[op] * 1024ull;
-    }
-    off[cu + 1] = off[cu] + b;
-  }
-  c->eng_layer_bytes = (size_t)off[eg.G];
-  const size_t total = c->eng_layer_bytes * g.n_layers;
-  CH_TRY(dalloc(c, total, (void**)&c->eng_stream));
-  CH_TRY(dalloc(c, (size_t)(eg.G + 1) * 8, (void**)&c->eng_cu_off));
-  CH_TRY(dalloc(c, (size_t)(dim / 4 + dim / 32) * 8, (void**)&c->xqgran));
-  if (!c->hgran) CH_TRY(dalloc(c, (size_t)(hidden_l / 4 + hidden_l / 32) * 8, (void**)&c->hgran));
-  hipStream_t st = dev->stream;
-  CH_HIP(dev, hipMemcpyAsync(c->eng_cu_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, st));
-  CH_HIP(dev, hipMemsetAsync(c->eng_stream, 0, total, st));
-  CH_HIP(dev, hipMemsetAsync(c->xqgran, 0, (size_t)(dim / 4 + dim / 32) * 8, st));
-  CH_HIP(dev, hipMemsetAsync(c->hgran, 0, (size_t)(hidden_l / 4 + hidden_l / 32) * 8, st));
-  for (size_t l = 0; l < g.n_layers; l++) {
-    unsigned char* dst = c->eng_stream + l * c->eng_layer_bytes;
-    for (int op = 0; op < 3; op++) {
-      const size_t n = (size_t)eg.G * nmax[op] * eg.R[op] * eg.nb[op];
-      if (n == 0) continue;
-      const Planes w0 = planes_of(op == 0 ? c->wo[l] : op == 1 ? c->gate[l] : c->down[l]);
-      const Planes w1 = planes_of(op == 1 ? c->up[l] : c->wo[l]);
-      k_eng_pack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(dst, c->eng_cu_off, eg, op, nmax[op], w0, w1);
-    }
-  }
-  // the layers' kernel arguments
-  const int L = (int)g.n_layers;
-  if (const char* e = getenv("CRABML_HIP_ENGINE_STAMPS")) {
-    if (atoi(e)) {
-      const size_t nb = (size_t)L * eg.G * ENG_STAMPS * 8;
-      CH_TRY(dalloc(c, nb, (void**)&c->eng_stamps));
-      CH_HIP(dev, hipMemsetAsync(c->eng_stamps, 0, nb, st));
-    }
-  }
-  CH_TRY(dalloc(c, (size_t)L * sizeof(EngArgs), (void**)&c->eng_args));
-  std::vector<EngArgs> args((size_t)L);
-  const ActLayout ala = act_layout(c->qt, (size_t)dim_l), ald = act_layout(c->qt, (size_t)dim), alh = act_layout(c->qt, (size_t)hidden_l);
-  const ActPtrs ad = act_ptrs(c->act_dim, (size_t)dim, c->qt);
-  for (int l = 0; l < L; l++) {
-    EngArgs& ea = args[(size_t)l];
-    ea = EngArgs{};
-    ea.stream = eng_g(c->eng_stream + (size_t)l * c->eng_layer_bytes);
-    ea.cu_off = eng_g(c->eng_cu_off);
-    ea.G = eg.G;
-    ea.D = D;
-    ea.dim = dim;
-    ea.nblk_h = eg.nblk_h;
-    ea.nb_wo = eg.nb[0]; ea.nb_gu = eg.nb[1]; ea.nb_dn = eg.nb[2];
-    ea.R_wo = eg.R[0]; ea.R_gu = eg.R[1]; ea.R_dn = eg.R[2];
-    ea.ni_wo = eg.ni[0]; ea.ni_gu = eg.ni[1]; ea.ni_dn = eg.ni[2];
-    ea.rpc = eg.rpc;
-    ea.n_row_cus = eg.n_row_cus;
-    ea.attn_bytes = (int)ala.total; ea.attn_off_d = (int)ala.off_d; ea.attn_off_aux = (int)ala.off_aux;
-    ea.dim_off_d = (int)ald.off_d; ea.dim_off_aux = (int)ald.off_aux;
-    ea.hid_off_d = (int)alh.off_d; ea.hid_off_aux = (int)alh.off_aux;
-    ea.act_attn = eng_g((const unsigned char*)c->act_attn);
-    ea.x = eng_g(c->x);
-    ea.wn_ffn = eng_g((const float*)c->rms_ffn[l]->ptr);
-    ea.wn_next = eng_g((const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr);
-    ea.eps_ffn = 1e-5f;  // the literal of llama2.rs:611
-    ea.eps_next = g.rms_norm_eps;
-    ea.exp_tab = eng_g((const unsigned short*)dev->exp_table);
-    ea.oq = eng_g(ad.q); ea.od = eng_g(ad.d); ea.oisum = eng_g((int*)ad.isum);
-    ea.slots = eng_g(c->slots);
-    ea.pair = eng_g(c->slots + dim / 16);
-    ea.xq_g = eng_g(c->xqgran);
-    ea.xs_g = eng_g(c->xqgran + dim / 4);
-    ea.hq_g = eng_g(c->hgran);
-    ea.hs_g = eng_g(c->hgran + hidden_l / 4);
-    ea.serial = eng_g(c->state + 4);
-    ea.fault = eng_g(c->state + 5);
-    ea.nseg = n_segments(c);
-    ea.seg0 = 2 * l;  // the wo edge carries the even segment's epoch, the gate/up and down edges the odd segment's
-    ea.flags = c->eng_flags;
-    ea.lag = c->eng_lag;
-    ea.stamps = c->eng_stamps ? eng_g(c->eng_stamps + (size_t)l * eg.G * ENG_STAMPS) : nullptr;
-  }
-  CH_HIP(dev, hipMemcpyAsync(c->eng_args, args.data(), args.size() * sizeof(EngArgs), hipMemcpyHostToDevice, st));
-  CH_HIP(dev, hipGetLastError());
-  CH_HIP(dev, hipStreamSynchronize(st));  // `off` and `args` leave scope
-  c->eng_g = eg;
-  c->engine = true;
   return 0;
 }
 
@@ -1684,10 +1457,6 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   // host neither the norm epilogue nor the collective, so over a P2P group the stand-alone all-reduce launch must run)
   c->norm_epi = !generic && !c->kfused && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
-  c->ffn_fused = c->norm_epi && (g.flags & CRABML_HIP_LLAMA_FFN_FUSION);  // opt-in: measured slower than the two kernels
-  if (c->ffn_fused) {
-    A((hidden_l / 4 + hidden_l / 32) * 8, (void**)&c->hgran);
-  }
   c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
                   !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) && g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
   c->q8k_producers = c->norm_epi_k && !(g.flags & (CRABML_HIP_LLAMA_NO_RHS_PROLOGUE | CRABML_HIP_LLAMA_NO_Q8K_PRODUCERS)) && dim_l % 256 == 0 &&
@@ -1695,23 +1464,6 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   if (c->q8k_producers) {
     A(dim_l * 8, (void**)&c->a8gran);
     A(hidden_l * 8, (void**)&c->h8gran);
-  }
-  if (rc == 0) rc = engine_setup(c);
-  {
-    // the q/k/v tail of the ffn_down launch (QkvTail): the split-chunk launch must be the one every layer takes, with ONE
-    // workgroup per CU (the tail's registers do not leave room for two), and a wave per row pair
-    const int split_down = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
-                           : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
-                           : (hidden_l / 32 >= 256 && (int)(g.embedding_dim / 32) <= dev->n_cu) ? 2
-                                                                                                 : 1;
-    const size_t nwg = g.embedding_dim / 16, npairs = (dim_l + 2 * kv_dim_l) / 2;
-    c->qkv_tail = (g.flags & CRABML_HIP_LLAMA_QKV_TAIL) && !generic && !c->kfused && wt == CRABML_HIP_Q4_0 && tp == 1 && c->norm_epi &&
-                  !c->ffn_fused && !c->engine && split_down == 2 && (int)nwg <= dev->n_cu && (npairs + nwg - 1) / nwg <= 16 &&
-                  g.embedding_dim <= 8192 && g.n_layers > 1;
-    if (c->qkv_tail && !c->xqgran) {
-      A((g.embedding_dim / 4 + g.embedding_dim / 32) * 8, (void**)&c->xqgran);
-      if (rc == 0 && hipMemsetAsync(c->xqgran, 0, (g.embedding_dim / 4 + g.embedding_dim / 32) * 8, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
-    }
   }
   c->out_cap = (int)g.seq_len;
   A((size_t)c->out_cap * 4, (void**)&c->out_tokens);
@@ -1740,7 +1492,6 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     // vocabulary split: the entries of the other ranks' shards read -inf (an element-wise max over the ranks is the all-gather)
     if (e == hipSuccess && c->split_vocab) e = hipMemsetD32Async((hipDeviceptr_t)c->logits, (int)0xff800000u, g.vocab_size, dev->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->slots, 0, (g.embedding_dim / 16 + g.embedding_dim) * 8, dev->stream);
-    if (e == hipSuccess && c->hgran) e = hipMemsetAsync(c->hgran, 0, (hidden_l / 4 + hidden_l / 32) * 8, dev->stream);
     if (e == hipSuccess && c->a8gran) e = hipMemsetAsync(c->a8gran, 0, dim_l * 8, dev->stream);
     if (e == hipSuccess && c->h8gran) e = hipMemsetAsync(c->h8gran, 0, hidden_l * 8, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
@@ -1947,13 +1698,6 @@ int crabml_hip_llama_reset(crabml_hip_llama_t* c) {
 int crabml_hip_llama_debug_kv(crabml_hip_llama_t* c, size_t layer, int32_t which_v, void* dst, size_t nbytes) {
   if (!c || !dst) return CRABML_HIP_BAD_INPUT;
   CH_USE(c->dev);
-  if (which_v == 2) {  // profiling hook of the engine (CRABML_HIP_ENGINE_STAMPS=1): the layer's [G][ENG_STAMPS] words
-    const size_t have = c->eng_stamps ? (size_t)c->eng_g.G * ENG_STAMPS * 8 : 0;
-    if (layer >= c->cfg.n_layers || nbytes > have) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: no engine stamps of that size");
-    CH_HIP(c->dev, hipMemcpyAsync(dst, c->eng_stamps + layer * (size_t)c->eng_g.G * ENG_STAMPS, nbytes, hipMemcpyDeviceToHost, c->dev->stream));
-    CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
-    return 0;
-  }
   if (layer >= c->cfg.n_layers || nbytes > c->kv_bytes) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: bad layer/size");
   CH_HIP(c->dev, hipMemcpyAsync(dst, which_v ? c->vc[layer] : c->kc[layer], nbytes, hipMemcpyDeviceToHost, c->dev->stream));
   CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));

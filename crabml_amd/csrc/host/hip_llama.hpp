@@ -144,12 +144,6 @@ class HipLlamaRunner {
     device_->check(crabml_hip_llama_debug_kv(ctx_, layer, v ? 1 : 0, out.data(), n));
     return out;
   }
-  // profiling hook of the engine (CRABML_HIP_ENGINE_STAMPS=1): `words` 64-bit words of the layer's stamp block
-  std::vector<uint64_t> engine_stamps(size_t layer, size_t words) {
-    std::vector<uint64_t> out(words);
-    device_->check(crabml_hip_llama_debug_kv(ctx_, layer, 2, out.data(), words * 8));
-    return out;
-  }
   // one decode step of a single-device simulated tp group (crabml_hip_llama_tp_sim_forward); logits from rank 0
   static std::vector<float> tp_sim_forward(const std::vector<HipLlamaRunner*>& ranks, size_t token, size_t pos) {
     if (ranks.empty()) throw Error(ErrorKind::BadInput, "tp_sim_forward: no ranks");

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "crabml_hip.h"
+#include "crabml_hip_debug.h"  // the parity hooks the tests reach through this mirror
 #include "strider.hpp"
 
 namespace crabml_host {

@@ -396,10 +396,6 @@ PYBIND11_MODULE(_host, m) {
       .def("debug_kv", [](HipLlamaRunner& r, size_t layer, bool v, bool f16) {
         std::vector<uint8_t> b = r.debug_kv(layer, v, f16);
         return py::array_t<uint8_t>(b.size(), b.data());
-      })
-      .def("engine_stamps", [](HipLlamaRunner& r, size_t layer, size_t words) {
-        std::vector<uint64_t> b = r.engine_stamps(layer, words);
-        return py::array_t<uint64_t>(b.size(), b.data());
       });
 
   py::class_<Runner>(m, "Llama2Runner")

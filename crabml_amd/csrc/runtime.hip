@@ -243,9 +243,16 @@ int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip
   if (hipGetDeviceProperties(&prop, dev->ordinal) == hipSuccess) dev->n_cu = prop.multiProcessorCount;
   // test hook (tests/test_hip_fault_paths.py): claim this many CUs whatever the device reports, so that a CU-masked process
   // (HSA_CU_MASK) loses the co-residency the in-launch hand-offs rely on -- their bounded polls must raise, not hang
-  if (const char* e = getenv("CRABML_HIP_ASSUME_CUS")) {
-    const int v = atoi(e);
-    if (v > 0 && v <= 1024) dev->n_cu = v;
+  // Armed only when CRABML_HIP_TEST_HOOKS=1 is set as well (a stray CRABML_HIP_ASSUME_CUS alone is ignored), and it says so.
+  const char* hooks = getenv("CRABML_HIP_TEST_HOOKS");
+  if (hooks != nullptr && hooks[0] == '1') {
+    if (const char* e = getenv("CRABML_HIP_ASSUME_CUS")) {
+      const int v = atoi(e);
+      if (v > 0 && v <= 1024) {
+        fprintf(stderr, "crabml_hip: TEST HOOK active: assuming %d CUs (device reports %d)\n", v, dev->n_cu);
+        dev->n_cu = v;
+      }
+    }
   }
   if (opts && opts->stream) {
     dev->stream = (hipStream_t)opts->stream;

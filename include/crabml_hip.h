@@ -160,35 +160,6 @@ int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a,
                             const crabml_hip_buf_t* b, size_t bb, size_t n, size_t sb0, size_t sb1, size_t sb2,
                             crabml_hip_buf_t** out);
 
-/* ---- parity / debug hooks (used by tests; not on the hot path) ------------------------------ */
-/* Quantizes the first n f32 elements of x to `qtype` (Q8_0 | Q8_1 | Q8_K) on the device and returns
- * the blocks in the reference's byte layout (buf_q8_0.rs:8-13, buf_q8_1.rs:73-79, buf_q8_k.rs:6-12). */
-int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* x, size_t n, uint32_t qtype,
-                              void* dst, size_t dst_bytes);
-/* Exact integer part of W(row) . X per 32-element group (one int32 each; k/32 values): the
- * bit-exact gate for the nibble unpack + integer dot. */
-int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
-                                const crabml_hip_buf_t* x, int32_t* dst);
-/* The integers of the PRODUCTION K-quant loops, per super-block (Q4_K / Q6_K weights, Q8_K rhs; north_star: "bit-exactly
- * at the integer unpack level").  The single-row kernels' own inner loops (rows_partial_q4k / rows_partial_q6k in their
- * debug instantiation: the same code k_gemv_q4_k / k_qkv / k_gemv_res_nq / k_gateup_k_lds run) walk row `row` and hand out
- * what their float part consumes: dst[2 sb] = isum = sum_j scale_j * sum(q * q8) and dst[2 sb + 1] = msum = sum_j min_j *
- * bsum_j for Q4_K (buf_q4_k.rs:212-263; variant 0 = quad-exchanged header dwords, 1 = whole-header loads, the form the
- * LDS-staged kernels use); dst[2 sb] = sum_g scale_g * sum((q6 - 32) * q8), dst[2 sb + 1] = 0 for Q6_K
- * (buf_q6_k.rs:183-234).  k / 256 pairs.  *value (optional) = the kernel's own f32 result for the row. */
-int crabml_hip_debug_superblock_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
-                                     const crabml_hip_buf_t* x, int32_t variant, int32_t* dst, float* value);
-/* The same integers out of the matrix-core GEMM (k_gemm_mfma_q4k / k_gemm_mfma_q6k themselves, run with their dump
- * pointer set): x holds b >= 16 rows of k; dst[((bi * m + row) * (k / 256) + sb) * 2 + {0, 1}] = (isum, msum) for Q4_K and
- * (sum_g scale_g * sum(q6 * q8), sum_g scale_g * bsum_g) for Q6_K -- the -32 offset is applied as isum - 32 * that.
- * out (optional, b * m floats) receives the GEMM's f32 result. */
-int crabml_hip_debug_gemm_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k,
-                               const crabml_hip_buf_t* x, size_t b, int32_t* dst, float* out);
-/* Sustained HBM read rate of this device as a plain streaming kernel reaches it (16-byte non-temporal loads over `bytes`
- * bytes, best of `reps` launches, HIP events on the device stream): the practical ceiling bench.py quotes next to the
- * 8 TB/s datasheet peak. */
-int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_t reps, double* gbytes_per_s);
-
 /* ---- fused Llama decode step (extension of the hot path) ------------------------------------------
  * The trait above costs ~31 launches per layer (one per Tensor call of crabml-llama2/src/llama2.rs:226-271),
  * which makes batch-1 decode launch-bound on MI355X (profiles/r01_trait_path_kernel_trace.md).  This entry
@@ -198,8 +169,7 @@ int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_
  *   wo GEMV + residual + the ffn RMSNorm + quantize | gate/up GEMV + SiLU*mul + quantize |
  *   ffn_down GEMV + residual + the next layer's RMSNorm + quantize
  * (the norms run in the producing GEMV's epilogue through one in-launch gather; attention switches to three
- * multi-workgroup kernels from `attn_long_from` cached positions), or as THREE with CRABML_HIP_LLAMA_ENGINE
- * (q/k/v | attention | one persistent launch for wo .. ffn_down fed by an LDS-DMA weight stream), with token id
+ * multi-workgroup kernels from `attn_long_from` cached positions), with token id
  * and position living in device memory (greedy argmax on device, sampler.rs:109-116).
  * Arithmetic is the reference's (same rounding points; RoPE cos/sin tabulated on the host with the same
  * libm + iterated-theta recurrence); only GEMV block terms (and, fast mode, the RMSNorm chunk sums and softmax
@@ -212,34 +182,16 @@ int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_
  * weights F32.  Tensor types whose rhs dtypes differ inside a layer: CRABML_HIP_NOT_IMPLEMENTED (use the
  * per-op trait path). */
 typedef struct crabml_hip_llama crabml_hip_llama_t;
+/* config flags (crabml_hip_llama_config_t.flags).  A/B switches between kernel variants and test hooks share the word: they are
+ * declared in crabml_hip_debug.h and are not part of the drop-in surface. */
 #define CRABML_HIP_LLAMA_NO_GRAPH 1 /* launch the kernels eagerly instead of replaying a hipGraph */
 #define CRABML_HIP_LLAMA_NO_PREFETCH 2 /* do not warm the Infinity Cache from the latency-bound stages */
-#define CRABML_HIP_LLAMA_NO_NORM_EPILOGUE 4 /* A/B: keep RMSNorm + quantize as its own launch (fast mode runs it in
-                                              the wo / ffn_down epilogue; bit-identical either way) */
 #define CRABML_HIP_LLAMA_TP_GRAPH 8 /* tp_size > 1: capture the RCCL all-reduces into the hipGraph as well
                                        (default for tp: eager launches; falls back to eager if capture fails) */
-#define CRABML_HIP_LLAMA_NO_KQUANT_FUSION 256 /* A/B: Q4_K / Q4_1 layers through the per-op segment path */
-#define CRABML_HIP_LLAMA_Q4_1_SEGMENTS 512 /* A/B: Q4_1 layers as 11 launches (separate norm / quantize launches) */
-#define CRABML_HIP_LLAMA_FFN_FUSION 4096 /* experiment (slower, off by default): gate/up + ffn_down as one launch (k_ffn) */
-#define CRABML_HIP_LLAMA_NO_TILE_ATTENTION 2048 /* A/B: prefill attention as one workgroup per (head, row) */
-#define CRABML_HIP_LLAMA_NO_RHS_PROLOGUE 1024 /* A/B: Q4_K layers quantize the rhs of wo / ffn_down in its own launch */
-#define CRABML_HIP_LLAMA_TP_DRY_RUN 128 /* measurement hook: a lone tp rank (tp_comm = NULL) steps with its all-reduces
-                                          skipped -- per-rank kernel time of a tp group; the logits are meaningless */
-#define CRABML_HIP_LLAMA_NO_LONG_ATTENTION 64 /* A/B: one attention workgroup per head at every context length */
-#define CRABML_HIP_LLAMA_NO_Q8K_PRODUCERS 32768 /* A/B: Q4_K layers quantize the rhs of wo / ffn_down in those kernels' prologues instead
-                                                  of receiving finished Q8_K planes from attention / gate-up (bit-identical) */
-#define CRABML_HIP_LLAMA_Q8K_ATTN_PRODUCER 65536 /* A/B, opt-in: the staged attention kernel also assembles wo's Q8_K planes (pairs of heads
-                                                   exchange their outputs); measured slower than wo's own 4096-element prologue */
-#define CRABML_HIP_LLAMA_NO_PV_PRODUCER_WAVES 131072 /* A/B: long-context decode runs k_attn_pv (the chain wave multiplies and adds)
-                                                       instead of k_attn_pv_split (producer waves multiply); bit-identical */
-#define CRABML_HIP_LLAMA_NO_PREFILL_ROW_FUSION 262144 /* A/B: the prompt pass keeps residual-add / RMSNorm / quantize and SiLU * mul / quantize as
-                                                        separate launches (bit-identical) */
-#define CRABML_HIP_LLAMA_NO_PV_ROW_TILES 16384 /* A/B: long-prompt prefill runs the PV pass one prompt row per workgroup */
-#define CRABML_HIP_LLAMA_NO_STAGED_ATTENTION 8192 /* A/B: short-context attention without the LDS staging of K / V (k_attn) */
-#define CRABML_HIP_LLAMA_ENGINE 524288 /* Q4_0 layers, fast mode, one GPU: wo + RMSNorm + gate/up + SiLU*mul + ffn_down + RMSNorm of a
-                                          layer as ONE persistent launch fed by an LDS-DMA loader over a CU-major copy of the
-                                          weights (crabml_amd/csrc/engine.hpp); bit-identical to the 5-launch layer; ignored
-                                          (5 launches) when the shape does not fit */
+#define CRABML_HIP_LLAMA_EXACT_ATTENTION 4194304 /* fast mode, from attn_long_from cached positions: keep the reference's serial
+                                          f16-accumulated PV chain (buf_f16.rs:152-163) instead of the split-KV kernels that
+                                          accumulate the same f16 products in f32 (DESIGN.md 2.2 states the deviation and its
+                                          measured size).  Strict-order devices always run the exact chain. */
 #define CRABML_HIP_LLAMA_TP_SPLIT_VOCAB 1048576 /* tp_size > 1 (P2P group, or the single-device simulation): the classifier is split by
                                           vocabulary -- weights.output_weight holds rows [tp_rank V / tp_size,
                                           (tp_rank + 1) V / tp_size) of output.weight (V % tp_size == 0, not tied to token_embed);
@@ -248,12 +200,6 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                           inboxes (rank order; the later index wins a tie across shards as it does inside one).
                                           Logits copied out by forward(): this rank's shard at its global offsets, -inf elsewhere
                                           (an element-wise max over the ranks' buffers is the all-gather) */
-#define CRABML_HIP_LLAMA_QKV_TAIL 2097152 /* Q4_0 layers, fast mode, one GPU: the NEXT layer's q/k/v GEMV (+ RoPE + KV append) runs as the
-                                          tail of the ffn_down launch -- its weights are requested into registers before the norm hop, the
-                                          quantized residual crosses the workgroups as granules -- instead of its own launch: 4 launches
-                                          per layer, bit-identical to 5 */
-#define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
-#define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
   size_t embedding_dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size;
   size_t seq_len;  /* KV cache capacity (Llama2Runner::new seq_len, llama2.rs:46-86) */
@@ -328,29 +274,6 @@ int crabml_hip_tp_p2p_connect_local(crabml_hip_tp_comm_t* const* comms, int n);
 /* single-device simulation of a tp group (ranks created on ONE device with tp_comm = NULL): same kernels, same
  * sharding, the all-reduce replaced by a local sum -- validates everything but the RCCL transport itself */
 int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, size_t token, size_t pos, float* logits);
-
-/* parity hook: copies the layer's K or V cache (raw f16/f32 bytes, [n_kv_heads][seq_len][head_dim]) */
-int crabml_hip_llama_debug_kv(crabml_hip_llama_t* ctx, size_t layer, int32_t which_v, void* dst, size_t nbytes);
-
-/* ---- measurement hook (bench.py `roofline` object) -------------------------------------------------
- * While enabled, every matmul_vec GEMV kernel launch is bracketed by a pair of HIP events recorded on
- * the device's own stream (the stream the kernel runs on); crabml_hip_prof_read() drains them and
- * returns, per weight dtype, the number of launches, the summed kernel time and the summed ALGORITHMIC
- * bytes  m*(k/QK)*BLK + 4k + 4m  (SURVEY.md section 8d).  Costs one event pair per launch: use it in a
- * dedicated instrumented pass, not inside a throughput-timed region. */
-typedef struct crabml_hip_prof_entry {
-  uint32_t dtype;        /* weight GGML type of the GEMV */
-  uint32_t reserved;     /* stage: 0 = matmul_vec; fused step (eager mode only): 1 qkv, 2 wo+res, 3 gate/up, 4 down+res, 5 classifier */
-  uint64_t launches;
-  double kernel_ms;      /* sum over launches of (stop - start) */
-  double algo_bytes;     /* sum over launches of algorithmic bytes */
-} crabml_hip_prof_entry_t;
-int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on);
-/* blocks until the recorded events completed; fills up to cap entries, returns the count in *n */
-int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n);
-/* the same drain, one value per launch in record order (for medians / percentiles): fills up to cap durations in
- * milliseconds, returns the count in *n */
-int crabml_hip_prof_read_launches(crabml_hip_device_t* dev, float* ms, size_t cap, size_t* n);
 
 #ifdef __cplusplus
 }

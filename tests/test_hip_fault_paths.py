@@ -1,8 +1,8 @@
-"""Fault path of the single-GPU in-launch hand-offs (round-2 verdict, item 7): the norm-epilogue gathers of wo / ffn_down and
-the engine's edges rely on all of their workgroups being resident at once (checked against the device's CU count at create).
-When that is lost behind the library's back -- here: the process is confined to a fraction of the CUs with HSA_CU_MASK=0:0-15 (measured on MI355X / ROCm 7.2: the 8B-shape
-wo gather of 128 workgroups and the engine's 256 both lose workgroups under it; with 0:0-31 only the engine does) while the library is
-told to assume 256 (CRABML_HIP_ASSUME_CUS, a test hook) -- the polls are BOUNDED: the step must raise CrabmlError ("gather
+"""Fault path of the single-GPU in-launch hand-offs (round-2 verdict, item 7): the norm-epilogue gathers of wo / ffn_down
+rely on all of their workgroups being resident at once (checked against the device's CU count at create).
+When that is lost behind the library's back -- here: the process is confined to a fraction of the CUs with HSA_CU_MASK=0:0-15
+(measured on MI355X / ROCm 7.2: the 8B-shape wo gather of 128 workgroups loses workgroups under it) while the library is
+told to assume 256 (CRABML_HIP_ASSUME_CUS, a hook that only a CRABML_HIP_TEST_HOOKS=1 environment arms) -- the polls are BOUNDED: the step must raise CrabmlError ("gather
 timed out") within seconds, not hang, and the device must stay usable afterwards.  The P2P collective has the same test
 (tests/test_hip_tp_p2p.py::test_a_peer_that_never_arrives_raises_instead_of_hanging).
 
@@ -40,9 +40,9 @@ print("USABLE" if np.array_equal(y, 2 * x) else "BROKEN", flush=True)
 """ % ROOT
 
 
-@pytest.mark.parametrize("flags,name", [(0, "norm-epilogue gathers"), (524288, "engine edges")])
+@pytest.mark.parametrize("flags,name", [(0, "norm-epilogue gathers")])
 def test_lost_co_residency_raises_instead_of_hanging(flags, name):
-    env = dict(os.environ, HSA_CU_MASK="0:0-15", CRABML_HIP_ASSUME_CUS="256")
+    env = dict(os.environ, HSA_CU_MASK="0:0-15", CRABML_HIP_TEST_HOOKS="1", CRABML_HIP_ASSUME_CUS="256")
     p = subprocess.run([sys.executable, "-c", SCRIPT, str(flags)], env=env, capture_output=True, text=True, timeout=600)
     out = p.stdout
     assert p.returncode == 0, (out[-2000:], p.stderr[-2000:])

@@ -328,44 +328,6 @@ def test_q4_k_hand_offs_under_load_llama3_8b_shape(ca):
         assert np.array_equal(c.forward(int(ta[-1]), 300).view(np.uint32), la.view(np.uint32)), fl
 
 
-@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1"])
-def test_fused_ffn_launch_equals_the_two_kernels(ca, fmt):
-    """gate/up + SiLU*mul + quantize + ffn_down + residual + next RMSNorm/quantize as ONE launch (k_ffn: h travels
-    as {4 quants, epoch} / {d | aux, epoch} granules into every workgroup's LDS, ffn_down's first weights are requested
-    before the hand-off; opt-in flag 4096 = FFN_FUSION, an experiment that measured slower) against the two kernels
-    of the default path: bit-identical logits.  The tiny shape needs SPLIT_CHUNKS_ALWAYS (16) to take the
-    two-workgroups-per-chunk ffn_down that k_ffn builds on."""
-    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=64)
-    dev = ca.HipTensorDevice(0)
-    conf, w = synth.to_hip(model, dev)
-    one = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=16 + 4096)
-    two = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=16)
-    for i, t in enumerate(PROMPT + [5, 6, 7, 8, 9]):
-        a, b = one.forward(t, i), two.forward(t, i)
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {i}"
-    assert list(one.decode_greedy(3, 30)) == list(two.decode_greedy(3, 30))
-
-
-def test_fused_ffn_under_load_llama3_8b_shape(ca):
-    """The benchmark's row counts (448 hidden blocks over 256 workgroups: 192 own two blocks, 64 own one), 4 layers,
-    300 greedy tokens: token for token the run with two kernels."""
-    model = synth.build_model(synth.SHAPES["llama3-8b"], synth.Q4_0, seed=73, n_layers=4)
-    dev = ca.HipTensorDevice(0)
-    conf, w = synth.to_hip(model, dev)
-    a = ca.HipLlamaRunner(conf, w, dev, 320, True, extra_flags=4096)
-    b = ca.HipLlamaRunner(conf, w, dev, 320, True)
-    ta, tb = a.decode_greedy(1, 300), b.decode_greedy(1, 300)
-    assert list(ta) == list(tb)
-    la, lb = a.forward(int(ta[-1]), 300), b.forward(int(tb[-1]), 300)
-    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
-    # the Q8_K planes of ffn_down's rhs assembled by gate/up (default), by ffn_down itself (32768), and wo's by the
-    # attention kernel (65536): the same bits at 448 / 32 exchanging workgroups
-    for fl in (32768, 65536):
-        c = ca.HipLlamaRunner(conf, w, dev, 320, True, extra_flags=fl)
-        assert list(c.decode_greedy(1, 300)) == list(ta), fl
-        assert np.array_equal(c.forward(int(ta[-1]), 300).view(np.uint32), la.view(np.uint32)), fl
-
-
 def test_in_launch_hand_offs_under_load_llama3_8b_shape(ca):
     """Soak at the benchmark's own shape (Llama-3-8B rows, 8 layers, every CU streaming): 400 greedy tokens through
     the norm-epilogue kernels (granule gather over 128 / 256 workgroups) must equal, token for token, the run with

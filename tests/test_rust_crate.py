@@ -100,7 +100,7 @@ def parse_ffi():
 def test_ffi_declares_exactly_the_functions_of_the_header():
     hp, _ = parse_header()
     fp, _ = parse_ffi()
-    assert len(hp) >= 50
+    assert len(hp) >= 44  # the drop-in surface (the hooks of crabml_hip_debug.h are not bound by the crate)
     assert sorted(hp) == sorted(fp), (sorted(set(hp) - set(fp)), sorted(set(fp) - set(hp)))
     for name, (ret, args) in hp.items():
         fret, fargs = fp[name]
@@ -113,7 +113,7 @@ def test_ffi_declares_exactly_the_functions_of_the_header():
 def test_repr_c_structs_match_the_header():
     _, hs = parse_header()
     _, fs = parse_ffi()
-    for name in ("crabml_hip_device_options_t", "crabml_hip_llama_config_t", "crabml_hip_llama_weights_t", "crabml_hip_prof_entry_t"):
+    for name in ("crabml_hip_device_options_t", "crabml_hip_llama_config_t", "crabml_hip_llama_weights_t"):
         assert name in hs and name in fs, name
         assert [f[0] for f in hs[name]] == [f[0] for f in fs[name]], name
         for (hn, ht), (fn, ft) in zip(hs[name], fs[name]):
