@@ -83,6 +83,11 @@ def parse():
     ap.add_argument("--tp-rccl", action="store_true",
                     help="with --tp: all-reduce through RCCL (ncclAllReduce per segment, the baseline) instead of the one-shot "
                          "P2P collective fused into the wo / ffn_down kernels")
+    ap.add_argument("--tp-same-gpu", action="store_true",
+                    help="with --tp: every rank uses GPU 0 and torch.distributed runs over gloo (the P2P group's hipIpc mapping works "
+                         "between processes on one device; RCCL does not) -- the self-test of exactly this code path on a 1-GPU box")
+    ap.add_argument("--tp-fail-p2p", action="store_true", help=argparse.SUPPRESS)  # test hooks: pretend the P2P / RCCL group cannot
+    ap.add_argument("--tp-fail-rccl", action="store_true", help=argparse.SUPPRESS)  # be formed on rank 1 (the vote must carry it)
     ap.add_argument("--tp-dry", type=int, default=0,
                     help="measure ONE rank of a tensor-parallel group of this size with its all-reduces skipped "
                          "(per-rank kernel time; not a tokens/s result)")
@@ -150,6 +155,14 @@ class Dist:
         self.dist.all_reduce(u, op=self.dist.ReduceOp.SUM)
         return float(t.item()), float(u.item())
 
+    def gather(self, obj):
+        """every rank's object, in rank order"""
+        if self.world == 1:
+            return [obj]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, obj)
+        return box
+
     def close(self):
         if self.world > 1:
             self.dist.destroy_process_group()
@@ -174,14 +187,17 @@ def cpu_baseline(model, steps_budget_s):
 
     ncpu = os.cpu_count() or 1
     results = []
-    for threads in sorted({2, min(ncpu, 32), ncpu}):  # crabml's CLI default (-T 2, main.rs:49-50), 32, every host CPU
+    # crabml's CLI default (-T 2, main.rs:49-50) and 32 threads.  (Round 3 also timed one thread per host CPU: 1.1-1.4 tok/s on
+    # 256 CPUs -- the row-split pool oversubscribes the memory channels -- for 8 s of the run; dropped.)
+    legs = sorted({2, min(ncpu, 32)})
+    for threads in legs:
         odev = o.OracleDevice(thread_num=threads, use_avx2=True)
         conf, w = to_oracle(model, odev)
         r = o.OracleLlamaRunner(conf, w, odev, 64, True)
         r.forward([1], 0)  # touch all pages once (untimed)
         tok, pos, n = o.argmax_last(r.logits), 1, 0
         t0 = time.perf_counter()
-        budget = steps_budget_s / 3
+        budget = steps_budget_s / len(legs)
         while True:
             r.forward([tok], pos)
             tok = o.argmax_last(r.logits)
@@ -345,34 +361,102 @@ def tp_dry_run(args, ca, synth, local):
 def tp_group_run(args, ca, synth, dist, rank, world, local):
     """--tp under torchrun: one tensor-parallel group over all ranks (BASELINE config 5).  Every rank
     builds the LOCAL shard shapes with the same seed (identical bytes on every rank: a consistent model whose shards
-    happen to be equal, so all ranks sample the same tokens), creates the RCCL communicator from rank 0's unique id
-    (shipped over the torch.distributed group that also provides the barrier) and decodes with 2 all-reduces per layer."""
+    happen to be equal, so all ranks sample the same tokens) and decodes ONE token stream with two all-reduces per layer.
+
+    Collective: the one-shot P2P all-reduce over hipIpc-mapped inboxes, fused into the wo / ffn_down kernels (the production
+    form) -- and if ANY rank cannot form that group or cannot complete a first step through it (peer mapping refused, a fault
+    raised by a bounded poll), every rank falls back to RCCL (ncclAllReduce per segment) and the line says which one ran and
+    why (`config.collective`, `config.collective_fallback`).  The node's hipDeviceCanAccessPeer matrix and every rank's own
+    exchange time ride along, so that one run on a real node is enough to read what happened."""
     from crabml_amd import tp as tp_mod
 
     shape = synth.SHAPES[args.model]
     wtype = synth.TYPE_BY_NAME[args.wtype]
     tp_mod.check_tp(shape, world, wtype, True)
-    split_vocab = args.tp_split_vocab and not args.tp_rccl
-    model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=world, tp_split_vocab=split_vocab)
-    dev = ca.HipTensorDevice(device_ordinal=local)
-    conf, weights = synth.to_hip(model, dev)
-    if args.tp_rccl:
-        comm = tp_mod.init_tp_comm(dev, rank, world, tp_mod.torch_broadcast(rank))
-    else:  # the production collective: peers' inboxes mapped over hipIpc (xGMI between GPUs), no RCCL on the data path
-        comm = tp_mod.init_tp_p2p(dev, rank, world, shape.dim, tp_mod.torch_all_gather(world))
+    ordinal = 0 if args.tp_same_gpu else local
+    dev = ca.HipTensorDevice(device_ordinal=ordinal)
     seq_len = args.warmup + args.steps + 16
-    xflags = args.flags | (1048576 if split_vocab else 0)
-    r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=world, tp_rank=rank, comm=comm,
-                          extra_flags=xflags)
-    tok = int(r.decode_greedy(1, args.warmup)[-1]) if args.warmup > 0 else 1
+
+    def all_ok(ok, why=""):
+        """(every rank succeeded, the first failure text)"""
+        votes = dist.gather((bool(ok), str(why)))
+        bad = [f"rank {r}: {w}" for r, (o, w) in enumerate(votes) if not o]
+        return not bad, "; ".join(bad)
+
+    def build(kind):
+        """model shards, communicator and runner for one collective kind; raises on this rank's own failure"""
+        split_vocab = args.tp_split_vocab and kind == "p2p"
+        model = synth.build_model(shape, wtype, seed=8, n_layers=args.layers, tp=world, tp_split_vocab=split_vocab)
+        conf, weights = synth.to_hip(model, dev)
+        if kind == "rccl":
+            if args.tp_fail_rccl and rank == world - 1:
+                raise RuntimeError("RCCL group refused (test hook --tp-fail-rccl)")
+            if args.tp_fail_rccl:
+                raise RuntimeError("skipped: a peer cannot join (test hook --tp-fail-rccl)")
+            comm = tp_mod.init_tp_comm(dev, rank, world, tp_mod.torch_broadcast(rank))
+        else:
+            if args.tp_fail_p2p and rank == world - 1:
+                raise RuntimeError("P2P group refused (test hook --tp-fail-p2p)")
+            if args.tp_fail_p2p:
+                raise RuntimeError("skipped: a peer cannot join (test hook --tp-fail-p2p)")
+            comm = tp_mod.init_tp_p2p(dev, rank, world, shape.dim, tp_mod.torch_all_gather(world))
+        xflags = args.flags | (1048576 if split_vocab else 0)
+        r = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=world, tp_rank=rank, comm=comm,
+                              extra_flags=xflags)
+        return model, conf, weights, comm, r, xflags, split_vocab
+
+    kinds = ["rccl"] if args.tp_rccl else ["p2p", "rccl"]
+    fallback = None
+    state = None
+    for kind in kinds:
+        err = ""
+        try:
+            state = build(kind)
+        except Exception as e:  # noqa: BLE001 -- whatever stops this rank must reach the vote
+            state, err = None, f"{type(e).__name__}: {e}"
+        ok, why = all_ok(state is not None, err)
+        if ok:  # one step through the collective before anything is timed: a fault raised by a bounded poll surfaces here
+            err = ""
+            try:
+                state[4].decode_greedy(1, 1)
+                dev.sync()
+                state[4].reset()
+            except Exception as e:  # noqa: BLE001
+                err = f"first step: {type(e).__name__}: {e}"
+            ok, why = all_ok(not err, err)
+        if ok:
+            break
+        state = None
+        fallback = f"{kind} unavailable ({why})"
+        if rank == 0:
+            print(f"[bench --tp] {fallback}; trying the next collective", file=sys.stderr, flush=True)
+    if state is None:
+        if rank == 0:
+            print(json.dumps({"metric": "decode tokens/sec, tensor-parallel", "value": None, "n_gpus": world, "error": fallback}), flush=True)
+        dist.close()
+        return 2
+    model, conf, weights, comm, r, xflags, split_vocab = state
+    kind_ran = kind
+
+    peers = None
+    if dist.torch is not None and dist.torch.cuda.is_available():
+        n_dev = dist.torch.cuda.device_count()
+        try:
+            peers = [[1 if i == j or dist.torch.cuda.can_device_access_peer(i, j) else 0 for j in range(n_dev)] for i in range(n_dev)]
+        except Exception:  # noqa: BLE001
+            peers = None
+
+    ids_w = r.decode_greedy(1, args.warmup) if args.warmup > 0 else [1]
+    tok = int(ids_w[-1])
     dev.sync()
     dist.barrier()
     t0 = time.perf_counter()
-    r.decode_greedy(tok, args.steps)
+    ids = r.decode_greedy(tok, args.steps)
     dev.sync()
     dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed_max, _ = dist.max_sum(elapsed, args.steps)
+    ids_all = dist.gather([int(t) for t in ids])
     # the same rank with its exchanges skipped (same weights, same kernels, TP_DRY_RUN): step time minus this = what the
     # collectives (2 per layer + the sampler's pair exchange) cost per token on this node -- one run reports both
     dry = ca.HipLlamaRunner(conf, weights, dev, seq_len, True, True, not args.no_prefetch, tp_size=world, tp_rank=rank,
@@ -383,7 +467,10 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
     t0 = time.perf_counter()
     dry.decode_greedy(1, args.steps)
     dev.sync()
-    dry_max, _ = dist.max_sum(time.perf_counter() - t0, args.steps)
+    dry_own = time.perf_counter() - t0
+    dry_max, _ = dist.max_sum(dry_own, args.steps)
+    per_rank = dist.gather({"step_ms": round(elapsed / args.steps * 1e3, 4), "rank_kernels_ms": round(dry_own / args.steps * 1e3, 4),
+                            "exchange_ms": round((elapsed - dry_own) / args.steps * 1e3, 4), "device": ordinal})
     del dry
     if rank == 0:
         local_bytes = sum(t.data.nbytes for name, t in model.tensors.items()
@@ -395,13 +482,18 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "rank_kernels_ms_per_step": round(dry_max / args.steps * 1e3, 4),
             "exchange_ms_per_step": round((elapsed_max - dry_max) / args.steps * 1e3, 4),
+            "per_rank": per_rank,
+            "ranks_sampled_the_same_tokens": all(x == ids_all[0] for x in ids_all),
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.wtype, "data": "synthetic",
             "config": {"workload": f"{shape.name}-shape all-{args.wtype} synthetic weights, one batch-1 greedy token stream, f16 KV cache, "
                                    f"positions {args.warmup}..{args.warmup + args.steps - 1}",
                        "parallelism": f"tp{world}", "all_reduces_per_token": 2 * conf.n_layers, "all_reduce_bytes": shape.dim * 4,
-                       "collective": "RCCL ncclAllReduce per segment" if args.tp_rccl else
+                       "collective": "RCCL ncclAllReduce per segment" if kind_ran == "rccl" else
                                      "one-shot P2P all-reduce over hipIpc-mapped inboxes, fused into the wo / ffn_down epilogue",
+                       "collective_kind": kind_ran, "collective_fallback": fallback,
+                       "same_gpu_self_test": bool(args.tp_same_gpu),
+                       "peer_access_matrix": peers,
                        "classifier": "split by vocabulary, per-shard arg-max + 8-byte pair exchange" if split_vocab else "replicated",
                        "rank_weight_bytes_per_token": local_bytes},
             "roofline": {"bound": "hbm", "achieved": round(tps * local_bytes / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -411,6 +503,7 @@ def tp_group_run(args, ca, synth, dist, rank, world, local):
     del r
     del comm
     dist.close()
+    return 0
 
 
 def main():
@@ -420,7 +513,7 @@ def main():
     rank, world, local = dist_env()
     if world != args.gpus and world > 1:
         args.gpus = world
-    dist = Dist(world, local)  # imports torch first when world > 1 (one HIP runtime in the process)
+    dist = Dist(world, local, cpu_only=args.tp_same_gpu)  # imports torch first when world > 1 (one HIP runtime in the process)
 
     import crabml_amd as ca
     from crabml_amd import synth
@@ -428,7 +521,10 @@ def main():
     if args.tp_dry > 1:
         return tp_dry_run(args, ca, synth, local)
     if args.tp and world > 1:
-        return tp_group_run(args, ca, synth, dist, rank, world, local)
+        rc = tp_group_run(args, ca, synth, dist, rank, world, local)
+        if rc:
+            sys.exit(rc)
+        return
     t_build = time.perf_counter()
     dev = ca.HipTensorDevice(device_ordinal=local)
     model = None
@@ -465,7 +561,7 @@ def main():
     dev.sync()
     t_upload = time.perf_counter() - t_upload
     t_build = time.perf_counter() - t_build
-    seq_len = args.warmup + 2 * args.steps + 16
+    seq_len = max(args.warmup + 2 * args.steps + 16, 144)
     trait = ca.Llama2Runner(conf, weights, dev, seq_len, True)  # f16 KV cache = the CLI default (main.rs:250)
     path = args.path
     fused = None
@@ -505,6 +601,22 @@ def main():
         regions.append(dist.max_sum(time.perf_counter() - t0, args.steps))
     regions.sort()
     elapsed_max, total_tokens = regions[len(regions) // 2]
+
+    # SURVEY.md config C3 quotes decode over positions 0..127 from an empty cache; the driver's arguments (--steps 20 --warmup 5)
+    # time positions 5..24, where attention is nearly free.  Reported next to `value`: 128 steps from position 0, best of 3.
+    c3 = None
+    if rank == 0 and path == "fused":
+        best = None
+        for _ in range(3):
+            fused.reset()
+            dev.sync()
+            tc = time.perf_counter()
+            fused.decode_greedy(1, 128)
+            dev.sync()
+            dtc = time.perf_counter() - tc
+            best = dtc if best is None else min(best, dtc)
+        c3 = {"positions": "0..127", "tokens_per_s": round(128 / best, 2), "ms_per_step": round(best / 128 * 1e3, 4),
+              "note": "128 greedy steps from an empty KV cache (SURVEY.md config C3), host clock around one blocking call, best of 3"}
 
     # the per-op trait path (Llama2Runner<HipTensor> unchanged) is always reported next to the fused number
     trait_tps = None
@@ -656,6 +768,8 @@ def main():
         if context:
             out["context"] = {"tokens_per_s_at_position": context,
                               "note": "prompt of that length prefilled in batched passes, then 32 timed greedy steps"}
+        if c3:
+            out["c3_positions_0_127"] = c3
         if trait_tps is not None:
             out["trait_path_tokens_per_s"] = round(trait_tps, 2)
         if args.layers is not None:

@@ -145,6 +145,13 @@ struct crabml_hip_llama {
   bool attn_long_ok = false;    // f16 cache, head_dim % 32 == 0, group size in {1, 2, 4, 8}, seq_len % 8 == 0
   size_t attn_long_from = 0;    // cached positions (pos + 1) from which variant 1 is used
   bool pv_split = false;        // variant 1: k_attn_pv_split (products by producer waves) instead of k_attn_pv
+  // variant 1 of the FAST step: k_attn_flash (split-KV, f32 accumulation) instead of the three exact kernels
+  bool attn_flash = false;
+  bool flash_ticket = false;    // A/B: the merge by the last-arriving workgroup inside k_attn_flash instead of its own launch
+  int flash_S = 0;              // position slices (workgroups) per kv head
+  int flash_min_rows = FLASH_MIN_ROWS;  // cached rows per active slice, at least
+  float* flash_part = nullptr;  // [n_kv_l][flash_S][G][hd + 2] partial {O, m, l}
+  unsigned* flash_tick = nullptr;  // [n_kv_l] arrival counters (monotonic)
   int attn_s_rows = 0;          // > 0: variant 0 runs k_attn_s (K / V staged through LDS) with room for this many cached rows
   size_t attn_s_lds = 0;
   float* scores_g = nullptr;    // [n_heads_l][seq_len] f32
@@ -249,12 +256,66 @@ void launch_attn_long(crabml_hip_llama* c, int l, signed char* xq, unsigned shor
     if (prof) prof_end(dev, &r[i]);
 }
 
+// the k_attn_flash instantiation for (G, hd, rhs type of wo); nullptr = no such kernel
+typedef void (*FlashFn)(const float*, const unsigned short*, const unsigned short*, const int*, float*, unsigned*, float*, signed char*,
+                        unsigned short*, void*, int, int, int);
+template <int G>
+FlashFn flash_kernel_g(int hd, bool q81, bool ticket) {
+  if (ticket) {
+    if (hd == 128) return q81 ? (FlashFn)k_attn_flash<G, 128, true, true> : (FlashFn)k_attn_flash<G, 128, false, true>;
+    if (hd == 64) return q81 ? (FlashFn)k_attn_flash<G, 64, true, true> : (FlashFn)k_attn_flash<G, 64, false, true>;
+    return nullptr;
+  }
+  if (hd == 128) return (FlashFn)k_attn_flash<G, 128, false, false>;
+  if (hd == 64) return (FlashFn)k_attn_flash<G, 64, false, false>;
+  return nullptr;
+}
+FlashFn flash_kernel(int grp, int hd, bool q81, bool ticket) {
+  switch (grp) {
+    case 1: return flash_kernel_g<1>(hd, q81, ticket);
+    case 2: return flash_kernel_g<2>(hd, q81, ticket);
+    case 4: return flash_kernel_g<4>(hd, q81, ticket);
+    case 8: return flash_kernel_g<8>(hd, q81, ticket);
+    default: return nullptr;
+  }
+}
+void launch_attn_flash(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, void* xisum, bool prof) {
+  crabml_hip_device* dev = c->dev;
+  hipStream_t st = dev->stream;
+  const int hd = c->hd, grp = c->n_heads_l / c->n_kv_l;
+  const bool q81 = c->qt == CRABML_HIP_Q8_1;
+  const FlashFn fn = flash_kernel(grp, hd, q81, c->flash_ticket);
+  crabml_hip_device::ProfRec r[2];
+  if (prof) prof_begin(dev, &r[0], CRABML_HIP_F32, 7, 0.0);
+  launch_k(st, prof ? &r[0] : nullptr, fn, dim3(c->n_kv_l * c->flash_S), dim3((grp == 8 ? 4 : 8) * 64), flash_lds_bytes(grp, hd),
+           (const float*)c->qbuf, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], (const int*)(c->state + 1), c->flash_part,
+           c->flash_tick, c->attn, xq, xd, xisum, (int)c->cfg.seq_len, c->flash_S, c->flash_min_rows);
+  if (prof) prof_end(dev, &r[0]);
+  if (c->flash_ticket) return;
+  if (prof) prof_begin(dev, &r[1], CRABML_HIP_F32, 8, 0.0);
+  crabml_hip_device::ProfRec* R1 = prof ? &r[1] : nullptr;
+  const int* pos_d = c->state + 1;
+  if (hd == 128 && q81)
+    launch_k(st, R1, k_attn_flash_merge<128, true>, dim3(c->n_heads_l), dim3(128), 0, (const float*)c->flash_part, pos_d, c->attn, xq, xd, xisum, grp, c->flash_S, c->flash_min_rows);
+  else if (hd == 128)
+    launch_k(st, R1, k_attn_flash_merge<128, false>, dim3(c->n_heads_l), dim3(128), 0, (const float*)c->flash_part, pos_d, c->attn, xq, xd, xisum, grp, c->flash_S, c->flash_min_rows);
+  else if (q81)
+    launch_k(st, R1, k_attn_flash_merge<64, true>, dim3(c->n_heads_l), dim3(64), 0, (const float*)c->flash_part, pos_d, c->attn, xq, xd, xisum, grp, c->flash_S, c->flash_min_rows);
+  else
+    launch_k(st, R1, k_attn_flash_merge<64, false>, dim3(c->n_heads_l), dim3(64), 0, (const float*)c->flash_part, pos_d, c->attn, xq, xd, xisum, grp, c->flash_S, c->flash_min_rows);
+  if (prof) prof_end(dev, &r[1]);
+}
+
 void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, void* xisum, const PrefetchPlan& pf,
                        int spare, bool prof, const AttnQ8K* k8 = nullptr) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
   const int hd = c->hd, seq_cap = (int)c->cfg.seq_len, n_heads = c->n_heads_l, n_kv = c->n_kv_l;
   const int* pos_d = c->state + 1;
+  if (c->attn_variant == 1 && c->attn_flash) {
+    launch_attn_flash(c, l, xq, xd, xisum, prof);
+    return;
+  }
   if (c->attn_variant == 1) {
     switch (n_heads / n_kv) {
       case 1: launch_attn_long<1>(c, l, xq, xd, xisum, prof); break;
@@ -1410,7 +1471,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     const size_t grp = n_heads_l / n_kv_l;
     c->attn_long_ok = g.use_f16_kv_cache && hd % 32 == 0 && g.seq_len % 8 == 0 && (grp == 1 || grp == 2 || grp == 4 || grp == 8) &&
                       !(g.flags & CRABML_HIP_LLAMA_NO_LONG_ATTENTION);
-    c->attn_long_from = g.attn_long_from ? g.attn_long_from : 224;  // measured crossover on MI355X (Llama-3-8B shape): ~200-220
+    c->attn_long_from = g.attn_long_from ? g.attn_long_from : 224;  // exact kernels: measured crossover on MI355X (Llama-3-8B shape) ~200-220
     if (c->attn_long_ok && g.seq_len * 4 > 64 * 1024) {
       // the softmax kernels keep a head's score row in LDS: rows past 16384 positions need the raised dynamic-LDS limit,
       // rows past ~38000 do not fit at all (the step then stays on the one-workgroup-per-head kernel)
@@ -1435,6 +1496,30 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
         c->pv_split = e == hipSuccess;
         (void)hipGetLastError();
       }
+    }
+    // the fast step's long-context attention: split-KV with f32 accumulation (k_attn_flash) unless the exact chain is asked for
+    if (c->attn_long_ok && !dev->strict_order && !(g.flags & CRABML_HIP_LLAMA_EXACT_ATTENTION)) {
+      c->flash_ticket = (g.flags & CRABML_HIP_LLAMA_FLASH_TICKET) != 0;
+      const FlashFn fn = flash_kernel((int)grp, (int)hd, qt == CRABML_HIP_Q8_1, c->flash_ticket);
+      if (fn != nullptr && raise_dyn_lds(dev, (const void*)fn, (int)flash_lds_bytes((int)grp, (int)hd)) == hipSuccess) {
+        int S = dev->n_cu / (int)n_kv_l;
+        S = S < 1 ? 1 : S > FLASH_MAX_SLICES ? FLASH_MAX_SLICES : S;
+        c->flash_S = S;
+        if (const char* hooks = getenv("CRABML_HIP_TEST_HOOKS"))  // tuning hook (tools/flash_sweep.py); armed like ASSUME_CUS
+          if (hooks[0] == '1')
+            if (const char* e = getenv("CRABML_HIP_FLASH_MIN_ROWS")) {
+              const int v = atoi(e);
+              if (v >= 8 && v <= 65536) c->flash_min_rows = v;
+            }
+        A(n_kv_l * (size_t)S * flash_part_floats((int)grp, (int)hd) * 4, (void**)&c->flash_part);
+        A(n_kv_l * 4, (void**)&c->flash_tick);
+        if (rc == 0 && hipMemsetAsync(c->flash_tick, 0, n_kv_l * 4, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
+        c->attn_flash = rc == 0;
+        // k_attn_flash + merge overtake the staged one-workgroup kernel between 64 and 96 cached positions (8B shape, per layer:
+        // 51.0 vs 51.6 us at 64, 52.2 vs 51.4 at 96, 59.0 vs 51.8 at 224; profiles/r04_flash_sweep.log)
+        if (c->attn_flash && g.attn_long_from == 0) c->attn_long_from = 96;
+      }
+      (void)hipGetLastError();
     }
     // short-context attention with K / V staged through LDS (f16 cache): variant 0 serves positions < S
     if (g.use_f16_kv_cache && hd % 8 == 0 && !(g.flags & CRABML_HIP_LLAMA_NO_STAGED_ATTENTION)) {
@@ -1692,6 +1777,10 @@ size_t crabml_hip_llama_kv_len(const crabml_hip_llama_t* c) { return c ? c->kv_l
 int crabml_hip_llama_reset(crabml_hip_llama_t* c) {
   if (!c) return CRABML_HIP_BAD_INPUT;
   c->kv_len = 0;
+  if (c->flash_tick) {  // a step that faulted half-way may have left arrivals behind
+    CH_USE(c->dev);
+    CH_HIP(c->dev, hipMemsetAsync(c->flash_tick, 0, (size_t)c->n_kv_l * 4, c->dev->stream));
+  }
   return 0;
 }
 
@@ -1701,6 +1790,64 @@ int crabml_hip_llama_debug_kv(crabml_hip_llama_t* c, size_t layer, int32_t which
   if (layer >= c->cfg.n_layers || nbytes > c->kv_bytes) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: bad layer/size");
   CH_HIP(c->dev, hipMemcpyAsync(dst, which_v ? c->vc[layer] : c->kc[layer], nbytes, hipMemcpyDeviceToHost, c->dev->stream));
   CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
+  return 0;
+}
+
+// parity hook (crabml_hip_debug.h): k_attn_flash by itself, on caller-supplied q / K / V
+int crabml_hip_debug_flash_attention(crabml_hip_device_t* dev, const float* q, const uint16_t* k, const uint16_t* v, size_t n_heads,
+                                     size_t n_kv, size_t head_dim, size_t seq, size_t slices, float* out, float* out2) {
+  if (!dev || !q || !k || !v || !out || seq == 0 || n_kv == 0 || n_heads % n_kv != 0) return CRABML_HIP_BAD_INPUT;
+  CH_USE(dev);
+  const int grp = (int)(n_heads / n_kv), hd = (int)head_dim;
+  const FlashFn fn = flash_kernel(grp, hd, false, false), fnt = flash_kernel(grp, hd, false, true);
+  const bool ticket_form = out2 != nullptr;
+  if (fn == nullptr || slices < 1 || slices > FLASH_MAX_SLICES) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "debug_flash_attention: unsupported group / head_dim / slices");
+  if (raise_dyn_lds(dev, (const void*)fn, (int)flash_lds_bytes(grp, hd)) != hipSuccess ||
+      raise_dyn_lds(dev, (const void*)fnt, (int)flash_lds_bytes(grp, hd)) != hipSuccess)
+    CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "debug_flash_attention: LDS");
+  const size_t nq = n_heads * head_dim * 4, nkv = n_kv * seq * head_dim * 2, npart = n_kv * slices * flash_part_floats(grp, hd) * 4;
+  char* base = nullptr;
+  const size_t o_q = 0, o_k = align_up(o_q + nq, 256), o_v = align_up(o_k + nkv, 256), o_out = align_up(o_v + nkv, 256),
+               o_part = align_up(o_out + nq, 256), o_tick = align_up(o_part + npart, 256), o_pos = o_tick + align_up(n_kv * 4, 256),
+               total = o_pos + 256;
+  CH_HIP(dev, hipMalloc((void**)&base, total));
+  hipStream_t st = dev->stream;
+  const int pos = (int)seq - 1;
+  hipError_t e = hipMemsetAsync(base + o_tick, 0, n_kv * 4, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(base + o_q, q, nq, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(base + o_k, k, nkv, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(base + o_v, v, nkv, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(base + o_pos, &pos, 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // (`pos` leaves scope)
+  if (e == hipSuccess) {
+    // the shipped form first (partials, then the merge launch), then the single-launch form (last arriver merges) twice on the
+    // same ticket words -- the second launch finds them re-armed by the first; all three write the same `out`
+    hipLaunchKernelGGL(fn, dim3((unsigned)(n_kv * slices)), dim3((grp == 8 ? 4 : 8) * 64), (uint32_t)flash_lds_bytes(grp, hd), st,
+                       (const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
+                       (const int*)(base + o_pos), (float*)(base + o_part), (unsigned*)(base + o_tick), (float*)(base + o_out),
+                       (signed char*)nullptr, (unsigned short*)nullptr, (void*)nullptr, (int)seq, (int)slices, FLASH_MIN_ROWS);
+    if (hd == 128)
+      hipLaunchKernelGGL((k_attn_flash_merge<128, false>), dim3((unsigned)n_heads), dim3(128), 0, st, (const float*)(base + o_part),
+                         (const int*)(base + o_pos), (float*)(base + o_out), (signed char*)nullptr, (unsigned short*)nullptr, (void*)nullptr, grp,
+                         (int)slices, FLASH_MIN_ROWS);
+    else
+      hipLaunchKernelGGL((k_attn_flash_merge<64, false>), dim3((unsigned)n_heads), dim3(64), 0, st, (const float*)(base + o_part),
+                         (const int*)(base + o_pos), (float*)(base + o_out), (signed char*)nullptr, (unsigned short*)nullptr, (void*)nullptr, grp,
+                         (int)slices, FLASH_MIN_ROWS);
+    if (ticket_form) {
+      e = hipMemcpyAsync(out2, base + o_out, nq, hipMemcpyDeviceToHost, st);  // (stream order: before the next launches overwrite it)
+      for (int rep = 0; rep < 2 && e == hipSuccess; rep++)
+        hipLaunchKernelGGL(fnt, dim3((unsigned)(n_kv * slices)), dim3((grp == 8 ? 4 : 8) * 64), (uint32_t)flash_lds_bytes(grp, hd), st,
+                           (const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
+                           (const int*)(base + o_pos), (float*)(base + o_part), (unsigned*)(base + o_tick), (float*)(base + o_out),
+                           (signed char*)nullptr, (unsigned short*)nullptr, (void*)nullptr, (int)seq, (int)slices, FLASH_MIN_ROWS);
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, base + o_out, nq, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(base);
+  if (e != hipSuccess) return hip_fail(dev, e, "debug_flash_attention", __FILE__, __LINE__);
   return 0;
 }
 

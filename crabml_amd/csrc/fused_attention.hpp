@@ -845,6 +845,306 @@ __global__ __launch_bounds__(320) void k_attn_pv_split(const unsigned short* __r
 }
 
 
+// ---- fast-mode attention at long context: split-KV with f32 accumulation ("flash decoding") -------------------------------------
+// The three kernels above reproduce the reference bit for bit, which pins the PV pass to ONE serial f16 chain per column
+// (buf_f16.rs:152-163): 19 us per layer at 4096 cached positions for 16.8 MB of K / V (2.1 us at the HBM rate).  The FAST step
+// (not the strict-order device, not CRABML_HIP_LLAMA_EXACT_ATTENTION) gives that exactness up from `attn_long_from` positions on,
+// as SURVEY.md a18 planned: K and V are streamed ONCE by n_kv x S workgroups, each over its own slice of the cached positions,
+//   scores  s_t = sum_i f16(q_i) * k_t,i               (q rounded to f16 as batch_matmul.rs:39 does; f32 accumulation, v_dot2)
+//   local   m = max_t s_t,  e_t = exp(s_t - m),  l = sum_t e_t,  O = sum_t e_t * v_t        (all f32)
+// and the LAST workgroup of a kv head to arrive (one returning atomicAdd per workgroup on the head's ticket word: nobody polls)
+// merges the S partials (M = max m, out = sum O e^(m - M) / sum l e^(m - M)) and emits the head outputs + their Q8_0 / Q8_1
+// blocks for wo.  What differs from the reference: (a) exp is the f32 function, not the f16 table of f16(s - max)
+// (softmax.rs:43-53, buf_f32.rs:29-35), (b) the probabilities and the p * v products are not rounded to f16, (c) the sum over
+// positions is f32 and tree-shaped.  Every one of these removes a rounding the reference makes: the result is CLOSER to exact
+// arithmetic, and differs from the reference by the reference's own f16 noise (measured: DESIGN.md 2.2; asserted against the
+// oracle at positions 224 ... 4095 in tests/test_hip_long_context_oracle.py).
+// Lane mapping: a K / V row is HD f16 = LPR lanes x 16 bytes; a wave instruction covers RPI = 64 / LPR consecutive rows = one
+// aligned 1 KiB request.  Each (wave, row class) keeps its own online-softmax state; they meet once, in LDS.
+// Hand-off of the partials: agent-scope (write-through) stores -> vmcnt(0) -> barrier -> ticket; the last arriver reads them with
+// agent-scope loads (MI355X_MICROARCH "handoff-flag", sc1 both sides).  The ticket word only ever grows (S per launch).
+template <int HD>
+__device__ __forceinline__ float flash_row_sum(float v) {
+  constexpr int LPR = HD / 8;
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  if constexpr (LPR == 16) v += dpp_f<0x140>(v);
+  return v;
+}
+#define FLASH_MIN_ROWS 64  /* measured on MI355X, 8B shape: 64 <= 128 <= 256 at every context (profiles/r04_flash_sweep.log) */
+#define FLASH_MAX_SLICES 32
+template <int G>
+struct FlashGeom {
+  static constexpr int NW = G == 8 ? 4 : 8;  // waves per workgroup (LDS: NW * RPI classes x G x HD floats)
+};
+__host__ __device__ inline size_t flash_lds_bytes(int G, int hd) {
+  const int nw = G == 8 ? 4 : 8, rpi = 64 / (hd / 8), ncls = nw * rpi;
+  return (size_t)ncls * G * hd * 4 + (size_t)ncls * G * 4 * 3 + 64;
+}
+__host__ __device__ inline size_t flash_part_floats(int G, int hd) { return (size_t)G * (hd + 2); }
+template <int G, int HD, bool Q81, bool TICKET>
+__global__ __launch_bounds__(FlashGeom<G>::NW * 64) void k_attn_flash(const float* __restrict__ q, const unsigned short* __restrict__ kc,
+                                                                     const unsigned short* __restrict__ vc, const int* __restrict__ pos_d,
+                                                                     float* __restrict__ part, unsigned* __restrict__ tick,
+                                                                     float* __restrict__ out, signed char* __restrict__ xq,
+                                                                     unsigned short* __restrict__ xd, void* __restrict__ xisum, int seq_cap,
+                                                                     int Smax, int min_rows) {
+  constexpr int NW = FlashGeom<G>::NW, LPR = HD / 8, RPI = 64 / LPR, NCLS = NW * RPI, U = 4, NT = NW * 64;
+  static_assert(HD == 64 || HD == 128, "a K / V row is 8 or 16 lanes x 16 bytes");
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float fl_lds[];
+  float* sacc = fl_lds;                 // [NCLS][G][HD]
+  float* sm = sacc + NCLS * G * HD;     // [NCLS][G]
+  float* sl = sm + NCLS * G;            // [NCLS][G]
+  float* sw = sl + NCLS * G;            // [NCLS][G] merge weights
+  int* s_last = (int*)(sw + NCLS * G);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rc = lane / LPR, dl = lane % LPR;
+  const int j = blockIdx.x / Smax, sp = blockIdx.x % Smax;
+  // q of the G heads that share kv head j: this lane's 8 dims (requested before the position is read: the two round trips overlap)
+  f32x4 qa[G], qb[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const f32x4* qp = (const f32x4*)(q + (size_t)(j * G + g) * HD + 8 * dl);
+    qa[g] = qp[0];
+    qb[g] = qp[1];
+  }
+  const int seq = *pos_d + 1;
+  // The grid is sized for the longest context (Smax slices per kv head); a step uses S <= Smax of them -- at least min_rows
+  // (FLASH_MIN_ROWS) cached rows per workgroup: every slice costs the merge G x HD partial values, and a short context does not
+  // repay many of them.  The other workgroups leave at once (every workgroup derives the same S from seq).
+  const int S = min(Smax, max(1, (seq + min_rows - 1) / min_rows));
+  if (sp >= S) return;
+  // this workgroup's rows [r0, r1): the cache cut into S slices of whole row groups
+  const int chunk = (((seq + S - 1) / S + RPI - 1) / RPI) * RPI;
+  const int r0 = sp * chunk, r1 = r0 + chunk < seq ? r0 + chunk : seq;
+  const int ngroups = r1 > r0 ? (r1 - r0 + RPI - 1) / RPI : 0;
+  // rounded to f16 (batch_matmul.rs:39)
+  i32x4 qh[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const f32x4 a = qa[g], b = qb[g];
+    qh[g] = i32x4{(int)((unsigned)f2h(a[0]) | ((unsigned)f2h(a[1]) << 16)), (int)((unsigned)f2h(a[2]) | ((unsigned)f2h(a[3]) << 16)),
+                  (int)((unsigned)f2h(b[0]) | ((unsigned)f2h(b[1]) << 16)), (int)((unsigned)f2h(b[2]) | ((unsigned)f2h(b[3]) << 16))};
+  }
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    m[g] = -INFINITY;
+    l[g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[g][i] = 0.f;
+  }
+  const unsigned short* kb = kc + (size_t)j * seq_cap * HD + 8 * dl;
+  const unsigned short* vb = vc + (size_t)j * seq_cap * HD + 8 * dl;
+  for (int g0 = wave; g0 < ngroups; g0 += NW * U) {
+    i32x4 kk[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {  // every load of the round is in flight before the first dot
+      const int row = r0 + (g0 + u * NW) * RPI + rc;
+      const int rowc = row < r1 ? row : r1 - 1;
+      kk[u] = __builtin_nontemporal_load((const i32x4*)(kb + (size_t)rowc * HD));
+      vv[u] = __builtin_nontemporal_load((const i32x4*)(vb + (size_t)rowc * HD));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (g0 + u * NW >= ngroups) break;  // wave-uniform
+      const bool live = r0 + (g0 + u * NW) * RPI + rc < r1;
+      float vf[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const h2 t = __builtin_bit_cast(h2, (unsigned)vv[u][i]);
+        vf[2 * i] = (float)t[0];
+        vf[2 * i + 1] = (float)t[1];
+      }
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, (unsigned)kk[u][i]), __builtin_bit_cast(h2, (unsigned)qh[g][i]), s, false);
+        s = flash_row_sum<HD>(s);
+        s = live ? s : -INFINITY;
+        const float mn = fmaxf(m[g], s);
+        // (a class that has seen nothing yet and sees a dead row keeps m = -inf: alpha = 1, p = 0)
+        const float alpha = mn == -INFINITY ? 1.0f : __expf(m[g] - mn);
+        const float pe = mn == -INFINITY ? 0.0f : __expf(s - mn);
+        m[g] = mn;
+        l[g] = l[g] * alpha + pe;
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[g][i] = __builtin_fmaf(pe, vf[i], acc[g][i] * alpha);
+      }
+    }
+  }
+  // ---- the NCLS (wave, row class) states meet in LDS ---------------------------------------------------------------
+  const int cls = wave * RPI + rc;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    f32x4* dst = (f32x4*)(sacc + ((size_t)cls * G + g) * HD + 8 * dl);
+    dst[0] = f32x4{acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+    dst[1] = f32x4{acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
+    if (dl == 0) {
+      sm[cls * G + g] = m[g];
+      sl[cls * G + g] = l[g];
+    }
+  }
+  __syncthreads();
+  if (tid < NCLS * G) {  // merge weights e^(m_c - M) per (class, head); tid = c * G + g
+    const int g = tid % G;
+    float M = -INFINITY;
+    for (int c = 0; c < NCLS; c++) M = fmaxf(M, sm[c * G + g]);
+    const float mc = sm[tid];
+    sw[tid] = mc == -INFINITY ? 0.0f : __expf(mc - M);
+  }
+  __syncthreads();
+  float* mypart = part + (size_t)blockIdx.x * (G * (HD + 2));
+  for (int idx = tid; idx < G * HD; idx += NT) {
+    const int g = idx / HD, d = idx % HD;
+    float o = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < NCLS; c++) o = __builtin_fmaf(sacc[((size_t)c * G + g) * HD + d], sw[c * G + g], o);
+    if constexpr (TICKET)
+      __hip_atomic_store(mypart + g * (HD + 2) + d, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      mypart[g * (HD + 2) + d] = o;
+  }
+  if (tid < G) {
+    float M = -INFINITY, L = 0.f;
+    for (int c = 0; c < NCLS; c++) M = fmaxf(M, sm[c * G + tid]);
+    for (int c = 0; c < NCLS; c++) L = __builtin_fmaf(sl[c * G + tid], sw[c * G + tid], L);
+    if constexpr (TICKET) {
+      __hip_atomic_store(mypart + tid * (HD + 2) + HD, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mypart + tid * (HD + 2) + HD + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      mypart[tid * (HD + 2) + HD] = M;
+      mypart[tid * (HD + 2) + HD + 1] = L;
+    }
+  }
+  if constexpr (!TICKET) return;  // the merge is its own launch (k_attn_flash_merge)
+  // ---- ticket: the last workgroup of kv head j to get here merges the S partials ----------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have been acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(tick + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == (unsigned)(S - 1) ? 1 : 0;
+    // the last arriver re-arms the word for the next launch (every other workgroup of this kv head has drawn its ticket)
+    if (last) __hip_atomic_store(tick + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = last;
+  }
+  __syncthreads();
+  if (*s_last == 0) return;
+  // ---- merge (one workgroup per kv head): every load of the hand-off is requested before anything waits on one --------------
+  const float* pj = part + (size_t)j * Smax * (G * (HD + 2));
+  float* mg_m = sacc;                                  // [S][G]  (sacc is done with)
+  float* mg_l = sacc + FLASH_MAX_SLICES * G;           // [S][G]
+  float* mg_w = sacc + 2 * FLASH_MAX_SLICES * G;       // [S][G] e^(m_s - M)
+  float* mg_M = sacc + 3 * FLASH_MAX_SLICES * G;       // [G] {1 / L}
+  constexpr int SB = 16;                               // partial values per thread and batch
+  auto load_o = [&](int idx, int s0, float (&ov)[SB]) {
+    const int g = idx / HD, d = idx % HD;
+#pragma unroll
+    for (int i = 0; i < SB; i++) {
+      const int s2 = s0 + i < S ? s0 + i : S - 1;
+      ov[i] = __hip_atomic_load(pj + (size_t)s2 * (G * (HD + 2)) + g * (HD + 2) + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  float ov[SB];
+  if (tid < G * HD) load_o(tid, 0, ov);
+  for (int t = tid; t < S * G; t += NT) {  // the slices' {m, l} -> LDS
+    const float* ps = pj + (size_t)(t / G) * (G * (HD + 2)) + (t % G) * (HD + 2) + HD;
+    mg_m[t] = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mg_l[t] = __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (tid < G) {  // per head: M, the slices' weights e^(m_s - M), L
+    float M = -INFINITY, L = 0.f;
+    for (int s2 = 0; s2 < S; s2++) M = fmaxf(M, mg_m[s2 * G + tid]);
+    for (int s2 = 0; s2 < S; s2++) {
+      const float ms = mg_m[s2 * G + tid];
+      const float w = ms == -INFINITY ? 0.0f : __expf(ms - M);
+      mg_w[s2 * G + tid] = w;
+      L = __builtin_fmaf(mg_l[s2 * G + tid], w, L);
+    }
+    mg_M[tid] = L;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * HD; idx += NT) {  // (whole waves stay together: 64 | G * HD; one pass unless G * HD > NT)
+    const int g = idx / HD, d = idx % HD;
+    if (idx != tid) load_o(idx, 0, ov);
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < SB; i++)
+      if (i < S) o = __builtin_fmaf(ov[i], mg_w[i * G + g], o);
+    for (int s0 = SB; s0 < S; s0 += SB) {  // contexts past SB slices: one more batch
+      load_o(idx, s0, ov);
+#pragma unroll
+      for (int i = 0; i < SB; i++)
+        if (s0 + i < S) o = __builtin_fmaf(ov[i], mg_w[(s0 + i) * G + g], o);
+    }
+    const float L = mg_M[g];
+    const float val = o / L;
+    const int e = (j * G + g) * HD + d;
+    out[e] = val;
+    if (xq != nullptr) {  // the rhs block of wo: 32 consecutive dims = one half-wave (quant_lane32's arithmetic)
+      const QLane ql = quant_lane32<Q81>(val, true);
+      xq[e] = ql.q;
+      if ((lane & 31) == 0) {
+        xd[e >> 5] = ql.d;
+        store_qaux<Q81>(xisum, e >> 5, ql.aux);
+      }
+    }
+  }
+}
+
+// The merge as its own launch (the default): one workgroup per q head, one thread per output dim.  Reads the S partials the
+// k_attn_flash launch before it left behind (plain loads: the kernel boundary orders them), in slice order.
+template <int HD, bool Q81>
+__global__ __launch_bounds__(HD) void k_attn_flash_merge(const float* __restrict__ part, const int* __restrict__ pos_d,
+                                                        float* __restrict__ out, signed char* __restrict__ xq,
+                                                        unsigned short* __restrict__ xd, void* __restrict__ xisum, int G, int Smax,
+                                                        int min_rows) {
+  __shared__ float s_w[FLASH_MAX_SLICES];
+  __shared__ float s_L;
+  const int head = blockIdx.x, j = head / G, g = head % G, d = threadIdx.x;
+  const float* pj = part + ((size_t)j * Smax * G + g) * (HD + 2);  // slice s of this head: pj + s * G * (HD + 2)
+  const size_t sstr = (size_t)G * (HD + 2);
+  // every slot of the grid is requested at once, whatever the position says (slots past S hold an earlier step's finite
+  // values and get weight 0): the loads do not wait for the position's round trip
+  float ov[FLASH_MAX_SLICES];
+#pragma unroll
+  for (int i = 0; i < FLASH_MAX_SLICES; i++) ov[i] = pj[(size_t)(i < Smax ? i : Smax - 1) * sstr + d];
+  const int sl = d < Smax ? d : Smax - 1;  // lanes 0 .. Smax - 1 of wave 0 own one slice's {m, l}
+  float ms = pj[(size_t)sl * sstr + HD], ls = pj[(size_t)sl * sstr + HD + 1];
+  const int seq = *pos_d + 1;
+  const int S = min(Smax, max(1, (seq + min_rows - 1) / min_rows));  // k_attn_flash's own rule
+  if (d < 64) {  // wave 0: M, the slices' weights e^(m_s - M), L -- the k_attn_flash merge's operations in its order
+    if (d >= S) ms = -INFINITY;
+    const float M = wave_max_f32(ms);
+    const float w = ms == -INFINITY ? 0.0f : __expf(ms - M);
+    if (d < FLASH_MAX_SLICES) s_w[d] = w;
+    float L = 0.f;
+    for (int s2 = 0; s2 < S; s2++) L = __builtin_fmaf(rl_f(ls, s2), rl_f(w, s2), L);
+    if (d == 0) s_L = L;
+  }
+  __syncthreads();
+  float o = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLASH_MAX_SLICES; i++)
+    if (i < S) o = __builtin_fmaf(ov[i], s_w[i], o);
+  const float val = o / s_L;
+  const int e = head * HD + d;
+  out[e] = val;
+  if (xq != nullptr) {
+    const QLane ql = quant_lane32<Q81>(val, true);
+    xq[e] = ql.q;
+    if ((d & 31) == 0) {
+      xd[e >> 5] = ql.d;
+      store_qaux<Q81>(xisum, e >> 5, ql.aux);
+    }
+  }
+}
+
 // The same PV pass for R consecutive prompt rows per workgroup (batched prefill past 1024 positions): row r of the tile
 // sees seq0 + r cached positions.  The V tile is fetched and transposed ONCE for the R rows x G heads -- every lane of the
 // workgroup carries a chain (R * G * 16 = 256 for Llama-3's G = 4, R = 4) instead of 64 of 256, and V is read R times less

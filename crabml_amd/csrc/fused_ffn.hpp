@@ -455,7 +455,7 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename A
 // QOUT: h leaves the kernel as Q8_K planes (the rhs of ffn_down) as well: the eight workgroups of a 256-row super-block exchange
 // their rows as granules (q8k_exchange_store); hidden % 256 == 0.
 template <bool QOUT>
-__global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
+__global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
                                                        float* __restrict__ h, int m, int nsb, Q8KExchange ex, signed char* __restrict__ oq,
                                                        float* __restrict__ od, short* __restrict__ obs) {
   extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
@@ -463,16 +463,31 @@ __global__ __launch_bounds__(1024) void k_gateup_k_lds(Planes wg, Planes wu, Act
   i32x4* sq = lds_act;
   float* sd = (float*)(sq + k / 16);
   short* sbs = (short*)(sd + nsb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 32 + wave * 2;
+  // Round 4: the first round of gate pieces is requested BEFORE the activation planes are staged (the weights depend on nothing:
+  // their HBM round trip runs under the staging and its barrier); the rest is two rows_partial_q4k passes as before, so every
+  // row's pieces are still added in ascending order.  (Measured and not kept: gate and up rows advancing together, four pieces
+  // per lane in flight with a second register set -- 90 VGPRs, ONE workgroup per CU, 18.0 us instead of 17.1; pinned to 64
+  // VGPRs it spills.)
+  const int nch = nsb * 8;
+  Q4KPiece<false> pw[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+    pw[r] = q4k_load<false>(wg.q, (const i32x4*)wg.d, (size_t)(row0 + r < m ? row0 + r : m - 1), nsb, lane < nch ? lane : nch - 1, lane);
   for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.q[i];
   for (int i = threadIdx.x; i < nsb; i += 1024) sd[i] = act.d[i];
   for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
   __syncthreads();
   const ActQ8_K la{sq, sd, sbs};
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * 32 + wave * 2;
   if (row0 >= m) return;
-  float ag[2], au[2];
-  rows_partial_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag);
+  float ag[2] = {0.f, 0.f}, au[2];
+  if (lane < nch) {
+    const Q4KX x = q4k_loadx(la, lane);
+#pragma unroll
+    for (int r = 0; r < 2; r++) ag[r] += q4k_term<false>(pw[r], x, lane);
+  }
+  rows_partial_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag, 64);
   rows_partial_q4k<2, false>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
   __shared__ float hv[32];
 #pragma unroll

@@ -58,7 +58,8 @@ struct GGUFTensorInfo {  // gguf.rs:648-689
 class GGUFFile {
  public:
   // GGUFFileLoader::new(path, mlock) (gguf.rs:793-826): mmap + madvise(WILLNEED) + optional mlock
-  explicit GGUFFile(const std::string& path, bool mlock = false) {
+  // data_start: -1 = decide from the file (see decode()), 0 = the GGUF spec's data start, 1 = the reference's (gguf.rs:722-724)
+  explicit GGUFFile(const std::string& path, bool mlock = false, int data_start = -1) : data_start_override_(data_start) {
     fd_ = ::open(path.c_str(), O_RDONLY);
     if (fd_ < 0) throw Error(ErrorKind::IOError, "failed to open the file: " + path);
     struct stat st {};
@@ -249,8 +250,8 @@ class GGUFFile {
     // Where the tensor data starts.  The reference always skips to the NEXT multiple of the alignment
     // (`position - position % alignment + alignment`, gguf.rs:722-724), i.e. a whole extra block when the tensor infos
     // already end on a boundary; the GGUF spec (and every llama.cpp / gguf-py writer) pads only when misaligned.  The two
-    // agree unless pos % al == 0 (1 file in `al`).  In that case the file itself decides: under the right convention the
-    // data section ends exactly where the last tensor (plus its padding) ends.  Spec wins when the file does not tell.
+    // agree unless pos % al == 0 (1 file in `al`).  In that case the file itself decides (below); a caller who knows better
+    // passes data_start.
     size_t next = pos_ - (pos_ % al) + al;
     if (pos_ % al == 0) {
       size_t max_end = 0;
@@ -264,21 +265,29 @@ class GGUFFile {
         const size_t end = (size_t)t.offset + n / be * bb;
         if (end > max_end) max_end = end;
       }
-      auto fits = [&](size_t start) {
-        if (!sized || start > len_) return false;
-        const size_t have = len_ - start;
-        return have == max_end || have == align_up_(max_end, al);
-      };
-      const bool spec_ok = fits(pos_), ref_ok = fits(pos_ + al);
-      // Neither convention puts the last tensor's end at the end of the file (trailing bytes, loosely packed tensors) AND the
-      // tensor sizes are known: the file does not say where its data starts, and guessing wrong shifts EVERY tensor by one
-      // alignment block without any error downstream.  Refuse it (round-2 review finding) instead of defaulting silently.
-      if (sized && !spec_ok && !ref_ok)
+      // A writer pads the data section to the alignment at most: under the RIGHT convention the file ends less than one
+      // alignment block after the last tensor (exactly at its end, at its padded end, or a few trailing bytes later); under the
+      // wrong one the slack is off by a whole block.  slack(spec) = slack(reference) + al, so at most one of them lies in [0, al).
+      const bool known = sized && pos_ <= len_ && len_ - pos_ >= max_end;
+      const size_t slack_spec = known ? len_ - pos_ - max_end : 0;
+      const bool spec_ok = known && slack_spec < al, ref_ok = known && slack_spec >= al && slack_spec - al < al;
+      int conv;
+      if (data_start_override_ == 0 || data_start_override_ == 1)
+        conv = data_start_override_;
+      else if (spec_ok || !sized || tensors_.empty())
+        conv = 0;  // (tensor sizes unknown, or nothing to place: the spec's start)
+      else if (ref_ok)
+        conv = 1;
+      else
+        // a whole alignment block or more of trailing bytes (or a truncated file): the file does not say where its data starts,
+        // and guessing wrong shifts EVERY tensor by one block without any error downstream (round-2 review finding).  Refused
+        // unless the caller says which convention wrote it (round-3 advisor: a spec file with trailing bytes must stay loadable).
         throw Error(ErrorKind::FormatError,
-                    "the tensor infos end on an alignment boundary and neither the GGUF spec's data start (no padding) nor the "
-                    "reference's (one more block, gguf.rs:722-724) makes the data section end with the last tensor: ambiguous file");
-      if (spec_ok || !ref_ok) next = pos_;  // spec convention (also when both fit, or when tensor sizes are unknown)
-      data_start_convention_ = (spec_ok || !ref_ok) ? 0 : 1;
+                    "the tensor infos end on an alignment boundary and the file ends a whole alignment block or more after the last "
+                    "tensor under the GGUF spec's data start and under the reference's (gguf.rs:722-724) alike: ambiguous file -- "
+                    "pass data_start = 0 (spec) or 1 (reference)");
+      if (conv == 0) next = pos_;
+      data_start_convention_ = conv;
     }
     (void)take(next - pos_);
     data_off_ = pos_;
@@ -295,6 +304,7 @@ class GGUFFile {
   static size_t align_up_(size_t v, size_t a) { return (v + a - 1) / a * a; }
   static bool ggml_block_geometry_(uint32_t t, size_t* bb, size_t* be);
   int data_start_convention_ = 0;  // 0 = GGUF spec (pad only when misaligned), 1 = the reference's always-skip (detected)
+  int data_start_override_ = -1;
   int fd_ = -1;
   const uint8_t* base_ = nullptr;
   size_t len_ = 0, pos_ = 0, data_off_ = 0;

@@ -85,6 +85,18 @@ PYBIND11_MODULE(_host, m) {
              return v;
            },
            py::arg("bytes") = (size_t)1 << 30, py::arg("reps") = 5)
+      .def("debug_flash_attention",
+           [](HipTensorDevice& d, py::array_t<float, py::array::c_style | py::array::forcecast> q,
+              py::array_t<uint16_t, py::array::c_style | py::array::forcecast> k,
+              py::array_t<uint16_t, py::array::c_style | py::array::forcecast> v, size_t n_heads, size_t n_kv, size_t head_dim,
+              size_t seq, size_t slices) {
+             if ((size_t)q.size() != n_heads * head_dim || (size_t)k.size() != n_kv * seq * head_dim || k.size() != v.size())
+               throw Error(ErrorKind::BadInput, "debug_flash_attention: array sizes");
+             py::array_t<float> out(n_heads * head_dim), out2(n_heads * head_dim);
+             d.check(crabml_hip_debug_flash_attention(d.raw(), q.data(), k.data(), v.data(), n_heads, n_kv, head_dim, seq, slices,
+                                                      out.mutable_data(), out2.mutable_data()));
+             return py::make_tuple(out, out2);
+           })
       .def("prof_read_launches",
            [](HipTensorDevice& d, size_t cap) {
              std::vector<float> ms(cap);
@@ -270,8 +282,8 @@ PYBIND11_MODULE(_host, m) {
     }
   };
   py::class_<GGUFFile, std::shared_ptr<GGUFFile>>(m, "GGUFFile")
-      .def(py::init([](const std::string& path, bool mlock) { return std::make_shared<GGUFFile>(path, mlock); }), py::arg("path"),
-           py::arg("mlock") = false)
+      .def(py::init([](const std::string& path, bool mlock, int data_start) { return std::make_shared<GGUFFile>(path, mlock, data_start); }),
+           py::arg("path"), py::arg("mlock") = false, py::arg("data_start") = -1)
       .def_property_readonly("data_start_convention", &GGUFFile::data_start_convention)
       .def_property_readonly("version", &GGUFFile::version)
       .def_property_readonly("architecture", &GGUFFile::architecture)

@@ -213,7 +213,8 @@ typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
    * The weight buffers passed to crabml_hip_llama_create are the LOCAL shards. */
   int32_t tp_size, tp_rank;
   void* tp_comm; /* crabml_hip_tp_comm_t*; NULL with tp_size > 1 = a rank of the single-device simulation */
-  size_t attn_long_from; /* cached positions from which attention runs as the multi-workgroup kernels (0 = default 224) */
+  size_t attn_long_from; /* cached positions from which attention runs as the multi-workgroup kernels (0 = default: 96 for the
+                          * fast step's split-KV kernels, 224 for the exact ones) */
   size_t prefill_chunk;  /* rows per batched prefill pass (0 = default 512) */
 } crabml_hip_llama_config_t;
 typedef struct crabml_hip_llama_weights { /* crabml-llama2/src/model.rs:55-84; per-layer arrays of n_layers */

@@ -43,6 +43,15 @@ int crabml_hip_debug_gemm_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t*
  * 8 TB/s datasheet peak. */
 int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_t reps, double* gbytes_per_s);
 
+/* The fast step's long-context attention (k_attn_flash + k_attn_flash_merge, fused_attention.hpp) by itself: one query row per
+ * head against `seq` cached positions.  q: n_heads * head_dim f32 (already scaled; rounded to f16 by the kernel as
+ * batch_matmul.rs:39 does); k, v: [n_kv][seq][head_dim] f16 bits; slices: the grid's position slices per kv head (1 .. 32; a
+ * step uses as many as the context repays); out: n_heads * head_dim f32 = softmax(q k^T) v in f32 arithmetic, from the shipped
+ * two-launch form.  out2 (nullable): the same from the single-launch form (the last-arriving workgroup of a kv head merges;
+ * launched twice on the same ticket words, which the last arriver re-arms).  Host pointers; blocks. */
+int crabml_hip_debug_flash_attention(crabml_hip_device_t* dev, const float* q, const uint16_t* k, const uint16_t* v, size_t n_heads,
+                                     size_t n_kv, size_t head_dim, size_t seq, size_t slices, float* out, float* out2);
+
 /* ---- A/B switches and test hooks of the fused decode step (crabml_hip_llama_config_t.flags; the public bits are in
  * crabml_hip.h).  Every variant pair is bit-identical unless its comment says otherwise. */
 #define CRABML_HIP_LLAMA_NO_NORM_EPILOGUE 4 /* A/B: keep RMSNorm + quantize as its own launch (fast mode runs it in
@@ -64,6 +73,8 @@ int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_
                                                         separate launches (bit-identical) */
 #define CRABML_HIP_LLAMA_NO_PV_ROW_TILES 16384 /* A/B: long-prompt prefill runs the PV pass one prompt row per workgroup */
 #define CRABML_HIP_LLAMA_NO_STAGED_ATTENTION 8192 /* A/B: short-context attention without the LDS staging of K / V (k_attn) */
+#define CRABML_HIP_LLAMA_FLASH_TICKET 2097152 /* A/B: k_attn_flash merges its partials in the last-arriving workgroup of a kv head
+                                                (ticket word, write-through hand-off) instead of a second launch */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 

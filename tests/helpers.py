@@ -55,8 +55,19 @@ GEMV_REL = 2e-5  # f32 re-association bound factor: |gpu - oracle| <= GEMV_REL *
 # Observed on MI355X (round 2, tests/golden/fast_path_errors_observed.json), worst (median, max) over all test models:
 #   Q4_0 3.0e-3 / 7.5e-3   Q8_0 2.7e-2 / 3.7e-2   Q4_1 4.1e-4 / 5.1e-4   Q4_K, Q6_K, Q8_K 1.9e-7 / 2.8e-7
 #   F32 1.1e-4 / 2.6e-4    F16 4.1e-4 / 5.6e-4     (full 8B shape, Q4_0 and Q4_K: 6e-5 / 5e-4, tests/test_hip_headline.py)
-FAST_TOL = {"Q4_0": (1e-2, 2.5e-2), "Q8_0": (6e-2, 1e-1), "Q4_1": (1.5e-3, 2e-3), "Q4_K": (1e-6, 2e-6), "Q6_K": (1e-6, 2e-6),
-            "Q8_K": (1e-6, 2e-6), "F32": (5e-4, 1e-3), "F16": (1.5e-3, 2e-3)}
+# K-quants: the rhs quantizer rounds to nearest, so a step normally reproduces the oracle to ~2e-7 (median bound 1e-6) -- but the
+# re-associated GEMV sums still move a value across a rounding boundary now and then: 55 of 2100 decode steps of the 1-layer
+# tiny-gqa model show ONE flipped quant (5e-3 .. 1.1e-2 of max|logit|; round 4, profiles/r04_kquant_flip_rate.log), with the
+# exact and the one-workgroup attention kernels alike.  The max bound has to admit such a step.
+# Round 4: every bound is at most 2 x the largest value observed on MI355X for that format (tests/golden/
+# fast_path_errors_observed.json; the K-quant max is 2 x the largest single-flip step).
+FAST_TOL = {"Q4_0": (8e-3, 1.5e-2), "Q8_0": (5.5e-2, 7.5e-2), "Q4_1": (8e-4, 1.1e-3), "Q4_K": (5e-7, 2.2e-2), "Q6_K": (5e-7, 2.2e-2),
+            "Q8_K": (5e-7, 2.2e-2), "F32": (2.5e-4, 5.5e-4), "F16": (8.5e-4, 1.2e-3)}
+# The fast step's long-context attention (k_attn_flash: f32 exp / f32 accumulation instead of the reference's f16 exp table, f16
+# probabilities, f16 products and serial f16 sum) against the oracle, positions 224 .. 4095: (median, max) bounds, 2 x observed.
+# With a round-to-nearest rhs quantizer (K-quants) the 1e-4-sized attention deviation flips a quant of wo's rhs at most steps:
+# the K-quant row is a flip-sized bound, not the 2e-7 of the exact kernels.
+FAST_TOL.update({"FLASH:Q4_0": (8.6e-3, 1.2e-2), "FLASH:Q4_K": (7e-3, 3e-2), "FLASH:Q8_0": (5.5e-2, 7.5e-2), "FLASH:F32": (5e-3, 1e-2)})
 _OBSERVED = {}
 
 

@@ -359,15 +359,37 @@ def test_mlock_flag_and_madvise(tmp_path):
         assert gf.load_config().n_layers == model.shape.n_layers
 
 
-def test_aligned_header_with_trailing_bytes_is_refused_not_guessed(tmp_path):
-    """Round-2 review finding: when the tensor infos end on an alignment boundary AND neither data-start convention makes the data
-    section end with the last tensor (here: trailing bytes appended), the reader used to fall back to the spec offset silently --
-    for a file written in the reference's convention every tensor would then be read one block early.  It must refuse instead."""
+@pytest.mark.parametrize("convention", ["spec", "reference"])
+def test_aligned_header_with_a_few_trailing_bytes_is_resolved_from_the_file(tmp_path, convention):
+    """Round-3 advisor finding: a file whose tensor infos end on an alignment boundary and that carries a few trailing bytes was
+    refused outright (the reference, gguf.rs:722-724, loads it).  A writer pads by less than one alignment block, so the right
+    convention is the one under which the file ends < alignment bytes after the last tensor: both kinds load, with the right
+    bytes."""
     model = small_model()
-    path = str(tmp_path / "aligned-trailing.gguf")
-    synth.write_gguf(model, path, data_start="reference", pad_header_to_alignment=True)
+    path = str(tmp_path / f"aligned-trailing-{convention}.gguf")
+    synth.write_gguf(model, path, data_start=convention, pad_header_to_alignment=True)
     with open(path, "ab") as f:
         f.write(b"\0" * 7)
-    with pytest.raises(Exception) as ei:
-        ca.GGUFFile(path)
-    assert "ambiguous" in str(ei.value)
+    gf = ca.GGUFFile(path)
+    assert gf.data_start_convention == (0 if convention == "spec" else 1)
+    for name, t in model.tensors.items():
+        assert gf.tensor_data(name)[:len(t.data)] == t.data.tobytes(), name
+
+
+def test_aligned_header_with_a_block_of_trailing_bytes_is_refused_unless_told(tmp_path):
+    """Round-2 review finding, narrowed: with a whole alignment block (or more) of trailing bytes the two conventions cannot be
+    told apart from the file, and guessing wrong reads EVERY tensor one block off without any error downstream.  The reader
+    refuses -- unless the caller names the convention (data_start), and then reads the right bytes."""
+    model = small_model()
+    for convention, code in (("spec", 0), ("reference", 1)):
+        path = str(tmp_path / f"aligned-junk-{convention}.gguf")
+        synth.write_gguf(model, path, data_start=convention, pad_header_to_alignment=True)
+        with open(path, "ab") as f:
+            f.write(b"\0" * 100)  # alignment is 32
+        with pytest.raises(Exception) as ei:
+            ca.GGUFFile(path)
+        assert "ambiguous" in str(ei.value)
+        gf = ca.GGUFFile(path, data_start=code)
+        assert gf.data_start_convention == code
+        for name, t in model.tensors.items():
+            assert gf.tensor_data(name)[:len(t.data)] == t.data.tobytes(), name
