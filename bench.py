@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated this many times (same positions)")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-context", action="store_true", help="skip the long-context decode points")
+    ap.add_argument("--no-c3", action="store_true",
+                    help="skip the 128-step run over positions 0..127 (rocprofv3 --kernel-trace segfaults inside the tracer on 128 "
+                         "back-to-back graph launches; tools/gpu_profile.sh passes this)")
     ap.add_argument("--no-gemv-points", action="store_true", help="skip the single-kernel GEMV points (SURVEY.md 8d)")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self test of the rank aggregation")
     return ap.parse_args()
@@ -605,7 +608,7 @@ def main():
     # SURVEY.md config C3 quotes decode over positions 0..127 from an empty cache; the driver's arguments (--steps 20 --warmup 5)
     # time positions 5..24, where attention is nearly free.  Reported next to `value`: 128 steps from position 0, best of 3.
     c3 = None
-    if rank == 0 and path == "fused":
+    if rank == 0 and path == "fused" and not args.no_c3:
         best = None
         for _ in range(3):
             fused.reset()

@@ -29,7 +29,7 @@ inline size_t block_elems(uint32_t t) {
   switch (t) {
     case CRABML_HIP_F32: case CRABML_HIP_F16: return 1;
     case CRABML_HIP_Q4_0: case CRABML_HIP_Q4_1: case CRABML_HIP_Q8_0: case CRABML_HIP_Q8_1: return 32;
-    case CRABML_HIP_Q4_K: case CRABML_HIP_Q6_K: case CRABML_HIP_Q8_K: return 256;
+    case CRABML_HIP_Q4_K: case CRABML_HIP_Q5_K: case CRABML_HIP_Q6_K: case CRABML_HIP_Q8_K: return 256;
     default: return 0;
   }
 }
@@ -42,6 +42,7 @@ inline size_t block_bytes(uint32_t t) {
     case CRABML_HIP_Q8_0: return 34;
     case CRABML_HIP_Q8_1: return 36;
     case CRABML_HIP_Q4_K: return 144;
+    case CRABML_HIP_Q5_K: return 176;
     case CRABML_HIP_Q6_K: return 210;
     case CRABML_HIP_Q8_K: return 292;
     default: return 0;
@@ -54,7 +55,7 @@ inline uint32_t vec_dot_rhs_dtype(uint32_t t) {
     case CRABML_HIP_F16: return CRABML_HIP_F16;
     case CRABML_HIP_Q8_0: case CRABML_HIP_Q4_0: return CRABML_HIP_Q8_0;
     case CRABML_HIP_Q8_1: case CRABML_HIP_Q4_1: return CRABML_HIP_Q8_1;
-    case CRABML_HIP_Q8_K: case CRABML_HIP_Q4_K: case CRABML_HIP_Q6_K: return CRABML_HIP_Q8_K;
+    case CRABML_HIP_Q8_K: case CRABML_HIP_Q4_K: case CRABML_HIP_Q5_K: case CRABML_HIP_Q6_K: return CRABML_HIP_Q8_K;
     default: return 0xffffffffu;
   }
 }
@@ -74,6 +75,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //                                scale[2p] | scale[2p+1] << 6 | min[2p] << 12 | min[2p+1] << 18 (get_scale_min_k4,
 //                                util.rs:19-27, is a bit permutation of the same 96 bits; done once at upload) --
 //                                so a lane extracts its pair's four fields with 7 VALU ops instead of 23
+//   Q5_K: qs[n][128]           | qh[n][32] | hdr[n][16] = Q4_K's header (d, dmin, pair-major 6-bit fields)   (off_scale = n * 128:
+//                                the qh plane; the header plane follows at off_scale + n * 32)
 //   Q6_K: ql[n][128]           | qh[n][64] | scales[n][16] | d[n] f16   (off_scale = n * 128 exactly, so the
 //                                kernels derive the other three plane offsets from it)
 //   Q8_K: qs[n][256]           | d[n] f32            (bsums are derived data; not kept for weights)

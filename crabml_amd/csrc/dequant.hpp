@@ -55,6 +55,29 @@ __device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dt
       v = d1 * qf - m1;
       break;
     }
+    case CRABML_HIP_Q5_K: {  // buf_q5_k.rs:24-63; planes qs | qh | hdr with n = off_scale / 128 blocks
+      const size_t n = off_scale / 128, sb = e / 256, j = e % 256;
+      const unsigned char* hdr = (const unsigned char*)w + off_scale + n * 32 + sb * 16;
+      const unsigned char* qs = (const unsigned char*)w + sb * 128;
+      const unsigned char* qh = (const unsigned char*)w + off_scale + sb * 32;
+      unsigned short dh, mh;
+      __builtin_memcpy(&dh, hdr, 2);
+      __builtin_memcpy(&mh, hdr + 2, 2);
+      float d = h2f(dh), mn = h2f(mh);
+      int c = (int)(j / 64), l = (int)(j % 64);
+      unsigned u0, u1, u2;
+      __builtin_memcpy(&u0, hdr + 4, 4);
+      __builtin_memcpy(&u1, hdr + 8, 4);
+      __builtin_memcpy(&u2, hdr + 12, 4);
+      const unsigned f = q4k_pair_field(u0, u1, u2, c);
+      const int s6 = (int)((l >= 32 ? f >> 6 : f) & 63u), m6 = (int)((l >= 32 ? f >> 18 : f >> 12) & 63u);
+      float d1 = d * (float)s6, m1 = mn * (float)m6;
+      unsigned char q = qs[32 * c + (l & 31)];
+      const int hbit = (qh[l & 31] >> (2 * c + (l >= 32 ? 1 : 0))) & 1;
+      float qf = (float)(l >= 32 ? (q >> 4) : (q & 0xF)) + (hbit ? 16.0f : 0.0f);
+      v = d1 * qf - m1;
+      break;
+    }
     case CRABML_HIP_Q6_K: {  // buf_q6_k.rs:21-48; planes ql | qh | scales | d with n = off_scale / 128 blocks
       const size_t n = off_scale / 128, sb = e / 256;
       const int j = (int)(e % 256), idx = j / 128, r = j % 128, l = r % 32, quarter = r / 32;

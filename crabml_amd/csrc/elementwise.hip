@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_repack(const unsigned short* __restrict
   for (int s = 0; s < plan.nseg; s++) {
     const int r = o - plan.src_off2[s];
     if (r >= 0 && r < plan.len2[s]) {
-      base[plan.dst_off[s] / 2 + (blk0 + b) * plan.len2[s] + r] = v;
+      base[plan.dst_off[s] / 2 + (blk0 + b) * plan.stride2[s] + r] = v;
       return;
     }
   }

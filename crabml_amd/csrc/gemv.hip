@@ -115,6 +115,23 @@ __global__ __launch_bounds__(256) void k_gemv_q4_k(const i32x4* __restrict__ wq,
   }
 }
 
+// ---- Q5_K x Q8_K (buf_q5_k.rs:229-325; rows_partial_q5k, gemv_core.hpp) ---------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_q5_k(const char* __restrict__ w, size_t off_qh, ActQ8_K act, float* __restrict__ out, int m,
+                                                   int nsb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+  rows_partial_q5k<R>(w, off_qh, act, row0, m, nsb, lane, acc);
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+
 // ---- Q6_K x Q8_K ---------------------------------------------------------------------------------
 // planes: ql[n][128] | qh[n][64] | scales[n][16] | d[n] (common.hpp).  A lane owns one 16-byte ql piece (8 lanes
 // per super-block: one aligned 1 KiB request per wave): piece (h, a, p) = ql[64 h + 32 a + 16 p .. +16) holds the low
@@ -277,6 +294,17 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         });
         break;
       }
+      case CRABML_HIP_Q5_K: {
+        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const int nsb = k / 256;
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            launch_k(st, rec, k_gemv_q5_k<2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, a, o, m, nsb);
+          else
+            launch_k(st, rec, k_gemv_q5_k<1>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, a, o, m, nsb);
+        });
+        break;
+      }
       case CRABML_HIP_Q6_K: {
         ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
         const int nsb = k / 256;
@@ -331,21 +359,29 @@ __global__ void k_block_dots_32(const i32x4* __restrict__ wq, int wtype, ActQ8_0
   }
 }
 __global__ void k_block_dots_k(const unsigned char* __restrict__ w, int wtype, ActQ8_K a, size_t row_sb0, int nsb,
-                               int* __restrict__ out) {
+                               int* __restrict__ out, size_t off_qh) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;  // 32-element group
   if (g >= nsb * 8) return;
   int sb = g >> 3;
-  if (wtype == CRABML_HIP_Q4_K) {
+  if (wtype == CRABML_HIP_Q4_K || wtype == CRABML_HIP_Q5_K) {
     int p = (g & 7) >> 1, hi_half = g & 1;
     const unsigned char* qs = w + (row_sb0 + sb) * 128;
     i32x4 qa = *(const i32x4*)(qs + p * 32), qb = *(const i32x4*)(qs + 16 + p * 32);
+    i32x4 ha = {0, 0, 0, 0}, hb = {0, 0, 0, 0};  // Q5_K: the fifth bit of this group's 32 levels, moved to bit 4 of their bytes
+    if (wtype == CRABML_HIP_Q5_K) {
+      const unsigned char* qh = w + off_qh + (row_sb0 + sb) * 32;
+      ha = *(const i32x4*)qh;
+      hb = *(const i32x4*)(qh + 16);
+    }
     const i32x4* xq = a.q + (size_t)sb * 16 + p * 4 + hi_half * 2;
     i32x4 x0 = xq[0], x1 = xq[1];
     int s = 0;
     for (int i = 0; i < 4; i++) {
       int wa = hi_half ? (qa[i] >> 4) : qa[i], wb = hi_half ? (qb[i] >> 4) : qb[i];
-      s = __builtin_amdgcn_sdot4(wa & 0x0F0F0F0F, x0[i], s, false);
-      s = __builtin_amdgcn_sdot4(wb & 0x0F0F0F0F, x1[i], s, false);
+      const int fa = (int)((((unsigned)ha[i] >> (2 * p + hi_half)) & 0x01010101u) << 4);
+      const int fb = (int)((((unsigned)hb[i] >> (2 * p + hi_half)) & 0x01010101u) << 4);
+      s = __builtin_amdgcn_sdot4((wa & 0x0F0F0F0F) | fa, x0[i], s, false);
+      s = __builtin_amdgcn_sdot4((wb & 0x0F0F0F0F) | fb, x1[i], s, false);
     }
     out[g] = s;
   } else {
@@ -430,10 +466,10 @@ void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t
     ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
     int nsb = (int)(k / 256);
     k_block_dots_q6k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, a, row * nsb, nsb, out);
-  } else if (w->dtype == CRABML_HIP_Q4_K || w->dtype == CRABML_HIP_Q8_K) {
+  } else if (w->dtype == CRABML_HIP_Q4_K || w->dtype == CRABML_HIP_Q5_K || w->dtype == CRABML_HIP_Q8_K) {
     ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
     int nsb = (int)(k / 256);
-    k_block_dots_k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>((const unsigned char*)wp, (int)w->dtype, a, row * nsb, nsb, out);
+    k_block_dots_k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>((const unsigned char*)wp, (int)w->dtype, a, row * nsb, nsb, out, w->wl.off_scale);
   } else {
     ActQ8_0 a0{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
     ActQ8_1 a1{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const unsigned short*)(ap + al.off_aux)};

@@ -278,6 +278,52 @@ __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, c
   }
 }
 
+// Q5_K rows (planes qs[n][128] | qh[n][32] | hdr[n][16], the reference's own block contents: buf_q5_k.rs:13-21) against a Q8_K
+// activation vector: Q4_K's mapping (lane = one 16-byte qs piece j of a super-block: pair p = j / 2, positions 16 (j & 1) .. +16)
+// plus the piece's 16 bytes of qh, whose bits 2p / 2p + 1 are the fifth bit of the low / high nibbles (buf_q5_k.rs:246-262).
+// Levels 0 .. 31 fit the signed bytes of v_dot4; scales, minimums and the float part are Q4_K's.  Not a tuned path (three
+// 16-byte loads per lane and piece): Q5_K runs as per-op segments.
+template <int R>
+__device__ __forceinline__ void rows_partial_q5k(const char* __restrict__ w, size_t off_qh, const ActQ8_K& act, int row0, int m,
+                                                 int nsb, int lane, float acc[R]) {
+  const size_t n = off_qh / 128;  // blocks in the tensor
+  const i32x4* wq = (const i32x4*)w;
+  const i32x4* wqh = (const i32x4*)(w + off_qh);
+  const i32x4* wh = (const i32x4*)(w + off_qh + n * 32);
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int nchunks = nsb * 8;
+  for (int c = lane; c < nchunks; c += 64) {
+    const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
+    const Q4KX x = q4k_loadx(act, c);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const size_t blk = (size_t)(row0 + r < m ? row0 + r : m - 1) * nsb + sb;
+      const i32x4 qv = __builtin_nontemporal_load(wq + blk * 8 + j);
+      const i32x4 hv = __builtin_nontemporal_load(wqh + blk * 2 + h);
+      const i32x4 hd = __builtin_nontemporal_load(wh + blk);
+      const unsigned f = q4k_pair_field((unsigned)hd[1], (unsigned)hd[2], (unsigned)hd[3], p);
+      const int sc_lo = (int)(f & 63u), sc_hi = (int)((f >> 6) & 63u);
+      const int m_lo = (int)((f >> 12) & 63u), m_hi = (int)(f >> 18);
+      int lo = 0, hi = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = (unsigned)qv[i], hb = (unsigned)hv[i] >> (2 * p);
+        const unsigned l5 = (q & 0x0F0F0F0Fu) | ((hb & 0x01010101u) << 4);
+        const unsigned h5 = ((q >> 4) & 0x0F0F0F0Fu) | (((hb >> 1) & 0x01010101u) << 4);
+        lo = __builtin_amdgcn_sdot4((int)l5, x.xl[i], lo, false);
+        hi = __builtin_amdgcn_sdot4((int)h5, x.xh[i], hi, false);
+      }
+      const int isum = sc_lo * lo + sc_hi * hi;
+      const int msum = m_lo * x.bs_lo + m_hi * x.bs_hi;
+      const unsigned h0 = (unsigned)hd[0];
+      const float dd = h2f((unsigned short)(h0 & 0xffff)) * x.d8;
+      const float dmin = h2f((unsigned short)(h0 >> 16)) * x.d8;
+      acc[r] += dd * (float)isum - dmin * (float)msum;
+    }
+  }
+}
+
 // Q6_K rows (planes ql[n][128] | qh[n][64] | scales[n][16] | d[n] f16; common.hpp) against a Q8_K activation vector:
 // lane = one 16-byte ql piece of a super-block (8 lanes per super-block), which carries the low nibbles of scale group
 // gi and the high nibbles of group gi + 4 (buf_q6_k.rs:21-48).  6-bit values are rebuilt as bytes for v_dot4; the -32

@@ -66,14 +66,18 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
       }
       break;
     }
-    case CRABML_HIP_Q4_K: {
+    case CRABML_HIP_Q4_K:
+    case CRABML_HIP_Q5_K: {  // buf_q5_k.rs:229-325 = buf_q4_k.rs:192-277 + the fifth bit (planes qs | qh | hdr, n = off_scale / 128 blocks)
+      const bool q5 = dtype == CRABML_HIP_Q5_K;
+      const size_t n5 = off_scale / 128;
       const int nsb = k / 256;
       const float* xd = (const float*)(act + off_d);
       const short* bsums = (const short*)(act + off_aux);
       float sums[8];
       for (int l = 0; l < 8; l++) sums[l] = 0.0f;
       for (int sb = 0; sb < nsb; sb++) {
-        const unsigned char* hdr = (const unsigned char*)w + off_scale + ((size_t)row * nsb + sb) * 16;
+        const unsigned char* hdr = (const unsigned char*)w + off_scale + (q5 ? n5 * 32 : 0) + ((size_t)row * nsb + sb) * 16;
+        const unsigned char* qh = (const unsigned char*)w + off_scale + ((size_t)row * nsb + sb) * 32;  // (Q5_K only)
         const signed char* q8 = (const signed char*)act + (size_t)sb * 256;
         unsigned short dh, mh;
         __builtin_memcpy(&dh, hdr, 2);
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
               int e = 8 * g + l;  // element within the 32-wide sub-block
               unsigned char qb = q4[32 * c + e];
               int a = hi ? (qb >> 4) : (qb & 0xF);
+              if (q5 && ((qh[e] >> (2 * c + hi)) & 1)) a += 16;
               int prod = (int)q8[32 * is + e] * a;  // aux16
               aux32[l] += scale * (float)prod;
             }

@@ -324,6 +324,7 @@ inline bool ggml_block_geometry(uint32_t t, size_t* block_bytes, size_t* block_e
     case 8: *block_bytes = 34; *block_elems = 32; return true;     // Q8_0
     case 9: *block_bytes = 36; *block_elems = 32; return true;     // Q8_1
     case 12: *block_bytes = 144; *block_elems = 256; return true;  // Q4_K
+    case 13: *block_bytes = 176; *block_elems = 256; return true;  // Q5_K (the reference's field order, buf_q5_k.rs:13-21)
     case 14: *block_bytes = 210; *block_elems = 256; return true;  // Q6_K
     case 15: *block_bytes = 292; *block_elems = 256; return true;  // Q8_K
     default: return false;

@@ -20,7 +20,7 @@
 
 namespace crabml_host {
 
-enum class GGMLType : uint32_t { F32 = 0, F16 = 1, Q4_0 = 2, Q4_1 = 3, Q8_0 = 8, Q8_1 = 9, Q4K = 12, Q6K = 14, Q8K = 15 };
+enum class GGMLType : uint32_t { F32 = 0, F16 = 1, Q4_0 = 2, Q4_1 = 3, Q8_0 = 8, Q8_1 = 9, Q4K = 12, Q5K = 13, Q6K = 14, Q8K = 15 };
 enum class RopeMode : uint32_t { Llama = 0, Neox = 1 };
 
 // replaces WgpuTensorDeviceOptions (crabml-wgpu/src/wgpu_device.rs:9-38)

@@ -29,10 +29,11 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
                        float* out);
 // weight upload: scatter the pieces of `n_blocks` GGUF blocks (`bb` bytes each) starting at block `blk0` into their
 // planes (byte moves only).  Piece s = bytes [2 src_off2, 2 src_off2 + 2 len2) of a block -> base + dst_off[s],
-// packed per block; bytes covered by no piece are dropped.
+// one `stride2`-unit record per block (stride2 = len2 unless two pieces share a record: Q5_K's header); bytes covered by no
+// piece are dropped.
 struct RepackPlan {
   int nseg;
-  int src_off2[4], len2[4];
+  int src_off2[4], len2[4], stride2[4];
   size_t dst_off[4];
 };
 void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, size_t n_blocks, int bb, const RepackPlan& plan);

@@ -44,6 +44,7 @@ WeightLayout weight_layout(uint32_t dtype, size_t n_elems) {
     case CRABML_HIP_Q8_0: wl.off_scale = align_up(n * 32, 256); wl.total = wl.off_scale + n * 2; break;
     case CRABML_HIP_Q4_1: wl.off_scale = align_up(n * 16, 256); wl.total = wl.off_scale + n * 4; break;
     case CRABML_HIP_Q4_K: wl.off_scale = align_up(n * 128, 256); wl.total = wl.off_scale + n * 16; break;
+    case CRABML_HIP_Q5_K: wl.off_scale = n * 128; wl.total = align_up(n * 176, 256); break;
     case CRABML_HIP_Q6_K: wl.off_scale = n * 128; wl.total = align_up(n * 210, 256); break;
     case CRABML_HIP_Q8_K: wl.off_scale = align_up(n * 256, 256); wl.total = wl.off_scale + n * 4; break;
     default: wl.total = 0;
@@ -357,9 +358,10 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
     // ping-pong so the re-layout of chunk i overlaps the copy of chunk i + 1.
     // per format: where each piece of a GGUF block goes (source offset, length, destination plane offset)
     RepackPlan plan{};
-    auto seg = [&](int src_off, int len, size_t dst_off) {
+    auto seg = [&](int src_off, int len, size_t dst_off, int stride = 0) {
       plan.src_off2[plan.nseg] = src_off / 2;
       plan.len2[plan.nseg] = len / 2;
+      plan.stride2[plan.nseg] = (stride ? stride : len) / 2;  // bytes per block in the destination plane
       plan.dst_off[plan.nseg] = dst_off;
       plan.nseg++;
     };
@@ -368,6 +370,9 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
       case CRABML_HIP_Q8_0: seg(0, 2, wl.off_scale); seg(2, 32, 0); break;
       case CRABML_HIP_Q4_1: seg(0, 4, wl.off_scale); seg(4, 16, 0); break;
       case CRABML_HIP_Q4_K: seg(0, 16, wl.off_scale); seg(16, 128, 0); break;
+      case CRABML_HIP_Q5_K:  // qs | qh | scales | d | dmin (buf_q5_k.rs:13-21) -> qs | qh | (d, dmin, scales)
+        seg(0, 128, 0); seg(128, 32, wl.off_scale); seg(172, 4, wl.off_scale + nblk * 32, 16); seg(160, 12, wl.off_scale + nblk * 32 + 4, 16);
+        break;
       case CRABML_HIP_Q6_K:  // ql | qh | scales | d (buf_q6_k.rs:11-18)
         seg(0, 128, 0); seg(128, 64, wl.off_scale); seg(192, 16, wl.off_scale + nblk * 64); seg(208, 2, wl.off_scale + nblk * 80);
         break;
@@ -392,6 +397,7 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
         if (e != hipSuccess) break;
         launch_repack(dev->stream, stage[slot], b->ptr, b0, nb, (int)bb, plan);
         if (t == CRABML_HIP_Q4_K) launch_q4k_pack_scales(dev->stream, (char*)b->ptr + wl.off_scale, b0, nb);
+        if (t == CRABML_HIP_Q5_K) launch_q4k_pack_scales(dev->stream, (char*)b->ptr + wl.off_scale + nblk * 32, b0, nb);
         e = hipEventRecord(done[slot], dev->stream);
       }
       if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);

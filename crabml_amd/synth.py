@@ -12,10 +12,10 @@ from typing import Dict, List, Optional
 
 import numpy as np
 
-F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q6_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 14, 15
-BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q6_K: 256, Q8_K: 256}
-BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q6_K: 210, Q8_K: 292}
-TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q4_K: "Q4_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
+F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 13, 14, 15
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292}
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
 TYPE_BY_NAME = {v: k for k, v in TYPE_NAMES.items()}
 
 
@@ -80,6 +80,10 @@ def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: f
         out[:, 0:2] = _f16_scales(rng, nb, lo / 32, hi / 32).reshape(nb, 1).view(np.uint8)
         out[:, 2:4] = _f16_scales(rng, nb, lo / 4, hi / 4).reshape(nb, 1).view(np.uint8)
         out[:, 4:] = rng.integers(0, 256, size=(nb, 140), dtype=np.uint8)  # 6-bit scales/mins + nibbles
+    elif typ == Q5_K:  # the REFERENCE's order: qs[128] | qh[32] | scales[12] | d f16 | dmin f16 (buf_q5_k.rs:13-21)
+        out[:, 0:172] = rng.integers(0, 256, size=(nb, 172), dtype=np.uint8)
+        out[:, 172:174] = _f16_scales(rng, nb, lo / 64, hi / 64).reshape(nb, 1).view(np.uint8)
+        out[:, 174:176] = _f16_scales(rng, nb, lo / 4, hi / 4).reshape(nb, 1).view(np.uint8)
     elif typ == Q6_K:  # ql[128] | qh[64] | scales i8[16] | d f16 (buf_q6_k.rs:11-18)
         out[:, 0:192] = rng.integers(0, 256, size=(nb, 192), dtype=np.uint8)
         out[:, 192:208] = rng.integers(-64, 64, size=(nb, 16), dtype=np.int8).view(np.uint8)
@@ -209,7 +213,7 @@ def to_hip(model: RawModel, device):
     import crabml_amd as ca
 
     tmap = {F32: ca.GGMLType.F32, F16: ca.GGMLType.F16, Q4_0: ca.GGMLType.Q4_0, Q4_1: ca.GGMLType.Q4_1,
-            Q8_0: ca.GGMLType.Q8_0, Q4_K: ca.GGMLType.Q4K, Q6_K: ca.GGMLType.Q6K, Q8_K: ca.GGMLType.Q8K}
+            Q8_0: ca.GGMLType.Q8_0, Q4_K: ca.GGMLType.Q4K, Q5_K: ca.GGMLType.Q5K, Q6_K: ca.GGMLType.Q6K, Q8_K: ca.GGMLType.Q8K}
     s = model.shape
 
     def up(name):

@@ -55,6 +55,8 @@ typedef enum crabml_hip_ggml_type {
   CRABML_HIP_Q8_0 = 8,
   CRABML_HIP_Q8_1 = 9,
   CRABML_HIP_Q4_K = 12,
+  CRABML_HIP_Q5_K = 13, /* weights only (rhs: Q8_K), in the REFERENCE's field order qs | qh | scales | d | dmin
+                         * (crabml-core/src/cpu/buf/buf_q5_k.rs:13-21) -- not ggml's */
   CRABML_HIP_Q6_K = 14, /* weights only (rhs: Q8_K), crabml-core/src/cpu/buf/buf_q6_k.rs */
   CRABML_HIP_Q8_K = 15
 } crabml_hip_ggml_type;
@@ -177,7 +179,7 @@ int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a,
  * CRABML_HIP_FLAG_STRICT_ORDER every sum runs in the reference's scalar order and the step is bit-identical
  * to the reference at every context length.
  * Weights: layer matrices in any matmul_vec format (Q4_0, Q8_0, Q4_1 and Q4_K run fused kernels, Q4_K also
- * with attn_v / ffn_down in Q6_K -- llama.cpp's *_K_M mixes; Q6_K, Q8_K, F16, F32 and any other mix sharing
+ * with attn_v / ffn_down in Q6_K -- llama.cpp's *_K_M mixes; Q5_K, Q6_K, Q8_K, F16, F32 and any other mix sharing
  * one rhs dtype run as per-op segments inside the same graph); the classifier may have another format; norm
  * weights F32.  Tensor types whose rhs dtypes differ inside a layer: CRABML_HIP_NOT_IMPLEMENTED (use the
  * per-op trait path). */

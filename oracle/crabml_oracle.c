@@ -112,7 +112,7 @@ size_t co_block_elems(uint32_t t) {
   switch (t) {
     case CO_F32: case CO_F16: return 1;
     case CO_Q4_0: case CO_Q4_1: case CO_Q8_0: case CO_Q8_1: return 32;
-    case CO_Q4_K: case CO_Q6_K: case CO_Q8_K: return 256;
+    case CO_Q4_K: case CO_Q5_K: case CO_Q6_K: case CO_Q8_K: return 256;
     default: return 0;
   }
 }
@@ -125,6 +125,7 @@ size_t co_block_bytes(uint32_t t) {
     case CO_Q8_0: return sizeof(co_block_q8_0);
     case CO_Q8_1: return sizeof(co_block_q8_1);
     case CO_Q4_K: return sizeof(co_block_q4_k);
+    case CO_Q5_K: return sizeof(co_block_q5_k);
     case CO_Q6_K: return sizeof(co_block_q6_k);
     case CO_Q8_K: return sizeof(co_block_q8_k);
     default: return 0;
@@ -136,7 +137,7 @@ uint32_t co_vec_dot_rhs_dtype(uint32_t t) { /* buf/api.rs:142-159 */
     case CO_F16: return CO_F16;
     case CO_Q8_0: case CO_Q4_0: return CO_Q8_0;
     case CO_Q8_1: case CO_Q4_1: return CO_Q8_1;
-    case CO_Q8_K: case CO_Q4_K: case CO_Q6_K: return CO_Q8_K;
+    case CO_Q8_K: case CO_Q4_K: case CO_Q5_K: case CO_Q6_K: return CO_Q8_K;
     default: return 0xffffffffu;
   }
 }
@@ -384,6 +385,81 @@ void co_quantize_f32_q4_k(const float* x, size_t n, co_block_q4_k* out) {
   }
 }
 
+/* buf_q5_k.rs:123-227: make_qkx1_quants(32, 31, .., 9) per 32 values, 6-bit scales / mins packed as in Q4_K, then the 5-bit
+ * levels re-derived from the rounded scales; the low nibbles go to qs (two 32-value halves of a 64-chunk per byte), bit 4 to qh
+ * (mask m1 = 1 << 2c for the first half of chunk c, m2 = 2 << 2c for the second). */
+void co_quantize_f32_q5_k(const float* x, size_t n, co_block_q5_k* out) {
+  float scales[8], mins[8];
+  memset(scales, 0, sizeof scales);
+  memset(mins, 0, sizeof mins);
+  for (size_t c = 0; c < n; c += 256) {
+    const float* chunk = x + c;
+    uint8_t l[256];
+    memset(l, 0, sizeof l);
+    float max_scale = 0.0f, max_min = 0.0f;
+    uint8_t bs[12];
+    memset(bs, 0, sizeof bs);
+    for (int ib = 0; ib < 8; ib++) {
+      scales[ib] = make_qkx1_quants(32, 31, chunk + 32 * ib, l + 32 * ib, &mins[ib], 9);
+      if (scales[ib] > max_scale) max_scale = scales[ib];
+      if (mins[ib] > max_min) max_min = mins[ib];
+    }
+    float inv_scale = max_scale > 0.0f ? 63.0f / max_scale : 0.0f;
+    float inv_min = max_min > 0.0f ? 63.0f / max_min : 0.0f;
+    for (int idx = 0; idx < 8; idx++) {
+      int32_t a = co_nearest_i32(inv_scale * scales[idx]);
+      int32_t b = co_nearest_i32(inv_min * mins[idx]);
+      uint8_t ls = (uint8_t)(a < 63 ? a : 63);
+      uint8_t lm = (uint8_t)(b < 63 ? b : 63);
+      if (idx < 4) {
+        bs[idx] = ls;
+        bs[idx + 4] = lm;
+      } else {
+        bs[idx + 4] = (uint8_t)((ls & 0xF) | ((lm & 0xF) << 4));
+        bs[idx - 4] |= (uint8_t)((ls >> 4) << 6);
+        bs[idx] |= (uint8_t)((lm >> 4) << 6);
+      }
+    }
+    float d = max_scale / 63.0f;
+    float dmin = max_min / 63.0f;
+    for (int idx = 0; idx < 8; idx++) {
+      uint8_t sc, m;
+      co_get_scale_min_k4(idx, bs, &sc, &m);
+      float dd = d * (float)sc;
+      if (dd == 0.0f) continue;
+      float dm = dmin * (float)m;
+      for (int i = 0; i < 32; i++) {
+        int index = 32 * idx + i;
+        int32_t ll = co_nearest_i32((chunk[index] + dm) / dd);
+        ll = ll < 0 ? 0 : (ll > 31 ? 31 : ll);
+        l[index] = (uint8_t)ll;
+      }
+    }
+    co_block_q5_k* b = &out[c / 256];
+    memset(b->qh, 0, sizeof b->qh);
+    uint8_t m1 = 1, m2 = 2;
+    for (int q = 0; q < 4; q++) {
+      for (int id = 0; id < 32; id++) {
+        uint8_t l1 = l[64 * q + id], l2 = l[64 * q + id + 32];
+        if (l1 > 15) {
+          l1 = (uint8_t)(l1 - 16);
+          b->qh[id] |= m1;
+        }
+        if (l2 > 15) {
+          l2 = (uint8_t)(l2 - 16);
+          b->qh[id] |= m2;
+        }
+        b->qs[32 * q + id] = (uint8_t)(l1 | (l2 << 4));
+      }
+      m1 = (uint8_t)(m1 << 2);
+      m2 = (uint8_t)(m2 << 2);
+    }
+    b->d = co_f32_to_f16(d);
+    b->dmin = co_f32_to_f16(dmin);
+    memcpy(b->scales, bs, 12);
+  }
+}
+
 int co_quantize(const float* x, size_t n, uint32_t type, void* out) {
   switch (type) {
     case CO_F32: memcpy(out, x, n * 4); return 0;
@@ -394,6 +470,7 @@ int co_quantize(const float* x, size_t n, uint32_t type, void* out) {
     case CO_Q4_0: co_quantize_f32_q4_0(x, n, (co_block_q4_0*)out); return 0;
     case CO_Q4_1: co_quantize_f32_q4_1(x, n, (co_block_q4_1*)out); return 0;
     case CO_Q4_K: co_quantize_f32_q4_k(x, n, (co_block_q4_k*)out); return 0;
+    case CO_Q5_K: co_quantize_f32_q5_k(x, n, (co_block_q5_k*)out); return 0;
     case CO_Q6_K: co_quantize_f32_q6_k(x, n, (co_block_q6_k*)out); return 0;
     default: return -1;
   }
@@ -447,6 +524,27 @@ static void dq_q4_k(const co_block_q4_k* b, float* o) { /* buf_q4_k.rs:24-47 (st
     is += 2;
   }
 }
+static void dq_q5_k(const co_block_q5_k* b, float* o) { /* buf_q5_k.rs:24-63 (stray println! not reproduced) */
+  float d = co_f16_to_f32(b->d), min = co_f16_to_f32(b->dmin);
+  int is = 0;
+  uint8_t u1 = 1, u2 = 2;
+  for (int c = 0; c < 4; c++) {
+    uint8_t sc, m;
+    co_get_scale_min_k4(is, b->scales, &sc, &m);
+    float d1 = d * (float)sc, m1 = min * (float)m;
+    co_get_scale_min_k4(is + 1, b->scales, &sc, &m);
+    float d2 = d * (float)sc, m2 = min * (float)m;
+    const uint8_t* q = b->qs + 32 * c;
+    float* oc = o + 64 * c;
+    for (int l = 0; l < 32; l++) {
+      oc[l] = d1 * ((float)(q[l] & 0xF) + ((b->qh[l] & u1) ? 16.0f : 0.0f)) - m1;
+      oc[l + 32] = d2 * ((float)(q[l] >> 4) + ((b->qh[l] & u2) ? 16.0f : 0.0f)) - m2;
+    }
+    is += 2;
+    u1 = (uint8_t)(u1 << 2);
+    u2 = (uint8_t)(u2 << 2);
+  }
+}
 static void dq_q8_k(const co_block_q8_k* b, float* o) { /* buf_q8_k.rs:15-20 */
   for (int i = 0; i < 256; i++) o[i] = b->d * (float)b->qs[i];
 }
@@ -496,6 +594,7 @@ int co_dequantize(const void* blocks, uint32_t type, size_t start, size_t n, flo
       case CO_Q4_1: dq_q4_1((const co_block_q4_1*)blk, tmp); break;
       case CO_Q8_1: dq_q8_1((const co_block_q8_1*)blk, tmp); break;
       case CO_Q4_K: dq_q4_k((const co_block_q4_k*)blk, tmp); break;
+      case CO_Q5_K: dq_q5_k((const co_block_q5_k*)blk, tmp); break;
       case CO_Q6_K: dq_q6_k((const co_block_q6_k*)blk, tmp); break;
       case CO_Q8_K: dq_q8_k((const co_block_q8_k*)blk, tmp); break;
       default: return -1;
@@ -568,6 +667,73 @@ float co_vec_dot_q4_k_q8_k(const co_block_q4_k* a, const co_block_q8_k* b, size_
         aux8[64 * c + l] = (int8_t)(q4[32 * c + l] & 0xF);
         aux8[64 * c + l + 32] = (int8_t)(q4[32 * c + l] >> 4);
       }
+    for (int i = 0; i < 3; i++) {
+      const uint8_t* s = a[bi].scales + 4 * i;
+      utmp[i] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+    }
+    utmp[3] = ((utmp[2] >> 4) & KMASK2) | (((utmp[1] >> 6) & KMASK3) << 4);
+    uint32_t uaux = utmp[1] & KMASK1;
+    utmp[1] = (utmp[2] & KMASK2) | (((utmp[0] >> 6) & KMASK3) << 4);
+    utmp[2] = uaux;
+    utmp[0] &= KMASK1;
+    uint8_t scales[8], mins[8];
+    for (int i = 0; i < 4; i++) {
+      scales[i] = (uint8_t)(utmp[0] >> (8 * i));
+      scales[4 + i] = (uint8_t)(utmp[1] >> (8 * i));
+      mins[i] = (uint8_t)(utmp[2] >> (8 * i));
+      mins[4 + i] = (uint8_t)(utmp[3] >> (8 * i));
+    }
+    int64_t sumi = 0;
+    for (int j = 0; j < 16; j++) {
+      int32_t prod = (int32_t)b[bi].bsums[j] * (int32_t)mins[j / 2];
+      if (prod > 32767 || prod < -32768) {
+        if (n_overflow) (*n_overflow)++;
+        if (i16_wrap) prod = (int32_t)(int16_t)(uint16_t)((uint32_t)prod & 0xffffu);
+      }
+      sumi += prod;
+    }
+    for (int is = 0; is < 8; is++) {
+      float scale = (float)scales[is];
+      const int8_t* a8 = aux8 + 32 * is;
+      const int8_t* b8 = q8 + 32 * is;
+      for (int g = 0; g < 4; g++)
+        for (int l = 0; l < 8; l++) {
+          aux16[l] = (int16_t)((int16_t)b8[8 * g + l] * (int16_t)a8[8 * g + l]);
+          aux32[l] += scale * (float)aux16[l];
+        }
+    }
+    float d = co_f16_to_f32(a[bi].d) * b[bi].d;
+    for (int l = 0; l < 8; l++) sums[l] += d * aux32[l];
+    float dmin = co_f16_to_f32(a[bi].dmin) * b[bi].d;
+    sumf -= dmin * (float)sumi;
+  }
+  for (int l = 0; l < 8; l++) sumf += sums[l];
+  return sumf;
+}
+
+/* buf_q5_k.rs:229-325.  aux8 = the 5-bit levels (low nibble + 16 if the chunk's qh bit is set: mask m = 1 << (2c) for the first
+ * 32 values of chunk c, 1 << (2c + 1) for the second); scales / mins unpacked as in Q4_K; eight f32 lanes (element e of a
+ * 32-group feeds lane e % 8), `sums[l] += d * aux32[l]` and `sumf -= dmin * sumi` per super-block, the lanes added at the end. */
+float co_vec_dot_q5_k_q8_k(const co_block_q5_k* a, const co_block_q8_k* b, size_t nb, int i16_wrap, size_t* n_overflow) {
+  const uint32_t KMASK1 = 0x3f3f3f3fu, KMASK2 = 0x0f0f0f0fu, KMASK3 = 0x03030303u;
+  uint32_t utmp[4];
+  int8_t aux8[256];
+  int16_t aux16[8];
+  float sums[8], aux32[8];
+  memset(sums, 0, sizeof sums);
+  float sumf = 0.0f;
+  for (size_t bi = 0; bi < nb; bi++) {
+    const uint8_t* q5 = a[bi].qs;
+    const uint8_t* qh = a[bi].qh;
+    const int8_t* q8 = b[bi].qs;
+    memset(aux32, 0, sizeof aux32);
+    uint8_t m = 1;
+    for (int c = 0; c < 4; c++) {
+      for (int l = 0; l < 32; l++) aux8[64 * c + l] = (int8_t)((q5[32 * c + l] & 0xF) + ((qh[l] & m) ? 16 : 0));
+      m = (uint8_t)(m << 1);
+      for (int l = 0; l < 32; l++) aux8[64 * c + l + 32] = (int8_t)((q5[32 * c + l] >> 4) + ((qh[l] & m) ? 16 : 0));
+      m = (uint8_t)(m << 1);
+    }
     for (int i = 0; i < 3; i++) {
       const uint8_t* s = a[bi].scales + 4 * i;
       utmp[i] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
@@ -990,6 +1156,21 @@ int co_block_dots(const void* w, uint32_t wtype, const void* x, size_t n, int32_
         }
       return 0;
     }
+    case CO_Q5_K: {
+      const co_block_q5_k* a = (const co_block_q5_k*)w;
+      const co_block_q8_k* b = (const co_block_q8_k*)x;
+      for (size_t i = 0; i < n / 256; i++)
+        for (int c = 0; c < 4; c++) {
+          int32_t lo = 0, hi = 0;
+          for (int l = 0; l < 32; l++) {
+            lo += ((int32_t)(a[i].qs[32 * c + l] & 0xF) + (((a[i].qh[l] >> (2 * c)) & 1) ? 16 : 0)) * b[i].qs[64 * c + l];
+            hi += ((int32_t)(a[i].qs[32 * c + l] >> 4) + (((a[i].qh[l] >> (2 * c + 1)) & 1) ? 16 : 0)) * b[i].qs[64 * c + 32 + l];
+          }
+          out[i * 8 + 2 * c] = lo;
+          out[i * 8 + 2 * c + 1] = hi;
+        }
+      return 0;
+    }
     case CO_Q6_K: { /* per 16-element scale group: sum (q6 - 32) * q8 (16 per super-block) */
       const co_block_q6_k* a = (const co_block_q6_k*)w;
       const co_block_q8_k* b = (const co_block_q8_k*)x;
@@ -1179,6 +1360,8 @@ static float vec_dot_dispatch(struct co_device* d, uint32_t wtype, const void* w
       return co_vec_dot_q4_1_q8_1((const co_block_q4_1*)wrow, (const co_block_q8_1*)xrow, k / 32);
     case CO_Q4_K:
       return co_vec_dot_q4_k_q8_k((const co_block_q4_k*)wrow, (const co_block_q8_k*)xrow, k / 256, 0, NULL);
+    case CO_Q5_K: /* scalar only in the reference */
+      return co_vec_dot_q5_k_q8_k((const co_block_q5_k*)wrow, (const co_block_q8_k*)xrow, k / 256, 0, NULL);
     case CO_Q6_K: /* the reference has no SIMD path for Q6_K */
       return co_vec_dot_q6_k_q8_k((const co_block_q6_k*)wrow, (const co_block_q8_k*)xrow, k / 256);
     case CO_Q8_K:

@@ -37,7 +37,7 @@ extern "C" {
 /* GGML type ids: crabml-core/src/gguf.rs:86-108 */
 enum {
   CO_F32 = 0, CO_F16 = 1, CO_Q4_0 = 2, CO_Q4_1 = 3, CO_Q8_0 = 8, CO_Q8_1 = 9,
-  CO_Q4_K = 12, CO_Q6_K = 14, CO_Q8_K = 15
+  CO_Q4_K = 12, CO_Q5_K = 13, CO_Q6_K = 14, CO_Q8_K = 15
 };
 
 #pragma pack(push, 1)
@@ -46,6 +46,8 @@ typedef struct { uint16_t d; uint8_t qs[16]; } co_block_q4_0;                /* 
 typedef struct { uint16_t d; uint16_t m; uint8_t qs[16]; } co_block_q4_1;    /* buf_q4_1.rs:10-16  20 B */
 typedef struct { uint16_t d; uint16_t s; int8_t qs[32]; } co_block_q8_1;     /* buf_q8_1.rs:73-79  36 B */
 typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qs[128]; } co_block_q4_k; /* buf_q4_k.rs:14-21 144 B */
+/* the REFERENCE's field order (qs first), which is not ggml's (d, dmin, scales, qh, qs): buf_q5_k.rs:13-21, 176 B */
+typedef struct { uint8_t qs[128]; uint8_t qh[32]; uint8_t scales[12]; uint16_t d; uint16_t dmin; } co_block_q5_k;
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; } co_block_q6_k;       /* buf_q6_k.rs:11-18  210 B */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; } co_block_q8_k;                     /* buf_q8_k.rs:6-12  292 B */
 #pragma pack(pop)
@@ -68,6 +70,7 @@ void co_quantize_f32_q8_k(const float* x, size_t n, co_block_q8_k* out); /* buf_
 void co_quantize_f32_q4_0(const float* x, size_t n, co_block_q4_0* out); /* buf_q4_0.rs:90-124 */
 void co_quantize_f32_q4_1(const float* x, size_t n, co_block_q4_1* out); /* buf_q4_1.rs:94-124 */
 void co_quantize_f32_q4_k(const float* x, size_t n, co_block_q4_k* out); /* buf_q4_k.rs:111-190 */
+void co_quantize_f32_q5_k(const float* x, size_t n, co_block_q5_k* out); /* buf_q5_k.rs:123-227 */
 /* generic: quantize f32 -> `type` into raw bytes; returns 0 ok, -1 unsupported */
 int co_quantize(const float* x, size_t n, uint32_t type, void* out);
 
@@ -86,6 +89,8 @@ float co_vec_dot_q4_1_q8_1(const co_block_q4_1* a, const co_block_q8_1* b, size_
  * *n_overflow (may be NULL) counts products that do not fit i16 (debug builds panic there). */
 float co_vec_dot_q4_k_q8_k(const co_block_q4_k* a, const co_block_q8_k* b, size_t nblocks,
                            int i16_wrap, size_t* n_overflow);                                /* buf_q4_k.rs:192-277 */
+/* same i16 caveat as Q4_K (buf_q5_k.rs:282-285); the eight f32 lanes aux32 / sums of buf_q5_k.rs:287-318 are kept as written */
+float co_vec_dot_q5_k_q8_k(const co_block_q5_k* a, const co_block_q8_k* b, size_t nblocks, int i16_wrap, size_t* n_overflow); /* buf_q5_k.rs:229-325 */
 float co_vec_dot_q8_k_q8_k(const co_block_q8_k* a, const co_block_q8_k* b, size_t nblocks); /* buf_q8_k.rs:211-224 */
 float co_vec_dot_q6_k_q8_k(const co_block_q6_k* a, const co_block_q8_k* b, size_t nblocks); /* buf_q6_k.rs:183-234 (scalar only) */
 void co_quantize_f32_q6_k(const float* x, size_t n, co_block_q6_k* out);                    /* buf_q6_k.rs:109-181, util.rs:29-152 */
@@ -101,7 +106,8 @@ float co_vec_dot_q8_k_q8_k_avx2(const co_block_q8_k* a, const co_block_q8_k* b, 
 
 /* ---- exact integer part of the dots: one i32 per 32-element group (bit-exact gate) ----
  * Q4_0: sum_j (nib-8)*q8 ; Q8_0: sum q*q ; Q4_1: sum nib*q8 (unsigned nibbles);
- * Q4_K: per 32-group sum nib*q8 (unscaled, 8 per super-block); Q8_K: per 32-group sum q*q. */
+ * Q4_K: per 32-group sum nib*q8 (unscaled, 8 per super-block); Q5_K: the same with the fifth bit (sum q5*q8);
+ * Q8_K: per 32-group sum q*q. */
 int co_block_dots(const void* w, uint32_t wtype, const void* x, size_t n_elems, int32_t* out);
 
 /* ---- exp / gelu f16 tables: cpu_device.rs:108-125, buf_f32.rs:29-35, gelu.rs:19-22 ---- */

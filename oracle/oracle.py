@@ -23,10 +23,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
-F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q6_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 14, 15
-TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q8_1: "Q8_1", Q4_K: "Q4_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
-BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q6_K: 256, Q8_K: 256}
-BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q6_K: 210, Q8_K: 292}
+F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 13, 14, 15
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q8_1: "Q8_1", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292}
 ROPE_LLAMA, ROPE_NEOX = 0, 1
 
 
@@ -71,6 +71,7 @@ def lib() -> C.CDLL:
     sig("co_vec_dot_q4_0_q8_0", f32, vp, vp, sz)
     sig("co_vec_dot_q4_1_q8_1", f32, vp, vp, sz)
     sig("co_vec_dot_q4_k_q8_k", f32, vp, vp, sz, i32, vp)
+    sig("co_vec_dot_q5_k_q8_k", f32, vp, vp, sz, i32, vp)
     sig("co_vec_dot_q8_k_q8_k", f32, vp, vp, sz)
     sig("co_vec_dot_q6_k_q8_k", f32, vp, vp, sz)
     sig("co_vec_dot_f32_f32", f32, vp, vp, sz)
@@ -168,6 +169,8 @@ def vec_dot(w_raw: np.ndarray, wtyp: int, x_raw: np.ndarray, n_elems: int, avx2:
         return L.co_vec_dot_q4_1_q8_1(_p(w_raw), _p(x_raw), nb)
     if wtyp == Q4_K:
         return L.co_vec_dot_q4_k_q8_k(_p(w_raw), _p(x_raw), nb, 0, None)
+    if wtyp == Q5_K:
+        return L.co_vec_dot_q5_k_q8_k(_p(w_raw), _p(x_raw), nb, 0, None)
     if wtyp == Q6_K:
         return L.co_vec_dot_q6_k_q8_k(_p(w_raw), _p(x_raw), nb)
     if wtyp == Q8_K:
@@ -198,7 +201,7 @@ def block_dots(w_raw: np.ndarray, wtyp: int, x_raw: np.ndarray, n_elems: int) ->
 
 
 def rhs_dtype(wtyp: int) -> int:
-    return {F32: F32, F16: F16, Q8_0: Q8_0, Q4_0: Q8_0, Q8_1: Q8_1, Q4_1: Q8_1, Q8_K: Q8_K, Q4_K: Q8_K, Q6_K: Q8_K}[wtyp]
+    return {F32: F32, F16: F16, Q8_0: Q8_0, Q4_0: Q8_0, Q8_1: Q8_1, Q4_1: Q8_1, Q8_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K}[wtyp]
 
 
 def argmax_last(x: np.ndarray) -> int:

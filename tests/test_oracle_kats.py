@@ -199,6 +199,61 @@ def test_q4_k_vec_dot_q8_k_statistical():  # buf_q4_k.rs:303-315
     assert o.q4k_overflow_count(qa, qb, 256) == 0
 
 
+def test_q5_k_block_layout_and_round_trip():  # buf_q5_k.rs:13-21 (field order qs | qh | scales | d | dmin), :334-342
+    """The file's own quantize -> dequantize test: array_rmse (util.rs:300-316: sqrt(sum of squares) / n) < 0.002 on
+    generate_data(0.0, 1024); pins make_qkx1_quants(32, 31, .., 9), the 6-bit scale packing, the qh bit layout and dequantize."""
+    import ctypes as C
+
+    assert o.BLOCK_BYTES[o.Q5_K] == 176 and o.lib().co_block_bytes(o.Q5_K) == 176 and o.lib().co_block_elems(o.Q5_K) == 256
+    data = _generate_data(0.0, 1024)
+    q = o.quantize(data, o.Q5_K)
+    assert q.view(np.uint8).size == 4 * 176
+    deq = o.dequantize(q, o.Q5_K, 0, 1024)
+    diff = np.sqrt(np.sum((deq - data).astype(np.float32) ** 2, dtype=np.float32)) / np.float32(1024)
+    assert diff < 0.002, diff
+    # every level of a block uses the fifth bit somewhere: the high-bit plane is exercised
+    blk = q.view(np.uint8).reshape(4, 176)
+    assert np.any(blk[:, 128:160] != 0)
+    # a hand-made block: d = 1, dmin = 0.5, scales[j] = j + 1, mins[j] = 1 (j < 4: plain 6-bit fields), all low nibbles 3,
+    # fifth bit set for the FIRST half of chunk 0 only -> elements 0..31 = 1 * (3 + 16) - 0.5, elements 32..63 = 2 * 3 - 0.5
+    b = np.zeros(176, dtype=np.uint8)
+    b[0:128] = 0x33
+    b[128:160] = 0x01
+    b[160:164] = [1, 2, 3, 4]
+    b[164:168] = [1, 1, 1, 1]
+    b[172:174] = np.array([1.0], dtype=np.float16).view(np.uint8)
+    b[174:176] = np.array([0.5], dtype=np.float16).view(np.uint8)
+    d = o.dequantize(b, o.Q5_K, 0, 256)
+    assert np.all(d[0:32] == np.float32(18.5)) and np.all(d[32:64] == np.float32(5.5))
+    assert np.all(d[64:96] == np.float32(3 * 3 - 0.5)) and np.all(d[96:128] == np.float32(4 * 3 - 0.5))
+
+
+def test_q5_k_vec_dot_q8_k_statistical():  # buf_q5_k.rs:344-355
+    a = _generate_data(0.0, 1024)
+    b = _generate_data(1.0, 1024)
+    qa = o.quantize(a, o.Q5_K)
+    qb = o.quantize(b, o.Q8_K)
+    dot = o.vec_dot(qa, o.Q5_K, qb, 1024)
+    ref = np.float32(0.0)
+    for x, y in zip(a, b):
+        ref = np.float32(ref + x * y)
+    assert abs(ref - dot) / 1024 < 0.02
+    # the dot against the dequantized weights (pinned above): the integer path agrees with the float one
+    deq_a = o.dequantize(qa, o.Q5_K, 0, 1024).astype(np.float64)
+    deq_b = o.dequantize(qb, o.Q8_K, 0, 1024).astype(np.float64)
+    assert abs(float(deq_a @ deq_b) - dot) <= 1e-4 * float(np.abs(deq_a) @ np.abs(deq_b))
+    # per-group integers of the bit-exact gate == a numpy unpack of the same bytes
+    blk = qa.view(np.uint8).reshape(4, 176)
+    q8 = qb.view(np.uint8).reshape(4, 292)[:, 4:260].view(np.int8).astype(np.int64)
+    got = o.block_dots(qa, o.Q5_K, qb, 1024).reshape(4, 8)
+    for i in range(4):
+        qs, qh = blk[i, 0:128].astype(np.int64), blk[i, 128:160].astype(np.int64)
+        for c in range(4):
+            lo = (qs[32 * c:32 * c + 32] & 15) + 16 * ((qh >> (2 * c)) & 1)
+            hi = (qs[32 * c:32 * c + 32] >> 4) + 16 * ((qh >> (2 * c + 1)) & 1)
+            assert got[i, 2 * c] == int(lo @ q8[i, 64 * c:64 * c + 32]) and got[i, 2 * c + 1] == int(hi @ q8[i, 64 * c + 32:64 * c + 64])
+
+
 def test_nearest_i32():  # util.rs:328-349
     cases = [(3_256_291.8, 3256292), (234_730.28, 234730), (3_271_636.3, 3271636), (143_427.25, 143427),
              (624_284.7, 624285), (601459.0, 601459), (929_129.4, 929129), (196_503.23, 196503),

@@ -187,6 +187,145 @@ __global__ __launch_bounds__(64 * WPB) void k_ticket(Planes wg, Planes wu, ActQ8
   }
 }
 
+// ---- V2: the production geometry (448 x 1024) with the activation planes staged in LDS and the wave's first round of weight
+// blocks requested BEFORE the staging (they depend on nothing: their HBM round trip runs under the staging and its barrier) ------
+template <bool PREFETCH>
+__global__ __launch_bounds__(1024) void k_prod_ldsx(Planes wg, Planes wu, ActQ8_0 act, const unsigned short* __restrict__ exp_tab,
+                                                    signed char* __restrict__ q, unsigned short* __restrict__ d, int* __restrict__ isum,
+                                                    int nb) {
+  using F = BlockFmt<CRABML_HIP_Q4_0>;
+  __shared__ float hv[32];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_planes[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int row = blk * 32 + wave * 2;
+  F::Blk p0, p1, p2, p3;
+  if constexpr (PREFETCH) {
+    p0 = F::load(wg.q, wg.d, (size_t)row, nb, lane);
+    p1 = F::load(wu.q, wu.d, (size_t)row, nb, lane);
+    p2 = F::load(wg.q, wg.d, (size_t)row + 1, nb, lane);
+    p3 = F::load(wu.q, wu.d, (size_t)row + 1, nb, lane);
+  }
+  const int k = nb * 32;
+  i32x4* sq = (i32x4*)lds_planes;
+  unsigned short* sd = (unsigned short*)(lds_planes + k);
+  int* ss = (int*)(lds_planes + k + ((nb * 2 + 15) & ~15));
+  for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.q[i];
+  for (int i = threadIdx.x; i < nb; i += 1024) {
+    sd[i] = act.d[i];
+    ss[i] = act.isum[i];
+  }
+  __syncthreads();
+  const ActQ8_0 a{sq, sd, ss};
+  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+  int u = lane;
+  if constexpr (PREFETCH) {
+    const XUnit x = F::loadx(a, u);
+    g0 += F::term(p0, x);
+    u0 += F::term(p1, x);
+    g1 += F::term(p2, x);
+    u1 += F::term(p3, x);
+    u += 64;
+  }
+  for (; u < nb; u += 64) {
+    F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, u);
+    F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, u);
+    F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
+    F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
+    const XUnit x = F::loadx(a, u);
+    g0 += F::term(bg0, x);
+    u0 += F::term(bu0, x);
+    g1 += F::term(bg1, x);
+    u1 += F::term(bu1, x);
+  }
+  g0 = wave_sum_f32(g0);
+  u0 = wave_sum_f32(u0);
+  g1 = wave_sum_f32(g1);
+  u1 = wave_sum_f32(u1);
+  if (lane == 0) {
+    hv[wave * 2] = silu_mul(g0, u0, exp_tab);
+    hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const QLane o = quant_lane32<false>(hv[threadIdx.x], true);
+    q[blk * 32 + threadIdx.x] = o.q;
+    if (threadIdx.x == 0) {
+      d[blk] = o.d;
+      isum[blk] = o.aux;
+    }
+  }
+}
+// the production kernel with BOTH rounds of weight blocks (k = 4096: two per row and lane) requested up front
+__global__ __launch_bounds__(1024) void k_prod_all_up_front(Planes wg, Planes wu, ActQ8_0 act, const unsigned short* __restrict__ exp_tab,
+                                                            signed char* __restrict__ q, unsigned short* __restrict__ d,
+                                                            int* __restrict__ isum, int nb) {
+  using F = BlockFmt<CRABML_HIP_Q4_0>;
+  __shared__ float hv[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int row = blk * 32 + wave * 2;
+  F::Blk p[2][4];
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int u = lane + 64 * it < nb ? lane + 64 * it : nb - 1;
+    p[it][0] = F::load(wg.q, wg.d, (size_t)row, nb, u);
+    p[it][1] = F::load(wu.q, wu.d, (size_t)row, nb, u);
+    p[it][2] = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
+    p[it][3] = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
+  }
+  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int u = lane + 64 * it;
+    if (u < nb) {
+      const XUnit x = F::loadx(act, u);
+      g0 += F::term(p[it][0], x);
+      u0 += F::term(p[it][1], x);
+      g1 += F::term(p[it][2], x);
+      u1 += F::term(p[it][3], x);
+    }
+  }
+  g0 = wave_sum_f32(g0);
+  u0 = wave_sum_f32(u0);
+  g1 = wave_sum_f32(g1);
+  u1 = wave_sum_f32(u1);
+  if (lane == 0) {
+    hv[wave * 2] = silu_mul(g0, u0, exp_tab);
+    hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const QLane o = quant_lane32<false>(hv[threadIdx.x], true);
+    q[blk * 32 + threadIdx.x] = o.q;
+    if (threadIdx.x == 0) {
+      d[blk] = o.d;
+      isum[blk] = o.aux;
+    }
+  }
+}
+
+// ---- exp by arithmetic instead of the 65536-entry f16 table (cpu_device.rs:108-124: table[x] = f16(expf(f32(x)))) ------------------
+// The table lookup is a dependent L2 round trip at the tail of gate/up (SiLU) and inside the softmax of every attention launch.
+// Candidates evaluated for ALL 65536 f16 bit patterns against the host-built table: (a) f16(expf(x)), (b) f16((float)exp((double)x)),
+// (c) f16(__expf(x)).  Any candidate with zero mismatches could replace the lookup bit for bit.
+__global__ void k_exp_candidates(const unsigned short* __restrict__ tab, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 65536) return;
+  const float x = h2f((unsigned short)i);
+  const unsigned short a = f2h(expf(x)), b = f2h((float)exp((double)x)), c = f2h(__expf(x));
+  if (a != tab[i]) atomicAdd(bad + 0, 1);
+  if (b != tab[i]) atomicAdd(bad + 1, 1);
+  if (c != tab[i]) atomicAdd(bad + 2, 1);
+  // restricted to what the decode step looks up: softmax arguments x <= 0 and SiLU arguments (any finite x)
+  if (x <= 0.f && a != tab[i]) atomicAdd(bad + 3, 1);
+  if (x <= 0.f && b != tab[i]) atomicAdd(bad + 4, 1);
+  // harness check: a candidate that is off by 5e-4 must show up
+  if (f2h(expf(x) * 1.0005f) != tab[i]) atomicAdd(bad + 5, 1);
+  // ... and one 2 ulp (f32) off: what a merely "fast" exp would look like
+  if (f2h(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, expf(x)) + 2u)) != tab[i]) atomicAdd(bad + 6, 1);
+}
+
 // compare two (q | d | isum) triples, count mismatching blocks
 __global__ void k_cmp(const signed char* q0, const unsigned short* d0, const int* s0, const signed char* q1, const unsigned short* d1,
                       const int* s1, int nblk, int* bad) {
@@ -341,6 +480,26 @@ int main(int argc, char** argv) {
     k_prod<<<nblk, 1024, 0, st>>>(planes(c, 0), planes(c, 1), act, exp_tab, q1, d1, s1, nb);
   }, true);
   const size_t ldsx = off_s + nb * 4;
+  bench("V2 prod 448 x 1024 + LDS activations (staged first)", [&](int c) {
+    k_prod_ldsx<false><<<nblk, 1024, ldsx, st>>>(planes(c, 0), planes(c, 1), act, exp_tab, q1, d1, s1, nb);
+  }, true);
+  bench("V2 prod 448 x 1024 + LDS activations, weights requested first", [&](int c) {
+    k_prod_ldsx<true><<<nblk, 1024, ldsx, st>>>(planes(c, 0), planes(c, 1), act, exp_tab, q1, d1, s1, nb);
+  }, true);
+  bench("V3 prod 448 x 1024, both rounds of weights up front", [&](int c) {
+    k_prod_all_up_front<<<nblk, 1024, 0, st>>>(planes(c, 0), planes(c, 1), act, exp_tab, q1, d1, s1, nb);
+  }, true);
+  {
+    int* badc;
+    CK(hipMalloc(&badc, 7 * 4));
+    CK(hipMemset(badc, 0, 7 * 4));
+    k_exp_candidates<<<256, 256, 0, st>>>(exp_tab, badc);
+    int hb[7];
+    CK(hipMemcpyAsync(hb, badc, 7 * 4, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    printf("# exp candidates vs the host table over all 65536 f16 inputs: f16(expf) %d mismatches, f16(exp double) %d, f16(__expf) %d; "
+           "x <= 0 only: expf %d, double %d; harness check: expf * 1.0005 %d mismatches, expf + 2 ulp %d\n", hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6]);
+  }
 #define RUN(WPB, MODE, XCD, LDSX, label)                                                                                              \
   bench(label, [&](int c) {                                                                                                            \
     Ticket t{gran, tick, fault, epoch++};                                                                                              \

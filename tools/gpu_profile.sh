@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="--steps 24 --warmup 8 --repeats 1 --no-cpu-baseline --no-parity-check --no-context --no-prefill $*"
+B="--steps 24 --warmup 8 --repeats 1 --no-cpu-baseline --no-parity-check --no-context --no-prefill --no-c3 --no-gemv-points $*"
 rm -rf $OUT/prof_$TAG $OUT/pmc_$TAG
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -- python $REPO/bench.py $B > $OUT/bench_under_rocprof_$TAG.json 2> $OUT/prof_$TAG.err
 DB=$(find $OUT/prof_$TAG -name "*_results.db" | head -1)
@@ -15,7 +15,7 @@ echo "# (under the tracer the graph replay is serialized per kernel node: the pe
 echo >> $OUT/kernel_trace_$TAG.md
 python $REPO/tools/rocpd_summary.py "$DB" >> $OUT/kernel_trace_$TAG.md 2>> $OUT/prof_$TAG.err
 head -22 $OUT/kernel_trace_$TAG.md
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -- python $REPO/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-parity-check --no-context --no-prefill $* > /dev/null 2>> $OUT/prof_$TAG.err
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -- python $REPO/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-parity-check --no-context --no-prefill --no-c3 --no-gemv-points $* > /dev/null 2>> $OUT/prof_$TAG.err
 DB2=$(find $OUT/pmc_$TAG -name "*_results.db" | head -1)
 cd $REPO && python tools/pmc_traffic.py "$DB2" $OUT/pmc_fetch_size_$TAG.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic_$TAG.json
 # keep the merge small
