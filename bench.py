@@ -716,8 +716,23 @@ def main():
                        "prompt_tokens_per_s": round(n_p / best, 1),
                        "vs_token_loop": round(n_p / best / (total_tokens / elapsed_max / args.gpus), 2),
                        "note": "llama2.rs:124-129 token loop as (rows, k) matmul_vec passes on the int8 MFMA GEMM + causal "
-                               "attention; host clock around the blocking call, best of 2"}
+                               "attention (fast step: flash attention on the f16 matrix cores); host clock around the blocking call, best of 2"}
             del pr
+            # a long prompt: attention is O(n^2) there (the fast step runs it on the f16 matrix cores, k_attn_flash_rows)
+            n_l = 4096
+            if n_l + 8 <= shape.seq_len:
+                pl = ca.HipLlamaRunner(conf, weights, dev, n_l + 8, True)
+                ltoks = [(7 * i + 1) % shape.vocab for i in range(n_l)]
+                lbest = None
+                for _ in range(2):
+                    pl.reset()
+                    dev.sync()
+                    tp0 = time.perf_counter()
+                    pl.prefill(ltoks)
+                    dtp = time.perf_counter() - tp0
+                    lbest = dtp if lbest is None else min(lbest, dtp)
+                prefill["long_prompt"] = {"prompt_tokens": n_l, "ms": round(lbest * 1e3, 2), "prompt_tokens_per_s": round(n_l / lbest, 1)}
+                del pl
         except Exception as e:
             prefill = {"error": repr(e)}
 

@@ -148,6 +148,7 @@ struct crabml_hip_llama {
   // variant 1 of the FAST step: k_attn_flash (split-KV, f32 accumulation) instead of the three exact kernels
   bool attn_flash = false;
   bool flash_ticket = false;    // A/B: the merge by the last-arriving workgroup inside k_attn_flash instead of its own launch
+  bool attn_flash_rows = false; // the batched prefill's attention runs k_attn_flash_rows (fast step, f16 cache, head_dim 64 / 128)
   int flash_S = 0;              // position slices (workgroups) per kv head
   int flash_min_rows = FLASH_MIN_ROWS;  // cached rows per active slice, at least
   float* flash_part = nullptr;  // [n_kv_l][flash_S][G][hd + 2] partial {O, m, l}
@@ -1035,7 +1036,17 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const int pairs = (dim + 2 * kv_dim) / 2;
     k_qkv_epi_rows<<<dim3((pairs + 255) / 256, rows), 256, 0, st>>>(c->pf_q, c->pf_k, c->pf_v, e);
     int along = 0;
-    if (!launch_attn_tile(c, l, (int)B, (int)pos0)) {
+    if (c->attn_flash_rows && kv16) {
+      // fast step: causal flash attention on the f16 matrix cores (k_attn_flash_rows; the deviation stated for k_attn_flash)
+      const dim3 fg((unsigned)((B + 63) / 64), (unsigned)n_heads);
+      if (hd == 128)
+        k_attn_flash_rows<128><<<fg, 256, flash_rows_lds_bytes(128), st>>>((const float*)c->pf_qr, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], pos_d,
+                                                   c->pf_attn, n_heads, n_kv, seq_cap, (int)B);
+      else
+        k_attn_flash_rows<64><<<fg, 256, flash_rows_lds_bytes(64), st>>>((const float*)c->pf_qr, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], pos_d,
+                                                  c->pf_attn, n_heads, n_kv, seq_cap, (int)B);
+      along = 1;
+    } else if (!launch_attn_tile(c, l, (int)B, (int)pos0)) {
       along = launch_attn_long_rows(c, l, (int)B);  // past 1024 positions: the long-context kernels, rows in grid.y
       if (along < 0) return CRABML_HIP_UNEXPECTED;
     } else {
@@ -1504,6 +1515,12 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       if (fn != nullptr && raise_dyn_lds(dev, (const void*)fn, (int)flash_lds_bytes((int)grp, (int)hd)) == hipSuccess) {
         int S = dev->n_cu / (int)n_kv_l;
         S = S < 1 ? 1 : S > FLASH_MAX_SLICES ? FLASH_MAX_SLICES : S;
+        if (const char* hooks = getenv("CRABML_HIP_TEST_HOOKS"))  // tuning hook (tools/flash_sweep.py): slices per kv head in the grid
+          if (hooks[0] == '1')
+            if (const char* e = getenv("CRABML_HIP_FLASH_SLICES")) {
+              const int v = atoi(e);
+              if (v >= 1 && v <= FLASH_MAX_SLICES) S = v;
+            }
         c->flash_S = S;
         if (const char* hooks = getenv("CRABML_HIP_TEST_HOOKS"))  // tuning hook (tools/flash_sweep.py); armed like ASSUME_CUS
           if (hooks[0] == '1')
@@ -1515,6 +1532,12 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
         A(n_kv_l * 4, (void**)&c->flash_tick);
         if (rc == 0 && hipMemsetAsync(c->flash_tick, 0, n_kv_l * 4, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
         c->attn_flash = rc == 0;
+        // the prompt pass's causal attention of the fast step (k_attn_flash_rows): 70 KB of LDS at head_dim 128
+        if (c->attn_flash && (hd == 128 || hd == 64) &&
+            raise_dyn_lds(dev, hd == 128 ? (const void*)k_attn_flash_rows<128> : (const void*)k_attn_flash_rows<64>,
+                          (int)flash_rows_lds_bytes((int)hd)) == hipSuccess)
+          c->attn_flash_rows = true;
+        (void)hipGetLastError();
         // k_attn_flash + merge overtake the staged one-workgroup kernel between 64 and 96 cached positions (8B shape, per layer:
         // 51.0 vs 51.6 us at 64, 52.2 vs 51.4 at 96, 59.0 vs 51.8 at 224; profiles/r04_flash_sweep.log)
         if (c->attn_flash && g.attn_long_from == 0) c->attn_long_from = 96;
@@ -1848,6 +1871,45 @@ int crabml_hip_debug_flash_attention(crabml_hip_device_t* dev, const float* q, c
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(base);
   if (e != hipSuccess) return hip_fail(dev, e, "debug_flash_attention", __FILE__, __LINE__);
+  return 0;
+}
+
+// parity hook (crabml_hip_debug.h): the fast prompt pass's causal attention kernel by itself
+int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float* q, const uint16_t* k, const uint16_t* v, size_t n_heads,
+                                          size_t n_kv, size_t head_dim, size_t pos0, size_t rows, size_t seq_cap, float* out) {
+  if (!dev || !q || !k || !v || !out || rows == 0 || n_kv == 0 || n_heads % n_kv != 0 || seq_cap < pos0 + rows) return CRABML_HIP_BAD_INPUT;
+  if (head_dim != 128 && head_dim != 64) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "debug_flash_attention_rows: head_dim 64 / 128");
+  CH_USE(dev);
+  if (raise_dyn_lds(dev, head_dim == 128 ? (const void*)k_attn_flash_rows<128> : (const void*)k_attn_flash_rows<64>,
+                    (int)flash_rows_lds_bytes((int)head_dim)) != hipSuccess)
+    CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "debug_flash_attention_rows: LDS");
+  const size_t seq = seq_cap;
+  const size_t nq = rows * n_heads * head_dim * 4, nkv = n_kv * seq * head_dim * 2;
+  const size_t o_q = 0, o_k = align_up(o_q + nq, 256), o_v = align_up(o_k + nkv, 256), o_out = align_up(o_v + nkv, 256),
+               o_pos = align_up(o_out + nq, 256), total = o_pos + 256;
+  char* base = nullptr;
+  CH_HIP(dev, hipMalloc((void**)&base, total));
+  hipStream_t st = dev->stream;
+  const int p0 = (int)pos0;
+  hipError_t e = hipMemcpyAsync(base + o_q, q, nq, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(base + o_k, k, nkv, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(base + o_v, v, nkv, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(base + o_pos, &p0, 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) {
+    const dim3 fg((unsigned)((rows + 63) / 64), (unsigned)n_heads);
+    if (head_dim == 128)
+      k_attn_flash_rows<128><<<fg, 256, flash_rows_lds_bytes(128), st>>>((const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
+                                                 (const int*)(base + o_pos), (float*)(base + o_out), (int)n_heads, (int)n_kv, (int)seq, (int)rows);
+    else
+      k_attn_flash_rows<64><<<fg, 256, flash_rows_lds_bytes(64), st>>>((const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
+                                                (const int*)(base + o_pos), (float*)(base + o_out), (int)n_heads, (int)n_kv, (int)seq, (int)rows);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, base + o_out, nq, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(base);
+  if (e != hipSuccess) return hip_fail(dev, e, "debug_flash_attention_rows", __FILE__, __LINE__);
   return 0;
 }
 

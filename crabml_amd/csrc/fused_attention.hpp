@@ -1145,6 +1145,162 @@ __global__ __launch_bounds__(HD) void k_attn_flash_merge(const float* __restrict
   }
 }
 
+// ---- fast-mode attention of the batched prefill: causal flash attention on the f16 matrix cores ---------------------------------
+// The prompt pass's exact attention (k_attn_tile / the three long-context kernels with a row dimension) runs the reference's f16
+// chains per (row, head, column): 137 us per layer at 512 prompt rows, most of a 4096-token prompt.  The FAST step (same switch and the
+// same stated deviation as k_attn_flash: f32 exp and accumulation; additionally the probabilities enter the second
+// matrix product as f16, as the reference's do) runs it as one launch on v_mfma_f32_16x16x32_f16 / 16x16x16_f16:
+//   workgroup = (64 prompt rows, head); wave = 16 of the rows; per 16 cached positions (two such chunks per step)
+//     S^T[pos][row] = K[pos][:] . Q[row][:]      A = 16 K rows (lane: position l % 16, dims 32 ks + 8 (l / 16) .. + 8: one 16-byte
+//                                                LDS read), B = the wave's q rows, rounded to f16 once (batch_matmul.rs:39)
+//     online softmax per q row = per C column n = l % 16: a lane holds positions 4 (l / 16) .. + 4 of its row; the running maximum
+//                                                is agreed across the four lane groups (two cross-lane steps), the row sum stays
+//                                                per lane until the end; causal mask p <= pos0 + row on the C registers
+//     O^T[dim][row] += V^T[dim][pos] . P^T[pos][row]   B = the S^T registers themselves (exp'd, packed to f16): the C layout of one
+//                                                product IS the B layout of the next, no transpose; A = V^T from an LDS tile that the
+//                                                workgroup fills TRANSPOSED
+//   K and V tiles of 64 positions go through LDS (two buffers each, one barrier per fill): the next tile's loads are requested
+//   before the current one is multiplied, so their round trip runs under a whole tile of matrix work.
+// GQA: the G heads of a kv head are separate workgroups (their K / V reads meet in L2).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define FLASH_ROWS_BN 64                   // cached positions per V^T fill
+#define FLASH_ROWS_VSTR (FLASH_ROWS_BN + 4)  // halfs per V^T row: 8-byte aligned fragments, rows 34 banks apart
+#define FLASH_ROWS_KPAD 8                   // halfs of padding per K row in LDS (16-byte aligned fragments, rows 4 banks apart)
+__host__ __device__ inline size_t flash_rows_lds_bytes(int hd) {
+  return (size_t)2 * ((size_t)hd * FLASH_ROWS_VSTR + (size_t)FLASH_ROWS_BN * (hd + FLASH_ROWS_KPAD)) * 2;
+}
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict__ q, const unsigned short* __restrict__ kc,
+                                                         const unsigned short* __restrict__ vc, const int* __restrict__ pos_d,
+                                                         float* __restrict__ out, int n_heads, int n_kv, int seq_cap, int B) {
+  constexpr int KS = HD / 32, DT = HD / 16, BN = FLASH_ROWS_BN, VSTR = FLASH_ROWS_VSTR, KSTR = HD + FLASH_ROWS_KPAD, NP = HD / 32;
+  // LDS, two buffers each: V^T tile [HD][VSTR] (filled transposed), K tile [BN][KSTR] (as the cache holds it)
+  extern __shared__ __attribute__((aligned(16))) unsigned short fr_lds[];
+  unsigned short* vt0 = fr_lds;
+  unsigned short* kt0 = fr_lds + 2 * HD * VSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, j = head / (n_heads / n_kv);
+  const int pos0 = *pos_d;
+  const int row_wg = blockIdx.x * 64, row_w = row_wg + wave * 16;
+  const int row = row_w + n < B ? row_w + n : B - 1;  // (rows past the batch recompute the last row; never stored)
+  // this wave's q rows as the B operand: lane (row n, dims 32 ks + 8 g .. + 8)
+  f16x8 qb[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    const f32x4* qp = (const f32x4*)(q + ((size_t)row * n_heads + head) * HD + 32 * ks + 8 * g);
+    const f32x4 a = qp[0], b = qp[1];
+    qb[ks] = f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+  }
+  const unsigned short* kb = kc + (size_t)j * seq_cap * HD;
+  const unsigned short* vb = vc + (size_t)j * seq_cap * HD;
+  const int last_wg = pos0 + (row_wg + 63 < B ? row_wg + 63 : B - 1);  // last cached position any row of the workgroup sees
+  const int last_w = pos0 + (row_w + 15 < B ? row_w + 15 : B - 1);     // ... any row of this wave
+  const int my_last = pos0 + row;                                      // ... this lane's row
+  const int ntiles = last_wg / BN + 1;
+  f32x4 acc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+  // staging: thread t moves NP 16-byte pieces of the K tile and of the V tile per fill (piece = 8 dims of one position); a whole
+  // tile of compute lies between the request and the commit
+  i32x4 vreg[NP], kreg[NP];
+  auto issue = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+      const int piece = tid + 256 * u, pr = piece / (HD / 8), pc = piece % (HD / 8);
+      int pos = tile * BN + pr;
+      pos = pos < seq_cap ? pos : seq_cap - 1;  // (past the cache only in its last tile; those positions are dead)
+      kreg[u] = *(const i32x4*)(kb + (size_t)pos * HD + 8 * pc);
+      vreg[u] = *(const i32x4*)(vb + (size_t)pos * HD + 8 * pc);
+    }
+  };
+  auto commit = [&](int buf, int tile) {
+    unsigned short* vt = vt0 + buf * HD * VSTR;
+    unsigned short* kt = kt0 + buf * BN * KSTR;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+      const int piece = tid + 256 * u, pr = piece / (HD / 8), pc = piece % (HD / 8);
+      // positions no row of the workgroup sees hold whatever the allocator or an earlier sequence left in the cache: their
+      // probabilities are exactly 0, but 0 x NaN / Inf is not -- V enters the product as zeros there (K: the scores are masked)
+      const bool live = tile * BN + pr <= last_wg;
+      *(i32x4*)(kt + pr * KSTR + 8 * pc) = kreg[u];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned w = live ? (unsigned)vreg[u][i] : 0u;
+        vt[(8 * pc + 2 * i) * VSTR + pr] = (unsigned short)(w & 0xffffu);
+        vt[(8 * pc + 2 * i + 1) * VSTR + pr] = (unsigned short)(w >> 16);
+      }
+    }
+  };
+  issue(0);
+  commit(0, 0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile++) {
+    const int buf = tile & 1;
+    const unsigned short* vt = vt0 + buf * HD * VSTR;
+    const unsigned short* kt = kt0 + buf * BN * KSTR;
+    if (tile + 1 < ntiles) issue(tile + 1);
+#pragma unroll
+    for (int c2 = 0; c2 < BN / 32; c2++) {
+      // 32 positions per step as two 16-position chunks a / b: two independent S^T chains (a lone wave per SIMD has nothing else
+      // to hide an MFMA's latency under), ONE agreement on the running maximum, and the second product on 16x16x32 with k-slot
+      // (g, i) = position 4 g + i of chunk a, (g, 4 + i) = the same of chunk b -- for both operands
+      const int ca0 = tile * BN + 32 * c2, cb0 = ca0 + 16;
+      if (ca0 > last_w) break;  // wave-uniform: no row of this wave sees the step (nor any later one)
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)(kt + (32 * c2 + n) * KSTR + 32 * ks + 8 * g), qb[ks], sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)(kt + (32 * c2 + 16 + n) * KSTR + 32 * ks + 8 * g), qb[ks], sb, 0, 0, 0);
+      }
+      float cm = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // causal mask (also: dead cache rows, whatever they hold)
+        if (ca0 + 4 * g + i > my_last) sa[i] = -INFINITY;
+        if (cb0 + 4 * g + i > my_last) sb[i] = -INFINITY;
+        cm = fmaxf(cm, fmaxf(sa[i], sb[i]));
+      }
+      cm = fmaxf(cm, __shfl_xor(cm, 16));
+      cm = fmaxf(cm, __shfl_xor(cm, 32));
+      const float mn = fmaxf(m, cm);  // finite from the first step on: position 0 is visible to every row
+      if (__any(mn > m)) {            // the running maximum of some row moved: rescale (rare after the first steps)
+        const float alpha = __expf(m - mn);
+        lsum *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) acc[dt] = acc[dt] * alpha;
+        m = mn;
+      }
+      f16x8 pT;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const _Float16 pa = (_Float16)__expf(sa[i] - m), pb = (_Float16)__expf(sb[i] - m);
+        pT[i] = pa;
+        pT[4 + i] = pb;
+        lsum += (float)pa + (float)pb;  // the normalizer sums what the second product multiplies
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const unsigned short* vr = vt + (16 * dt + n) * VSTR + 32 * c2 + 4 * g;
+        const f16x4 va = *(const f16x4*)vr, vb2 = *(const f16x4*)(vr + 16);
+        const f16x8 vf = {va[0], va[1], va[2], va[3], vb2[0], vb2[1], vb2[2], vb2[3]};
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pT, acc[dt], 0, 0, 0);
+      }
+    }
+    if (tile + 1 < ntiles) commit(buf ^ 1, tile + 1);  // those buffers were last read one tile ago (barrier below)
+    __syncthreads();
+  }
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  if (row_w + n < B) {
+    const float inv = 1.0f / lsum;
+    float* o = out + ((size_t)(row_w + n) * n_heads + head) * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) *(f32x4*)(o + 16 * dt + 4 * g) = acc[dt] * inv;
+  }
+}
+
 // The same PV pass for R consecutive prompt rows per workgroup (batched prefill past 1024 positions): row r of the tile
 // sees seq0 + r cached positions.  The V tile is fetched and transposed ONCE for the R rows x G heads -- every lane of the
 // workgroup carries a chain (R * G * 16 = 256 for Llama-3's G = 4, R = 4) instead of 64 of 256, and V is read R times less

@@ -97,6 +97,20 @@ PYBIND11_MODULE(_host, m) {
                                                       out.mutable_data(), out2.mutable_data()));
              return py::make_tuple(out, out2);
            })
+      .def("debug_flash_attention_rows",
+           [](HipTensorDevice& d, py::array_t<float, py::array::c_style | py::array::forcecast> q,
+              py::array_t<uint16_t, py::array::c_style | py::array::forcecast> k,
+              py::array_t<uint16_t, py::array::c_style | py::array::forcecast> v, size_t n_heads, size_t n_kv, size_t head_dim,
+              size_t pos0, size_t rows) {
+             if (n_kv == 0 || head_dim == 0 || (size_t)q.size() != rows * n_heads * head_dim || (size_t)k.size() % (n_kv * head_dim) != 0 ||
+                 k.size() != v.size())
+               throw Error(ErrorKind::BadInput, "debug_flash_attention_rows: array sizes");
+             const size_t seq_cap = (size_t)k.size() / (n_kv * head_dim);  // k, v: [n_kv][seq_cap][head_dim]
+             py::array_t<float> out(rows * n_heads * head_dim);
+             d.check(crabml_hip_debug_flash_attention_rows(d.raw(), q.data(), k.data(), v.data(), n_heads, n_kv, head_dim, pos0, rows, seq_cap,
+                                                           out.mutable_data()));
+             return out;
+           })
       .def("prof_read_launches",
            [](HipTensorDevice& d, size_t cap) {
              std::vector<float> ms(cap);

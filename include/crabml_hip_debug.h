@@ -52,6 +52,13 @@ int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_
 int crabml_hip_debug_flash_attention(crabml_hip_device_t* dev, const float* q, const uint16_t* k, const uint16_t* v, size_t n_heads,
                                      size_t n_kv, size_t head_dim, size_t seq, size_t slices, float* out, float* out2);
 
+/* The fast prompt pass's causal attention (k_attn_flash_rows: flash attention on the f16 matrix cores) by itself.  q: rows *
+ * n_heads * head_dim f32 (row r is the prompt row at position pos0 + r); k, v: [n_kv][seq_cap][head_dim] f16 bits (the cache
+ * after the pass's appends: positions 0 .. pos0 + rows - 1 are live, whatever lies beyond must not matter); out: rows * n_heads *
+ * head_dim f32, row r = softmax(q_r k^T over positions 0 .. pos0 + r) v.  head_dim 64 / 128.  Host pointers; blocks. */
+int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float* q, const uint16_t* k, const uint16_t* v, size_t n_heads,
+                                          size_t n_kv, size_t head_dim, size_t pos0, size_t rows, size_t seq_cap, float* out);
+
 /* ---- A/B switches and test hooks of the fused decode step (crabml_hip_llama_config_t.flags; the public bits are in
  * crabml_hip.h).  Every variant pair is bit-identical unless its comment says otherwise. */
 #define CRABML_HIP_LLAMA_NO_NORM_EPILOGUE 4 /* A/B: keep RMSNorm + quantize as its own launch (fast mode runs it in

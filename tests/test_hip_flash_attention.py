@@ -66,3 +66,52 @@ def test_flash_attention_merge_edge_cases(ca, kind):
     for seq in (130, 513, 3000):
         err = run_case(ca, dev, rng, 32, 8, 128, seq, 32, spread=4.0, kind=kind)
         assert err <= 2e-5, (kind, seq, err)
+
+
+def f64_causal_attention(q, k, v, n_heads, n_kv, hd, pos0, rows):
+    """row r (position pos0 + r) over the cached positions 0 .. pos0 + r; the kernel rounds the probabilities to f16 before
+    the second product (as the reference does, batch_matmul.rs:39): restated here, so that the bound measures the kernel"""
+    q16 = q.astype(np.float16).astype(np.float64).reshape(rows, n_heads, hd)
+    kf = k.view(np.float16).astype(np.float64).reshape(n_kv, pos0 + rows, hd)
+    vf = v.view(np.float16).astype(np.float64).reshape(n_kv, pos0 + rows, hd)
+    grp = n_heads // n_kv
+    out = np.zeros((rows, n_heads, hd))
+    for h in range(n_heads):
+        s = q16[:, h, :] @ kf[h // grp].T                      # rows x positions
+        mask = np.arange(pos0 + rows)[None, :] > (pos0 + np.arange(rows))[:, None]
+        s[mask] = -np.inf
+        p = np.exp(s - s.max(axis=1, keepdims=True))
+        out[:, h, :] = (p / p.sum(axis=1, keepdims=True)) @ vf[h // grp]
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("n_heads,n_kv,hd", [(32, 8, 128), (8, 8, 128), (8, 1, 128), (8, 2, 64), (4, 4, 64)])
+def test_flash_prefill_attention_equals_float64_arithmetic(ca, n_heads, n_kv, hd):
+    """k_attn_flash_rows -- the fast prompt pass's causal attention on the f16 matrix cores -- against float64 softmax(q K^T) V
+    on the same f16 inputs: whole and ragged 64-row workgroups, batches that start in the middle of the cache (pos0 > 0), tiles
+    of 64 cached positions with and without a tail.  The probabilities enter the second matrix product as f16 (2^-12 relative
+    each, as in the reference): stated bound 1.5e-3 of max|out| (observed ~3e-4)."""
+    dev = ca.HipTensorDevice(0)
+    rng = np.random.default_rng(31 * n_kv + hd)
+    worst = 0.0
+    for pos0, rows in ((0, 1), (0, 17), (0, 64), (0, 65), (0, 200), (0, 512), (5, 33), (64, 64), (100, 129), (777, 300)):
+        q = (rng.standard_normal(rows * n_heads * hd) / np.sqrt(hd)).astype(np.float32)
+        k = rng.standard_normal((n_kv, pos0 + rows, hd)).astype(np.float16)
+        v = rng.standard_normal((n_kv, pos0 + rows, hd)).astype(np.float16)
+        got = dev.debug_flash_attention_rows(q, k.view(np.uint16).reshape(-1), v.view(np.uint16).reshape(-1), n_heads, n_kv, hd, pos0, rows)
+        ref = f64_causal_attention(q, k.view(np.uint16), v.view(np.uint16), n_heads, n_kv, hd, pos0, rows)
+        # the cache behind the live positions holds whatever an earlier sequence or the allocator left there: NaN / Inf / huge
+        # values in the tail of the K / V buffers must not reach any output (masked scores; zero probabilities times V)
+        for junk in (0xFFFF, 0x7C00, 0x7BFF):
+            cap = pos0 + rows + 37
+            kj = np.full((n_kv, cap, hd), junk, dtype=np.uint16)
+            vj = np.full((n_kv, cap, hd), junk, dtype=np.uint16)
+            kj[:, :pos0 + rows] = k.view(np.uint16)
+            vj[:, :pos0 + rows] = v.view(np.uint16)
+            gj = dev.debug_flash_attention_rows(q, kj.reshape(-1), vj.reshape(-1), n_heads, n_kv, hd, pos0, rows)
+            assert np.array_equal(gj.view(np.uint32), got.view(np.uint32)), (pos0, rows, hex(junk))
+        assert np.all(np.isfinite(got)), (pos0, rows)
+        err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+        worst = max(worst, err)
+        assert err <= 1.5e-3, (pos0, rows, err)
+    print(f"flash prefill vs float64, {n_heads} heads / {n_kv} kv x {hd}: worst {worst:.2e} of max|out|")

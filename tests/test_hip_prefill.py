@@ -12,6 +12,7 @@ from crabml_amd import synth
 from oracle import oracle as o
 from tests.helpers import to_oracle
 
+EXACT = 4194304  # CRABML_HIP_LLAMA_EXACT_ATTENTION: the fast step keeps the reference's exact attention arithmetic
 pytestmark = pytest.mark.gpu
 PROMPT = [1, 365, 400, 282, 7, 9, 11, 13, 2, 77, 500, 31, 8, 19, 64, 128, 3, 5, 900, 12, 14, 16, 18]  # 23 tokens
 
@@ -138,8 +139,8 @@ def test_row_tiled_attention_equals_the_per_row_kernel(ca, n_heads, n_kv, kv_f16
     model = synth.build_model(shape, synth.Q8_0, seed=86)
     dev = ca.HipTensorDevice(0)
     conf, w = synth.to_hip(model, dev)
-    a = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16)
-    b = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16, extra_flags=2048)
+    a = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16, extra_flags=EXACT)  # (the fast step's default is k_attn_flash_rows, not these)
+    b = ca.HipLlamaRunner(conf, w, dev, 64, kv_f16, extra_flags=EXACT + 2048)
     for r in (a, b):
         r.forward(3, 0)
         r.forward(4, 1)
@@ -169,12 +170,12 @@ def test_long_prompt_attention_paths_are_bit_identical(ca, n_heads, n_kv):
     dev = ca.HipTensorDevice(0)
     conf, w = synth.to_hip(model, dev)
     prompt = [(7 * i + 3) % 1024 for i in range(1100)]
-    a = ca.HipLlamaRunner(conf, w, dev, 1200, True)
-    b = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=2048)
+    a = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=EXACT)
+    b = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=EXACT + 2048)
     la, lb = a.prefill(prompt), b.prefill(prompt)
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
     # ... and the PV pass with one prompt row per workgroup (flag 16384) instead of the row tiles
-    c = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=16384)
+    c = ca.HipLlamaRunner(conf, w, dev, 1200, True, extra_flags=EXACT + 16384)
     assert np.array_equal(c.prefill(prompt).view(np.uint32), la.view(np.uint32))
     nxt = int(np.argmax(la))
     assert list(a.decode_greedy(nxt, 6)) == list(b.decode_greedy(nxt, 6))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Long-prompt prefill: time of an n-token prompt (8B shape by default) with and without the row-tiled PV pass.
+"""Long-prompt prefill: time of an n-token prompt (8B shape by default): the fast step's flash attention on the f16 matrix cores
+(default), the exact kernels (EXACT_ATTENTION) with and without the row-tiled PV pass.
 usage: long_prefill_bench.py [--n 4096] [--model llama3-8b]"""
 import argparse
 import sys
@@ -19,7 +20,8 @@ model = synth.build_model(shape, synth.TYPE_BY_NAME[a.wtype], seed=8)
 dev = ca.HipTensorDevice(0)
 conf, w = synth.to_hip(model, dev)
 toks = [(7 * i + 1) % shape.vocab for i in range(a.n)]
-for label, flags in (("row-tiled PV (default)", 0), ("PV one prompt row per workgroup (flag 16384)", 16384)):
+for label, flags in (("flash attention on the f16 matrix cores (default fast step)", 0), ("exact kernels, row-tiled PV (EXACT_ATTENTION)", 4194304),
+                     ("exact kernels, PV one prompt row per workgroup (+ flag 16384)", 4194304 + 16384)):
     r = ca.HipLlamaRunner(conf, w, dev, a.n + 8, True, extra_flags=flags)
     best = None
     for rep in range(2):
