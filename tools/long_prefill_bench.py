@@ -14,14 +14,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="llama3-8b")
 ap.add_argument("--wtype", default="Q4_0")
 ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--layers", type=int, default=0)
+ap.add_argument("--only-default", action="store_true")
 a = ap.parse_args()
 shape = synth.SHAPES[a.model]
-model = synth.build_model(shape, synth.TYPE_BY_NAME[a.wtype], seed=8)
+model = synth.build_model(shape, synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers or None)
 dev = ca.HipTensorDevice(0)
 conf, w = synth.to_hip(model, dev)
 toks = [(7 * i + 1) % shape.vocab for i in range(a.n)]
 for label, flags in (("flash attention on the f16 matrix cores (default fast step)", 0), ("exact kernels, row-tiled PV (EXACT_ATTENTION)", 4194304),
                      ("exact kernels, PV one prompt row per workgroup (+ flag 16384)", 4194304 + 16384)):
+    if a.only_default and flags:
+        continue
     r = ca.HipLlamaRunner(conf, w, dev, a.n + 8, True, extra_flags=flags)
     best = None
     for rep in range(2):
