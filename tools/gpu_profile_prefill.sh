@@ -5,7 +5,7 @@ TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+export TMPDIR=/tmp; cd $REPO  # (the tools put "." on sys.path)
 rm -rf $OUT/pmc_prefill_$TAG $OUT/pmc_prefill_long_$TAG
 timeout 400 rocprofv3 --kernel-trace --pmc MfmaUtil VALUBusy -d $OUT/pmc_prefill_$TAG -- python $REPO/tools/prefill_bench.py --chunks 512 --loop 2 --layers 4 > $OUT/pmc_prefill_$TAG.out 2> $OUT/pmc_prefill_$TAG.err
 timeout 400 rocprofv3 --kernel-trace --pmc MfmaUtil VALUBusy -d $OUT/pmc_prefill_long_$TAG -- python $REPO/tools/long_prefill_bench.py --n 4096 --layers 2 --only-default > $OUT/pmc_prefill_long_$TAG.out 2>> $OUT/pmc_prefill_$TAG.err
