@@ -1040,10 +1040,10 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       // fast step: causal flash attention on the f16 matrix cores (k_attn_flash_rows; the deviation stated for k_attn_flash)
       const dim3 fg((unsigned)((B + 63) / 64), (unsigned)n_heads);
       if (hd == 128)
-        k_attn_flash_rows<128><<<fg, 256, flash_rows_lds_bytes(128), st>>>((const float*)c->pf_qr, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], pos_d,
+        k_attn_flash_rows<128><<<fg, 512, flash_rows_lds_bytes(128), st>>>((const float*)c->pf_qr, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], pos_d,
                                                    c->pf_attn, n_heads, n_kv, seq_cap, (int)B);
       else
-        k_attn_flash_rows<64><<<fg, 256, flash_rows_lds_bytes(64), st>>>((const float*)c->pf_qr, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], pos_d,
+        k_attn_flash_rows<64><<<fg, 512, flash_rows_lds_bytes(64), st>>>((const float*)c->pf_qr, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], pos_d,
                                                   c->pf_attn, n_heads, n_kv, seq_cap, (int)B);
       along = 1;
     } else if (!launch_attn_tile(c, l, (int)B, (int)pos0)) {
@@ -1899,10 +1899,10 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
   if (e == hipSuccess) {
     const dim3 fg((unsigned)((rows + 63) / 64), (unsigned)n_heads);
     if (head_dim == 128)
-      k_attn_flash_rows<128><<<fg, 256, flash_rows_lds_bytes(128), st>>>((const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
+      k_attn_flash_rows<128><<<fg, 512, flash_rows_lds_bytes(128), st>>>((const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
                                                  (const int*)(base + o_pos), (float*)(base + o_out), (int)n_heads, (int)n_kv, (int)seq, (int)rows);
     else
-      k_attn_flash_rows<64><<<fg, 256, flash_rows_lds_bytes(64), st>>>((const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
+      k_attn_flash_rows<64><<<fg, 512, flash_rows_lds_bytes(64), st>>>((const float*)(base + o_q), (const unsigned short*)(base + o_k), (const unsigned short*)(base + o_v),
                                                 (const int*)(base + o_pos), (float*)(base + o_out), (int)n_heads, (int)n_kv, (int)seq, (int)rows);
     e = hipGetLastError();
   }

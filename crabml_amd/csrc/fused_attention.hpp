@@ -1171,10 +1171,11 @@ __host__ __device__ inline size_t flash_rows_lds_bytes(int hd) {
   return (size_t)2 * ((size_t)hd * FLASH_ROWS_VSTR + (size_t)FLASH_ROWS_BN * (hd + FLASH_ROWS_KPAD)) * 2;
 }
 template <int HD>
-__global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict__ q, const unsigned short* __restrict__ kc,
+__global__ __launch_bounds__(512) void k_attn_flash_rows(const float* __restrict__ q, const unsigned short* __restrict__ kc,
                                                          const unsigned short* __restrict__ vc, const int* __restrict__ pos_d,
                                                          float* __restrict__ out, int n_heads, int n_kv, int seq_cap, int B) {
-  constexpr int KS = HD / 32, DT = HD / 16, BN = FLASH_ROWS_BN, VSTR = FLASH_ROWS_VSTR, KSTR = HD + FLASH_ROWS_KPAD, NP = HD / 32;
+  constexpr int KS = HD / 32, DT = HD / 16, BN = FLASH_ROWS_BN, VSTR = FLASH_ROWS_VSTR, KSTR = HD + FLASH_ROWS_KPAD, NP = HD / 64;
+  static_assert(BN == 64, "a fill is two 32-position steps: one per wave of a pair");
   // LDS, two buffers each: V^T tile [HD][VSTR] (filled transposed), K tile [BN][KSTR] (as the cache holds it)
   extern __shared__ __attribute__((aligned(16))) unsigned short fr_lds[];
   unsigned short* vt0 = fr_lds;
@@ -1183,7 +1184,10 @@ __global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict
   const int n = lane & 15, g = lane >> 4;
   const int head = blockIdx.y, j = head / (n_heads / n_kv);
   const int pos0 = *pos_d;
-  const int row_wg = blockIdx.x * 64, row_w = row_wg + wave * 16;
+  // eight waves: waves w and w + 4 share 16 prompt rows and take alternate 32-position steps (two waves per SIMD: one's matrix work
+  // runs under the other's softmax); their {m, l, O} states are merged once, at the end
+  const int rw = wave & 3, par = wave >> 2;
+  const int row_wg = blockIdx.x * 64, row_w = row_wg + rw * 16;
   const int row = row_w + n < B ? row_w + n : B - 1;  // (rows past the batch recompute the last row; never stored)
   // this wave's q rows as the B operand: lane (row n, dims 32 ks + 8 g .. + 8)
   f16x8 qb[KS];
@@ -1209,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict
   auto issue = [&](int tile) {
 #pragma unroll
     for (int u = 0; u < NP; u++) {
-      const int piece = tid + 256 * u, pr = piece / (HD / 8), pc = piece % (HD / 8);
+      const int piece = tid + 512 * u, pr = piece / (HD / 8), pc = piece % (HD / 8);
       int pos = tile * BN + pr;
       pos = pos < seq_cap ? pos : seq_cap - 1;  // (past the cache only in its last tile; those positions are dead)
       kreg[u] = *(const i32x4*)(kb + (size_t)pos * HD + 8 * pc);
@@ -1221,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict
     unsigned short* kt = kt0 + buf * BN * KSTR;
 #pragma unroll
     for (int u = 0; u < NP; u++) {
-      const int piece = tid + 256 * u, pr = piece / (HD / 8), pc = piece % (HD / 8);
+      const int piece = tid + 512 * u, pr = piece / (HD / 8), pc = piece % (HD / 8);
       // positions no row of the workgroup sees hold whatever the allocator or an earlier sequence left in the cache: their
       // probabilities are exactly 0, but 0 x NaN / Inf is not -- V enters the product as zeros there (K: the scores are masked)
       const bool live = tile * BN + pr <= last_wg;
@@ -1242,13 +1246,13 @@ __global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict
     const unsigned short* vt = vt0 + buf * HD * VSTR;
     const unsigned short* kt = kt0 + buf * BN * KSTR;
     if (tile + 1 < ntiles) issue(tile + 1);
-#pragma unroll
-    for (int c2 = 0; c2 < BN / 32; c2++) {
-      // 32 positions per step as two 16-position chunks a / b: two independent S^T chains (a lone wave per SIMD has nothing else
-      // to hide an MFMA's latency under), ONE agreement on the running maximum, and the second product on 16x16x32 with k-slot
-      // (g, i) = position 4 g + i of chunk a, (g, 4 + i) = the same of chunk b -- for both operands
+    {
+      // 32 positions per step as two 16-position chunks a / b: two independent S^T chains, ONE agreement on the running maximum, and
+      // the second product on 16x16x32 with k-slot (g, i) = position 4 g + i of chunk a, (g, 4 + i) = the same of chunk b -- for
+      // both operands.  This wave's step of the tile: c2 = par.
+      const int c2 = par;
       const int ca0 = tile * BN + 32 * c2, cb0 = ca0 + 16;
-      if (ca0 > last_w) break;  // wave-uniform: no row of this wave sees the step (nor any later one)
+      if (ca0 <= last_w) {  // wave-uniform: some row of this wave sees the step
       f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) {
@@ -1264,9 +1268,10 @@ __global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict
       }
       cm = fmaxf(cm, __shfl_xor(cm, 16));
       cm = fmaxf(cm, __shfl_xor(cm, 32));
-      const float mn = fmaxf(m, cm);  // finite from the first step on: position 0 is visible to every row
-      if (__any(mn > m)) {            // the running maximum of some row moved: rescale (rare after the first steps)
-        const float alpha = __expf(m - mn);
+      // (a row may have seen nothing yet -- the odd-step wave of a pair starts at position 32: m = mn = -inf, alpha = 1, p = 0)
+      const float mn = fmaxf(m, cm);
+      if (__any(mn > m)) {  // the running maximum of some row moved: rescale (rare after the first steps)
+        const float alpha = mn == -INFINITY ? 1.0f : __expf(m - mn);
         lsum *= alpha;
 #pragma unroll
         for (int dt = 0; dt < DT; dt++) acc[dt] = acc[dt] * alpha;
@@ -1275,7 +1280,8 @@ __global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict
       f16x8 pT;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const _Float16 pa = (_Float16)__expf(sa[i] - m), pb = (_Float16)__expf(sb[i] - m);
+        const _Float16 pa = m == -INFINITY ? (_Float16)0.0f : (_Float16)__expf(sa[i] - m);
+        const _Float16 pb = m == -INFINITY ? (_Float16)0.0f : (_Float16)__expf(sb[i] - m);
         pT[i] = pa;
         pT[4 + i] = pb;
         lsum += (float)pa + (float)pb;  // the normalizer sums what the second product multiplies
@@ -1287,17 +1293,33 @@ __global__ __launch_bounds__(256) void k_attn_flash_rows(const float* __restrict
         const f16x8 vf = {va[0], va[1], va[2], va[3], vb2[0], vb2[1], vb2[2], vb2[3]};
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pT, acc[dt], 0, 0, 0);
       }
+      }
     }
     if (tile + 1 < ntiles) commit(buf ^ 1, tile + 1);  // those buffers were last read one tile ago (barrier below)
     __syncthreads();
   }
   lsum += __shfl_xor(lsum, 16);
   lsum += __shfl_xor(lsum, 32);
-  if (row_w + n < B) {
-    const float inv = 1.0f / lsum;
+  // ---- the two waves of a pair meet: the odd-step wave hands {m, l, O} over through LDS (the tiles are done with: the loop's last
+  // barrier is behind every wave), the even-step wave merges and stores
+  float* xch = (float*)fr_lds + (size_t)rw * 64 * (4 * DT + 2);  // [lane][4 DT + 2] floats per row group
+  if (par == 1) {
+    float* d = xch + lane * (4 * DT + 2);
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) *(f32x4*)(d + 4 * dt) = acc[dt];
+    d[4 * DT] = m;
+    d[4 * DT + 1] = lsum;
+  }
+  __syncthreads();
+  if (par == 0 && row_w + n < B) {
+    const float* d = xch + lane * (4 * DT + 2);
+    const float m1 = d[4 * DT], l1 = d[4 * DT + 1];
+    const float M = fmaxf(m, m1);  // (m is finite: the even-step wave saw position 0; m1 = -inf if the odd wave saw nothing)
+    const float w0 = __expf(m - M), w1 = m1 == -INFINITY ? 0.0f : __expf(m1 - M);
+    const float inv = 1.0f / (lsum * w0 + l1 * w1);
     float* o = out + ((size_t)(row_w + n) * n_heads + head) * HD;
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++) *(f32x4*)(o + 16 * dt + 4 * g) = acc[dt] * inv;
+    for (int dt = 0; dt < DT; dt++) *(f32x4*)(o + 16 * dt + 4 * g) = (acc[dt] * w0 + *(const f32x4*)(d + 4 * dt) * w1) * inv;
   }
 }
 
