@@ -15,6 +15,7 @@
 //         elements 16+4g..16+4g+3 (buf_q4_0.rs:24-33); the -8 offset is applied as -8 * sum(x) per block (exact);
 //   Q8_0: lane group g takes elements [8g, 8g+8).
 // D: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15.
+#include <cstdlib>
 #include <type_traits>
 
 #include "devutil.hpp"
@@ -859,7 +860,13 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
   const int row_tiles = (int)((m + 63) / 64);
   // 64-column tiles amortize a weight tile over more batch rows; when that grid leaves the chip under-occupied
   // (m = 4096: 64 row tiles) 32-column tiles double the workgroups per CU -- the k loop is latency-bound per wave
-  const bool narrow = (size_t)row_tiles * ((b + 63) / 64) < (size_t)4 * dev->n_cu && b > 16;
+  static const int narrow_wgs_per_cu = [] {  // tuning hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_NARROW=n): default 4
+    const char* hooks = getenv("CRABML_HIP_TEST_HOOKS");
+    const char* e = getenv("CRABML_HIP_GEMM_NARROW");
+    const int v = hooks && hooks[0] == '1' && e ? atoi(e) : 4;
+    return v >= 0 && v <= 16 ? v : 4;
+  }();
+  const bool narrow = (size_t)row_tiles * ((b + 63) / 64) < (size_t)narrow_wgs_per_cu * dev->n_cu && b > 16;
   const int cw = narrow ? 32 : 64;
   const int col_tiles = (int)((b + cw - 1) / cw);
   const unsigned short* wd = (const unsigned short*)(wp + w->wl.off_scale);
