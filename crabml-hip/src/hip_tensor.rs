@@ -128,7 +128,8 @@ impl HipTensor {
 impl Tensor for HipTensor {
     type DeviceRef = HipTensorDeviceRef;
 
-    /// Uploads the GGML-layout bytes as they are stored in the GGUF file: F32, F16, Q8_0, Q4_0, Q4_1, Q4_K, Q6_K, Q8_K.
+    /// Uploads the GGML-layout bytes as they are stored in the GGUF file: every weight format of CpuTensorBuf -- F32, F16, Q8_0, Q4_0, Q4_1, Q5_0, Q5_1,
+    /// Q2_K .. Q6_K, Q8_K.
     /// Quantized tensors are re-laid-out on the device into planes (quants | scales); no arithmetic touches them.
     fn from_cpu(
         buf: &[u8],

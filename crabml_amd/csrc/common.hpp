@@ -28,8 +28,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 inline size_t block_elems(uint32_t t) {
   switch (t) {
     case CRABML_HIP_F32: case CRABML_HIP_F16: return 1;
-    case CRABML_HIP_Q4_0: case CRABML_HIP_Q4_1: case CRABML_HIP_Q8_0: case CRABML_HIP_Q8_1: return 32;
-    case CRABML_HIP_Q4_K: case CRABML_HIP_Q5_K: case CRABML_HIP_Q6_K: case CRABML_HIP_Q8_K: return 256;
+    case CRABML_HIP_Q4_0: case CRABML_HIP_Q4_1: case CRABML_HIP_Q5_0: case CRABML_HIP_Q5_1: case CRABML_HIP_Q8_0: case CRABML_HIP_Q8_1: return 32;
+    case CRABML_HIP_Q2_K: case CRABML_HIP_Q3_K: case CRABML_HIP_Q4_K: case CRABML_HIP_Q5_K: case CRABML_HIP_Q6_K: case CRABML_HIP_Q8_K: return 256;
     default: return 0;
   }
 }
@@ -39,6 +39,10 @@ inline size_t block_bytes(uint32_t t) {
     case CRABML_HIP_F16: return 2;
     case CRABML_HIP_Q4_0: return 18;
     case CRABML_HIP_Q4_1: return 20;
+    case CRABML_HIP_Q5_0: return 22;
+    case CRABML_HIP_Q5_1: return 24;
+    case CRABML_HIP_Q2_K: return 84;
+    case CRABML_HIP_Q3_K: return 110;
     case CRABML_HIP_Q8_0: return 34;
     case CRABML_HIP_Q8_1: return 36;
     case CRABML_HIP_Q4_K: return 144;
@@ -53,9 +57,10 @@ inline uint32_t vec_dot_rhs_dtype(uint32_t t) {
   switch (t) {
     case CRABML_HIP_F32: return CRABML_HIP_F32;
     case CRABML_HIP_F16: return CRABML_HIP_F16;
-    case CRABML_HIP_Q8_0: case CRABML_HIP_Q4_0: return CRABML_HIP_Q8_0;
-    case CRABML_HIP_Q8_1: case CRABML_HIP_Q4_1: return CRABML_HIP_Q8_1;
-    case CRABML_HIP_Q8_K: case CRABML_HIP_Q4_K: case CRABML_HIP_Q5_K: case CRABML_HIP_Q6_K: return CRABML_HIP_Q8_K;
+    case CRABML_HIP_Q8_0: case CRABML_HIP_Q4_0: case CRABML_HIP_Q5_0: return CRABML_HIP_Q8_0;
+    case CRABML_HIP_Q8_1: case CRABML_HIP_Q4_1: case CRABML_HIP_Q5_1: return CRABML_HIP_Q8_1;
+    case CRABML_HIP_Q8_K: case CRABML_HIP_Q2_K: case CRABML_HIP_Q3_K: case CRABML_HIP_Q4_K: case CRABML_HIP_Q5_K: case CRABML_HIP_Q6_K:
+      return CRABML_HIP_Q8_K;
     default: return 0xffffffffu;
   }
 }
@@ -80,6 +85,10 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //   Q6_K: ql[n][128]           | qh[n][64] | scales[n][16] | d[n] f16   (off_scale = n * 128 exactly, so the
 //                                kernels derive the other three plane offsets from it)
 //   Q8_K: qs[n][256]           | d[n] f32            (bsums are derived data; not kept for weights)
+//   Q5_0: qs[n][16]            | qh[n] u32 | d[n] f16                      (off_scale = n * 16: the qh plane)
+//   Q5_1: qs[n][16]            | (d f16, m f16, qh u32)[n]                 (off_scale = n * 16)
+//   Q2_K: qs[n][64]            | scales[n][16] | (d f16, dmin f16)[n]      (off_scale = n * 64)
+//   Q3_K: qs[n][64]            | hmask[n][32] | (scales[12], d f16, 2 unused bytes)[n]   (off_scale = n * 64)
 // Quantized ACTIVATIONS (the rhs of matmul_vec) live in a per-buffer scratch, also as planes:
 //   Q8_0: qs[n] i8 | d[n/32] f16 | isum[n/32] i32 (sum of the 32 quants; exact, derived)
 //   Q8_1: qs[n] i8 | d[n/32] f16 | s[n/32] f16

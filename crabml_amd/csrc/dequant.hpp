@@ -92,6 +92,46 @@ __device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dt
       v = d * (float)sc[l / 16 + 2 * quarter] * (float)q;
       break;
     }
+    case CRABML_HIP_Q5_0: {  // buf_q5_0.rs:22-37; planes qs | qh | d with n = off_scale / 16 blocks
+      const size_t n = off_scale / 16, b = e / 32, j = e % 32;
+      const unsigned qh = ((const unsigned*)(w + off_scale))[b];
+      const float d = h2f(((const unsigned short*)(w + off_scale + n * 4))[b]);
+      const unsigned char q = ((const unsigned char*)w)[b * 16 + (j & 15)];
+      const int xi = (int)((j < 16 ? (q & 0x0F) : (q >> 4)) | (((qh >> j) & 1u) << 4)) - 16;
+      v = (float)xi * d;
+      break;
+    }
+    case CRABML_HIP_Q5_1: {  // buf_q5_1.rs:20-36 (element i | element i + 16 per byte: not interleaved)
+      const size_t b = e / 32, j = e % 32;
+      const unsigned dm = ((const unsigned*)(w + off_scale))[2 * b], qh = ((const unsigned*)(w + off_scale))[2 * b + 1];
+      const unsigned char q = ((const unsigned char*)w)[b * 16 + (j & 15)];
+      const unsigned xi = (unsigned)(j < 16 ? (q & 0x0F) : (q >> 4)) | (((qh >> j) & 1u) << 4);
+      v = (float)xi * h2f((unsigned short)(dm & 0xffffu)) + h2f((unsigned short)(dm >> 16));
+      break;
+    }
+    case CRABML_HIP_Q2_K: {  // buf_q2_k.rs:35-69; planes qs | scales | (d, dmin) with n = off_scale / 64 blocks
+      const size_t n = off_scale / 64, sb = e / 256;
+      const int j = (int)(e % 256), g = j / 16, half = g >> 3, s = (g & 7) >> 1, h = g & 1;
+      const unsigned char sc = ((const unsigned char*)w)[off_scale + sb * 16 + g];
+      const unsigned dm = ((const unsigned*)(w + off_scale + n * 16))[sb];
+      const unsigned char q = ((const unsigned char*)w)[sb * 64 + 32 * half + 16 * h + (j & 15)];
+      const float dl = h2f((unsigned short)(dm & 0xffffu)) * (float)(sc & 0xF), ml = h2f((unsigned short)(dm >> 16)) * (float)(sc >> 4);
+      v = dl * (float)((q >> (2 * s)) & 3) - ml;
+      break;
+    }
+    case CRABML_HIP_Q3_K: {  // buf_q3_k.rs:37-88; planes qs | hmask | (scales[12], d) with n = off_scale / 64 blocks
+      const size_t n = off_scale / 64, sb = e / 256;
+      const int j = (int)(e % 256), g = j / 16, half = g >> 3, s = (g & 7) >> 1, h = g & 1, pos = 16 * h + (j & 15);
+      const unsigned char* sd = (const unsigned char*)w + off_scale + n * 32 + sb * 16;
+      const int lo = g < 8 ? (sd[g] & 0xF) : (sd[g - 8] >> 4), hi = (sd[8 + (g & 3)] >> (2 * (g >> 2))) & 3;
+      unsigned short dh;
+      __builtin_memcpy(&dh, sd + 12, 2);
+      const float dl = h2f(dh) * (float)((lo | (hi << 4)) - 32);
+      const unsigned char q = ((const unsigned char*)w)[sb * 64 + 32 * half + pos];
+      const unsigned char hb = ((const unsigned char*)w)[off_scale + sb * 32 + pos];
+      v = dl * (float)((int)((q >> (2 * s)) & 3) - (((hb >> (4 * half + s)) & 1) ? 0 : 4));
+      break;
+    }
     case CRABML_HIP_Q8_K: {
       size_t sb = e / 256;
       float d = ((const float*)(w + off_scale))[sb];

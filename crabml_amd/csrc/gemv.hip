@@ -132,6 +132,37 @@ __global__ __launch_bounds__(256) void k_gemv_q5_k(const char* __restrict__ w, s
   }
 }
 
+// ---- Q5_0 / Q5_1 / Q2_K / Q3_K (piece policies, gemv_core.hpp) -------------------------------------------------------------
+template <class P, int R>
+__global__ __launch_bounds__(256) void k_gemv_pieces(const char* __restrict__ w, size_t off, size_t n, typename P::Act act,
+                                                     float* __restrict__ out, int m, int nbr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  float acc[R];
+  rows_partial_pieces<P, R>(w, off, n, act, row0, m, nbr, lane, acc);
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float s = wave_sum_f32(acc[r]);
+    if (lane == 0 && row0 + r < m) out[row0 + r] = s;
+  }
+}
+// parity hook: the exact integers of those formats through the production unpack -- one per 32-element block (Q5_0, Q5_1) or
+// per 16-element scale group in element order (Q2_K, Q3_K)
+template <class P>
+__global__ void k_block_dots_pieces(const char* __restrict__ w, size_t off, size_t n, typename P::Act act, size_t blk0, int np,
+                                    int* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= np) return;
+  const typename P::W wv = P::load(w, off, n, blk0, c);
+  const typename P::X x = P::loadx(act, c);
+  int o[P::GROUPS];
+  P::ints(wv, x, c, o);
+#pragma unroll
+  for (int g = 0; g < P::GROUPS; g++) out[P::group_index(c, g)] = o[g];
+}
+
 // ---- Q6_K x Q8_K ---------------------------------------------------------------------------------
 // planes: ql[n][128] | qh[n][64] | scales[n][16] | d[n] (common.hpp).  A lane owns one 16-byte ql piece (8 lanes
 // per super-block: one aligned 1 KiB request per wave): piece (h, a, p) = ql[64 h + 32 a + 16 p .. +16) holds the low
@@ -327,6 +358,46 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         });
         break;
       }
+      case CRABML_HIP_Q5_0: {
+        ActQ8_0 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            launch_k(st, rec, k_gemv_pieces<PieceQ5_0, 2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 32);
+          else
+            launch_k(st, rec, k_gemv_pieces<PieceQ5_0, 1>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 32);
+        });
+        break;
+      }
+      case CRABML_HIP_Q5_1: {
+        ActQ8_1 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const unsigned short*)(ap + al.off_aux)};
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            launch_k(st, rec, k_gemv_pieces<PieceQ5_1, 2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 32);
+          else
+            launch_k(st, rec, k_gemv_pieces<PieceQ5_1, 1>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 32);
+        });
+        break;
+      }
+      case CRABML_HIP_Q2_K: {
+        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            launch_k(st, rec, k_gemv_pieces<PieceQ2_K, 2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 256);
+          else
+            launch_k(st, rec, k_gemv_pieces<PieceQ2_K, 1>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 256);
+        });
+        break;
+      }
+      case CRABML_HIP_Q3_K: {
+        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
+          if (R == 2)
+            launch_k(st, rec, k_gemv_pieces<PieceQ3_K, 2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 256);
+          else
+            launch_k(st, rec, k_gemv_pieces<PieceQ3_K, 1>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 256);
+        });
+        break;
+      }
       case CRABML_HIP_F32: {
         int grid = (m + 3) / 4;
         launch_k(st, rec, k_gemv_f32, dim3(grid), dim3(256), 0, (const float*)wp, (const float*)ap, o, m, k);
@@ -462,7 +533,22 @@ void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t
   const char* ap = (const char*)act;
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   const ActLayout al = act_layout(qt, k);
-  if (w->dtype == CRABML_HIP_Q6_K) {
+  if (w->dtype == CRABML_HIP_Q5_0) {
+    ActQ8_0 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
+    const int nb = (int)(k / 32);
+    k_block_dots_pieces<PieceQ5_0><<<(nb + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, w->wl.n_blocks, a, row * nb, nb, out);
+  } else if (w->dtype == CRABML_HIP_Q5_1) {
+    ActQ8_1 a{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const unsigned short*)(ap + al.off_aux)};
+    const int nb = (int)(k / 32);
+    k_block_dots_pieces<PieceQ5_1><<<(nb + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, w->wl.n_blocks, a, row * nb, nb, out);
+  } else if (w->dtype == CRABML_HIP_Q2_K || w->dtype == CRABML_HIP_Q3_K) {
+    ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+    const int nsb = (int)(k / 256);
+    if (w->dtype == CRABML_HIP_Q2_K)
+      k_block_dots_pieces<PieceQ2_K><<<(nsb * 4 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, w->wl.n_blocks, a, row * nsb, nsb * 4, out);
+    else
+      k_block_dots_pieces<PieceQ3_K><<<(nsb * 4 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, w->wl.n_blocks, a, row * nsb, nsb * 4, out);
+  } else if (w->dtype == CRABML_HIP_Q6_K) {
     ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
     int nsb = (int)(k / 256);
     k_block_dots_q6k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, a, row * nsb, nsb, out);

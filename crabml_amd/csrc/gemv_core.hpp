@@ -407,4 +407,254 @@ struct ActOf<CRABML_HIP_Q4_1> {
   typedef ActQ8_1 type;
 };
 
+// ---- Q5_0 / Q5_1 / Q2_K / Q3_K: the formats the reference serves with scalar code only --------------------------------------
+// (buf_q5_0.rs, buf_q5_1.rs, buf_q2_k.rs, buf_q3_k.rs).  They run the per-op path (matmul_vec, embedding rows, the generic
+// decode step); one policy per format describes a lane's 16-byte PIECE of quants: what it loads, the exact integers it yields,
+// and the f32 term in the reference's own expression.  Planes (common.hpp): the first plane holds QB bytes of quants per block,
+// `off` = n * QB is where the second starts (n = blocks of the tensor), the others follow.
+// four bits b -> bit 4 of four bytes (the fifth bit of four 5-bit levels)
+__device__ __forceinline__ unsigned spread4_to_bit4(unsigned b) { return ((b * 0x00204081u) & 0x01010101u) << 4; }
+__device__ __forceinline__ int quad_sum_i32(int v) {
+  v += dpp_i<0xB1>(v);
+  v += dpp_i<0x4E>(v);
+  return v;
+}
+
+struct PieceQ5_0 {  // planes qs[n][16] | qh[n] u32 | d[n] f16; rhs Q8_0
+  static constexpr int PIECES = 1, QB = 16, GROUPS = 1;
+  typedef ActQ8_0 Act;
+  struct W {
+    i32x4 q;
+    unsigned qh;
+    unsigned short d;
+  };
+  struct X {
+    i32x4 x0, x1;
+    float dx;
+    int xs;
+  };
+  static __device__ __forceinline__ W load(const char* __restrict__ w, size_t off, size_t n, size_t blk0, int c) {
+    const size_t b = blk0 + c;
+    W r;
+    r.q = __builtin_nontemporal_load((const i32x4*)w + b);
+    r.qh = __builtin_nontemporal_load((const unsigned*)(w + off) + b);
+    r.d = __builtin_nontemporal_load((const unsigned short*)(w + off + n * 4) + b);
+    return r;
+  }
+  static __device__ __forceinline__ X loadx(const Act& a, int c) { return X{a.q[2 * c], a.q[2 * c + 1], h2f(a.d[c]), a.isum[c]}; }
+  // sum (q5 - 16) * q8, exact (buf_q5_0.rs:148-157)
+  static __device__ __forceinline__ void ints(const W& w, const X& x, int c, int* o) {
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const unsigned v = (unsigned)w.q[i];
+      s = __builtin_amdgcn_sdot4((int)((v & 0x0F0F0F0Fu) | spread4_to_bit4((w.qh >> (4 * i)) & 0xFu)), x.x0[i], s, false);
+      s = __builtin_amdgcn_sdot4((int)(((v >> 4) & 0x0F0F0F0Fu) | spread4_to_bit4((w.qh >> (16 + 4 * i)) & 0xFu)), x.x1[i], s, false);
+    }
+    o[0] = s - 16 * x.xs;
+  }
+  static __device__ __forceinline__ int group_index(int c, int g) { return c; }
+  static __device__ __forceinline__ float term(const W& w, const X& x, int lane) {  // buf_q5_0.rs:158
+    int si;
+    ints(w, x, 0, &si);
+    return ((float)si * h2f(w.d)) * x.dx;
+  }
+};
+
+struct PieceQ5_1 {  // planes qs[n][16] | (d f16, m f16, qh u32)[n]; rhs Q8_1
+  static constexpr int PIECES = 1, QB = 16, GROUPS = 1;
+  typedef ActQ8_1 Act;
+  struct W {
+    i32x4 q;
+    i32x2 h;  // d | m << 16, qh
+  };
+  struct X {
+    i32x4 x0, x1;
+    unsigned ds;  // the Q8_1 block's raw f16 pair d | s << 16
+  };
+  static __device__ __forceinline__ W load(const char* __restrict__ w, size_t off, size_t n, size_t blk0, int c) {
+    const size_t b = blk0 + c;
+    W r;
+    r.q = __builtin_nontemporal_load((const i32x4*)w + b);
+    r.h = __builtin_nontemporal_load((const i32x2*)(w + off) + b);
+    return r;
+  }
+  static __device__ __forceinline__ X loadx(const Act& a, int c) {
+    return X{a.q[2 * c], a.q[2 * c + 1], (unsigned)a.d[c] | ((unsigned)a.s[c] << 16)};
+  }
+  static __device__ __forceinline__ void ints(const W& w, const X& x, int c, int* o) {  // sum q5 * q8 (buf_q5_1.rs:146-155)
+    const unsigned qh = (unsigned)w.h[1];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const unsigned v = (unsigned)w.q[i];
+      s = __builtin_amdgcn_sdot4((int)((v & 0x0F0F0F0Fu) | spread4_to_bit4((qh >> (4 * i)) & 0xFu)), x.x0[i], s, false);
+      s = __builtin_amdgcn_sdot4((int)(((v >> 4) & 0x0F0F0F0Fu) | spread4_to_bit4((qh >> (16 + 4 * i)) & 0xFu)), x.x1[i], s, false);
+    }
+    o[0] = s;
+  }
+  static __device__ __forceinline__ int group_index(int c, int g) { return c; }
+  // buf_q5_1.rs:156: sumi as f32 * f16(d_w * d_x) + f16(m * s) -- the two products are f16 * f16 rounded to f16, as Q4_1's
+  static __device__ __forceinline__ float term(const W& w, const X& x, int lane) {
+    int si;
+    ints(w, x, 0, &si);
+    const unsigned dm = (unsigned)w.h[0];
+    return (float)si * h2f(h_mul((unsigned short)(dm & 0xffffu), (unsigned short)(x.ds & 0xffffu))) +
+           h2f(h_mul((unsigned short)(dm >> 16), (unsigned short)(x.ds >> 16)));
+  }
+};
+
+// The activation side of a K-quant piece that spans four 16-element scale groups (Q2_K, Q3_K): piece j = (half, h) of a
+// super-block holds qs bytes 32 half + 16 h .. +16, whose 2-bit field s (shift 2 s) belongs to group g = 8 half + 2 s + h =
+// elements 16 g .. 16 g + 16 (buf_q2_k.rs:44-67, buf_q3_k.rs:62-86).
+struct KGroupsX {
+  i32x4 xq[4];
+  int bs[4];
+  float d8;
+};
+__device__ __forceinline__ KGroupsX kgroups_loadx(const ActQ8_K& a, int c) {
+  const int sb = c >> 2, half = (c >> 1) & 1, h = c & 1;
+  KGroupsX x;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int g = 8 * half + 2 * s + h;
+    x.xq[s] = a.q[(size_t)sb * 16 + g];
+    x.bs[s] = (int)a.bsums[sb * 16 + g];
+  }
+  x.d8 = a.d[sb];
+  return x;
+}
+
+struct PieceQ2_K {  // planes qs[n][64] | scales[n][16] | (d f16, dmin f16)[n]; rhs Q8_K
+  static constexpr int PIECES = 4, QB = 64, GROUPS = 4;
+  typedef ActQ8_K Act;
+  typedef KGroupsX X;
+  struct W {
+    i32x4 qv;
+    i32x2 sc;  // the half's eight (scale | min << 4) bytes
+    unsigned dm;
+  };
+  static __device__ __forceinline__ W load(const char* __restrict__ w, size_t off, size_t n, size_t blk0, int c) {
+    const size_t b = blk0 + (c >> 2);
+    W r;
+    r.qv = __builtin_nontemporal_load((const i32x4*)w + b * 4 + (c & 3));
+    r.sc = __builtin_nontemporal_load((const i32x2*)(w + off) + b * 2 + ((c >> 1) & 1));
+    r.dm = __builtin_nontemporal_load((const unsigned*)(w + off + n * 16) + b);
+    return r;
+  }
+  static __device__ __forceinline__ X loadx(const Act& a, int c) { return kgroups_loadx(a, c); }
+  static __device__ __forceinline__ unsigned scale_byte(const W& w, int c, int s) {
+    return ((unsigned)w.sc[s >> 1] >> (8 * (2 * (s & 1) + (c & 1)))) & 0xFFu;
+  }
+  static __device__ __forceinline__ int group_dot(const W& w, const X& x, int s) {  // sum q2 * q8 over the group
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) d = __builtin_amdgcn_sdot4((int)(((unsigned)w.qv[i] >> (2 * s)) & 0x03030303u), x.xq[s][i], d, false);
+    return d;
+  }
+  static __device__ __forceinline__ void ints(const W& w, const X& x, int c, int* o) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) o[s] = group_dot(w, x, s);
+  }
+  static __device__ __forceinline__ int group_index(int c, int s) { return (c >> 2) * 16 + 8 * ((c >> 1) & 1) + 2 * s + (c & 1); }
+  // buf_q2_k.rs:216-258: the super-block's isum = sum (scale & 15) * group dot and summs = sum bsum * (scale >> 4) are exact
+  // integers (the four pieces of a super-block add theirs across the quad), then ONE f32 expression per super-block
+  static __device__ __forceinline__ float term(const W& w, const X& x, int c, int lane) {
+    int isum = 0, summs = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const unsigned sc = scale_byte(w, c, s);
+      isum += (int)(sc & 15u) * group_dot(w, x, s);
+      summs += x.bs[s] * (int)(sc >> 4);
+    }
+    isum = quad_sum_i32(isum);
+    summs = quad_sum_i32(summs);
+    const float dall = x.d8 * h2f((unsigned short)(w.dm & 0xffffu)), dmin = x.d8 * h2f((unsigned short)(w.dm >> 16));
+    const float t = dall * (float)isum - dmin * (float)summs;
+    return (lane & 3) == 0 ? t : 0.0f;
+  }
+};
+
+struct PieceQ3_K {  // planes qs[n][64] | hmask[n][32] | (scales[12], d f16, 2 unused bytes)[n]; rhs Q8_K
+  static constexpr int PIECES = 4, QB = 64, GROUPS = 4;
+  typedef ActQ8_K Act;
+  typedef KGroupsX X;
+  struct W {
+    i32x4 qv, hm, sd;
+  };
+  static __device__ __forceinline__ W load(const char* __restrict__ w, size_t off, size_t n, size_t blk0, int c) {
+    const size_t b = blk0 + (c >> 2);
+    W r;
+    r.qv = __builtin_nontemporal_load((const i32x4*)w + b * 4 + (c & 3));
+    r.hm = __builtin_nontemporal_load((const i32x4*)(w + off) + b * 2 + (c & 1));
+    r.sd = __builtin_nontemporal_load((const i32x4*)(w + off + n * 32) + b);
+    return r;
+  }
+  static __device__ __forceinline__ X loadx(const Act& a, int c) { return kgroups_loadx(a, c); }
+  // sum (q3 - 4) * q8 over group s of the piece: 2 low bits | the hmask bit as bit 2, minus 4 * (sum of the group's q8)
+  static __device__ __forceinline__ int group_dot(const W& w, const X& x, int c, int s) {
+    const int bit = 4 * ((c >> 1) & 1) + s;
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const unsigned u = (((unsigned)w.qv[i] >> (2 * s)) & 0x03030303u) | ((((unsigned)w.hm[i] >> bit) & 0x01010101u) << 2);
+      d = __builtin_amdgcn_sdot4((int)u, x.xq[s][i], d, false);
+    }
+    return d - 4 * x.bs[s];
+  }
+  // the 6-bit scale of group g = 8 half + 2 s + h, minus 32 (buf_q3_k.rs:44-55: low 4 bits in scales[g & 7]'s low / high nibble,
+  // high 2 bits in scales[8 + g % 4] at bit 2 (g / 4))
+  static __device__ __forceinline__ int scale(const W& w, int c, int s) {
+    const int half = (c >> 1) & 1, j = 2 * s + (c & 1);  // j = g & 7
+    const unsigned lo = (((unsigned)w.sd[j >> 2] >> (8 * (j & 3))) >> (4 * half)) & 0xFu;
+    const unsigned hi = (((unsigned)w.sd[2] >> (8 * (j & 3))) >> (2 * (2 * half + (s >> 1)))) & 3u;
+    return (int)(lo | (hi << 4)) - 32;
+  }
+  static __device__ __forceinline__ void ints(const W& w, const X& x, int c, int* o) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) o[s] = group_dot(w, x, c, s);
+  }
+  static __device__ __forceinline__ int group_index(int c, int s) { return (c >> 2) * 16 + 8 * ((c >> 1) & 1) + 2 * s + (c & 1); }
+  // buf_q3_k.rs:303-327 keeps eight i32 lanes per super-block (element e feeds lane e % 8) and multiplies each by d: the fast
+  // path adds the lanes first (exact) and multiplies once -- the strict-order kernel keeps the eight lanes
+  static __device__ __forceinline__ float term(const W& w, const X& x, int c, int lane) {
+    int tot = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) tot += scale(w, c, s) * group_dot(w, x, c, s);
+    tot = quad_sum_i32(tot);
+    const float t = (h2f((unsigned short)((unsigned)w.sd[3] & 0xffffu)) * x.d8) * (float)tot;
+    return (lane & 3) == 0 ? t : 0.0f;
+  }
+};
+
+// R rows of a matrix in one of those formats against its activation planes; lane l owns pieces l, l + 64, ...
+template <class P, int R>
+__device__ __forceinline__ void rows_partial_pieces(const char* __restrict__ w, size_t off, size_t n, const typename P::Act& act, int row0,
+                                                    int m, int nbr, int lane, float acc[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int np = nbr * P::PIECES;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < np;  // pieces per row are a multiple of PIECES: a super-block's quad is live or dead as a whole
+    const int cc = live ? c : np - 1;
+    typename P::W wv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      wv[r] = P::load(w, off, n, (size_t)row * nbr, cc);
+    }
+    const typename P::X x = P::loadx(act, cc);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float t;
+      if constexpr (P::PIECES == 1)
+        t = P::term(wv[r], x, lane);
+      else
+        t = P::term(wv[r], x, cc, lane);
+      acc[r] += live ? t : 0.0f;
+    }
+  }
+}
+
 }  // namespace crabml_hip

@@ -66,6 +66,106 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
       }
       break;
     }
+    case CRABML_HIP_Q5_0: {  // buf_q5_0.rs:143-161; planes qs | qh | d with n = off_scale / 16 blocks
+      const int nb = k / 32;
+      const size_t n = off_scale / 16;
+      const unsigned* wqh = (const unsigned*)(w + off_scale);
+      const unsigned short* wd = (const unsigned short*)(w + off_scale + n * 4);
+      const unsigned short* xd = (const unsigned short*)(act + off_d);
+      for (int b = 0; b < nb; b++) {
+        const size_t blk = (size_t)row * nb + b;
+        const unsigned char* qs = (const unsigned char*)w + blk * 16;
+        const signed char* xq = (const signed char*)act + (size_t)b * 32;
+        const unsigned qh = wqh[blk];
+        int sumi = 0;
+        for (int j = 0; j < 16; j++) {
+          const int x0 = (int)((qs[j] & 0x0F) | (((qh >> j) & 1u) << 4)) - 16, x1 = (int)((qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4)) - 16;
+          sumi += x0 * (int)xq[j] + x1 * (int)xq[j + 16];
+        }
+        sumf += (float)sumi * h2f(wd[blk]) * h2f(xd[b]);
+      }
+      break;
+    }
+    case CRABML_HIP_Q5_1: {  // buf_q5_1.rs:141-160; planes qs | (d, m, qh)
+      const int nb = k / 32;
+      const unsigned* rec = (const unsigned*)(w + off_scale);
+      const unsigned short* xd = (const unsigned short*)(act + off_d);
+      const unsigned short* xs = (const unsigned short*)(act + off_aux);
+      for (int b = 0; b < nb; b++) {
+        const size_t blk = (size_t)row * nb + b;
+        const unsigned char* qs = (const unsigned char*)w + blk * 16;
+        const signed char* xq = (const signed char*)act + (size_t)b * 32;
+        const unsigned dm = rec[2 * blk], qh = rec[2 * blk + 1];
+        int sumi = 0;
+        for (int j = 0; j < 16; j++) {
+          const int x0 = (int)((qs[j] & 0x0F) | (((qh >> j) & 1u) << 4)), x1 = (int)((qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4));
+          sumi += x0 * (int)xq[j] + x1 * (int)xq[j + 16];
+        }
+        sumf += (float)sumi * h2f(h_mul((unsigned short)(dm & 0xffffu), xd[b])) + h2f(h_mul((unsigned short)(dm >> 16), xs[b]));
+      }
+      break;
+    }
+    case CRABML_HIP_Q2_K: {  // buf_q2_k.rs:216-258; planes qs | scales | (d, dmin) with n = off_scale / 64 blocks
+      const int nsb = k / 256;
+      const size_t n = off_scale / 64;
+      const float* xd = (const float*)(act + off_d);
+      const short* bsums = (const short*)(act + off_aux);
+      for (int sb = 0; sb < nsb; sb++) {
+        const size_t blk = (size_t)row * nsb + sb;
+        const unsigned char* q2 = (const unsigned char*)w + blk * 64;
+        const unsigned char* sc = (const unsigned char*)w + off_scale + blk * 16;
+        const unsigned dm = ((const unsigned*)(w + off_scale + n * 16))[blk];
+        const signed char* q8 = (const signed char*)act + (size_t)sb * 256;
+        int summs = 0;  // an i16 in the reference: exact here (the oracle counts the inputs on which the two differ)
+        for (int j = 0; j < 16; j++) summs += (int)bsums[sb * 16 + j] * (int)(sc[j] >> 4);
+        const float dall = xd[sb] * h2f((unsigned short)(dm & 0xffffu)), dmin = xd[sb] * h2f((unsigned short)(dm >> 16));
+        int isum = 0, is = 0;
+        for (int half = 0; half < 2; half++)
+          for (int shift = 0; shift < 8; shift += 2)
+            for (int h = 0; h < 2; h++) {
+              const int d = sc[is] & 0xF;
+              int isuml = 0;
+              for (int l = 0; l < 16; l++) isuml += (int)q8[16 * is + l] * (int)((q2[32 * half + 16 * h + l] >> shift) & 3);
+              isum += d * isuml;
+              is++;
+            }
+        sumf += dall * (float)isum - dmin * (float)summs;
+      }
+      break;
+    }
+    case CRABML_HIP_Q3_K: {  // buf_q3_k.rs:238-329: eight i32 lanes per block (element e feeds lane e % 8), eight f32 sums
+      const int nsb = k / 256;
+      const size_t n = off_scale / 64;
+      const float* xd = (const float*)(act + off_d);
+      float sums[8];
+      for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+      for (int sb = 0; sb < nsb; sb++) {
+        const size_t blk = (size_t)row * nsb + sb;
+        const unsigned char* q3 = (const unsigned char*)w + blk * 64;
+        const unsigned char* hm = (const unsigned char*)w + off_scale + blk * 32;
+        const unsigned char* sd = (const unsigned char*)w + off_scale + n * 32 + blk * 16;
+        const signed char* q8 = (const signed char*)act + (size_t)sb * 256;
+        int aux32[8];
+        for (int l = 0; l < 8; l++) aux32[l] = 0;
+        for (int g = 0; g < 16; g++) {
+          const int half = g >> 3, s = (g & 7) >> 1, h = g & 1;
+          const int lo = g < 8 ? (sd[g] & 0xF) : (sd[g - 8] >> 4), hi = (sd[8 + (g & 3)] >> (2 * (g >> 2))) & 3;
+          const int scale = (lo | (hi << 4)) - 32;
+          for (int e = 0; e < 16; e++) {
+            const int pos = 16 * h + e;  // position within the half's 32 qs bytes / the 32 hmask bytes
+            const int a8 = (int)((q3[32 * half + pos] >> (2 * s)) & 3) - (((hm[pos] >> (4 * half + s)) & 1) ? 0 : 4);
+            aux32[e & 7] += scale * ((int)q8[16 * g + e] * a8);
+          }
+        }
+        unsigned short dh;
+        __builtin_memcpy(&dh, sd + 12, 2);
+        const float d = h2f(dh) * xd[sb];
+        for (int l = 0; l < 8; l++) sums[l] += d * (float)aux32[l];
+      }
+      sumf = sums[0];
+      for (int l = 1; l < 8; l++) sumf = sumf + sums[l];
+      break;
+    }
     case CRABML_HIP_Q4_K:
     case CRABML_HIP_Q5_K: {  // buf_q5_k.rs:229-325 = buf_q4_k.rs:192-277 + the fifth bit (planes qs | qh | hdr, n = off_scale / 128 blocks)
       const bool q5 = dtype == CRABML_HIP_Q5_K;

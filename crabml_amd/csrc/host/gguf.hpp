@@ -321,8 +321,12 @@ inline bool ggml_block_geometry(uint32_t t, size_t* block_bytes, size_t* block_e
     case 1: *block_bytes = 2; *block_elems = 1; return true;       // F16
     case 2: *block_bytes = 18; *block_elems = 32; return true;     // Q4_0
     case 3: *block_bytes = 20; *block_elems = 32; return true;     // Q4_1
+    case 6: *block_bytes = 22; *block_elems = 32; return true;     // Q5_0
+    case 7: *block_bytes = 24; *block_elems = 32; return true;     // Q5_1
     case 8: *block_bytes = 34; *block_elems = 32; return true;     // Q8_0
     case 9: *block_bytes = 36; *block_elems = 32; return true;     // Q8_1
+    case 10: *block_bytes = 84; *block_elems = 256; return true;   // Q2_K
+    case 11: *block_bytes = 110; *block_elems = 256; return true;  // Q3_K
     case 12: *block_bytes = 144; *block_elems = 256; return true;  // Q4_K
     case 13: *block_bytes = 176; *block_elems = 256; return true;  // Q5_K (the reference's field order, buf_q5_k.rs:13-21)
     case 14: *block_bytes = 210; *block_elems = 256; return true;  // Q6_K

@@ -20,7 +20,7 @@
 
 namespace crabml_host {
 
-enum class GGMLType : uint32_t { F32 = 0, F16 = 1, Q4_0 = 2, Q4_1 = 3, Q8_0 = 8, Q8_1 = 9, Q4K = 12, Q5K = 13, Q6K = 14, Q8K = 15 };
+enum class GGMLType : uint32_t { F32 = 0, F16 = 1, Q4_0 = 2, Q4_1 = 3, Q5_0 = 6, Q5_1 = 7, Q8_0 = 8, Q8_1 = 9, Q2K = 10, Q3K = 11, Q4K = 12, Q5K = 13, Q6K = 14, Q8K = 15 };
 enum class RopeMode : uint32_t { Llama = 0, Neox = 1 };
 
 // replaces WgpuTensorDeviceOptions (crabml-wgpu/src/wgpu_device.rs:9-38)
@@ -329,7 +329,8 @@ class HipTensor {
   }
   std::vector<int32_t> debug_block_dots(size_t row, const HipTensor& x) const {
     size_t m = shape()[0], k = shape()[1];
-    std::vector<int32_t> out(dtype_ == GGMLType::Q6K ? k / 16 : k / 32);  // Q6_K: one per 16-element scale group
+    // Q6_K / Q2_K / Q3_K: one per 16-element scale group
+    std::vector<int32_t> out(dtype_ == GGMLType::Q6K || dtype_ == GGMLType::Q2K || dtype_ == GGMLType::Q3K ? k / 16 : k / 32);
     device_->check(crabml_hip_debug_block_dots(device_->raw(), buf_.get(), m, k, row, x.buf_.get(), out.data()));
     return out;
   }

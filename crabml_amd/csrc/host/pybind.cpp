@@ -44,6 +44,7 @@ PYBIND11_MODULE(_host, m) {
   py::enum_<GGMLType>(m, "GGMLType")
       .value("F32", GGMLType::F32).value("F16", GGMLType::F16).value("Q4_0", GGMLType::Q4_0)
       .value("Q4_1", GGMLType::Q4_1).value("Q8_0", GGMLType::Q8_0).value("Q8_1", GGMLType::Q8_1)
+      .value("Q5_0", GGMLType::Q5_0).value("Q5_1", GGMLType::Q5_1).value("Q2K", GGMLType::Q2K).value("Q3K", GGMLType::Q3K)
       .value("Q4K", GGMLType::Q4K).value("Q5K", GGMLType::Q5K).value("Q6K", GGMLType::Q6K).value("Q8K", GGMLType::Q8K);
   py::enum_<RopeMode>(m, "RopeMode").value("Llama", RopeMode::Llama).value("Neox", RopeMode::Neox);
 

@@ -45,6 +45,10 @@ WeightLayout weight_layout(uint32_t dtype, size_t n_elems) {
     case CRABML_HIP_Q4_1: wl.off_scale = align_up(n * 16, 256); wl.total = wl.off_scale + n * 4; break;
     case CRABML_HIP_Q4_K: wl.off_scale = align_up(n * 128, 256); wl.total = wl.off_scale + n * 16; break;
     case CRABML_HIP_Q5_K: wl.off_scale = n * 128; wl.total = align_up(n * 176, 256); break;
+    case CRABML_HIP_Q5_0: wl.off_scale = n * 16; wl.total = align_up(n * 22, 256); break;
+    case CRABML_HIP_Q5_1: wl.off_scale = n * 16; wl.total = align_up(n * 24, 256); break;
+    case CRABML_HIP_Q2_K: wl.off_scale = n * 64; wl.total = align_up(n * 84, 256); break;
+    case CRABML_HIP_Q3_K: wl.off_scale = n * 64; wl.total = align_up(n * 112, 256); break;
     case CRABML_HIP_Q6_K: wl.off_scale = n * 128; wl.total = align_up(n * 210, 256); break;
     case CRABML_HIP_Q8_K: wl.off_scale = align_up(n * 256, 256); wl.total = wl.off_scale + n * 4; break;
     default: wl.total = 0;
@@ -372,6 +376,12 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
       case CRABML_HIP_Q4_K: seg(0, 16, wl.off_scale); seg(16, 128, 0); break;
       case CRABML_HIP_Q5_K:  // qs | qh | scales | d | dmin (buf_q5_k.rs:13-21) -> qs | qh | (d, dmin, scales)
         seg(0, 128, 0); seg(128, 32, wl.off_scale); seg(172, 4, wl.off_scale + nblk * 32, 16); seg(160, 12, wl.off_scale + nblk * 32 + 4, 16);
+        break;
+      case CRABML_HIP_Q5_0: seg(0, 2, wl.off_scale + nblk * 4); seg(2, 4, wl.off_scale); seg(6, 16, 0); break;  // d | qh | qs
+      case CRABML_HIP_Q5_1: seg(0, 8, wl.off_scale); seg(8, 16, 0); break;                                     // d, m, qh | qs
+      case CRABML_HIP_Q2_K: seg(0, 16, wl.off_scale); seg(16, 64, 0); seg(80, 4, wl.off_scale + nblk * 16); break;  // scales | qs | d, dmin
+      case CRABML_HIP_Q3_K:  // hmask | qs | scales | d (buf_q3_k.rs:19-30)
+        seg(0, 32, wl.off_scale); seg(32, 64, 0); seg(96, 14, wl.off_scale + nblk * 32, 16);
         break;
       case CRABML_HIP_Q6_K:  // ql | qh | scales | d (buf_q6_k.rs:11-18)
         seg(0, 128, 0); seg(128, 64, wl.off_scale); seg(192, 16, wl.off_scale + nblk * 64); seg(208, 2, wl.off_scale + nblk * 80);
@@ -820,7 +830,8 @@ int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t
   CH_TRY(need_f32(dev, x, k, "debug_block_dots rhs"));
   const void* act = nullptr;
   CH_TRY(ensure_act(dev, x, 1, k, qt, &act));
-  size_t n = w->dtype == CRABML_HIP_Q6_K ? k / 16 : k / 32;  // Q6_K: one value per 16-element scale group
+  // Q6_K / Q2_K / Q3_K: one value per 16-element scale group
+  size_t n = w->dtype == CRABML_HIP_Q6_K || w->dtype == CRABML_HIP_Q2_K || w->dtype == CRABML_HIP_Q3_K ? k / 16 : k / 32;
   void* d = nullptr;
   size_t cap = 0;
   CH_TRY(pool_alloc(dev, n * 4, &d, &cap));

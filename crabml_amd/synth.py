@@ -13,9 +13,11 @@ from typing import Dict, List, Optional
 import numpy as np
 
 F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 13, 14, 15
-BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256}
-BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292}
-TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
+Q5_0, Q5_1, Q2_K, Q3_K = 6, 7, 10, 11
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256, Q5_0: 32, Q5_1: 32, Q2_K: 256, Q3_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, Q5_0: 22, Q5_1: 24, Q2_K: 84, Q3_K: 110}
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K",
+              Q5_0: "Q5_0", Q5_1: "Q5_1", Q2_K: "Q2_K", Q3_K: "Q3_K"}
 TYPE_BY_NAME = {v: k for k, v in TYPE_NAMES.items()}
 
 
@@ -88,6 +90,20 @@ def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: f
         out[:, 0:192] = rng.integers(0, 256, size=(nb, 192), dtype=np.uint8)
         out[:, 192:208] = rng.integers(-64, 64, size=(nb, 16), dtype=np.int8).view(np.uint8)
         out[:, 208:210] = _f16_scales(rng, nb, lo / 256, hi / 256).reshape(nb, 1).view(np.uint8)
+    elif typ == Q5_0:  # d f16 | qh[4] | qs[16] (buf_q5_0.rs:13-19): levels -16..15
+        out[:, 0:2] = _f16_scales(rng, nb, lo / 2, hi / 2).reshape(nb, 1).view(np.uint8)
+        out[:, 2:] = rng.integers(0, 256, size=(nb, 20), dtype=np.uint8)
+    elif typ == Q5_1:  # d f16 | m f16 | qh[4] | qs[16] (buf_q5_1.rs:10-17): levels 0..31, m centres them
+        out[:, 0:2] = _f16_scales(rng, nb, lo / 2, hi / 2).reshape(nb, 1).view(np.uint8)
+        out[:, 2:4] = (-rng.uniform(8 * lo, 8 * hi, size=nb)).astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
+        out[:, 4:] = rng.integers(0, 256, size=(nb, 20), dtype=np.uint8)
+    elif typ == Q2_K:  # scales[16] (scale | min << 4) | qs[64] | d f16 | dmin f16 (buf_q2_k.rs:17-28)
+        out[:, 0:80] = rng.integers(0, 256, size=(nb, 80), dtype=np.uint8)
+        out[:, 80:82] = _f16_scales(rng, nb, lo / 4, hi / 4).reshape(nb, 1).view(np.uint8)
+        out[:, 82:84] = _f16_scales(rng, nb, lo / 3, hi / 3).reshape(nb, 1).view(np.uint8)
+    elif typ == Q3_K:  # hmask[32] | qs[64] | scales[12] | d f16 (buf_q3_k.rs:19-30): 6-bit scales - 32, levels -4..3
+        out[:, 0:108] = rng.integers(0, 256, size=(nb, 108), dtype=np.uint8)
+        out[:, 108:110] = _f16_scales(rng, nb, lo / 8, hi / 8).reshape(nb, 1).view(np.uint8)
     elif typ == Q8_K:
         out[:, 0:4] = rng.uniform(lo / 8, hi / 8, size=nb).astype(np.float32).reshape(nb, 1).view(np.uint8)
         q = rng.integers(-127, 128, size=(nb, 256), dtype=np.int8)
@@ -213,7 +229,8 @@ def to_hip(model: RawModel, device):
     import crabml_amd as ca
 
     tmap = {F32: ca.GGMLType.F32, F16: ca.GGMLType.F16, Q4_0: ca.GGMLType.Q4_0, Q4_1: ca.GGMLType.Q4_1,
-            Q8_0: ca.GGMLType.Q8_0, Q4_K: ca.GGMLType.Q4K, Q5_K: ca.GGMLType.Q5K, Q6_K: ca.GGMLType.Q6K, Q8_K: ca.GGMLType.Q8K}
+            Q8_0: ca.GGMLType.Q8_0, Q4_K: ca.GGMLType.Q4K, Q5_K: ca.GGMLType.Q5K, Q6_K: ca.GGMLType.Q6K, Q8_K: ca.GGMLType.Q8K,
+            Q5_0: ca.GGMLType.Q5_0, Q5_1: ca.GGMLType.Q5_1, Q2_K: ca.GGMLType.Q2K, Q3_K: ca.GGMLType.Q3K}
     s = model.shape
 
     def up(name):

@@ -52,8 +52,12 @@ typedef enum crabml_hip_ggml_type {
   CRABML_HIP_F16 = 1,
   CRABML_HIP_Q4_0 = 2,
   CRABML_HIP_Q4_1 = 3,
+  CRABML_HIP_Q5_0 = 6, /* weights only (rhs: Q8_0), crabml-core/src/cpu/buf/buf_q5_0.rs */
+  CRABML_HIP_Q5_1 = 7, /* weights only (rhs: Q8_1), crabml-core/src/cpu/buf/buf_q5_1.rs */
   CRABML_HIP_Q8_0 = 8,
   CRABML_HIP_Q8_1 = 9,
+  CRABML_HIP_Q2_K = 10, /* weights only (rhs: Q8_K), crabml-core/src/cpu/buf/buf_q2_k.rs */
+  CRABML_HIP_Q3_K = 11, /* weights only (rhs: Q8_K), crabml-core/src/cpu/buf/buf_q3_k.rs */
   CRABML_HIP_Q4_K = 12,
   CRABML_HIP_Q5_K = 13, /* weights only (rhs: Q8_K), in the REFERENCE's field order qs | qh | scales | d | dmin
                          * (crabml-core/src/cpu/buf/buf_q5_k.rs:13-21) -- not ggml's */
@@ -95,7 +99,8 @@ size_t crabml_hip_device_mem_in_use(crabml_hip_device_t* dev);
 
 /* ---- buffers ----------------------------------------------------------------------------- */
 /* Tensor::from_cpu (api.rs:14-19): uploads `nbytes` of GGML-layout bytes.  Accepts F32, F16,
- * Q8_0, Q4_0, Q4_1, Q4_K, Q6_K, Q8_K.  Quantized tensors must be 2-D (m, k) (or 1-D) with k a multiple
+ * Q8_0, Q4_0, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K -- every weight format of CpuTensorBuf (buf/api.rs:33-47).
+ * Quantized tensors must be 2-D (m, k) (or 1-D) with k a multiple
  * of the block size; they are re-laid-out once at upload into 16-byte-aligned planes (quants /
  * scales) -- the unpacked integers and scales are bit-identical to the GGUF bytes. */
 int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t nbytes, const size_t* shape,
@@ -179,7 +184,7 @@ int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a,
  * CRABML_HIP_FLAG_STRICT_ORDER every sum runs in the reference's scalar order and the step is bit-identical
  * to the reference at every context length.
  * Weights: layer matrices in any matmul_vec format (Q4_0, Q8_0, Q4_1 and Q4_K run fused kernels, Q4_K also
- * with attn_v / ffn_down in Q6_K -- llama.cpp's *_K_M mixes; Q5_K, Q6_K, Q8_K, F16, F32 and any other mix sharing
+ * with attn_v / ffn_down in Q6_K -- llama.cpp's *_K_M mixes; Q5_0, Q5_1, Q2_K, Q3_K, Q5_K, Q6_K, Q8_K, F16, F32 and any other mix sharing
  * one rhs dtype run as per-op segments inside the same graph); the classifier may have another format; norm
  * weights F32.  Tensor types whose rhs dtypes differ inside a layer: CRABML_HIP_NOT_IMPLEMENTED (use the
  * per-op trait path). */

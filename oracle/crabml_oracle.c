@@ -111,8 +111,8 @@ static inline int8_t rs_i32_as_i8(int32_t v) { return (int8_t)(uint8_t)((uint32_
 size_t co_block_elems(uint32_t t) {
   switch (t) {
     case CO_F32: case CO_F16: return 1;
-    case CO_Q4_0: case CO_Q4_1: case CO_Q8_0: case CO_Q8_1: return 32;
-    case CO_Q4_K: case CO_Q5_K: case CO_Q6_K: case CO_Q8_K: return 256;
+    case CO_Q4_0: case CO_Q4_1: case CO_Q5_0: case CO_Q5_1: case CO_Q8_0: case CO_Q8_1: return 32;
+    case CO_Q2_K: case CO_Q3_K: case CO_Q4_K: case CO_Q5_K: case CO_Q6_K: case CO_Q8_K: return 256;
     default: return 0;
   }
 }
@@ -122,6 +122,10 @@ size_t co_block_bytes(uint32_t t) {
     case CO_F16: return 2;
     case CO_Q4_0: return sizeof(co_block_q4_0);
     case CO_Q4_1: return sizeof(co_block_q4_1);
+    case CO_Q5_0: return sizeof(co_block_q5_0);
+    case CO_Q5_1: return sizeof(co_block_q5_1);
+    case CO_Q2_K: return sizeof(co_block_q2_k);
+    case CO_Q3_K: return sizeof(co_block_q3_k);
     case CO_Q8_0: return sizeof(co_block_q8_0);
     case CO_Q8_1: return sizeof(co_block_q8_1);
     case CO_Q4_K: return sizeof(co_block_q4_k);
@@ -135,9 +139,9 @@ uint32_t co_vec_dot_rhs_dtype(uint32_t t) { /* buf/api.rs:142-159 */
   switch (t) {
     case CO_F32: return CO_F32;
     case CO_F16: return CO_F16;
-    case CO_Q8_0: case CO_Q4_0: return CO_Q8_0;
-    case CO_Q8_1: case CO_Q4_1: return CO_Q8_1;
-    case CO_Q8_K: case CO_Q4_K: case CO_Q5_K: case CO_Q6_K: return CO_Q8_K;
+    case CO_Q8_0: case CO_Q4_0: case CO_Q5_0: return CO_Q8_0;
+    case CO_Q8_1: case CO_Q4_1: case CO_Q5_1: return CO_Q8_1;
+    case CO_Q8_K: case CO_Q2_K: case CO_Q3_K: case CO_Q4_K: case CO_Q5_K: case CO_Q6_K: return CO_Q8_K;
     default: return 0xffffffffu;
   }
 }
@@ -472,7 +476,75 @@ int co_quantize(const float* x, size_t n, uint32_t type, void* out) {
     case CO_Q4_K: co_quantize_f32_q4_k(x, n, (co_block_q4_k*)out); return 0;
     case CO_Q5_K: co_quantize_f32_q5_k(x, n, (co_block_q5_k*)out); return 0;
     case CO_Q6_K: co_quantize_f32_q6_k(x, n, (co_block_q6_k*)out); return 0;
+    case CO_Q5_0: co_quantize_f32_q5_0(x, n, (co_block_q5_0*)out); return 0;
+    case CO_Q5_1: co_quantize_f32_q5_1(x, n, (co_block_q5_1*)out); return 0;
+    case CO_Q2_K: co_quantize_f32_q2_k(x, n, (co_block_q2_k*)out); return 0;
+    case CO_Q3_K: co_quantize_f32_q3_k(x, n, (co_block_q3_k*)out); return 0;
     default: return -1;
+  }
+}
+
+static uint32_t rd_u32le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static void dq_q5_0(const co_block_q5_0* b, float* o) { /* buf_q5_0.rs:22-37 */
+  const float d = co_f16_to_f32(b->d);
+  const uint32_t qh = rd_u32le(b->qh);
+  for (int i = 0; i < 16; i++) {
+    const uint8_t xh0 = (uint8_t)(((qh >> i) << 4) & 0x10), xh1 = (uint8_t)((qh >> (i + 12)) & 0x10);
+    const int32_t x0 = (int32_t)((b->qs[i] & 0x0F) | xh0) - 16, x1 = (int32_t)((b->qs[i] >> 4) | xh1) - 16;
+    o[i] = (float)x0 * d;
+    o[i + 16] = (float)x1 * d;
+  }
+}
+static void dq_q5_1(const co_block_q5_1* b, float* o) { /* buf_q5_1.rs:20-36 (NOT interleaved, unlike Q4_1's) */
+  const float d = co_f16_to_f32(b->d), m = co_f16_to_f32(b->m);
+  const uint32_t qh = rd_u32le(b->qh);
+  for (int i = 0; i < 16; i++) {
+    const uint8_t xh0 = (uint8_t)(((qh >> i) << 4) & 0x10), xh1 = (uint8_t)((qh >> (i + 12)) & 0x10);
+    const uint8_t x0 = (uint8_t)((b->qs[i] & 0x0F) | xh0), x1 = (uint8_t)((b->qs[i] >> 4) | xh1);
+    o[i] = (float)x0 * d + m;
+    o[i + 16] = (float)x1 * d + m;
+  }
+}
+static void dq_q2_k(const co_block_q2_k* b, float* o) { /* buf_q2_k.rs:35-69 */
+  const float d = co_f16_to_f32(b->d), mn = co_f16_to_f32(b->dmin);
+  int is = 0, oi = 0;
+  for (int half = 0; half < 2; half++) {
+    const uint8_t* qs = b->qs + 32 * half;
+    for (int shift = 0; shift < 8; shift += 2) {
+      for (int h = 0; h < 2; h++) {
+        const uint8_t sc = b->scales[is++];
+        const float dl = d * (float)(sc & 0xF), ml = mn * (float)(sc >> 4);
+        for (int l = 0; l < 16; l++) o[oi++] = dl * (float)((qs[16 * h + l] >> shift) & 3) - ml;
+      }
+    }
+  }
+}
+/* the 16 6-bit scales of a Q3_K block, as the reference's u32 shuffle leaves them (buf_q3_k.rs:44-55 / :289-301) */
+static void q3k_scales(const uint8_t* s12, int8_t* sc16) {
+  for (int j = 0; j < 16; j++) {
+    const uint8_t lo = j < 8 ? (uint8_t)(s12[j] & 0xF) : (uint8_t)(s12[j - 8] >> 4);
+    const uint8_t hi = (uint8_t)((s12[8 + j % 4] >> (2 * (j / 4))) & 3);
+    sc16[j] = (int8_t)(lo | (hi << 4));
+  }
+}
+static void dq_q3_k(const co_block_q3_k* b, float* o) { /* buf_q3_k.rs:37-88 */
+  const float d_all = co_f16_to_f32(b->d);
+  int8_t sc[16];
+  q3k_scales(b->scales, sc);
+  uint8_t m = 1;
+  int is = 0, oi = 0;
+  for (int half = 0; half < 2; half++) {
+    const uint8_t* qs = b->qs + 32 * half;
+    for (int shift = 0; shift < 8; shift += 2) {
+      for (int h = 0; h < 2; h++) {
+        const float dl = d_all * (float)(int8_t)(sc[is++] - 32);
+        for (int l = 0; l < 16; l++) {
+          const int8_t mm = (b->hmask[16 * h + l] & m) ? 0 : 4;
+          o[oi++] = dl * (float)(int8_t)((int8_t)((qs[16 * h + l] >> shift) & 3) - mm);
+        }
+      }
+      m = (uint8_t)(m << 1);
+    }
   }
 }
 
@@ -597,6 +669,10 @@ int co_dequantize(const void* blocks, uint32_t type, size_t start, size_t n, flo
       case CO_Q5_K: dq_q5_k((const co_block_q5_k*)blk, tmp); break;
       case CO_Q6_K: dq_q6_k((const co_block_q6_k*)blk, tmp); break;
       case CO_Q8_K: dq_q8_k((const co_block_q8_k*)blk, tmp); break;
+      case CO_Q5_0: dq_q5_0((const co_block_q5_0*)blk, tmp); break;
+      case CO_Q5_1: dq_q5_1((const co_block_q5_1*)blk, tmp); break;
+      case CO_Q2_K: dq_q2_k((const co_block_q2_k*)blk, tmp); break;
+      case CO_Q3_K: dq_q3_k((const co_block_q3_k*)blk, tmp); break;
       default: return -1;
     }
     size_t take = n - done < be ? n - done : be;
@@ -1104,6 +1180,319 @@ __attribute__((target("avx2,fma"))) float co_vec_dot_q8_k_q8_k_avx2(const co_blo
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Q5_0 / Q5_1 / Q2_K / Q3_K: the formats the reference handles with scalar code only
+ * ---------------------------------------------------------------------------------------- */
+float co_vec_dot_q5_0_q8_0(const co_block_q5_0* a, const co_block_q8_0* b, size_t nb) { /* buf_q5_0.rs:143-161 */
+  float sumf = 0.0f;
+  for (size_t i = 0; i < nb; i++) {
+    const uint32_t qh = rd_u32le(a[i].qh);
+    int32_t sumi = 0;
+    for (int j = 0; j < 16; j++) {
+      const uint32_t xh0 = ((qh & (1u << j)) >> j) << 4, xh1 = (qh & (1u << (j + 16))) >> (j + 12);
+      const int32_t x0 = (((int32_t)a[i].qs[j] & 0x0F) | (int32_t)xh0) - 16, x1 = (((int32_t)a[i].qs[j] >> 4) | (int32_t)xh1) - 16;
+      sumi += x0 * (int32_t)b[i].qs[j] + x1 * (int32_t)b[i].qs[j + 16];
+    }
+    sumf += (float)sumi * co_f16_to_f32(a[i].d) * co_f16_to_f32(b[i].d);
+  }
+  return sumf;
+}
+float co_vec_dot_q5_1_q8_1(const co_block_q5_1* a, const co_block_q8_1* b, size_t nb) { /* buf_q5_1.rs:141-160: f16 products, as Q4_1 */
+  float sumf = 0.0f;
+  for (size_t i = 0; i < nb; i++) {
+    const uint32_t qh = rd_u32le(a[i].qh);
+    int32_t sumi = 0;
+    for (int j = 0; j < 16; j++) {
+      const uint32_t xh0 = ((qh >> j) << 4) & 0x10, xh1 = (qh >> (j + 12)) & 0x10;
+      const int32_t x0 = ((int32_t)a[i].qs[j] & 0xF) | (int32_t)xh0, x1 = ((int32_t)a[i].qs[j] >> 4) | (int32_t)xh1;
+      sumi += x0 * (int32_t)b[i].qs[j] + x1 * (int32_t)b[i].qs[j + 16];
+    }
+    sumf += (float)sumi * co_f16_to_f32(h_mul(a[i].d, b[i].d)) + co_f16_to_f32(h_mul(a[i].m, b[i].s));
+  }
+  return sumf;
+}
+float co_vec_dot_q2_k_q8_k(const co_block_q2_k* a, const co_block_q8_k* b, size_t nb, int i16_wrap, size_t* n_overflow) { /* buf_q2_k.rs:216-258 */
+  float sumf = 0.0f;
+  size_t over = 0;
+  for (size_t i = 0; i < nb; i++) {
+    int32_t summs = 0;
+    for (int j = 0; j < 16; j++) {
+      int32_t prod = (int32_t)b[i].bsums[j] * (int32_t)(a[i].scales[j] >> 4);
+      if (prod < -32768 || prod > 32767) over++;
+      if (i16_wrap) prod = (int16_t)(uint16_t)((uint32_t)prod & 0xffffu);
+      summs += prod;
+      if (summs < -32768 || summs > 32767) over++;
+      if (i16_wrap) summs = (int16_t)(uint16_t)((uint32_t)summs & 0xffffu);
+    }
+    const float dall = b[i].d * co_f16_to_f32(a[i].d), dmin = b[i].d * co_f16_to_f32(a[i].dmin);
+    int32_t isum = 0;
+    int is = 0;
+    const int8_t* q8 = b[i].qs;
+    for (int half = 0; half < 2; half++) {
+      const uint8_t* q2 = a[i].qs + 32 * half;
+      for (int shift = 0; shift < 8; shift += 2) {
+        for (int h = 0; h < 2; h++) {
+          const int32_t d = a[i].scales[is++] & 0xF;
+          int32_t isuml = 0;
+          for (int l = 16 * h; l < 16 * h + 16; l++) isuml += (int32_t)q8[l] * (int32_t)((q2[l] >> shift) & 3);
+          isum += d * isuml;
+        }
+        q8 += 32;
+      }
+    }
+    sumf += dall * (float)isum - dmin * (float)summs;
+  }
+  if (n_overflow) *n_overflow = over;
+  return sumf;
+}
+/* aux8 of buf_q3_k.rs:247-281: the 256 signed 3-bit levels (2 low bits, minus 4 where the hmask bit is clear) */
+static void q3k_levels(const co_block_q3_k* a, int8_t* aux8) {
+  uint8_t m = 1;
+  int o = 0;
+  for (int half = 0; half < 2; half++) {
+    const uint8_t* q3 = a->qs + 32 * half;
+    for (int shift = 0; shift < 8; shift += 2) {
+      for (int l = 0; l < 32; l++) aux8[o + l] = (int8_t)((int8_t)((q3[l] >> shift) & 3) - ((a->hmask[l] & m) ? 0 : 4));
+      o += 32;
+      m = (uint8_t)(m << 1);
+    }
+  }
+}
+float co_vec_dot_q3_k_q8_k(const co_block_q3_k* a, const co_block_q8_k* b, size_t nb) { /* buf_q3_k.rs:238-329 */
+  float sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int8_t aux8[256], sc[16];
+  for (size_t i = 0; i < nb; i++) {
+    q3k_levels(&a[i], aux8);
+    q3k_scales(a[i].scales, sc);
+    int32_t aux32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < 16; j++) {
+      const int32_t s = (int32_t)(int8_t)(sc[j] - 32);
+      for (int g = 0; g < 2; g++)
+        for (int l = 0; l < 8; l++) {
+          const int16_t p = (int16_t)((int16_t)b[i].qs[16 * j + 8 * g + l] * (int16_t)aux8[16 * j + 8 * g + l]);
+          aux32[l] += s * (int32_t)p;
+        }
+    }
+    const float d = co_f16_to_f32(a[i].d) * b[i].d;
+    for (int l = 0; l < 8; l++) sums[l] += d * (float)aux32[l];
+  }
+  float r = sums[0];
+  for (int l = 1; l < 8; l++) r = r + sums[l];
+  return r;
+}
+
+void co_quantize_f32_q5_0(const float* x, size_t n, co_block_q5_0* out) { /* buf_q5_0.rs:96-141 */
+  for (size_t c = 0; c < n / 32; c++) {
+    const float* ch = x + 32 * c;
+    float max_val = 0.0f, max_abs = 0.0f;
+    for (int i = 0; i < 32; i++) {
+      const float av = fabsf(ch[i]);
+      if (max_abs < av) {
+        max_abs = av;
+        max_val = ch[i];
+      }
+    }
+    const float d = max_val / -16.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint32_t iqh = 0;
+    for (int i = 0; i < 16; i++) {
+      const float x0 = ch[i] * id, x1 = ch[i + 16] * id;
+      int8_t a0 = rs_f32_as_i8(x0 + 16.5f), a1 = rs_f32_as_i8(x1 + 16.5f);
+      const uint8_t xi0 = (uint8_t)(a0 < 31 ? a0 : 31), xi1 = (uint8_t)(a1 < 31 ? a1 : 31);
+      out[c].qs[i] = (uint8_t)((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+      iqh |= (((uint32_t)xi0 & 0x10u) >> 4) << i;
+      iqh |= (((uint32_t)xi1 & 0x10u) >> 4) << (i + 16);
+    }
+    for (int i = 0; i < 4; i++) out[c].qh[i] = (uint8_t)(iqh >> (8 * i));
+    out[c].d = co_f32_to_f16(d);
+  }
+}
+void co_quantize_f32_q5_1(const float* x, size_t n, co_block_q5_1* out) { /* buf_q5_1.rs:99-139 */
+  for (size_t c = 0; c < n / 32; c++) {
+    const float* ch = x + 32 * c;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f; /* f32::MAX, f32::MIN; f32::min / max skip NaN operands */
+    for (int i = 0; i < 32; i++) {
+      mn = fminf(ch[i], mn);
+      mx = fmaxf(ch[i], mx);
+    }
+    const float d = (mx - mn) / 31.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint32_t iqh = 0;
+    for (int i = 0; i < 16; i++) {
+      const float x0 = (ch[i] - mn) * id, x1 = (ch[i + 16] - mn) * id;
+      const uint8_t xi0 = rs_f32_as_u8(x0 + 0.5f), xi1 = rs_f32_as_u8(x1 + 0.5f);
+      out[c].qs[i] = (uint8_t)((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+      iqh |= (((uint32_t)xi0 & 0x10u) >> 4) << i;
+      iqh |= (((uint32_t)xi1 & 0x10u) >> 4) << (i + 16);
+    }
+    for (int i = 0; i < 4; i++) out[c].qh[i] = (uint8_t)(iqh >> (8 * i));
+    out[c].d = co_f32_to_f16(d);
+    out[c].m = co_f32_to_f16(mn);
+  }
+}
+void co_quantize_f32_q2_k(const float* x, size_t n, co_block_q2_k* out) { /* buf_q2_k.rs:145-214 */
+  uint8_t L[256]; /* declared outside the block loop in the reference: make_qkx1_quants' did_change sees the previous block's levels */
+  float mins[16], scales[16];
+  memset(L, 0, sizeof L);
+  for (size_t i = 0; i < n / 256; i++) {
+    const float* ch = x + 256 * i;
+    co_block_q2_k* b = &out[i];
+    memset(b, 0, sizeof *b);
+    float max_scale = 0.0f, max_min = 0.0f;
+    for (int j = 0; j < 16; j++) {
+      scales[j] = make_qkx1_quants(16, 3, ch + 16 * j, L + 16 * j, &mins[j], 5);
+      if (scales[j] > max_scale) max_scale = scales[j];
+      if (mins[j] > max_min) max_min = mins[j];
+    }
+    if (max_scale > 0.0f) {
+      const float iscale = 15.0f / max_scale;
+      for (int j = 0; j < 16; j++) b->scales[j] = (uint8_t)(uint32_t)co_nearest_i32(iscale * scales[j]);
+      b->d = co_f32_to_f16(max_scale / 15.0f);
+    }
+    if (max_min > 0.0f) {
+      const float iscale = 15.0f / max_min;
+      for (int j = 0; j < 16; j++) {
+        const uint8_t l = (uint8_t)(uint32_t)co_nearest_i32(iscale * mins[j]);
+        b->scales[j] |= (uint8_t)(l << 4);
+      }
+      b->dmin = co_f32_to_f16(max_min / 15.0f);
+    }
+    for (int j = 0; j < 16; j++) {
+      const float d = co_f16_to_f32(b->d) * (float)(b->scales[j] & 0xF);
+      if (d == 0.0f) continue;
+      const float dm = co_f16_to_f32(b->dmin) * (float)(b->scales[j] >> 4);
+      for (int ii = 0; ii < 16; ii++) {
+        int32_t l = co_nearest_i32((x[16 * j + ii] + dm) / d); /* `data`, not `data_chunk`: buf_q2_k.rs:197 */
+        l = l < 3 ? l : 3;
+        l = l > 0 ? l : 0;
+        L[16 * j + ii] = (uint8_t)l;
+      }
+    }
+    for (int j = 0; j < 256; j += 128)
+      for (int l = 0; l < 32; l++)
+        b->qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+  }
+}
+/* util.rs:218-284 (do_rmse = true is the only call: buf_q3_k.rs:167) */
+static float make_q3_quants(int n, int nmax, const float* data, int8_t* l, int do_rmse) {
+  float max = 0.0f, amax = 0.0f;
+  for (int i = 0; i < n; i++) {
+    const float ax = fabsf(data[i]);
+    if (ax > amax) {
+      amax = ax;
+      max = data[i];
+    }
+  }
+  if (amax == 0.0f) {
+    for (int i = 0; i < n; i++) l[i] = 0;
+    return 0.0f;
+  }
+  const float iscale = -(float)nmax / max;
+  if (do_rmse) {
+    float sumlx = 0.0f, suml2 = 0.0f;
+    for (int i = 0; i < n; i++) {
+      int32_t li = co_nearest_i32(iscale * data[i]);
+      li = li < nmax - 1 ? li : nmax - 1;
+      li = li > -nmax ? li : -nmax;
+      l[i] = (int8_t)li;
+      const float w = data[i] * data[i];
+      sumlx += w * data[i] * (float)li;
+      suml2 += w * (float)(li * li);
+    }
+    for (int t = 0; t < 5; t++) {
+      int n_changed = 0;
+      for (int i = 0; i < n; i++) {
+        const float w = data[i] * data[i];
+        float slx = sumlx - w * data[i] * (float)l[i];
+        if (slx > 0.0f) {
+          float sl2 = suml2 - w * (float)l[i] * (float)l[i];
+          int32_t new_l = co_nearest_i32(data[i] * sl2 / slx);
+          new_l = new_l < nmax - 1 ? new_l : nmax - 1;
+          new_l = new_l > -nmax ? new_l : -nmax;
+          if (new_l != (int32_t)l[i]) {
+            slx += w * data[i] * (float)new_l;
+            sl2 += w * (float)(new_l * new_l);
+            if (sl2 > 0.0f && slx * slx * suml2 > sumlx * sumlx * sl2) {
+              l[i] = (int8_t)new_l;
+              sumlx = slx;
+              suml2 = sl2;
+              n_changed++;
+            }
+          }
+        }
+      }
+      if (n_changed == 0) break;
+    }
+    for (int i = 0; i < n; i++) l[i] = (int8_t)(l[i] + nmax);
+    return sumlx / suml2;
+  }
+  for (int i = 0; i < n; i++) {
+    int32_t li = co_nearest_i32(iscale * data[i]);
+    li = li < nmax - 1 ? li : nmax - 1;
+    li = li > -nmax ? li : -nmax;
+    l[i] = (int8_t)(li + nmax);
+  }
+  return 1.0f / iscale;
+}
+void co_quantize_f32_q3_k(const float* x, size_t n, co_block_q3_k* out) { /* buf_q3_k.rs:155-236 */
+  int8_t L[256];
+  float scales[16];
+  for (size_t i = 0; i < n / 256; i++) {
+    const float* ch = x + 256 * i;
+    co_block_q3_k* b = &out[i];
+    memset(b, 0, sizeof *b);
+    float max_scale = 0.0f, amax = 0.0f;
+    for (int j = 0; j < 16; j++) {
+      scales[j] = make_q3_quants(16, 4, ch + 16 * j, L + 16 * j, 1);
+      const float sc = fabsf(scales[j]);
+      if (sc > amax) {
+        amax = sc;
+        max_scale = scales[j];
+      }
+    }
+    if (max_scale != 0.0f) {
+      const float iscale = -32.0f / max_scale;
+      for (int j = 0; j < 16; j++) {
+        int8_t l = rs_i32_as_i8(co_nearest_i32(iscale * scales[j]));
+        l = (int8_t)((l < -32 ? -32 : l > 31 ? 31 : l) + 32);
+        if (j < 8)
+          b->scales[j] = (uint8_t)((uint8_t)l & 0xf);
+        else
+          b->scales[j - 8] |= (uint8_t)(((uint8_t)l & 0xf) << 4);
+        l = (int8_t)(l >> 4);
+        b->scales[j % 4 + 8] |= (uint8_t)((uint8_t)l << (2 * (j / 4)));
+      }
+      b->d = co_f32_to_f16(1.0f / iscale);
+    }
+    for (int j = 0; j < 16; j++) {
+      int8_t sc = j < 8 ? (int8_t)(b->scales[j] & 0xf) : (int8_t)(b->scales[j - 8] >> 4);
+      sc = (int8_t)((sc | (int8_t)(((b->scales[8 + j % 4] >> (2 * (j / 4))) & 3) << 4)) - 32);
+      const float d = co_f16_to_f32(b->d) * (float)sc;
+      if (d == 0.0f) continue;
+      for (int ii = 0; ii < 16; ii++) {
+        int32_t l = co_nearest_i32(ch[16 * j + ii] / d);
+        l = l < -4 ? -4 : l > 3 ? 3 : l;
+        L[16 * j + ii] = (int8_t)(l + 4);
+      }
+    }
+    int m = 0;
+    uint8_t hm = 1;
+    for (int e = 0; e < 256; e++) {
+      if (L[e] > 3) {
+        b->hmask[m] |= hm;
+        L[e] = (int8_t)(L[e] - 4);
+      }
+      if (++m == 32) {
+        m = 0;
+        hm = (uint8_t)(hm << 1);
+      }
+    }
+    for (int j = 0; j < 256; j += 128)
+      for (int l = 0; l < 32; l++)
+        b->qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Exact integer parts (bit-exact gate for the HIP unpack + integer dot)
  * ---------------------------------------------------------------------------------------- */
 int co_block_dots(const void* w, uint32_t wtype, const void* x, size_t n, int32_t* out) {
@@ -1186,6 +1575,62 @@ int co_block_dots(const void* w, uint32_t wtype, const void* x, size_t n, int32_
             aux8[j + l + 96] = (int8_t)((int32_t)((q4[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32);
           }
         }
+        for (int gq = 0; gq < 16; gq++) {
+          int32_t sacc = 0;
+          for (int l = 0; l < 16; l++) sacc += (int32_t)aux8[16 * gq + l] * b[i].qs[16 * gq + l];
+          out[i * 16 + gq] = sacc;
+        }
+      }
+      return 0;
+    }
+    case CO_Q5_0: {
+      const co_block_q5_0* a = (const co_block_q5_0*)w;
+      const co_block_q8_0* b = (const co_block_q8_0*)x;
+      for (size_t i = 0; i < g; i++) {
+        const uint32_t qh = rd_u32le(a[i].qh);
+        int32_t s = 0;
+        for (int j = 0; j < 16; j++) {
+          const int32_t x0 = (int32_t)((a[i].qs[j] & 0xF) | (((qh >> j) & 1) << 4)) - 16;
+          const int32_t x1 = (int32_t)((a[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4)) - 16;
+          s += x0 * b[i].qs[j] + x1 * b[i].qs[j + 16];
+        }
+        out[i] = s;
+      }
+      return 0;
+    }
+    case CO_Q5_1: {
+      const co_block_q5_1* a = (const co_block_q5_1*)w;
+      const co_block_q8_1* b = (const co_block_q8_1*)x;
+      for (size_t i = 0; i < g; i++) {
+        const uint32_t qh = rd_u32le(a[i].qh);
+        int32_t s = 0;
+        for (int j = 0; j < 16; j++) {
+          const int32_t x0 = (int32_t)((a[i].qs[j] & 0xF) | (((qh >> j) & 1) << 4));
+          const int32_t x1 = (int32_t)((a[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4));
+          s += x0 * b[i].qs[j] + x1 * b[i].qs[j + 16];
+        }
+        out[i] = s;
+      }
+      return 0;
+    }
+    case CO_Q2_K: { /* per 16-element scale group, in element order: sum q2 * q8 */
+      const co_block_q2_k* a = (const co_block_q2_k*)w;
+      const co_block_q8_k* b = (const co_block_q8_k*)x;
+      for (size_t i = 0; i < n / 256; i++)
+        for (int gq = 0; gq < 16; gq++) {
+          const int half = gq / 8, shift = 2 * ((gq % 8) / 2), h = gq & 1;
+          int32_t sacc = 0;
+          for (int l = 0; l < 16; l++) sacc += (int32_t)((a[i].qs[32 * half + 16 * h + l] >> shift) & 3) * b[i].qs[16 * gq + l];
+          out[i * 16 + gq] = sacc;
+        }
+      return 0;
+    }
+    case CO_Q3_K: { /* per 16-element scale group: sum (q3 - 4) * q8 */
+      const co_block_q3_k* a = (const co_block_q3_k*)w;
+      const co_block_q8_k* b = (const co_block_q8_k*)x;
+      int8_t aux8[256];
+      for (size_t i = 0; i < n / 256; i++) {
+        q3k_levels(&a[i], aux8);
         for (int gq = 0; gq < 16; gq++) {
           int32_t sacc = 0;
           for (int l = 0; l < 16; l++) sacc += (int32_t)aux8[16 * gq + l] * b[i].qs[16 * gq + l];
@@ -1362,6 +1807,10 @@ static float vec_dot_dispatch(struct co_device* d, uint32_t wtype, const void* w
       return co_vec_dot_q4_k_q8_k((const co_block_q4_k*)wrow, (const co_block_q8_k*)xrow, k / 256, 0, NULL);
     case CO_Q5_K: /* scalar only in the reference */
       return co_vec_dot_q5_k_q8_k((const co_block_q5_k*)wrow, (const co_block_q8_k*)xrow, k / 256, 0, NULL);
+    case CO_Q5_0: return co_vec_dot_q5_0_q8_0((const co_block_q5_0*)wrow, (const co_block_q8_0*)xrow, k / 32);
+    case CO_Q5_1: return co_vec_dot_q5_1_q8_1((const co_block_q5_1*)wrow, (const co_block_q8_1*)xrow, k / 32);
+    case CO_Q2_K: return co_vec_dot_q2_k_q8_k((const co_block_q2_k*)wrow, (const co_block_q8_k*)xrow, k / 256, 0, NULL);
+    case CO_Q3_K: return co_vec_dot_q3_k_q8_k((const co_block_q3_k*)wrow, (const co_block_q8_k*)xrow, k / 256);
     case CO_Q6_K: /* the reference has no SIMD path for Q6_K */
       return co_vec_dot_q6_k_q8_k((const co_block_q6_k*)wrow, (const co_block_q8_k*)xrow, k / 256);
     case CO_Q8_K:

@@ -36,8 +36,8 @@ extern "C" {
 
 /* GGML type ids: crabml-core/src/gguf.rs:86-108 */
 enum {
-  CO_F32 = 0, CO_F16 = 1, CO_Q4_0 = 2, CO_Q4_1 = 3, CO_Q8_0 = 8, CO_Q8_1 = 9,
-  CO_Q4_K = 12, CO_Q5_K = 13, CO_Q6_K = 14, CO_Q8_K = 15
+  CO_F32 = 0, CO_F16 = 1, CO_Q4_0 = 2, CO_Q4_1 = 3, CO_Q5_0 = 6, CO_Q5_1 = 7, CO_Q8_0 = 8, CO_Q8_1 = 9,
+  CO_Q2_K = 10, CO_Q3_K = 11, CO_Q4_K = 12, CO_Q5_K = 13, CO_Q6_K = 14, CO_Q8_K = 15
 };
 
 #pragma pack(push, 1)
@@ -50,6 +50,10 @@ typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qs[128];
 typedef struct { uint8_t qs[128]; uint8_t qh[32]; uint8_t scales[12]; uint16_t d; uint16_t dmin; } co_block_q5_k;
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; } co_block_q6_k;       /* buf_q6_k.rs:11-18  210 B */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; } co_block_q8_k;                     /* buf_q8_k.rs:6-12  292 B */
+typedef struct { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; } co_block_q5_0;                      /* buf_q5_0.rs:13-19  22 B */
+typedef struct { uint16_t d; uint16_t m; uint8_t qh[4]; uint8_t qs[16]; } co_block_q5_1;          /* buf_q5_1.rs:10-17  24 B */
+typedef struct { uint8_t scales[16]; uint8_t qs[64]; uint16_t d; uint16_t dmin; } co_block_q2_k;  /* buf_q2_k.rs:17-28  84 B */
+typedef struct { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t d; } co_block_q3_k; /* buf_q3_k.rs:19-30 110 B */
 #pragma pack(pop)
 
 /* ---- half crate ---- */
@@ -71,6 +75,12 @@ void co_quantize_f32_q4_0(const float* x, size_t n, co_block_q4_0* out); /* buf_
 void co_quantize_f32_q4_1(const float* x, size_t n, co_block_q4_1* out); /* buf_q4_1.rs:94-124 */
 void co_quantize_f32_q4_k(const float* x, size_t n, co_block_q4_k* out); /* buf_q4_k.rs:111-190 */
 void co_quantize_f32_q5_k(const float* x, size_t n, co_block_q5_k* out); /* buf_q5_k.rs:123-227 */
+void co_quantize_f32_q5_0(const float* x, size_t n, co_block_q5_0* out); /* buf_q5_0.rs:96-141 */
+void co_quantize_f32_q5_1(const float* x, size_t n, co_block_q5_1* out); /* buf_q5_1.rs:99-139 */
+/* buf_q2_k.rs:145-214.  Reproduces the reference's indexing slip at :197 (`data[16 * j + ii]` reads the FIRST super-block's
+ * values for every super-block): weights quantized by the reference carry it, so the restatement does too. */
+void co_quantize_f32_q2_k(const float* x, size_t n, co_block_q2_k* out);
+void co_quantize_f32_q3_k(const float* x, size_t n, co_block_q3_k* out); /* buf_q3_k.rs:155-236, util.rs:218-284 */
 /* generic: quantize f32 -> `type` into raw bytes; returns 0 ok, -1 unsupported */
 int co_quantize(const float* x, size_t n, uint32_t type, void* out);
 
@@ -92,6 +102,11 @@ float co_vec_dot_q4_k_q8_k(const co_block_q4_k* a, const co_block_q8_k* b, size_
 /* same i16 caveat as Q4_K (buf_q5_k.rs:282-285); the eight f32 lanes aux32 / sums of buf_q5_k.rs:287-318 are kept as written */
 float co_vec_dot_q5_k_q8_k(const co_block_q5_k* a, const co_block_q8_k* b, size_t nblocks, int i16_wrap, size_t* n_overflow); /* buf_q5_k.rs:229-325 */
 float co_vec_dot_q8_k_q8_k(const co_block_q8_k* a, const co_block_q8_k* b, size_t nblocks); /* buf_q8_k.rs:211-224 */
+float co_vec_dot_q5_0_q8_0(const co_block_q5_0* a, const co_block_q8_0* b, size_t nblocks); /* buf_q5_0.rs:143-161 (scalar only) */
+float co_vec_dot_q5_1_q8_1(const co_block_q5_1* a, const co_block_q8_1* b, size_t nblocks); /* buf_q5_1.rs:141-160 (scalar only) */
+/* `summs` (bsums x the 4-bit mins) is an i16 in the reference (buf_q2_k.rs:219-222): same wrap / overflow reporting as Q4_K */
+float co_vec_dot_q2_k_q8_k(const co_block_q2_k* a, const co_block_q8_k* b, size_t nblocks, int i16_wrap, size_t* n_overflow); /* buf_q2_k.rs:216-258 */
+float co_vec_dot_q3_k_q8_k(const co_block_q3_k* a, const co_block_q8_k* b, size_t nblocks); /* buf_q3_k.rs:238-329: eight i32 lanes per block, eight f32 sums */
 float co_vec_dot_q6_k_q8_k(const co_block_q6_k* a, const co_block_q8_k* b, size_t nblocks); /* buf_q6_k.rs:183-234 (scalar only) */
 void co_quantize_f32_q6_k(const float* x, size_t n, co_block_q6_k* out);                    /* buf_q6_k.rs:109-181, util.rs:29-152 */
 float co_vec_dot_f32_f32(const float* a, const float* b, size_t n);                          /* buf_f32.rs:19-27 */
@@ -107,7 +122,8 @@ float co_vec_dot_q8_k_q8_k_avx2(const co_block_q8_k* a, const co_block_q8_k* b, 
 /* ---- exact integer part of the dots: one i32 per 32-element group (bit-exact gate) ----
  * Q4_0: sum_j (nib-8)*q8 ; Q8_0: sum q*q ; Q4_1: sum nib*q8 (unsigned nibbles);
  * Q4_K: per 32-group sum nib*q8 (unscaled, 8 per super-block); Q5_K: the same with the fifth bit (sum q5*q8);
- * Q8_K: per 32-group sum q*q. */
+ * Q8_K: per 32-group sum q*q; Q5_0: sum (q5-16)*q8; Q5_1: sum q5*q8;
+ * Q2_K / Q3_K: one i32 per 16-element scale group (16 per super-block): sum q2*q8 / sum (q3-4)*q8, unscaled. */
 int co_block_dots(const void* w, uint32_t wtype, const void* x, size_t n_elems, int32_t* out);
 
 /* ---- exp / gelu f16 tables: cpu_device.rs:108-125, buf_f32.rs:29-35, gelu.rs:19-22 ---- */

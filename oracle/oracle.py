@@ -24,9 +24,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 3, 8, 9, 12, 13, 14, 15
-TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q8_1: "Q8_1", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
-BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256}
-BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292}
+Q5_0, Q5_1, Q2_K, Q3_K = 6, 7, 10, 11  # gguf.rs:93-99
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q8_0: "Q8_0", Q8_1: "Q8_1", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K",
+              Q5_0: "Q5_0", Q5_1: "Q5_1", Q2_K: "Q2_K", Q3_K: "Q3_K"}
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256, Q5_0: 32, Q5_1: 32, Q2_K: 256, Q3_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, Q5_0: 22, Q5_1: 24, Q2_K: 84, Q3_K: 110}
 ROPE_LLAMA, ROPE_NEOX = 0, 1
 
 
@@ -73,6 +75,10 @@ def lib() -> C.CDLL:
     sig("co_vec_dot_q4_k_q8_k", f32, vp, vp, sz, i32, vp)
     sig("co_vec_dot_q5_k_q8_k", f32, vp, vp, sz, i32, vp)
     sig("co_vec_dot_q8_k_q8_k", f32, vp, vp, sz)
+    sig("co_vec_dot_q5_0_q8_0", f32, vp, vp, sz)
+    sig("co_vec_dot_q5_1_q8_1", f32, vp, vp, sz)
+    sig("co_vec_dot_q2_k_q8_k", f32, vp, vp, sz, i32, vp)
+    sig("co_vec_dot_q3_k_q8_k", f32, vp, vp, sz)
     sig("co_vec_dot_q6_k_q8_k", f32, vp, vp, sz)
     sig("co_vec_dot_f32_f32", f32, vp, vp, sz)
     sig("co_vec_dot_f16_f16", f32, vp, vp, sz)
@@ -173,6 +179,14 @@ def vec_dot(w_raw: np.ndarray, wtyp: int, x_raw: np.ndarray, n_elems: int, avx2:
         return L.co_vec_dot_q5_k_q8_k(_p(w_raw), _p(x_raw), nb, 0, None)
     if wtyp == Q6_K:
         return L.co_vec_dot_q6_k_q8_k(_p(w_raw), _p(x_raw), nb)
+    if wtyp == Q5_0:
+        return L.co_vec_dot_q5_0_q8_0(_p(w_raw), _p(x_raw), nb)
+    if wtyp == Q5_1:
+        return L.co_vec_dot_q5_1_q8_1(_p(w_raw), _p(x_raw), nb)
+    if wtyp == Q2_K:
+        return L.co_vec_dot_q2_k_q8_k(_p(w_raw), _p(x_raw), nb, 0, None)
+    if wtyp == Q3_K:
+        return L.co_vec_dot_q3_k_q8_k(_p(w_raw), _p(x_raw), nb)
     if wtyp == Q8_K:
         return (L.co_vec_dot_q8_k_q8_k_avx2 if avx2 else L.co_vec_dot_q8_k_q8_k)(_p(w_raw), _p(x_raw), nb)
     if wtyp == F32:
@@ -180,6 +194,15 @@ def vec_dot(w_raw: np.ndarray, wtyp: int, x_raw: np.ndarray, n_elems: int, avx2:
     if wtyp == F16:
         return L.co_vec_dot_f16_f16(_p(w_raw), _p(x_raw), n_elems)
     raise TensorError(f"vec_dot on {wtyp}")
+
+
+def q2k_overflow_count(w_raw: np.ndarray, x_raw: np.ndarray, n_elems: int) -> int:
+    """products / partial sums of buf_q2_k.rs:219-222 that do not fit the reference's i16 `summs`"""
+    cnt = C.c_size_t(0)
+    w_raw = np.ascontiguousarray(w_raw).view(np.uint8)
+    x_raw = np.ascontiguousarray(x_raw).view(np.uint8)
+    lib().co_vec_dot_q2_k_q8_k(_p(w_raw), _p(x_raw), n_elems // 256, 0, C.byref(cnt))
+    return int(cnt.value)
 
 
 def q4k_overflow_count(w_raw: np.ndarray, x_raw: np.ndarray, n_elems: int) -> int:
@@ -193,7 +216,7 @@ def q4k_overflow_count(w_raw: np.ndarray, x_raw: np.ndarray, n_elems: int) -> in
 def block_dots(w_raw: np.ndarray, wtyp: int, x_raw: np.ndarray, n_elems: int) -> np.ndarray:
     w_raw = np.ascontiguousarray(w_raw).view(np.uint8)
     x_raw = np.ascontiguousarray(x_raw).view(np.uint8)
-    out = np.empty(n_elems // (16 if wtyp == Q6_K else 32), dtype=np.int32)  # Q6_K: one per 16-element scale group
+    out = np.empty(n_elems // (16 if wtyp in (Q6_K, Q2_K, Q3_K) else 32), dtype=np.int32)  # Q6_K / Q2_K / Q3_K: one per 16-element scale group
     rc = lib().co_block_dots(_p(w_raw), wtyp, _p(x_raw), n_elems, _p(out))
     if rc != 0:
         raise TensorError("block_dots unsupported type")
@@ -201,7 +224,8 @@ def block_dots(w_raw: np.ndarray, wtyp: int, x_raw: np.ndarray, n_elems: int) ->
 
 
 def rhs_dtype(wtyp: int) -> int:
-    return {F32: F32, F16: F16, Q8_0: Q8_0, Q4_0: Q8_0, Q8_1: Q8_1, Q4_1: Q8_1, Q8_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K}[wtyp]
+    return {F32: F32, F16: F16, Q8_0: Q8_0, Q4_0: Q8_0, Q8_1: Q8_1, Q4_1: Q8_1, Q8_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K,
+            Q5_0: Q8_0, Q5_1: Q8_1, Q2_K: Q8_K, Q3_K: Q8_K}[wtyp]
 
 
 def argmax_last(x: np.ndarray) -> int:

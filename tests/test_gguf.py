@@ -142,7 +142,7 @@ def test_reference_fixture_known_answers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt,out", [("Q4_0", None), ("Q4_K", "Q6_K"), ("F32", None), ("Q8_0", "Q6_K"), ("Q5_K", None)])
+@pytest.mark.parametrize("fmt,out", [("Q4_0", None), ("Q4_K", "Q6_K"), ("F32", None), ("Q8_0", "Q6_K"), ("Q5_K", None), ("Q3_K", "Q5_0"), ("Q2_K", "Q5_1")])
 def test_gguf_loaded_model_decodes_like_the_uploaded_one(tmp_path, fmt, out):
     """llama.cpp-style files: layers of one type, token_embd / output of another; norm weights F32."""
     kw = dict(output_type=synth.TYPE_BY_NAME[out], embed_type=synth.TYPE_BY_NAME[out]) if out else {}

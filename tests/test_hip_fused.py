@@ -58,7 +58,7 @@ def test_fused_strict_is_bit_exact(ca, shape, fmt, kv_f16):
                     assert np.array_equal(got[lo:lo + n], exp[lo:lo + n]), (layer, which, h)
 
 
-@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F16", "F32"])
+@pytest.mark.parametrize("fmt", ["Q4_1", "Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F16", "F32"])
 @pytest.mark.parametrize("kv_f16", [False, True])
 def test_decode_step_other_formats_strict_is_bit_exact(ca, fmt, kv_f16):
     """Formats without fused kernels run the per-op segment path inside the same graph (rhs quantized to
@@ -73,7 +73,7 @@ def test_decode_step_other_formats_strict_is_bit_exact(ca, fmt, kv_f16):
         assert np.array_equal(r.forward(t, i).view(np.uint32), ref[i].view(np.uint32)), f"{fmt} step {i}"
 
 
-@pytest.mark.parametrize("fmt", ["Q4_1", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F16", "F32"])
+@pytest.mark.parametrize("fmt", ["Q4_1", "Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F16", "F32"])
 def test_decode_step_other_formats_fast(ca, fmt):
     model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=15)
     toks = PROMPT + [7, 9]

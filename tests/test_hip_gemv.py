@@ -17,8 +17,8 @@ from tests.helpers import GEMV_REL, gemv_order_bound
 
 pytestmark = pytest.mark.gpu
 
-FORMATS = ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q5_K", "Q6_K", "Q8_K"]
-HT = {"Q4_0": "Q4_0", "Q8_0": "Q8_0", "Q4_1": "Q4_1", "Q4_K": "Q4K", "Q5_K": "Q5K", "Q6_K": "Q6K", "Q8_K": "Q8K", "F32": "F32", "F16": "F16"}
+FORMATS = ["Q4_0", "Q8_0", "Q4_1", "Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K"]
+HT = {"Q4_0": "Q4_0", "Q8_0": "Q8_0", "Q4_1": "Q4_1", "Q5_0": "Q5_0", "Q5_1": "Q5_1", "Q2_K": "Q2K", "Q3_K": "Q3K", "Q4_K": "Q4K", "Q5_K": "Q5K", "Q6_K": "Q6K", "Q8_K": "Q8K", "F32": "F32", "F16": "F16"}
 
 
 def make(fmt, m, k, seed):
@@ -36,7 +36,7 @@ SHAPES_256 = [(3, 256), (5, 768), (512, 512), (1000, 4096), (257, 14336), (1024,
 
 
 def shapes_for(fmt):
-    return SHAPES_256 if fmt in ("Q4_K", "Q5_K", "Q6_K", "Q8_K") else SHAPES_32
+    return SHAPES_256 if fmt in ("Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K") else SHAPES_32
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
@@ -76,7 +76,7 @@ def test_gemv_vs_oracle(ca, hdev, odev, fmt):
         assert got.shape() == [m]
         got = got.export()
         ref = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(x, [k], odev)).export()
-        bound = gemv_order_bound(raw, typ, x, m, k) * GEMV_REL * (8 if fmt in ("Q4_1", "Q4_K", "Q5_K") else 1) + 1e-30
+        bound = gemv_order_bound(raw, typ, x, m, k) * GEMV_REL * (8 if fmt in ("Q4_1", "Q5_1", "Q2_K", "Q4_K", "Q5_K") else 1) + 1e-30
         err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
         assert np.all(err <= bound), f"{fmt} ({m},{k}): max err/bound {np.max(err / bound):.3f}"
         if typ == o.Q4_K:

@@ -111,7 +111,7 @@ def test_15m_shape_strict_order_is_bit_exact(ca, fmt, kv_f16):
     assert ids_h == ids_o
 
 
-@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F32", "F16"])
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F32", "F16"])
 @pytest.mark.parametrize("kv_f16", [False, True])
 def test_gqa_shape_all_formats_strict_order_is_bit_exact(ca, fmt, kv_f16):
     model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=7)
@@ -121,7 +121,7 @@ def test_gqa_shape_all_formats_strict_order_is_bit_exact(ca, fmt, kv_f16):
     assert ids_h == ids_o
 
 
-@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F32", "F16"])
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1", "Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F32", "F16"])
 def test_gqa_shape_all_formats(ca, fmt):
     """n_heads != n_kv_heads: exercises the GQA broadcast of batch_matmul with an f16 KV cache
     (bi / (ba/bb), batch_matmul.rs:89-91) for every weight format of the hot path."""

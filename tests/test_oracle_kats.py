@@ -412,3 +412,178 @@ def test_strider_suite():
 
 def test_argmax_returns_last_max():  # sampler.rs:109-116
     assert o.argmax_last(np.array([1, 5, 2, 5, 0], dtype=np.float32)) == 3
+
+
+# ---- Q5_0 / Q5_1 / Q2_K / Q3_K: the formats the reference serves with scalar code only ------------------------------------------
+_RAMP = np.array(list(range(-8, 8)) * 2, dtype=np.float32)
+
+
+def _np_q5(blk, off_qh, off_qs):
+    """the 32 unsigned 5-bit levels of a Q5_0 / Q5_1 block: element j < 16 = low nibble of qs[j] + bit j of qh, element j + 16 =
+    high nibble + bit j + 16 (buf_q5_0.rs:26-35)"""
+    qh = int.from_bytes(bytes(blk[off_qh:off_qh + 4]), "little")
+    qs = blk[off_qs:off_qs + 16].astype(np.int64)
+    lo = (qs & 15) | np.array([((qh >> j) & 1) << 4 for j in range(16)])
+    hi = (qs >> 4) | np.array([((qh >> (j + 16)) & 1) << 4 for j in range(16)])
+    return np.concatenate([lo, hi])
+
+
+def test_q5_0_block_layout_quantize_and_dot():  # buf_q5_0.rs:175-218
+    assert o.BLOCK_BYTES[o.Q5_0] == 22 and o.lib().co_block_bytes(o.Q5_0) == 22 and o.lib().co_block_elems(o.Q5_0) == 32
+    buf = np.full(22, 1, dtype=np.uint8)  # test_q5_0_block: d = 3.0, qh = [2, 3, 4, 1], qs all 1 except qs[11] = 7
+    buf[0:2] = np.array([3.0], dtype=np.float16).view(np.uint8)
+    buf[2:5] = [2, 3, 4]
+    buf[2 + 15] = 7
+    deq = o.dequantize(buf, o.Q5_0, 0, 32)
+    assert np.array_equal(deq, ((_np_q5(buf, 2, 6) - 16) * 3.0).astype(np.float32))
+    b = o.quantize(_RAMP, o.Q5_0).view(np.uint8)  # test_q5_0_quantize
+    assert b.size == 22 and np.float16(0.5).view(np.uint16) == b[0:2].view(np.uint16)[0]
+    assert list(b[6:22]) == [0, 34, 68, 102, 136, 170, 204, 238, 0, 34, 68, 102, 136, 170, 204, 238]
+    assert np.array_equal(np.round(o.dequantize(b, o.Q5_0, 0, 32)), _RAMP)
+    # the dot: integers through a numpy unpack of the same bytes, then the reference's f32 expression per block
+    rng = np.random.default_rng(50)
+    w = o.quantize(rng.standard_normal(256).astype(np.float32), o.Q5_0).view(np.uint8).reshape(8, 22)
+    x = o.quantize(rng.standard_normal(256).astype(np.float32), o.Q8_0).view(np.uint8).reshape(8, 34)
+    ints = o.block_dots(w, o.Q5_0, x, 256)
+    sumf = np.float32(0.0)
+    for i in range(8):
+        si = int((_np_q5(w[i], 2, 6) - 16) @ x[i, 2:].view(np.int8).astype(np.int64))
+        assert ints[i] == si
+        sumf = np.float32(sumf + np.float32(np.float32(si) * np.float32(w[i, 0:2].view(np.float16)[0])) * np.float32(x[i, 0:2].view(np.float16)[0]))
+    assert np.float32(o.vec_dot(w, o.Q5_0, x, 256)) == sumf
+
+
+def test_q5_1_block_layout_quantize_and_dot():  # buf_q5_1.rs:177-221
+    assert o.BLOCK_BYTES[o.Q5_1] == 24 and o.lib().co_block_bytes(o.Q5_1) == 24 and o.lib().co_block_elems(o.Q5_1) == 32
+    buf = np.full(24, 1, dtype=np.uint8)  # test_q5_1_block: d = 3.0, m = 1.0, qh = [2, 3, 4, 1]
+    buf[0:2] = np.array([3.0], dtype=np.float16).view(np.uint8)
+    buf[2:4] = np.array([1.0], dtype=np.float16).view(np.uint8)
+    buf[4:7] = [2, 3, 4]
+    buf[4 + 15] = 7
+    deq = o.dequantize(buf, o.Q5_1, 0, 32)
+    assert np.array_equal(deq, (_np_q5(buf, 4, 8) * 3.0 + 1.0).astype(np.float32))
+    b = o.quantize(_RAMP, o.Q5_1).view(np.uint8)  # test_q5_1_quantize
+    assert np.float32(b[0:2].view(np.float16)[0]) == np.float32(0.48388672) and b[2:4].view(np.float16)[0] == -8.0
+    assert list(b[8:24]) == [0, 34, 68, 102, 136, 170, 204, 238, 17, 51, 85, 119, 153, 187, 221, 255]
+    assert np.array_equal(np.round(o.dequantize(b, o.Q5_1, 0, 32)), _RAMP)
+    rng = np.random.default_rng(51)
+    w = o.quantize(rng.standard_normal(256).astype(np.float32), o.Q5_1).view(np.uint8).reshape(8, 24)
+    x = o.quantize(rng.standard_normal(256).astype(np.float32), o.Q8_1).view(np.uint8).reshape(8, 36)
+    ints = o.block_dots(w, o.Q5_1, x, 256)
+    sumf = np.float32(0.0)
+    for i in range(8):
+        si = int(_np_q5(w[i], 4, 8) @ x[i, 4:].view(np.int8).astype(np.int64))
+        assert ints[i] == si
+        dd = np.float16(np.float32(w[i, 0:2].view(np.float16)[0]) * np.float32(x[i, 0:2].view(np.float16)[0]))  # f16 * f16 -> f16
+        ms = np.float16(np.float32(w[i, 2:4].view(np.float16)[0]) * np.float32(x[i, 2:4].view(np.float16)[0]))
+        sumf = np.float32(sumf + np.float32(np.float32(np.float32(si) * np.float32(dd)) + np.float32(ms)))
+    assert np.float32(o.vec_dot(w, o.Q5_1, x, 256)) == sumf
+
+
+def _np_q2k_levels(blk):
+    """element order of buf_q2_k.rs:44-67: per 128-half, shift 0 / 2 / 4 / 6 of the half's 32 qs bytes"""
+    qs = blk[16:80].astype(np.int64)
+    return np.concatenate([(qs[32 * half:32 * half + 32] >> s) & 3 for half in range(2) for s in (0, 2, 4, 6)])
+
+
+def test_q2_k_quantize_dequantize_and_dot():  # buf_q2_k.rs:260-293
+    assert o.BLOCK_BYTES[o.Q2_K] == 84 and o.lib().co_block_bytes(o.Q2_K) == 84 and o.lib().co_block_elems(o.Q2_K) == 256
+    a, b = _generate_data(0.0, 256), _generate_data(1.0, 256)
+    qa, qb = o.quantize(a, o.Q2_K), o.quantize(b, o.Q8_K)
+    dot = o.vec_dot(qa, o.Q2_K, qb, 256)
+    ref = np.float32(0.0)
+    for x, y in zip(a, b):
+        ref = np.float32(ref + x * y)
+    assert abs(ref - dot) / 256 < 0.02  # test_q2_k_vec_dot_q8_k's assertion (MAX_Q2K_PRODUCT_ERROR)
+    assert o.q2k_overflow_count(qa, qb, 256) == 0
+    # dequantize == an independent unpack: d * (scale & 15) * level - dmin * (scale >> 4), sixteen 16-element groups in order
+    blk = qa.view(np.uint8)
+    d, dmin = np.float32(blk[80:82].view(np.float16)[0]), np.float32(blk[82:84].view(np.float16)[0])
+    lv = _np_q2k_levels(blk)
+    want = np.empty(256, dtype=np.float32)
+    for g in range(16):
+        dl, ml = np.float32(d * np.float32(blk[g] & 15)), np.float32(dmin * np.float32(blk[g] >> 4))
+        want[16 * g:16 * g + 16] = (dl * lv[16 * g:16 * g + 16].astype(np.float32) - ml).astype(np.float32)
+    deq = o.dequantize(qa, o.Q2_K, 0, 256)
+    assert np.array_equal(deq, want)
+    q8 = qb.view(np.uint8)[4:260].view(np.int8).astype(np.int64)
+    ints = o.block_dots(qa, o.Q2_K, qb, 256)
+    assert [int(v) for v in ints] == [int(lv[16 * g:16 * g + 16] @ q8[16 * g:16 * g + 16]) for g in range(16)]
+    # the dot from those integers, with the reference's single f32 expression per super-block (buf_q2_k.rs:255)
+    bs = qb.view(np.uint8)[260:292].view(np.int16).astype(np.int64)
+    isum = sum(int(blk[g] & 15) * int(ints[g]) for g in range(16))
+    summs = sum(int(bs[g]) * int(blk[g] >> 4) for g in range(16))
+    d8 = qb.view(np.uint8)[0:4].view(np.float32)[0]
+    assert np.float32(dot) == np.float32(np.float32(np.float32(d8 * d) * np.float32(isum)) - np.float32(np.float32(d8 * dmin) * np.float32(summs)))
+
+
+def test_q2_k_quantizer_reads_the_first_block_for_every_block():  # buf_q2_k.rs:197 (`data`, not `data_chunk`)
+    a, b = _generate_data(0.0, 256), _generate_data(0.5, 256) * np.float32(0.7)
+    two = o.quantize(np.concatenate([a, b]), o.Q2_K).view(np.uint8).reshape(2, 84)
+    blk = two[1]
+    d, dmin = np.float32(blk[80:82].view(np.float16)[0]), np.float32(blk[82:84].view(np.float16)[0])
+    lv = _np_q2k_levels(blk)
+    n_checked = 0
+    for g in range(16):
+        dl = np.float32(d * np.float32(blk[g] & 15))
+        if dl == 0:
+            continue  # the levels of make_qkx1_quants stay (buf_q2_k.rs:192-194)
+        dm = np.float32(dmin * np.float32(blk[g] >> 4))
+        from_first = [min(3, max(0, o.lib().co_nearest_i32(np.float32(np.float32(a[16 * g + i] + dm) / dl)))) for i in range(16)]
+        from_own = [min(3, max(0, o.lib().co_nearest_i32(np.float32(np.float32(b[16 * g + i] + dm) / dl)))) for i in range(16)]
+        assert list(lv[16 * g:16 * g + 16]) == from_first  # the second block's levels come from the FIRST block's values
+        n_checked += from_first != from_own
+    assert n_checked >= 8  # ... and that is visible: they are not what the block's own values give
+
+
+def _np_q3k(blk):
+    """(levels -4..3 in element order, the 16 scales - 32) of a Q3_K block: buf_q3_k.rs:37-88"""
+    hm, qs, sc = blk[0:32].astype(np.int64), blk[32:96].astype(np.int64), blk[96:108].astype(np.int64)
+    lv = []
+    for half in range(2):
+        for si, s in enumerate((0, 2, 4, 6)):
+            bit = (hm >> (4 * half + si)) & 1
+            lv.append(((qs[32 * half:32 * half + 32] >> s) & 3) - 4 * (1 - bit))
+    scales = [int((sc[j] & 15) if j < 8 else (sc[j - 8] >> 4)) | (int((sc[8 + j % 4] >> (2 * (j // 4))) & 3) << 4) for j in range(16)]
+    return np.concatenate(lv), np.array(scales) - 32
+
+
+def test_q3_k_quantize_dequantize_and_dot():  # buf_q3_k.rs:331-365 (its assertions are commented out there: pinned here instead)
+    assert o.BLOCK_BYTES[o.Q3_K] == 110 and o.lib().co_block_bytes(o.Q3_K) == 110 and o.lib().co_block_elems(o.Q3_K) == 256
+    a, b = _generate_data(0.0, 512), _generate_data(1.0, 512)
+    qa, qb = o.quantize(a, o.Q3_K), o.quantize(b, o.Q8_K)
+    deq = o.dequantize(qa, o.Q3_K, 0, 512)
+    rmse = np.sqrt(np.sum((deq - a) ** 2)) / 512
+    assert rmse < 0.02, rmse  # 3-bit levels of a cosine of amplitude 2: a sanity bound on make_q3_quants + the packing
+    blks = qa.view(np.uint8).reshape(2, 110)
+    q8 = qb.view(np.uint8).reshape(2, 292)
+    ints = o.block_dots(qa, o.Q3_K, qb, 512).reshape(2, 16)
+    sums = np.zeros(8, dtype=np.float32)
+    for i in range(2):
+        lv, sc = _np_q3k(blks[i])
+        d = np.float32(blks[i, 108:110].view(np.float16)[0])
+        want = np.concatenate([np.float32(d * np.float32(sc[g])) * lv[16 * g:16 * g + 16].astype(np.float32) for g in range(16)]).astype(np.float32)
+        assert np.array_equal(deq[256 * i:256 * i + 256], want)
+        x8 = q8[i, 4:260].view(np.int8).astype(np.int64)
+        assert [int(v) for v in ints[i]] == [int(lv[16 * g:16 * g + 16] @ x8[16 * g:16 * g + 16]) for g in range(16)]
+        # eight i32 lanes per block (element e feeds lane e % 8), eight f32 sums across blocks: buf_q3_k.rs:303-327
+        aux32 = np.zeros(8, dtype=np.int64)
+        for g in range(16):
+            p = lv[16 * g:16 * g + 16] * x8[16 * g:16 * g + 16] * sc[g]
+            aux32 += p[0:8] + p[8:16]
+        dd = np.float32(d * q8[i, 0:4].view(np.float32)[0])
+        sums = (sums + dd * aux32.astype(np.float32)).astype(np.float32)
+    r = sums[0]
+    for l in range(1, 8):
+        r = np.float32(r + sums[l])
+    assert np.float32(o.vec_dot(qa, o.Q3_K, qb, 512)) == r
+    # a hand-made block: d = 2, every scale field 33 (-> +1), low bits 1, hmask bit 0 set for the first 16 positions only:
+    # elements 0..15 = 2 * 1 * (1 - 0), elements 16..31 = 2 * (1 - 4); elements 32.. (hmask bit 1 clear) = 2 * (1 - 4)
+    hb = np.zeros(110, dtype=np.uint8)
+    hb[0:16] = 0x01
+    hb[32:96] = 0x55
+    hb[96:104] = 0x11
+    hb[104:108] = 0xAA
+    hb[108:110] = np.array([2.0], dtype=np.float16).view(np.uint8)
+    hd = o.dequantize(hb, o.Q3_K, 0, 256)
+    assert np.all(hd[0:16] == 2.0) and np.all(hd[16:256] == -6.0)

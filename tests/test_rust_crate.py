@@ -144,14 +144,16 @@ def test_ggml_type_ids_are_passed_as_the_enum_discriminants():
     src = strip_c_comments(open(HEADER).read())
     enum = re.search(r"typedef enum crabml_hip_ggml_type \{(.*?)\}", src, flags=re.S).group(1)
     ids = {m.group(1): int(m.group(2)) for m in re.finditer(r"CRABML_HIP_([A-Z0-9_]+)\s*=\s*(\d+)", enum)}
-    assert ids == {"F32": 0, "F16": 1, "Q4_0": 2, "Q4_1": 3, "Q8_0": 8, "Q8_1": 9, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14, "Q8_K": 15}
+    assert ids == {"F32": 0, "F16": 1, "Q4_0": 2, "Q4_1": 3, "Q5_0": 6, "Q5_1": 7, "Q8_0": 8, "Q8_1": 9, "Q2_K": 10, "Q3_K": 11, "Q4_K": 12,
+                   "Q5_K": 13, "Q6_K": 14, "Q8_K": 15}
     assert "dtype as u32" in open(os.path.join(CRATE, "src", "hip_tensor.rs")).read()
     if os.path.exists(os.path.join(REFERENCE, "crabml-core", "src", "gguf.rs")):
         g = open(os.path.join(REFERENCE, "crabml-core", "src", "gguf.rs")).read()
         enum = re.search(r"pub enum GGMLType \{(.*?)\n\}", g, flags=re.S).group(1)
         ref = {m.group(1): int(m.group(2)) for m in re.finditer(r"(\w+) = (\d+),", enum)}
         for c_name, r_name in (("F32", "F32"), ("F16", "F16"), ("Q4_0", "Q4_0"), ("Q4_1", "Q4_1"), ("Q8_0", "Q8_0"), ("Q8_1", "Q8_1"),
-                               ("Q4_K", "Q4K"), ("Q5_K", "Q5K"), ("Q6_K", "Q6K"), ("Q8_K", "Q8K")):
+                               ("Q4_K", "Q4K"), ("Q5_K", "Q5K"), ("Q6_K", "Q6K"), ("Q8_K", "Q8K"), ("Q5_0", "Q5_0"), ("Q5_1", "Q5_1"),
+                               ("Q2_K", "Q2K"), ("Q3_K", "Q3K")):
             assert ids[c_name] == ref[r_name]
 
 
