@@ -59,6 +59,29 @@ def test_prefill_strict_equals_the_oracle_token_loop(ca, fmt, kv_f16, chunk):
     assert kv_equal(r, orr, model, n + 2, kv_f16)
 
 
+@pytest.mark.parametrize("fmt", ["Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q5_K"])
+@pytest.mark.parametrize("strict", [True, False])
+def test_prefill_formats_without_a_matrix_core_kernel(ca, fmt, strict):
+    """The formats the reference serves with scalar code only: a prompt pass runs their GEMVs row by row (no MFMA tile kernel).
+    Strict order: bit-identical to the oracle's token loop; fast: inside the format's decode tolerance."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=84)
+    ref, orr = oracle_run(model, True, PROMPT + [21])
+    dev = ca.HipTensorDevice(0, False, 0, strict)
+    conf, w = synth.to_hip(model, dev)
+    r = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    lg = r.prefill(PROMPT)
+    n = len(PROMPT)
+    nxt = r.forward(21, n)
+    if strict:
+        assert np.array_equal(lg.view(np.uint32), ref[n - 1].view(np.uint32))
+        assert np.array_equal(nxt.view(np.uint32), ref[n].view(np.uint32))
+        assert kv_equal(r, orr, model, n + 1, True)
+    else:
+        from tests.helpers import FAST_TOL
+        for got, want in ((lg, ref[n - 1]), (nxt, ref[n])):
+            assert np.max(np.abs(got - want)) / np.max(np.abs(want)) <= FAST_TOL[fmt][1], fmt
+
+
 def test_prefill_15m_shape_head_dim_48_strict(ca):
     """tinyllamas-15M geometry: head_dim 48, rope_dim 48, dim 288 (k not a multiple of 256)."""
     model = synth.build_model(synth.SHAPES["15m"], synth.Q8_0, seed=82)
