@@ -75,8 +75,12 @@ def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: f
         return out.reshape(-1)
     out = np.empty((nb, bb), dtype=np.uint8)
     if typ == Q4_1:
-        out[:, 0:2] = _f16_scales(rng, nb, lo, hi).reshape(nb, 1).view(np.uint8)
-        out[:, 2:4] = (-rng.uniform(8 * lo, 8 * hi, size=nb)).astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
+        # m centres the block's levels 0..15 (m ~ -7.5 d): weights with a common offset make a 32-layer model's residual stream grow
+        # until the f16 KV cache overflows (NaN logits at the 8B depth with the independent m of rounds 1-3)
+        d16 = _f16_scales(rng, nb, lo, hi)
+        out[:, 0:2] = d16.reshape(nb, 1).view(np.uint8)
+        m = -7.5 * d16.view(np.float16).astype(np.float32) * rng.uniform(0.9, 1.1, size=nb).astype(np.float32)
+        out[:, 2:4] = m.astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
         out[:, 4:] = rng.integers(0, 256, size=(nb, 16), dtype=np.uint8)
     elif typ == Q4_K:
         out[:, 0:2] = _f16_scales(rng, nb, lo / 32, hi / 32).reshape(nb, 1).view(np.uint8)
@@ -94,8 +98,10 @@ def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: f
         out[:, 0:2] = _f16_scales(rng, nb, lo / 2, hi / 2).reshape(nb, 1).view(np.uint8)
         out[:, 2:] = rng.integers(0, 256, size=(nb, 20), dtype=np.uint8)
     elif typ == Q5_1:  # d f16 | m f16 | qh[4] | qs[16] (buf_q5_1.rs:10-17): levels 0..31, m centres them
-        out[:, 0:2] = _f16_scales(rng, nb, lo / 2, hi / 2).reshape(nb, 1).view(np.uint8)
-        out[:, 2:4] = (-rng.uniform(8 * lo, 8 * hi, size=nb)).astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
+        d16 = _f16_scales(rng, nb, lo / 2, hi / 2)
+        out[:, 0:2] = d16.reshape(nb, 1).view(np.uint8)
+        m = -15.5 * d16.view(np.float16).astype(np.float32) * rng.uniform(0.9, 1.1, size=nb).astype(np.float32)
+        out[:, 2:4] = m.astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
         out[:, 4:] = rng.integers(0, 256, size=(nb, 20), dtype=np.uint8)
     elif typ == Q2_K:  # scales[16] (scale | min << 4) | qs[64] | d f16 | dmin f16 (buf_q2_k.rs:17-28)
         out[:, 0:80] = rng.integers(0, 256, size=(nb, 80), dtype=np.uint8)

@@ -20,7 +20,7 @@ from oracle import oracle as o  # noqa: E402
 from tests.helpers import to_oracle  # noqa: E402
 
 TOKENS = [1, 365, 400, 282, 7, 9]
-CASES = [(shape, fmt, kv16) for shape in ("tiny-gqa",) for fmt in ("Q4_0", "Q8_0", "Q4_1", "Q4_K", "Q6_K", "Q8_K", "F16", "F32")
+CASES = [(shape, fmt, kv16) for shape in ("tiny-gqa",) for fmt in ("Q4_0", "Q8_0", "Q4_1", "Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F16", "F32")
          for kv16 in (True, False)] + [("15m", "Q4_0", True), ("15m", "Q8_0", False),
                                       # llama.cpp's Q4_K_M recipe: mixed GGML types inside a layer + Q6_K classifier
                                       ("tiny-gqa", "Q4_K_M", True), ("tiny-gqa", "Q4_K_M", False)]
