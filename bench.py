@@ -285,7 +285,7 @@ def parity_check(ca, synth, model, conf, weights, dev, ordinal, n_pos=4):
     del fast
     out = {"tokens_compared": len(toks), "fast_max_rel_logit_err": round(max(errs), 6), "fast_rel_logit_err_per_pos": [round(e, 6) for e in errs],
            "fast_tokens_equal": equal, "oracle": "scalar-order restatement of the reference CPU path", "oracle_s": round(t_oracle, 2),
-           "yardstick": "the reference's own scalar-vs-AVX2 builds differ by 4.3e-4..4.8e-4 on this Q4_0 model and by 7e-2..1e-1 on zero-mean "
+           "yardstick": "the reference's own scalar-vs-AVX2 builds differ by 4.3e-4..4.8e-4 on the default Q4_0 benchmark model and by 7e-2..1e-1 on zero-mean "
                         "random weights of the same shape (profiles/r04_reference_order_sensitivity.log): re-association + a truncating rhs quantizer"}
     try:
         sdev = ca.HipTensorDevice(ordinal, False, 0, True)

@@ -6,7 +6,10 @@
 // same f32 expression, same association -- on the same device planes the fast kernels read.  Logits are
 // then bit-identical to the default (non-SIMD) build of the reference, which turns the end-to-end parity
 // check into an equality test.  Not a performance path (uncoalesced by construction).
+#include <cstdlib>
+
 #include "devutil.hpp"
+#include "gemv_core.hpp"
 #include "kernels.hpp"
 
 namespace crabml_hip {
@@ -286,16 +289,189 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
   out[row] = sumf;
 }
 
+// ---- the same sums at streaming speed (round 4) -----------------------------------------------------------------------------------
+// For the formats whose reference dot is ONE f32 term per block added in block order (Q4_0, Q8_0, Q4_1, Q5_0, Q5_1; per
+// super-block: Q2_K, Q8_K) the order only matters for the final chain.  The terms are evaluated the way the fast kernels do it --
+// coalesced 16-byte loads, one unit per lane, exact integers, the reference's f32 expression per block -- but instead of being
+// added per lane and reduced through a tree they are parked in LDS, and one lane per row then adds them strictly in block order:
+// sumf = 0; sumf += t_0; sumf += t_1; ...  Every output equals k_gemv_strict's bit for bit (tests/test_hip_gemv.py compares the two
+// and the oracle).  The chain (nb dependent adds) runs in one lane while the other waves of the CU keep streaming.
+// Formats with f32 lanes inside the block (Q3_K .. Q6_K) and dense F32 / F16 rows stay on k_gemv_strict.
+template <int R>
+__device__ __forceinline__ void exact_chain_store(const float* __restrict__ T, int nterms, int stride, int row0, int m, int lane,
+                                                  float* __restrict__ out) {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS stores have landed (no other wave touches its region)
+  __builtin_amdgcn_wave_barrier();
+  if (lane < R && row0 + lane < m) {
+    const float* t = T + (size_t)lane * stride;  // (rows of the term table are padded to 16 bytes)
+    float sumf = 0.0f;
+    int i = 0;
+    for (; i + 4 <= nterms; i += 4) {
+      const f32x4 v = *(const f32x4*)(t + i);
+      sumf += v[0];
+      sumf += v[1];
+      sumf += v[2];
+      sumf += v[3];
+    }
+    for (; i < nterms; i++) sumf += t[i];
+    out[row0 + lane] = sumf;
+  }
+}
+
+template <int FMT, int R>
+__global__ __launch_bounds__(256) void k_gemv_exact_blk(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
+                                                        typename ActOf<FMT>::type act, float* __restrict__ out, int m, int nb) {
+  using F = BlockFmt<FMT>;
+  extern __shared__ __attribute__((aligned(16))) float exact_terms[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  const int nt = (nb + 3) & ~3;  // row stride of the term table (16-byte aligned rows)
+  float* T = exact_terms + (size_t)wv * R * nt;
+  const int nu = nb * F::UNITS;
+  for (int u0 = 0; u0 < nu; u0 += 64) {
+    const int u = u0 + lane;
+    const bool live = u < nu;  // (Q8_0: nu is even, the two lanes of a block are live or dead together)
+    const int uu = live ? u : nu - 1;
+    typename F::Blk blk[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      blk[r] = F::load(wq, wd, (size_t)row, nb, uu);
+    }
+    const XUnit x = F::loadx(act, uu);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float t = F::term(blk[r], x);
+      if (live && (F::UNITS == 1 || (lane & 1) == 0)) T[r * nt + uu / F::UNITS] = t;
+    }
+  }
+  exact_chain_store<R>(T, nb, nt, row0, m, lane, out);
+}
+
+template <class P, int R>
+__global__ __launch_bounds__(256) void k_gemv_exact_pieces(const char* __restrict__ w, size_t off, size_t n, typename P::Act act,
+                                                           float* __restrict__ out, int m, int nbr) {
+  extern __shared__ __attribute__((aligned(16))) float exact_terms[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  const int nt = (nbr + 3) & ~3;
+  float* T = exact_terms + (size_t)wv * R * nt;
+  const int np = nbr * P::PIECES;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < np;
+    const int cc = live ? c : np - 1;
+    typename P::W wvv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      wvv[r] = P::load(w, off, n, (size_t)row * nbr, cc);
+    }
+    const typename P::X x = P::loadx(act, cc);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float t;
+      if constexpr (P::PIECES == 1)
+        t = P::term(wvv[r], x, lane);
+      else
+        t = P::term(wvv[r], x, cc, lane);  // the block's one term, on the first lane of its quad
+      if (live && (P::PIECES == 1 || (lane & (P::PIECES - 1)) == 0)) T[r * nt + cc / P::PIECES] = t;
+    }
+  }
+  exact_chain_store<R>(T, nbr, nt, row0, m, lane, out);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_exact_q8k(const i32x4* __restrict__ wq, const float* __restrict__ wd, ActQ8_K act,
+                                                        float* __restrict__ out, int m, int nsb) {
+  extern __shared__ __attribute__((aligned(16))) float exact_terms[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  const int nt = (nsb + 3) & ~3;
+  float* T = exact_terms + (size_t)wv * R * nt;
+  const int ngroups = nsb * 8;
+  for (int g0 = 0; g0 < ngroups; g0 += 64) {
+    const int g = g0 + lane;
+    const bool live = g < ngroups;
+    const int gg = live ? g : ngroups - 1;
+    const int sb = gg >> 3;
+    const i32x4 x0 = act.q[2 * (size_t)gg], x1 = act.q[2 * (size_t)gg + 1];
+    const float d8 = act.d[sb];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      const size_t gi = (size_t)row * ngroups + gg;
+      const i32x4 q0 = __builtin_nontemporal_load(wq + 2 * gi), q1 = __builtin_nontemporal_load(wq + 2 * gi + 1);
+      int si = live ? dot_i8x32(q0, q1, x0, x1) : 0;
+      si += dpp_i<0xB1>(si);   // the eight 32-element groups of a super-block: exact integer sum (buf_q8_k.rs:216-220)
+      si += dpp_i<0x4E>(si);
+      si += dpp_i<0x141>(si);  // row_half_mirror: lanes 0-3 <-> 7-4 of each 8
+      if (live && (lane & 7) == 0) T[r * nt + sb] = ((float)si * wd[(size_t)row * nsb + sb]) * d8;
+    }
+  }
+  exact_chain_store<R>(T, nsb, nt, row0, m, lane, out);
+}
+
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out) {
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (qt == 0xffffffffu) return set_error(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
   const ActLayout al = act_layout(qt, k);
   const size_t act_stride = qt == CRABML_HIP_F32 ? k * 4 : al.total;
-  for (size_t bi = 0; bi < b; bi++)
-    k_gemv_strict<<<(unsigned)((m + 63) / 64), 64, 0, dev->stream>>>((const char*)w->ptr, (int)w->dtype, w->wl.off_scale,
-                                                                     (const char*)act + bi * act_stride, al.off_d,
-                                                                     al.off_aux, out + bi * m, (int)m, (int)k);
+  constexpr int R = 2, WAVES = 4;
+  const char* wp = (const char*)w->ptr;
+  const size_t nterms = k / block_elems(w->dtype);
+  const size_t lds = (size_t)WAVES * R * ((nterms + 3) & ~(size_t)3) * sizeof(float);
+  const unsigned grid = (unsigned)((m + R * WAVES - 1) / (R * WAVES));
+  // CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_STRICT_SCALAR=1: every format through the one-thread-per-row kernel (the A/B of the tests)
+  static const bool scalar_only = [] {
+    const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+    const char* e = getenv("CRABML_HIP_STRICT_SCALAR");
+    return h && h[0] == '1' && e && e[0] == '1';
+  }();
+  for (size_t bi = 0; bi < b; bi++) {
+    const char* ap = (const char*)act + bi * act_stride;
+    float* o = out + bi * m;
+    bool done = false;
+    if (!scalar_only && lds <= 48 * 1024 && block_elems(w->dtype) > 1) {
+      done = true;
+      const ActQ8_0 a0{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
+      const ActQ8_1 a1{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const unsigned short*)(ap + al.off_aux)};
+      const ActQ8_K ak{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+      switch (w->dtype) {
+        case CRABML_HIP_Q4_0:
+          k_gemv_exact_blk<CRABML_HIP_Q4_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a0, o, (int)m, (int)(k / 32));
+          break;
+        case CRABML_HIP_Q8_0:
+          k_gemv_exact_blk<CRABML_HIP_Q8_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a0, o, (int)m, (int)(k / 32));
+          break;
+        case CRABML_HIP_Q4_1:
+          k_gemv_exact_blk<CRABML_HIP_Q4_1, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a1, o, (int)m, (int)(k / 32));
+          break;
+        case CRABML_HIP_Q5_0:
+          k_gemv_exact_pieces<PieceQ5_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, a0, o, (int)m, (int)(k / 32));
+          break;
+        case CRABML_HIP_Q5_1:
+          k_gemv_exact_pieces<PieceQ5_1, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, a1, o, (int)m, (int)(k / 32));
+          break;
+        case CRABML_HIP_Q2_K:
+          k_gemv_exact_pieces<PieceQ2_K, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, ak, o, (int)m, (int)(k / 256));
+          break;
+        case CRABML_HIP_Q8_K:
+          k_gemv_exact_q8k<R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), ak, o, (int)m, (int)(k / 256));
+          break;
+        default: done = false;
+      }
+    }
+    if (!done)
+      k_gemv_strict<<<(unsigned)((m + 63) / 64), 64, 0, dev->stream>>>(wp, (int)w->dtype, w->wl.off_scale, ap, al.off_d, al.off_aux, o, (int)m, (int)k);
+  }
   return 0;
 }
 

@@ -229,3 +229,56 @@ def test_linearity_at_full_8b_shape(ca, hdev):
     for row in (0, 7777, m - 1):
         ref = o.vec_dot(raw[row * rb:(row + 1) * rb], typ, xq, k)
         assert abs(y1[row] - ref) <= 1e-4 * (abs(ref) + 1.0)
+
+
+# ---- strict order: every matmul_vec output equals the oracle's scalar loop bit for bit ---------------------------------------------
+STRICT_FORMATS = FORMATS + ["F32", "F16"]
+
+
+def _strict_cases(fmt):
+    if fmt in ("F32", "F16"):
+        return [(37, 64), (5, 2080)]
+    # ragged rows (fewer than a wave's two, odd counts), k of 1 / 9 / 65 / 128 / 448 blocks, one super-block .. 56
+    return [(3, 256), (5, 768), (129, 4096), (64, 14336)] if fmt in ("Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K") else \
+        [(1, 32), (3, 288), (7, 2080), (129, 4096), (64, 14336)]
+
+
+def _strict_gemv_equals_oracle(ca, fmt):
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    odev = o.OracleDevice(thread_num=2)
+    for (m, k) in _strict_cases(fmt):
+        typ, raw, x = make(fmt, m, k, 3 * m + k)
+        w = ca.HipTensor.from_cpu(raw, [m, k], getattr(ca.GGMLType, HT[fmt]), dev)
+        got = w.matmul_vec(ca.HipTensor.new(x, [k], dev)).export()
+        ref = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(x, [k], odev)).export()
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{fmt} ({m},{k})"
+        # a batch of rhs rows (the strict prompt pass): row by row the same
+        xb = np.stack([x, -x, x * np.float32(0.5)]).astype(np.float32)
+        gb = w.matmul_vec(ca.HipTensor.new(xb.reshape(-1), [3, k], dev)).export().reshape(3, m)
+        rb = o.OracleTensor.from_bytes(raw, typ, [m, k], odev).matmul_vec(o.OracleTensor.new(xb.reshape(-1), [3, k], odev)).export().reshape(3, m)
+        assert np.array_equal(gb.view(np.uint32), rb.view(np.uint32)), f"{fmt} ({m},{k}) batched"
+
+
+@pytest.mark.parametrize("fmt", STRICT_FORMATS)
+def test_strict_order_gemv_is_bit_exact(ca, fmt):
+    """CRABML_HIP_FLAG_STRICT_ORDER: Q4_0 / Q8_0 / Q4_1 / Q5_0 / Q5_1 / Q2_K / Q8_K through the streaming kernels that park the block
+    terms in LDS and add them in block order (k_gemv_exact_*), the rest through the one-thread-per-row kernel."""
+    _strict_gemv_equals_oracle(ca, fmt)
+
+
+def test_strict_order_scalar_kernel_still_covers_every_format():
+    """the one-thread-per-row kernel (k_gemv_strict) behind the test hook: the two strict implementations agree with the oracle
+    independently (a subprocess: the hook is read once per process)"""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, '.')\n"
+            "import crabml_amd as ca\n"
+            "from tests import test_hip_gemv as t\n"
+            "for f in t.STRICT_FORMATS:\n"
+            "    t._strict_gemv_equals_oracle(ca, f)\n"
+            "print('scalar kernel ok')\n")
+    env = dict(os.environ, CRABML_HIP_TEST_HOOKS="1", CRABML_HIP_STRICT_SCALAR="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "scalar kernel ok" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
