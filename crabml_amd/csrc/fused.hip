@@ -123,6 +123,7 @@ struct crabml_hip_llama {
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
   bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
   bool generic = false;      // per-op launches (strict-order device, or a weight format without fused kernels)
+  bool ord = false;          // strict-order device, Q4_0 / Q8_0 / Q4_1 layers: the fused launches with block-ordered sums (k_*_ord)
   uint32_t qt = 0, out_qt = 0;  // vec_dot_rhs_dtype of the layer weights / of the classifier
   float* xn = nullptr;       // generic path: normalized residual (f32, dim)
   bool norm_epi = false;     // fast mode, tp == 1: RMSNorm + quantize run in the wo / ffn_down epilogue
@@ -420,9 +421,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     if (prof) prof_begin(dev, &nr, CRABML_HIP_F32, 6, 8.0 * dim);
     const float* addv = add_pending ? c->partial : nullptr;
     if (dim <= 4096)
-      launch_k(st, prof ? &nr : nullptr, k_norm_quant<4, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf, 1);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<4, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf, c->ord ? 0 : 1);
     else
-      launch_k(st, prof ? &nr : nullptr, k_norm_quant<12, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf, 1);
+      launch_k(st, prof ? &nr : nullptr, k_norm_quant<12, Q81>, dim3(1 + spare), dim3(1024), norm_lds, c->x, addv, wn, dim, eps, ad.q, ad.d, ad.isum, pf, c->ord ? 0 : 1);
     if (prof) prof_end(dev, &nr);
   };
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
@@ -454,6 +455,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
         launch_k(st, R, k_gemv_res_nq<FMT, 1>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
                  ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
+    } else if (c->ord) {
+      launch_k(st, R, k_gemv_res_ord<FMT>, dim3((dim + 7) / 8), dim3(256), (size_t)8 * ((k / 32 + 3) & ~3) * sizeof(float), planes_of(w), act_view<FMT>(a),
+               c->x, dim, k / 32);
     } else if (tp) {
       launch_k(st, R, k_gemv_res<FMT, 1, false>, dim3((dim + 1) / 2), dim3(128), 0, planes_of(w), act_view<FMT>(a), dst, dim, k / 32);
     } else {
@@ -471,9 +475,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       const size_t nlds = norm_lds_bytes(dim);
       const float* addv = tp && !norm_epi ? c->partial : nullptr;  // (fused collective: x is already final)
       if (dim <= 4096)
-        k_norm_f32<4><<<1, 1024, nlds, st>>>(c->x, addv, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, 1);
+        k_norm_f32<4><<<1, 1024, nlds, st>>>(c->x, addv, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, c->ord ? 0 : 1);
       else
-        k_norm_f32<12><<<1, 1024, nlds, st>>>(c->x, addv, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, 1);
+        k_norm_f32<12><<<1, 1024, nlds, st>>>(c->x, addv, (const float*)c->rms_final->ptr, dim, g.rms_norm_eps, c->xn, c->ord ? 0 : 1);
       if (c->out_qt == CRABML_HIP_F32) {
         cls_act = c->xn;
       } else {
@@ -503,8 +507,12 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(&pr, 1, total_rows, dim));
-    launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-             planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
+    if (c->ord)
+      launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * ((dim / 32 + 3) & ~3) * sizeof(float), planes_of(c->wq[l]),
+               planes_of(c->wk[l]), planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e);
+    else
+      launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
+               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;
@@ -519,8 +527,12 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     const float* wnext_down = (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr;
     // gate / up + silu * mul (llama2.rs:620-630), local rows
     CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
-    launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
-             act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
+    if (c->ord)
+      launch_k(st, R, k_gateup_q_ord<FMT>, dim3(hidden_l / 32), dim3(1024), (size_t)64 * (((dim / 32 + 3) & ~3) + 4) * sizeof(float), planes_of(c->gate[l]),
+               planes_of(c->up[l]), act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
+    else
+      launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
+               act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
     CH_TRY(P1(&pr));
     // down (+ residual, llama2.rs:633-636): k = the local hidden slice
     CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps));
@@ -1342,7 +1354,19 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   // fused kernels exist for Q4_0 / Q8_0 layers (fast mode); everything else runs the per-op segment path
   // (a classifier of another format -- llama.cpp's "Q4_0" files keep output.weight in Q6_K -- does not take the layers
   // off the fused kernels: the final segment quantizes the normalized row for the classifier's own rhs type)
-  bool generic = dev->strict_order || (wt != CRABML_HIP_Q4_0 && wt != CRABML_HIP_Q8_0 && wt != CRABML_HIP_Q4_1);
+  const bool fused_fmt = wt == CRABML_HIP_Q4_0 || wt == CRABML_HIP_Q8_0 || wt == CRABML_HIP_Q4_1;
+  // strict order, one device, a format whose dot is one term per block: the fused launches in their block-ordered form (7 per
+  // layer: norm + quantize stay their own launches); everything else strict runs the per-op segments
+  bool ord = dev->strict_order && fused_fmt && tp == 1;
+  if (ord) {  // the term tables must fit LDS: 64 rows of gate|up (k_gateup_q_ord), 8 rows of the longest k (ffn_down)
+    const size_t gu = (size_t)64 * (((g.embedding_dim / 32 + 3) & ~(size_t)3) + 4) * 4, dn = (size_t)8 * ((hidden_l / 32 + 3) & ~(size_t)3) * 4;
+    const void* fn = wt == CRABML_HIP_Q4_0   ? (const void*)k_gateup_q_ord<CRABML_HIP_Q4_0>
+                     : wt == CRABML_HIP_Q8_0 ? (const void*)k_gateup_q_ord<CRABML_HIP_Q8_0>
+                                             : (const void*)k_gateup_q_ord<CRABML_HIP_Q4_1>;
+    if (gu > 150 * 1024 || dn > 60 * 1024 || (gu > 60 * 1024 && raise_dyn_lds(dev, fn, (int)gu) != hipSuccess)) ord = false;
+    (void)hipGetLastError();
+  }
+  bool generic = (dev->strict_order && !ord) || !fused_fmt;
   const bool out_differs = out_wt != wt;
   {
     const size_t be = block_elems(wt) > block_elems(qt) ? block_elems(wt) : block_elems(qt);
@@ -1405,8 +1429,13 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
                                !(g.flags & (CRABML_HIP_LLAMA_NO_NORM_EPILOGUE | CRABML_HIP_LLAMA_NO_KQUANT_FUSION)) &&
                                g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
   const bool mix_fused = mixed && mix_v_down_q6k && nepi_k_possible;
+  if (mixed && ord) {  // (a mixed file: per-op segments)
+    ord = false;
+    generic = true;
+  }
   generic = generic || (mixed && !mix_fused);
   c->generic = generic;
+  c->ord = ord;
   // Q4_K always; Q4_1 when it cannot take the 5-kernel path (mixed classifier format) or for the A/B flag
   c->kfused = !dev->strict_order && (!mixed || mix_fused) && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
               (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || out_differs || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS))));
@@ -1563,7 +1592,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   const bool p2p_comm = c->comm != nullptr && c->comm->p2p;
   // (not for the K-quant segment path -- a Q4_1 body with a classifier of another format runs it: its wo / ffn_down launches
   // host neither the norm epilogue nor the collective, so over a P2P group the stand-alone all-reduce launch must run)
-  c->norm_epi = !generic && !c->kfused && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
+  c->norm_epi = !generic && !c->kfused && !c->ord && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
                   !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) && g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;

@@ -405,6 +405,37 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
   if (lane == 0) qkv_epilogue(e, pre, row0, s0, s1);
 }
+// strict order (CRABML_HIP_FLAG_STRICT_ORDER, Q4_0 / Q8_0 / Q4_1 layers): the same launch with the block terms parked in LDS and
+// added in block order by one lane per row (rows_terms / ordered_sum, gemv_core.hpp) -- q, k and v rows bit-identical to the scalar
+// loops of the reference, then the same epilogue.  Workgroup = 4 waves x one (even, odd) row pair; dynamic LDS = 8 * nt floats.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e) {
+  extern __shared__ __attribute__((aligned(16))) float ord_terms[];
+  const int lane = threadIdx.x & 63, wv_i = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv_i;
+  const int row0 = wave * 2;
+  const int total = e.dim + 2 * e.kv_dim;
+  if (row0 >= total) return;
+  Planes w;
+  int local, m;
+  if (row0 < e.dim) {
+    w = wq; local = row0; m = e.dim;
+  } else if (row0 < e.dim + e.kv_dim) {
+    w = wk; local = row0 - e.dim; m = e.kv_dim;
+  } else {
+    w = wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
+  }
+  QkvPre pre{};
+  if (lane == 0) pre = qkv_preload(e, row0);
+  const int nt = (nb + 3) & ~3;
+  float* T = ord_terms + (size_t)wv_i * 2 * nt;
+  rows_terms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, T, nt);
+  __builtin_amdgcn_wave_barrier();
+  float s = 0.0f;
+  if (lane < 2) s = ordered_sum(T + lane * nt, nb);
+  const float s1 = __shfl(s, 1, 64);
+  if (lane == 0) qkv_epilogue(e, pre, row0, s, s1);
+}
 // strict mode: the three GEMVs ran in scalar order into tmp[dim + 2 kv_dim]; apply the same epilogue
 __global__ __launch_bounds__(256) void k_qkv_epi(const float* __restrict__ tmp, QkvEpi e) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;

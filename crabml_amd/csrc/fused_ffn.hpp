@@ -25,6 +25,22 @@ __global__ __launch_bounds__(128) void k_gemv_res(Planes w, typename ActOf<FMT>:
   }
 }
 
+// strict order: x[row] = (the row's block terms added in block order) + x[row]; 4 waves x 2 rows, dynamic LDS = 8 * nt floats
+template <int FMT>
+__global__ __launch_bounds__(256) void k_gemv_res_ord(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x, int m, int nb) {
+  extern __shared__ __attribute__((aligned(16))) float ord_terms[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int row0 = wave * 2;
+  if (row0 >= m) return;
+  const float res = (lane < 2 && row0 + lane < m) ? x[row0 + lane] : 0.f;
+  const int nt = (nb + 3) & ~3;
+  float* T = ord_terms + (size_t)wv * 2 * nt;
+  rows_terms<FMT, 2>(w.q, w.d, act, row0, m, nb, lane, T, nt);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 2 && row0 + lane < m) x[row0 + lane] = ordered_sum(T + lane * nt, nb) + res;
+}
+
 __global__ __launch_bounds__(256) void k_res_epi(const float* __restrict__ tmp, float* __restrict__ x, int m, int add) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) x[i] = add ? tmp[i] + x[i] : tmp[i];
@@ -549,6 +565,37 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typenam
     if (threadIdx.x == 0) {
       d[blk] = o.d;
       store_qaux<Q81>(isum, blk, o.aux);
+    }
+  }
+}
+// strict order: k_gateup_q with the block terms of the 32 gate and 32 up rows parked in LDS (row stride nt + 4 floats: the 64 chain
+// lanes read 16-byte pieces four banks apart) and added in block order by one lane per (matrix, row); SiLU * mul and the Q8_0 / Q8_1
+// block of h as in k_gateup_q.  Dynamic LDS = 64 * (nt + 4) floats.
+template <int FMT>
+__global__ __launch_bounds__(1024) void k_gateup_q_ord(Planes wg, Planes wu, typename ActOf<FMT>::type act,
+                                                       const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
+                                                       unsigned short* __restrict__ d, void* __restrict__ isum, int nb) {
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  extern __shared__ __attribute__((aligned(16))) float ord_terms[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int row = blk * 32 + wave * 2;
+  const int nt = ((nb + 3) & ~3) + 4;
+  // table rows: gate rows 0..31, then up rows 0..31 (the last workgroup is whole: hidden is a multiple of 32)
+  rows_terms<FMT, 2>(wg.q, wg.d, act, row, 0x7fffffff, nb, lane, ord_terms + (size_t)(wave * 2) * nt, nt);
+  rows_terms<FMT, 2>(wu.q, wu.d, act, row, 0x7fffffff, nb, lane, ord_terms + (size_t)(32 + wave * 2) * nt, nt);
+  __syncthreads();
+  if (wave == 0) {
+    const float s = ordered_sum(ord_terms + (size_t)lane * nt, nb);  // lane < 32: gate row `lane`; else up row `lane - 32`
+    const float u = __shfl(s, (lane & 31) + 32, 64);
+    const float h = lane < 32 ? silu_mul(s, u, exp_tab) : 0.0f;
+    const QLane o = quant_lane32<Q81>(h, lane < 32);  // (whole wave: the upper half quantizes zeros and stores nothing)
+    if (lane < 32) {
+      q[blk * 32 + lane] = o.q;
+      if (lane == 0) {
+        d[blk] = o.d;
+        store_qaux<Q81>(isum, blk, o.aux);
+      }
     }
   }
 }

@@ -165,6 +165,49 @@ __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const
   }
 }
 
+// ---- strict order at streaming speed: the block terms of R rows into a term table, then one lane per row adds them in block order ----
+// (CRABML_HIP_FLAG_STRICT_ORDER.)  The reference's scalar dot of these formats is `sumf = 0; for block: sumf += term(block)` with one
+// f32 term per block (buf_q4_0.rs:240-253, buf_q8_0.rs:275-286, buf_q4_1.rs:266-280): the terms are evaluated exactly as the fast
+// kernels do (same loads, same integers, the reference's expression per block), parked in LDS -- T[r * stride + block] -- and added by
+// ordered_sum.  Bit-identical to the one-thread-per-row loop (k_gemv_strict) and to the oracle.
+template <int FMT, int R, class ACT>
+__device__ __forceinline__ void rows_terms(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd, const ACT& act, int row0,
+                                           int m, int nb, int lane, float* __restrict__ T, int stride) {
+  using F = BlockFmt<FMT>;
+  const int nu = nb * F::UNITS;
+  for (int u0 = 0; u0 < nu; u0 += 64) {
+    const int u = u0 + lane;
+    const bool live = u < nu;  // (Q8_0: nu is even, the two lanes of a block are live or dead together)
+    const int uu = live ? u : nu - 1;
+    typename F::Blk blk[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      blk[r] = F::load(wq, wd, (size_t)row, nb, uu);
+    }
+    const XUnit x = F::loadx(act, uu);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float t = F::term(blk[r], x);
+      if (live && (F::UNITS == 1 || (lane & 1) == 0)) T[r * stride + uu / F::UNITS] = t;
+    }
+  }
+}
+// t: 16-byte aligned
+__device__ __forceinline__ float ordered_sum(const float* __restrict__ t, int nterms) {
+  float sumf = 0.0f;
+  int i = 0;
+  for (; i + 4 <= nterms; i += 4) {
+    const f32x4 v = *(const f32x4*)(t + i);
+    sumf += v[0];
+    sumf += v[1];
+    sumf += v[2];
+    sumf += v[3];
+  }
+  for (; i < nterms; i++) sumf += t[i];
+  return sumf;
+}
+
 // Q4_K rows (planes qs[n][128] | hdr[n][16]) against a Q8_K activation vector: lane = one 16-byte qs piece j of a
 // super-block (8 lanes per super-block: a wave's load is one aligned 1 KiB request); piece j belongs to the
 // 64-element pair p = j / 2 and carries, for positions 16 (j & 1) .. +16, the low nibbles of sub-block 2p and the

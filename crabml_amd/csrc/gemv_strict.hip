@@ -303,17 +303,7 @@ __device__ __forceinline__ void exact_chain_store(const float* __restrict__ T, i
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS stores have landed (no other wave touches its region)
   __builtin_amdgcn_wave_barrier();
   if (lane < R && row0 + lane < m) {
-    const float* t = T + (size_t)lane * stride;  // (rows of the term table are padded to 16 bytes)
-    float sumf = 0.0f;
-    int i = 0;
-    for (; i + 4 <= nterms; i += 4) {
-      const f32x4 v = *(const f32x4*)(t + i);
-      sumf += v[0];
-      sumf += v[1];
-      sumf += v[2];
-      sumf += v[3];
-    }
-    for (; i < nterms; i++) sumf += t[i];
+    const float sumf = ordered_sum(T + (size_t)lane * stride, nterms);  // (rows of the term table are padded to 16 bytes)
     out[row0 + lane] = sumf;
   }
 }
@@ -321,7 +311,6 @@ __device__ __forceinline__ void exact_chain_store(const float* __restrict__ T, i
 template <int FMT, int R>
 __global__ __launch_bounds__(256) void k_gemv_exact_blk(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
                                                         typename ActOf<FMT>::type act, float* __restrict__ out, int m, int nb) {
-  using F = BlockFmt<FMT>;
   extern __shared__ __attribute__((aligned(16))) float exact_terms[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -329,24 +318,7 @@ __global__ __launch_bounds__(256) void k_gemv_exact_blk(const i32x4* __restrict_
   if (row0 >= m) return;
   const int nt = (nb + 3) & ~3;  // row stride of the term table (16-byte aligned rows)
   float* T = exact_terms + (size_t)wv * R * nt;
-  const int nu = nb * F::UNITS;
-  for (int u0 = 0; u0 < nu; u0 += 64) {
-    const int u = u0 + lane;
-    const bool live = u < nu;  // (Q8_0: nu is even, the two lanes of a block are live or dead together)
-    const int uu = live ? u : nu - 1;
-    typename F::Blk blk[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int row = row0 + r < m ? row0 + r : m - 1;
-      blk[r] = F::load(wq, wd, (size_t)row, nb, uu);
-    }
-    const XUnit x = F::loadx(act, uu);
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const float t = F::term(blk[r], x);
-      if (live && (F::UNITS == 1 || (lane & 1) == 0)) T[r * nt + uu / F::UNITS] = t;
-    }
-  }
+  rows_terms<FMT, R>(wq, wd, act, row0, m, nb, lane, T, nt);
   exact_chain_store<R>(T, nb, nt, row0, m, lane, out);
 }
 
