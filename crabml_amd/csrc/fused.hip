@@ -447,6 +447,14 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
         else
           launch_k(st, R, k_gemv_res_nq<FMT, 1, false, true>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
                    c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
+      } else if (c->ord) {  // strict order: the same launch with block-ordered GEMV sums and the reference's norm order
+        const size_t lds = (size_t)(32 / split) * (((k / 32 + 3) & ~3) + 4) * sizeof(float);
+        if (split == 2)
+          launch_k(st, R, k_gemv_res_nq_ord<FMT, 2>, dim3(dim / 16), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q, ad.d,
+                   ad.isum, ng, k / 32);
+        else
+          launch_k(st, R, k_gemv_res_nq_ord<FMT, 1>, dim3(dim / 32), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q, ad.d,
+                   ad.isum, ng, k / 32);
       } else if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,
@@ -1358,8 +1366,9 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   // strict order, one device, a format whose dot is one term per block: the fused launches in their block-ordered form (7 per
   // layer: norm + quantize stay their own launches); everything else strict runs the per-op segments
   bool ord = dev->strict_order && fused_fmt && tp == 1;
-  if (ord) {  // the term tables must fit LDS: 64 rows of gate|up (k_gateup_q_ord), 8 rows of the longest k (ffn_down)
-    const size_t gu = (size_t)64 * (((g.embedding_dim / 32 + 3) & ~(size_t)3) + 4) * 4, dn = (size_t)8 * ((hidden_l / 32 + 3) & ~(size_t)3) * 4;
+  if (ord) {  // the term tables must fit LDS: 64 rows of gate|up (k_gateup_q_ord), a workgroup's 16 / 32 rows of the longest k (ffn_down)
+    const size_t gu = (size_t)64 * (((g.embedding_dim / 32 + 3) & ~(size_t)3) + 4) * 4, 
+                 dn = (size_t)((hidden_l / 32 >= 256 && (int)(g.embedding_dim / 32) <= dev->n_cu) ? 16 : 32) * (((hidden_l / 32 + 3) & ~(size_t)3) + 4) * 4;
     const void* fn = wt == CRABML_HIP_Q4_0   ? (const void*)k_gateup_q_ord<CRABML_HIP_Q4_0>
                      : wt == CRABML_HIP_Q8_0 ? (const void*)k_gateup_q_ord<CRABML_HIP_Q8_0>
                                              : (const void*)k_gateup_q_ord<CRABML_HIP_Q4_1>;
@@ -1592,7 +1601,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   const bool p2p_comm = c->comm != nullptr && c->comm->p2p;
   // (not for the K-quant segment path -- a Q4_1 body with a classifier of another format runs it: its wo / ffn_down launches
   // host neither the norm epilogue nor the collective, so over a P2P group the stand-alone all-reduce launch must run)
-  c->norm_epi = !generic && !c->kfused && !c->ord && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
+  c->norm_epi = !generic && !c->kfused && (tp == 1 || p2p_comm || c->tp_dry) && !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) &&
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
                   !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) && g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;

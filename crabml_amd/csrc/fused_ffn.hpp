@@ -448,6 +448,100 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
                               (int)gridDim.x, tp);
 }
 
+// ---- strict order: wo / ffn_down + residual + the next RMSNorm + quantize in ONE launch, every sum in the reference's order ----------
+// k_gemv_res_nq's structure (32-row chunks, SPLIT workgroups per chunk, one in-launch hop) with:
+//   * the GEMV rows from block terms added in block order (rows_terms / ordered_sum; term table ROWS x (nt + 4) floats of dynamic LDS);
+//   * a chunk's sum of squares as ONE 32-element scan (rms_norm.rs:35-38): with two workgroups per chunk the second continues the
+//     first one's scan from its granule (one more dependent round trip, for that half of the workgroups);
+//   * the chunk sums added strictly in chunk order through v_readlane (rms_norm.rs:38-40), as norm_quant_block does with half = 0.
+// Same outputs as k_gemv_res_ord + k_norm_quant(half = 0), bit for bit, in one launch instead of two.
+template <int FMT, int SPLIT>
+__global__ __launch_bounds__(1024) void k_gemv_res_nq_ord(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x,
+                                                          const float* __restrict__ wnext, float eps, signed char* __restrict__ q,
+                                                          void* __restrict__ d, void* __restrict__ isum, NormGather ng, int nb) {
+  constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
+  constexpr int RW = 2 / SPLIT, ROWS = 32 / SPLIT;
+  extern __shared__ __attribute__((aligned(16))) float ord_terms[];
+  __shared__ __attribute__((aligned(16))) float hv[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+  const int nchunks = gridDim.x / SPLIT;
+  const int row_wg = blk * 32 + part * ROWS;
+  float res = 0.f, wn = 0.f;
+  unsigned epoch = 0;
+  if (wave == 0) {
+    if (lane < ROWS) res = x[row_wg + lane];
+    wn = wnext[blk * 32 + (lane & 31)];
+    epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
+  }
+  const int nt = ((nb + 3) & ~3) + 4;
+  rows_terms<FMT, RW>(w.q, w.d, act, row_wg + wave * RW, 0x7fffffff, nb, lane, ord_terms + (size_t)(wave * RW) * nt, nt);
+  __syncthreads();
+  if (wave != 0) return;
+  if (lane < ROWS) {
+    const float xv = ordered_sum(ord_terms + (size_t)lane * nt, nb) + res;  // x = matmul_out + x (llama2.rs:266 / :636)
+    x[row_wg + lane] = xv;
+    hv[part * ROWS + lane] = xv;
+    if (SPLIT > 1)
+      __hip_atomic_store(ng.pair + row_wg + lane, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  auto poll = [&](const unsigned long long* p) -> float {
+    unsigned long long g = ld_granule(p);
+    int tries = 0;
+    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+      __builtin_amdgcn_s_sleep(2);
+      g = ld_granule(p);
+      tries++;
+    }
+    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+    return __builtin_bit_cast(float, (unsigned)g);
+  };
+  // the chunk's sum of squares: one scan over its 32 rows, starting from -0.0 as norm_quant_block does
+  float cs = -0.0f;
+  if (SPLIT > 1 && part > 0) cs = poll(ng.slots + 2 * blk);  // the first half's scan, continued
+#pragma unroll
+  for (int j = 0; j < ROWS / 4; j++) {
+    const f32x4 t = ((const f32x4*)hv)[part * (ROWS / 4) + j];
+    cs += t[0] * t[0];
+    cs += t[1] * t[1];
+    cs += t[2] * t[2];
+    cs += t[3] * t[3];
+  }
+  if (lane == 0)
+    __hip_atomic_store(ng.slots + blockIdx.x, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  const int l32 = lane & 31;
+  const bool own = l32 >= part * ROWS && l32 < (part + 1) * ROWS;
+  float v = 0.0f;
+  if (SPLIT > 1) {
+    if (lane < 32) v = own ? hv[l32] : poll(ng.pair + blk * 32 + l32);
+  } else {
+    v = hv[l32];
+  }
+  // every chunk's sum (SPLIT = 2: the second workgroup's granule holds the whole chunk), added in chunk order
+  float sum = 0.0f;
+  for (int base = 0; base < nchunks; base += 64) {
+    const int c = base + lane;
+    const float cv = c < nchunks ? poll(ng.slots + (SPLIT > 1 ? 2 * c + 1 : c)) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 64; i++) sum += rl_f(cv, i);
+  }
+  const float rms = sqrtf(sum / (float)(nchunks * 32) + eps);
+  const float xn = (v / rms) * wn;
+  const QLane o = quant_lane32<Q81>(xn, true);
+  if (lane < 32 && own) {
+    q[blk * 32 + lane] = o.q;
+    if (lane == 0) {
+      ((unsigned short*)d)[blk] = o.d;
+      store_qaux<Q81>(isum, blk, o.aux);
+    }
+  }
+}
+
 // ---- gate/up GEMV + SiLU * mul: h[i] = silu(Wg[i].xq) * (Wu[i].xq)   (silu.rs:6-13, arithmetic.rs:57-66) ---
 __device__ __forceinline__ float silu_mul(float g, float u, const unsigned short* __restrict__ exp_tab) {
   float nexp = exp_cached_f(-g, exp_tab);
