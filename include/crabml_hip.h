@@ -72,10 +72,13 @@ typedef struct crabml_hip_device crabml_hip_device_t;
 typedef struct crabml_hip_buf crabml_hip_buf_t;
 
 /* replaces WgpuTensorDeviceOptions (crabml-wgpu/src/wgpu_device.rs:9-38) */
-/* flags: CRABML_HIP_FLAG_STRICT_ORDER makes matmul_vec add the per-block terms in the reference's
- * scalar-loop order (vec_dot_*_fallback), one thread per output row.  Slow; it exists so that parity
- * can be checked BIT-EXACTLY end to end (the truncating activation quantizer amplifies 1-ulp
- * re-association differences).  Default (0) = the fast wave-parallel kernels. */
+/* flags: CRABML_HIP_FLAG_STRICT_ORDER makes every sum run in the reference's scalar order (matmul_vec adds the
+ * per-block terms in block order as vec_dot_*_fallback does; RMSNorm scans and adds its chunks in order;
+ * softmax sums sequentially; attention keeps the f16 chains): results BIT-IDENTICAL to the reference's
+ * default build end to end (the truncating activation quantizer amplifies 1-ulp re-association differences,
+ * see DESIGN.md 2.2).  For Q4_0 / Q8_0 / Q4_1 layers the decode step keeps its five launches per layer
+ * (block terms parked in LDS, one lane per row adds them in order): 664 tok/s on the Llama-3-8B shape
+ * against 745 for the default.  Default (0) = the fast wave-parallel kernels (re-associated sums). */
 #define CRABML_HIP_FLAG_STRICT_ORDER 1
 typedef struct crabml_hip_device_options {
   int32_t device_ordinal; /* HIP device index (one process per GPU: LOCAL_RANK) */
