@@ -390,6 +390,113 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q8k(const i32x4* __restrict_
   exact_chain_store<R>(T, nsb, nt, row0, m, lane, out);
 }
 
+// ---- Q4_K / Q5_K in the reference's order at streaming speed ---------------------------------------------------------------------------
+// buf_q4_k.rs:192-277 / buf_q5_k.rs:229-325 keep EIGHT f32 lanes per row: inside a super-block `aux32[l] += scale * (q8 * q4)` for the
+// elements e with e % 8 == l -- sums of integers below 2^24, exact in f32 in any order --, then per super-block
+// `sums[l] += d * aux32[l]` and `sumf -= dmin * sumi`, and at the end `sumf += sums[0..8)` in order.  So a super-block contributes nine
+// f32 terms per row: d * A[l] with A[l] the exact integer lane sum, and dmin * sumi.  A lane takes one 16-byte piece of quants as the
+// fast kernel does, splits its v_dot4 sums by byte position (byte k of dword i is element class 4 (i & 1) + k: the activation dword
+// is masked to one byte per v_dot4), the eight lanes of a super-block add their integers (DPP), and the first of them parks the nine
+// terms in LDS; one lane per row then runs the nine chains over the super-blocks in order.  Bit-identical to k_gemv_strict's case.
+template <bool Q5, int R>
+__global__ __launch_bounds__(256) void k_gemv_exact_q4k(const char* __restrict__ w, size_t off_scale, ActQ8_K act, float* __restrict__ out, int m,
+                                                        int nsb) {
+  extern __shared__ __attribute__((aligned(16))) float exact_terms[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  const size_t n5 = off_scale / 128;  // (Q5_K: blocks in the tensor; planes qs | qh | hdr)
+  const i32x4* wq = (const i32x4*)w;
+  const i32x4* wqh = (const i32x4*)(w + off_scale);
+  const i32x4* wh = (const i32x4*)(w + off_scale + (Q5 ? n5 * 32 : 0));
+  const int stride = nsb * 12;  // nine terms per super-block, padded to 12 floats (16-byte aligned records)
+  float* T = exact_terms + (size_t)wv * R * stride;
+  const int np = nsb * 8;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < np;
+    const int cc = live ? c : np - 1;
+    const int sb = cc >> 3, j = cc & 7, p = j >> 1, h = j & 1;
+    const Q4KX x = q4k_loadx(act, cc);
+    // the activation dwords masked to one byte each: xm[i][k] keeps byte k of dword i (class 4 (i & 1) + k)
+    int xlm[4][4], xhm[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        xlm[i][k] = (int)((unsigned)x.xl[i] & (0xFFu << (8 * k)));
+        xhm[i][k] = (int)((unsigned)x.xh[i] & (0xFFu << (8 * k)));
+      }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const size_t blk = (size_t)(row0 + r < m ? row0 + r : m - 1) * nsb + sb;
+      const i32x4 qv = __builtin_nontemporal_load(wq + blk * 8 + j);
+      const i32x4 hd = __builtin_nontemporal_load(wh + blk);
+      i32x4 hv = {0, 0, 0, 0};
+      if constexpr (Q5) hv = __builtin_nontemporal_load(wqh + blk * 2 + h);
+      const unsigned f = q4k_pair_field((unsigned)hd[1], (unsigned)hd[2], (unsigned)hd[3], p);
+      const int sc_lo = (int)(f & 63u), sc_hi = (int)((f >> 6) & 63u);
+      const int m_lo = (int)((f >> 12) & 63u), m_hi = (int)(f >> 18);
+      int lo[8], hi[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) lo[l] = hi[l] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = (unsigned)qv[i], hb = (unsigned)hv[i] >> (2 * p);
+        const unsigned l4 = (q & 0x0F0F0F0Fu) | (Q5 ? (hb & 0x01010101u) << 4 : 0u);
+        const unsigned h4 = ((q >> 4) & 0x0F0F0F0Fu) | (Q5 ? ((hb >> 1) & 0x01010101u) << 4 : 0u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          lo[4 * (i & 1) + k] = __builtin_amdgcn_sdot4((int)l4, xlm[i][k], lo[4 * (i & 1) + k], false);
+          hi[4 * (i & 1) + k] = __builtin_amdgcn_sdot4((int)h4, xhm[i][k], hi[4 * (i & 1) + k], false);
+        }
+      }
+      int A[9];
+#pragma unroll
+      for (int l = 0; l < 8; l++) A[l] = live ? sc_lo * lo[l] + sc_hi * hi[l] : 0;
+      A[8] = live ? m_lo * x.bs_lo + m_hi * x.bs_hi : 0;
+#pragma unroll
+      for (int l = 0; l < 9; l++) {  // the eight pieces of the super-block: exact integer sums
+        A[l] += dpp_i<0xB1>(A[l]);
+        A[l] += dpp_i<0x4E>(A[l]);
+        A[l] += dpp_i<0x141>(A[l]);
+      }
+      if (live && (lane & 7) == 0) {
+        const unsigned h0 = (unsigned)hd[0];
+        const float d = h2f((unsigned short)(h0 & 0xffff)) * x.d8, dmin = h2f((unsigned short)(h0 >> 16)) * x.d8;
+        float* t = T + (size_t)r * stride + sb * 12;
+#pragma unroll
+        for (int l = 0; l < 8; l++) t[l] = d * (float)A[l];
+        t[8] = dmin * (float)A[8];
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < R && row0 + lane < m) {
+    const float* t = T + (size_t)lane * stride;
+    float sums[8], sumf = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+    for (int sb = 0; sb < nsb; sb++) {
+      const f32x4 a = *(const f32x4*)(t + sb * 12), b = *(const f32x4*)(t + sb * 12 + 4);
+      sums[0] += a[0];
+      sums[1] += a[1];
+      sums[2] += a[2];
+      sums[3] += a[3];
+      sums[4] += b[0];
+      sums[5] += b[1];
+      sums[6] += b[2];
+      sums[7] += b[3];
+      sumf -= t[sb * 12 + 8];
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++) sumf += sums[l];
+    out[row0 + lane] = sumf;
+  }
+}
+
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out) {
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
@@ -435,6 +542,18 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
         case CRABML_HIP_Q2_K:
           k_gemv_exact_pieces<PieceQ2_K, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, ak, o, (int)m, (int)(k / 256));
           break;
+        case CRABML_HIP_Q4_K:
+        case CRABML_HIP_Q5_K: {
+          const size_t lk = (size_t)WAVES * R * (k / 256) * 12 * sizeof(float);
+          if (lk > 48 * 1024) {
+            done = false;
+          } else if (w->dtype == CRABML_HIP_Q4_K) {
+            k_gemv_exact_q4k<false, R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
+          } else {
+            k_gemv_exact_q4k<true, R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
+          }
+          break;
+        }
         case CRABML_HIP_Q8_K:
           k_gemv_exact_q8k<R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), ak, o, (int)m, (int)(k / 256));
           break;
