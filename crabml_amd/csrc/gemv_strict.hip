@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
 // added per lane and reduced through a tree they are parked in LDS, and one lane per row then adds them strictly in block order:
 // sumf = 0; sumf += t_0; sumf += t_1; ...  Every output equals k_gemv_strict's bit for bit (tests/test_hip_gemv.py compares the two
 // and the oracle).  The chain (nb dependent adds) runs in one lane while the other waves of the CU keep streaming.
-// Formats with f32 lanes inside the block (Q3_K .. Q6_K) and dense F32 / F16 rows stay on k_gemv_strict.
+// Q4_K / Q5_K / Q6_K (f32 lanes inside the super-block) have their own kernels below; Q3_K and dense F32 / F16 rows stay on k_gemv_strict.
 template <int R>
 __device__ __forceinline__ void exact_chain_store(const float* __restrict__ T, int nterms, int stride, int row0, int m, int lane,
                                                   float* __restrict__ out) {
@@ -497,6 +497,106 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q4k(const char* __restrict__
   }
 }
 
+// ---- Q6_K (buf_q6_k.rs:183-234): eight f32 lanes as above, no minimum term; the levels are made signed bytes (q6 - 32) so that the
+// byte-split v_dot4 sums are the reference's products directly.  planes ql | qh | scales | d (common.hpp), n = off_scale / 128 blocks.
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_exact_q6k(const char* __restrict__ w, size_t off_qh, ActQ8_K act, float* __restrict__ out, int m,
+                                                        int nsb) {
+  extern __shared__ __attribute__((aligned(16))) float exact_terms[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  const size_t n = off_qh / 128;
+  const i32x4* wql = (const i32x4*)w;
+  const i32x4* wqh = (const i32x4*)(w + off_qh);
+  const i32x4* wsc = (const i32x4*)(w + off_qh + n * 64);
+  const unsigned short* wd = (const unsigned short*)(w + off_qh + n * 80);
+  const int stride = nsb * 8;
+  float* T = exact_terms + (size_t)wv * R * stride;
+  const int np = nsb * 8;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < np;
+    const int cc = live ? c : np - 1;
+    const int sb = cc >> 3, h = (cc >> 2) & 1, a = (cc >> 1) & 1, p = cc & 1;
+    const int gi = 8 * h + p + 2 * a;  // the low nibbles' 16-element scale group; the high nibbles' is gi + 4
+    const i32x4* xq = act.q + (size_t)sb * 16 + gi;
+    const i32x4 xl = xq[0], xh = xq[4];
+    const float d8 = act.d[sb];
+    int xlm[4][4], xhm[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        xlm[i][k] = (int)((unsigned)xl[i] & (0xFFu << (8 * k)));
+        xhm[i][k] = (int)((unsigned)xh[i] & (0xFFu << (8 * k)));
+      }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const size_t blk = (size_t)(row0 + r < m ? row0 + r : m - 1) * nsb + sb;
+      const i32x4 qv = __builtin_nontemporal_load(wql + blk * 8 + (cc & 7));
+      const i32x4 hv = __builtin_nontemporal_load(wqh + blk * 4 + 2 * h + p);
+      const i32x4 sc4 = __builtin_nontemporal_load(wsc + blk);
+      const int sc_lo = (int)(signed char)(((unsigned)sc4[gi >> 2] >> (8 * (gi & 3))) & 0xFFu);
+      const int sc_hi = (int)(signed char)(((unsigned)sc4[(gi + 4) >> 2] >> (8 * (gi & 3))) & 0xFFu);
+      int lo[8], hi[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) lo[l] = hi[l] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = (unsigned)qv[i], hb = (unsigned)hv[i] >> (2 * a);
+        const unsigned l6 = (q & 0x0F0F0F0Fu) | ((hb & 0x03030303u) << 4);
+        const unsigned h6 = ((q >> 4) & 0x0F0F0F0Fu) | (((hb >> 4) & 0x03030303u) << 4);
+        // 0 .. 63 -> signed bytes v - 32 without carries between bytes
+        const int ls = (int)((((l6 | 0x80808080u) - 0x20202020u)) ^ 0x80808080u);
+        const int hs = (int)((((h6 | 0x80808080u) - 0x20202020u)) ^ 0x80808080u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          lo[4 * (i & 1) + k] = __builtin_amdgcn_sdot4(ls, xlm[i][k], lo[4 * (i & 1) + k], false);
+          hi[4 * (i & 1) + k] = __builtin_amdgcn_sdot4(hs, xhm[i][k], hi[4 * (i & 1) + k], false);
+        }
+      }
+      int A[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        A[l] = live ? sc_lo * lo[l] + sc_hi * hi[l] : 0;
+        A[l] += dpp_i<0xB1>(A[l]);
+        A[l] += dpp_i<0x4E>(A[l]);
+        A[l] += dpp_i<0x141>(A[l]);
+      }
+      if (live && (lane & 7) == 0) {
+        const float d = h2f(wd[blk]) * d8;
+        float* t = T + (size_t)r * stride + sb * 8;
+#pragma unroll
+        for (int l = 0; l < 8; l++) t[l] = (float)A[l] * d;
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < R && row0 + lane < m) {
+    const float* t = T + (size_t)lane * stride;
+    float sums[8], sumf = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+    for (int sb = 0; sb < nsb; sb++) {
+      const f32x4 a = *(const f32x4*)(t + sb * 8), b = *(const f32x4*)(t + sb * 8 + 4);
+      sums[0] += a[0];
+      sums[1] += a[1];
+      sums[2] += a[2];
+      sums[3] += a[3];
+      sums[4] += b[0];
+      sums[5] += b[1];
+      sums[6] += b[2];
+      sums[7] += b[3];
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++) sumf += sums[l];
+    out[row0 + lane] = sumf;
+  }
+}
+
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out) {
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
@@ -552,6 +652,14 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
           } else {
             k_gemv_exact_q4k<true, R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
           }
+          break;
+        }
+        case CRABML_HIP_Q6_K: {
+          const size_t lk = (size_t)WAVES * R * (k / 256) * 8 * sizeof(float);
+          if (lk > 48 * 1024)
+            done = false;
+          else
+            k_gemv_exact_q6k<R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
           break;
         }
         case CRABML_HIP_Q8_K:
