@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
 // added per lane and reduced through a tree they are parked in LDS, and one lane per row then adds them strictly in block order:
 // sumf = 0; sumf += t_0; sumf += t_1; ...  Every output equals k_gemv_strict's bit for bit (tests/test_hip_gemv.py compares the two
 // and the oracle).  The chain (nb dependent adds) runs in one lane while the other waves of the CU keep streaming.
-// Q4_K / Q5_K / Q6_K (f32 lanes inside the super-block) have their own kernels below; Q3_K and dense F32 / F16 rows stay on k_gemv_strict.
+// Q3_K .. Q6_K (eight lanes inside the super-block) have their own kernels below; dense F32 / F16 rows stay on k_gemv_strict.
 template <int R>
 __device__ __forceinline__ void exact_chain_store(const float* __restrict__ T, int nterms, int stride, int row0, int m, int lane,
                                                   float* __restrict__ out) {
@@ -597,6 +597,87 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q6k(const char* __restrict__
   }
 }
 
+// ---- Q3_K (buf_q3_k.rs:238-329): eight i32 lanes per super-block (element e feeds lane e % 8), `sums[l] += d * aux32[l]`, the sums
+// reduced in order at the end.  A lane takes one 16-byte qs piece = four 16-element scale groups (PieceQ3_K, gemv_core.hpp); the levels
+// (2 low bits | hmask bit << 2) - 4 are made signed bytes and the v_dot4 sums split by byte position as for Q4_K.
+template <int R>
+__global__ __launch_bounds__(256) void k_gemv_exact_q3k(const char* __restrict__ w, size_t off, size_t n, ActQ8_K act, float* __restrict__ out,
+                                                        int m, int nsb) {
+  extern __shared__ __attribute__((aligned(16))) float exact_terms[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int row0 = wave * R;
+  if (row0 >= m) return;
+  const int stride = nsb * 8;
+  float* T = exact_terms + (size_t)wv * R * stride;
+  const int np = nsb * 4;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < np;
+    const int cc = live ? c : np - 1;
+    const int sb = cc >> 2;
+    const KGroupsX x = kgroups_loadx(act, cc);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const PieceQ3_K::W wv3 = PieceQ3_K::load(w, off, n, (size_t)(row0 + r < m ? row0 + r : m - 1) * nsb, cc);
+      int A[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) A[l] = 0;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int sc = PieceQ3_K::scale(wv3, cc, s);
+        const int bit = 4 * ((cc >> 1) & 1) + s;
+        int g8[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) g8[l] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const unsigned u = (((unsigned)wv3.qv[i] >> (2 * s)) & 0x03030303u) | ((((unsigned)wv3.hm[i] >> bit) & 0x01010101u) << 2);
+          const int lv = (int)(((u | 0x80808080u) - 0x04040404u) ^ 0x80808080u);  // 0 .. 7 -> signed bytes u - 4
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            g8[4 * (i & 1) + k] = __builtin_amdgcn_sdot4(lv, (int)((unsigned)x.xq[s][i] & (0xFFu << (8 * k))), g8[4 * (i & 1) + k], false);
+        }
+#pragma unroll
+        for (int l = 0; l < 8; l++) A[l] += sc * g8[l];
+      }
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        A[l] = quad_sum_i32(live ? A[l] : 0);  // the four pieces of the super-block
+      }
+      if (live && (lane & 3) == 0) {
+        const float d = h2f((unsigned short)((unsigned)wv3.sd[3] & 0xffffu)) * x.d8;
+        float* t = T + (size_t)r * stride + sb * 8;
+#pragma unroll
+        for (int l = 0; l < 8; l++) t[l] = d * (float)A[l];
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < R && row0 + lane < m) {
+    const float* t = T + (size_t)lane * stride;
+    float sums[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+    for (int sb = 0; sb < nsb; sb++) {
+      const f32x4 a = *(const f32x4*)(t + sb * 8), b = *(const f32x4*)(t + sb * 8 + 4);
+      sums[0] += a[0];
+      sums[1] += a[1];
+      sums[2] += a[2];
+      sums[3] += a[3];
+      sums[4] += b[0];
+      sums[5] += b[1];
+      sums[6] += b[2];
+      sums[7] += b[3];
+    }
+    float sumf = sums[0];
+#pragma unroll
+    for (int l = 1; l < 8; l++) sumf = sumf + sums[l];
+    out[row0 + lane] = sumf;
+  }
+}
+
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out) {
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
@@ -660,6 +741,14 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
             done = false;
           else
             k_gemv_exact_q6k<R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
+          break;
+        }
+        case CRABML_HIP_Q3_K: {
+          const size_t lk = (size_t)WAVES * R * (k / 256) * 8 * sizeof(float);
+          if (lk > 48 * 1024)
+            done = false;
+          else
+            k_gemv_exact_q3k<R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, ak, o, (int)m, (int)(k / 256));
           break;
         }
         case CRABML_HIP_Q8_K:
