@@ -449,12 +449,28 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
                    c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
       } else if (c->ord) {  // strict order: the same launch with block-ordered GEMV sums and the reference's norm order
         const size_t lds = (size_t)(32 / split) * (((k / 32 + 3) & ~3) + 4) * sizeof(float);
-        if (split == 2)
-          launch_k(st, R, k_gemv_res_nq_ord<FMT, 2>, dim3(dim / 16), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q, ad.d,
-                   ad.isum, ng, k / 32);
-        else
-          launch_k(st, R, k_gemv_res_nq_ord<FMT, 1>, dim3(dim / 32), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q, ad.d,
-                   ad.isum, ng, k / 32);
+        static const int pipe_mode = [] {  // tuning hook: 0 = never, 1 = ffn_down only, 2 = wo too (-1 / unset: the default below)
+          const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+          const char* e = getenv("CRABML_HIP_ORD_PIPE");
+          return h && h[0] == '1' && e ? atoi(e) : -1;
+        }();
+        // measured (profiles/r04_strict_order_decode.md): the pipelined chain pays in ffn_down for every format, in wo for Q8_0 only
+        const int pipe = pipe_mode >= 0 ? pipe_mode : FMT == CRABML_HIP_Q8_0 ? 2 : 1;
+        if (split == 2) {
+          if (pipe >= 1)
+            launch_k(st, R, k_gemv_res_nq_ord<FMT, 2, true>, dim3(dim / 16), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32);
+          else
+            launch_k(st, R, k_gemv_res_nq_ord<FMT, 2, false>, dim3(dim / 16), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32);
+        } else {
+          if (pipe >= 2)
+            launch_k(st, R, k_gemv_res_nq_ord<FMT, 1, true>, dim3(dim / 32), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32);
+          else
+            launch_k(st, R, k_gemv_res_nq_ord<FMT, 1, false>, dim3(dim / 32), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32);
+        }
       } else if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
                  eps_next,

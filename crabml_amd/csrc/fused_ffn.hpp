@@ -455,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
 //     first one's scan from its granule (one more dependent round trip, for that half of the workgroups);
 //   * the chunk sums added strictly in chunk order through v_readlane (rms_norm.rs:38-40), as norm_quant_block does with half = 0.
 // Same outputs as k_gemv_res_ord + k_norm_quant(half = 0), bit for bit, in one launch instead of two.
-template <int FMT, int SPLIT>
+template <int FMT, int SPLIT, bool PIPE>  // PIPE: the chain follows the stream step by step (below); else one chain behind the last load
 __global__ __launch_bounds__(1024) void k_gemv_res_nq_ord(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x,
                                                           const float* __restrict__ wnext, float eps, signed char* __restrict__ q,
                                                           void* __restrict__ d, void* __restrict__ isum, NormGather ng, int nb) {
@@ -475,11 +475,91 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq_ord(Planes w, typename Act
     epoch = (unsigned)(*ng.serial) * (unsigned)ng.nseg + (unsigned)ng.seg + 1u;
   }
   const int nt = ((nb + 3) & ~3) + 4;
-  rows_terms<FMT, RW>(w.q, w.d, act, row_wg + wave * RW, 0x7fffffff, nb, lane, ord_terms + (size_t)(wave * RW) * nt, nt);
+  // The rows' block terms into the table, step by step (64 units per row); each wave posts how many steps of ITS rows are in the
+  // table, and wave 0 -- between its own steps, while its next loads are in flight -- lets lane r add what has arrived of row r, in
+  // block order.  The chain (nb dependent adds per row: 448 for ffn_down) thus runs under the stream instead of behind its last load.
+  __shared__ int prog[16];
+  if (PIPE) {
+    if (lane == 0) prog[wave] = 0;
+    __syncthreads();
+  }
+  using F = BlockFmt<FMT>;
+  constexpr int TPS = 64 / F::UNITS;  // terms per row and step
+  const int nu = nb * F::UNITS;
+  float csum = 0.0f;                  // wave 0, lane r < ROWS: the running sum of row r
+  int cst = 0;                        // whole steps of every row already added (wave-uniform)
+  const float* trow = ord_terms + (size_t)(lane < ROWS ? lane : 0) * nt;
+  auto chain_step = [&](int st) {     // the TPS terms of step st, every row at once: all reads first, then the dependent adds
+    const float* t = trow + st * TPS;
+    f32x4 v[TPS / 4];
+#pragma unroll
+    for (int i = 0; i < TPS / 4; i++) v[i] = *(const f32x4*)(t + 4 * i);
+#pragma unroll
+    for (int i = 0; i < TPS / 4; i++) {
+      csum += v[i][0];
+      csum += v[i][1];
+      csum += v[i][2];
+      csum += v[i][3];
+    }
+  };
+  if constexpr (!PIPE) {
+    rows_terms<FMT, RW>(w.q, w.d, act, row_wg + wave * RW, 0x7fffffff, nb, lane, ord_terms + (size_t)(wave * RW) * nt, nt);
+  } else {
+    float* T = ord_terms + (size_t)(wave * RW) * nt;
+    const int row = row_wg + wave * RW;
+    typename F::Blk cur[RW], nxt[RW];
+    XUnit xc, xn;
+    auto fetch = [&](int u0, typename F::Blk (&blk_)[RW], XUnit& xx) {
+      const int u = u0 + lane;
+      const int uu = u < nu ? u : nu - 1;
+#pragma unroll
+      for (int r = 0; r < RW; r++) blk_[r] = F::load(w.q, w.d, (size_t)(row + r), nb, uu);
+      xx = F::loadx(act, uu);
+    };
+    fetch(0, cur, xc);
+    int step = 0;
+    for (int u0 = 0; u0 < nu; u0 += 64, step++) {
+      // (unconditional, clamped: with a conditional request the compiler waits for every load in flight before each use)
+      fetch(u0 + 64 < nu ? u0 + 64 : u0, nxt, xn);
+      const int u = u0 + lane;
+      const bool live = u < nu;
+#pragma unroll
+      for (int r = 0; r < RW; r++) {
+        const float t = F::term(cur[r], xc);
+        if (live && (F::UNITS == 1 || (lane & 1) == 0)) T[r * nt + u / F::UNITS] = t;
+      }
+      // (LDS executes a wave's instructions in order: the flag store lands after the term stores, and a reader that has the flag
+      // issues its term loads after it.  A workgroup-scope release here would also wait for the next step's global loads.)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (lane == 0) __hip_atomic_store(&prog[wave], step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (wave == 0) {  // the steps EVERY wave has posted (whole steps only; the ragged last one waits for the barrier)
+        int pr = __hip_atomic_load(&prog[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pr = min(pr, dpp_i<0xB1>(pr));
+        pr = min(pr, dpp_i<0x4E>(pr));
+        pr = min(pr, dpp_i<0x141>(pr));
+        pr = min(pr, dpp_i<0x140>(pr));
+        const int ready = min(__builtin_amdgcn_readlane(pr, 0), nu / 64);
+        while (cst < ready) {
+          if (lane < ROWS) chain_step(cst);
+          cst++;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RW; r++) cur[r] = nxt[r];
+      xc = xn;
+    }
+  }
   __syncthreads();
   if (wave != 0) return;
   if (lane < ROWS) {
-    const float xv = ordered_sum(ord_terms + (size_t)lane * nt, nb) + res;  // x = matmul_out + x (llama2.rs:266 / :636)
+    if constexpr (PIPE) {
+      for (; cst < nu / 64; cst++) chain_step(cst);            // what arrived after wave 0's last look
+      for (int i = cst * TPS; i < nb; i++) csum += trow[i];    // (a ragged last step)
+    } else {
+      csum = ordered_sum(trow, nb);
+    }
+    const float xv = csum + res;                               // x = matmul_out + x (llama2.rs:266 / :636)
     x[row_wg + lane] = xv;
     hv[part * ROWS + lane] = xv;
     if (SPLIT > 1)
