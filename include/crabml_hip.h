@@ -77,7 +77,7 @@ typedef struct crabml_hip_buf crabml_hip_buf_t;
  * softmax sums sequentially; attention keeps the f16 chains): results BIT-IDENTICAL to the reference's
  * default build end to end (the truncating activation quantizer amplifies 1-ulp re-association differences,
  * see DESIGN.md 2.2).  For Q4_0 / Q8_0 / Q4_1 layers the decode step keeps its five launches per layer
- * (block terms parked in LDS, one lane per row adds them in order): 664 tok/s on the Llama-3-8B shape
+ * (block terms parked in LDS, one lane per row adds them in order): 677 tok/s on the Llama-3-8B shape
  * against 745 for the default.  Default (0) = the fast wave-parallel kernels (re-associated sums). */
 #define CRABML_HIP_FLAG_STRICT_ORDER 1
 typedef struct crabml_hip_device_options {
