@@ -58,6 +58,24 @@ def test_fused_strict_is_bit_exact(ca, shape, fmt, kv_f16):
                     assert np.array_equal(got[lo:lo + n], exp[lo:lo + n]), (layer, which, h)
 
 
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_1"])
+def test_fused_strict_without_the_norm_epilogue_is_bit_exact(ca, fmt):
+    """The strict-order device's seven-launch form (CRABML_HIP_LLAMA_NO_NORM_EPILOGUE = 4: k_gemv_res_ord + the norm / quantize
+    launch in the reference's order) -- what a model whose dim / 32 exceeds the CU count would run -- against the oracle, and equal
+    to the default five-launch form (k_gemv_res_nq_ord) bit for bit."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=16)
+    toks = PROMPT + [7, 9, 11]
+    ref, _ = oracle_logits(model, True, toks)
+    dev = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=4)
+    b = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    for i, t in enumerate(toks):
+        la, lb = a.forward(t, i).copy(), b.forward(t, i).copy()
+        assert np.array_equal(la.view(np.uint32), ref[i].view(np.uint32)), f"{fmt} step {i} (no norm epilogue)"
+        assert np.array_equal(lb.view(np.uint32), ref[i].view(np.uint32)), f"{fmt} step {i}"
+
+
 @pytest.mark.parametrize("fmt", ["Q4_1", "Q5_0", "Q5_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "Q8_K", "F16", "F32"])
 @pytest.mark.parametrize("kv_f16", [False, True])
 def test_decode_step_other_formats_strict_is_bit_exact(ca, fmt, kv_f16):
