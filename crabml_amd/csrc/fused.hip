@@ -635,8 +635,12 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
     k_qkv_epi<<<(total_rows / 2 + 255) / 256, 256, 0, st>>>(c->tmp, e);
     enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
     const void* aact = quant(c->attn, dim_l, c->qt, c->act_attn);
-    CH_TRY(gemv(c->wo[l], dim, dim_l, aact, c->tmp, 2));
-    k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+    if (strict && !tp) {  // the residual inside the GEMV's own store: x = matmul_out + x (llama2.rs:266)
+      CH_TRY(launch_gemv_strict(dev, c->wo[l], dim, dim_l, aact, 1, c->x, c->x));
+    } else {
+      CH_TRY(gemv(c->wo[l], dim, dim_l, aact, c->tmp, 2));
+      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+    }
   } else {
     norm((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp);  // llama2.rs:611
     const void* act = quant(c->xn, dim, c->qt, c->act_dim);
@@ -644,8 +648,12 @@ int enqueue_segment_generic(crabml_hip_llama* c, int seg) {
     CH_TRY(gemv(c->up[l], hidden_l, dim, act, c->tmp + hidden_l, 3));
     k_gateup_epi<<<(hidden_l + 255) / 256, 256, 0, st>>>(c->tmp, c->tmp + hidden_l, dev->exp_table, c->h, hidden_l);
     const void* hact = quant(c->h, hidden_l, c->qt, c->act_hid);
-    CH_TRY(gemv(c->down[l], dim, hidden_l, hact, c->tmp, 4));
-    k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+    if (strict && !tp) {
+      CH_TRY(launch_gemv_strict(dev, c->down[l], dim, hidden_l, hact, 1, c->x, c->x));
+    } else {
+      CH_TRY(gemv(c->down[l], dim, hidden_l, hact, c->tmp, 4));
+      k_res_epi<<<(dim + 255) / 256, 256, 0, st>>>(c->tmp, dst, dim, tp ? 0 : 1);
+    }
   }
   CH_HIP(dev, hipGetLastError());
   return 0;

@@ -16,7 +16,7 @@ namespace crabml_hip {
 
 __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, int dtype, size_t off_scale,
                                                     const char* __restrict__ act, size_t off_d, size_t off_aux,
-                                                    float* __restrict__ out, int m, int k) {
+                                                    float* __restrict__ out, const float* add, int m, int k) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
   float sumf = 0.0f;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
     }
     default: break;
   }
-  out[row] = sumf;
+  out[row] = add ? sumf + add[row] : sumf;  // (add: the residual, x = matmul_out + x)
 }
 
 // ---- the same sums at streaming speed (round 4) -----------------------------------------------------------------------------------
@@ -299,18 +299,18 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
 // Q3_K .. Q6_K (eight lanes inside the super-block) have their own kernels below; dense F32 / F16 rows stay on k_gemv_strict.
 template <int R>
 __device__ __forceinline__ void exact_chain_store(const float* __restrict__ T, int nterms, int stride, int row0, int m, int lane,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ out, const float* add) {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS stores have landed (no other wave touches its region)
   __builtin_amdgcn_wave_barrier();
   if (lane < R && row0 + lane < m) {
     const float sumf = ordered_sum(T + (size_t)lane * stride, nterms);  // (rows of the term table are padded to 16 bytes)
-    out[row0 + lane] = sumf;
+    out[row0 + lane] = add ? sumf + add[row0 + lane] : sumf;
   }
 }
 
 template <int FMT, int R>
 __global__ __launch_bounds__(256) void k_gemv_exact_blk(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
-                                                        typename ActOf<FMT>::type act, float* __restrict__ out, int m, int nb) {
+                                                        typename ActOf<FMT>::type act, float* __restrict__ out, const float* add, int m, int nb) {
   extern __shared__ __attribute__((aligned(16))) float exact_terms[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -319,12 +319,12 @@ __global__ __launch_bounds__(256) void k_gemv_exact_blk(const i32x4* __restrict_
   const int nt = (nb + 3) & ~3;  // row stride of the term table (16-byte aligned rows)
   float* T = exact_terms + (size_t)wv * R * nt;
   rows_terms<FMT, R>(wq, wd, act, row0, m, nb, lane, T, nt);
-  exact_chain_store<R>(T, nb, nt, row0, m, lane, out);
+  exact_chain_store<R>(T, nb, nt, row0, m, lane, out, add);
 }
 
 template <class P, int R>
 __global__ __launch_bounds__(256) void k_gemv_exact_pieces(const char* __restrict__ w, size_t off, size_t n, typename P::Act act,
-                                                           float* __restrict__ out, int m, int nbr) {
+                                                           float* __restrict__ out, const float* add, int m, int nbr) {
   extern __shared__ __attribute__((aligned(16))) float exact_terms[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -354,12 +354,12 @@ __global__ __launch_bounds__(256) void k_gemv_exact_pieces(const char* __restric
       if (live && (P::PIECES == 1 || (lane & (P::PIECES - 1)) == 0)) T[r * nt + cc / P::PIECES] = t;
     }
   }
-  exact_chain_store<R>(T, nbr, nt, row0, m, lane, out);
+  exact_chain_store<R>(T, nbr, nt, row0, m, lane, out, add);
 }
 
 template <int R>
 __global__ __launch_bounds__(256) void k_gemv_exact_q8k(const i32x4* __restrict__ wq, const float* __restrict__ wd, ActQ8_K act,
-                                                        float* __restrict__ out, int m, int nsb) {
+                                                        float* __restrict__ out, const float* add, int m, int nsb) {
   extern __shared__ __attribute__((aligned(16))) float exact_terms[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q8k(const i32x4* __restrict_
       if (live && (lane & 7) == 0) T[r * nt + sb] = ((float)si * wd[(size_t)row * nsb + sb]) * d8;
     }
   }
-  exact_chain_store<R>(T, nsb, nt, row0, m, lane, out);
+  exact_chain_store<R>(T, nsb, nt, row0, m, lane, out, add);
 }
 
 // ---- Q4_K / Q5_K in the reference's order at streaming speed ---------------------------------------------------------------------------
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q8k(const i32x4* __restrict_
 // is masked to one byte per v_dot4), the eight lanes of a super-block add their integers (DPP), and the first of them parks the nine
 // terms in LDS; one lane per row then runs the nine chains over the super-blocks in order.  Bit-identical to k_gemv_strict's case.
 template <bool Q5, int R>
-__global__ __launch_bounds__(256) void k_gemv_exact_q4k(const char* __restrict__ w, size_t off_scale, ActQ8_K act, float* __restrict__ out, int m,
+__global__ __launch_bounds__(256) void k_gemv_exact_q4k(const char* __restrict__ w, size_t off_scale, ActQ8_K act, float* __restrict__ out, const float* add, int m,
                                                         int nsb) {
   extern __shared__ __attribute__((aligned(16))) float exact_terms[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -493,14 +493,14 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q4k(const char* __restrict__
     }
 #pragma unroll
     for (int l = 0; l < 8; l++) sumf += sums[l];
-    out[row0 + lane] = sumf;
+    out[row0 + lane] = add ? sumf + add[row0 + lane] : sumf;
   }
 }
 
 // ---- Q6_K (buf_q6_k.rs:183-234): eight f32 lanes as above, no minimum term; the levels are made signed bytes (q6 - 32) so that the
 // byte-split v_dot4 sums are the reference's products directly.  planes ql | qh | scales | d (common.hpp), n = off_scale / 128 blocks.
 template <int R>
-__global__ __launch_bounds__(256) void k_gemv_exact_q6k(const char* __restrict__ w, size_t off_qh, ActQ8_K act, float* __restrict__ out, int m,
+__global__ __launch_bounds__(256) void k_gemv_exact_q6k(const char* __restrict__ w, size_t off_qh, ActQ8_K act, float* __restrict__ out, const float* add, int m,
                                                         int nsb) {
   extern __shared__ __attribute__((aligned(16))) float exact_terms[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q6k(const char* __restrict__
     }
 #pragma unroll
     for (int l = 0; l < 8; l++) sumf += sums[l];
-    out[row0 + lane] = sumf;
+    out[row0 + lane] = add ? sumf + add[row0 + lane] : sumf;
   }
 }
 
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q6k(const char* __restrict__
 // (2 low bits | hmask bit << 2) - 4 are made signed bytes and the v_dot4 sums split by byte position as for Q4_K.
 template <int R>
 __global__ __launch_bounds__(256) void k_gemv_exact_q3k(const char* __restrict__ w, size_t off, size_t n, ActQ8_K act, float* __restrict__ out,
-                                                        int m, int nsb) {
+                                                        const float* add, int m, int nsb) {
   extern __shared__ __attribute__((aligned(16))) float exact_terms[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -674,12 +674,12 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q3k(const char* __restrict__
     float sumf = sums[0];
 #pragma unroll
     for (int l = 1; l < 8; l++) sumf = sumf + sums[l];
-    out[row0 + lane] = sumf;
+    out[row0 + lane] = add ? sumf + add[row0 + lane] : sumf;
   }
 }
 
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
-                       float* out) {
+                       float* out, const float* add) {
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (qt == 0xffffffffu) return set_error(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
   const ActLayout al = act_layout(qt, k);
@@ -706,22 +706,22 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
       const ActQ8_K ak{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
       switch (w->dtype) {
         case CRABML_HIP_Q4_0:
-          k_gemv_exact_blk<CRABML_HIP_Q4_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a0, o, (int)m, (int)(k / 32));
+          k_gemv_exact_blk<CRABML_HIP_Q4_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a0, o, add, (int)m, (int)(k / 32));
           break;
         case CRABML_HIP_Q8_0:
-          k_gemv_exact_blk<CRABML_HIP_Q8_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a0, o, (int)m, (int)(k / 32));
+          k_gemv_exact_blk<CRABML_HIP_Q8_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a0, o, add, (int)m, (int)(k / 32));
           break;
         case CRABML_HIP_Q4_1:
-          k_gemv_exact_blk<CRABML_HIP_Q4_1, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a1, o, (int)m, (int)(k / 32));
+          k_gemv_exact_blk<CRABML_HIP_Q4_1, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a1, o, add, (int)m, (int)(k / 32));
           break;
         case CRABML_HIP_Q5_0:
-          k_gemv_exact_pieces<PieceQ5_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, a0, o, (int)m, (int)(k / 32));
+          k_gemv_exact_pieces<PieceQ5_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, a0, o, add, (int)m, (int)(k / 32));
           break;
         case CRABML_HIP_Q5_1:
-          k_gemv_exact_pieces<PieceQ5_1, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, a1, o, (int)m, (int)(k / 32));
+          k_gemv_exact_pieces<PieceQ5_1, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, a1, o, add, (int)m, (int)(k / 32));
           break;
         case CRABML_HIP_Q2_K:
-          k_gemv_exact_pieces<PieceQ2_K, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, ak, o, (int)m, (int)(k / 256));
+          k_gemv_exact_pieces<PieceQ2_K, R><<<grid, 64 * WAVES, lds, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, ak, o, add, (int)m, (int)(k / 256));
           break;
         case CRABML_HIP_Q4_K:
         case CRABML_HIP_Q5_K: {
@@ -729,9 +729,9 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
           if (lk > 48 * 1024) {
             done = false;
           } else if (w->dtype == CRABML_HIP_Q4_K) {
-            k_gemv_exact_q4k<false, R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
+            k_gemv_exact_q4k<false, R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, add, (int)m, (int)(k / 256));
           } else {
-            k_gemv_exact_q4k<true, R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
+            k_gemv_exact_q4k<true, R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, add, (int)m, (int)(k / 256));
           }
           break;
         }
@@ -740,7 +740,7 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
           if (lk > 48 * 1024)
             done = false;
           else
-            k_gemv_exact_q6k<R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, (int)m, (int)(k / 256));
+            k_gemv_exact_q6k<R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, ak, o, add, (int)m, (int)(k / 256));
           break;
         }
         case CRABML_HIP_Q3_K: {
@@ -748,17 +748,17 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
           if (lk > 48 * 1024)
             done = false;
           else
-            k_gemv_exact_q3k<R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, ak, o, (int)m, (int)(k / 256));
+            k_gemv_exact_q3k<R><<<grid, 64 * WAVES, lk, dev->stream>>>(wp, w->wl.off_scale, w->wl.n_blocks, ak, o, add, (int)m, (int)(k / 256));
           break;
         }
         case CRABML_HIP_Q8_K:
-          k_gemv_exact_q8k<R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), ak, o, (int)m, (int)(k / 256));
+          k_gemv_exact_q8k<R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const float*)(wp + w->wl.off_scale), ak, o, add, (int)m, (int)(k / 256));
           break;
         default: done = false;
       }
     }
     if (!done)
-      k_gemv_strict<<<(unsigned)((m + 63) / 64), 64, 0, dev->stream>>>(wp, (int)w->dtype, w->wl.off_scale, ap, al.off_d, al.off_aux, o, (int)m, (int)k);
+      k_gemv_strict<<<(unsigned)((m + 63) / 64), 64, 0, dev->stream>>>(wp, (int)w->dtype, w->wl.off_scale, ap, al.off_d, al.off_aux, o, add, (int)m, (int)k);
   }
   return 0;
 }

@@ -26,7 +26,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_
                 float* out, crabml_hip_device::ProfRec* rec = nullptr);
 // gemv_strict.hip: same contract, block terms added in the reference's scalar order (bit-exact; slow)
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
-                       float* out);
+                       float* out, const float* add = nullptr);  // add: out[i] = sum + add[i] (the residual; may alias out)
 // weight upload: scatter the pieces of `n_blocks` GGUF blocks (`bb` bytes each) starting at block `blk0` into their
 // planes (byte moves only).  Piece s = bytes [2 src_off2, 2 src_off2 + 2 len2) of a block -> base + dst_off[s],
 // one `stride2`-unit record per block (stride2 = len2 unless two pieces share a record: Q5_K's header); bytes covered by no
