@@ -570,7 +570,8 @@ def main():
     t_upload = time.perf_counter() - t_upload
     t_build = time.perf_counter() - t_build
     seq_len = max(args.warmup + 2 * args.steps + 16, 144)
-    trait = ca.Llama2Runner(conf, weights, dev, seq_len, True)  # f16 KV cache = the CLI default (main.rs:250)
+    trait_seq = max(seq_len, args.warmup + 3 * max(args.steps, 16) + 16)
+    trait = ca.Llama2Runner(conf, weights, dev, trait_seq, True)  # f16 KV cache = the CLI default (main.rs:250)
     path = args.path
     fused = None
     if path in ("auto", "fused"):
@@ -598,7 +599,7 @@ def main():
             if path == "fused":
                 fused.reset()
             else:
-                trait = ca.Llama2Runner(conf, weights, dev, seq_len, True)
+                trait = ca.Llama2Runner(conf, weights, dev, trait_seq, True)
         tok = decode(1, args.warmup) if args.warmup > 0 else 1
         dev.sync()
         dist.barrier()
@@ -626,16 +627,45 @@ def main():
         c3 = {"positions": "0..127", "tokens_per_s": round(128 / best, 2), "ms_per_step": round(best / 128 * 1e3, 4),
               "note": "128 greedy steps from an empty KV cache (SURVEY.md config C3), host clock around one blocking call, best of 3"}
 
-    # the per-op trait path (Llama2Runner<HipTensor> unchanged) is always reported next to the fused number
+    # The reference's API: Llama2Runner<HipTensor> UNCHANGED, one Tensor call after the other (what `crabml-cli -D hip` runs,
+    # patches/0002).  Since ABI version 2 the calls are recorded and a decode token is served by the fused step (csrc/lazy.hpp);
+    # the same runner on a device that launches every call immediately (ABI version 1, "per-op") is timed next to it.
     trait_tps = None
+    trait_info = None
     if rank == 0 and path == "fused":
-        n_t = min(args.steps, 16)
-        t_tok = int(trait.timed_decode(1, 2)[0][-1])
+        n_t = max(args.steps, 16)
+        st0 = dev.lazy_stats()
+        t_tok = int(trait.timed_decode(1, args.warmup if args.warmup > 0 else 2)[0][-1])
         dev.sync()
-        tt = time.perf_counter()
-        trait.timed_decode(t_tok, n_t)
-        dev.sync()
-        trait_tps = n_t / (time.perf_counter() - tt)
+        best = None
+        for _ in range(3):
+            tt = time.perf_counter()
+            t_tok = int(trait.timed_decode(t_tok, n_t)[0][-1])
+            dev.sync()
+            dt = time.perf_counter() - tt
+            best = dt if best is None else min(best, dt)
+        trait_tps = n_t / best
+        st1 = dev.lazy_stats()
+        trait_info = {"tokens_per_s": round(trait_tps, 2), "ms_per_step": round(best / n_t * 1e3, 4), "steps": n_t,
+                      "api": "Llama2Runner<HipTensor>::forward + host arg-max per token (the reference's generic runner, unchanged); "
+                             "logits exported every token",
+                      "queue": {k: int(st1[k] - st0[k]) for k in st1},
+                      "note": "best of 3 regions; `queue`: Tensor calls recorded / run one launch at a time / tokens served by the fused step"}
+        try:
+            pdev = ca.HipTensorDevice(local, False, 0, False, "per-op")
+            if model is not None:
+                pconf, pweights = synth.to_hip(model, pdev)
+                ptrait = ca.Llama2Runner(pconf, pweights, pdev, 64, True)
+                p_tok = int(ptrait.timed_decode(1, 2)[0][-1])
+                pdev.sync()
+                tt = time.perf_counter()
+                ptrait.timed_decode(p_tok, 8)
+                pdev.sync()
+                trait_info["per_op_launches_tokens_per_s"] = round(8 / (time.perf_counter() - tt), 2)
+                del ptrait, pweights
+            del pdev
+        except Exception as e:
+            trait_info["per_op_launches_tokens_per_s"] = repr(e)
 
     # ---- instrumented pass: HIP event pairs around every GEMV-stage launch (same process, same weights) ---
     # Events cannot live inside the captured graph, so the fused step is replayed EAGERLY (identical kernels
@@ -795,6 +825,7 @@ def main():
             out["c3_positions_0_127"] = c3
         if trait_tps is not None:
             out["trait_path_tokens_per_s"] = round(trait_tps, 2)
+            out["trait_path"] = trait_info
         if args.layers is not None:
             out["INVALID"] = "layer count truncated with --layers (debug run)"
         if roof:

@@ -1,4 +1,4 @@
-//! Raw bindings of include/crabml_hip.h (ABI version 1; the parity / measurement hooks of crabml_hip_debug.h are test
+//! Raw bindings of include/crabml_hip.h (ABI version 2; the parity / measurement hooks of crabml_hip_debug.h are test
 //! infrastructure of the backend repository and are not bound), written by hand: the header is small, plain C
 //! (opaque handles, pointers, sizes, fixed-width integers), and a checked-in binding keeps `bindgen` / libclang out
 //! of the build.  tests/test_rust_crate.py (backend repository) parses this `extern "C"` block and the header and
@@ -12,9 +12,11 @@
 use std::os::raw::c_char;
 use std::os::raw::c_void;
 
-pub const CRABML_HIP_ABI_VERSION: i32 = 1;
+pub const CRABML_HIP_ABI_VERSION: i32 = 2;
 
 pub const CRABML_HIP_FLAG_STRICT_ORDER: i32 = 1;
+/// every Tensor call launches immediately instead of being recorded (ABI version 1 behaviour)
+pub const CRABML_HIP_FLAG_PER_OP: i32 = 2;
 
 pub const CRABML_HIP_LLAMA_NO_GRAPH: i32 = 1;
 pub const CRABML_HIP_LLAMA_NO_PREFETCH: i32 = 2;

@@ -24,6 +24,11 @@ pub struct HipTensorDeviceOptions {
     /// CRABML_HIP_FLAG_STRICT_ORDER: matmul_vec adds the block terms in the scalar-loop order of the
     /// reference's default build; every result is then bit-identical to the CPU backend. Slow.
     pub strict_order: bool,
+
+    /// CRABML_HIP_FLAG_PER_OP: launch every Tensor call immediately. Default (false): the calls are recorded and
+    /// run at the next `export` / `sync` -- a decode token of `Llama2Runner::forward` as the fused step
+    /// (five launches per layer), anything else op by op; the results are the same either way.
+    pub per_op: bool,
 }
 
 impl Default for HipTensorDeviceOptions {
@@ -38,6 +43,7 @@ impl HipTensorDeviceOptions {
             device_ordinal: 0,
             debug_named_tensor: false,
             strict_order: false,
+            per_op: false,
         }
     }
 
@@ -53,6 +59,11 @@ impl HipTensorDeviceOptions {
 
     pub fn with_strict_order(mut self, v: bool) -> Self {
         self.strict_order = v;
+        self
+    }
+
+    pub fn with_per_op(mut self, v: bool) -> Self {
+        self.per_op = v;
         self
     }
 }
@@ -106,11 +117,15 @@ impl HipTensorDevice {
         let c_opts = ffi::crabml_hip_device_options_t {
             device_ordinal: opts.device_ordinal,
             stream: ptr::null_mut(),
-            flags: if opts.strict_order {
+            flags: (if opts.strict_order {
                 ffi::CRABML_HIP_FLAG_STRICT_ORDER
             } else {
                 0
-            },
+            }) | (if opts.per_op {
+                ffi::CRABML_HIP_FLAG_PER_OP
+            } else {
+                0
+            }),
         };
         let mut raw = ptr::null_mut();
         let rc = unsafe { ffi::crabml_hip_device_create(&c_opts, &mut raw) };

@@ -108,6 +108,10 @@ ActLayout act_layout(uint32_t qtype, size_t n_elems);
 
 }  // namespace crabml_hip
 
+namespace crabml_hip {
+struct LazyState;  // lazy.hpp: the recorded-op queue + the fused-step matcher of this device
+}
+
 // ---- the opaque C types ------------------------------------------------------------------------
 struct crabml_hip_device {
   int ordinal = 0;
@@ -133,6 +137,12 @@ struct crabml_hip_device {
   };
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_free_events;
+  // Tensor ops are RECORDED and run at the next point the host can observe data (export / sync): lazy.hip.  `lazy` off
+  // (CRABML_HIP_FLAG_PER_OP): every call launches immediately.  `fuse` off: the queue is replayed op by op, never matched.
+  bool lazy = true, fuse = true;
+  bool dry = false;  // test hook (CRABML_HIP_FLAG_DRY + CRABML_HIP_TEST_HOOKS=1): no HIP device behind this object -- ops are
+                     // recorded, matched and counted, nothing is computed (the CPU suite drives the recorder / matcher with it)
+  crabml_hip::LazyState* lz = nullptr;
 };
 
 struct crabml_hip_buf {
@@ -140,7 +150,10 @@ struct crabml_hip_buf {
   std::atomic<int> refcnt{1};
   uint32_t dtype = 0;
   size_t n_elems = 0;
-  void* ptr = nullptr;
+  void* ptr = nullptr;  // device memory; bound on first use (ensure_mem) for buffers created by recorded ops / alloc
+  size_t bytes = 0;     // size to bind
+  bool zero_init = false;  // Tensor::alloc(F32): zero-filled when the memory is bound (vec![0.0; n], cpu_tensor.rs:146-149)
+  uint8_t deferred = 0;    // lazy.hip: the value still lives in the fused context (1 = the final RMSNorm of its residual stream)
   size_t cap = 0;       // pool capacity in bytes
   size_t m = 0, k = 0;  // logical 2-D shape of quantized weights
   crabml_hip::WeightLayout wl;
@@ -189,6 +202,18 @@ int hip_fail(crabml_hip_device* dev, hipError_t e, const char* what, const char*
 int pool_alloc(crabml_hip_device* dev, size_t bytes, void** out, size_t* cap);
 void pool_free(crabml_hip_device* dev, void* ptr, size_t cap);
 int buf_new(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes, crabml_hip_buf** out);
+// a handle without memory: bound by ensure_mem when an executed op first touches it (outputs of recorded ops that a fused
+// launch makes redundant never get any)
+crabml_hip_buf* buf_new_unbound(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes);
+int ensure_mem(crabml_hip_device* dev, crabml_hip_buf* b);
+// runs every recorded op (lazy.hip); every entry point that touches the stream or reads device memory calls it first
+int lazy_flush(crabml_hip_device* dev);
+#define CH_FLUSH(dev) CH_TRY(::crabml_hip::lazy_flush(dev))
+// entry points that compute or measure have nothing to offer on the record-only test device
+#define CH_LIVE(dev)                                                                                                      \
+  do {                                                                                                                    \
+    if ((dev)->dry) return ::crabml_hip::set_error((dev), CRABML_HIP_NOT_IMPLEMENTED, "record-only test device: no HIP device"); \
+  } while (0)
 inline void touch(crabml_hip_buf* b) { b->version++; }
 // measurement hook helpers (runtime.hip)
 // prof_begin hands out an event pair; the kernel is then launched with hipExtLaunchKernelGGL(start, stop), which

@@ -21,6 +21,7 @@
 #include "fused_common.hpp"
 #include "fused_attention.hpp"
 #include "fused_ffn.hpp"
+#include "lazy.hpp"
 
 
 // ==============================================================================================================
@@ -109,6 +110,8 @@ struct crabml_hip_llama {
   float* attn = nullptr;     // attention output (dim_l)
   float* h = nullptr;        // ffn hidden (hidden_l), strict mode only
   float* logits = nullptr;   // vocab
+  float* logits_ext = nullptr;  // lazy.hip: the classifier of this step writes the caller's buffer instead
+  bool ext_kv = false;          // lazy.hip: kc / vc are the runner's own cache buffers (retained in `held`), not allocations of ours
   float* tmp = nullptr;      // strict-mode GEMV outputs
   char* act_dim = nullptr;   // Q8_0 planes of the normalized residual (dim)
   char* act_attn = nullptr;  // Q8_0 planes of the attention output (dim_l)
@@ -192,6 +195,7 @@ TpP2P tp_view(const crabml_hip_llama* c, bool fused_collective) {
 hipError_t raise_dyn_lds(const crabml_hip_device* dev, const void* fn, int bytes) {
   static std::mutex mu;
   static std::map<std::pair<int, const void*>, int> have;
+  if (dev->dry) return hipErrorNoDevice;  // record-only test device
   std::lock_guard<std::mutex> g(mu);
   int& cur = have[{dev->ordinal, fn}];
   if (bytes <= cur) return hipSuccess;
@@ -359,7 +363,7 @@ int enqueue_classifier_and_sampler(crabml_hip_llama* c, const void* cls_act, cra
   const auto& g = c->cfg;
   const int dim = (int)g.embedding_dim;
   int *token_d = c->state, *pos_d = c->state + 1, *step_d = c->state + 2;
-  float* out = c->logits + c->vocab_off;
+  float* out = (c->logits_ext ? c->logits_ext : c->logits) + c->vocab_off;
   if (dev->strict_order)
     CH_TRY(launch_gemv_strict(dev, c->output, (size_t)c->vocab_l, dim, cls_act, 1, out));
   else
@@ -1185,7 +1189,9 @@ int crabml_hip_tp_comm_create(crabml_hip_device_t* dev, const void* id128, int n
   *out = nullptr;
   Rccl* r = rccl();
   if (!r) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "librccl.so could not be loaded");
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   Rccl::IdT id;
   memcpy(&id, id128, sizeof id);
   void* comm = nullptr;
@@ -1227,7 +1233,9 @@ int crabml_hip_tp_comm_destroy(crabml_hip_tp_comm_t* comm) {
 int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, size_t n) {
   if (!comm || !buf) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = comm->dev;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   if (buf->dtype != CRABML_HIP_F32 || n > buf->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: needs an f32 buffer of >= n elements");
   if (comm->p2p) {
     if (!comm->connected) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_all_reduce: the p2p group is not connected");
@@ -1259,7 +1267,9 @@ int crabml_hip_tp_p2p_create(crabml_hip_device_t* dev, int nranks, int rank, siz
   if (!dev || !out || nranks < 1 || nranks > 8 || rank < 0 || rank >= nranks || max_elems == 0 || max_elems > (1u << 24))
     return CRABML_HIP_BAD_INPUT;
   *out = nullptr;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   crabml_hip_tp_comm* c = new crabml_hip_tp_comm();
   c->dev = dev;
   c->nranks = nranks;
@@ -1295,7 +1305,9 @@ int crabml_hip_tp_p2p_create(crabml_hip_device_t* dev, int nranks, int rank, siz
 int crabml_hip_tp_p2p_export(crabml_hip_tp_comm_t* comm, void* handle64) {
   if (!comm || !comm->p2p || !handle64) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = comm->dev;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   hipIpcMemHandle_t h;
   CH_HIP(dev, hipIpcGetMemHandle(&h, comm->inbox));
@@ -1307,7 +1319,9 @@ int crabml_hip_tp_p2p_export(crabml_hip_tp_comm_t* comm, void* handle64) {
 int crabml_hip_tp_p2p_connect(crabml_hip_tp_comm_t* comm, const void* handles) {
   if (!comm || !comm->p2p || !handles) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = comm->dev;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   if (comm->connected && comm->nranks > 1) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_p2p_connect: already connected");
   for (int r = 0; r < comm->nranks; r++) {
     if (r == comm->rank) continue;
@@ -1346,10 +1360,15 @@ int crabml_hip_tp_p2p_connect_local(crabml_hip_tp_comm_t* const* comms, int n) {
   return 0;
 }
 
-int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_config_t* cfg,
-                            const crabml_hip_llama_weights_t* w, crabml_hip_llama_t** out) {
+}  // extern "C"
+
+// ext_kc / ext_vc (lazy.hip): the caller's KV caches, [n_kv_heads][seq_len][head_dim] in the configured element type -- the layout
+// of Llama2Runner's own cache tensors (llama2.rs:65-86) -- used in place
+static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_config_t* cfg, const crabml_hip_llama_weights_t* w,
+                             crabml_hip_buf* const* ext_kc, crabml_hip_buf* const* ext_vc, crabml_hip_llama_t** out) {
   if (!dev || !cfg || !w || !out) return CRABML_HIP_BAD_INPUT;
   *out = nullptr;
+  const bool dry = dev->dry;
   const auto& g = *cfg;
   const int tp = g.tp_size > 1 ? g.tp_size : 1;
   if (!g.n_heads || !g.n_kv_heads || !g.n_layers || g.embedding_dim % g.n_heads || g.n_heads % g.n_kv_heads)
@@ -1448,10 +1467,10 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
       w->token_embed->n_elems != g.vocab_size * g.embedding_dim)
     CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "llama fused path: classifier / final norm / embedding dtype or shape");
 
-  CH_USE(dev);
+  if (!dry) CH_USE(dev);
   crabml_hip_llama* c = new crabml_hip_llama();
   c->dev = dev;
-  if (hipHostMalloc((void**)&c->h_state, crabml_hip_llama::H_STATE_SLOTS * 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+  if (!dry && hipHostMalloc((void**)&c->h_state, (crabml_hip_llama::H_STATE_SLOTS * 4 + 4) * sizeof(int), hipHostMallocDefault) != hipSuccess) {
     delete c;
     CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "llama: hipHostMalloc of the state staging ring failed");
   }
@@ -1489,10 +1508,12 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->dim_l = (int)dim_l;
   c->kv_dim_l = (int)kv_dim_l;
   c->hidden_l = (int)hidden_l;
+  int rc = 0;
   auto hold = [&](const crabml_hip_buf* b) {
     crabml_hip_buf* m = const_cast<crabml_hip_buf*>(b);
     crabml_hip_buf_retain(m);
     c->held.push_back(m);
+    if (rc == 0) rc = ensure_mem(dev, m);
     return m;
   };
   c->token_embed = hold(w->token_embed);
@@ -1509,7 +1530,6 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
     c->down.push_back(hold(w->ffn_down_weight[l]));
     c->up.push_back(hold(w->ffn_up_weight[l]));
   }
-  int rc = 0;
   auto A = [&](size_t bytes, void** p) {
     if (rc == 0) rc = dalloc(c, bytes, p);
   };
@@ -1517,9 +1537,21 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   c->kv_bytes = n_kv_l * g.seq_len * hd * es;
   c->kc.resize(g.n_layers);
   c->vc.resize(g.n_layers);
+  c->ext_kv = ext_kc != nullptr;
   for (size_t l = 0; l < g.n_layers; l++) {
-    A(c->kv_bytes, &c->kc[l]);
-    A(c->kv_bytes, &c->vc[l]);
+    if (c->ext_kv) {
+      const uint32_t kvt = g.use_f16_kv_cache ? CRABML_HIP_F16 : CRABML_HIP_F32;
+      if (!ext_kc[l] || !ext_vc[l] || ext_kc[l]->dtype != kvt || ext_vc[l]->dtype != kvt || ext_kc[l]->n_elems * es != c->kv_bytes ||
+          ext_vc[l]->n_elems * es != c->kv_bytes) {
+        if (rc == 0) rc = set_error(dev, CRABML_HIP_BAD_INPUT, "llama: external kv cache of layer %zu has the wrong type or size", l);
+        continue;
+      }
+      c->kc[l] = hold(ext_kc[l])->ptr;
+      c->vc[l] = hold(ext_vc[l])->ptr;
+    } else {
+      A(c->kv_bytes, &c->kc[l]);
+      A(c->kv_bytes, &c->vc[l]);
+    }
   }
   A(g.embedding_dim * 4, (void**)&c->x);
   A(g.embedding_dim * 4, (void**)&c->partial);
@@ -1592,7 +1624,7 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
             }
         A(n_kv_l * (size_t)S * flash_part_floats((int)grp, (int)hd) * 4, (void**)&c->flash_part);
         A(n_kv_l * 4, (void**)&c->flash_tick);
-        if (rc == 0 && hipMemsetAsync(c->flash_tick, 0, n_kv_l * 4, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
+        if (rc == 0 && !dry && hipMemsetAsync(c->flash_tick, 0, n_kv_l * 4, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
         c->attn_flash = rc == 0;
         // the prompt pass's causal attention of the fast step (k_attn_flash_rows): 70 KB of LDS at head_dim 128
         if (c->attn_flash && (hd == 128 || hd == 64) &&
@@ -1657,7 +1689,11 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
         theta *= theta_scale;
       }
     }
-    hipError_t e = hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
+    hipError_t e = dry ? hipErrorUnknown : hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, dev->stream);
+    if (dry) {  // record-only test device: nothing to initialize
+      *out = c;
+      return 0;
+    }
     if (e == hipSuccess) e = hipMemsetAsync(c->state, 0, 8 * sizeof(int), dev->stream);
     // vocabulary split: the entries of the other ranks' shards read -inf (an element-wise max over the ranks is the all-gather)
     if (e == hipSuccess && c->split_vocab) e = hipMemsetD32Async((hipDeviceptr_t)c->logits, (int)0xff800000u, g.vocab_size, dev->stream);
@@ -1714,10 +1750,24 @@ int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_con
   return 0;
 }
 
+extern "C" {
+
+int crabml_hip_llama_create(crabml_hip_device_t* dev, const crabml_hip_llama_config_t* cfg,
+                            const crabml_hip_llama_weights_t* w, crabml_hip_llama_t** out) {
+  if (!dev || !cfg || !w || !out) return CRABML_HIP_BAD_INPUT;
+  *out = nullptr;
+  CH_LIVE(dev);
+  CH_USE(dev);
+  CH_FLUSH(dev);
+  return llama_create_impl(dev, cfg, w, nullptr, nullptr, out);
+}
+
 int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
   if (!c) return 0;
-  (void)hipSetDevice(c->dev->ordinal);
-  (void)hipStreamSynchronize(c->dev->stream);
+  if (!c->dev->dry) {
+    (void)hipSetDevice(c->dev->ordinal);
+    (void)hipStreamSynchronize(c->dev->stream);
+  }
   for (int v = 0; v < 2; v++) {
     if (c->exec[v]) (void)hipGraphExecDestroy(c->exec[v]);
     if (c->graph[v]) (void)hipGraphDestroy(c->graph[v]);
@@ -1740,7 +1790,9 @@ static int check_step(crabml_hip_llama* c, size_t token, size_t pos) {
 int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, float* logits) {
   if (!c) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   if (c->tp > 1 && !c->comm && !c->tp_dry)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   CH_TRY(check_step(c, token, pos));
@@ -1761,7 +1813,9 @@ int crabml_hip_llama_forward(crabml_hip_llama_t* c, size_t token, size_t pos, fl
 int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n_steps, uint32_t* out_tokens) {
   if (!c || (!out_tokens && n_steps)) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   if (c->tp > 1 && !c->comm && !c->tp_dry)
     CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: a tp rank without a communicator is driven by crabml_hip_llama_tp_sim_*");
   if (token >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %zu out of range", token);
@@ -1784,7 +1838,9 @@ int crabml_hip_llama_decode_greedy(crabml_hip_llama_t* c, size_t token, size_t n
 int crabml_hip_llama_prefill(crabml_hip_llama_t* c, const uint32_t* tokens, size_t n, float* logits) {
   if (!c || (!tokens && n)) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = c->dev;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   if (n == 0) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama prefill: expected at least 1 prompt token");  // llama2.rs:117-122
   for (size_t i = 0; i < n; i++)
     if (tokens[i] >= c->cfg.vocab_size) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "llama: token %u out of range", tokens[i]);
@@ -1814,7 +1870,9 @@ int crabml_hip_llama_prefill(crabml_hip_llama_t* c, const uint32_t* tokens, size
 int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, size_t token, size_t pos, float* logits) {
   if (!ranks || n < 1 || n > 8 || !ranks[0]) return CRABML_HIP_BAD_INPUT;
   crabml_hip_device* dev = ranks[0]->dev;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   for (int r = 0; r < n; r++) {
     if (!ranks[r] || ranks[r]->dev != dev || ranks[r]->tp != n || ranks[r]->tp_rank != r || ranks[r]->comm)
       CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_sim: rank %d is not a communicator-less rank %d of %d on this device", r, r, n);
@@ -1864,6 +1922,7 @@ int crabml_hip_llama_reset(crabml_hip_llama_t* c) {
   c->kv_len = 0;
   if (c->flash_tick) {  // a step that faulted half-way may have left arrivals behind
     CH_USE(c->dev);
+    CH_FLUSH(c->dev);
     CH_HIP(c->dev, hipMemsetAsync(c->flash_tick, 0, (size_t)c->n_kv_l * 4, c->dev->stream));
   }
   return 0;
@@ -1872,6 +1931,7 @@ int crabml_hip_llama_reset(crabml_hip_llama_t* c) {
 int crabml_hip_llama_debug_kv(crabml_hip_llama_t* c, size_t layer, int32_t which_v, void* dst, size_t nbytes) {
   if (!c || !dst) return CRABML_HIP_BAD_INPUT;
   CH_USE(c->dev);
+  CH_FLUSH(c->dev);
   if (layer >= c->cfg.n_layers || nbytes > c->kv_bytes) CH_BAIL(c->dev, CRABML_HIP_BAD_INPUT, "llama debug_kv: bad layer/size");
   CH_HIP(c->dev, hipMemcpyAsync(dst, which_v ? c->vc[layer] : c->kc[layer], nbytes, hipMemcpyDeviceToHost, c->dev->stream));
   CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
@@ -1882,7 +1942,9 @@ int crabml_hip_llama_debug_kv(crabml_hip_llama_t* c, size_t layer, int32_t which
 int crabml_hip_debug_flash_attention(crabml_hip_device_t* dev, const float* q, const uint16_t* k, const uint16_t* v, size_t n_heads,
                                      size_t n_kv, size_t head_dim, size_t seq, size_t slices, float* out, float* out2) {
   if (!dev || !q || !k || !v || !out || seq == 0 || n_kv == 0 || n_heads % n_kv != 0) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   const int grp = (int)(n_heads / n_kv), hd = (int)head_dim;
   const FlashFn fn = flash_kernel(grp, hd, false, false), fnt = flash_kernel(grp, hd, false, true);
   const bool ticket_form = out2 != nullptr;
@@ -1941,7 +2003,9 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
                                           size_t n_kv, size_t head_dim, size_t pos0, size_t rows, size_t seq_cap, float* out) {
   if (!dev || !q || !k || !v || !out || rows == 0 || n_kv == 0 || n_heads % n_kv != 0 || seq_cap < pos0 + rows) return CRABML_HIP_BAD_INPUT;
   if (head_dim != 128 && head_dim != 64) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "debug_flash_attention_rows: head_dim 64 / 128");
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   if (raise_dyn_lds(dev, head_dim == 128 ? (const void*)k_attn_flash_rows<128> : (const void*)k_attn_flash_rows<64>,
                     (int)flash_rows_lds_bytes((int)head_dim)) != hipSuccess)
     CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "debug_flash_attention_rows: LDS");
@@ -1976,3 +2040,79 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
 }
 
 }  // extern "C"
+
+// ==============================================================================================================
+// The decode context as lazy.hip drives it: built from the buffers a recorded token of the reference's unchanged runner
+// names (its weight handles, its own KV caches), stepped one SEGMENT at a time while the host is still recording the
+// next one.  Everything below runs the same enqueue_segment as crabml_hip_llama_forward.
+// ==============================================================================================================
+namespace crabml_hip {
+
+int lazy_ctx_create(crabml_hip_device* dev, const LazyModel& m, crabml_hip_llama** out) {
+  *out = nullptr;
+  crabml_hip_llama_weights_t w{};
+  w.token_embed = m.token_embed;
+  w.rms_att_weight = m.rms_att.data();
+  w.rms_ffn_weight = m.rms_ffn.data();
+  w.wq = m.wq.data();
+  w.wk = m.wk.data();
+  w.wv = m.wv.data();
+  w.wo = m.wo.data();
+  w.ffn_gate_weight = m.gate.data();
+  w.ffn_down_weight = m.down.data();
+  w.ffn_up_weight = m.up.data();
+  w.rms_final_weight = m.rms_final;
+  w.output_weight = m.output;
+  const size_t L = m.cfg.n_layers;
+  if (m.rms_att.size() != L || m.rms_ffn.size() != L || m.wq.size() != L || m.wk.size() != L || m.wv.size() != L || m.wo.size() != L ||
+      m.gate.size() != L || m.down.size() != L || m.up.size() != L || m.kc.size() != L || m.vc.size() != L)
+    return CRABML_HIP_BAD_INPUT;
+  return llama_create_impl(dev, &m.cfg, &w, m.kc.data(), m.vc.data(), out);
+}
+
+void lazy_ctx_destroy(crabml_hip_llama* c) { (void)crabml_hip_llama_destroy(c); }
+
+int lazy_ctx_n_segments(const crabml_hip_llama* c) { return n_segments(c); }
+
+int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos) {
+  if (c->dev->dry) return 0;
+  CH_TRY(set_state(c, token, pos, 0));
+  c->attn_variant = c->attn_long_ok && pos + 1 >= c->attn_long_from ? 1 : 0;
+  c->kv_len = pos + 1;
+  return 0;
+}
+
+int lazy_ctx_segment(crabml_hip_llama* c, int seg, float* logits_out) {
+  if (c->dev->dry) return 0;
+  c->logits_ext = logits_out;
+  int rc = enqueue_segment(c, seg);
+  c->logits_ext = nullptr;
+  return rc;
+}
+
+int lazy_ctx_final_norm(crabml_hip_llama* c, float* dst) {
+  crabml_hip_device* dev = c->dev;
+  if (dev->dry) return 0;
+  const int dim = (int)c->cfg.embedding_dim;
+  const size_t lds = norm_lds_bytes(dim);
+  // the order of the step's own final norm: the reference's scan on a strict-order device, the fast split otherwise
+  const int half = dev->strict_order ? 0 : 1;
+  if (dim <= 4096)
+    k_norm_f32<4><<<1, 1024, lds, dev->stream>>>(c->x, nullptr, (const float*)c->rms_final->ptr, dim, c->cfg.rms_norm_eps, dst, half);
+  else
+    k_norm_f32<12><<<1, 1024, lds, dev->stream>>>(c->x, nullptr, (const float*)c->rms_final->ptr, dim, c->cfg.rms_norm_eps, dst, half);
+  CH_HIP(dev, hipGetLastError());
+  return 0;
+}
+
+// the fault word of the in-launch gathers travels with the sync the caller performs anyway: request it before, read it after
+int lazy_ctx_fault_request(crabml_hip_llama* c) {
+  crabml_hip_device* dev = c->dev;
+  if (dev->dry) return 0;
+  int* h = c->h_state + crabml_hip_llama::H_STATE_SLOTS * 4;  // pinned, behind the state ring
+  CH_HIP(dev, hipMemcpyAsync(h, c->state + 5, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+  return 0;
+}
+int lazy_ctx_fault_value(const crabml_hip_llama* c) { return c->dev->dry ? 0 : c->h_state[crabml_hip_llama::H_STATE_SLOTS * 4]; }
+
+}  // namespace crabml_hip

@@ -27,7 +27,11 @@ enum class RopeMode : uint32_t { Llama = 0, Neox = 1 };
 struct HipTensorDeviceOptions {
   int device_ordinal = 0;
   bool debug_named_tensor = false;
-  bool strict_order = false;  // CRABML_HIP_FLAG_STRICT_ORDER: bit-exact (slow) matmul_vec
+  bool strict_order = false;  // CRABML_HIP_FLAG_STRICT_ORDER: every sum in the reference's scalar order (bit-identical)
+  // how the Tensor calls reach the GPU (crabml_hip.h, ABI version 2): "lazy" = recorded, run at export / sync, a Llama decode
+  // token through the fused step (the default); "lazy-per-op" = recorded, always run op by op; "per-op" = one launch per
+  // call, immediately (ABI version 1); "dry" = the record-only test device (needs CRABML_HIP_TEST_HOOKS=1)
+  std::string mode = "lazy";
   void* stream = nullptr;
 };
 
@@ -38,6 +42,14 @@ class HipTensorDevice {
     c.device_ordinal = o.device_ordinal;
     c.stream = o.stream;
     c.flags = o.strict_order ? CRABML_HIP_FLAG_STRICT_ORDER : 0;
+    if (o.mode == "per-op")
+      c.flags |= CRABML_HIP_FLAG_PER_OP;
+    else if (o.mode == "lazy-per-op")
+      c.flags |= CRABML_HIP_FLAG_LAZY_NO_FUSION;
+    else if (o.mode == "dry" || o.mode == "dry-per-op")
+      c.flags |= CRABML_HIP_FLAG_DRY | (o.mode == "dry-per-op" ? CRABML_HIP_FLAG_LAZY_NO_FUSION : 0);
+    else if (o.mode != "lazy")
+      throw Error(ErrorKind::BadInput, "HipTensorDevice: unknown mode `" + o.mode + "`");
     int rc = crabml_hip_device_create(&c, &dev_);
     if (rc != 0 || !dev_)
       throw Error(ErrorKind::Unexpected,
@@ -52,6 +64,12 @@ class HipTensorDevice {
   crabml_hip_device_t* raw() const { return dev_; }
   void sync() { check(crabml_hip_device_sync(dev_)); }
   size_t mem_in_use() const { return crabml_hip_device_mem_in_use(dev_); }
+  // counters of the recorded-op queue (crabml_hip_debug.h)
+  std::vector<uint64_t> lazy_stats() const {
+    std::vector<uint64_t> v(8, 0);
+    check(crabml_hip_debug_lazy_stats(dev_, v.data(), v.size()));
+    return v;
+  }
 
   // maps a C-ABI status back onto crabml::error::Error
   void check(int rc) const {

@@ -63,16 +63,25 @@ PYBIND11_MODULE(_host, m) {
       .def("is_contiguous", &TensorStrider::is_contiguous);
 
   py::class_<HipTensorDevice, std::shared_ptr<HipTensorDevice>>(m, "HipTensorDevice")
-      .def(py::init([](int ordinal, bool debug_named_tensor, size_t stream, bool strict_order) {
+      .def(py::init([](int ordinal, bool debug_named_tensor, size_t stream, bool strict_order, const std::string& mode) {
              HipTensorDeviceOptions o;
              o.device_ordinal = ordinal;
              o.debug_named_tensor = debug_named_tensor;
              o.stream = reinterpret_cast<void*>(stream);
              o.strict_order = strict_order;
+             o.mode = mode;
              return std::make_shared<HipTensorDevice>(o);
            }),
            py::arg("device_ordinal") = 0, py::arg("debug_named_tensor") = false, py::arg("stream") = 0,
-           py::arg("strict_order") = false)
+           py::arg("strict_order") = false, py::arg("mode") = "lazy")
+      .def("lazy_stats",
+           [](HipTensorDevice& d) {
+             const std::vector<uint64_t> v = d.lazy_stats();
+             py::dict r;
+             const char* names[8] = {"recorded", "replayed", "fused_tokens", "fused_ops", "segments", "aborts", "learned", "deferred_bound"};
+             for (int i = 0; i < 8; i++) r[names[i]] = v[i];
+             return r;
+           })
       .def("sync", &HipTensorDevice::sync, py::call_guard<py::gil_scoped_release>())
       .def("mem_in_use", &HipTensorDevice::mem_in_use)
       .def("stream", [](HipTensorDevice& d) { return reinterpret_cast<size_t>(crabml_hip_device_stream(d.raw())); })

@@ -8,6 +8,7 @@
 #include <cmath>
 
 #include "kernels.hpp"
+#include "lazy.hpp"
 
 using namespace crabml_hip;
 
@@ -105,6 +106,15 @@ int pool_alloc(crabml_hip_device* dev, size_t bytes, void** out, size_t* cap) {
     }
   }
   void* p = nullptr;
+  if (dev->dry) {  // record-only test device: the pointer is never dereferenced
+    p = malloc(cls);
+    if (!p) return set_error(dev, CRABML_HIP_UNEXPECTED, "malloc(%zu) failed", cls);
+    std::lock_guard<std::mutex> g(dev->mu);
+    dev->bytes_reserved += cls;
+    *out = p;
+    *cap = cls;
+    return 0;
+  }
   (void)hipSetDevice(dev->ordinal);  // hipMalloc allocates on the calling thread's current device
   hipError_t e = hipMalloc(&p, cls);
   if (e != hipSuccess) {
@@ -142,6 +152,7 @@ int buf_new(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes
   b->dev = dev;
   b->dtype = dtype;
   b->n_elems = n_elems;
+  b->bytes = bytes;
   int rc = pool_alloc(dev, bytes, &b->ptr, &b->cap);
   if (rc != 0) {
     delete b;
@@ -149,24 +160,6 @@ int buf_new(crabml_hip_device* dev, uint32_t dtype, size_t n_elems, size_t bytes
   }
   *out = b;
   return 0;
-}
-
-// ---- host helpers ------------------------------------------------------------------------------------
-static uint16_t host_f2h(float f) {
-  _Float16 h = (_Float16)f;  // IEEE RNE
-  uint16_t u;
-  memcpy(&u, &h, 2);
-  return u;
-}
-static float host_h2f(uint16_t u) {
-  _Float16 h;
-  memcpy(&h, &u, 2);
-  return (float)h;
-}
-static float gelu_single(float x) {  // gelu.rs:19-22
-  const float COEF_A = 0.044715f;
-  const float S = (float)0.7978845608028654;
-  return 0.5f * x * (1.0f + tanhf(S * x * (1.0f + COEF_A * x * x)));
 }
 
 int prof_begin(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec, uint32_t dtype, uint32_t stage, double bytes) {
@@ -190,34 +183,8 @@ int prof_end(crabml_hip_device* dev, crabml_hip_device::ProfRec* rec) {
   return 0;
 }
 
-// quantize rhs of matmul_vec (cached per buffer version)
-static int ensure_act(crabml_hip_device* dev, const crabml_hip_buf* x_, size_t b, size_t k, uint32_t qt,
-                      const void** act) {
-  crabml_hip_buf* x = const_cast<crabml_hip_buf*>(x_);
-  if (qt == CRABML_HIP_F32) {
-    *act = x->ptr;  // CpuTensorBuf::quantize(F32) is a copy (buf/api.rs:197)
-    return 0;
-  }
-  ActLayout al = act_layout(qt, k);
-  size_t need = al.total * b;
-  if (x->qc.qtype == qt && x->qc.version == x->version && x->qc.n == b * k && x->qc.k == k && x->qc.ptr) {
-    *act = x->qc.ptr;
-    return 0;
-  }
-  if (x->qc.cap < need) {
-    if (x->qc.ptr) pool_free(dev, x->qc.ptr, x->qc.cap);
-    x->qc.ptr = nullptr;
-    x->qc.cap = 0;
-    CH_TRY(pool_alloc(dev, need, &x->qc.ptr, &x->qc.cap));
-  }
-  launch_quantize_act_rows(dev->stream, qt, (const float*)x->ptr, b, k, x->qc.ptr);  // one launch for the b rows
-  x->qc.qtype = qt;
-  x->qc.version = x->version;
-  x->qc.n = b * k;
-  x->qc.k = k;
-  *act = x->qc.ptr;
-  return 0;
-}
+// record the op (default) or run its launches right away (CRABML_HIP_FLAG_PER_OP)
+static int submit(crabml_hip_device* dev, LazyOp& op) { return dev->lazy ? lazy_record(dev, op) : lazy_exec(dev, op); }
 
 }  // namespace crabml_hip
 
@@ -234,23 +201,41 @@ int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip
   crabml_hip_device* dev = new crabml_hip_device();
   dev->ordinal = opts ? opts->device_ordinal : 0;
   dev->strict_order = opts && (opts->flags & CRABML_HIP_FLAG_STRICT_ORDER);
+  dev->lazy = !(opts && (opts->flags & CRABML_HIP_FLAG_PER_OP));
+  dev->fuse = dev->lazy && !(opts && (opts->flags & CRABML_HIP_FLAG_LAZY_NO_FUSION));
+  dev->lz = new LazyState();
+  const char* hooks = getenv("CRABML_HIP_TEST_HOOKS");
+  const bool hooks_on = hooks != nullptr && hooks[0] == '1';
+  if (opts && (opts->flags & CRABML_HIP_FLAG_DRY)) {
+    // test hook (tests/test_lazy_queue.py): a device object with NO HIP device behind it -- Tensor calls are recorded, matched
+    // against the decode template and counted; nothing is computed and export() hands out zeros.  Armed only together with
+    // CRABML_HIP_TEST_HOOKS=1, and it says so: this is not a CPU fallback, it cannot produce a single logit.
+    if (!hooks_on) {
+      lazy_destroy(dev);
+      delete dev;
+      return CRABML_HIP_UNEXPECTED;
+    }
+    fprintf(stderr, "crabml_hip: TEST HOOK active: record-only device (no HIP device, nothing is computed)\n");
+    dev->dry = true;
+    dev->own_stream = false;
+    *out = dev;
+    return 0;
+  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0 || dev->ordinal >= n) {
+  auto fail = [&]() {
+    lazy_destroy(dev);
     delete dev;
     return CRABML_HIP_UNEXPECTED;  // no usable MI355X: the backend fails loudly, there is no CPU fallback
-  }
-  if (hipSetDevice(dev->ordinal) != hipSuccess) {
-    delete dev;
-    return CRABML_HIP_UNEXPECTED;
-  }
+  };
+  if (e != hipSuccess || n <= 0 || dev->ordinal >= n) return fail();
+  if (hipSetDevice(dev->ordinal) != hipSuccess) return fail();
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev->ordinal) == hipSuccess) dev->n_cu = prop.multiProcessorCount;
   // test hook (tests/test_hip_fault_paths.py): claim this many CUs whatever the device reports, so that a CU-masked process
   // (HSA_CU_MASK) loses the co-residency the in-launch hand-offs rely on -- their bounded polls must raise, not hang
   // Armed only when CRABML_HIP_TEST_HOOKS=1 is set as well (a stray CRABML_HIP_ASSUME_CUS alone is ignored), and it says so.
-  const char* hooks = getenv("CRABML_HIP_TEST_HOOKS");
-  if (hooks != nullptr && hooks[0] == '1') {
+  if (hooks_on) {
     if (const char* e = getenv("CRABML_HIP_ASSUME_CUS")) {
       const int v = atoi(e);
       if (v > 0 && v <= 1024) {
@@ -263,30 +248,32 @@ int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip
     dev->stream = (hipStream_t)opts->stream;
     dev->own_stream = false;
   } else {
-    if (hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking) != hipSuccess) {
-      delete dev;
-      return CRABML_HIP_UNEXPECTED;
-    }
+    if (hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking) != hipSuccess) return fail();
     dev->own_stream = true;
   }
   // exp table: f16 bits -> f16(exp(f32(x)))   (cpu_device.rs:108-115)
   std::vector<uint16_t> tab(65536);
   for (uint32_t x = 0; x < 65536; x++) tab[x] = host_f2h(expf(host_h2f((uint16_t)x)));
   if (hipMalloc((void**)&dev->exp_table, 65536 * 2) != hipSuccess ||
-      hipMemcpy(dev->exp_table, tab.data(), 65536 * 2, hipMemcpyHostToDevice) != hipSuccess) {
-    delete dev;
-    return CRABML_HIP_UNEXPECTED;
-  }
+      hipMemcpy(dev->exp_table, tab.data(), 65536 * 2, hipMemcpyHostToDevice) != hipSuccess)
+    return fail();
   *out = dev;
   return 0;
 }
 
 int crabml_hip_device_destroy(crabml_hip_device_t* dev) {
   if (!dev) return 0;
-  (void)hipSetDevice(dev->ordinal);
-  (void)hipStreamSynchronize(dev->stream);
+  if (!dev->dry) (void)hipSetDevice(dev->ordinal);
+  (void)lazy_flush(dev);
+  if (!dev->dry) (void)hipStreamSynchronize(dev->stream);
+  lazy_destroy(dev);  // the decode context the queue built, its retained buffers
   for (auto& kv : dev->pool)
-    for (void* p : kv.second) (void)hipFree(p);
+    for (void* p : kv.second) {
+      if (dev->dry)
+        free(p);
+      else
+        (void)hipFree(p);
+    }
   dev->pool.clear();
   if (dev->exp_table) (void)hipFree(dev->exp_table);
   if (dev->gelu_table) (void)hipFree(dev->gelu_table);
@@ -297,9 +284,12 @@ int crabml_hip_device_destroy(crabml_hip_device_t* dev) {
 
 int crabml_hip_device_sync(crabml_hip_device_t* dev) {
   if (!dev) return CRABML_HIP_BAD_INPUT;
+  if (dev->dry) return lazy_flush(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
+  CH_TRY(lazy_fault_request(dev));
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
-  return 0;
+  return lazy_fault_check(dev);
 }
 
 size_t crabml_hip_last_error(crabml_hip_device_t* dev, char* buf, size_t cap) {
@@ -340,9 +330,17 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
   size_t expect = n_elems / be * bb;
   if (nbytes < expect)  // GGUF slices may carry trailing alignment padding (gguf.rs:743-748): >= is accepted
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "data length %zu too small for shape (need %zu)", nbytes, expect);
-  CH_USE(dev);
   WeightLayout wl = weight_layout(t, n_elems);
   crabml_hip_buf* b = nullptr;
+  if (dev->dry) {  // record-only device: the handle and its geometry, no bytes
+    CH_TRY(buf_new(dev, t, n_elems, 256, &b));
+    b->wl = wl;
+    b->m = m;
+    b->k = k;
+    *out = b;
+    return 0;
+  }
+  CH_USE(dev);
   CH_TRY(buf_new(dev, t, n_elems, wl.total, &b));
   b->wl = wl;
   b->m = m;
@@ -433,16 +431,17 @@ int crabml_hip_buf_alloc(crabml_hip_device_t* dev, size_t n_elems, uint32_t t, c
   if (!dev || !out) return CRABML_HIP_BAD_INPUT;
   *out = nullptr;
   if (t != CRABML_HIP_F32 && t != CRABML_HIP_F16) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 is supported");
-  CH_USE(dev);
   size_t bytes = n_elems * (t == CRABML_HIP_F32 ? 4 : 2);
-  crabml_hip_buf* b = nullptr;
-  CH_TRY(buf_new(dev, t, n_elems, bytes, &b));
-  b->wl = weight_layout(t, n_elems);
-  if (t == CRABML_HIP_F32 && bytes) {  // vec![0.0; n] (cpu_tensor.rs:146-149); F16 contents are unspecified
-    hipError_t e = hipMemsetAsync(b->ptr, 0, bytes, dev->stream);
-    if (e != hipSuccess) {
+  // the memory is bound -- and, F32, zero-filled: vec![0.0; n] (cpu_tensor.rs:146-149); F16 contents are unspecified -- when an
+  // executed op first touches the buffer (a destination a fused launch makes redundant never costs a memset)
+  crabml_hip_buf* b = buf_new_unbound(dev, t, n_elems, bytes);
+  b->zero_init = t == CRABML_HIP_F32;
+  if (!dev->lazy) {
+    if (!dev->dry) CH_USE(dev);
+    int rc = ensure_mem(dev, b);
+    if (rc != 0) {
       crabml_hip_buf_release(b);
-      return hip_fail(dev, e, "hipMemsetAsync", __FILE__, __LINE__);
+      return rc;
     }
   }
   *out = b;
@@ -458,7 +457,7 @@ int crabml_hip_buf_retain(crabml_hip_buf_t* b) {
 int crabml_hip_buf_release(crabml_hip_buf_t* b) {
   if (!b) return 0;
   if (b->refcnt.fetch_sub(1) == 1) {
-    pool_free(b->dev, b->ptr, b->cap);
+    if (b->ptr) pool_free(b->dev, b->ptr, b->cap);
     if (b->qc.ptr) pool_free(b->dev, b->qc.ptr, b->qc.cap);
     delete b;
   }
@@ -469,45 +468,77 @@ uint32_t crabml_hip_buf_dtype(const crabml_hip_buf_t* b) { return b ? b->dtype :
 size_t crabml_hip_buf_len(const crabml_hip_buf_t* b) { return b ? b->n_elems : 0; }
 
 // ---- data movement -----------------------------------------------------------------------------------
+// the host looks at a buffer: run what was recorded, bind the buffer (a handle nothing has written yet reads as Tensor::alloc
+// left it)
+static int observe(crabml_hip_device* dev, const crabml_hip_buf* b) {
+  CH_FLUSH(dev);
+  lazy_use(dev, b);
+  return ensure_mem(dev, const_cast<crabml_hip_buf*>(b));
+}
+
 int crabml_hip_export(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, float* dst, size_t n) {
   if (!dev || !b || (!dst && n)) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
   if (b->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: not f32, but got %u", b->dtype);
   if (n > b->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: %zu elements requested, buffer holds %zu", n, b->n_elems);
+  if (dev->dry) {
+    CH_TRY(observe(dev, b));
+    if (n) memset(dst, 0, n * 4);
+    return 0;
+  }
+  CH_USE(dev);
+  CH_TRY(observe(dev, b));
   if (n) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, n * 4, hipMemcpyDeviceToHost, dev->stream));
+  CH_TRY(lazy_fault_request(dev));
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
-  return 0;
+  return lazy_fault_check(dev);
 }
 
 int crabml_hip_export_raw(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, void* dst, size_t nbytes) {
   if (!dev || !b || (!dst && nbytes)) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
   if (b->dtype != CRABML_HIP_F32 && b->dtype != CRABML_HIP_F16)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export_raw: only f32/f16 buffers");
   size_t have = b->n_elems * (b->dtype == CRABML_HIP_F32 ? 4 : 2);
   if (nbytes > have) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export_raw: %zu bytes requested, buffer holds %zu", nbytes, have);
+  if (dev->dry) {
+    CH_TRY(observe(dev, b));
+    if (nbytes) memset(dst, 0, nbytes);
+    return 0;
+  }
+  CH_USE(dev);
+  CH_TRY(observe(dev, b));
   if (nbytes) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, nbytes, hipMemcpyDeviceToHost, dev->stream));
+  CH_TRY(lazy_fault_request(dev));
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  return lazy_fault_check(dev);
+}
+
+#define CH_USE_LIVE(dev)          \
+  do {                            \
+    if (!(dev)->dry) CH_USE(dev); \
+  } while (0)
+
+// hands a recorded (or, per-op mode, executed) op's fresh output to the caller
+static int submit_out(crabml_hip_device* dev, LazyOp& op, crabml_hip_buf_t** out) {
+  int rc = submit(dev, op);
+  if (rc != 0) {
+    crabml_hip_buf_release(op.out);
+    return rc;
+  }
+  *out = op.out;
   return 0;
 }
 
 int crabml_hip_dup(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, crabml_hip_buf_t** out) {
   if (!dev || !src || !out) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   *out = nullptr;
   if (src->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "dup: not f32, but got %u", src->dtype);
-  crabml_hip_buf* b = nullptr;
-  CH_TRY(buf_new(dev, CRABML_HIP_F32, src->n_elems, src->n_elems * 4, &b));
-  b->wl = weight_layout(CRABML_HIP_F32, src->n_elems);
-  if (src->n_elems) {
-    hipError_t e = hipMemcpyAsync(b->ptr, src->ptr, src->n_elems * 4, hipMemcpyDeviceToDevice, dev->stream);
-    if (e != hipSuccess) {
-      crabml_hip_buf_release(b);
-      return hip_fail(dev, e, "dup", __FILE__, __LINE__);
-    }
-  }
-  *out = b;
-  return 0;
+  lazy_use(dev, src);
+  LazyOp op;
+  op.kind = LZ_DUP;
+  op.a = const_cast<crabml_hip_buf*>(src);
+  op.out = buf_new_unbound(dev, CRABML_HIP_F32, src->n_elems, src->n_elems * 4);
+  return submit_out(dev, op, out);
 }
 
 static void pad3(const size_t* v, int ndim, size_t fill, size_t out[3]) {
@@ -519,12 +550,14 @@ static void pad3(const size_t* v, int ndim, size_t fill, size_t out[3]) {
 int crabml_hip_contiguous(crabml_hip_device_t* dev, const crabml_hip_buf_t* src, const size_t* shape,
                           const size_t* strides, int ndim, crabml_hip_buf_t** out) {
   if (!dev || !src || !out || !shape || !strides) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   *out = nullptr;
   if (ndim != 2 && ndim != 3) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "contiguous: only 2-d / 3-d tensors");
   if (src->dtype != CRABML_HIP_F32 && src->dtype != CRABML_HIP_F16)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "contiguous: only f32/f16");
-  size_t sh[3], st[3];
+  LazyOp op;
+  op.kind = LZ_CONTIGUOUS;
+  size_t *sh = op.s, *st = op.s + 3;
   pad3(shape, ndim, 1, sh);
   pad3(strides, ndim, 0, st);
   size_t n = sh[0] * sh[1] * sh[2];
@@ -533,19 +566,17 @@ int crabml_hip_contiguous(crabml_hip_device_t* dev, const crabml_hip_buf_t* src,
     if (sh[i]) max_off += (sh[i] - 1) * st[i];
   if (n && max_off >= src->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "contiguous: view exceeds the buffer");
   int es = src->dtype == CRABML_HIP_F32 ? 4 : 2;
-  crabml_hip_buf* b = nullptr;
-  CH_TRY(buf_new(dev, src->dtype, n, n * es, &b));
-  b->wl = weight_layout(src->dtype, n);
-  launch_contiguous(dev->stream, src->ptr, b->ptr, es, sh, st);
-  *out = b;
-  return 0;
+  lazy_use(dev, src);
+  op.a = const_cast<crabml_hip_buf*>(src);
+  op.out = buf_new_unbound(dev, src->dtype, n, n * es);
+  return submit_out(dev, op, out);
 }
 
 int crabml_hip_concatenate(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, const size_t* dshape,
                            const size_t* dstrides, const crabml_hip_buf_t* rhs, const size_t* rshape,
                            const size_t* rstrides, int ndim, int axis) {
   if (!dev || !dst || !rhs || !dshape || !dstrides || !rshape || !rstrides) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   if (ndim < 1 || ndim > 3 || axis < 0 || axis >= ndim) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "concatenate: bad ndim/axis");
   if (dst->dtype != CRABML_HIP_F32 && dst->dtype != CRABML_HIP_F16)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 is supported on concatenate");
@@ -556,7 +587,9 @@ int crabml_hip_concatenate(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, cons
   for (int i = 0; i < ndim; i++)
     if (i != axis && dshape[i] != rshape[i])
       CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "shape mismatch on concatenate");
-  size_t sh[3], ds[3], ss[3];
+  LazyOp op;
+  op.kind = LZ_CONCAT;
+  size_t *sh = op.s, *ds = op.s + 3, *ss = op.s + 6;
   pad3(rshape, ndim, 1, sh);
   pad3(dstrides, ndim, 0, ds);
   pad3(rstrides, ndim, 0, ss);
@@ -571,16 +604,20 @@ int crabml_hip_concatenate(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, cons
     if (dmax >= dst->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "concatenate: destination is full");
     if (smax >= rhs->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "concatenate: rhs view exceeds its buffer");
   }
-  launch_concatenate(dev->stream, dst->ptr, dst->dtype == CRABML_HIP_F16, off, ds, rhs->ptr,
-                     rhs->dtype == CRABML_HIP_F16, sh, ss);
-  touch(dst);
-  return 0;
+  op.s[9] = off;
+  op.s[10] = (size_t)(axis + 3 - ndim);
+  op.s[11] = dshape[axis];
+  lazy_use(dev, dst);
+  lazy_use(dev, rhs);
+  op.a = dst;
+  op.b = const_cast<crabml_hip_buf*>(rhs);
+  return submit(dev, op);
 }
 
 int crabml_hip_copy_rows_from(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, const crabml_hip_buf_t* src, size_t cols,
                               const size_t* rows, size_t n_rows) {
   if (!dev || !dst || !src || (!rows && n_rows)) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   if (dst->dtype != CRABML_HIP_F32 && dst->dtype != CRABML_HIP_F16)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "only f32/f16 can be copied to");
   size_t be = block_elems(src->dtype);
@@ -591,8 +628,26 @@ int crabml_hip_copy_rows_from(crabml_hip_device_t* dev, crabml_hip_buf_t* dst, c
     if (start + cols > src->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "copy_rows_from: row %zu out of range", rows[i]);
     if (be > 1 && start % be != 0)  // QuantBuf*::dequantize asserts start % block == 0
       CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "copy_rows_from: row start %zu is not block aligned", start);
+  }
+  lazy_use(dev, dst);
+  lazy_use(dev, src);
+  if (n_rows == 1) {  // the embedding lookup / the last row of a batch (llama2.rs:222-223, 192-197)
+    LazyOp op;
+    op.kind = LZ_COPY_ROW;
+    op.a = dst;
+    op.b = const_cast<crabml_hip_buf*>(src);
+    op.s[0] = cols;
+    op.s[1] = rows[0];
+    return submit(dev, op);
+  }
+  // several rows (a prompt batch, dequantize()): run what is queued, then one launch per row right away
+  CH_FLUSH(dev);
+  CH_TRY(ensure_mem(dev, dst));
+  CH_TRY(ensure_mem(dev, const_cast<crabml_hip_buf*>(src)));
+  if (dev->dry) return 0;
+  for (size_t i = 0; i < n_rows; i++) {
     char* d = (char*)dst->ptr + i * cols * (dst->dtype == CRABML_HIP_F32 ? 4 : 2);
-    launch_dequant_row(dev->stream, src, start, cols, d, dst->dtype == CRABML_HIP_F16);
+    launch_dequant_row(dev->stream, src, rows[i] * cols, cols, d, dst->dtype == CRABML_HIP_F16);
   }
   touch(dst);
   return 0;
@@ -608,7 +663,7 @@ static int need_f32(crabml_hip_device* dev, const crabml_hip_buf* b, size_t n, c
 int crabml_hip_rope_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n_batch, size_t bi_stride,
                             size_t head_dim, uint32_t mode, size_t pos, size_t rope_dims) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   CH_TRY(need_f32(dev, x, n_batch * bi_stride, "rope"));
   if (head_dim == 0 || rope_dims > head_dim || (mode != 0 && mode != 1))
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rope: bad head_dim/rope_dims/mode");
@@ -616,87 +671,77 @@ int crabml_hip_rope_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_
   if (npairs > 256) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "rope: more than 256 rotary pairs");
   if (mode == 0 && (rope_dims & 1) && rope_dims + 1 > head_dim)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rope: odd rope_dims reaches past the head");
-  size_t n_heads = bi_stride / head_dim;
-  for (size_t bi = 0; bi < n_batch; bi++) {
-    RopeTable tab;
-    size_t p = pos + bi;  // rope.rs:35-36
-    if (mode == 0) {      // rope.rs:47-63: theta is an iterated f32 product, base 10000 hard-coded
-      float theta_scale = powf(10000.0f, -2.0f / (float)head_dim);
-      float theta = (float)p;
-      for (size_t i = 0; i < npairs; i++) {
-        tab.cs[2 * i] = cosf(theta);
-        tab.cs[2 * i + 1] = sinf(theta);
-        theta *= theta_scale;
-      }
-    } else {  // rope.rs:65-80
-      for (size_t i = 0; i < npairs; i++) {
-        float fe = 2.0f * (float)i / (float)head_dim;
-        float timescale = powf(10000.0f, fe);
-        float theta = (float)p / timescale;
-        tab.cs[2 * i] = cosf(theta);
-        tab.cs[2 * i + 1] = sinf(theta);
-      }
-    }
-    launch_rope(dev->stream, (float*)x->ptr + bi * bi_stride, n_heads, head_dim, (int)mode, rope_dims, tab);
-  }
-  touch(x);
-  return 0;
+  lazy_use(dev, x);
+  LazyOp op;
+  op.kind = LZ_ROPE;
+  op.a = x;
+  op.s[0] = n_batch;
+  op.s[1] = bi_stride;
+  op.s[2] = head_dim;
+  op.s[3] = mode;
+  op.s[4] = pos;
+  op.s[5] = rope_dims;
+  return submit(dev, op);
 }
 
 int crabml_hip_rms_norm_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols, float eps) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   CH_TRY(need_f32(dev, x, rows * cols, "rms_norm"));
   if (cols % 32 != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "rms_norm: row length %zu is not a multiple of 32", cols);
   if (cols / 32 * 4 > 64 * 1024) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "rms_norm: row too long");
-  launch_rms_norm(dev->stream, (float*)x->ptr, rows, cols, eps);
-  touch(x);
-  return 0;
+  lazy_use(dev, x);
+  LazyOp op;
+  op.kind = LZ_RMS_NORM;
+  op.a = x;
+  op.s[0] = rows;
+  op.s[1] = cols;
+  op.f = eps;
+  return submit(dev, op);
 }
 
 int crabml_hip_softmax_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t rows, size_t cols) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   CH_TRY(need_f32(dev, x, rows * cols, "softmax"));
-  launch_softmax(dev->stream, (float*)x->ptr, rows, cols, dev->exp_table);
-  touch(x);
-  return 0;
+  lazy_use(dev, x);
+  LazyOp op;
+  op.kind = LZ_SOFTMAX;
+  op.a = x;
+  op.s[0] = rows;
+  op.s[1] = cols;
+  return submit(dev, op);
 }
 
-int crabml_hip_silu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) {
+static int unary(crabml_hip_device* dev, uint8_t kind, crabml_hip_buf* x, size_t n, const char* name) {
   if (!dev || !x) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
-  CH_TRY(need_f32(dev, x, n, "silu"));
-  launch_silu(dev->stream, (float*)x->ptr, n, dev->exp_table);
-  touch(x);
-  return 0;
+  CH_USE_LIVE(dev);
+  CH_TRY(need_f32(dev, x, n, name));
+  lazy_use(dev, x);
+  LazyOp op;
+  op.kind = kind;
+  op.a = x;
+  op.s[0] = n;
+  return submit(dev, op);
 }
+int crabml_hip_silu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) { return unary(dev, LZ_SILU, x, n, "silu"); }
+int crabml_hip_gelu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) { return unary(dev, LZ_GELU, x, n, "gelu"); }
 
-int crabml_hip_gelu_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* x, size_t n) {
-  if (!dev || !x) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
-  CH_TRY(need_f32(dev, x, n, "gelu"));
-  if (!dev->gelu_table) {  // OnceLock<Vec<f16>> (cpu_device.rs:117-124)
-    std::vector<uint16_t> tab(65536);
-    for (uint32_t i = 0; i < 65536; i++) tab[i] = host_f2h(gelu_single(host_h2f((uint16_t)i)));
-    CH_HIP(dev, hipMalloc((void**)&dev->gelu_table, 65536 * 2));
-    CH_HIP(dev, hipMemcpyAsync(dev->gelu_table, tab.data(), 65536 * 2, hipMemcpyHostToDevice, dev->stream));
-    CH_HIP(dev, hipStreamSynchronize(dev->stream));
-  }
-  launch_gelu(dev->stream, (float*)x->ptr, n, dev->gelu_table);
-  touch(x);
-  return 0;
-}
-
-static int binary(crabml_hip_device* dev, int op, crabml_hip_buf* a, size_t na, const crabml_hip_buf* b, size_t nb) {
+static int binary(crabml_hip_device* dev, int op_, crabml_hip_buf* a, size_t na, const crabml_hip_buf* b, size_t nb) {
   if (!dev || !a || !b) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
-  CH_TRY(need_f32(dev, a, na, op ? "mul" : "add"));
-  CH_TRY(need_f32(dev, b, nb, op ? "mul" : "add"));
-  if (nb == 0 || na % nb != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "%s: lhs len %zu is not a multiple of rhs len %zu", op ? "mul" : "add", na, nb);
-  launch_binary(dev->stream, op, (float*)a->ptr, na, (const float*)b->ptr, nb);
-  touch(a);
-  return 0;
+  CH_USE_LIVE(dev);
+  CH_TRY(need_f32(dev, a, na, op_ ? "mul" : "add"));
+  CH_TRY(need_f32(dev, b, nb, op_ ? "mul" : "add"));
+  if (nb == 0 || na % nb != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "%s: lhs len %zu is not a multiple of rhs len %zu", op_ ? "mul" : "add", na, nb);
+  lazy_use(dev, a);
+  lazy_use(dev, b);
+  LazyOp op;
+  op.kind = op_ ? LZ_MUL : LZ_ADD;
+  op.a = a;
+  op.b = const_cast<crabml_hip_buf*>(b);
+  op.s[0] = na;
+  op.s[1] = nb;
+  return submit(dev, op);
 }
 int crabml_hip_mul_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, const crabml_hip_buf_t* b, size_t nb) {
   return binary(dev, 1, a, na, b, nb);
@@ -706,17 +751,21 @@ int crabml_hip_add_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t
 }
 int crabml_hip_scale_inplace(crabml_hip_device_t* dev, crabml_hip_buf_t* a, size_t na, float f) {
   if (!dev || !a) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   CH_TRY(need_f32(dev, a, na, "scale"));
-  launch_scale(dev->stream, (float*)a->ptr, na, f);
-  touch(a);
-  return 0;
+  lazy_use(dev, a);
+  LazyOp op;
+  op.kind = LZ_SCALE;
+  op.a = a;
+  op.s[0] = na;
+  op.f = f;
+  return submit(dev, op);
 }
 
 int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k,
                           const crabml_hip_buf_t* x, size_t b, crabml_hip_buf_t** out) {
   if (!dev || !w || !x || !out) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   *out = nullptr;
   uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (qt == 0xffffffffu) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
@@ -727,39 +776,24 @@ int crabml_hip_matmul_vec(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, s
   if (k % block_elems(qt) != 0 || k % block_elems(w->dtype) != 0)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: k=%zu is not a multiple of the block size", k);
   if (m > 0x7fffffff || k > 0x7fffffff) CH_BAIL(dev, CRABML_HIP_NOT_IMPLEMENTED, "matmul_vec: dimension too large");
-  const void* act = nullptr;
-  CH_TRY(ensure_act(dev, x, b, k, qt, &act));
-  crabml_hip_buf* o = nullptr;
-  CH_TRY(buf_new(dev, CRABML_HIP_F32, b * m, b * m * 4, &o));
-  o->wl = weight_layout(CRABML_HIP_F32, b * m);
-  crabml_hip_device::ProfRec rec{};
-  const bool prof = dev->prof_on && !dev->strict_order;  // the strict-order kernels carry no events: take none
-  if (prof)
-    CH_TRY(prof_begin(dev, &rec, w->dtype, 0,
-                      (double)b * ((double)m * (double)(k / block_elems(w->dtype)) * (double)block_bytes(w->dtype) + 4.0 * k + 4.0 * m)));
-  int rc = dev->strict_order ? launch_gemv_strict(dev, w, m, k, act, b, (float*)o->ptr)
-                             : launch_gemv(dev, w, m, k, act, b, (float*)o->ptr, prof ? &rec : nullptr);
-  if (prof) {
-    if (rc == 0) {
-      CH_TRY(prof_end(dev, &rec));
-    } else {  // nothing was recorded: hand the pair back
-      dev->prof_free_events.push_back(rec.e0);
-      dev->prof_free_events.push_back(rec.e1);
-    }
-  }
-  if (rc != 0) {
-    crabml_hip_buf_release(o);
-    return rc;
-  }
-  *out = o;
-  return 0;
+  lazy_use(dev, w);
+  lazy_use(dev, x);
+  LazyOp op;
+  op.kind = LZ_MATMUL_VEC;
+  op.a = const_cast<crabml_hip_buf*>(w);
+  op.b = const_cast<crabml_hip_buf*>(x);
+  op.s[0] = m;
+  op.s[1] = k;
+  op.s[2] = b;
+  op.out = buf_new_unbound(dev, CRABML_HIP_F32, b * m, b * m * 4);
+  return submit_out(dev, op, out);
 }
 
 int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a, size_t ba, size_t m, size_t k,
                             const crabml_hip_buf_t* b, size_t bb, size_t n, size_t sb0, size_t sb1, size_t sb2,
                             crabml_hip_buf_t** out) {
   if (!dev || !a || !b || !out) return CRABML_HIP_BAD_INPUT;
-  CH_USE(dev);
+  CH_USE_LIVE(dev);
   *out = nullptr;
   CH_TRY(need_f32(dev, a, ba * m * k, "batch_matmul lhs"));
   if (b->dtype != CRABML_HIP_F32 && b->dtype != CRABML_HIP_F16)
@@ -770,20 +804,31 @@ int crabml_hip_batch_matmul(crabml_hip_device_t* dev, const crabml_hip_buf_t* a,
     size_t max_off = (bb - 1) * sb0 + (k - 1) * sb1 + (n - 1) * sb2;
     if (max_off >= b->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "batch_matmul: rhs view exceeds its buffer");
   }
-  crabml_hip_buf* o = nullptr;
-  CH_TRY(buf_new(dev, CRABML_HIP_F32, ba * m * n, ba * m * n * 4, &o));
-  o->wl = weight_layout(CRABML_HIP_F32, ba * m * n);
-  launch_batch_matmul(dev->stream, (const float*)a->ptr, ba, m, k, b->ptr, b->dtype == CRABML_HIP_F16, bb, n, sb0, sb1,
-                      sb2, (float*)o->ptr);
-  *out = o;
-  return 0;
+  lazy_use(dev, a);
+  lazy_use(dev, b);
+  LazyOp op;
+  op.kind = LZ_BATCH_MATMUL;
+  op.a = const_cast<crabml_hip_buf*>(a);
+  op.b = const_cast<crabml_hip_buf*>(b);
+  op.s[0] = ba;
+  op.s[1] = m;
+  op.s[2] = k;
+  op.s[3] = bb;
+  op.s[4] = n;
+  op.s[5] = sb0;
+  op.s[6] = sb1;
+  op.s[7] = sb2;
+  op.out = buf_new_unbound(dev, CRABML_HIP_F32, ba * m * n, ba * m * n * 4);
+  return submit_out(dev, op, out);
 }
 
 // ---- parity / debug hooks ----------------------------------------------------------------------------
 int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* x, size_t n, uint32_t qt, void* dst,
                               size_t dst_bytes) {
   if (!dev || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_TRY(observe(dev, x));
   CH_TRY(need_f32(dev, x, n, "debug_quantize"));
   if (qt != CRABML_HIP_Q8_0 && qt != CRABML_HIP_Q8_1 && qt != CRABML_HIP_Q8_K)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_quantize: unsupported target %u", qt);
@@ -822,7 +867,10 @@ int crabml_hip_debug_quantize(crabml_hip_device_t* dev, const crabml_hip_buf_t* 
 int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
                                 const crabml_hip_buf_t* x, int32_t* dst) {
   if (!dev || !w || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_TRY(observe(dev, w));
+  CH_TRY(observe(dev, x));
   uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (block_elems(w->dtype) <= 1 || qt == 0xffffffffu)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_block_dots: quantized weights only");
@@ -846,7 +894,10 @@ int crabml_hip_debug_block_dots(crabml_hip_device_t* dev, const crabml_hip_buf_t
 int crabml_hip_debug_superblock_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, size_t row,
                                      const crabml_hip_buf_t* x, int32_t variant, int32_t* dst, float* value) {
   if (!dev || !w || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_TRY(observe(dev, w));
+  CH_TRY(observe(dev, x));
   if (w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_superblock_ints: Q4_K / Q6_K weights only");
   if (row >= m || w->k != k || m * k > w->n_elems || k % 256 != 0)
@@ -888,7 +939,10 @@ int crabml_hip_debug_superblock_ints(crabml_hip_device_t* dev, const crabml_hip_
 int crabml_hip_debug_gemm_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t* w, size_t m, size_t k, const crabml_hip_buf_t* x,
                                size_t b, int32_t* dst, float* out) {
   if (!dev || !w || !x || !dst) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_TRY(observe(dev, w));
+  CH_TRY(observe(dev, x));
   if (w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K)
     CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_gemm_ints: Q4_K / Q6_K weights only");
   if (b < 16 || w->k != k || m * k > w->n_elems || k % 256 != 0) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "debug_gemm_ints: needs b >= 16 rows and a matching shape");
@@ -918,7 +972,9 @@ int crabml_hip_debug_gemm_ints(crabml_hip_device_t* dev, const crabml_hip_buf_t*
 
 int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_t reps, double* gbytes_per_s) {
   if (!dev || !gbytes_per_s || reps < 1) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   bytes = bytes / 4096 * 4096;
   if (bytes < ((size_t)1 << 20)) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "debug_read_ceiling: at least 1 MiB");
   void *buf = nullptr, *sink = nullptr;
@@ -959,7 +1015,9 @@ int crabml_hip_prof_enable(crabml_hip_device_t* dev, int on) {
 
 int crabml_hip_prof_read_launches(crabml_hip_device_t* dev, float* ms_out, size_t cap, size_t* n) {
   if (!dev || !n || (!ms_out && cap)) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
   size_t i = 0;
   for (auto& r : dev->prof_recs) {
@@ -976,7 +1034,9 @@ int crabml_hip_prof_read_launches(crabml_hip_device_t* dev, float* ms_out, size_
 
 int crabml_hip_prof_read(crabml_hip_device_t* dev, crabml_hip_prof_entry_t* out, size_t cap, size_t* n) {
   if (!dev || !n || (!out && cap)) return CRABML_HIP_BAD_INPUT;
+  CH_LIVE(dev);
   CH_USE(dev);
+  CH_FLUSH(dev);
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
   std::map<uint64_t, crabml_hip_prof_entry_t> agg;
   for (auto& r : dev->prof_recs) {

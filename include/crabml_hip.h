@@ -15,9 +15,17 @@
  *    host side of the boundary: ops take explicit shapes / strides (in ELEMENTS).
  *  - A `crabml_hip_buf_t` is a reference-counted device allocation + its GGML dtype; cloning a
  *    Rust tensor = retain, dropping = release; views share one buf (with_strider is free).
- *  - All work is enqueued on the device's HIP stream and returns immediately; only
- *    crabml_hip_export / crabml_hip_device_sync / debug snapshots block the host (the same
- *    contract as the wgpu backend: crabml-wgpu/src/wgpu_tensor.rs:293-333).
+ *  - Nothing blocks the host but crabml_hip_export / crabml_hip_device_sync / debug snapshots (the same
+ *    contract as the wgpu backend: crabml-wgpu/src/wgpu_tensor.rs:293-333), and those are also the only
+ *    points where the host can observe data.  Since ABI version 2 the Tensor calls below are therefore
+ *    RECORDED (validated, queued, a result handle returned at once) and run when such a point is reached --
+ *    op by op, or, when the queue holds the op sequence Llama2Runner::forward issues for one token of a
+ *    Llama model (crabml-llama2/src/llama2.rs:184-281, 527-638), as the fused decode step over the
+ *    runner's own weight and KV-cache buffers: five launches per layer instead of ~31, enqueued segment by
+ *    segment while the host is still recording the next layer (crabml_amd/csrc/lazy.hpp).  Results are
+ *    those of the per-op launches bit for bit on a strict-order device; argument errors are still
+ *    reported by the call that makes them, device errors by the next export / sync.
+ *    A device is driven from one host thread at a time.
  *  - GGML type ids are the #[repr(u32)] values of crabml-core/src/gguf.rs:86-108.
  */
 #ifndef CRABML_HIP_H
@@ -30,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CRABML_HIP_ABI_VERSION 1
+#define CRABML_HIP_ABI_VERSION 2 /* 2: Tensor calls are recorded and run at export / sync (below); attn_long_from defaults to 96 */
 
 /* crabml-core/src/error.rs:5-33 */
 typedef enum crabml_hip_status {
@@ -80,6 +88,9 @@ typedef struct crabml_hip_buf crabml_hip_buf_t;
  * (block terms parked in LDS, one lane per row adds them in order): 677 tok/s on the Llama-3-8B shape
  * against 745 for the default.  Default (0) = the fast wave-parallel kernels (re-associated sums). */
 #define CRABML_HIP_FLAG_STRICT_ORDER 1
+/* every Tensor call launches its kernel(s) immediately instead of being recorded (ABI version 1 behaviour: one launch
+ * per call, ~31 per layer; the parity tests of the individual ops and the A/B of the queue use it) */
+#define CRABML_HIP_FLAG_PER_OP 2
 typedef struct crabml_hip_device_options {
   int32_t device_ordinal; /* HIP device index (one process per GPU: LOCAL_RANK) */
   void* stream;           /* optional caller-owned hipStream_t; NULL = the library creates one */

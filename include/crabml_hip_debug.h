@@ -14,6 +14,16 @@
 extern "C" {
 #endif
 
+/* ---- device flags of the tests (crabml_hip_device_options_t.flags; the public bits are in crabml_hip.h) ---- */
+#define CRABML_HIP_FLAG_LAZY_NO_FUSION 4 /* A/B: record the Tensor calls but always run the queue op by op (never match the decode step) */
+#define CRABML_HIP_FLAG_DRY 0x40000000  /* test hook, needs CRABML_HIP_TEST_HOOKS=1: a record-only device object with NO HIP device behind
+                                           it -- calls are validated, recorded, matched and counted, nothing is computed, export() yields
+                                           zeros.  The CPU test suite drives the queue and the matcher through it. */
+/* counters of the recorded-op queue (crabml_amd/csrc/lazy.hpp, LazyStats): out[0..7] = ops recorded, ops run one launch at a time,
+ * tokens served by the fused step, recorded ops those tokens replaced, fused segments enqueued, shadow tokens aborted, decode
+ * contexts built, final-norm rows bound on demand */
+int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* out, size_t cap);
+
 /* ---- parity / debug hooks (used by tests; not on the hot path) ------------------------------ */
 /* Quantizes the first n f32 elements of x to `qtype` (Q8_0 | Q8_1 | Q8_K) on the device and returns
  * the blocks in the reference's byte layout (buf_q8_0.rs:8-13, buf_q8_1.rs:73-79, buf_q8_k.rs:6-12). */

@@ -48,7 +48,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/crabml_hip.h but not exported: {missing}"
     lib.crabml_hip_abi_version.restype = ctypes.c_int
-    assert lib.crabml_hip_abi_version() == 1
+    assert lib.crabml_hip_abi_version() == 2
 
 
 def test_no_extra_undeclared_exports():

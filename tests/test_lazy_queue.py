@@ -1,0 +1,277 @@
+"""The recorded-op queue behind the Tensor entry points and the matcher that serves the reference's unchanged runner from the
+fused decode step (crabml_amd/csrc/lazy.hpp) -- the HOST logic, on the CPU.
+
+These tests run the real stack -- Llama2Runner<HipTensor> (the C++ mirror of crabml-llama2/src/llama2.rs:184-281, 527-638) ->
+HipTensor -> the C ABI -> the queue / the matcher -- over the library's record-only test device (CRABML_HIP_FLAG_DRY, armed by
+CRABML_HIP_TEST_HOOKS=1): calls are validated, recorded, matched and counted, nothing is computed.  What is asserted is which
+ops were replaced by fused segments and which ran one launch at a time; what the segments COMPUTE is the GPU suite's business
+(tests/test_hip_lazy.py: bit-identical logits against the per-op launches and the oracle)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+os.environ["CRABML_HIP_TEST_HOOKS"] = "1"
+
+import crabml_amd as ca  # noqa: E402
+from crabml_amd import synth  # noqa: E402
+
+F32, F16 = ca.GGMLType.F32, ca.GGMLType.F16
+
+
+def dry(mode="dry", named=False):
+    return ca.HipTensorDevice(0, named, 0, False, mode)
+
+
+def tiny(dev, wtype=synth.Q4_0, shape="tiny-gqa"):
+    model = synth.build_model(synth.SHAPES[shape], wtype, seed=1)
+    conf, w = synth.to_hip(model, dev)
+    return model.shape, conf, w
+
+
+def ops_per_token(n_layers):
+    return 1 + 26 * n_layers + 4  # embedding; 26 Tensor calls per layer; final norm (2), last-row copy, classifier
+
+
+def test_the_unchanged_runner_is_served_by_the_fused_step():
+    dev = dry()
+    s, conf, w = tiny(dev)
+    r = ca.Llama2Runner(conf, w, dev, 32, True)
+    n = ops_per_token(s.n_layers)
+    for i, t in enumerate([1, 2, 3, 4, 5]):
+        r.forward([t], i)
+        st = dev.lazy_stats()
+        # every token -- the one the decode context is learned from included -- runs as 2 L + 1 fused segments
+        assert st["recorded"] == n * (i + 1)
+        assert st["fused_tokens"] == i + 1 and st["fused_ops"] == n * (i + 1)
+        assert st["segments"] == (2 * s.n_layers + 1) * (i + 1)
+        assert st["replayed"] == 0 and st["aborts"] == 0 and st["learned"] == 1
+        assert st["deferred_bound"] == 0  # x / x_final of forward() were dropped unread: never bound, never computed
+    assert r.kv_cache_len() == 5
+
+
+@pytest.mark.parametrize("mode", ["dry-per-op"])
+def test_no_fusion_mode_replays_every_op(mode):
+    dev = dry(mode)
+    s, conf, w = tiny(dev)
+    r = ca.Llama2Runner(conf, w, dev, 32, True)
+    for i, t in enumerate([1, 2, 3]):
+        r.forward([t], i)
+    st = dev.lazy_stats()
+    assert st["replayed"] == st["recorded"] == 3 * ops_per_token(s.n_layers)
+    assert st["fused_tokens"] == 0 and st["learned"] == 0
+
+
+def test_f32_cache_and_other_formats_are_matched_too():
+    for wtype in (synth.Q8_0, synth.Q4_1, synth.Q4_K, synth.F32):
+        dev = dry()
+        s, conf, w = tiny(dev, wtype)
+        r = ca.Llama2Runner(conf, w, dev, 16, False)  # f32 KV cache
+        for i, t in enumerate([3, 1, 2]):
+            r.forward([t], i)
+        st = dev.lazy_stats()
+        assert st["fused_tokens"] == 3 and st["replayed"] == 0, (wtype, st)
+
+
+def test_a_second_runner_on_the_same_weights_gets_its_own_context():
+    dev = dry()
+    s, conf, w = tiny(dev)
+    n = ops_per_token(s.n_layers)
+    r1 = ca.Llama2Runner(conf, w, dev, 32, True)
+    for i in range(3):
+        r1.forward([i + 1], i)
+    r2 = ca.Llama2Runner(conf, w, dev, 32, True)  # other KV-cache buffers: the template's cache handles do not match
+    for i in range(3):
+        r2.forward([i + 1], i)
+    st = dev.lazy_stats()
+    assert st["learned"] == 2
+    # r2's first token starts as a shadow of r1's template, deviates at the first concatenate (before anything was launched),
+    # and is then the token the new context is learned from -- and served by
+    assert st["aborts"] == 1 and st["fused_tokens"] == 6 and st["replayed"] == 0
+    assert st["recorded"] == 6 * n
+    # ... and going back to r1 costs another context
+    r1.forward([9], 3)
+    st = dev.lazy_stats()
+    assert st["learned"] == 3 and st["fused_tokens"] == 7 and st["replayed"] == 0
+
+
+def test_named_tensor_snapshots_force_the_per_op_path():
+    dev = dry("dry", named=True)  # with_name() exports: a flush in the middle of every layer
+    s, conf, w = tiny(dev)
+    r = ca.Llama2Runner(conf, w, dev, 32, True)
+    for i, t in enumerate([1, 2]):
+        r.forward([t], i)
+    st = dev.lazy_stats()
+    assert st["fused_tokens"] == 0 and st["replayed"] == st["recorded"] == 2 * ops_per_token(s.n_layers)
+    assert dev.dump_debug_tensor("attn_out:0:1") is not None
+
+
+# ---- the same op sequence issued from python, so that single calls can be perturbed -------------------------------
+def forward_py(conf, w, dev, kc, vc, tok, pos, seq, eps=1e-5, ffn_eps=1e-5, extra_op_at=None, keep=None, scale=None):
+    """Llama2Runner::forward (llama2.rs:184-281, 527-638), n_batch = 1, call for call; returns (logits tensor, kept handles)"""
+    kept = []
+    dim, hd = conf.embedding_dim, conf.head_size()
+    nh, nkv = conf.n_heads, conf.n_kv_heads
+    x = ca.HipTensor.alloc([1, dim], F32, dev)
+    x.copy_rows_from(w.token_embed, [tok])
+    for l in range(conf.n_layers):
+        xo = x.dup()
+        x = x.rms_norm_inplace(eps)
+        x = x.mul_inplace(w.rms_att_weight[l])
+        q = w.wq[l].matmul_vec(x)
+        k = w.wk[l].matmul_vec(x)
+        v = w.wv[l].matmul_vec(x)
+        q = q.reshape([1, nh, hd])
+        k = k.reshape([1, nkv, hd])
+        q = q.rope_inplace(ca.RopeMode.Llama, pos, hd)
+        k = k.rope_inplace(ca.RopeMode.Llama, pos, hd)
+        if extra_op_at == l:
+            k = k.scale_inplace(1.0)  # a call forward_llama does not make
+        kc[l].concatenate(k.reshape([1, nkv, hd]).transpose([1, 0, 2]), 1)
+        vc[l].concatenate(v.reshape([1, nkv, hd]).transpose([1, 0, 2]), 1)
+        qc = q.reshape([1, nh, hd]).transpose([1, 0, 2]).contiguous().scale_inplace(scale if scale else 1.0 / math.sqrt(np.float32(hd)))
+        korig = kc[l].strider()
+        kt = kc[l].transpose([0, 2, 1])
+        att = qc.batch_matmul(kt).softmax_inplace(2)
+        kc[l] = kt.with_strider(korig)
+        xa = att.batch_matmul(vc[l]).reshape([1, dim])
+        if keep == ("xa", l):
+            kept.append(xa)  # an intermediate the fused step never materializes escapes
+        x = w.wo[l].matmul_vec(xa)
+        x = x.add_inplace(xo)
+        xo2 = x.dup()
+        x = x.rms_norm_inplace(ffn_eps)
+        x = x.mul_inplace(w.rms_ffn_weight[l])
+        h1 = w.ffn_gate_weight[l].matmul_vec(x)
+        h2 = w.ffn_up_weight[l].matmul_vec(x)
+        h1 = h1.silu_inplace().mul_inplace(h2)
+        x = w.ffn_down_weight[l].matmul_vec(h1)
+        x = x.add_inplace(xo2)
+        del xo, q, k, v, qc, kt, att, xa, xo2, h1, h2  # the locals of the Rust loop body go out of scope here
+    x = x.rms_norm_inplace(eps)
+    x = x.mul_inplace(w.rms_final_weight)
+    xf = ca.HipTensor.alloc([dim], F32, dev)
+    xf.copy_rows_from(x, [0])
+    ow = w.output_weight if w.output_weight is not None else w.token_embed
+    logits = ow.matmul_vec(xf)
+    if keep == "final":
+        kept += [x, xf]
+    return logits, kept
+
+
+def caches(conf, dev, seq, f16=True):
+    mk = lambda: ca.HipTensor.alloc([conf.n_kv_heads, seq, conf.head_size()], F16 if f16 else F32, dev).resize(1, 0)  # noqa: E731
+    return [mk() for _ in range(conf.n_layers)], [mk() for _ in range(conf.n_layers)]
+
+
+def test_the_python_restatement_issues_the_runners_sequence():
+    dev = dry()
+    s, conf, w = tiny(dev)
+    kc, vc = caches(conf, dev, 32)
+    for i in range(3):
+        lg, _ = forward_py(conf, w, dev, kc, vc, i + 1, i, 32, eps=s.rms_eps)
+        lg.export()
+    st = dev.lazy_stats()
+    assert st["fused_tokens"] == 3 and st["replayed"] == 0 and st["recorded"] == 3 * ops_per_token(s.n_layers)
+
+
+@pytest.mark.parametrize("what", ["extra_op", "ffn_eps", "scale", "pos"])
+def test_a_deviating_token_runs_op_by_op(what):
+    dev = dry()
+    s, conf, w = tiny(dev)
+    n = ops_per_token(s.n_layers)
+    kc, vc = caches(conf, dev, 32)
+    for i in range(2):
+        forward_py(conf, w, dev, kc, vc, i + 1, i, 32, eps=s.rms_eps)[0].export()
+    base = dev.lazy_stats()
+    assert base["fused_tokens"] == 2
+    kw = {}
+    extra = 0
+    if what == "extra_op":
+        kw["extra_op_at"] = s.n_layers - 1  # the earlier layers' segments are already enqueued when the stream deviates
+        extra = 1
+    elif what == "ffn_eps":
+        kw["ffn_eps"] = 1e-6  # the fused step hard-codes the literal 1e-5 of llama2.rs:611
+    elif what == "scale":
+        kw["scale"] = 0.25
+    pos = 2
+    if what == "pos":  # rope position != cache length
+        x = ca.HipTensor.alloc([1, conf.embedding_dim], F32, dev)
+        x.copy_rows_from(w.token_embed, [1])
+        q = w.wq[0].matmul_vec(x.dup().rms_norm_inplace(s.rms_eps))
+        q.reshape([1, conf.n_heads, conf.head_size()]).rope_inplace(ca.RopeMode.Llama, 5, conf.head_size())
+        q.export()
+        st = dev.lazy_stats()
+        assert st["fused_tokens"] == 2 and st["replayed"] == 5 and st["aborts"] == 1
+        return
+    forward_py(conf, w, dev, kc, vc, 3, pos, 32, eps=s.rms_eps, **kw)[0].export()
+    st = dev.lazy_stats()
+    assert st["fused_tokens"] == 2 and st["aborts"] == 1
+    assert st["replayed"] == n + extra  # the whole token, the ops whose segments had been enqueued included
+    # the next regular token is served by the fused step again
+    forward_py(conf, w, dev, kc, vc, 4, pos + 1, 32, eps=s.rms_eps)[0].export()
+    st = dev.lazy_stats()
+    assert st["fused_tokens"] == 3 and st["replayed"] == n + extra
+
+
+def test_an_escaping_intermediate_takes_the_model_off_the_fused_step():
+    dev = dry()
+    s, conf, w = tiny(dev)
+    n = ops_per_token(s.n_layers)
+    kc, vc = caches(conf, dev, 32)
+    forward_py(conf, w, dev, kc, vc, 1, 0, 32, eps=s.rms_eps)[0].export()
+    lg, kept = forward_py(conf, w, dev, kc, vc, 2, 1, 32, eps=s.rms_eps, keep=("xa", 0))
+    lg.export()
+    st = dev.lazy_stats()
+    # the host holds a handle whose value only the per-op launches produce: the token is replayed, nothing is committed
+    assert st["fused_tokens"] == 1 and st["aborts"] == 1 and st["replayed"] == n
+    kept[0].export()  # and is readable
+
+
+def test_the_final_row_is_bound_only_when_somebody_keeps_it():
+    dev = dry()
+    s, conf, w = tiny(dev)
+    kc, vc = caches(conf, dev, 32)
+    forward_py(conf, w, dev, kc, vc, 1, 0, 32, eps=s.rms_eps)[0].export()
+    assert dev.lazy_stats()["deferred_bound"] == 0
+    lg, kept = forward_py(conf, w, dev, kc, vc, 2, 1, 32, eps=s.rms_eps, keep="final")
+    lg.export()
+    assert dev.lazy_stats()["deferred_bound"] == 0  # still only promised
+    kept[0].export()  # x: read -> both handles are bound from the context's residual stream
+    st = dev.lazy_stats()
+    assert st["deferred_bound"] == 2 and st["fused_tokens"] == 2 and st["replayed"] == 0
+    # kept, never read, and the next token starts: bound before the residual stream moves on
+    lg, kept2 = forward_py(conf, w, dev, kc, vc, 3, 2, 32, eps=s.rms_eps, keep="final")
+    lg.export()
+    forward_py(conf, w, dev, kc, vc, 4, 3, 32, eps=s.rms_eps)[0].export()
+    st = dev.lazy_stats()
+    assert st["deferred_bound"] == 4 and st["fused_tokens"] == 4
+    del kept, kept2
+
+
+def test_ops_before_a_token_run_first_and_ops_outside_tokens_are_replayed():
+    dev = dry()
+    s, conf, w = tiny(dev)
+    kc, vc = caches(conf, dev, 32)
+    forward_py(conf, w, dev, kc, vc, 1, 0, 32, eps=s.rms_eps)[0].export()
+    a = ca.HipTensor.new(np.ones(64, np.float32), [64], dev)
+    b = a.dup().scale_inplace(2.0).add_inplace(a)  # three recorded ops that belong to no token
+    lg, _ = forward_py(conf, w, dev, kc, vc, 2, 1, 32, eps=s.rms_eps)
+    st = dev.lazy_stats()
+    assert st["replayed"] == 3 and st["fused_tokens"] == 2  # flushed when the token started; the token itself already committed
+    lg.export()
+    b.export()
+
+
+def test_unsupported_models_stay_on_the_per_op_path():
+    dev = dry()
+    sh = synth.SHAPES["tiny-gqa"]
+    model = synth.build_model(sh, synth.Q4_0, seed=1)
+    conf, w = synth.to_hip(model, dev)
+    kc, vc = caches(conf, dev, 32)
+    # a neox-style rope is not the sequence of forward_llama
+    x = ca.HipTensor.alloc([1, conf.embedding_dim], F32, dev)
+    x.copy_rows_from(w.token_embed, [1])
+    x.export()
+    assert dev.lazy_stats()["learned"] == 0
