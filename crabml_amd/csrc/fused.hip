@@ -1237,6 +1237,8 @@ int crabml_hip_tp_all_reduce(crabml_hip_tp_comm_t* comm, crabml_hip_buf_t* buf, 
   CH_USE(dev);
   CH_FLUSH(dev);
   if (buf->dtype != CRABML_HIP_F32 || n > buf->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: needs an f32 buffer of >= n elements");
+  lazy_use(dev, buf);
+  CH_TRY(ensure_mem(dev, buf));
   if (comm->p2p) {
     if (!comm->connected) CH_BAIL(dev, CRABML_HIP_BAD_INPUT, "tp_all_reduce: the p2p group is not connected");
     if (n > comm->cap) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "tp_all_reduce: %zu elements exceed the inbox rows (%u)", n, comm->cap);
