@@ -22,8 +22,8 @@ if not _os.path.exists(LIB_PATH):
 from . import _host  # noqa: E402  (raises ImportError loudly if the extension was not built)
 from ._host import (  # noqa: E402,F401
     CrabmlError, GGMLType, GGUFFile, HipLlamaRunner, HipTensor, HipTensorDevice, Llama2Runner, LlamaConfig, LlamaWeights, RopeMode,
-    TensorStrider, TpComm, abi_version,
+    TensorStrider, TpComm, abi_version, sample_argmax,
 )
 
 __all__ = ["CrabmlError", "GGMLType", "GGUFFile", "HipLlamaRunner", "HipTensor", "HipTensorDevice", "Llama2Runner", "LlamaConfig", "LlamaWeights",
-           "RopeMode", "TensorStrider", "TpComm", "abi_version", "LIB_PATH"]
+           "RopeMode", "TensorStrider", "TpComm", "abi_version", "sample_argmax", "LIB_PATH"]

@@ -16,6 +16,7 @@
 //   k_gemv_res     wo / ffn_down matmul_vec + add_inplace(residual)
 //   k_gateup       ffn_gate/ffn_up matmul_vec + silu_inplace + mul_inplace
 //   k_argmax_step  greedy sampler (last maximum) + token/position advance
+#include <chrono>
 #include <cmath>
 
 #include "fused_common.hpp"
@@ -111,6 +112,10 @@ struct crabml_hip_llama {
   float* h = nullptr;        // ffn hidden (hidden_l), strict mode only
   float* logits = nullptr;   // vocab
   float* logits_ext = nullptr;  // lazy.hip: the classifier of this step writes the caller's buffer instead
+  float* host_logits = nullptr; // lazy.hip: pinned host copy of the logits, written by a kernel behind the classifier; the two words
+                                // behind the vocab_size floats are {sequence number of the step that wrote them, its fault word}
+  unsigned out_seq = 0;         // sequence number of the last step whose logits were sent to host_logits
+  unsigned lazy_serial = 0;     // lazy.hip: the step serial is set by the host at every begin (see lazy_ctx_begin)
   bool ext_kv = false;          // lazy.hip: kc / vc are the runner's own cache buffers (retained in `held`), not allocations of ours
   float* tmp = nullptr;      // strict-mode GEMV outputs
   char* act_dim = nullptr;   // Q8_0 planes of the normalized residual (dim)
@@ -176,6 +181,26 @@ struct crabml_hip_llama {
   unsigned h_state_next = 0;
   static constexpr unsigned H_STATE_SLOTS = 256;
 };
+
+// ---- lazy.hip's context: token / position / serial of a step straight from kernel arguments (a launch on the stream's own queue:
+// no copy-engine hand-off in front of the step's first kernel), and the logits to pinned host memory by a kernel behind the
+// classifier, followed by a flag the host can spin on (no copy-engine hand-off, no interrupt-driven wait behind the step's last)
+__global__ void k_set_state5(int* __restrict__ st, int token, int pos, int step, int serial) {
+  st[0] = token;
+  st[1] = pos;
+  st[2] = step;
+  st[4] = serial;
+}
+__global__ __launch_bounds__(256) void k_logits_to_host(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int n4, const float* __restrict__ src1,
+                                                        float* __restrict__ dst1, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) __builtin_nontemporal_store(src[i], dst + i);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst1[n4 * 4 + threadIdx.x] = src1[n4 * 4 + threadIdx.x];
+}
+__global__ void k_host_flag(unsigned* __restrict__ flag, unsigned seq, const int* __restrict__ fault) {
+  flag[1] = (unsigned)*fault;
+  __threadfence_system();  // (the copy kernel has completed: stream order; this orders the fault word before the flag)
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 namespace {
 
@@ -368,6 +393,17 @@ int enqueue_classifier_and_sampler(crabml_hip_llama* c, const void* cls_act, cra
     CH_TRY(launch_gemv_strict(dev, c->output, (size_t)c->vocab_l, dim, cls_act, 1, out));
   else
     CH_TRY(launch_gemv(dev, c->output, (size_t)c->vocab_l, dim, cls_act, 1, out, R));
+  if (c->ext_kv) {
+    // a context driven by the recorded-op queue (lazy.hip): the HOST samples (Llama2Runner exports the logits and runs its own
+    // sampler, llama2.rs:208), token / position / serial of the next step come from the host (lazy_ctx_begin) -- no sampler launch
+    if (c->host_logits != nullptr && c->logits_ext != nullptr) {
+      const int n = c->vocab_l;
+      k_logits_to_host<<<64, 256, 0, st>>>((const f32x4*)out, (f32x4*)c->host_logits, n / 4, out, c->host_logits, n);
+      k_host_flag<<<1, 1, 0, st>>>((unsigned*)(c->host_logits + c->cfg.vocab_size), ++c->out_seq, c->state + 5);
+    }
+    CH_HIP(dev, hipGetLastError());
+    return 0;
+  }
   k_argmax_partial<<<ARGMAX_BLOCKS, 256, 0, st>>>(out, c->vocab_l, c->am_val, c->am_idx, c->vocab_off);
   if (c->split_vocab && c->comm && c->comm->p2p)
     k_argmax_step_tp<<<1, 64, 0, st>>>(c->am_val, c->am_idx, ARGMAX_BLOCKS, token_d, pos_d, step_d, c->out_tokens, c->out_cap, c->state + 4,
@@ -1160,7 +1196,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
   return 0;
 }
 
-int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step) {
+int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step, const unsigned* serial = nullptr) {
   if (c->h_state_next == crabml_hip_llama::H_STATE_SLOTS) {  // every slot may still be waiting for its copy: drain, start over
     CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
     c->h_state_next = 0;
@@ -1169,6 +1205,19 @@ int set_state(crabml_hip_llama* c, size_t token, size_t pos, int step) {
   st[0] = (int)token;
   st[1] = (int)pos;
   st[2] = step;
+  if (serial != nullptr) {  // token, pos, step, (prefetch sink), serial: the serial set from the host (lazy_ctx_begin)
+    int st5[5] = {st[0], st[1], st[2], 0, (int)*serial};
+    // the ring slot holds 4 ints: the 5-int form takes two consecutive slots
+    if (c->h_state_next == crabml_hip_llama::H_STATE_SLOTS) {
+      CH_HIP(c->dev, hipStreamSynchronize(c->dev->stream));
+      c->h_state_next = 1;
+      st = c->h_state;
+    }
+    c->h_state_next++;
+    memcpy(st, st5, sizeof st5);
+    CH_HIP(c->dev, hipMemcpyAsync(c->state, st, 5 * sizeof(int), hipMemcpyHostToDevice, c->dev->stream));
+    return 0;
+  }
   CH_HIP(c->dev, hipMemcpyAsync(c->state, st, 3 * sizeof(int), hipMemcpyHostToDevice, c->dev->stream));
   return 0;
 }
@@ -1478,6 +1527,14 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
   }
   c->cfg = g;
   c->wtype = wt;
+  if (ext_kc != nullptr && !dry) {
+    static const bool on = [] { const char* e = getenv("CRABML_HIP_LAZY_NO_HOST_LOGITS"); return !(e && e[0] == '1'); }();
+    if (on && hipHostMalloc((void**)&c->host_logits, g.vocab_size * 4 + 64, hipHostMallocDefault) == hipSuccess)
+      memset(c->host_logits + g.vocab_size, 0, 64);
+    else
+      c->host_logits = nullptr;
+    (void)hipGetLastError();
+  }
   // the Q4_K fused kernels take a Q6_K attn_v / ffn_down beside the Q4_K planes, but only in the norm-epilogue form
   const bool nepi_k_possible = !dev->strict_order && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
                                !(g.flags & (CRABML_HIP_LLAMA_NO_NORM_EPILOGUE | CRABML_HIP_LLAMA_NO_KQUANT_FUSION)) &&
@@ -1777,6 +1834,7 @@ int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
   for (auto& a : c->allocs) pool_free(c->dev, a.first, a.second);
   for (auto* b : c->held) crabml_hip_buf_release(b);
   if (c->h_state) (void)hipHostFree(c->h_state);
+  if (c->host_logits) (void)hipHostFree(c->host_logits);
   delete c;
   return 0;
 }
@@ -2078,7 +2136,18 @@ int lazy_ctx_n_segments(const crabml_hip_llama* c) { return n_segments(c); }
 
 int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos) {
   if (c->dev->dry) return 0;
-  CH_TRY(set_state(c, token, pos, 0));
+  // A token whose shadow is dropped half-way (lazy.hip: the op stream left the template) never reaches the sampler launch that
+  // advances the step serial on the device -- and the epochs of the in-launch hand-offs (norm gathers, Q8_K exchanges) are derived
+  // from it: the NEXT token's first segments would match the dropped token's granules.  So here the host owns the serial: every
+  // begin sets a fresh even value, the sampler's own + 1 lands on the odd one in between.
+  c->lazy_serial += 2;
+  static const bool by_copy = [] { const char* e = getenv("CRABML_HIP_LAZY_STATE_MEMCPY"); return e && e[0] == '1'; }();
+  if (by_copy) {
+    CH_TRY(set_state(c, token, pos, 0, &c->lazy_serial));
+  } else {
+    k_set_state5<<<1, 1, 0, c->dev->stream>>>(c->state, (int)token, (int)pos, 0, (int)c->lazy_serial);
+    CH_HIP(c->dev, hipGetLastError());
+  }
   c->attn_variant = c->attn_long_ok && pos + 1 >= c->attn_long_from ? 1 : 0;
   c->kv_len = pos + 1;
   return 0;
@@ -2115,6 +2184,25 @@ int lazy_ctx_fault_request(crabml_hip_llama* c) {
   CH_HIP(dev, hipMemcpyAsync(h, c->state + 5, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
   return 0;
 }
+// the logits of the last final segment in pinned host memory: spins on the flag the step's last kernel raises (bounded; then the
+// stream is drained the ordinary way).  nullptr: this context has no host copy.
+const float* lazy_ctx_wait_logits(crabml_hip_llama* c, int* fault) {
+  if (c->dev->dry || c->host_logits == nullptr || c->out_seq == 0) return nullptr;
+  volatile unsigned* flag = (volatile unsigned*)(c->host_logits + c->cfg.vocab_size);
+  const unsigned want = c->out_seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; __atomic_load_n((const unsigned*)flag, __ATOMIC_ACQUIRE) != want; spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      if (hipStreamSynchronize(c->dev->stream) != hipSuccess) return nullptr;
+      if (__atomic_load_n((const unsigned*)flag, __ATOMIC_ACQUIRE) != want) return nullptr;
+      break;
+    }
+  }
+  *fault = (int)flag[1];
+  return c->host_logits;
+}
+bool lazy_ctx_has_host_logits(const crabml_hip_llama* c) { return c != nullptr && c->host_logits != nullptr; }
 int lazy_ctx_fault_value(const crabml_hip_llama* c) { return c->dev->dry ? 0 : c->h_state[crabml_hip_llama::H_STATE_SLOTS * 4]; }
 
 }  // namespace crabml_hip

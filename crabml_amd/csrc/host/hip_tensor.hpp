@@ -66,7 +66,7 @@ class HipTensorDevice {
   size_t mem_in_use() const { return crabml_hip_device_mem_in_use(dev_); }
   // counters of the recorded-op queue (crabml_hip_debug.h)
   std::vector<uint64_t> lazy_stats() const {
-    std::vector<uint64_t> v(8, 0);
+    std::vector<uint64_t> v(10, 0);
     check(crabml_hip_debug_lazy_stats(dev_, v.data(), v.size()));
     return v;
   }
@@ -198,6 +198,13 @@ class HipTensor {
     std::vector<float> v(strider_.len());
     device_->check(crabml_hip_export(device_->raw(), buf_.get(), v.data(), v.size()));
     return v;
+  }
+  // Tensor::export (api.rs:52: `fn export(&self, buf: &mut [f32])`) -- into the caller's buffer, as the reference's runner
+  // does with its preallocated logits (llama2.rs:208)
+  void export_into(std::vector<float>& v) const {
+    if (!is_contiguous()) throw Error(ErrorKind::TensorError, "export: tensor is not contiguous");
+    v.resize(strider_.len());
+    device_->check(crabml_hip_export(device_->raw(), buf_.get(), v.data(), v.size()));
   }
   std::vector<uint8_t> export_raw() const {
     size_t nbytes = buf_len() * (dtype_ == GGMLType::F32 ? 4 : 2);

@@ -35,9 +35,78 @@ struct LlamaWeights {
 };
 
 // Iterator::max_by keeps the LAST maximum (crabml-llama2/src/sampler.rs:109-116)
+#if defined(__x86_64__)
+// the maximum of NaN-free data; *clean = false when a NaN was seen (the caller then takes the defining loop)
+__attribute__((target("avx2"))) inline float max_avx2(const float* p, size_t n, bool* clean) {
+  typedef float v8 __attribute__((vector_size(32), aligned(4)));
+  v8 m0 = *(const v8*)p, m1 = *(const v8*)(p + 8), m2 = *(const v8*)(p + 16), m3 = *(const v8*)(p + 24);
+  typedef int i8 __attribute__((vector_size(32)));
+  i8 ok = (m0 == m0) & (m1 == m1) & (m2 == m2) & (m3 == m3);
+  size_t i = 32;
+  for (; i + 32 <= n; i += 32) {
+    const v8 a = *(const v8*)(p + i), b = *(const v8*)(p + i + 8), c = *(const v8*)(p + i + 16), d = *(const v8*)(p + i + 24);
+    ok &= (a == a) & (b == b) & (c == c) & (d == d);
+    m0 = a > m0 ? a : m0;
+    m1 = b > m1 ? b : m1;
+    m2 = c > m2 ? c : m2;
+    m3 = d > m3 ? d : m3;
+  }
+  m0 = m1 > m0 ? m1 : m0;
+  m2 = m3 > m2 ? m3 : m2;
+  m0 = m2 > m0 ? m2 : m0;
+  float mx = m0[0];
+  bool c = true;
+  for (int j = 0; j < 8; j++) {
+    c &= ok[j] != 0;
+    mx = m0[j] > mx ? m0[j] : mx;
+  }
+  for (; i < n; i++) {
+    c &= p[i] == p[i];
+    mx = p[i] > mx ? p[i] : mx;
+  }
+  *clean = c;
+  return mx;
+}
+#endif
+
 inline size_t sample_argmax(const std::vector<float>& p) {
+  const size_t n = p.size();
+#if defined(__x86_64__)
+  if (n >= 64 && __builtin_cpu_supports("avx2")) {
+    bool clean = false;
+    const float mx = max_avx2(p.data(), n, &clean);
+    if (clean)
+      for (size_t k = n; k-- > 0;)
+        if (p[k] == mx) return k;
+  } else
+#endif
+  if (n >= 64) {
+    // two passes over NaN-free logits: the maximum (eight independent compare chains), then its last position -- the element
+    // max_by returns.  Anything with a NaN in it takes the loop below, whose tie / NaN behaviour is the definition.
+    float m[8];
+    bool clean = true;
+    for (int j = 0; j < 8; j++) m[j] = p[j];
+    size_t i = 8;
+    for (; i + 8 <= n; i += 8)
+      for (int j = 0; j < 8; j++) {
+        const float v = p[i + j];
+        clean &= v == v;
+        m[j] = v > m[j] ? v : m[j];
+      }
+    for (int j = 0; j < 8; j++) clean &= m[j] == m[j];
+    for (; i < n; i++) {
+      clean &= p[i] == p[i];
+      m[0] = p[i] > m[0] ? p[i] : m[0];
+    }
+    if (clean) {
+      float mx = m[0];
+      for (int j = 1; j < 8; j++) mx = m[j] > mx ? m[j] : mx;
+      for (size_t k = n; k-- > 0;)
+        if (p[k] == mx) return k;
+    }
+  }
   size_t best = 0;
-  for (size_t i = 1; i < p.size(); i++)
+  for (size_t i = 1; i < n; i++)
     if (!(p[best] > p[i])) best = i;
   return best;
 }
@@ -70,7 +139,7 @@ class Llama2Runner {
     x_final.copy_rows_from(x, {tokens.size() - 1});
     const T& ow = weights_->output_weight ? *weights_->output_weight : weights_->token_embed;
     T logits = ow.matmul_vec(x_final);
-    logits_ = logits.export_();
+    logits.export_into(logits_);  // logits.export(&mut self.logits), llama2.rs:208
   }
 
   // prefill token by token (llama2.rs:127-129), then greedy generation; returns the sampled ids

@@ -40,6 +40,11 @@ PYBIND11_MODULE(_host, m) {
     }
   });
   m.def("abi_version", []() { return crabml_hip_abi_version(); });
+  // the runner's greedy sampler (sampler.rs:109-116: Iterator::max_by keeps the LAST maximum)
+  m.def("sample_argmax", [](py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+    std::vector<float> v(a.data(), a.data() + a.size());
+    return sample_argmax(v);
+  });
 
   py::enum_<GGMLType>(m, "GGMLType")
       .value("F32", GGMLType::F32).value("F16", GGMLType::F16).value("Q4_0", GGMLType::Q4_0)
@@ -78,8 +83,9 @@ PYBIND11_MODULE(_host, m) {
            [](HipTensorDevice& d) {
              const std::vector<uint64_t> v = d.lazy_stats();
              py::dict r;
-             const char* names[8] = {"recorded", "replayed", "fused_tokens", "fused_ops", "segments", "aborts", "learned", "deferred_bound"};
-             for (int i = 0; i < 8; i++) r[names[i]] = v[i];
+             const char* names[10] = {"recorded", "replayed", "fused_tokens", "fused_ops", "segments", "aborts", "learned", "deferred_bound",
+                                      "wait_ns", "pinned_exports"};
+             for (int i = 0; i < 10; i++) r[names[i]] = v[i];
              return r;
            })
       .def("sync", &HipTensorDevice::sync, py::call_guard<py::gil_scoped_release>())
@@ -460,13 +466,16 @@ PYBIND11_MODULE(_host, m) {
         py::gil_scoped_release rel;
         std::vector<size_t> ids;
         size_t pos = r.kv_cache_len();
+        double sample_sec = 0.0;
         auto t0 = std::chrono::steady_clock::now();
         for (size_t s = 0; s < steps; s++) {
           r.forward({token}, pos + s);
+          auto ta = std::chrono::steady_clock::now();
           token = sample_argmax(r.logits());
+          sample_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
           ids.push_back(token);
         }
         double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return std::make_pair(ids, sec);
+        return std::make_tuple(ids, sec, sample_sec);  // (ids, seconds, of which in the host arg-max)
       });
 }

@@ -1,5 +1,6 @@
 // lazy.hip -- the recorded-op queue of a device, the launches of each recorded op, and the matcher that serves the op stream
 // of the reference's unchanged runner from the fused decode step.  Design and invariants: lazy.hpp.
+#include <chrono>
 #include <cmath>
 
 #include "kernels.hpp"
@@ -573,7 +574,34 @@ int commit_token(crabml_hip_device* dev, LazyState& L) {
       L.deferred[di++] = b;
     }
   }
-  touch(L.slots[L.slot_logits]);  // written in place by the classifier launch
+  crabml_hip_buf* lb = L.slots[L.slot_logits];
+  touch(lb);  // written in place by the classifier launch
+  if (L.pin_buf) crabml_hip_buf_release(L.pin_buf);
+  L.pin_buf = nullptr;
+  L.pin_kind = 0;
+  if (!dev->dry && lb->bytes && lazy_ctx_has_host_logits(L.ctx)) {  // the final segment's own kernels send the logits to the host
+    crabml_hip_buf_retain(lb);
+    L.pin_buf = lb;
+    L.pin_version = lb->version;
+    L.pin_n = lb->n_elems;
+    L.pin_kind = 1;
+  } else if (!dev->dry && lb->bytes) {
+    static const bool pin_on = [] { const char* e = getenv("CRABML_HIP_LAZY_NO_PINNED_LOGITS"); return !(e && e[0] == '1'); }();
+    if (pin_on && L.pin_bytes < lb->bytes) {
+      if (L.pin) (void)hipHostFree(L.pin);
+      L.pin = nullptr;
+      L.pin_bytes = 0;
+      if (hipHostMalloc(&L.pin, lb->bytes, hipHostMallocDefault) == hipSuccess) L.pin_bytes = lb->bytes;
+      (void)hipGetLastError();
+    }
+    if (pin_on && L.pin && hipMemcpyAsync(L.pin, lb->ptr, lb->bytes, hipMemcpyDeviceToHost, dev->stream) == hipSuccess) {
+      crabml_hip_buf_retain(lb);
+      L.pin_buf = lb;
+      L.pin_version = lb->version;
+      L.pin_n = lb->n_elems;
+      L.pin_kind = 2;
+    }
+  }
   L.stats.fused_tokens++;
   L.stats.fused_ops += L.q.size();
   for (LazyOp& o : L.q) release_op(o);
@@ -690,6 +718,27 @@ int lazy_resolve(crabml_hip_device* dev) {
   return rc;
 }
 
+int lazy_pinned_kind(crabml_hip_device* dev, const crabml_hip_buf* b, size_t n) {
+  if (!dev->lz) return 0;
+  LazyState& L = *dev->lz;
+  if (L.pin_buf != b || L.pin_version != b->version || n > L.pin_n) return 0;
+  return L.pin_kind;
+}
+
+int lazy_export_wait(crabml_hip_device* dev, float* dst, size_t n) {
+  LazyState& L = *dev->lz;
+  int fault = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const float* src = lazy_ctx_wait_logits(L.ctx, &fault);
+  L.stats.wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  if (!src) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "the logits of the fused decode step never reached the host");
+  memcpy(dst, src, n * 4);
+  L.stats.pinned_exports++;
+  L.check_fault = false;  // this step's fault word travelled with the flag
+  if (fault) CH_BAIL(dev, CRABML_HIP_UNEXPECTED, "a norm-epilogue gather of the fused decode step timed out (workgroups not co-resident?)");
+  return 0;
+}
+
 int lazy_fault_request(crabml_hip_device* dev) {
   if (!dev->lz || !dev->lz->check_fault || !dev->lz->ctx) return 0;
   dev->lz->check_fault = false;
@@ -711,6 +760,8 @@ void lazy_destroy(crabml_hip_device* dev) {
   for (LazyOp& o : L.q) release_op(o);  // (device_destroy flushed first; whatever is left is dropped)
   L.q.clear();
   drop_model(dev, L);
+  if (L.pin_buf) crabml_hip_buf_release(L.pin_buf);
+  if (L.pin) (void)hipHostFree(L.pin);
   delete dev->lz;
   dev->lz = nullptr;
 }
@@ -719,7 +770,7 @@ void lazy_destroy(crabml_hip_device* dev) {
 
 extern "C" int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* out, size_t cap) {
   if (!dev || !out) return CRABML_HIP_BAD_INPUT;
-  uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (dev->lz) {
     const crabml_hip::LazyStats& s = dev->lz->stats;
     v[0] = s.recorded;
@@ -730,7 +781,9 @@ extern "C" int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* o
     v[5] = s.aborts;
     v[6] = s.learned;
     v[7] = s.deferred_bound;
+    v[8] = s.wait_ns;
+    v[9] = s.pinned_exports;
   }
-  for (size_t i = 0; i < cap && i < 8; i++) out[i] = v[i];
+  for (size_t i = 0; i < cap && i < 10; i++) out[i] = v[i];
   return 0;
 }

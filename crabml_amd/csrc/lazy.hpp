@@ -105,6 +105,8 @@ struct LazyStats {  // crabml_hip_debug_lazy_stats
   uint64_t aborts = 0;         // tokens whose shadow was dropped (deviation from the template, flush in mid-token)
   uint64_t learned = 0;        // decode contexts built from a recorded token
   uint64_t deferred_bound = 0; // final-norm rows produced on demand for a handle the host kept
+  uint64_t wait_ns = 0;        // host time blocked in export / sync (the GPU still working: the host was ahead)
+  uint64_t pinned_exports = 0; // exports served from the logits copy that was requested when the token committed
 };
 
 struct LazyState {
@@ -124,6 +126,13 @@ struct LazyState {
   bool pos_known = false, begun = false, dead = false;
   // handles the host kept whose value is the final norm of the context's residual stream (bound on demand)
   crabml_hip_buf* deferred[2] = {nullptr, nullptr};
+  // the logits of a committed token are copied to pinned host memory right behind the classifier launch (the runner exports
+  // them next, llama2.rs:208): export() of that very buffer, unmodified, is then a wait + a host copy
+  void* pin = nullptr;
+  size_t pin_bytes = 0, pin_n = 0;
+  crabml_hip_buf* pin_buf = nullptr;  // retained while the copy is valid for it
+  uint64_t pin_version = 0;
+  int pin_kind = 0;  // 1: sent by the context's own kernels + flag, 2: copy-engine transfer into `pin`
   bool check_fault = false;  // a committed token's gather-fault word has not been looked at yet
   bool fault_requested = false;
   LazyStats stats;
@@ -153,6 +162,11 @@ inline void lazy_use(crabml_hip_device* dev, const crabml_hip_buf* b) {
 }
 // around a sync: did a committed token's in-launch gather time out?  (the decode context's fault word; requested before the
 // sync, looked at after it)
+// export(): was a host copy of this buffer's first n floats requested when its token committed, and is the buffer unchanged?
+// 1: the context's kernels send it to pinned memory and raise a flag (lazy_export_wait copies it out); 2: a copy-engine transfer
+// into L.pin is in flight (valid after the stream is drained); 0: no
+int lazy_pinned_kind(crabml_hip_device* dev, const crabml_hip_buf* b, size_t n);
+int lazy_export_wait(crabml_hip_device* dev, float* dst, size_t n);  // kind 1: wait for the flag, copy, report a gather fault
 int lazy_fault_request(crabml_hip_device* dev);
 int lazy_fault_check(crabml_hip_device* dev);
 
@@ -162,6 +176,8 @@ void lazy_ctx_destroy(crabml_hip_llama* c);
 int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos);            // token id / position of the step -> device state
 int lazy_ctx_segment(crabml_hip_llama* c, int seg, float* logits_out);        // enqueue one segment (logits_out: the last one)
 int lazy_ctx_final_norm(crabml_hip_llama* c, float* dst);                     // dst = rms_norm(residual) * rms_final
+const float* lazy_ctx_wait_logits(crabml_hip_llama* c, int* fault);  // spins; nullptr = no host copy of the logits
+bool lazy_ctx_has_host_logits(const crabml_hip_llama* c);
 int lazy_ctx_fault_request(crabml_hip_llama* c);
 int lazy_ctx_fault_value(const crabml_hip_llama* c);
 int lazy_ctx_n_segments(const crabml_hip_llama* c);

@@ -5,6 +5,7 @@
 // wgpu_tensor.rs:20-28, wgpu_device.rs) is done here with: one HIP stream per device (all work is
 // stream-ordered, the host only blocks in export), a size-class caching allocator over hipMalloc
 // (activations are allocated and dropped ~30x per layer by the runner), and reference-counted buffers.
+#include <chrono>
 #include <cmath>
 
 #include "kernels.hpp"
@@ -487,9 +488,17 @@ int crabml_hip_export(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, float
   }
   CH_USE(dev);
   CH_TRY(observe(dev, b));
-  if (n) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, n * 4, hipMemcpyDeviceToHost, dev->stream));
+  const int pinned = n ? lazy_pinned_kind(dev, b, n) : 0;  // the logits of a token the fused step served: already on their way
+  if (pinned == 1) return lazy_export_wait(dev, dst, n);    // (waits for THAT data, not for the whole stream)
+  if (n && !pinned) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, n * 4, hipMemcpyDeviceToHost, dev->stream));
   CH_TRY(lazy_fault_request(dev));
+  const auto t0 = std::chrono::steady_clock::now();
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
+  dev->lz->stats.wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  if (pinned) {
+    memcpy(dst, dev->lz->pin, n * 4);
+    dev->lz->stats.pinned_exports++;
+  }
   return lazy_fault_check(dev);
 }
 

@@ -21,7 +21,8 @@ extern "C" {
                                            zeros.  The CPU test suite drives the queue and the matcher through it. */
 /* counters of the recorded-op queue (crabml_amd/csrc/lazy.hpp, LazyStats): out[0..7] = ops recorded, ops run one launch at a time,
  * tokens served by the fused step, recorded ops those tokens replaced, fused segments enqueued, shadow tokens aborted, decode
- * contexts built, final-norm rows bound on demand */
+ * contexts built, final-norm rows bound on demand, [8] nanoseconds the host spent blocked in export, [9] exports served from
+ * the pinned logits copy requested at commit */
 int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* out, size_t cap);
 
 /* ---- parity / debug hooks (used by tests; not on the hot path) ------------------------------ */

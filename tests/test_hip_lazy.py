@@ -98,15 +98,19 @@ def test_a_deviating_token_is_replayed_with_per_op_results(ca, what):
         conf, w = synth.to_hip(model, dev)
         kc, vc = caches(conf, dev, 32)
         lgs = []
-        for i, t in enumerate(TOKS[:6]):
-            extra = kw if i == 3 else {}
+        toks = (TOKS * 3)[:20]
+        bad = (3, 5, 6, 9, 14, 15, 16)
+        for i, t in enumerate(toks):
+            extra = kw if i in bad else {}
             lg, _ = forward_py(conf, w, dev, kc, vc, t, i, 32, eps=model.shape.rms_eps, **extra)
             lgs.append(np.array(lg.export()))
         res[mode] = (lgs, dev.lazy_stats())
-    for i in range(6):
+    # (a dropped shadow leaves granules of its in-launch hand-offs behind: the next token must not match them -- the step serial
+    # their epochs derive from is set by the host at every token, lazy_ctx_begin)
+    for i in range(20):
         assert np.array_equal(u32(res["lazy"][0][i]), u32(res["per-op"][0][i])), f"step {i}"
     st = res["lazy"][1]
-    assert st["fused_tokens"] == 5 and st["aborts"] == 1, st
+    assert st["fused_tokens"] == 13 and st["aborts"] == 7, st
 
 
 @pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0", "Q4_K"])

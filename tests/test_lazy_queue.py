@@ -275,3 +275,30 @@ def test_unsupported_models_stay_on_the_per_op_path():
     x.copy_rows_from(w.token_embed, [1])
     x.export()
     assert dev.lazy_stats()["learned"] == 0
+
+
+def test_the_runners_greedy_sampler_keeps_the_last_maximum():
+    """sampler.rs:109-116 (max_by keeps the last maximum); the mirror's two-pass form against the defining loop"""
+    def ref(p):
+        best = 0
+        for i in range(1, len(p)):
+            if not (p[best] > p[i]):
+                best = i
+        return best
+
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 63, 64, 65, 100, 1000, 4099):
+        for case in range(6):
+            p = rng.standard_normal(n).astype(np.float32)
+            if case == 1:
+                p[rng.integers(0, n, size=3)] = p.max()  # ties
+            elif case == 2:
+                p[:] = 0.0
+                p[rng.integers(0, n)] = -0.0  # +-0 compare equal
+            elif case == 3:
+                p[rng.integers(0, n)] = np.nan
+            elif case == 4:
+                p[rng.integers(0, n, size=2)] = np.inf
+            elif case == 5:
+                p = np.round(p * 2).astype(np.float32)  # many ties
+            assert ca.sample_argmax(p) == ref(p), (n, case)
