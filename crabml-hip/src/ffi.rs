@@ -23,6 +23,8 @@ pub const CRABML_HIP_LLAMA_NO_PREFETCH: i32 = 2;
 pub const CRABML_HIP_LLAMA_TP_GRAPH: i32 = 8;
 /// fast mode at long context: keep the reference's f16-accumulated PV chain instead of the f32 split-KV kernels
 pub const CRABML_HIP_LLAMA_EXACT_ATTENTION: i32 = 4194304;
+/// fast mode: RMSNorm's division stays in the producing launch (no deferred 1 / rms)
+pub const CRABML_HIP_LLAMA_EXACT_NORM: i32 = 8388608;
 /// tensor parallelism: `output_weight` is the rank's vocabulary shard of the classifier (P2P group)
 pub const CRABML_HIP_LLAMA_TP_SPLIT_VOCAB: i32 = 1048576;
 

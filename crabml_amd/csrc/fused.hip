@@ -135,6 +135,10 @@ struct crabml_hip_llama {
   uint32_t qt = 0, out_qt = 0;  // vec_dot_rhs_dtype of the layer weights / of the classifier
   float* xn = nullptr;       // generic path: normalized residual (f32, dim)
   bool norm_epi = false;     // fast mode, tp == 1: RMSNorm + quantize run in the wo / ffn_down epilogue
+  // the hop-free norm of the fast step (Q4_0 / Q8_0 layers, one GPU): wo quantizes x * w_norm block by block and leaves 1 / rms to
+  // the gate/up launch (RmsTail, gemv_core.hpp) -- no in-launch gather.  Off: CRABML_HIP_LLAMA_EXACT_NORM, strict order, tp.
+  bool defer_norm = false;
+  float* rsums = nullptr;    // [dim / 16] chunk sums of squares of the residual stream
   bool norm_epi_k = false;   // the same for Q4_K layers (Q8_K planes out of the epilogue)
   unsigned* out_tokens = nullptr;
   int out_cap = 0;
@@ -468,17 +472,25 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   };
   // W(dim x k_local) . act -> x (+= residual) or partial (tp)
   const bool norm_epi = c->norm_epi;
+  // workgroups per 32-row chunk of a wo / ffn_down launch: two for long rows (ffn_down), so that every CU streams
+  auto split_of = [&](int k) {
+    return (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
+           : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
+           : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
+                                                             : 1;
+  };
+  // the hop-free norm between wo and gate/up of a layer: decided once, for the producer and the consumer alike
+  const bool defer_wo = c->defer_norm && !Q81;
+  // ... and between ffn_down of layer l and q/k/v of layer l + 1 (the last ffn_down feeds the classifier launch: exact planes)
+  const bool defer_down = c->defer_norm && !Q81;
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
-  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next) -> int {
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next, bool defer = false) -> int {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
     if (norm_epi) {
-      NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg};
+      NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg, c->rsums};
       // long rows (ffn_down): two workgroups per chunk, so that every CU streams (a CU sustains ~26 GB/s here)
-      const int split = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
-                        : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
-                        : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
-                                                                          : 1;
+      const int split = split_of(k);
       const TpP2P tpv = tp_view(c, tp);
       if (tpv.n > 1) {  // tensor parallel over a P2P group: the collective runs inside this launch
         if (split == 2)
@@ -510,6 +522,15 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
           else
             launch_k(st, R, k_gemv_res_nq_ord<FMT, 1, false>, dim3(dim / 32), dim3(1024), lds, planes_of(w), act_view<FMT>(a), c->x, wnext, eps_next, ad.q,
                      ad.d, ad.isum, ng, k / 32);
+        }
+      } else if (defer && !Q81) {  // hop-free: the consumer applies 1 / rms
+        if constexpr (!Q81) {
+          if (split == 2)
+            launch_k(st, R, k_gemv_res_nq<FMT, 2, 0, false, true>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
+                     c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
+          else
+            launch_k(st, R, k_gemv_res_nq<FMT, 1, 0, false, true>, dim3(dim / 32), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
+                     c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
         }
       } else if (split == 2)
         launch_k(st, R, k_gemv_res_nq<FMT, 2>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr, c->x, wnext,
@@ -571,12 +592,18 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(&pr, 1, total_rows, dim));
+    // (the planes of layer l > 0 come from the previous layer's ffn_down launch: dim / 32 chunk sums, or dim / 16 halves)
+    const RmsTail rtq{c->rsums, split_of(hidden_l) == 2 ? dim / 16 : dim / 32, 1.0f / (float)dim, g.rms_norm_eps};
     if (c->ord)
       launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * ((dim / 32 + 3) & ~3) * sizeof(float), planes_of(c->wq[l]),
                planes_of(c->wk[l]), planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e);
-    else
+    else if (defer_down && l > 0) {
+      if constexpr (!Q81)
+        launch_k(st, R, k_qkv<FMT, true>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
+                 planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq);
+    } else
       launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
+               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq);
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;
@@ -584,22 +611,27 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     enqueue_attention(c, l, attn_quant ? aa.q : (signed char*)nullptr, aa.d, aa.isum, plan(c->wo[l], nullptr, nullptr), attn_spare, prof);
     if (!attn_quant) launch_quantize_act(st, qt, c->attn, (size_t)dim_l, c->act_attn);
     // wo (+ residual, llama2.rs:600, 266): k = the local heads' slice
-    CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f));
+    CH_TRY(gemv_out(c->wo[l], aa, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f, defer_wo));
   } else {
     // ffn rmsnorm, eps = the literal 1e-5 (llama2.rs:611)
     if (!norm_epi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, plan(nullptr, nullptr, nullptr));
     const float* wnext_down = (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr;
     // gate / up + silu * mul (llama2.rs:620-630), local rows
     CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
+    const RmsTail rt{c->rsums, split_of(dim_l) == 2 ? dim / 16 : dim / 32, 1.0f / (float)dim, 1e-5f};  // eps: the literal 1e-5 (llama2.rs:611)
     if (c->ord)
       launch_k(st, R, k_gateup_q_ord<FMT>, dim3(hidden_l / 32), dim3(1024), (size_t)64 * (((dim / 32 + 3) & ~3) + 4) * sizeof(float), planes_of(c->gate[l]),
                planes_of(c->up[l]), act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
-    else
+    else if (defer_wo) {
+      if constexpr (!Q81)
+        launch_k(st, R, k_gateup_q<FMT, true>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]), act_view<FMT>(ad),
+                 dev->exp_table, ah.q, ah.d, ah.isum, dim / 32, rt);
+    } else
       launch_k(st, R, k_gateup_q<FMT>, dim3(hidden_l / 32), dim3(1024), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
-               act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
+               act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32, rt);
     CH_TRY(P1(&pr));
     // down (+ residual, llama2.rs:633-636): k = the local hidden slice
-    CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps));
+    CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps, defer_down && l + 1 < L));
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
@@ -821,7 +853,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(1, total_rows, dim));
     launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
-             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]));
+             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]), RmsTail{nullptr, 0, 0.f, 0.f});
     CH_TRY(P1());
     // Q8_K producers: the (short-context) attention kernel assembles the planes of wo's rhs itself; wo copies them
     const bool aq8 = qout && (g.flags & CRABML_HIP_LLAMA_Q8K_ATTN_PRODUCER) && c->attn_variant == 0 && c->attn_s_rows > 0;
@@ -1720,6 +1752,9 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
                 (int)(g.embedding_dim / 32) <= dev->n_cu;  // every workgroup of the gather must be resident
   c->norm_epi_k = c->kfused && wt == CRABML_HIP_Q4_K && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
                   !(g.flags & CRABML_HIP_LLAMA_NO_NORM_EPILOGUE) && g.embedding_dim % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
+  c->defer_norm = c->norm_epi && tp == 1 && !ord && !dev->strict_order && (wt == CRABML_HIP_Q4_0 || wt == CRABML_HIP_Q8_0) &&
+                  !(g.flags & CRABML_HIP_LLAMA_EXACT_NORM) && (int)(g.embedding_dim / 32) <= dev->n_cu;
+  if (c->defer_norm) A(g.embedding_dim / 16 * 4, (void**)&c->rsums);
   c->q8k_producers = c->norm_epi_k && !(g.flags & (CRABML_HIP_LLAMA_NO_RHS_PROLOGUE | CRABML_HIP_LLAMA_NO_Q8K_PRODUCERS)) && dim_l % 256 == 0 &&
                      hidden_l % 256 == 0 && (hd == 64 || hd == 128 || hd == 256) && (int)(hidden_l / 32) <= 2 * dev->n_cu;
   if (c->q8k_producers) {

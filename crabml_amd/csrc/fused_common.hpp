@@ -327,6 +327,19 @@ __device__ __forceinline__ QkvPre qkv_preload(const QkvEpi& e, int row0, int row
   }
   return p;
 }
+// the same without a load inside a branch (the rotation of a clamped pair is fetched unconditionally and ignored where `rot` is
+// false): a loaded value that leaves a lane-predicated region is copied at its end, i.e. waited for on the spot -- a memory round
+// trip in front of the wave's first weight request
+__device__ __forceinline__ QkvPre qkv_preload_nb(const QkvEpi& e, int row0) {
+  QkvPre p;
+  p.pos = *e.pos_d;
+  const int i = (row0 < e.dim ? row0 : row0 - e.dim) % e.hd;
+  p.rot = row0 < e.dim + e.kv_dim && i < e.rope_dim;
+  const float* cs = e.rope + ((size_t)p.pos * e.npairs + (p.rot ? (i >> 1) : 0)) * 2;
+  p.c = cs[0];
+  p.s = cs[1];
+  return p;
+}
 __device__ __forceinline__ void qkv_epilogue(const QkvEpi& e, const QkvPre& pre, int row0, float s0, float s1) {
   const int pos = pre.pos;
   if (row0 < e.dim + e.kv_dim) {  // q or k: rotate the (even, odd) pair
@@ -374,9 +387,10 @@ struct Planes6 {
   size_t off_qh;
 };
 
-template <int FMT>
+// DEFER: the rhs planes come from a hop-free ffn_down launch -- the row dots are multiplied by 1 / rms (RmsTail, gemv_core.hpp)
+template <int FMT, bool DEFER = false>
 __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e,
-                                             Planes6 wv6) {
+                                             Planes6 wv6, RmsTail rt) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int row0 = wave * 2;
@@ -392,7 +406,15 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
     w = wv; local = row0 - e.dim - e.kv_dim; m = e.kv_dim;
   }
   QkvPre pre{};
-  if (lane == 0) pre = qkv_preload(e, row0);
+  RmsReq rq{0.f, 0.f};
+  if constexpr (DEFER) {
+    // (every lane loads the pair's rotation -- one address -- instead of lane 0 alone: with the chunk sums requested next to it, a
+    // load inside a lane-predicated branch would make the wave wait for all of them before its first weight request)
+    pre = qkv_preload_nb(e, row0);
+    rq = rms_request(rt, lane);
+  } else {
+    if (lane == 0) pre = qkv_preload(e, row0);
+  }
   float acc[2];
   bool done = false;
   if constexpr (FMT == CRABML_HIP_Q4_K) {
@@ -403,6 +425,11 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
   }
   if (!done) rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
+  if constexpr (DEFER) {
+    const float inv_rms = rms_finish(rt, rq, lane);
+    s0 *= inv_rms;
+    s1 *= inv_rms;
+  }
   if (lane == 0) qkv_epilogue(e, pre, row0, s0, s1);
 }
 // strict order (CRABML_HIP_FLAG_STRICT_ORDER, Q4_0 / Q8_0 / Q4_1 layers): the same launch with the block terms parked in LDS and

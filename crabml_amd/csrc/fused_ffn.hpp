@@ -187,6 +187,7 @@ struct NormGather {
   const int* serial;          // decode-step serial number (never reset): makes the epoch unique per launch
   int* fault;
   int nseg, seg;
+  float* sums;                // DEFER launches: the chunk sums of squares go here as plain floats (read by the NEXT launch)
 };
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -195,7 +196,9 @@ __device__ __forceinline__ unsigned long long ld_granule(const unsigned long lon
 // The tail of the wo / ffn_down kernels (k_gemv_res_nq, k_ffn): acc[] = this wave's RW row dots.  Publishes the
 // workgroup's rows / sum of squares, takes the one in-launch hop, normalizes + quantizes the rows it owns.
 // wg_index / nwg_all: this workgroup's index among the SPLIT * nchunks workgroups of the stage.
-template <int FMT, int SPLIT, bool TP = false>
+// DEFER (the fast step's hop-free norm, gemv_core.hpp `RmsTail`; Q8_0 rhs, one workgroup per chunk): no gather.  The workgroup
+// quantizes x * w_norm of its own 32 rows and leaves its chunk's sum of squares for the consuming launch.
+template <int FMT, int SPLIT, bool TP = false, bool DEFER = false>
 __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
                                             float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
                                             void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
@@ -258,6 +261,56 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     } else {
       cs = h0;
     }
+  }
+  if constexpr (DEFER) {
+    static_assert(!DEFER || (!KQ && !Q81 && !TP), "the hop-free epilogue: Q8_0 rhs");
+    // the chunk (SPLIT == 2: half-chunk) sum of squares for the consuming launch -- a plain store, read after the kernel boundary
+    if (lane == 0) ng.sums[wg_index] = cs;
+    float v;
+    if (SPLIT > 1) {
+      // the block's other 16 rows live in the partner workgroup: ONE pairwise hand-off (its row granules), no gather of the row
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): our own granules are on their way before the polls queue up behind them
+      const int l32d = lane & 31;
+      const bool ownd = l32d >= part * ROWS && l32d < (part + 1) * ROWS;
+      v = 0.0f;
+      if (lane < 32) {
+        if (ownd) {
+          v = hv[l32d];
+        } else {
+          const unsigned long long* p = ng.pair + blk * 32 + l32d;
+          unsigned long long g = ld_granule(p);
+          int tries = 0;
+          while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+            __builtin_amdgcn_s_sleep(1);
+            g = ld_granule(p);
+            tries++;
+          }
+          if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;
+          v = __builtin_bit_cast(float, (unsigned)g);
+        }
+      }
+      v = __shfl(v, lane & 31, 64);  // (the upper half quantizes a copy, as everywhere)
+      const QLane o = quant_lane32<false>(v * wn, true);
+      if (lane < 32 && ownd) {
+        q[blk * 32 + lane] = o.q;
+        if (l32d == part * ROWS) {  // (both halves computed the same block scale / sum: part 0 stores them)
+          if (part == 0) {
+            ((unsigned short*)d)[blk] = o.d;
+            ((int*)isum)[blk] = o.aux;
+          }
+        }
+      }
+    } else {
+      const QLane o = quant_lane32<false>(hv[lane & 31] * wn, true);
+      if (lane < 32) {
+        q[blk * 32 + lane] = o.q;
+        if (lane == 0) {
+          ((unsigned short*)d)[blk] = o.d;
+          ((int*)isum)[blk] = o.aux;
+        }
+      }
+    }
+    return;
   }
   if (lane == 0)
     __hip_atomic_store(ng.slots + wg_index, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
@@ -342,7 +395,7 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
 
 // QIN (Q4_K): 0 = the rhs planes are read from global memory; 1 = the rhs arrives as f32 (xin) and is quantized into LDS
 // by this workgroup; 2 = the finished planes (act) are copied into LDS
-template <int FMT, int SPLIT, int QIN = 0, bool TP = false>
+template <int FMT, int SPLIT, int QIN = 0, bool TP = false, bool DEFER = false>
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
@@ -444,8 +497,8 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       }
     }
   }
-  nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave, (int)blockIdx.x,
-                              (int)gridDim.x, tp);
+  nq_epilogue<FMT, SPLIT, TP, DEFER>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
+                                     (int)blockIdx.x, (int)gridDim.x, tp);
 }
 
 // ---- strict order: wo / ffn_down + residual + the next RMSNorm + quantize in ONE launch, every sum in the reference's order ----------
@@ -701,16 +754,19 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
 // workgroups (448 for Llama-3-8B) are all resident at once (2 per CU).  Saves a launch per layer.
 // (Round 3: two units per row in flight -- 8 weight loads per lane and step -- measured slower on the full grid, 12.9 -> 14.6 us,
 // and on a tensor-parallel rank's 112 workgroups, 10.65 -> 11.35 us: a CU's ~26 GB/s is not a matter of bytes in flight.)
-template <int FMT>
+// DEFER: the rhs planes come from a hop-free wo launch -- the row dots are multiplied by 1 / rms (RmsTail, gemv_core.hpp)
+template <int FMT, bool DEFER = false>
 __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typename ActOf<FMT>::type act,
                                                    const unsigned short* __restrict__ exp_tab, signed char* __restrict__ q,
-                                                   unsigned short* __restrict__ d, void* __restrict__ isum, int nb) {
+                                                   unsigned short* __restrict__ d, void* __restrict__ isum, int nb, RmsTail rt) {
   using F = BlockFmt<FMT>;
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   __shared__ float hv[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.x;
   const int row = blk * 32 + wave * 2;  // rows row, row+1
+  RmsReq rq{0.f, 0.f};
+  if constexpr (DEFER) rq = rms_request(rt, lane);
   float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
   const int nu = nb * F::UNITS;
   for (int u = lane; u < nu; u += 64) {
@@ -728,6 +784,13 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typenam
   u0 = wave_sum_f32(u0);
   g1 = wave_sum_f32(g1);
   u1 = wave_sum_f32(u1);
+  if constexpr (DEFER) {
+    const float inv_rms = rms_finish(rt, rq, lane);
+    g0 *= inv_rms;
+    u0 *= inv_rms;
+    g1 *= inv_rms;
+    u1 *= inv_rms;
+  }
   if (lane == 0) {
     hv[wave * 2] = silu_mul(g0, u0, exp_tab);
     hv[wave * 2 + 1] = silu_mul(g1, u1, exp_tab);

@@ -55,6 +55,40 @@ struct ActQ8_K {
   const short* bsums;
 };
 
+// ---- the fast step's hop-free norm: 1 / rms applied by the CONSUMER of the quantized row ------------------------------------
+// RMSNorm divides the whole row by one number, and the truncating rhs quantizer's levels q = trunc(v / (max|v| / 127))
+// (buf_q8_0.rs:119-124) do not depend on a common factor of v.  So the wo / ffn_down launch that produces the residual row x
+// quantizes x * w_norm block by block (no in-launch gather of the row's sum of squares), stores the block scale f16(max|x w| /
+// 127) in the ordinary d plane together with its chunk's sum of squares of x, and every consuming GEMV multiplies its finished
+// row dots by 1 / rms -- a common factor of every block term -- formed from the chunk sums (each wave the same sum in the same
+// order; requested when the wave starts, reduced when its dots are done).  Against the exact form: the levels agree up to the
+// 126-vs-127 rounding of a block's largest element (which every re-associated GEMV sum of the fast step re-rolls anyway), the
+// block scales are f16(max|x w| / 127) / rms where the reference has f16(max|x w| / rms / 127): one f16 rounding either way.
+struct RmsTail {
+  const float* sums;  // n_sums partial sums of squares of the row, in chunk order
+  int n_sums;
+  float inv_n, eps;
+};
+struct RmsReq {
+  float v0, v1;
+};
+// (unconditional loads of clamped indices: a load inside a lane-predicated branch makes the compiler's wait-count pass drain every
+// outstanding load at the next divergent join -- in k_qkv that stalled each wave for a memory round trip before its first
+// weight request; the lanes past the row's chunks are masked when the values are used)
+__device__ __forceinline__ RmsReq rms_request(const RmsTail& t, int lane) {
+  const int last = t.n_sums - 1;
+  return RmsReq{t.sums[lane < last ? lane : last], t.sums[lane + 64 < last ? lane + 64 : last]};
+}
+// The tail of a consuming wave: kept short (one DPP tree, the hardware's reciprocal square root) because every wave of a launch
+// reaches it at about the same time -- nothing hides it.  A fixed lane-strided order + v_rsq_f32: every wave of every consumer
+// forms the same bits (the scale is a common factor; its last-ulp value is not the reference's -- nor is anything else here).
+__device__ __forceinline__ float rms_finish(const RmsTail& t, const RmsReq& r, int lane) {
+  float part = (lane < t.n_sums ? r.v0 : 0.0f) + (lane + 64 < t.n_sums ? r.v1 : 0.0f);
+  for (int base = 128; base < t.n_sums; base += 64)  // rows past 4096 elements
+    part += base + lane < t.n_sums ? t.sums[base + lane] : 0.0f;
+  return __builtin_amdgcn_rsqf(wave_sum_f32(part) * t.inv_n + t.eps);
+}
+
 // ---- per-format access for the 32-element formats whose rhs is Q8_0 --------------------------------------
 // A lane processes one 16-byte UNIT of quants per step, so that a wave's weight load is always one aligned 1 KiB
 // request: a whole Q4_0 block (32 nibbles), or HALF a Q8_0 block (16 int8; the two lanes of a block add their

@@ -187,6 +187,18 @@ def use_more_bits(i_layer: int, n_layers: int) -> bool:
     return i_layer < n_layers // 8 or i_layer >= 7 * n_layers // 8 or (i_layer - n_layers // 8) % 3 == 2
 
 
+def flip_scale_signs(model: "RawModel", seed: int = 5) -> None:
+    """Q4_0 blocks with d of EITHER sign, in place (what a quantizer that divides by the signed maximum produces,
+    buf_q4_0.rs:96-104).  random_blocks draws every d > 0, i.e. a mean level of -0.5 d: a common-mode component in every GEMV,
+    which a metric relative to max|logit| rewards.  Zero-mean weights are the hard case for any re-association / re-rounding
+    (profiles/r04_reference_order_sensitivity.log: the reference's own scalar and AVX2 builds differ by 7-10 % of max|logit| there)."""
+    rng = np.random.default_rng(seed)
+    for t in model.tensors.values():
+        if t.typ == Q4_0:
+            blk = t.data.reshape(-1, 18)
+            blk[:, 1] ^= (rng.integers(0, 2, size=blk.shape[0], dtype=np.uint8) << 7)
+
+
 def build_model(shape: ModelShape, wtype: int, seed: int = 8, n_layers: Optional[int] = None,
                 embed_type: Optional[int] = None, tp: int = 1, output_type: Optional[int] = None,
                 k_m_mix: bool = False, tp_split_vocab: bool = False) -> RawModel:

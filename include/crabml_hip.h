@@ -213,6 +213,11 @@ typedef struct crabml_hip_llama crabml_hip_llama_t;
                                           f16-accumulated PV chain (buf_f16.rs:152-163) instead of the split-KV kernels that
                                           accumulate the same f16 products in f32 (DESIGN.md 2.2 states the deviation and its
                                           measured size).  Strict-order devices always run the exact chain. */
+#define CRABML_HIP_LLAMA_EXACT_NORM 8388608 /* fast mode, Q4_0 / Q8_0 layers: keep RMSNorm's division inside the launch that produces the row
+                                          (one in-launch gather of the chunk sums per wo launch) instead of handing 1 / rms to the consuming
+                                          launch -- which quantizes x * w per block first and scales the block scale afterwards: the same
+                                          levels up to the 126-vs-127 rounding of a block's largest element.  Strict-order
+                                          devices always keep the exact form. */
 #define CRABML_HIP_LLAMA_TP_SPLIT_VOCAB 1048576 /* tp_size > 1 (P2P group, or the single-device simulation): the classifier is split by
                                           vocabulary -- weights.output_weight holds rows [tp_rank V / tp_size,
                                           (tp_rank + 1) V / tp_size) of output.weight (V % tp_size == 0, not tied to token_embed);

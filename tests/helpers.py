@@ -43,6 +43,10 @@ def gemv_order_bound(w_raw, wtyp, x, m, k):
     return np.abs(wd) @ np.abs(x.astype(np.float64))
 
 
+# CRABML_HIP_LLAMA_EXACT_NORM: the fast step keeps RMSNorm's division in the producing launch (in-launch gather) -- the form whose
+# variants (own launch / epilogue / split chunks) are bit-identical to each other; the default hands 1 / rms to the consumer
+EXACT_NORM = 8388608
+
 GEMV_REL = 2e-5  # f32 re-association bound factor: |gpu - oracle| <= GEMV_REL * sum_i |w_i x_i| + tiny
 
 # End-to-end tolerance of the FAST kernels PER WEIGHT FORMAT: (median, max) over the tested steps of

@@ -20,7 +20,7 @@ import pytest
 
 from crabml_amd import synth, tp as tp_mod
 from oracle import oracle as o
-from tests.helpers import to_oracle
+from tests.helpers import EXACT_NORM, to_oracle
 from tests.test_hip_tp_p2p import spawn
 
 pytestmark = pytest.mark.gpu
@@ -71,9 +71,10 @@ def test_c5_shape_fast_path_against_the_oracle(ca, c5):
         assert a_h == a_o or float(ref[i][a_o] - ref[i][a_h]) / scale <= 2 * errs[-1], (i, errs)
     assert max(errs) <= FAST_TOL, errs
     # without the norm epilogue (k_norm_quant<12> as its own launch) and with split chunks forced: same bits
-    for kw in ({"norm_epilogue": False}, {"extra_flags": 16}, {"extra_flags": 32}):
+    # (RMSNorm's division kept in the producing launch: EXACT_NORM -- the default hands 1 / rms to the consuming launch)
+    for kw in ({"norm_epilogue": False}, {"extra_flags": 16 + EXACT_NORM}, {"extra_flags": 32 + EXACT_NORM}):
         g = ca.HipLlamaRunner(conf, w, dev, 64, True, True, True, **kw)
-        h = ca.HipLlamaRunner(conf, w, dev, 64, True)
+        h = ca.HipLlamaRunner(conf, w, dev, 64, True, extra_flags=EXACT_NORM)
         for i, t in enumerate(TOKS[:2]):
             assert np.array_equal(g.forward(t, i).view(np.uint32), h.forward(t, i).view(np.uint32)), (kw, i)
 
