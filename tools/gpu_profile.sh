@@ -17,6 +17,6 @@ python $REPO/tools/rocpd_summary.py "$DB" >> $OUT/kernel_trace_$TAG.md 2>> $OUT/
 head -22 $OUT/kernel_trace_$TAG.md
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -- python $REPO/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-parity-check --no-context --no-prefill --no-c3 --no-gemv-points $* > /dev/null 2>> $OUT/prof_$TAG.err
 DB2=$(find $OUT/pmc_$TAG -name "*_results.db" | head -1)
-cd $REPO && python tools/pmc_traffic.py "$DB2" $OUT/pmc_fetch_size_$TAG.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic_$TAG.json
+cd $REPO && python tools/pmc_traffic.py "$DB2" $OUT/${TAG}_pmc_fetch_size.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic_$TAG.json
 # keep the merge small
 find $OUT/prof_$TAG $OUT/pmc_$TAG -name "*.db" -size +20M -delete

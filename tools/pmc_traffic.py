@@ -36,7 +36,9 @@ def main():
     if kib is None:
         sys.exit(f"{KERNEL} not found in the PMC table")
     hbm = int(round(kib * 1024 * 2))
-    out = {"source": (md_out or dbs[0]) + " (rocprofv3 --pmc FETCH_SIZE, separate pass; FETCH_SIZE KiB x 1024 x 2 gfx950 correction)",
+    # the tracked copy of the table: gpu_profile.sh writes gpurun_out/<tag>_pmc_fetch_size.md, which is committed as profiles/<same name>
+    tracked = "profiles/" + os.path.basename(md_out) if md_out else os.path.basename(dbs[0])
+    out = {"source": tracked + " (rocprofv3 --pmc FETCH_SIZE, separate pass; FETCH_SIZE KiB x 1024 x 2 gfx950 correction)",
            "dominant_kernel": KERNEL + "<Q4_0>", "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": ALGO_BYTES,
            "ratio": round(hbm / ALGO_BYTES, 4), "kernel_code_hash": bench.kernel_code_hash()}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
