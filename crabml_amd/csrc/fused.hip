@@ -592,8 +592,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(&pr, 1, total_rows, dim));
-    // (the planes of layer l > 0 come from the previous layer's ffn_down launch: dim / 32 chunk sums, or dim / 16 halves)
-    const RmsTail rtq{c->rsums, split_of(hidden_l) == 2 ? dim / 16 : dim / 32, 1.0f / (float)dim, g.rms_norm_eps};
+    // (the planes of layer l > 0 come from the previous layer's ffn_down launch, with its dim / 32 chunk sums)
+    const RmsTail rtq{c->rsums, dim / 32, 1.0f / (float)dim, g.rms_norm_eps};
     if (c->ord)
       launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * ((dim / 32 + 3) & ~3) * sizeof(float), planes_of(c->wq[l]),
                planes_of(c->wk[l]), planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e);
@@ -618,7 +618,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     const float* wnext_down = (const float*)(l + 1 < L ? c->rms_att[l + 1] : c->rms_final)->ptr;
     // gate / up + silu * mul (llama2.rs:620-630), local rows
     CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
-    const RmsTail rt{c->rsums, split_of(dim_l) == 2 ? dim / 16 : dim / 32, 1.0f / (float)dim, 1e-5f};  // eps: the literal 1e-5 (llama2.rs:611)
+    const RmsTail rt{c->rsums, dim / 32, 1.0f / (float)dim, 1e-5f};  // eps: the literal 1e-5 (llama2.rs:611)
     if (c->ord)
       launch_k(st, R, k_gateup_q_ord<FMT>, dim3(hidden_l / 32), dim3(1024), (size_t)64 * (((dim / 32 + 3) & ~3) + 4) * sizeof(float), planes_of(c->gate[l]),
                planes_of(c->up[l]), act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);

@@ -423,10 +423,14 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
       done = true;
     }
   }
-  if (!done) rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
+  float inv_rms = 1.0f;
+  if constexpr (DEFER && FMT != CRABML_HIP_Q4_K) {
+    inv_rms = rows_partial_rms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc, rt, rq);
+  } else {
+    if (!done) rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
+  }
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);
   if constexpr (DEFER) {
-    const float inv_rms = rms_finish(rt, rq, lane);
     s0 *= inv_rms;
     s1 *= inv_rms;
   }

@@ -264,8 +264,8 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
   }
   if constexpr (DEFER) {
     static_assert(!DEFER || (!KQ && !Q81 && !TP), "the hop-free epilogue: Q8_0 rhs");
-    // the chunk (SPLIT == 2: half-chunk) sum of squares for the consuming launch -- a plain store, read after the kernel boundary
-    if (lane == 0) ng.sums[wg_index] = cs;
+    // the chunk's sum of squares for the consuming launch -- a plain store, read after the kernel boundary
+    if (SPLIT == 1 && lane == 0) ng.sums[blk] = cs;
     float v;
     if (SPLIT > 1) {
       // the block's other 16 rows live in the partner workgroup: ONE pairwise hand-off (its row granules), no gather of the row
@@ -290,6 +290,15 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
         }
       }
       v = __shfl(v, lane & 31, 64);  // (the upper half quantizes a copy, as everywhere)
+      // both halves hold the block's 32 rows now: ONE sum of squares per chunk (every consuming wave reads all of them: half
+      // as many is 512 bytes less per wave), the same tree in both workgroups; part 0 stores it
+      {
+        // (the cross-lane reads stay OUTSIDE the lane-0 branch: the compiler sinks the last add of the tree into a branch that only
+        // lane 0 executes, and v_readlane then picks up lane 16's unfinished value)
+        const float sq = row16_sum_f32(v * v);
+        const float tot = rl_f(sq, 0) + rl_f(sq, 16);
+        if (lane == 0 && part == 0) ng.sums[blk] = tot;
+      }
       const QLane o = quant_lane32<false>(v * wn, true);
       if (lane < 32 && ownd) {
         q[blk * 32 + lane] = o.q;
@@ -769,23 +778,51 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typenam
   if constexpr (DEFER) rq = rms_request(rt, lane);
   float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
   const int nu = nb * F::UNITS;
-  for (int u = lane; u < nu; u += 64) {
-    typename F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, u);
-    typename F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, u);
-    typename F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
-    typename F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
-    const XUnit x = F::loadx(act, u);
-    g0 += F::term(bg0, x);
-    u0 += F::term(bu0, x);
-    g1 += F::term(bg1, x);
-    u1 += F::term(bu1, x);
+  float inv_rms = 1.0f;
+  if constexpr (DEFER) {
+    // a uniform trip count (lanes past the row's units redo the last one and add nothing), so that the whole wave can reduce the
+    // chunk sums INSIDE the first step -- behind its weight requests, while they are in flight: everything a wave does after its
+    // last step sits on the launch's critical path (all workgroups are resident at once and finish together)
+    for (int u0i = 0; u0i < nu; u0i += 64) {
+      const int u = u0i + lane;
+      const bool live = u < nu;
+      const int uu = live ? u : nu - 1;
+      typename F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, uu);
+      typename F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, uu);
+      typename F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, uu);
+      typename F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, uu);
+      const XUnit x = F::loadx(act, uu);
+      if (u0i == 0) {
+        // (pinned behind this step's requests: the empty asm keeps the reduction from being hoisted out of the loop, the scheduling
+        // barrier from being moved above the loads)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(rq.v0), "+v"(rq.v1));
+        inv_rms = rms_finish(rt, rq, lane);
+      }
+      const float t0 = F::term(bg0, x), t1 = F::term(bu0, x), t2 = F::term(bg1, x), t3 = F::term(bu1, x);
+      g0 += live ? t0 : 0.0f;
+      u0 += live ? t1 : 0.0f;
+      g1 += live ? t2 : 0.0f;
+      u1 += live ? t3 : 0.0f;
+    }
+  } else {
+    for (int u = lane; u < nu; u += 64) {
+      typename F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, u);
+      typename F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, u);
+      typename F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
+      typename F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
+      const XUnit x = F::loadx(act, u);
+      g0 += F::term(bg0, x);
+      u0 += F::term(bu0, x);
+      g1 += F::term(bg1, x);
+      u1 += F::term(bu1, x);
+    }
   }
   g0 = wave_sum_f32(g0);
   u0 = wave_sum_f32(u0);
   g1 = wave_sum_f32(g1);
   u1 = wave_sum_f32(u1);
   if constexpr (DEFER) {
-    const float inv_rms = rms_finish(rt, rq, lane);
     g0 *= inv_rms;
     u0 *= inv_rms;
     g1 *= inv_rms;

@@ -199,6 +199,45 @@ __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const
   }
 }
 
+// rows_partial for a wave that also has to form 1 / rms from the chunk sums it requested when it started (RmsTail): a uniform trip
+// count (lanes past the row's units redo the last one and add nothing) so that the whole wave can run the reduction INSIDE the
+// first step -- behind that step's weight requests, while they are in flight.  After its last step a wave is on the launch's
+// critical path; in the first step it is waiting for memory anyway.
+template <int FMT, int R, class ACT>
+__device__ __forceinline__ float rows_partial_rms(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd, const ACT& act,
+                                                  int row0, int m, int nb, int lane, float acc[R], const RmsTail& rt, RmsReq rq) {
+  using F = BlockFmt<FMT>;
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int nu = nb * F::UNITS;
+  float inv_rms = 1.0f;
+  for (int u0 = 0; u0 < nu; u0 += 64) {
+    const int u = u0 + lane;
+    const bool live = u < nu;  // (Q8_0: nu is even, the two lanes of a block are live or dead together)
+    const int uu = live ? u : nu - 1;
+    typename F::Blk blk[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row = row0 + r < m ? row0 + r : m - 1;
+      blk[r] = F::load(wq, wd, (size_t)row, nb, uu);
+    }
+    const XUnit x = F::loadx(act, uu);
+    if (u0 == 0) {
+      // (pinned behind this step's requests: the empty asm keeps the reduction from being hoisted out of the loop, the scheduling
+      // barrier from being moved above the loads)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(rq.v0), "+v"(rq.v1));
+      inv_rms = rms_finish(rt, rq, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float t = F::term(blk[r], x);
+      acc[r] += live ? t : 0.0f;
+    }
+  }
+  return inv_rms;
+}
+
 // ---- strict order at streaming speed: the block terms of R rows into a term table, then one lane per row adds them in block order ----
 // (CRABML_HIP_FLAG_STRICT_ORDER.)  The reference's scalar dot of these formats is `sumf = 0; for block: sumf += term(block)` with one
 // f32 term per block (buf_q4_0.rs:240-253, buf_q8_0.rs:275-286, buf_q4_1.rs:266-280): the terms are evaluated exactly as the fast
