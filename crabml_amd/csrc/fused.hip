@@ -1152,7 +1152,9 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const int pairs = (dim + 2 * kv_dim) / 2;
     k_qkv_epi_rows<<<dim3((pairs + 255) / 256, rows), 256, 0, st>>>(c->pf_q, c->pf_k, c->pf_v, e);
     int along = 0;
-    if (c->attn_flash_rows && kv16) {
+    // (a pass whose every row sees fewer cached positions than the decode step's switch to the f32 kernels -- attn_long_from --
+    // keeps the exact tile kernel, so that prefill(prompt) and a token loop over the same short prompt agree bit for bit)
+    if (c->attn_flash_rows && kv16 && pos0 + B >= c->attn_long_from) {
       // fast step: causal flash attention on the f16 matrix cores (k_attn_flash_rows; the deviation stated for k_attn_flash)
       const dim3 fg((unsigned)((B + 63) / 64), (unsigned)n_heads);
       if (hd == 128)

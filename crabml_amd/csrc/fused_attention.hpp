@@ -1302,9 +1302,11 @@ __global__ __launch_bounds__(512) void k_attn_flash_rows(const float* __restrict
   lsum += __shfl_xor(lsum, 32);
   // ---- the two waves of a pair meet: the odd-step wave hands {m, l, O} over through LDS (the tiles are done with: the loop's last
   // barrier is behind every wave), the even-step wave merges and stores
-  float* xch = (float*)fr_lds + (size_t)rw * 64 * (4 * DT + 2);  // [lane][4 DT + 2] floats per row group
+  // [lane][4 DT + 4] floats per row group: {O, m, l} padded to whole 16-byte pieces, so that the f32x4 accesses of every lane are
+  // 16-byte aligned (a record of 4 DT + 2 floats put the odd lanes on 8-byte boundaries)
+  float* xch = (float*)fr_lds + (size_t)rw * 64 * (4 * DT + 4);
   if (par == 1) {
-    float* d = xch + lane * (4 * DT + 2);
+    float* d = xch + lane * (4 * DT + 4);
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) *(f32x4*)(d + 4 * dt) = acc[dt];
     d[4 * DT] = m;
@@ -1312,7 +1314,7 @@ __global__ __launch_bounds__(512) void k_attn_flash_rows(const float* __restrict
   }
   __syncthreads();
   if (par == 0 && row_w + n < B) {
-    const float* d = xch + lane * (4 * DT + 2);
+    const float* d = xch + lane * (4 * DT + 4);
     const float m1 = d[4 * DT], l1 = d[4 * DT + 1];
     const float M = fmaxf(m, m1);  // (m is finite: the even-step wave saw position 0; m1 = -inf if the odd wave saw nothing)
     const float w0 = __expf(m - M), w1 = m1 == -INFINITY ? 0.0f : __expf(m1 - M);

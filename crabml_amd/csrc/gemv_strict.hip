@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q3k(const char* __restrict__
 }
 
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
-                       float* out, const float* add) {
+                       float* out, const float* add_all) {
   const uint32_t qt = vec_dot_rhs_dtype(w->dtype);
   if (qt == 0xffffffffu) return set_error(dev, CRABML_HIP_TENSOR_ERROR, "matmul_vec: unsupported weight dtype %u", w->dtype);
   const ActLayout al = act_layout(qt, k);
@@ -698,6 +698,7 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
   for (size_t bi = 0; bi < b; bi++) {
     const char* ap = (const char*)act + bi * act_stride;
     float* o = out + bi * m;
+    const float* add = add_all ? add_all + bi * m : nullptr;  // the residual row of THIS batch row
     bool done = false;
     if (!scalar_only && lds <= 48 * 1024 && block_elems(w->dtype) > 1) {
       done = true;

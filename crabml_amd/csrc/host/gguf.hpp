@@ -15,6 +15,7 @@
 // Llama architecture only, like the rest of this host layer.  The tensor bytes go to the device straight from the
 // mapping (Tensor::from_cpu -> crabml_hip_buf_from_cpu: chunked H2D + plane repack on the device).
 #pragma once
+#include <cstdio>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -377,6 +378,16 @@ inline HipTensor load_gguf_tensor(const GGUFFile& gf, const std::string& name, c
       throw Error(ErrorKind::FormatError, "tensor " + name + " " + fmt_dims(dims) + ": element count overflows");
   if (dims.empty() || n % be != 0 || dims.back() % be != 0)
     throw Error(ErrorKind::TensorError, "tensor " + name + " " + fmt_dims(dims) + " is not a whole number of blocks per row");
+  if (info->ggml_type == 13) {
+    // Q5_K is read in the REFERENCE's field order (qs | qh | scales | d | dmin, buf_q5_k.rs:13-21), which is not ggml's
+    // (d | dmin | scales | qh | qs): a llama.cpp Q5_K / *_K_M file decodes to garbage in crabml, and identically here.  Say so, once.
+    static bool warned = false;
+    if (!warned) {
+      warned = true;
+      fprintf(stderr, "crabml_hip: WARNING: %s is Q5_K; blocks are read in crabml's own field order (buf_q5_k.rs:13-21), NOT ggml's -- a file "
+                      "written by llama.cpp decodes wrongly (as it does in the reference)\n", name.c_str());
+    }
+  }
   const size_t nbytes = n / be * bb;
   if (nbytes > info->data_len) throw Error(ErrorKind::FormatError, "tensor " + name + " needs " + std::to_string(nbytes) + " bytes, the file holds " + std::to_string(info->data_len));
   return HipTensor::from_cpu(info->data, nbytes, dims, (GGMLType)info->ggml_type, device);
