@@ -55,6 +55,11 @@ def _rand_bytes(rng: np.random.Generator, n: int) -> np.ndarray:
     return out
 
 
+# Q4_1 blocks with m drawn independently of d (rounds 1-3): a large common offset in every GEMV, which makes relative logit errors
+# small -- the fast kernels were pinned at (1.5e-3, 2e-3) on these weights, and one test keeps that pin (tests/test_hip_fused.py)
+Q4_1_INDEPENDENT_M = False
+
+
 def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: float = 1.0) -> np.ndarray:
     """Raw bytes (uint8) of n_elems elements in GGML layout `typ`, filled with random quants."""
     be, bb = BLOCK_ELEMS[typ], BLOCK_BYTES[typ]
@@ -79,7 +84,10 @@ def random_blocks(rng: np.random.Generator, n_elems: int, typ: int, scale_mul: f
         # until the f16 KV cache overflows (NaN logits at the 8B depth with the independent m of rounds 1-3)
         d16 = _f16_scales(rng, nb, lo, hi)
         out[:, 0:2] = d16.reshape(nb, 1).view(np.uint8)
-        m = -7.5 * d16.view(np.float16).astype(np.float32) * rng.uniform(0.9, 1.1, size=nb).astype(np.float32)
+        if Q4_1_INDEPENDENT_M:
+            m = -rng.uniform(8 * lo, 8 * hi, size=nb)
+        else:
+            m = -7.5 * d16.view(np.float16).astype(np.float32) * rng.uniform(0.9, 1.1, size=nb).astype(np.float32)
         out[:, 2:4] = m.astype(np.float16).view(np.uint16).reshape(nb, 1).view(np.uint8)
         out[:, 4:] = rng.integers(0, 256, size=(nb, 16), dtype=np.uint8)
     elif typ == Q4_K:

@@ -110,6 +110,16 @@ def check_fast(key, fmt, err):
         pass
     med, mx = FAST_TOL[fmt]
     assert np.median(err) <= med and np.max(err) <= mx, (key, err)
+    if fmt in ROUND_TO_NEAREST:
+        # a second gate for the formats whose rhs quantizer rounds to nearest: the max bound has to admit a step with ONE flipped
+        # quant (above), but flips are rare events -- a change that corrupts many steps by a flip-sized amount must not hide under it
+        flips = int(np.sum(err > FLIP_SIZED))
+        assert flips <= max(3, err.size // 4), (key, "flip-sized steps", flips, err)
+
+
+# K-quants: the rhs quantizer (buf_q8_k.rs:84-131) rounds half away from zero; a step without a flipped quant sits at ~2e-7
+ROUND_TO_NEAREST = ("Q4_K", "Q5_K", "Q6_K", "Q8_K", "Q2_K", "Q3_K")
+FLIP_SIZED = 1e-4
 
 
 # ---- an independent (pure Python) GGUF reader for the checker side ------------------------------------------------------

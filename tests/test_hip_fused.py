@@ -546,3 +546,21 @@ def test_three_thousand_token_decode_across_every_attention_regime(ca):
         else:
             a2.forward_async(toks[i], i)
             b2.forward_async(toks[i], i)
+
+
+def test_q4_1_kernels_on_offset_weights_keep_the_tight_pin(ca):
+    """Q4_1 blocks whose m is drawn independently of d (the synthetic weights of rounds 1-3): the common offset makes the
+    relative logit error small, so the fast kernels are pinned at the tolerance they were tuned under, (1.5e-3, 2e-3) -- 20 x
+    tighter than FAST_TOL's row for the zero-mean blocks the other tests use."""
+    synth.Q4_1_INDEPENDENT_M = True
+    try:
+        model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_1, seed=12)
+    finally:
+        synth.Q4_1_INDEPENDENT_M = False
+    toks = PROMPT + [3, 5, 8, 13, 21, 34]
+    ref, _ = oracle_logits(model, True, toks)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    f = ca.HipLlamaRunner(conf, w, dev, 64, True)
+    err = rel_errs([f.forward(t, i).copy() for i, t in enumerate(toks)], ref)
+    assert np.median(err) <= 1.5e-3 and np.max(err) <= 2e-3, err
