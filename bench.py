@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--output-type", default=None,
                     help="GGML type of output.weight when it differs from --wtype (llama.cpp's Q4_0 files: Q6_K)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncate the layer count (INVALID as a result)")
+    ap.add_argument("--no-affinity", action="store_true", help="do not move the process to the GPU's NUMA node")
+    ap.add_argument("--no-trait", action="store_true", help="skip the reference-API leg (traced runs)")
     ap.add_argument("--path", default="auto", choices=["auto", "trait", "fused"],
                     help="trait = one launch per Tensor op (Llama2Runner unchanged); fused = fused decode step")
     ap.add_argument("--no-norm-epilogue", action="store_true", help="A/B: keep RMSNorm+quantize as its own launch")
@@ -628,6 +630,16 @@ def main():
     t_upload = time.perf_counter() - t_upload
     t_build = time.perf_counter() - t_build
     seq_len = max(args.warmup + 2 * args.steps + 16, 144)
+    # host placement: run this process's threads on the NUMA node the GPU is attached to (what `numactl --cpunodebind` would do).
+    # The fused entry point does not care (one blocking call for K tokens); a host that drives the device token by token -- the
+    # reference's runner -- does: launches, the logits in pinned memory and the completion flag cross the socket otherwise
+    # (tools/trait_var.py: 670-735 tok/s from the far socket, 760 from the near one, same box).
+    host_affinity = None
+    if not args.no_affinity:
+        try:
+            host_affinity = ca.pin_host_to_device_node(dev)
+        except Exception as e:  # pragma: no cover
+            host_affinity = "unchanged (" + repr(e) + ")"
     trait_seq = max(seq_len, args.warmup + 3 * max(args.steps, 16) + 16)
     trait = ca.Llama2Runner(conf, weights, dev, trait_seq, True)  # f16 KV cache = the CLI default (main.rs:250)
     path = args.path
@@ -690,7 +702,7 @@ def main():
     # the same runner on a device that launches every call immediately (ABI version 1, "per-op") is timed next to it.
     trait_tps = None
     trait_info = None
-    if rank == 0 and path == "fused":
+    if rank == 0 and path == "fused" and not args.no_trait:
         n_t = max(args.steps, 16)
         st0 = dev.lazy_stats()
         t_tok = int(trait.timed_decode(1, args.warmup if args.warmup > 0 else 2)[0][-1])
@@ -889,6 +901,7 @@ def main():
                               "note": "prompt of that length prefilled in batched passes, then 32 timed greedy steps"}
         if c3:
             out["c3_positions_0_127"] = c3
+        out["config"]["host_affinity"] = host_affinity
         out["value_api"] = ("crabml_hip_llama_decode_greedy: the fused step from its hipGraph, arg-max on the device, one blocking call for K tokens" if path == "fused"
                             else "Llama2Runner<HipTensor>::forward per token")
         if trait_tps is not None:

@@ -26,4 +26,24 @@ from ._host import (  # noqa: E402,F401
 )
 
 __all__ = ["CrabmlError", "GGMLType", "GGUFFile", "HipLlamaRunner", "HipTensor", "HipTensorDevice", "Llama2Runner", "LlamaConfig", "LlamaWeights",
-           "RopeMode", "TensorStrider", "TpComm", "abi_version", "sample_argmax", "LIB_PATH"]
+           "RopeMode", "TensorStrider", "TpComm", "abi_version", "sample_argmax", "pin_host_to_device_node", "LIB_PATH"]
+
+
+def pin_host_to_device_node(device):
+    """Runs this process's threads on the host NUMA node the GPU is attached to (what `numactl --cpunodebind` does) and says what
+    it did.  The fused entry points do not care where the host sits; a host that drives the device token by token -- the
+    reference's runner: ~840 recorded calls, 160 launches, a completion flag and 513 KB of logits per token -- is 5-10 % faster
+    from the near socket (tools/trait_var.py)."""
+    node = device.numa_node()
+    if node < 0:
+        return "unchanged (the device's NUMA node is unknown)"
+    cpus = set()
+    with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+        for part in f.read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    cpus &= _os.sched_getaffinity(0)
+    if not cpus:
+        return "unchanged (no allowed cpu on NUMA node %d)" % node
+    _os.sched_setaffinity(0, cpus)
+    return "NUMA node %d of the GPU (%d cpus)" % (node, len(cpus))

@@ -118,6 +118,7 @@ struct crabml_hip_device {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int n_cu = 256;
+  int numa_node = -1;         // the host NUMA node the GPU hangs off (sysfs), -1 = unknown
   bool strict_order = false;  // CRABML_HIP_FLAG_STRICT_ORDER
   std::mutex mu;
   std::string last_error;

@@ -111,7 +111,6 @@ struct crabml_hip_llama {
   float* attn = nullptr;     // attention output (dim_l)
   float* h = nullptr;        // ffn hidden (hidden_l), strict mode only
   float* logits = nullptr;   // vocab
-  float* logits_ext = nullptr;  // lazy.hip: the classifier of this step writes the caller's buffer instead
   float* host_logits = nullptr; // lazy.hip: pinned host copy of the logits, written by a kernel behind the classifier; the two words
                                 // behind the vocab_size floats are {sequence number of the step that wrote them, its fault word}
   unsigned out_seq = 0;         // sequence number of the last step whose logits were sent to host_logits
@@ -189,18 +188,20 @@ struct crabml_hip_llama {
 // ---- lazy.hip's context: token / position / serial of a step straight from kernel arguments (a launch on the stream's own queue:
 // no copy-engine hand-off in front of the step's first kernel), and the logits to pinned host memory by a kernel behind the
 // classifier, followed by a flag the host can spin on (no copy-engine hand-off, no interrupt-driven wait behind the step's last)
-__global__ void k_set_state5(int* __restrict__ st, int token, int pos, int step, int serial) {
+__global__ void k_set_state5(int* __restrict__ st, int token, int pos, int step, int serial, int out_seq) {
   st[0] = token;
   st[1] = pos;
   st[2] = step;
   st[4] = serial;
+  st[7] = out_seq;  // what k_host_flag raises when this step's logits have reached the host
 }
 __global__ __launch_bounds__(256) void k_logits_to_host(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int n4, const float* __restrict__ src1,
                                                         float* __restrict__ dst1, int n) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) __builtin_nontemporal_store(src[i], dst + i);
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst1[n4 * 4 + threadIdx.x] = src1[n4 * 4 + threadIdx.x];
 }
-__global__ void k_host_flag(unsigned* __restrict__ flag, unsigned seq, const int* __restrict__ fault) {
+__global__ void k_host_flag(unsigned* __restrict__ flag, const int* __restrict__ seq_d, const int* __restrict__ fault) {
+  const unsigned seq = (unsigned)*seq_d;  // (from device memory: the launch may be a node of the step's replayed graph)
   flag[1] = (unsigned)*fault;
   __threadfence_system();  // (the copy kernel has completed: stream order; this orders the fault word before the flag)
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -392,7 +393,7 @@ int enqueue_classifier_and_sampler(crabml_hip_llama* c, const void* cls_act, cra
   const auto& g = c->cfg;
   const int dim = (int)g.embedding_dim;
   int *token_d = c->state, *pos_d = c->state + 1, *step_d = c->state + 2;
-  float* out = (c->logits_ext ? c->logits_ext : c->logits) + c->vocab_off;
+  float* out = c->logits + c->vocab_off;
   if (dev->strict_order)
     CH_TRY(launch_gemv_strict(dev, c->output, (size_t)c->vocab_l, dim, cls_act, 1, out));
   else
@@ -400,10 +401,10 @@ int enqueue_classifier_and_sampler(crabml_hip_llama* c, const void* cls_act, cra
   if (c->ext_kv) {
     // a context driven by the recorded-op queue (lazy.hip): the HOST samples (Llama2Runner exports the logits and runs its own
     // sampler, llama2.rs:208), token / position / serial of the next step come from the host (lazy_ctx_begin) -- no sampler launch
-    if (c->host_logits != nullptr && c->logits_ext != nullptr) {
+    if (c->host_logits != nullptr) {
       const int n = c->vocab_l;
       k_logits_to_host<<<64, 256, 0, st>>>((const f32x4*)out, (f32x4*)c->host_logits, n / 4, out, c->host_logits, n);
-      k_host_flag<<<1, 1, 0, st>>>((unsigned*)(c->host_logits + c->cfg.vocab_size), ++c->out_seq, c->state + 5);
+      k_host_flag<<<1, 1, 0, st>>>((unsigned*)(c->host_logits + c->cfg.vocab_size), (const int*)(c->state + 7), c->state + 5);
     }
     CH_HIP(dev, hipGetLastError());
     return 0;
@@ -2178,24 +2179,31 @@ int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos) {
   // from it: the NEXT token's first segments would match the dropped token's granules.  So here the host owns the serial: every
   // begin sets a fresh even value, the sampler's own + 1 lands on the odd one in between.
   c->lazy_serial += 2;
-  static const bool by_copy = [] { const char* e = getenv("CRABML_HIP_LAZY_STATE_MEMCPY"); return e && e[0] == '1'; }();
-  if (by_copy) {
-    CH_TRY(set_state(c, token, pos, 0, &c->lazy_serial));
-  } else {
-    k_set_state5<<<1, 1, 0, c->dev->stream>>>(c->state, (int)token, (int)pos, 0, (int)c->lazy_serial);
-    CH_HIP(c->dev, hipGetLastError());
-  }
+  c->out_seq++;
+  k_set_state5<<<1, 1, 0, c->dev->stream>>>(c->state, (int)token, (int)pos, 0, (int)c->lazy_serial, (int)c->out_seq);
+  CH_HIP(c->dev, hipGetLastError());
   c->attn_variant = c->attn_long_ok && pos + 1 >= c->attn_long_from ? 1 : 0;
   c->kv_len = pos + 1;
   return 0;
 }
 
-int lazy_ctx_segment(crabml_hip_llama* c, int seg, float* logits_out) {
+int lazy_ctx_segment(crabml_hip_llama* c, int seg) {
   if (c->dev->dry) return 0;
-  c->logits_ext = logits_out;
-  int rc = enqueue_segment(c, seg);
-  c->logits_ext = nullptr;
-  return rc;
+  return enqueue_segment(c, seg);
+}
+
+// the whole step at once: the context's captured graph (false: this context has none -- the caller enqueues segment by segment)
+bool lazy_ctx_has_graph(const crabml_hip_llama* c) { return !c->dev->dry && c->use_graph && c->exec[0] != nullptr; }
+int lazy_ctx_step(crabml_hip_llama* c, size_t pos) {
+  if (c->dev->dry) return 0;
+  return run_step(c, pos);
+}
+
+// dst = the logits of the last step (device to device; for a handle the host kept and uses as an operand)
+int lazy_ctx_copy_logits(crabml_hip_llama* c, float* dst) {
+  if (c->dev->dry) return 0;
+  CH_HIP(c->dev, hipMemcpyAsync(dst, c->logits, c->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, c->dev->stream));
+  return 0;
 }
 
 int lazy_ctx_final_norm(crabml_hip_llama* c, float* dst) {
@@ -2239,7 +2247,7 @@ const float* lazy_ctx_wait_logits(crabml_hip_llama* c, int* fault) {
   *fault = (int)flag[1];
   return c->host_logits;
 }
-bool lazy_ctx_has_host_logits(const crabml_hip_llama* c) { return c != nullptr && c->host_logits != nullptr; }
+bool lazy_ctx_has_host_logits(const crabml_hip_llama* c) { return c != nullptr && (c->host_logits != nullptr || c->dev->dry); }
 int lazy_ctx_fault_value(const crabml_hip_llama* c) { return c->dev->dry ? 0 : c->h_state[crabml_hip_llama::H_STATE_SLOTS * 4]; }
 
 }  // namespace crabml_hip

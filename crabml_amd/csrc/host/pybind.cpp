@@ -79,6 +79,12 @@ PYBIND11_MODULE(_host, m) {
            }),
            py::arg("device_ordinal") = 0, py::arg("debug_named_tensor") = false, py::arg("stream") = 0,
            py::arg("strict_order") = false, py::arg("mode") = "lazy")
+      .def("numa_node",
+           [](HipTensorDevice& d) {
+             int32_t node = -1;
+             d.check(crabml_hip_debug_device_numa_node(d.raw(), &node));
+             return (int)node;
+           })
       .def("lazy_stats",
            [](HipTensorDevice& d) {
              const std::vector<uint64_t> v = d.lazy_stats();

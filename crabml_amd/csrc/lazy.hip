@@ -336,6 +336,7 @@ bool learn_token(Learner& P, LazyModel& M, int* slot_xnorm, int* slot_xfinal, in
       NEED(o->s[3] == seq * hd && pos < seq && o->a->dtype == kv_dtype && o->a->n_elems == n_kv * seq * hd);
       caches[which] = o->a;
       P.push(*o, LR_CONCAT);
+      if (first && which == 1) P.T.back().go = true;  // token id, position and layer 0's caches are known from here on
     }
     NEED(caches[0] != caches[1]);
     M.kc.push_back(caches[0]);
@@ -440,7 +441,7 @@ bool learn_token(Learner& P, LazyModel& M, int* slot_xnorm, int* slot_xfinal, in
   c.rope_dim = rope_dim;
   c.rms_norm_eps = eps;
   c.use_f16_kv_cache = kv_dtype == CRABML_HIP_F16 ? 1 : 0;
-  c.flags = CRABML_HIP_LLAMA_NO_GRAPH;  // the segments are enqueued as their ops arrive
+  c.flags = 0;  // (the step's graph is captured: the whole token is launched as soon as its position is verified)
   c.tp_size = 1;
   return true;
 }
@@ -575,32 +576,21 @@ int commit_token(crabml_hip_device* dev, LazyState& L) {
     }
   }
   crabml_hip_buf* lb = L.slots[L.slot_logits];
-  touch(lb);  // written in place by the classifier launch
+  touch(lb);
   if (L.pin_buf) crabml_hip_buf_release(L.pin_buf);
   L.pin_buf = nullptr;
   L.pin_kind = 0;
-  if (!dev->dry && lb->bytes && lazy_ctx_has_host_logits(L.ctx)) {  // the final segment's own kernels send the logits to the host
+  // the logits live in the context's buffer and -- sent there by the step's last kernels -- in pinned host memory: export() of this
+  // handle is served from the host copy; device memory is bound (and filled) only if the handle is used as an operand
+  lb->deferred = 2;
+  crabml_hip_buf_retain(lb);
+  L.deferred[2] = lb;
+  if (lazy_ctx_has_host_logits(L.ctx)) {
     crabml_hip_buf_retain(lb);
     L.pin_buf = lb;
     L.pin_version = lb->version;
     L.pin_n = lb->n_elems;
     L.pin_kind = 1;
-  } else if (!dev->dry && lb->bytes) {
-    static const bool pin_on = [] { const char* e = getenv("CRABML_HIP_LAZY_NO_PINNED_LOGITS"); return !(e && e[0] == '1'); }();
-    if (pin_on && L.pin_bytes < lb->bytes) {
-      if (L.pin) (void)hipHostFree(L.pin);
-      L.pin = nullptr;
-      L.pin_bytes = 0;
-      if (hipHostMalloc(&L.pin, lb->bytes, hipHostMallocDefault) == hipSuccess) L.pin_bytes = lb->bytes;
-      (void)hipGetLastError();
-    }
-    if (pin_on && L.pin && hipMemcpyAsync(L.pin, lb->ptr, lb->bytes, hipMemcpyDeviceToHost, dev->stream) == hipSuccess) {
-      crabml_hip_buf_retain(lb);
-      L.pin_buf = lb;
-      L.pin_version = lb->version;
-      L.pin_n = lb->n_elems;
-      L.pin_kind = 2;
-    }
   }
   L.stats.fused_tokens++;
   L.stats.fused_ops += L.q.size();
@@ -627,6 +617,7 @@ int track(crabml_hip_device* dev, LazyState& L) {
     L.next = 0;
     L.pos_known = false;
     L.begun = false;
+    L.whole_step = false;
     L.slots.assign(L.mentions.size(), nullptr);
   }
   const LazyOp& o = L.q.back();
@@ -635,29 +626,34 @@ int track(crabml_hip_device* dev, LazyState& L) {
     return 0;
   }
   const TmplOp& t = L.tmpl[L.next++];
-  if (t.seg_end >= 0) {
-    int rc = 0;
+  const bool last = L.next == L.tmpl.size();
+  int rc = 0;
+  if (t.go && !dev->prof_on && lazy_ctx_has_graph(L.ctx)) {
+    // token id, position and the first layer's caches are verified: the WHOLE step goes out now, as one graph launch (the rest
+    // of the token's ~800 calls are only compared with the template; should one deviate, the shadow is dropped as always -- what
+    // it wrote beyond its private buffers are cache rows at the position of the very concatenate ops the replay re-runs, or,
+    // for layers whose ops never came, rows one past the caches' live length)
+    rc = lazy_resolve(dev);  // the previous token's promised handles, if the host still holds them: the context is about to move on
+    if (rc == 0) rc = lazy_ctx_begin(L.ctx, L.token, L.pos);
+    if (rc == 0) rc = lazy_ctx_step(L.ctx, L.pos);
+    L.begun = true;
+    L.whole_step = true;
+    if (rc == 0) L.stats.segments += (uint64_t)lazy_ctx_n_segments(L.ctx);
+  } else if (t.seg_end >= 0 && !L.whole_step) {
     if (!L.begun) {
-      rc = lazy_resolve(dev);  // the previous token's final row, if the host still holds it: the residual stream is about to move on
+      rc = lazy_resolve(dev);
       if (rc == 0) rc = lazy_ctx_begin(L.ctx, L.token, L.pos);
       L.begun = true;
     }
-    float* logits_out = nullptr;
-    const bool last = L.next == L.tmpl.size();
-    if (rc == 0 && last) {
-      crabml_hip_buf* lb = L.slots[L.slot_logits];
-      rc = ensure_mem(dev, lb);
-      logits_out = (float*)lb->ptr;
-    }
-    if (rc == 0) rc = lazy_ctx_segment(L.ctx, t.seg_end, logits_out);
-    if (rc != 0) {  // the decode context failed: this model goes back to the per-op launches for good
-      abort_token(L);
-      L.dead = true;
-      return 0;
-    }
-    L.stats.segments++;
-    if (last) return commit_token(dev, L);
+    if (rc == 0) rc = lazy_ctx_segment(L.ctx, t.seg_end);
+    if (rc == 0) L.stats.segments++;
   }
+  if (rc != 0) {  // the decode context failed: this model goes back to the per-op launches for good
+    abort_token(L);
+    L.dead = true;
+    return 0;
+  }
+  if (last) return commit_token(dev, L);
   return 0;
 }
 
@@ -702,15 +698,20 @@ int lazy_resolve(crabml_hip_device* dev) {
   if (!dev->lz) return 0;
   LazyState& L = *dev->lz;
   int rc = 0;
-  for (int i = 0; i < 2; i++) {
+  // (the host copy of the logits belongs to the step that is being left behind: from here on its handle, if anybody still holds
+  // it, is an ordinary bound buffer)
+  if (L.pin_buf) crabml_hip_buf_release(L.pin_buf);
+  L.pin_buf = nullptr;
+  L.pin_kind = 0;
+  for (int i = 0; i < 3; i++) {
     crabml_hip_buf* b = L.deferred[i];
     if (!b) continue;
     L.deferred[i] = nullptr;
+    const int kind = b->deferred;
     b->deferred = 0;
-    if (b->refcnt.load() > 1 && rc == 0) {  // still held by the host: bind it and produce the row
+    if (b->refcnt.load() > 1 && rc == 0) {  // still held by the host: bind it and produce the value
       rc = ensure_mem(dev, b);
-      if (rc == 0) rc = lazy_ctx_final_norm(L.ctx, (float*)b->ptr);
-      touch(b);
+      if (rc == 0) rc = kind == 2 ? lazy_ctx_copy_logits(L.ctx, (float*)b->ptr) : lazy_ctx_final_norm(L.ctx, (float*)b->ptr);
       L.stats.deferred_bound++;
     }
     crabml_hip_buf_release(b);
@@ -727,6 +728,11 @@ int lazy_pinned_kind(crabml_hip_device* dev, const crabml_hip_buf* b, size_t n) 
 
 int lazy_export_wait(crabml_hip_device* dev, float* dst, size_t n) {
   LazyState& L = *dev->lz;
+  if (dev->dry) {  // record-only test device: the path is taken, nothing is there to copy
+    memset(dst, 0, n * 4);
+    L.stats.pinned_exports++;
+    return 0;
+  }
   int fault = 0;
   const auto t0 = std::chrono::steady_clock::now();
   const float* src = lazy_ctx_wait_logits(L.ctx, &fault);
@@ -761,7 +767,6 @@ void lazy_destroy(crabml_hip_device* dev) {
   L.q.clear();
   drop_model(dev, L);
   if (L.pin_buf) crabml_hip_buf_release(L.pin_buf);
-  if (L.pin) (void)hipHostFree(L.pin);
   delete dev->lz;
   dev->lz = nullptr;
 }

@@ -89,6 +89,7 @@ struct TmplOp {
   uint8_t kind = 0, rule = LR_NONE;
   bool a_new = false;   // `a` is a buffer the host allocated for this token (the destination of copy_rows_from)
   int16_t seg_end = -1; // the decode segment whose ops are complete with this op
+  bool go = false;      // token, position and the first layer's caches are verified with this op: the whole step may be launched
   // operands: slot >= 0 = the token's own buffer number `slot`; -1 = the persistent buffer p*; -2 = none
   int32_t sa = -2, sb = -2, so = -2;
   const crabml_hip_buf *pa = nullptr, *pb = nullptr;
@@ -125,14 +126,14 @@ struct LazyState {
   size_t token = 0, pos = 0;
   bool pos_known = false, begun = false, dead = false;
   // handles the host kept whose value is the final norm of the context's residual stream (bound on demand)
-  crabml_hip_buf* deferred[2] = {nullptr, nullptr};
-  // the logits of a committed token are copied to pinned host memory right behind the classifier launch (the runner exports
-  // them next, llama2.rs:208): export() of that very buffer, unmodified, is then a wait + a host copy
-  void* pin = nullptr;
-  size_t pin_bytes = 0, pin_n = 0;
+  crabml_hip_buf* deferred[3] = {nullptr, nullptr, nullptr};  // (buf->deferred: 1 = the final norm row, 2 = the logits)
+  bool whole_step = false;  // the token being shadowed was launched as one graph (at its `go` op)
+  // the logits of a committed token are sent to pinned host memory by the step's last kernels (the runner exports them next,
+  // llama2.rs:208): export() of that very handle, unmodified, is then a wait on a flag + a host copy
+  size_t pin_n = 0;
   crabml_hip_buf* pin_buf = nullptr;  // retained while the copy is valid for it
   uint64_t pin_version = 0;
-  int pin_kind = 0;  // 1: sent by the context's own kernels + flag, 2: copy-engine transfer into `pin`
+  int pin_kind = 0;  // 1: the handle's value is (on its way) in the context's pinned host copy
   bool check_fault = false;  // a committed token's gather-fault word has not been looked at yet
   bool fault_requested = false;
   LazyStats stats;
@@ -163,8 +164,7 @@ inline void lazy_use(crabml_hip_device* dev, const crabml_hip_buf* b) {
 // around a sync: did a committed token's in-launch gather time out?  (the decode context's fault word; requested before the
 // sync, looked at after it)
 // export(): was a host copy of this buffer's first n floats requested when its token committed, and is the buffer unchanged?
-// 1: the context's kernels send it to pinned memory and raise a flag (lazy_export_wait copies it out); 2: a copy-engine transfer
-// into L.pin is in flight (valid after the stream is drained); 0: no
+// 1: the context's kernels send it to pinned memory and raise a flag (lazy_export_wait copies it out); 0: no
 int lazy_pinned_kind(crabml_hip_device* dev, const crabml_hip_buf* b, size_t n);
 int lazy_export_wait(crabml_hip_device* dev, float* dst, size_t n);  // kind 1: wait for the flag, copy, report a gather fault
 int lazy_fault_request(crabml_hip_device* dev);
@@ -174,7 +174,10 @@ int lazy_fault_check(crabml_hip_device* dev);
 int lazy_ctx_create(crabml_hip_device* dev, const LazyModel& m, crabml_hip_llama** out);
 void lazy_ctx_destroy(crabml_hip_llama* c);
 int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos);            // token id / position of the step -> device state
-int lazy_ctx_segment(crabml_hip_llama* c, int seg, float* logits_out);        // enqueue one segment (logits_out: the last one)
+int lazy_ctx_segment(crabml_hip_llama* c, int seg);                           // enqueue one segment
+bool lazy_ctx_has_graph(const crabml_hip_llama* c);
+int lazy_ctx_step(crabml_hip_llama* c, size_t pos);                           // the whole step from the context's graph
+int lazy_ctx_copy_logits(crabml_hip_llama* c, float* dst);                    // dst = the last step's logits (device to device)
 int lazy_ctx_final_norm(crabml_hip_llama* c, float* dst);                     // dst = rms_norm(residual) * rms_final
 const float* lazy_ctx_wait_logits(crabml_hip_llama* c, int* fault);  // spins; nullptr = no host copy of the logits
 bool lazy_ctx_has_host_logits(const crabml_hip_llama* c);

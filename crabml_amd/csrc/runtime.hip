@@ -233,6 +233,22 @@ int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip
   if (hipSetDevice(dev->ordinal) != hipSuccess) return fail();
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev->ordinal) == hipSuccess) dev->n_cu = prop.multiProcessorCount;
+  {  // which host NUMA node is the GPU attached to?  (a host thread that drives it token by token -- the reference's runner -- is a
+     // few percent faster from that node: launches, the logits in pinned memory, the completion flag all cross the socket otherwise)
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev->ordinal) == hipSuccess) {
+      for (char* p = bus; *p; p++)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+      char path[160];
+      snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+      if (FILE* f = fopen(path, "r")) {
+        int node = -1;
+        if (fscanf(f, "%d", &node) == 1) dev->numa_node = node;
+        fclose(f);
+      }
+    }
+    (void)hipGetLastError();
+  }
   // test hook (tests/test_hip_fault_paths.py): claim this many CUs whatever the device reports, so that a CU-masked process
   // (HSA_CU_MASK) loses the co-residency the in-launch hand-offs rely on -- their bounded polls must raise, not hang
   // Armed only when CRABML_HIP_TEST_HOOKS=1 is set as well (a stray CRABML_HIP_ASSUME_CUS alone is ignored), and it says so.
@@ -481,24 +497,23 @@ int crabml_hip_export(crabml_hip_device_t* dev, const crabml_hip_buf_t* b, float
   if (!dev || !b || (!dst && n)) return CRABML_HIP_BAD_INPUT;
   if (b->dtype != CRABML_HIP_F32) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: not f32, but got %u", b->dtype);
   if (n > b->n_elems) CH_BAIL(dev, CRABML_HIP_TENSOR_ERROR, "export: %zu elements requested, buffer holds %zu", n, b->n_elems);
+  if (!dev->dry) CH_USE(dev);
+  CH_FLUSH(dev);
+  // the logits of a token the fused step served are already on their way to pinned host memory (sent by the step's last kernels):
+  // wait for THAT data -- a flag in host memory -- and copy; the handle never needs device memory for this
+  if (n && lazy_pinned_kind(dev, b, n) == 1) return lazy_export_wait(dev, dst, n);
   if (dev->dry) {
     CH_TRY(observe(dev, b));
     if (n) memset(dst, 0, n * 4);
     return 0;
   }
-  CH_USE(dev);
-  CH_TRY(observe(dev, b));
-  const int pinned = n ? lazy_pinned_kind(dev, b, n) : 0;  // the logits of a token the fused step served: already on their way
-  if (pinned == 1) return lazy_export_wait(dev, dst, n);    // (waits for THAT data, not for the whole stream)
-  if (n && !pinned) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, n * 4, hipMemcpyDeviceToHost, dev->stream));
+  lazy_use(dev, b);
+  CH_TRY(ensure_mem(dev, const_cast<crabml_hip_buf*>(b)));
+  if (n) CH_HIP(dev, hipMemcpyAsync(dst, b->ptr, n * 4, hipMemcpyDeviceToHost, dev->stream));
   CH_TRY(lazy_fault_request(dev));
   const auto t0 = std::chrono::steady_clock::now();
   CH_HIP(dev, hipStreamSynchronize(dev->stream));
   dev->lz->stats.wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-  if (pinned) {
-    memcpy(dst, dev->lz->pin, n * 4);
-    dev->lz->stats.pinned_exports++;
-  }
   return lazy_fault_check(dev);
 }
 
@@ -1013,6 +1028,12 @@ int crabml_hip_debug_read_ceiling(crabml_hip_device_t* dev, size_t bytes, int32_
   pool_free(dev, sink, scap);
   if (e != hipSuccess) return hip_fail(dev, e, "debug_read_ceiling", __FILE__, __LINE__);
   *gbytes_per_s = best > 0.f ? (double)bytes / ((double)best * 1e-3) / 1e9 : 0.0;
+  return 0;
+}
+
+int crabml_hip_debug_device_numa_node(crabml_hip_device_t* dev, int32_t* node) {
+  if (!dev || !node) return CRABML_HIP_BAD_INPUT;
+  *node = dev->numa_node;
   return 0;
 }
 

@@ -25,6 +25,10 @@ extern "C" {
  * the pinned logits copy requested at commit */
 int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* out, size_t cap);
 
+/* the host NUMA node the device is attached to (sysfs numa_node of its PCI function), -1 if unknown: bench.py runs its host
+ * threads there (a host that drives the device token by token is sensitive to the socket it sits on) */
+int crabml_hip_debug_device_numa_node(crabml_hip_device_t* dev, int32_t* node);
+
 /* ---- parity / debug hooks (used by tests; not on the hot path) ------------------------------ */
 /* Quantizes the first n f32 elements of x to `qtype` (Q8_0 | Q8_1 | Q8_K) on the device and returns
  * the blocks in the reference's byte layout (buf_q8_0.rs:8-13, buf_q8_1.rs:73-79, buf_q8_k.rs:6-12). */

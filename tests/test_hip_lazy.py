@@ -83,7 +83,7 @@ def test_kv_cache_bytes_and_kept_handles(ca, fmt):
             a = a.view(np.uint16).reshape(s.n_kv_heads, 32, hd)[:, :5]
             b = b.view(np.uint16).reshape(s.n_kv_heads, 32, hd)[:, :5]
             assert np.array_equal(a, b), f"kv cache bytes, layer {l}"
-    assert lz[3]["fused_tokens"] == 5 and lz[3]["deferred_bound"] == 10 and lz[3]["replayed"] == 0, lz[3]
+    assert lz[3]["fused_tokens"] == 5 and lz[3]["deferred_bound"] == 15 and lz[3]["replayed"] == 0, lz[3]
 
 
 @pytest.mark.parametrize("what", ["extra_op", "ffn_eps"])

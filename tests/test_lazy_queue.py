@@ -238,15 +238,15 @@ def test_the_final_row_is_bound_only_when_somebody_keeps_it():
     lg, kept = forward_py(conf, w, dev, kc, vc, 2, 1, 32, eps=s.rms_eps, keep="final")
     lg.export()
     assert dev.lazy_stats()["deferred_bound"] == 0  # still only promised
-    kept[0].export()  # x: read -> both handles are bound from the context's residual stream
-    st = dev.lazy_stats()
-    assert st["deferred_bound"] == 2 and st["fused_tokens"] == 2 and st["replayed"] == 0
+    kept[0].export()  # x: read -> every promised handle the host still holds is bound: x, x_final (the context's residual stream) and
+    st = dev.lazy_stats()  # the logits handle (the context's logits buffer; its export above was served from the pinned host copy)
+    assert st["deferred_bound"] == 3 and st["fused_tokens"] == 2 and st["replayed"] == 0 and st["pinned_exports"] == 2
     # kept, never read, and the next token starts: bound before the residual stream moves on
     lg, kept2 = forward_py(conf, w, dev, kc, vc, 3, 2, 32, eps=s.rms_eps, keep="final")
     lg.export()
     forward_py(conf, w, dev, kc, vc, 4, 3, 32, eps=s.rms_eps)[0].export()
     st = dev.lazy_stats()
-    assert st["deferred_bound"] == 4 and st["fused_tokens"] == 4
+    assert st["deferred_bound"] == 6 and st["fused_tokens"] == 4
     del kept, kept2
 
 

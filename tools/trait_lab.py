@@ -19,6 +19,8 @@ ap.add_argument("--strict", action="store_true")
 args = ap.parse_args()
 
 dev = ca.HipTensorDevice(0, False, 0, args.strict)
+if not os.environ.get("NO_PIN"):
+    print(ca.pin_host_to_device_node(dev), file=sys.stderr)
 model = synth.build_model(synth.SHAPES[args.model], synth.TYPE_BY_NAME[args.wtype], seed=8, n_layers=args.layers)
 conf, w = synth.to_hip(model, dev)
 out = {"model": args.model, "wtype": args.wtype, "steps": args.steps, "strict": args.strict}
