@@ -654,98 +654,46 @@ def main():
                 raise
             path = "trait"
 
-    def decode(tok, n):
+    # What `value` times.  Default: the reference's OWN API -- Llama2Runner<HipTensor>::forward + the host-side greedy sampler per
+    # token, unchanged (what `crabml-cli -D hip` runs, patches/0002); its Tensor calls are recorded and served by the fused step
+    # (csrc/lazy.hpp).  `--path fused`: crabml_hip_llama_decode_greedy (the step from its hipGraph, arg-max on the device, one blocking
+    # call for K tokens) -- reported as `fused_entry_point` next to the headline otherwise.
+    headline = "fused" if (args.path == "fused" and path == "fused") else "reference"
+
+    def decode(tok, n, which=None):
         """n greedy decode steps, returns the last sampled token"""
-        if path == "fused":
+        if (which or headline) == "fused":
             return int(fused.decode_greedy(tok, n)[-1])
         return int(trait.timed_decode(tok, n)[0][-1])
 
     # ---- warm-up (untimed), then the timed region: EXACTLY K steps between barrier + synchronize ------------------
     # The region is repeated `--repeats` times over the SAME positions (the sequence is rewound: kv length back to 0,
     # W warm-up steps, K timed steps), so the repeats are comparable; `value` is the MEDIAN region, all of them are listed.
-    regions = []
-    for rep in range(max(1, args.repeats)):
-        if rep > 0:
-            if path == "fused":
+    def timed_regions(which):
+        nonlocal trait
+        out_r = []
+        for rep in range(max(1, args.repeats)):
+            if which == "fused":
                 fused.reset()
-            else:
-                trait = ca.Llama2Runner(conf, weights, dev, trait_seq, True)
-        tok = decode(1, args.warmup) if args.warmup > 0 else 1
-        dev.sync()
-        dist.barrier()
-        t0 = time.perf_counter()
-        tok = decode(tok, args.steps)
-        dev.sync()
-        dist.barrier()
-        regions.append(dist.max_sum(time.perf_counter() - t0, args.steps))
-    regions.sort()
+            elif rep > 0 or trait.kv_cache_len() > 0:
+                trait = ca.Llama2Runner(conf, weights, dev, trait_seq, True)  # (an empty cache: the runner has no rewind)
+            tok = decode(1, args.warmup, which) if args.warmup > 0 else 1
+            dev.sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            tok = decode(tok, args.steps, which)
+            dev.sync()
+            dist.barrier()
+            out_r.append(dist.max_sum(time.perf_counter() - t0, args.steps))
+        out_r.sort()
+        return out_r
+
+    regions = timed_regions(headline)
     elapsed_max, total_tokens = regions[len(regions) // 2]
+    fused_regions = timed_regions("fused") if (headline == "reference" and path == "fused") else None
 
-    # SURVEY.md config C3 quotes decode over positions 0..127 from an empty cache; the driver's arguments (--steps 20 --warmup 5)
-    # time positions 5..24, where attention is nearly free.  Reported next to `value`: 128 steps from position 0, best of 3.
-    c3 = None
-    if rank == 0 and path == "fused" and not args.no_c3:
-        best = None
-        for _ in range(3):
-            fused.reset()
-            dev.sync()
-            tc = time.perf_counter()
-            fused.decode_greedy(1, 128)
-            dev.sync()
-            dtc = time.perf_counter() - tc
-            best = dtc if best is None else min(best, dtc)
-        c3 = {"positions": "0..127", "tokens_per_s": round(128 / best, 2), "ms_per_step": round(best / 128 * 1e3, 4),
-              "note": "128 greedy steps from an empty KV cache (SURVEY.md config C3), host clock around one blocking call, best of 3"}
-
-    # The reference's API: Llama2Runner<HipTensor> UNCHANGED, one Tensor call after the other (what `crabml-cli -D hip` runs,
-    # patches/0002).  Since ABI version 2 the calls are recorded and a decode token is served by the fused step (csrc/lazy.hpp);
-    # the same runner on a device that launches every call immediately (ABI version 1, "per-op") is timed next to it.
-    trait_tps = None
-    trait_info = None
-    if rank == 0 and path == "fused" and not args.no_trait:
-        n_t = max(args.steps, 16)
-        st0 = dev.lazy_stats()
-        t_tok = int(trait.timed_decode(1, args.warmup if args.warmup > 0 else 2)[0][-1])
-        dev.sync()
-        best = None
-        split = None
-        for _ in range(3):
-            sa = dev.lazy_stats()
-            tt = time.perf_counter()
-            ids_t, _sec, samp = trait.timed_decode(t_tok, n_t)
-            t_tok = int(ids_t[-1])
-            dev.sync()
-            dt = time.perf_counter() - tt
-            sb = dev.lazy_stats()
-            if best is None or dt < best:
-                best = dt
-                split = {"host_blocked_in_export_ms_per_step": round((sb["wait_ns"] - sa["wait_ns"]) / n_t * 1e-6, 4),
-                         "host_argmax_ms_per_step": round(samp / n_t * 1e3, 4)}
-        trait_tps = n_t / best
-        st1 = dev.lazy_stats()
-        trait_info = {"tokens_per_s": round(trait_tps, 2), "ms_per_step": round(best / n_t * 1e3, 4), "steps": n_t,
-                      "api": "Llama2Runner<HipTensor>::forward + host arg-max per token (the reference's generic runner, unchanged); "
-                             "logits exported every token",
-                      "queue": {k: int(st1[k] - st0[k]) for k in st1 if k != "wait_ns"},
-                      "split": split,
-                      "note": "best of 3 regions; `queue`: Tensor calls recorded / run one launch at a time / tokens served by the fused step"}
-        try:
-            pdev = ca.HipTensorDevice(local, False, 0, False, "per-op")
-            if model is not None:
-                pconf, pweights = synth.to_hip(model, pdev)
-                ptrait = ca.Llama2Runner(pconf, pweights, pdev, 64, True)
-                p_tok = int(ptrait.timed_decode(1, 2)[0][-1])
-                pdev.sync()
-                tt = time.perf_counter()
-                ptrait.timed_decode(p_tok, 8)
-                pdev.sync()
-                trait_info["per_op_launches_tokens_per_s"] = round(8 / (time.perf_counter() - tt), 2)
-                del ptrait, pweights
-            del pdev
-        except Exception as e:
-            trait_info["per_op_launches_tokens_per_s"] = repr(e)
-
-    # ---- instrumented pass: HIP event pairs around every GEMV-stage launch (same process, same weights) ---
+    # ---- instrumented pass: HIP event pairs around every GEMV-stage launch (same process, same weights),
+    # taken RIGHT AFTER the timed regions (before the other legs create more contexts and devices) ---
     # Events cannot live inside the captured graph, so the fused step is replayed EAGERLY (identical kernels
     # and launch geometry) with one event pair per GEMV stage, on the backend's own stream.
     roof = None
@@ -809,6 +757,71 @@ def main():
                           "cannot carry events) right after the timed region; rocprofv3 --kernel-trace durations of the "
                           "same command are committed under profiles/",
             }
+
+    # SURVEY.md config C3 quotes decode over positions 0..127 from an empty cache; the driver's arguments (--steps 20 --warmup 5)
+    # time positions 5..24, where attention is nearly free.  Reported next to `value`: 128 steps from position 0, best of 3.
+    c3 = None
+    if rank == 0 and path == "fused" and not args.no_c3:
+        best = None
+        for _ in range(3):
+            fused.reset()
+            dev.sync()
+            tc = time.perf_counter()
+            fused.decode_greedy(1, 128)
+            dev.sync()
+            dtc = time.perf_counter() - tc
+            best = dtc if best is None else min(best, dtc)
+        c3 = {"positions": "0..127", "tokens_per_s": round(128 / best, 2), "ms_per_step": round(best / 128 * 1e3, 4),
+              "note": "128 greedy steps from an empty KV cache (SURVEY.md config C3), host clock around one blocking call, best of 3"}
+
+    # The reference's API: Llama2Runner<HipTensor> UNCHANGED, one Tensor call after the other (what `crabml-cli -D hip` runs,
+    # patches/0002).  Since ABI version 2 the calls are recorded and a decode token is served by the fused step (csrc/lazy.hpp);
+    # the same runner on a device that launches every call immediately (ABI version 1, "per-op") is timed next to it.
+    trait_tps = None
+    trait_info = None
+    if rank == 0 and path == "fused" and not args.no_trait:
+        n_t = max(args.steps, 16)
+        trait = ca.Llama2Runner(conf, weights, dev, trait_seq, True)  # (an empty cache for this leg)
+        st0 = dev.lazy_stats()
+        t_tok = int(trait.timed_decode(1, args.warmup if args.warmup > 0 else 2)[0][-1])
+        dev.sync()
+        best = None
+        split = None
+        for _ in range(3):
+            sa = dev.lazy_stats()
+            tt = time.perf_counter()
+            ids_t, _sec, samp = trait.timed_decode(t_tok, n_t)
+            t_tok = int(ids_t[-1])
+            dev.sync()
+            dt = time.perf_counter() - tt
+            sb = dev.lazy_stats()
+            if best is None or dt < best:
+                best = dt
+                split = {"host_blocked_in_export_ms_per_step": round((sb["wait_ns"] - sa["wait_ns"]) / n_t * 1e-6, 4),
+                         "host_argmax_ms_per_step": round(samp / n_t * 1e3, 4)}
+        trait_tps = n_t / best
+        st1 = dev.lazy_stats()
+        trait_info = {"tokens_per_s": round(trait_tps, 2), "ms_per_step": round(best / n_t * 1e3, 4), "steps": n_t,
+                      "api": "Llama2Runner<HipTensor>::forward + host arg-max per token (the reference's generic runner, unchanged); "
+                             "logits exported every token",
+                      "queue": {k: int(st1[k] - st0[k]) for k in st1 if k != "wait_ns"},
+                      "split": split,
+                      "note": "best of 3 regions; `queue`: Tensor calls recorded / run one launch at a time / tokens served by the fused step"}
+        try:
+            pdev = ca.HipTensorDevice(local, False, 0, False, "per-op")
+            if model is not None:
+                pconf, pweights = synth.to_hip(model, pdev)
+                ptrait = ca.Llama2Runner(pconf, pweights, pdev, 64, True)
+                p_tok = int(ptrait.timed_decode(1, 2)[0][-1])
+                pdev.sync()
+                tt = time.perf_counter()
+                ptrait.timed_decode(p_tok, 8)
+                pdev.sync()
+                trait_info["per_op_launches_tokens_per_s"] = round(8 / (time.perf_counter() - tt), 2)
+                del ptrait, pweights
+            del pdev
+        except Exception as e:
+            trait_info["per_op_launches_tokens_per_s"] = repr(e)
 
     # ---- batched prefill of a 512-token prompt (crabml_hip_llama_prefill), reported next to the decode number ------
     prefill = None
@@ -882,7 +895,10 @@ def main():
             "config": {
                 "workload": f"{shape.name}-shape all-{args.wtype} synthetic GGUF-layout weights, batch-1 greedy decode, "
                             f"f16 KV cache, positions {args.warmup}..{args.warmup + args.steps - 1}",
-                "path": path, "n_layers": conf.n_layers, "replicas": args.gpus,
+                "path": ("the reference's API: Llama2Runner<HipTensor>::forward + host arg-max per token, unchanged (crabml-llama2/src/llama2.rs:184-211; "
+                         "what crabml-cli -D hip runs) -> recorded Tensor calls -> the fused decode step" if headline == "reference" else
+                         "crabml_hip_llama_decode_greedy (the fused decode step from its hipGraph, arg-max on the device)"),
+                "n_layers": conf.n_layers, "replicas": args.gpus,
                 "gemv_weight_bytes_per_token": gemv_bytes,
             },
             "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / gemv_bytes, 1),
@@ -894,7 +910,8 @@ def main():
                               "median": round(tps, 2),
                               "p10": round(regions[min(len(regions) - 1, int(0.9 * len(regions)))][1] / regions[min(len(regions) - 1, int(0.9 * len(regions)))][0], 2),
                               "p90": round(regions[int(0.1 * len(regions))][1] / regions[int(0.1 * len(regions))][0], 2),
-                              "note": "every region = the same W warm-up + K timed steps from an empty KV cache; value = the median region"},
+                              "note": "every region = the same W warm-up + K timed steps from an empty KV cache; value = the median region "
+                                      "(reference API: a fresh runner per region; its first warm-up token is the one the decode context is learned from)"},
         }
         if context:
             out["context"] = {"tokens_per_s_at_position": context,
@@ -902,12 +919,19 @@ def main():
         if c3:
             out["c3_positions_0_127"] = c3
         out["config"]["host_affinity"] = host_affinity
-        out["value_api"] = ("crabml_hip_llama_decode_greedy: the fused step from its hipGraph, arg-max on the device, one blocking call for K tokens" if path == "fused"
-                            else "Llama2Runner<HipTensor>::forward per token")
+        out["value_api"] = ("crabml_hip_llama_decode_greedy: the fused step from its hipGraph, arg-max on the device, one blocking call for K tokens"
+                            if headline == "fused" else
+                            "the reference's own API: Llama2Runner<HipTensor>::forward + host-side greedy sampler per token, unchanged "
+                            "(logits exported every token); its recorded Tensor calls are served by the fused decode step (csrc/lazy.hpp)")
+        if headline == "reference":
+            out["value_through_reference_api"] = round(tps, 2)  # (= value)
+        if fused_regions:
+            fe, fu = fused_regions[len(fused_regions) // 2]
+            out["fused_entry_point"] = {"tokens_per_s": round(fu / fe, 2), "ms_per_step": round(fe / args.steps * 1e3, 4),
+                                        "regions_tokens_per_s": [round(u / t, 2) for t, u in fused_regions][::-1],
+                                        "api": "crabml_hip_llama_decode_greedy: the same step from its hipGraph, arg-max on the device, one blocking call "
+                                               "for K tokens (the headline of rounds 1-4; same positions, same region protocol)"}
         if trait_tps is not None:
-            # the same model through the reference's OWN API (what `crabml-cli -D hip` runs, patches/0002): the unchanged generic runner,
-            # logits exported and sampled on the host every token
-            out["value_through_reference_api"] = round(trait_tps, 2)
             out["trait_path_tokens_per_s"] = round(trait_tps, 2)
             out["trait_path"] = trait_info
         if args.layers is not None:

@@ -18,6 +18,7 @@ ap.add_argument("--vocab", type=int, default=0, help="experiment: override the v
 ap.add_argument("--attn-long-from", type=int, default=0)
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--pos0", type=int, default=8)
+ap.add_argument("--burn", type=float, default=0.0, help="seconds of back-to-back decoding before the measured steps (thermal / power state)")
 ap.add_argument("--model", default="llama3-8b")
 ap.add_argument("--wtype", default="Q4_0")
 a = ap.parse_args()
@@ -31,6 +32,15 @@ model = synth.build_model(shape, synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a
 dev = ca.HipTensorDevice(0)
 conf, w = synth.to_hip(model, dev)
 r = ca.HipLlamaRunner(conf, w, dev, a.pos0 + a.steps + 8, True, False, not a.no_prefetch, norm_epilogue=not a.no_norm_epilogue, extra_flags=a.flags, attn_long_from=a.attn_long_from)
+if a.burn > 0:
+    import time
+    g = ca.HipLlamaRunner(conf, w, dev, 256, True)
+    t0 = time.time()
+    while time.time() - t0 < a.burn:
+        g.reset()
+        g.decode_greedy(1, 200)
+    dev.sync()
+    del g
 r.decode_greedy(1, a.pos0)
 dev.sync()
 dev.prof_enable(True)
