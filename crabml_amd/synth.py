@@ -157,6 +157,8 @@ SHAPES = {
     "llama3-70b": ModelShape("Llama-3-70B", 8192, 28672, 80, 64, 8, 128256, 8192, 1e-5, None),
     # a small GQA shape with every dim a multiple of 256 (valid for all formats incl. K-quants); used by tests
     "tiny-gqa": ModelShape("tiny-gqa", 512, 1024, 2, 8, 2, 1024, 64, 1e-5, None),
+    # ... and one with Llama-3's head_dim of 128 (the kernels specialized for it: k_attn_s<128>, k_attn_wo)
+    "tiny-hd128": ModelShape("tiny-hd128", 512, 1024, 2, 4, 2, 1024, 128, 1e-5, None),
 }
 
 

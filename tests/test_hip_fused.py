@@ -30,7 +30,7 @@ def rel_errs(a, b):
     return np.array([np.max(np.abs(x - y)) / np.max(np.abs(y)) for x, y in zip(a, b)])
 
 
-@pytest.mark.parametrize("shape", ["15m", "tiny-gqa"])
+@pytest.mark.parametrize("shape", ["15m", "tiny-gqa", "tiny-hd128"])
 @pytest.mark.parametrize("fmt", ["Q4_0", "Q8_0"])
 @pytest.mark.parametrize("kv_f16", [False, True])
 def test_fused_strict_is_bit_exact(ca, shape, fmt, kv_f16):
