@@ -130,6 +130,7 @@ struct crabml_hip_device {
   uint16_t* gelu_table = nullptr;
   // measurement hook (crabml_hip_prof_*): event pairs around GEMV launches
   bool prof_on = false;
+  bool gemm_fused_add = false;  // set by the fast prompt pass around its weight GEMMs: the block term's last product and the add as one fma
   struct ProfRec {
     hipEvent_t e0, e1;
     uint32_t dtype;

@@ -1099,8 +1099,18 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     launch_quantize_act_rows(st, c->qt, src, B, (size_t)n, planes);
     return planes;
   };
+  static const bool gemm_exact_hook = [] {  // A/B hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_EXACT=1): the fast pass with matmul_vec's own scaling
+    const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+    const char* e = getenv("CRABML_HIP_GEMM_EXACT");
+    return h && h[0] == '1' && e && e[0] == '1';
+  }();
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
-    if (!strict) return launch_gemv(dev, w, m, k, act, B, out, nullptr);
+    if (!strict) {
+      dev->gemm_fused_add = !gemm_exact_hook;
+      const int rc = launch_gemv(dev, w, m, k, act, B, out, nullptr);
+      dev->gemm_fused_add = false;
+      return rc;
+    }
     // strict order: the Q4_0 / Q8_0 / Q4_1 MFMA GEMM scales its exact integer tiles block by block in the reference's scalar
     // order, i.e. it IS the strict result (bit for bit) -- the other formats take the scalar-order GEMV row by row
     if ((w->dtype == CRABML_HIP_Q4_0 || w->dtype == CRABML_HIP_Q8_0 || w->dtype == CRABML_HIP_Q4_1 || w->dtype == CRABML_HIP_Q8_K) && B >= 16 &&

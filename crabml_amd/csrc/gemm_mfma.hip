@@ -45,7 +45,11 @@ struct GemmGeo {
   static constexpr int A_LOADS = 64 * KC * APC / 256, B_LOADS = CW * KC * 2 / 256, S_LOADS = 64 * KC / 256;
 };
 
-template <int FMT, int NT>
+// FMA (the fast prompt pass only, crabml_hip_llama_prefill): sumf = fma(sumi as f32 * d_w, d_x, sumf) -- the block term's second
+// product and the add as one v_pk_fma_f32 (8 instead of 10 VALU operations per MFMA; one rounding fewer than the reference's
+// expression, the same distance the fast decode step's re-associated sums are allowed).  matmul_vec itself and the strict-order
+// device keep the reference's three roundings (bit-exact, tests/test_hip_gemv.py).
+template <int FMT, int NT, bool FMA = false>
 __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, const unsigned short* __restrict__ wd,
                                                    const char* __restrict__ act, size_t act_stride, size_t off_d, size_t off_aux,
                                                    float* __restrict__ out, int m, int nb, int b, int row_tiles) {
@@ -245,8 +249,13 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
       for (int jt = 0; jt < NT; jt++) {
         const f32x2 c01 = {(float)D[jt][0], (float)D[jt][1]}, c23 = {(float)D[jt][2], (float)D[jt][3]};
         const f32x2 dxx = {dx[jt], dx[jt]};
-        F[jt][0] += (c01 * dw01) * dxx;  // sumf += (sumi as f32 * d_w) * d_x, block after block
-        F[jt][1] += (c23 * dw23) * dxx;
+        if constexpr (FMA) {
+          F[jt][0] = __builtin_elementwise_fma(c01 * dw01, dxx, F[jt][0]);
+          F[jt][1] = __builtin_elementwise_fma(c23 * dw23, dxx, F[jt][1]);
+        } else {
+          F[jt][0] += (c01 * dw01) * dxx;  // sumf += (sumi as f32 * d_w) * d_x, block after block
+          F[jt][1] += (c23 * dw23) * dxx;
+        }
       }
     };
     if (kc == KC) {  // straight-line: the scheduler may start block kb + 1's LDS reads under block kb's scaling
@@ -873,7 +882,21 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
 #define CRABML_GEMM_LAUNCH(F, N)                                                                                              \
   launch_k(st, rec, k_gemm_mfma<F, N>, dim3(row_tiles * col_tiles), dim3(256), GemmGeo<F, N>::LDS_BYTES, wp, wd, (const char*)act, \
            al.total, al.off_d, al.off_aux, out, (int)m, nb, (int)b, row_tiles)
-  if (w->dtype == CRABML_HIP_Q4_0) {
+#define CRABML_GEMM_LAUNCH_FMA(F, N)                                                                                                    \
+  launch_k(st, rec, k_gemm_mfma<F, N, true>, dim3(row_tiles * col_tiles), dim3(256), GemmGeo<F, N>::LDS_BYTES, wp, wd, (const char*)act, \
+           al.total, al.off_d, al.off_aux, out, (int)m, nb, (int)b, row_tiles)
+  const bool fma = dev->gemm_fused_add && !dev->strict_order;
+  if (w->dtype == CRABML_HIP_Q4_0 && fma) {
+    if (narrow)
+      CRABML_GEMM_LAUNCH_FMA(CRABML_HIP_Q4_0, 2);
+    else
+      CRABML_GEMM_LAUNCH_FMA(CRABML_HIP_Q4_0, 4);
+  } else if (w->dtype == CRABML_HIP_Q8_0 && fma) {
+    if (narrow)
+      CRABML_GEMM_LAUNCH_FMA(CRABML_HIP_Q8_0, 2);
+    else
+      CRABML_GEMM_LAUNCH_FMA(CRABML_HIP_Q8_0, 4);
+  } else if (w->dtype == CRABML_HIP_Q4_0) {
     if (narrow)
       CRABML_GEMM_LAUNCH(CRABML_HIP_Q4_0, 2);
     else
@@ -890,6 +913,7 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
       CRABML_GEMM_LAUNCH(CRABML_HIP_Q8_0, 4);
   }
 #undef CRABML_GEMM_LAUNCH
+#undef CRABML_GEMM_LAUNCH_FMA
   return true;
 }
 
