@@ -17,11 +17,12 @@ ap.add_argument("--wtype", default="Q4_0")
 ap.add_argument("--layers", type=int, default=None)
 ap.add_argument("--steps", type=int, default=32)
 ap.add_argument("--fast", action="store_true", help="the default (fast) device instead, for comparison")
+ap.add_argument("--flags", type=int, default=0, help="extra CRABML_HIP_LLAMA_* flags (A/B runs)")
 a = ap.parse_args()
 model = synth.build_model(synth.SHAPES[a.model], synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers)
 dev = ca.HipTensorDevice(0) if a.fast else ca.HipTensorDevice(0, False, 0, True)
 conf, w = synth.to_hip(model, dev)
-r = ca.HipLlamaRunner(conf, w, dev, a.steps + 24, True)
+r = ca.HipLlamaRunner(conf, w, dev, a.steps + 24, True, extra_flags=a.flags)
 r.decode_greedy(1, 8)
 dev.sync()
 t0 = time.perf_counter()
