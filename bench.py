@@ -866,7 +866,7 @@ def main():
     context = None
     if rank == 0 and path == "fused" and not args.no_context and not args.gguf:
         context = {}
-        for ctx_len in (1024, 4096):
+        for ctx_len in (256, 1024, 4096):
             try:
                 if ctx_len + 64 > shape.seq_len:
                     continue

@@ -149,11 +149,13 @@ struct crabml_hip_llama {
   int* am_best = nullptr;   // {max bits, index} of this rank's shard (single-device simulation: combined by the driver)
   size_t kv_len = 0;
   // [0]: one attention workgroup per head; [1]: the long-context attention kernels (from attn_long_from positions)
-  hipGraph_t graph[2] = {nullptr, nullptr};
-  hipGraphExec_t exec[2] = {nullptr, nullptr};
+  hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
+  hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
   bool use_graph = false;
   bool capturing = false;
-  int attn_variant = 0;         // which of the two the next enqueue emits
+  int attn_variant = 0;         // which of them the next enqueue emits: 0 = one workgroup per head, 1 = the long-context kernels,
+                                // 2 = split-KV attention with the merge inside the launch (ticket form: the mid range)
+  size_t flash_ticket_until = 0;  // > 0: positions [attn_long_from, this) run variant 2
   bool attn_long_ok = false;    // f16 cache, head_dim % 32 == 0, group size in {1, 2, 4, 8}, seq_len % 8 == 0
   size_t attn_long_from = 0;    // cached positions (pos + 1) from which variant 1 is used
   bool pv_split = false;        // variant 1: k_attn_pv_split (products by producer waves) instead of k_attn_pv
@@ -315,19 +317,25 @@ FlashFn flash_kernel(int grp, int hd, bool q81, bool ticket) {
     default: return nullptr;
   }
 }
+// which attention form serves cache position `pos` (see attn_variant)
+int variant_of(const crabml_hip_llama* c, size_t pos) {
+  if (!(c->attn_long_ok && pos + 1 >= c->attn_long_from)) return 0;
+  return c->flash_ticket_until > 0 && pos + 1 < c->flash_ticket_until ? 2 : 1;
+}
 void launch_attn_flash(crabml_hip_llama* c, int l, signed char* xq, unsigned short* xd, void* xisum, bool prof) {
   crabml_hip_device* dev = c->dev;
   hipStream_t st = dev->stream;
   const int hd = c->hd, grp = c->n_heads_l / c->n_kv_l;
   const bool q81 = c->qt == CRABML_HIP_Q8_1;
-  const FlashFn fn = flash_kernel(grp, hd, q81, c->flash_ticket);
+  const bool ticket = c->flash_ticket || c->attn_variant == 2;
+  const FlashFn fn = flash_kernel(grp, hd, q81, ticket);
   crabml_hip_device::ProfRec r[2];
   if (prof) prof_begin(dev, &r[0], CRABML_HIP_F32, 7, 0.0);
   launch_k(st, prof ? &r[0] : nullptr, fn, dim3(c->n_kv_l * c->flash_S), dim3((grp == 8 ? 4 : 8) * 64), flash_lds_bytes(grp, hd),
            (const float*)c->qbuf, (const unsigned short*)c->kc[l], (const unsigned short*)c->vc[l], (const int*)(c->state + 1), c->flash_part,
            c->flash_tick, c->attn, xq, xd, xisum, (int)c->cfg.seq_len, c->flash_S, c->flash_min_rows);
   if (prof) prof_end(dev, &r[0]);
-  if (c->flash_ticket) return;
+  if (ticket) return;
   if (prof) prof_begin(dev, &r[1], CRABML_HIP_F32, 8, 0.0);
   crabml_hip_device::ProfRec* R1 = prof ? &r[1] : nullptr;
   const int* pos_d = c->state + 1;
@@ -348,11 +356,11 @@ void enqueue_attention(crabml_hip_llama* c, int l, signed char* xq, unsigned sho
   hipStream_t st = dev->stream;
   const int hd = c->hd, seq_cap = (int)c->cfg.seq_len, n_heads = c->n_heads_l, n_kv = c->n_kv_l;
   const int* pos_d = c->state + 1;
-  if (c->attn_variant == 1 && c->attn_flash) {
+  if (c->attn_variant >= 1 && c->attn_flash) {
     launch_attn_flash(c, l, xq, xd, xisum, prof);
     return;
   }
-  if (c->attn_variant == 1) {
+  if (c->attn_variant >= 1) {
     switch (n_heads / n_kv) {
       case 1: launch_attn_long<1>(c, l, xq, xd, xisum, prof); break;
       case 2: launch_attn_long<2>(c, l, xq, xd, xisum, prof); break;
@@ -949,7 +957,7 @@ int enqueue_step(crabml_hip_llama* c) {
 
 // one decode step at cache position `pos` (the host tracks it; the kernels read their own copy from device memory)
 int run_step(crabml_hip_llama* c, size_t pos) {
-  const int variant = c->attn_long_ok && pos + 1 >= c->attn_long_from ? 1 : 0;
+  const int variant = variant_of(c, pos);
   if (c->use_graph && c->exec[variant]) {
     CH_HIP(c->dev, hipGraphLaunch(c->exec[variant], c->dev->stream));
     return 0;
@@ -1730,6 +1738,19 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
         A(n_kv_l * 4, (void**)&c->flash_tick);
         if (rc == 0 && !dry && hipMemsetAsync(c->flash_tick, 0, n_kv_l * 4, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
         c->attn_flash = rc == 0;
+        // Below ~768 cached positions the merge inside the launch (last-arriving workgroup of a kv head, ticket word) beats the
+        // second launch -- 7.4 vs 5.1 + 4.1 us per layer at 128 positions, 8.7 vs 10.0 at 512, 10.8 vs 9.95 at 1024
+        // (profiles/r05_flash_ticket_sweep.md; same partials, same merge order: bit-identical): a third graph variant serves that range.
+        if (c->attn_flash && !c->flash_ticket) {
+          size_t until = 768;
+          if (const char* hooks = getenv("CRABML_HIP_TEST_HOOKS"))  // tuning hook: 0 = never
+            if (hooks[0] == '1')
+              if (const char* e = getenv("CRABML_HIP_FLASH_TICKET_UNTIL")) until = (size_t)atol(e);
+          const FlashFn tfn = flash_kernel((int)grp, (int)hd, qt == CRABML_HIP_Q8_1, true);
+          if (until > 0 && tfn != nullptr && raise_dyn_lds(dev, (const void*)tfn, (int)flash_lds_bytes((int)grp, (int)hd)) == hipSuccess)
+            c->flash_ticket_until = until;
+          (void)hipGetLastError();
+        }
         // the prompt pass's causal attention of the fast step (k_attn_flash_rows): 70 KB of LDS at head_dim 128
         if (c->attn_flash && (hd == 128 || hd == 64) &&
             raise_dyn_lds(dev, hd == 128 ? (const void*)k_attn_flash_rows<128> : (const void*)k_attn_flash_rows<64>,
@@ -1819,7 +1840,7 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
   const bool want_graph = !(g.flags & CRABML_HIP_LLAMA_NO_GRAPH) &&
                           (tp == 1 || c->tp_dry || p2p_comm || (c->comm != nullptr && (g.flags & CRABML_HIP_LLAMA_TP_GRAPH)));
   if (want_graph) {
-    const int nvar = c->attn_long_ok ? 2 : 1;
+    const int nvar = c->attn_long_ok ? (c->flash_ticket_until > 0 ? 3 : 2) : 1;
     bool ok = true;
     for (int v = 0; v < nvar && ok; v++) {
       ok = false;
@@ -1875,7 +1896,7 @@ int crabml_hip_llama_destroy(crabml_hip_llama_t* c) {
     (void)hipSetDevice(c->dev->ordinal);
     (void)hipStreamSynchronize(c->dev->stream);
   }
-  for (int v = 0; v < 2; v++) {
+  for (int v = 0; v < 3; v++) {
     if (c->exec[v]) (void)hipGraphExecDestroy(c->exec[v]);
     if (c->graph[v]) (void)hipGraphDestroy(c->graph[v]);
   }
@@ -1991,7 +2012,7 @@ int crabml_hip_llama_tp_sim_forward(crabml_hip_llama_t* const* ranks, int n, siz
   SimPtrs ptrs{};
   for (int r = 0; r < n; r++) ptrs.p[r] = ranks[r]->partial;
   const int dim = (int)ranks[0]->cfg.embedding_dim;
-  for (int r = 0; r < n; r++) ranks[r]->attn_variant = ranks[r]->attn_long_ok && pos + 1 >= ranks[r]->attn_long_from ? 1 : 0;
+  for (int r = 0; r < n; r++) ranks[r]->attn_variant = variant_of(ranks[r], pos);
   for (int s = 0; s < nseg; s++) {
     for (int r = 0; r < n; r++) CH_TRY(enqueue_segment(ranks[r], s));
     if (n > 1 && s + 1 < nseg) k_sim_allreduce<<<(dim + 255) / 256, 256, 0, dev->stream>>>(ptrs, n, dim);
@@ -2192,7 +2213,7 @@ int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos) {
   c->out_seq++;
   k_set_state5<<<1, 1, 0, c->dev->stream>>>(c->state, (int)token, (int)pos, 0, (int)c->lazy_serial, (int)c->out_seq);
   CH_HIP(c->dev, hipGetLastError());
-  c->attn_variant = c->attn_long_ok && pos + 1 >= c->attn_long_from ? 1 : 0;
+  c->attn_variant = variant_of(c, pos);
   c->kv_len = pos + 1;
   return 0;
 }
