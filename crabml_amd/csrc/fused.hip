@@ -156,7 +156,8 @@ struct crabml_hip_llama {
   int attn_variant = 0;         // which of them the next enqueue emits: 0 = one workgroup per head, 1 = the long-context kernels,
                                 // 2 = split-KV attention with the merge inside the launch (ticket form: the mid range)
   size_t flash_ticket_until = 0;  // > 0: positions [attn_long_from, this) run variant 2
-  bool attn_long_ok = false;    // f16 cache, head_dim % 32 == 0, group size in {1, 2, 4, 8}, seq_len % 8 == 0
+  bool attn_long_ok = false;    // f16 cache, head_dim % 32 == 0, group size in {1, 2, 4, 8}; and seq_len % 8 == 0 (exact kernels) or k_attn_flash
+  bool exact_long_ok = false;   // the exact long-context kernels (score / probability rows of seq_len elements read as 16-byte vectors)
   size_t attn_long_from = 0;    // cached positions (pos + 1) from which variant 1 is used
   bool pv_split = false;        // variant 1: k_attn_pv_split (products by producer waves) instead of k_attn_pv
   // variant 1 of the FAST step: k_attn_flash (split-KV, f32 accumulation) instead of the three exact kernels
@@ -1064,7 +1065,7 @@ int launch_attn_long_rows_t(crabml_hip_llama* c, int l, int B) {
 }
 // 1 = launched, 0 = not covered, < 0 = error
 int launch_attn_long_rows(crabml_hip_llama* c, int l, int B) {
-  if (!c->attn_long_ok || (c->cfg.flags & CRABML_HIP_LLAMA_NO_TILE_ATTENTION)) return 0;
+  if (!c->exact_long_ok || (c->cfg.flags & CRABML_HIP_LLAMA_NO_TILE_ATTENTION)) return 0;
   int rc;
   switch (c->n_heads_l / c->n_kv_l) {
     case 1: rc = launch_attn_long_rows_t<1>(c, l, B); break;
@@ -1686,8 +1687,9 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
   A(g.seq_len * (size_t)(c->npairs ? c->npairs : 1) * 2 * 4, (void**)&c->rope);
   {
     const size_t grp = n_heads_l / n_kv_l;
-    c->attn_long_ok = g.use_f16_kv_cache && hd % 32 == 0 && g.seq_len % 8 == 0 && (grp == 1 || grp == 2 || grp == 4 || grp == 8) &&
-                      !(g.flags & CRABML_HIP_LLAMA_NO_LONG_ATTENTION);
+    const bool long_geom = g.use_f16_kv_cache && hd % 32 == 0 && (grp == 1 || grp == 2 || grp == 4 || grp == 8) &&
+                           !(g.flags & CRABML_HIP_LLAMA_NO_LONG_ATTENTION);
+    c->attn_long_ok = long_geom && g.seq_len % 8 == 0;
     c->attn_long_from = g.attn_long_from ? g.attn_long_from : 224;  // exact kernels: measured crossover on MI355X (Llama-3-8B shape) ~200-220
     if (c->attn_long_ok && g.seq_len * 4 > 64 * 1024) {
       // the softmax kernels keep a head's score row in LDS: rows past 16384 positions need the raised dynamic-LDS limit,
@@ -1699,6 +1701,7 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
         c->attn_long_ok = false;
       (void)hipGetLastError();
     }
+    c->exact_long_ok = c->attn_long_ok;
     if (c->attn_long_ok) {
       A(n_heads_l * g.seq_len * 4, (void**)&c->scores_g);
       A(n_heads_l * g.seq_len * 2, (void**)&c->p16);
@@ -1715,7 +1718,9 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
       }
     }
     // the fast step's long-context attention: split-KV with f32 accumulation (k_attn_flash) unless the exact chain is asked for
-    if (c->attn_long_ok && !dev->strict_order && !(g.flags & CRABML_HIP_LLAMA_EXACT_ATTENTION)) {
+    // (k_attn_flash reads the cache rows only -- head_dim halves each --, so any seq_len will do: a cache of 1001 positions must not
+    // fall back to one workgroup per head, 45 us per layer at 900 positions)
+    if (long_geom && !dev->strict_order && !(g.flags & CRABML_HIP_LLAMA_EXACT_ATTENTION)) {
       c->flash_ticket = (g.flags & CRABML_HIP_LLAMA_FLASH_TICKET) != 0;
       const FlashFn fn = flash_kernel((int)grp, (int)hd, qt == CRABML_HIP_Q8_1, c->flash_ticket);
       if (fn != nullptr && raise_dyn_lds(dev, (const void*)fn, (int)flash_lds_bytes((int)grp, (int)hd)) == hipSuccess) {
@@ -1738,6 +1743,7 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
         A(n_kv_l * 4, (void**)&c->flash_tick);
         if (rc == 0 && !dry && hipMemsetAsync(c->flash_tick, 0, n_kv_l * 4, dev->stream) != hipSuccess) rc = CRABML_HIP_UNEXPECTED;
         c->attn_flash = rc == 0;
+        if (c->attn_flash) c->attn_long_ok = true;
         // Below ~768 cached positions the merge inside the launch (last-arriving workgroup of a kv head, ticket word) beats the
         // second launch -- 7.4 vs 5.1 + 4.1 us per layer at 128 positions, 8.7 vs 10.0 at 512, 10.8 vs 9.95 at 1024
         // (profiles/r05_flash_ticket_sweep.md; same partials, same merge order: bit-identical): a third graph variant serves that range.

@@ -10,6 +10,8 @@ the kernel's, that separates the two paths end to end (tests/test_hip_long_conte
 import numpy as np
 import pytest
 
+from crabml_amd import synth
+
 pytestmark = pytest.mark.gpu
 
 
@@ -115,3 +117,21 @@ def test_flash_prefill_attention_equals_float64_arithmetic(ca, n_heads, n_kv, hd
         worst = max(worst, err)
         assert err <= 1.5e-3, (pos0, rows, err)
     print(f"flash prefill vs float64, {n_heads} heads / {n_kv} kv x {hd}: worst {worst:.2e} of max|out|")
+
+
+def test_a_cache_length_that_is_no_multiple_of_eight_keeps_the_split_kv_kernels(ca):
+    """The exact long-context kernels read score / probability rows of seq_len elements as 16-byte vectors (seq_len % 8 == 0);
+    k_attn_flash reads cache rows only.  A cache of 203 positions used to drop the fast step to one workgroup per head past 96
+    positions (45 us per layer at 900 positions of the 8B shape); now it runs the same kernels as a cache of 208 -- the cache row
+    stride differs, nothing else: the logits agree bit for bit."""
+    model = synth.build_model(synth.SHAPES["tiny-hd128"], synth.Q4_0, seed=77)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    odd = ca.HipLlamaRunner(conf, w, dev, 203, True)
+    even = ca.HipLlamaRunner(conf, w, dev, 208, True)
+    odd_eager = ca.HipLlamaRunner(conf, w, dev, 203, True, False)
+    for i in range(200):
+        t = (5 * i + 2) % 1000
+        a, b, c = odd.forward(t, i).copy(), even.forward(t, i).copy(), odd_eager.forward(t, i).copy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"cache of 203 vs 208 positions, step {i}"
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), f"graph vs eager, step {i}"
