@@ -174,3 +174,36 @@ def test_single_ops_are_unaffected_by_the_queue(ca):
     assert np.all(raw[:, 0] == 1) and np.all(raw[:, 1] == 3)
     st = dev.lazy_stats()
     assert st["replayed"] == st["recorded"] and st["fused_tokens"] == 0
+
+
+def test_two_runners_taking_turns_on_one_device(ca):
+    """Two Llama2Runner instances over the SAME weights, each with its own KV caches, advancing token by token in turns (two
+    sequences served by one process): every switch is a token whose cache handles are not the learned context's -- it must be
+    re-learned or replayed, never served by the other runner's context.  Strict device: both streams bit-identical to the per-op
+    launches and to the oracle."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_0, seed=23)
+    odev = o.OracleDevice(thread_num=4, use_avx2=False)
+    oconf, ow = to_oracle(model, odev)
+    streams = ([1, 365, 400, 282, 7, 99], [3, 512, 99, 7, 282, 400])
+    refs = []
+    for toks in streams:
+        orr = o.OracleLlamaRunner(oconf, ow, odev, 32, True)
+        refs.append([orr.forward([t], i).copy() for i, t in enumerate(toks)])
+    lazy = ca.HipTensorDevice(0, False, 0, True)
+    conf, w = synth.to_hip(model, lazy)
+    ra, rb = ca.Llama2Runner(conf, w, lazy, 32, True), ca.Llama2Runner(conf, w, lazy, 32, True)
+    for i in range(6):
+        a = ra.forward([streams[0][i]], i).copy()
+        b = rb.forward([streams[1][i]], i).copy()
+        assert np.array_equal(u32(a), u32(refs[0][i])), f"first runner, step {i}"
+        assert np.array_equal(u32(b), u32(refs[1][i])), f"second runner, step {i}"
+    # ... and a stretch of one runner alone afterwards is served by the fused step again
+    st0 = lazy.lazy_stats()
+    extra = [5, 6, 7, 8]
+    orr = o.OracleLlamaRunner(oconf, ow, odev, 32, True)
+    for i, t in enumerate(streams[0]):
+        orr.forward([t], i)
+    for j, t in enumerate(extra):
+        assert np.array_equal(u32(ra.forward([t], 6 + j)), u32(orr.forward([t], 6 + j))), f"alone, step {j}"
+    st1 = lazy.lazy_stats()
+    assert st1["fused_tokens"] - st0["fused_tokens"] >= len(extra) - 1, (st0, st1)
