@@ -168,6 +168,7 @@ struct crabml_hip_llama {
   int flash_min_rows = FLASH_MIN_ROWS;  // cached rows per active slice, at least
   float* flash_part = nullptr;  // [n_kv_l][flash_S][G][hd + 2] partial {O, m, l}
   unsigned* flash_tick = nullptr;  // [n_kv_l] arrival counters (monotonic)
+  int gu_rows = 0;              // > 0 (tensor-parallel ranks): gate/up leaves h as f32 from workgroups of this many rows, ffn_down quantizes it
   int attn_s_rows = 0;          // > 0: variant 0 runs k_attn_s (K / V staged through LDS) with room for this many cached rows
   size_t attn_s_lds = 0;
   float* scores_g = nullptr;    // [n_heads_l][seq_len] f32
@@ -494,7 +495,8 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
   // ... and between ffn_down of layer l and q/k/v of layer l + 1 (the last ffn_down feeds the classifier launch: exact planes)
   const bool defer_down = c->defer_norm && !Q81;
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
-  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next, bool defer = false) -> int {
+  auto gemv_out = [&](const crabml_hip_buf* w, const ActPtrs& a, int k, uint32_t stage, const float* wnext, float eps_next, bool defer = false,
+                      const float* xin = nullptr) -> int {
     CH_TRY(P0(&pr, stage, dim, k));
     float* dst = tp ? c->partial : c->x;
     if (norm_epi) {
@@ -502,7 +504,23 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
       // long rows (ffn_down): two workgroups per chunk, so that every CU streams (a CU sustains ~26 GB/s here)
       const int split = split_of(k);
       const TpP2P tpv = tp_view(c, tp);
-      if (tpv.n > 1) {  // tensor parallel over a P2P group: the collective runs inside this launch
+      if (xin != nullptr && !Q81) {  // (tensor-parallel ranks) the rhs arrives as f32 -- h from k_gateup_h -- and is quantized in the prologue
+        if constexpr (!Q81) {
+          const size_t qlds = q8_0_lds_bytes(k / 32);
+          if (tpv.n > 1 && split == 2)
+            launch_k(st, R, k_gemv_res_nq<FMT, 2, 1, true>, dim3(dim / 16), dim3(1024), qlds, planes_of(w), act_view<FMT>(a), xin, c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
+          else if (tpv.n > 1)
+            launch_k(st, R, k_gemv_res_nq<FMT, 1, 1, true>, dim3(dim / 32), dim3(1024), qlds, planes_of(w), act_view<FMT>(a), xin, c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
+          else if (split == 2)
+            launch_k(st, R, k_gemv_res_nq<FMT, 2, 1>, dim3(dim / 16), dim3(1024), qlds, planes_of(w), act_view<FMT>(a), xin, c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
+          else
+            launch_k(st, R, k_gemv_res_nq<FMT, 1, 1>, dim3(dim / 32), dim3(1024), qlds, planes_of(w), act_view<FMT>(a), xin, c->x, wnext, eps_next, ad.q,
+                     ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, NoTp{});
+        }
+      } else if (tpv.n > 1) {  // tensor parallel over a P2P group: the collective runs inside this launch
         if (split == 2)
           launch_k(st, R, k_gemv_res_nq<FMT, 2, false, true>, dim3(dim / 16), dim3(1024), 0, planes_of(w), act_view<FMT>(a), (const float*)nullptr,
                    c->x, wnext, eps_next, ad.q, ad.d, ad.isum, ng, k / 32, Planes6{nullptr, 0}, tpv);
@@ -629,7 +647,12 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     // gate / up + silu * mul (llama2.rs:620-630), local rows
     CH_TRY(P0(&pr, 3, 2.0 * hidden_l, dim));
     const RmsTail rt{c->rsums, dim / 32, 1.0f / (float)dim, 1e-5f};  // eps: the literal 1e-5 (llama2.rs:611)
-    if (c->ord)
+    const bool hq = c->gu_rows > 0 && !c->ord && norm_epi && !Q81 && !defer_wo;
+    if (hq) {
+      if constexpr (!Q81)
+        launch_k(st, R, k_gateup_h<FMT>, dim3(hidden_l / c->gu_rows), dim3(c->gu_rows / 2 * 64), 0, planes_of(c->gate[l]), planes_of(c->up[l]),
+                 act_view<FMT>(ad), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 32);
+    } else if (c->ord)
       launch_k(st, R, k_gateup_q_ord<FMT>, dim3(hidden_l / 32), dim3(1024), (size_t)64 * (((dim / 32 + 3) & ~3) + 4) * sizeof(float), planes_of(c->gate[l]),
                planes_of(c->up[l]), act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32);
     else if (defer_wo) {
@@ -641,7 +664,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
                act_view<FMT>(ad), dev->exp_table, ah.q, ah.d, ah.isum, dim / 32, rt);
     CH_TRY(P1(&pr));
     // down (+ residual, llama2.rs:633-636): k = the local hidden slice
-    CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps, defer_down && l + 1 < L));
+    CH_TRY(gemv_out(c->down[l], ah, hidden_l, 4, wnext_down, g.rms_norm_eps, defer_down && l + 1 < L, hq ? c->h : nullptr));
   }
   CH_HIP(dev, hipGetLastError());
   return 0;
@@ -1795,6 +1818,16 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
   c->defer_norm = c->norm_epi && tp == 1 && !ord && !dev->strict_order && (wt == CRABML_HIP_Q4_0 || wt == CRABML_HIP_Q8_0) &&
                   !(g.flags & CRABML_HIP_LLAMA_EXACT_NORM) && (int)(g.embedding_dim / 32) <= dev->n_cu;
   if (c->defer_norm) A(g.embedding_dim / 16 * 4, (void**)&c->rsums);
+  // A tensor-parallel rank's gate/up: hidden / tp / 32 workgroups of 32 rows would leave most CUs idle.  h stays f32 from workgroups
+  // of `gu_rows` rows (the largest even divisor of the rank's rows, at most 32, that gives at least one workgroup per CU) and
+  // ffn_down quantizes it in its prologue.
+  if (c->norm_epi && tp > 1 && !ord && !dev->strict_order && (wt == CRABML_HIP_Q4_0 || wt == CRABML_HIP_Q8_0) &&
+      !(g.flags & CRABML_HIP_LLAMA_NO_H_CONSUMER_QUANT) && hidden_l % 32 == 0 && (int)(hidden_l / 32) * 2 <= dev->n_cu && !dry) {
+    int pick = 0;
+    for (int r = 30; r >= 2 && !pick; r -= 2)
+      if (hidden_l % r == 0 && (int)(hidden_l / r) >= dev->n_cu && (int)(hidden_l / r) <= 2 * dev->n_cu) pick = r;
+    if (pick && q8_0_lds_bytes((int)(hidden_l / 32)) <= 60 * 1024) c->gu_rows = pick;
+  }
   c->q8k_producers = c->norm_epi_k && !(g.flags & (CRABML_HIP_LLAMA_NO_RHS_PROLOGUE | CRABML_HIP_LLAMA_NO_Q8K_PRODUCERS)) && dim_l % 256 == 0 &&
                      hidden_l % 256 == 0 && (hd == 64 || hd == 128 || hd == 256) && (int)(hidden_l / 32) <= 2 * dev->n_cu;
   if (c->q8k_producers) {

@@ -181,6 +181,45 @@ __device__ __forceinline__ void stage_copy_q8k(const ActQ8_K& act, int nsb, i32x
   __syncthreads();
 }
 
+// Q8_0 quantizer of an f32 vector into LDS planes (q[k] | d[nb] f16 | isum[nb] i32): a half-wave per 32-element block
+// (quant_lane32 = buf_q8_0.rs:87-134, the arithmetic of the gate/up epilogue and of the quantizer launch), four rounds of loads in
+// flight per wave.  A tensor-parallel rank's ffn_down runs it as its prologue on h (k_gateup_h leaves h as f32), each workgroup
+// for itself: 14 KB of L2 reads at the 70B / 8 shape, under the first weight requests.
+// (two phases so that the caller can put its first weight requests BETWEEN them: loads return in order, and the rows of h are what
+// the barrier below waits for -- requested behind 64 KB of weights they arrived 2 us later)
+struct StageQ8Regs {
+  float v[4];
+};
+__device__ __forceinline__ StageQ8Regs stage_quant_q8_0_request(const float* __restrict__ x, int nb, int b0) {
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int l32 = lane & 31, hf = lane >> 5;
+  StageQ8Regs r;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int b = b0 + u * 2 * nw + hf;
+    r.v[u] = x[(size_t)(b < nb ? b : nb - 1) * 32 + l32];
+  }
+  return r;
+}
+__device__ __forceinline__ void stage_quant_q8_0_store(const StageQ8Regs& r, int nb, int b0, signed char* sq, unsigned short* sd, int* ss) {
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int l32 = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    if (b0 + u * 2 * nw >= nb) break;  // wave-uniform
+    const int b = b0 + u * 2 * nw + hf;
+    const QLane o = quant_lane32<false>(r.v[u], true);
+    if (b < nb) {
+      sq[b * 32 + l32] = o.q;
+      if (l32 == 0) {
+        sd[b] = o.d;
+        ss[b] = o.aux;
+      }
+    }
+  }
+}
+__host__ __device__ inline size_t q8_0_lds_bytes(int nb) { return (size_t)nb * 32 + (size_t)((nb + 1) & ~1) * 2 + (size_t)nb * 4; }
+
 struct NormGather {
   unsigned long long* slots;  // dim/16 granules: each workgroup's ordered sum of squares over its rows
   unsigned long long* pair;   // dim row granules (read by a split chunk's partner / a Q8_K super-block's neighbours)
@@ -482,6 +521,60 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       rows_partial_q6k<RW>(w6.base, w6.off_qh, act, row, nchunks * 32, nb, lane, acc);
     else
       rows_partial_q4k<RW>(w.q, (const i32x4*)w.d, act, row, nchunks * 32, nb, lane, acc);
+  } else if constexpr (QIN == 1) {
+    // the rhs arrives as f32 (h from k_gateup_h): quantized to Q8_0 into LDS by this workgroup, under the first weight requests
+    static_assert(KQ || QIN != 1 || FMT == CRABML_HIP_Q4_0 || FMT == CRABML_HIP_Q8_0, "Q8_0 rhs");
+    using F = BlockFmt<FMT>;
+    extern __shared__ i32x4 lds_act[];
+    signed char* sq = (signed char*)lds_act;
+    unsigned short* sd = (unsigned short*)(sq + (size_t)nb * 32);
+    int* ss = (int*)(sd + ((nb + 1) & ~1));
+#pragma unroll
+    for (int r = 0; r < RW; r++) acc[r] = 0.f;
+    const int nu = nb * F::UNITS;
+    typename F::Blk ka0[RW], kb0[RW];
+    const int ua = lane < nu ? lane : nu - 1, ub = lane + 64 < nu ? lane + 64 : nu - 1;
+    const int nw16 = (int)(blockDim.x >> 6);
+    StageQ8Regs hq = stage_quant_q8_0_request(xin, nb, wave * 2);  // h first ...
+#pragma unroll
+    for (int r = 0; r < RW; r++) {                                  // ... the weights behind it, in flight while h is quantized
+      ka0[r] = F::load(w.q, w.d, (size_t)(row + r), nb, ua);
+      kb0[r] = F::load(w.q, w.d, (size_t)(row + r), nb, ub);
+    }
+    for (int b0 = wave * 2; b0 < nb; b0 += 8 * nw16) {
+      if (b0 != wave * 2) hq = stage_quant_q8_0_request(xin, nb, b0);
+      stage_quant_q8_0_store(hq, nb, b0, sq, sd, ss);
+    }
+    __syncthreads();
+    const ActQ8_0 la{(const i32x4*)sq, sd, ss};
+    if (lane < nu) {
+      const XUnit xa = F::loadx(la, ua);
+#pragma unroll
+      for (int r = 0; r < RW; r++) acc[r] += F::term(ka0[r], xa);
+    }
+    if (lane + 64 < nu) {
+      const XUnit xb = F::loadx(la, ub);
+#pragma unroll
+      for (int r = 0; r < RW; r++) acc[r] += F::term(kb0[r], xb);
+    }
+    for (int u = lane + 128; u < nu; u += 128) {
+      const int u2 = u + 64;
+      const bool two = u2 < nu;
+      const int uu = two ? u2 : u;
+      typename F::Blk ka[RW], kb[RW];
+#pragma unroll
+      for (int r = 0; r < RW; r++) {
+        ka[r] = F::load(w.q, w.d, (size_t)(row + r), nb, u);
+        kb[r] = F::load(w.q, w.d, (size_t)(row + r), nb, uu);
+      }
+      const XUnit xa = F::loadx(la, u), xb = F::loadx(la, uu);
+#pragma unroll
+      for (int r = 0; r < RW; r++) acc[r] += F::term(ka[r], xa);
+      if (two) {
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] += F::term(kb[r], xb);
+      }
+    }
   } else {
     using F = BlockFmt<FMT>;
 #pragma unroll
@@ -840,6 +933,39 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typenam
       d[blk] = o.d;
       store_qaux<Q81>(isum, blk, o.aux);
     }
+  }
+}
+// The rows of k_gateup_q with h left as f32 (ffn_down quantizes it in its prologue, stage_quant_q8_0): without the 32-row quant block
+// the workgroup's row count is free.  For a tensor-parallel rank, whose hidden / tp / 32 workgroups would cover less than half the
+// CUs (112 of 256 at the 70B / 8 shape: 10.8 us for 33 MB, a CU streams ~26 GB/s whatever is resident), the host picks a row
+// count that gives one workgroup per CU.  Same dots, same SiLU * mul: h -- and the planes ffn_down makes of it -- bit for bit.
+template <int FMT>
+__global__ __launch_bounds__(1024) void k_gateup_h(Planes wg, Planes wu, typename ActOf<FMT>::type act, const unsigned short* __restrict__ exp_tab,
+                                                   float* __restrict__ h, int m, int nb) {
+  using F = BlockFmt<FMT>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = ((int)blockIdx.x * (int)(blockDim.x >> 6) + wave) * 2;
+  if (row >= m) return;
+  float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+  const int nu = nb * F::UNITS;
+  for (int u = lane; u < nu; u += 64) {
+    typename F::Blk bg0 = F::load(wg.q, wg.d, (size_t)row, nb, u);
+    typename F::Blk bu0 = F::load(wu.q, wu.d, (size_t)row, nb, u);
+    typename F::Blk bg1 = F::load(wg.q, wg.d, (size_t)row + 1, nb, u);
+    typename F::Blk bu1 = F::load(wu.q, wu.d, (size_t)row + 1, nb, u);
+    const XUnit x = F::loadx(act, u);
+    g0 += F::term(bg0, x);
+    u0 += F::term(bu0, x);
+    g1 += F::term(bg1, x);
+    u1 += F::term(bu1, x);
+  }
+  g0 = wave_sum_f32(g0);
+  u0 = wave_sum_f32(u0);
+  g1 = wave_sum_f32(g1);
+  u1 = wave_sum_f32(u1);
+  if (lane == 0) {
+    h[row] = silu_mul(g0, u0, exp_tab);
+    h[row + 1] = silu_mul(g1, u1, exp_tab);
   }
 }
 // strict order: k_gateup_q with the block terms of the 32 gate and 32 up rows parked in LDS (row stride nt + 4 floats: the 64 chain

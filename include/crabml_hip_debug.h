@@ -97,6 +97,8 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
 #define CRABML_HIP_LLAMA_NO_STAGED_ATTENTION 8192 /* A/B: short-context attention without the LDS staging of K / V (k_attn) */
 #define CRABML_HIP_LLAMA_FLASH_TICKET 2097152 /* A/B: k_attn_flash merges its partials in the last-arriving workgroup of a kv head
                                                 (ticket word, write-through hand-off) instead of a second launch */
+#define CRABML_HIP_LLAMA_NO_H_CONSUMER_QUANT 4096 /* A/B, tensor-parallel ranks: gate/up quantizes h itself (hidden / tp / 32 workgroups of 32 rows, k_gateup_q)
+                                                   instead of leaving h as f32 from one workgroup per CU for ffn_down's prologue (bit-identical) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 
