@@ -136,7 +136,18 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
 #pragma unroll
     for (int u = 0; u < G::B_LOADS; u++) {
       const int t = tid + 256 * u, col = t / (KC * 2), rem = t % (KC * 2), kb = rem / 2, pc = rem % 2;
-      *(i32x4*)(sB + (kb * CW + col) * BRW + pc * 4) = rb[u];
+      if constexpr (FMT == CRABML_HIP_Q4_0) {
+        // lane group g multiplies the block's elements [4 g, 4 g + 4) and [16 + 4 g, ..): dword g of piece 0 and of piece 1 go side
+        // by side, so that the fragment is ONE 8-byte LDS read (the LDS pipe is what this kernel saturates: every instruction
+        // costs it ~8 cycles whatever its width -- rocprofv3 SQ_ACTIVE_INST_LDS / SQ_INSTS_LDS, profiles/r05_prefill_gemm_experiments.md)
+        unsigned* brow = sB + (kb * CW + col) * BRW + pc;
+        brow[0] = (unsigned)rb[u][0];
+        brow[2] = (unsigned)rb[u][1];
+        brow[4] = (unsigned)rb[u][2];
+        brow[6] = (unsigned)rb[u][3];
+      } else {
+        *(i32x4*)(sB + (kb * CW + col) * BRW + pc * 4) = rb[u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < G::S_LOADS; u++) {
@@ -146,7 +157,8 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
         ((unsigned*)sBd)[kb * 64 + rc] = rbd[u];
       } else {
         sAd[kb * 64 + rc] = h2f((unsigned short)rad[u]);
-        sBd[kb * 64 + rc] = h2f((unsigned short)rbd[u]);
+        // (the activation scales of a lane's NT column tiles side by side: one 16-byte read per block instead of NT reads)
+        sBd[kb * 64 + (rc & 15) * 4 + (rc >> 4)] = h2f((unsigned short)rbd[u]);
       }
     }
   };
@@ -237,10 +249,14 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const char* __restrict__ wq, 
         const int col = 16 * jt + i;
         const unsigned* brow = sB + (kb * CW + col) * BRW;
         if (FMT == CRABML_HIP_Q4_0)
-          Bf[jt] = (long)(((unsigned long long)brow[4 + g] << 32) | (unsigned long long)brow[g]);
+          Bf[jt] = *(const long*)(brow + 2 * g);  // (dword g of piece 0 | dword g of piece 1: see commit)
         else
           Bf[jt] = *(const long*)(brow + 2 * g);
-        dx[jt] = sBd[kb * 64 + col];
+      }
+      {
+        const f32x4 dx4 = *(const f32x4*)(sBd + kb * 64 + i * 4);
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) dx[jt] = dx4[jt];
       }
       i32x4 D[NT];
 #pragma unroll
