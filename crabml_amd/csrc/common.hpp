@@ -76,6 +76,11 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //   Q8_0: qs[n][32]            | d[n] f16
 //   Q4_1: qs[n][16]            | dm[n] (d f16, m f16)
 //   Q4_K: qs[n][128]           | hdr[n][16]: d f16, dmin f16, then the 8 (scale, min) 6-bit pairs of scales[12]
+//                                (qs CLASS-MAJOR since round 6: inside every 32-byte chunk -- the low / high nibbles of one 64-element
+//                                pair -- byte 4 l + k holds what the file's byte 8 k + l held, l = 0..7, k = 0..3, so that dword l
+//                                carries the four elements e of the 32-group with e % 8 == l: the reference keeps eight f32 lanes per
+//                                row fed by exactly those classes (buf_q4_k.rs:243-263), and one v_dot4 against the equally permuted
+//                                activation plane (`qp` below) is a whole class sum; q4k_perm_index)
 //                                re-packed pair-major -- 24 bits per 64-element pair p, little endian at bit 24 p:
 //                                scale[2p] | scale[2p+1] << 6 | min[2p] << 12 | min[2p+1] << 18 (get_scale_min_k4,
 //                                util.rs:19-27, is a bit permutation of the same 96 bits; done once at upload) --
@@ -92,7 +97,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // Quantized ACTIVATIONS (the rhs of matmul_vec) live in a per-buffer scratch, also as planes:
 //   Q8_0: qs[n] i8 | d[n/32] f16 | isum[n/32] i32 (sum of the 32 quants; exact, derived)
 //   Q8_1: qs[n] i8 | d[n/32] f16 | s[n/32] f16
-//   Q8_K: qs[n] i8 | d[n/256] f32 | bsums[n/16] i16
+//   Q8_K: qs[n] i8 | d[n/256] f32 | bsums[n/16] i16 | qp[n] i8 -- the same quants once more, class-major inside every 32-element
+//         group (byte 4 l + k = element 8 k + l): the plane the Q4_K kernels read; every other K-quant reads qs
 //   F16 : h[n] f16 (buf/api.rs:198)
 struct WeightLayout {
   size_t n_blocks = 0;
@@ -103,7 +109,11 @@ WeightLayout weight_layout(uint32_t dtype, size_t n_elems);
 
 struct ActLayout {
   size_t off_d = 0, off_aux = 0, total = 0;
+  size_t off_p = 0;  // Q8_K: the class-major copy of the quants (read by the Q4_K kernels)
 };
+// position of element e (0..31) of a 32-element group inside its class-major 32 bytes, and back (an involution it is not:
+// element 8 k + l sits at byte 4 l + k)
+__host__ __device__ inline int q4k_perm_index(int e) { return 4 * (e & 7) + (e >> 3); }
 ActLayout act_layout(uint32_t qtype, size_t n_elems);
 
 }  // namespace crabml_hip

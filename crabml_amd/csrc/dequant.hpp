@@ -50,7 +50,7 @@ __device__ __forceinline__ float dequant_elem(const char* __restrict__ w, int dt
       const unsigned f = q4k_pair_field(u0, u1, u2, c);
       const int s6 = (int)((l >= 32 ? f >> 6 : f) & 63u), m6 = (int)((l >= 32 ? f >> 18 : f >> 12) & 63u);
       float d1 = d * (float)s6, m1 = mn * (float)m6;
-      unsigned char q = qs[32 * c + (l & 31)];
+      unsigned char q = qs[32 * c + q4k_perm_index(l & 31)];  // (class-major qs plane, common.hpp)
       float qf = (float)(l >= 32 ? (q >> 4) : (q & 0xF));
       v = d1 * qf - m1;
       break;

@@ -175,4 +175,15 @@ __device__ __forceinline__ Q8KLane q8k_wave_quant(const f32x4 v, int lane) {
   return o;
 }
 
+// The class-major copy of a super-block's quants (plane `qp`, common.hpp): q8k_wave_quant leaves lane L the four consecutive
+// elements 4 L .. 4 L + 3; element 4 j + k of 32-group c = L / 8 (j = L % 8) goes to byte 4 ((4 j + k) % 8) + (4 j + k) / 8 =
+// 16 (j & 1) + 4 k + j / 2 of the group.  sb_base: the super-block's 256 bytes (global memory or LDS).
+__device__ __forceinline__ void q8k_store_class_major(signed char* sb_base, int lane, unsigned packed) {
+  signed char* p = sb_base + 32 * (lane >> 3) + 16 * (lane & 1) + ((lane & 7) >> 1);
+  p[0] = (signed char)(packed & 0xffu);
+  p[4] = (signed char)((packed >> 8) & 0xffu);
+  p[8] = (signed char)((packed >> 16) & 0xffu);
+  p[12] = (signed char)(packed >> 24);
+}
+
 }  // namespace crabml_hip

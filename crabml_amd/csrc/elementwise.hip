@@ -277,6 +277,33 @@ __global__ __launch_bounds__(256) void k_q4k_pack_scales(unsigned char* __restri
     q[3 * p + 2] = (unsigned char)(f >> 16);
   }
 }
+// Q4_K: the qs plane class-major, in place (common.hpp): one thread per 32-byte chunk, byte 4 l + k <- byte 8 k + l.  A byte move:
+// every nibble keeps its value; dequantized rows, block dots and the GEMM address the plane through q4k_perm_index.
+__global__ __launch_bounds__(256) void k_q4k_class_major(unsigned* __restrict__ qs, size_t chunk0, size_t n_chunks) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  unsigned* p = qs + (chunk0 + c) * 8;
+  unsigned in[8], out[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) in[i] = p[i];
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int e = 8 * k + l;  // source byte
+      v |= ((in[e >> 2] >> (8 * (e & 3))) & 0xffu) << (8 * k);
+    }
+    out[l] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) p[i] = out[i];
+}
+void launch_q4k_class_major(hipStream_t st, void* qs_plane, size_t blk0, size_t n_blocks) {
+  if (n_blocks == 0) return;
+  const size_t n_chunks = n_blocks * 4;
+  k_q4k_class_major<<<(unsigned)((n_chunks + 255) / 256), 256, 0, st>>>((unsigned*)qs_plane, blk0 * 4, n_chunks);
+}
 void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t n_blocks) {
   if (n_blocks == 0) return;
   k_q4k_pack_scales<<<(unsigned)((n_blocks + 255) / 256), 256, 0, st>>>((unsigned char*)hdr_plane, blk0, n_blocks);

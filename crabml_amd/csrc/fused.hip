@@ -793,7 +793,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   auto act_k = [&](char* planes, int n) {
     ActLayout al = act_layout(QT, (size_t)n);
     if constexpr (FMT == CRABML_HIP_Q4_K)
-      return ActQ8_K{(const i32x4*)planes, (const float*)(planes + al.off_d), (const short*)(planes + al.off_aux)};
+      return act_q8k_at(planes, al.off_d, al.off_aux, al.off_p);
     else
       return ActQ8_1{(const i32x4*)planes, (const unsigned short*)(planes + al.off_d), (const unsigned short*)(planes + al.off_aux)};
   };
@@ -831,6 +831,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       if (nepi) {
         NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg};
         ActLayout al = act_layout(QT, (size_t)dim);
+        ng.qp = (signed char*)(c->act_dim + al.off_p);
         signed char* oq = (signed char*)c->act_dim;
         void* od = (void*)(c->act_dim + al.off_d);
         void* ob = (void*)(c->act_dim + al.off_aux);
@@ -894,7 +895,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       if (aq8) {
         const ActLayout ala = act_layout(QT, (size_t)dim_l);
         const AttnQ8K k8{Q8KExchange{c->a8gran, c->state + 4, c->state + 5, n_segments(c), seg}, (float*)(c->act_attn + ala.off_d),
-                         (short*)(c->act_attn + ala.off_aux)};
+                         (short*)(c->act_attn + ala.off_aux), (signed char*)(c->act_attn + ala.off_p)};
         enqueue_attention(c, l, (signed char*)c->act_attn, nullptr, nullptr, PrefetchPlan{}, 0, prof, &k8);
       } else {
         enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
@@ -914,11 +915,11 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       if (qout)
         launch_k(st, R, k_gateup_k_lds<true>, dim3(hidden_l / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
-                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux));
+                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p));
       else
         launch_k(st, R, k_gateup_k_lds<false>, dim3((hidden_l + 31) / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)nullptr,
-                 (float*)nullptr, (short*)nullptr);
+                 (float*)nullptr, (short*)nullptr, (signed char*)nullptr);
     } else {
       launch_k(st, R, k_gateup<FMT>, dim3((hidden_l + 1) / 2), dim3(128), 0, planes_k(c->gate[l]), planes_k(c->up[l]),
                act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / BE);

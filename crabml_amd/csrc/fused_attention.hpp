@@ -201,6 +201,7 @@ struct AttnQ8K {
   Q8KExchange ex;
   float* d;
   short* bs;
+  signed char* qp;  // the class-major copy of the quants
 };
 template <int HD, bool STAMP = false>  // HD: head_dim when known at compile time (128: the score loop is fully unrolled), 0 = run time
 __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, const unsigned short* __restrict__ kc,
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void k_attn_s(const float* __restrict__ q, con
       qs[2 * tid + 1] = v1;
     }
     __syncthreads();
-    if (wave == 0) q8k_exchange_store(k8.ex, qs, head * hd, hd, lane, xq, k8.d, k8.bs);
+    if (wave == 0) q8k_exchange_store(k8.ex, qs, head * hd, hd, lane, xq, k8.d, k8.bs, k8.qp);
   } else if (xq != nullptr && wave * 64 < npair) {
   // ---- quantize the head's output for wo: a 32-element block = the 16 lanes of one DPP row (two columns each)  // whole waves (hd % 32 == 0 here: rows of 16 lanes are all-live or all-dead)
     const bool live = tid < npair;

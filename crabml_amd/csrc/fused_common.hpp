@@ -65,9 +65,10 @@ struct Q8KExchange {
   int nseg, seg;
 };
 // called by ONE whole wave.  own: this workgroup's n_own consecutive values (LDS), the first of which is element `first` of
-// the vector; n_own divides 256 and is a multiple of 16.  oq / od / obs: the Q8_K planes of the vector (q | d | bsums).
+// the vector; n_own divides 256 and is a multiple of 16.  oq / od / obs / oqp: the Q8_K planes of the vector (q | d | bsums | qp).
 __device__ __forceinline__ void q8k_exchange_store(const Q8KExchange& ex, const float* own, int first, int n_own, int lane,
-                                                   signed char* __restrict__ oq, float* __restrict__ od, short* __restrict__ obs) {
+                                                   signed char* __restrict__ oq, float* __restrict__ od, short* __restrict__ obs,
+                                                   signed char* __restrict__ oqp) {
   const unsigned epoch = (unsigned)(*ex.serial) * (unsigned)ex.nseg + (unsigned)ex.seg + 1u;
   if (n_own < 256) {
     for (int i = lane; i < n_own; i += 64)
@@ -100,6 +101,7 @@ __device__ __forceinline__ void q8k_exchange_store(const Q8KExchange& ex, const 
   const Q8KLane o = q8k_wave_quant(v, lane);
   if (mine) {
     ((unsigned*)oq)[sb * 64 + lane] = o.packed;
+    q8k_store_class_major(oqp + sb * 256, lane, o.packed);
     if ((lane & 3) == 0) obs[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
   }
   if (lane == 0 && first == sb * 256) od[sb] = o.d;

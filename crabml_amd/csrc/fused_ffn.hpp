@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void k_tp_allreduce(float* __restrict__ buf, i
 // Q8_K quantizer of an f32 vector straight into LDS planes (q | d | bsums, as stage_act_q8k lays them out): one
 // wave per super-block.  The Q4_K wo / ffn_down kernels run it as their prologue on the attention output / h,
 // each workgroup for itself (16 KB / 56 KB of L2 reads), instead of a quantizer launch in front of them.
-__device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int nsb, unsigned* sq, float* sd, short* sbs) {
+// cm: the quants go to LDS class-major (the rhs of Q4_K rows; common.hpp) instead of in element order (a Q6_K matrix of a *_K_M mix)
+__device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int nsb, unsigned* sq, float* sd, short* sbs, bool cm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // four super-blocks of loads in flight per wave (ffn_down: 56 super-blocks over 16 waves; a round is one L2 latency)
   for (int sb0 = wave; sb0 < nsb; sb0 += 4 * nw) {
@@ -164,7 +165,10 @@ __device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int
       const int sb = sb0 + u * nw;
       if (sb >= nsb) break;  // wave-uniform
       const Q8KLane o = q8k_wave_quant(v[u], lane);
-      sq[sb * 64 + lane] = o.packed;
+      if (cm)
+        q8k_store_class_major((signed char*)sq + sb * 256, lane, o.packed);
+      else
+        sq[sb * 64 + lane] = o.packed;
       if ((lane & 3) == 0) sbs[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
       if (lane == 0) sd[sb] = o.d;
     }
@@ -174,8 +178,9 @@ __device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int
 
 // the finished Q8_K planes of a vector (written by the kernel that produced it: q8k_exchange_store) copied into LDS:
 // coalesced 16-byte pieces, one round trip
-__device__ __forceinline__ void stage_copy_q8k(const ActQ8_K& act, int nsb, i32x4* sq, float* sd, short* sbs) {
-  for (int i = threadIdx.x; i < nsb * 16; i += blockDim.x) sq[i] = act.q[i];
+__device__ __forceinline__ void stage_copy_q8k(const ActQ8_K& act, int nsb, i32x4* sq, float* sd, short* sbs, bool cm) {
+  const i32x4* src = cm ? act.qp : act.q;
+  for (int i = threadIdx.x; i < nsb * 16; i += blockDim.x) sq[i] = src[i];
   for (int i = threadIdx.x; i < nsb; i += blockDim.x) sd[i] = act.d[i];
   for (int i = threadIdx.x; i < nsb * 2; i += blockDim.x) ((i32x4*)sbs)[i] = ((const i32x4*)act.bsums)[i];
   __syncthreads();
@@ -227,6 +232,7 @@ struct NormGather {
   int* fault;
   int nseg, seg;
   float* sums;                // DEFER launches: the chunk sums of squares go here as plain floats (read by the NEXT launch)
+  signed char* qp = nullptr;  // Q8_K output: the class-major copy of the quants (the plane the next Q4_K GEMV reads)
 };
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -435,6 +441,7 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     const int l0 = (blk & 7) * 8 + part * (ROWS / 4);
     if (lane >= l0 && lane < l0 + ROWS / 4) {
       ((unsigned*)q)[sb * 64 + lane] = o.packed;
+      q8k_store_class_major(ng.qp + sb * 256, lane, o.packed);
       if ((lane & 3) == 0) ((short*)isum)[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
     }
     if (lane == 0 && (blk & 7) == 0 && part == 0) ((float*)d)[sb] = o.d;
@@ -482,10 +489,10 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     // and the quantizer run under the HBM latency of the stream's head
     if (w6.base != nullptr) {  // this layer's matrix is Q6_K (a *_K_M mix): same rhs, its own inner loop
       if constexpr (QIN == 2)
-        stage_copy_q8k(act, nb, lds_act, sd, sbs);
+        stage_copy_q8k(act, nb, lds_act, sd, sbs, false);
       else
-        stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
-      const ActQ8_K la6{lds_act, sd, sbs};
+        stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs, false);
+      const ActQ8_K la6{lds_act, sd, sbs, lds_act};
       rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
       nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
                                   (int)blockIdx.x, (int)gridDim.x, tp);
@@ -500,10 +507,10 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       for (int r = 0; r < RW; r++) pw[it][r] = q4k_load<false>(w.q, (const i32x4*)w.d, (size_t)(row + r), nb, c < nb * 8 ? c : nb * 8 - 1, lane);
     }
     if constexpr (QIN == 2)
-      stage_copy_q8k(act, nb, lds_act, sd, sbs);
+      stage_copy_q8k(act, nb, lds_act, sd, sbs, true);
     else
-      stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs);
-    const ActQ8_K la{lds_act, sd, sbs};
+      stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs, true);
+    const ActQ8_K la{lds_act, sd, sbs, lds_act};
 #pragma unroll
     for (int r = 0; r < RW; r++) acc[r] = 0.f;
 #pragma unroll
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename A
 template <bool QOUT>
 __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
                                                        float* __restrict__ h, int m, int nsb, Q8KExchange ex, signed char* __restrict__ oq,
-                                                       float* __restrict__ od, short* __restrict__ obs) {
+                                                       float* __restrict__ od, short* __restrict__ obs, signed char* __restrict__ oqp) {
   extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
   const int k = nsb * 256;
   i32x4* sq = lds_act;
@@ -820,11 +827,11 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
 #pragma unroll
   for (int r = 0; r < 2; r++)
     pw[r] = q4k_load<false>(wg.q, (const i32x4*)wg.d, (size_t)(row0 + r < m ? row0 + r : m - 1), nsb, lane < nch ? lane : nch - 1, lane);
-  for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.q[i];
+  for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.qp[i];  // (class-major: the rhs of Q4_K rows)
   for (int i = threadIdx.x; i < nsb; i += 1024) sd[i] = act.d[i];
   for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
   __syncthreads();
-  const ActQ8_K la{sq, sd, sbs};
+  const ActQ8_K la{sq, sd, sbs, sq};
   if (row0 >= m) return;
   float ag[2] = {0.f, 0.f}, au[2];
   if (lane < nch) {
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
   }
   if constexpr (QOUT) {
     __syncthreads();
-    if (wave == 0) q8k_exchange_store(ex, hv, (int)blockIdx.x * 32, 32, lane, oq, od, obs);
+    if (wave == 0) q8k_exchange_store(ex, hv, (int)blockIdx.x * 32, 32, lane, oq, od, obs, oqp);
   }
 }
 

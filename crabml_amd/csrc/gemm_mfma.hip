@@ -331,7 +331,8 @@ struct GemmGeoK {
 template <int NT>
 __global__ __launch_bounds__(256) void k_gemm_mfma_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh,
                                                        const char* __restrict__ act, size_t act_stride, size_t off_d, size_t off_aux,
-                                                       float* __restrict__ out, int m, int nsb, int b, int row_tiles, int* __restrict__ dbg) {
+                                                       size_t off_p, float* __restrict__ out, int m, int nsb, int b, int row_tiles,
+                                                       int* __restrict__ dbg) {
   using G = GemmGeoK<NT>;
   constexpr int CW = G::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q4k(const i32x4* __restrict__
     for (int u = 0; u < G::B_LOADS; u++) {
       const int t = tid + 256 * u, col = t >> 4, pc = t & 15;
       const int gcol = c0 + col < b ? c0 + col : b - 1;
-      rb[u] = *((const i32x4*)(act + (size_t)gcol * act_stride) + (size_t)sb * 16 + pc);
+      rb[u] = *((const i32x4*)(act + (size_t)gcol * act_stride + off_p) + (size_t)sb * 16 + pc);  // the class-major plane (common.hpp)
     }
     if (tid < CW) {
       const int gcol = c0 + tid < b ? c0 + tid : b - 1;
@@ -874,10 +875,10 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
     const i32x4* whk = (const i32x4*)(wp + w->wl.off_scale);
     if (narrow_k)
       launch_k(st, rec, k_gemm_mfma_q4k<2>, dim3(rtl * ctl), dim3(256), GemmGeoK<2>::LDS_BYTES, wqk, whk, (const char*)act, alk.total,
-               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl, dbg);
+               alk.off_d, alk.off_aux, alk.off_p, out, (int)m, nsb, (int)b, rtl, dbg);
     else
       launch_k(st, rec, k_gemm_mfma_q4k<4>, dim3(rtl * ctl), dim3(256), GemmGeoK<4>::LDS_BYTES, wqk, whk, (const char*)act, alk.total,
-               alk.off_d, alk.off_aux, out, (int)m, nsb, (int)b, rtl, dbg);
+               alk.off_d, alk.off_aux, alk.off_p, out, (int)m, nsb, (int)b, rtl, dbg);
     return true;
   }
   const ActLayout al = act_layout(w->dtype == CRABML_HIP_Q4_1 ? CRABML_HIP_Q8_1 : CRABML_HIP_Q8_0, k);

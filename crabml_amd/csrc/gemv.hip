@@ -315,7 +315,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         break;
       }
       case CRABML_HIP_Q4_K: {
-        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
         const int nsb = k / 256;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
@@ -326,7 +326,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         break;
       }
       case CRABML_HIP_Q5_K: {
-        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
         const int nsb = k / 256;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
@@ -337,7 +337,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         break;
       }
       case CRABML_HIP_Q6_K: {
-        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
         const int nsb = k / 256;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
@@ -348,7 +348,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         break;
       }
       case CRABML_HIP_Q8_K: {
-        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
         const int nsb = k / 256;
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
@@ -379,7 +379,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         break;
       }
       case CRABML_HIP_Q2_K: {
-        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
             launch_k(st, rec, k_gemv_pieces<PieceQ2_K, 2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 256);
@@ -389,7 +389,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
         break;
       }
       case CRABML_HIP_Q3_K: {
-        ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+        const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
         launch_rows(st, m, dev->n_cu, [&](int R, int grid, int tpb) {
           if (R == 2)
             launch_k(st, rec, k_gemv_pieces<PieceQ3_K, 2>, dim3(grid), dim3(tpb), 0, wp, w->wl.off_scale, w->wl.n_blocks, a, o, m, k / 256);
@@ -444,7 +444,8 @@ __global__ void k_block_dots_k(const unsigned char* __restrict__ w, int wtype, A
       ha = *(const i32x4*)qh;
       hb = *(const i32x4*)(qh + 16);
     }
-    const i32x4* xq = a.q + (size_t)sb * 16 + p * 4 + hi_half * 2;
+    // (Q4_K: weights and activations class-major inside the 32-group, common.hpp -- the group's sum is the same)
+    const i32x4* xq = (wtype == CRABML_HIP_Q4_K ? a.qp : a.q) + (size_t)sb * 16 + p * 4 + hi_half * 2;
     i32x4 x0 = xq[0], x1 = xq[1];
     int s = 0;
     for (int i = 0; i < 4; i++) {
@@ -513,7 +514,7 @@ int launch_piece_ints(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
   const char* wp = (const char*)w->ptr;
   const char* ap = (const char*)act;
   const ActLayout al = act_layout(CRABML_HIP_Q8_K, k);
-  ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+  const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
   const int nsb = (int)(k / 256);
   if (w->dtype == CRABML_HIP_Q4_K) {
     if (variant == 0)
@@ -542,18 +543,18 @@ void launch_block_dots(hipStream_t st, const crabml_hip_buf* w, size_t k, size_t
     const int nb = (int)(k / 32);
     k_block_dots_pieces<PieceQ5_1><<<(nb + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, w->wl.n_blocks, a, row * nb, nb, out);
   } else if (w->dtype == CRABML_HIP_Q2_K || w->dtype == CRABML_HIP_Q3_K) {
-    ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+    const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
     const int nsb = (int)(k / 256);
     if (w->dtype == CRABML_HIP_Q2_K)
       k_block_dots_pieces<PieceQ2_K><<<(nsb * 4 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, w->wl.n_blocks, a, row * nsb, nsb * 4, out);
     else
       k_block_dots_pieces<PieceQ3_K><<<(nsb * 4 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, w->wl.n_blocks, a, row * nsb, nsb * 4, out);
   } else if (w->dtype == CRABML_HIP_Q6_K) {
-    ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+    const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
     int nsb = (int)(k / 256);
     k_block_dots_q6k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>(wp, w->wl.off_scale, a, row * nsb, nsb, out);
   } else if (w->dtype == CRABML_HIP_Q4_K || w->dtype == CRABML_HIP_Q5_K || w->dtype == CRABML_HIP_Q8_K) {
-    ActQ8_K a{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+    const ActQ8_K a = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
     int nsb = (int)(k / 256);
     k_block_dots_k<<<(nsb * 8 + 63) / 64, 64, 0, st>>>((const unsigned char*)wp, (int)w->dtype, a, row * nsb, nsb, out, w->wl.off_scale);
   } else {

@@ -50,10 +50,15 @@ struct ActQ8_1 {
   const unsigned short* s;
 };
 struct ActQ8_K {
-  const i32x4* q;
+  const i32x4* q;   // quants in element order (Q5_K, Q6_K, Q2_K, Q3_K, Q8_K weights)
   const float* d;
   const short* bsums;
+  const i32x4* qp;  // the same quants class-major inside every 32-element group (common.hpp): what the Q4_K kernels read
 };
+// the planes of one Q8_K vector (act_layout(Q8_K, n): q | d | bsums | qp)
+__host__ __device__ inline ActQ8_K act_q8k_at(const char* planes, size_t off_d, size_t off_aux, size_t off_p) {
+  return ActQ8_K{(const i32x4*)planes, (const float*)(planes + off_d), (const short*)(planes + off_aux), (const i32x4*)(planes + off_p)};
+}
 
 // ---- the fast step's hop-free norm: 1 / rms applied by the CONSUMER of the quantized row ------------------------------------
 // RMSNorm divides the whole row by one number, and the truncating rhs quantizer's levels q = trunc(v / (max|v| / 127))
@@ -283,8 +288,9 @@ __device__ __forceinline__ float ordered_sum(const float* __restrict__ t, int nt
 
 // Q4_K rows (planes qs[n][128] | hdr[n][16]) against a Q8_K activation vector: lane = one 16-byte qs piece j of a
 // super-block (8 lanes per super-block: a wave's load is one aligned 1 KiB request); piece j belongs to the
-// 64-element pair p = j / 2 and carries, for positions 16 (j & 1) .. +16, the low nibbles of sub-block 2p and the
-// high nibbles of sub-block 2p + 1 (buf_q4_k.rs:212-217).  The 16-byte header is shared by the 8 lanes; its
+// 64-element pair p = j / 2 and carries the low nibbles of sub-block 2p and the high nibbles of sub-block 2p + 1
+// (buf_q4_k.rs:212-217) for the element classes 4 (j & 1) .. +4 -- dword i of the piece = the four elements e of the
+// 32-group with e % 8 == 4 (j & 1) + i (class-major planes, common.hpp; the activation plane `qp` is laid out the same way).  The 16-byte header is shared by the 8 lanes; its
 // (scale, min) fields were re-packed pair-major at upload (common.hpp), so the lane's four 6-bit values are one
 // funnel shift and four bit-field extracts.
 // HDR_DPP: each lane loads ONE dword of the 16-byte header (lane & 3 selects it) and the quad exchanges the four
@@ -313,13 +319,15 @@ struct Q4KX {  // the activation side of piece c
   float d8;
   int bs_lo, bs_hi;
 };
+template <bool CM = true>  // CM: the class-major plane (Q4_K weights); else element order (Q5_K, whose planes keep the file's order)
 __device__ __forceinline__ Q4KX q4k_loadx(const ActQ8_K& act, int c) {
   const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
   Q4KX x;
-  const i32x4* xq = act.q + (size_t)sb * 16 + p * 4 + h;
+  const i32x4* xq = (CM ? act.qp : act.q) + (size_t)sb * 16 + p * 4 + h;  // class-major: dwords 4 h .. 4 h + 3 of each 32-group = classes 4 h ..
   x.xl = xq[0];
   x.xh = xq[2];
   x.d8 = act.d[sb];
+  // (the minimum term only needs every bsums entry taken once per super-block: the piece keeps the two it always took)
   const short* bs = act.bsums + sb * 16 + p * 4 + h;
   x.bs_lo = (int)bs[0];
   x.bs_hi = (int)bs[2];
@@ -368,6 +376,92 @@ __device__ __forceinline__ float q4k_term(const Q4KPiece<HDR_DPP>& w, const Q4KX
   const float dmin = h2f((unsigned short)(h0 >> 16)) * x.d8;
   return dd * (float)isum - dmin * (float)msum;
 }
+// ---- Q4_K in the reference's order (strict-order device) ---------------------------------------------------------------------
+// buf_q4_k.rs:192-277 keeps EIGHT f32 lanes per row: inside a super-block `aux32[l] += scale * (q8 * q4)` for the elements e of every
+// 32-group with e % 8 == l -- sums of integers below 2^24, exact in f32 in any order --, then per super-block `sums[l] += d * aux32[l]`
+// and `sumf -= dmin * sumi`, and at the end `sumf += sums[0..8)` in order.  A super-block therefore contributes nine f32 terms per row:
+// d * A[l] with A[l] the exact integer lane sum, and dmin * sumi.  With the planes class-major (common.hpp) dword i of piece (p, h) IS
+// class 4 h + i of pair p: one v_dot4 per nibble half and class, A[4 h + i] = sum over the four pairs (the four lanes of the
+// super-block with the same h: lane ^ 2 and lane ^ 4 over DPP).  The lane with p = 0 parks its four terms in the super-block's
+// 12-float record t (floats 0..7 = d * A[l], 8 = dmin * sumi); q4k_ordered_sum then runs the nine chains over the records in order.
+// All 64 lanes converged; `live` = the lane's piece exists (dead lanes contribute zeros and store nothing).
+template <bool HDR_DPP>
+__device__ __forceinline__ void q4k_class_terms(const Q4KPiece<HDR_DPP>& w, const Q4KX& x, int c, bool live, float* __restrict__ t) {
+  const int j = c & 7, p = j >> 1, h = j & 1;
+  unsigned h0, h1, h2, h3;
+  if constexpr (HDR_DPP) {
+    h0 = (unsigned)dpp_i<0x00>((int)w.hw);
+    h1 = (unsigned)dpp_i<0x55>((int)w.hw);
+    h2 = (unsigned)dpp_i<0xAA>((int)w.hw);
+    h3 = (unsigned)dpp_i<0xFF>((int)w.hw);
+  } else {
+    h0 = (unsigned)w.hdr[0];
+    h1 = (unsigned)w.hdr[1];
+    h2 = (unsigned)w.hdr[2];
+    h3 = (unsigned)w.hdr[3];
+  }
+  const unsigned f = q4k_pair_field(h1, h2, h3, p);
+  const int sc_lo = (int)(f & 63u), sc_hi = (int)((f >> 6) & 63u);
+  const int m_lo = (int)((f >> 12) & 63u), m_hi = (int)(f >> 18);
+  int A[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int lo = __builtin_amdgcn_sdot4(w.qv[i] & 0x0F0F0F0F, x.xl[i], 0, false);
+    const int hi = __builtin_amdgcn_sdot4((w.qv[i] >> 4) & 0x0F0F0F0F, x.xh[i], 0, false);
+    int a = live ? sc_lo * lo + sc_hi * hi : 0;
+    a += dpp_i<0x4E>(a);                // lane ^ 2 (quad_perm [2,3,0,1])
+    a += dpp_i<0x1B>(dpp_i<0x141>(a));  // lane ^ 4 (row_half_mirror: j -> 7 - j, then quad_perm [3,2,1,0]: j -> j ^ 3)
+    A[i] = a;
+  }
+  int ms = live ? m_lo * x.bs_lo + m_hi * x.bs_hi : 0;  // i32: the intended math of buf_q4_k.rs:238-241
+  ms += dpp_i<0xB1>(ms);
+  ms += dpp_i<0x4E>(ms);
+  ms += dpp_i<0x141>(ms);
+  if (live && p == 0) {
+    const float d = h2f((unsigned short)(h0 & 0xffff)) * x.d8;
+    *(f32x4*)(t + 4 * h) = f32x4{d * (float)A[0], d * (float)A[1], d * (float)A[2], d * (float)A[3]};
+    if (h == 0) t[8] = (h2f((unsigned short)(h0 >> 16)) * x.d8) * (float)ms;
+  }
+}
+// the nine chains of one row over its nsb records (12 floats each, 16-byte aligned), in super-block order: buf_q4_k.rs:263-276
+__device__ __forceinline__ float q4k_ordered_sum(const float* __restrict__ t, int nsb) {
+  float sums[8], sumf = 0.0f;
+#pragma unroll
+  for (int l = 0; l < 8; l++) sums[l] = 0.0f;
+  for (int sb = 0; sb < nsb; sb++) {
+    const f32x4 a = *(const f32x4*)(t + sb * 12), b = *(const f32x4*)(t + sb * 12 + 4);
+    sums[0] += a[0];
+    sums[1] += a[1];
+    sums[2] += a[2];
+    sums[3] += a[3];
+    sums[4] += b[0];
+    sums[5] += b[1];
+    sums[6] += b[2];
+    sums[7] += b[3];
+    sumf -= t[sb * 12 + 8];
+  }
+#pragma unroll
+  for (int l = 0; l < 8; l++) sumf += sums[l];
+  return sumf;
+}
+// the records of R rows of a Q4_K matrix: T[r * stride + sb * 12 ..]; lane = one 16-byte piece, as rows_partial_q4k
+template <int R, bool HDR_DPP>
+__device__ __forceinline__ void rows_terms_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act, int row0, int m,
+                                               int nsb, int lane, float* __restrict__ T, int stride) {
+  const int np = nsb * 8;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < np;  // (a super-block's eight lanes are live or dead together)
+    const int cc = live ? c : np - 1;
+    Q4KPiece<HDR_DPP> w[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) w[r] = q4k_load<HDR_DPP>(wq, wh, (size_t)(row0 + r < m ? row0 + r : m - 1), nsb, cc, lane);
+    const Q4KX x = q4k_loadx(act, cc);
+#pragma unroll
+    for (int r = 0; r < R; r++) q4k_class_terms<HDR_DPP>(w[r], x, cc, live, T + (size_t)r * stride + (cc >> 3) * 12);
+  }
+}
+
 template <int R, bool HDR_DPP = true, bool DBG = false>
 __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act,
                                                  int row0, int m, int nsb, int lane, float acc[R], int c0 = 0, int* dbg = nullptr) {
@@ -411,7 +505,7 @@ __device__ __forceinline__ void rows_partial_q5k(const char* __restrict__ w, siz
   const int nchunks = nsb * 8;
   for (int c = lane; c < nchunks; c += 64) {
     const int sb = c >> 3, j = c & 7, p = j >> 1, h = j & 1;
-    const Q4KX x = q4k_loadx(act, c);
+    const Q4KX x = q4k_loadx<false>(act, c);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const size_t blk = (size_t)(row0 + r < m ? row0 + r : m - 1) * nsb + sb;

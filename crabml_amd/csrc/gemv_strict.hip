@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void k_gemv_strict(const char* __restrict__ w, 
           for (int g = 0; g < 4; g++)
             for (int l = 0; l < 8; l++) {
               int e = 8 * g + l;  // element within the 32-wide sub-block
-              unsigned char qb = q4[32 * c + e];
+              unsigned char qb = q4[32 * c + (q5 ? e : q4k_perm_index(e))];  // (Q4_K: class-major qs plane, common.hpp)
               int a = hi ? (qb >> 4) : (qb & 0xF);
               if (q5 && ((qh[e] >> (2 * c + hi)) & 1)) a += 16;
               int prod = (int)q8[32 * is + e] * a;  // aux16
@@ -413,12 +413,24 @@ __global__ __launch_bounds__(256) void k_gemv_exact_q4k(const char* __restrict__
   const int stride = nsb * 12;  // nine terms per super-block, padded to 12 floats (16-byte aligned records)
   float* T = exact_terms + (size_t)wv * R * stride;
   const int np = nsb * 8;
+  if constexpr (!Q5) {
+    // Q4_K: class-major planes -- one v_dot4 per class and nibble half (q4k_class_terms, gemv_core.hpp)
+    rows_terms_q4k<R, true>(wq, wh, act, row0, m, nsb, lane, T, stride);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < R && row0 + lane < m) {
+      const float sumf = q4k_ordered_sum(T + (size_t)lane * stride, nsb);
+      out[row0 + lane] = add ? sumf + add[row0 + lane] : sumf;
+    }
+    return;
+  }
+  // Q5_K (planes in the file's element order): the activation dwords masked to one byte per v_dot4
   for (int c0 = 0; c0 < np; c0 += 64) {
     const int c = c0 + lane;
     const bool live = c < np;
     const int cc = live ? c : np - 1;
     const int sb = cc >> 3, j = cc & 7, p = j >> 1, h = j & 1;
-    const Q4KX x = q4k_loadx(act, cc);
+    const Q4KX x = q4k_loadx<false>(act, cc);
     // the activation dwords masked to one byte each: xm[i][k] keeps byte k of dword i (class 4 (i & 1) + k)
     int xlm[4][4], xhm[4][4];
 #pragma unroll
@@ -704,7 +716,7 @@ int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m
       done = true;
       const ActQ8_0 a0{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const int*)(ap + al.off_aux)};
       const ActQ8_1 a1{(const i32x4*)ap, (const unsigned short*)(ap + al.off_d), (const unsigned short*)(ap + al.off_aux)};
-      const ActQ8_K ak{(const i32x4*)ap, (const float*)(ap + al.off_d), (const short*)(ap + al.off_aux)};
+      const ActQ8_K ak = act_q8k_at(ap, al.off_d, al.off_aux, al.off_p);
       switch (w->dtype) {
         case CRABML_HIP_Q4_0:
           k_gemv_exact_blk<CRABML_HIP_Q4_0, R><<<grid, 64 * WAVES, lds, dev->stream>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale), a0, o, add, (int)m, (int)(k / 32));

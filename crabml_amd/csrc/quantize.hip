@@ -75,10 +75,11 @@ __global__ __launch_bounds__(256) void k_quantize_q8_1(const float* __restrict__
 
 // one wave per 256-element super-block, 4 consecutive elements per lane
 __global__ __launch_bounds__(256) void k_quantize_q8_k(const float* __restrict__ x, signed char* __restrict__ q,
-                                                       float* __restrict__ d, short* __restrict__ bsums,
+                                                       float* __restrict__ d, short* __restrict__ bsums, signed char* __restrict__ qp,
                                                        size_t nblocks, size_t row_elems, size_t row_bytes) {
   x += blockIdx.y * row_elems;
   q += blockIdx.y * row_bytes;
+  qp += blockIdx.y * row_bytes;
   d = (float*)((char*)d + blockIdx.y * row_bytes);
   bsums = (short*)((char*)bsums + blockIdx.y * row_bytes);
   const int lane = threadIdx.x & 63;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void k_quantize_q8_k(const float* __restrict__
   const f32x4 v = *(const f32x4*)(x + blk * 256 + lane * 4);
   const Q8KLane o = q8k_wave_quant(v, lane);  // devutil.hpp
   *(unsigned*)(q + blk * 256 + lane * 4) = o.packed;
+  q8k_store_class_major(qp + blk * 256, lane, o.packed);  // the plane the Q4_K kernels read
   if ((lane & 3) == 0) bsums[blk * 16 + (lane >> 2)] = (short)o.quad_sum;
   if (lane == 0) d[blk] = o.d;
 }
@@ -127,7 +129,8 @@ void launch_quantize_act_rows(hipStream_t st, uint32_t qtype, const float* x, si
     case CRABML_HIP_Q8_K: {
       size_t nb = n / 256;
       unsigned grid = (unsigned)((nb + 3) / 4);
-      k_quantize_q8_k<<<dim3(grid, ry), 256, 0, st>>>(x, (signed char*)p, (float*)(p + al.off_d), (short*)(p + al.off_aux), nb, n, al.total);
+      k_quantize_q8_k<<<dim3(grid, ry), 256, 0, st>>>(x, (signed char*)p, (float*)(p + al.off_d), (short*)(p + al.off_aux),
+                                                      (signed char*)(p + al.off_p), nb, n, al.total);
       break;
     }
     case CRABML_HIP_F16: {

@@ -76,7 +76,8 @@ ActLayout act_layout(uint32_t qtype, size_t n) {
     case CRABML_HIP_Q8_K:
       al.off_d = align_up(n, 256);
       al.off_aux = al.off_d + align_up(n / 256 * 4, 256);
-      al.total = al.off_aux + align_up(n / 16 * 2, 256);
+      al.off_p = al.off_aux + align_up(n / 16 * 2, 256);
+      al.total = al.off_p + align_up(n, 256);
       break;
     default: break;
   }
@@ -422,6 +423,7 @@ int crabml_hip_buf_from_cpu(crabml_hip_device_t* dev, const void* bytes, size_t 
         if (e != hipSuccess) break;
         launch_repack(dev->stream, stage[slot], b->ptr, b0, nb, (int)bb, plan);
         if (t == CRABML_HIP_Q4_K) launch_q4k_pack_scales(dev->stream, (char*)b->ptr + wl.off_scale, b0, nb);
+        if (t == CRABML_HIP_Q4_K) launch_q4k_class_major(dev->stream, b->ptr, b0, nb);
         if (t == CRABML_HIP_Q5_K) launch_q4k_pack_scales(dev->stream, (char*)b->ptr + wl.off_scale + nblk * 32, b0, nb);
         e = hipEventRecord(done[slot], dev->stream);
       }
