@@ -809,15 +809,18 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   auto norm_quant = [&](const float* wn, float eps, bool add_pending, uint32_t qt) -> const void* {
     const float* addv = add_pending ? c->partial : nullptr;
     if (dim <= 4096)
-      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, 1);
+      k_norm_f32<4><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, c->ord ? 0 : 1);
     else
-      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, 1);
+      k_norm_f32<12><<<1, 1024, norm_lds, st>>>(c->x, addv, wn, dim, eps, c->xn, c->ord ? 0 : 1);
     if (qt == CRABML_HIP_F32) return c->xn;
     launch_quantize_act(st, qt, c->xn, (size_t)dim, c->act_dim);
     return c->act_dim;
   };
   float* dst = tp ? c->partial : c->x;
   const bool nepi = FMT == CRABML_HIP_Q4_K && c->norm_epi_k;
+  // strict-order device, Q4_K layers (c->ord): the same five launches with every sum in the reference's order -- nine-term records per
+  // super-block added in order (q4k_class_terms / q4k_ordered_sum, gemv_core.hpp), the reference's norm order in the epilogue
+  const bool ordk = FMT == CRABML_HIP_Q4_K && c->ord;
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only)
   // the rhs of wo / ffn_down quantized by the consuming kernel itself (no quantizer launch)
   const bool qin = nepi && !(g.flags & CRABML_HIP_LLAMA_NO_RHS_PROLOGUE) && dim_l % 256 == 0 && hidden_l % 256 == 0;
@@ -840,6 +843,22 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
                           : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
                                                                             : 1;
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
+        if (ordk) {  // (qmode is 1 or 2 here: `qin` holds on every ordered context)
+          const size_t ldso = ((lds + 15) & ~(size_t)15) + (size_t)(32 / split) * 12 * (size_t)(k / 256) * sizeof(float);
+#define CRABML_NQ_KO(SPLIT_, QIN_, GRID_)                                                                                                \
+  launch_k(st, R, k_gemv_res_nq<FMT, SPLIT_, QIN_, false, false, true>, dim3(GRID_), dim3(1024), ldso, planes_k(w), a, xin, c->x, wnext, \
+           eps_next, oq, od, ob, ng, k / BE, six(w), NoTp{})
+          if (split == 2 && qmode == 2)
+            CRABML_NQ_KO(2, 2, dim / 16);
+          else if (split == 2)
+            CRABML_NQ_KO(2, 1, dim / 16);
+          else if (qmode == 2)
+            CRABML_NQ_KO(1, 2, dim / 32);
+          else
+            CRABML_NQ_KO(1, 1, dim / 32);
+#undef CRABML_NQ_KO
+          return P1();
+        }
 #define CRABML_NQ_K(SPLIT_, QIN_, GRID_, LDS_)                                                                                          \
   launch_k(st, R, k_gemv_res_nq<FMT, SPLIT_, QIN_>, dim3(GRID_), dim3(1024), LDS_, planes_k(w), a, xin, c->x, wnext, eps_next, oq, od, ob, \
            ng, k / BE, six(w), NoTp{})
@@ -886,8 +905,12 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(1, total_rows, dim));
-    launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
-             planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]), RmsTail{nullptr, 0, 0.f, 0.f});
+    if (ordk)
+      launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * 12 * (size_t)(dim / BE) * sizeof(float),
+               planes_k(c->wq[l]), planes_k(c->wk[l]), planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e);
+    else
+      launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
+               planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]), RmsTail{nullptr, 0, 0.f, 0.f});
     CH_TRY(P1());
     // Q8_K producers: the (short-context) attention kernel assembles the planes of wo's rhs itself; wo copies them
     const bool aq8 = qout && (g.flags & CRABML_HIP_LLAMA_Q8K_ATTN_PRODUCER) && c->attn_variant == 0 && c->attn_s_rows > 0;
@@ -912,7 +935,16 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       const size_t lds = (size_t)dim + (size_t)(dim / 256) * 4 + (size_t)(dim / 16) * 2;
       const ActLayout alh = act_layout(QT, (size_t)hidden_l);
       const Q8KExchange hx{c->h8gran, c->state + 4, c->state + 5, n_segments(c), seg};
-      if (qout)
+      const size_t ldso = ((lds + 15) & ~(size_t)15) + (size_t)64 * 12 * (size_t)(dim / 256) * sizeof(float);
+      if (ordk && qout)
+        launch_k(st, R, k_gateup_k_lds<true, true>, dim3(hidden_l / 32), dim3(1024), ldso, planes_k(c->gate[l]), planes_k(c->up[l]),
+                 act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
+                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p));
+      else if (ordk)
+        launch_k(st, R, k_gateup_k_lds<false, true>, dim3(hidden_l / 32), dim3(1024), ldso, planes_k(c->gate[l]), planes_k(c->up[l]),
+                 act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)nullptr,
+                 (float*)nullptr, (short*)nullptr, (signed char*)nullptr);
+      else if (qout)
         launch_k(st, R, k_gateup_k_lds<true>, dim3(hidden_l / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
                  (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p));
@@ -1623,11 +1655,40 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
     generic = true;
   }
   generic = generic || (mixed && !mix_fused);
+  // strict order, pure Q4_K layers on one device (round 6): the five fused launches of the fast Q4_K step in their ORDERED form -- nine
+  // f32 terms per super-block (eight exact class sums x d, and dmin x sumi) parked in LDS and added in super-block order, the
+  // reference's norm order in the wo / ffn_down epilogue (k_qkv_ord, k_gemv_res_nq<.., ORD>, k_gateup_k_lds<.., ORD>); bit-identical
+  // to the per-op segments they replace (16 launches per layer).  The term tables must fit LDS.
+  bool ordk = dev->strict_order && wt == CRABML_HIP_Q4_K && !mixed && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
+              !(g.flags & (CRABML_HIP_LLAMA_NO_NORM_EPILOGUE | CRABML_HIP_LLAMA_NO_KQUANT_FUSION | CRABML_HIP_LLAMA_NO_RHS_PROLOGUE)) &&
+              g.embedding_dim % 256 == 0 && dim_l % 256 == 0 && hidden_l % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
+  if (ordk && !dry) {
+    auto planes_b = [](size_t k) { return ((k + k / 256 * 4 + k / 16 * 2) + 15) & ~(size_t)15; };
+    const int split_dn = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS) ? 2 : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1 : hidden_l / 32 >= 256 ? 2 : 1;
+    const int split_wo = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS) ? 2 : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1 : dim_l / 32 >= 256 ? 2 : 1;
+    const size_t gu = planes_b(g.embedding_dim) + (size_t)64 * 12 * (g.embedding_dim / 256) * 4;
+    const size_t dn = planes_b(hidden_l) + (size_t)(32 / split_dn) * 12 * (hidden_l / 256) * 4;
+    const size_t wo = planes_b(dim_l) + (size_t)(32 / split_wo) * 12 * (dim_l / 256) * 4;
+    const size_t nq = dn > wo ? dn : wo;
+    bool fits = gu <= 150 * 1024 && nq <= 150 * 1024;
+    if (fits && gu > 48 * 1024)
+      fits = raise_dyn_lds(dev, (const void*)k_gateup_k_lds<true, true>, (int)gu) == hipSuccess &&
+             raise_dyn_lds(dev, (const void*)k_gateup_k_lds<false, true>, (int)gu) == hipSuccess;
+    if (fits && nq > 48 * 1024)
+      fits = raise_dyn_lds(dev, (const void*)k_gemv_res_nq<CRABML_HIP_Q4_K, 1, 1, false, false, true>, (int)nq) == hipSuccess &&
+             raise_dyn_lds(dev, (const void*)k_gemv_res_nq<CRABML_HIP_Q4_K, 1, 2, false, false, true>, (int)nq) == hipSuccess &&
+             raise_dyn_lds(dev, (const void*)k_gemv_res_nq<CRABML_HIP_Q4_K, 2, 1, false, false, true>, (int)nq) == hipSuccess &&
+             raise_dyn_lds(dev, (const void*)k_gemv_res_nq<CRABML_HIP_Q4_K, 2, 2, false, false, true>, (int)nq) == hipSuccess;
+    (void)hipGetLastError();
+    if (!fits) ordk = false;
+  }
+  if (ordk) ord = true;
   c->generic = generic;
   c->ord = ord;
   // Q4_K always; Q4_1 when it cannot take the 5-kernel path (mixed classifier format) or for the A/B flag
-  c->kfused = !dev->strict_order && (!mixed || mix_fused) && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
-              (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || out_differs || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS))));
+  c->kfused = ordk ||
+              (!dev->strict_order && (!mixed || mix_fused) && !(g.flags & CRABML_HIP_LLAMA_NO_KQUANT_FUSION) &&
+               (wt == CRABML_HIP_Q4_K || (wt == CRABML_HIP_Q4_1 && (generic || out_differs || (g.flags & CRABML_HIP_LLAMA_Q4_1_SEGMENTS)))));
   c->qt = qt;
   c->out_qt = out_qt;
   c->tp = tp;

@@ -460,12 +460,22 @@ __global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv
   }
   QkvPre pre{};
   if (lane == 0) pre = qkv_preload(e, row0);
-  const int nt = (nb + 3) & ~3;
-  float* T = ord_terms + (size_t)wv_i * 2 * nt;
-  rows_terms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, T, nt);
-  __builtin_amdgcn_wave_barrier();
   float s = 0.0f;
-  if (lane < 2) s = ordered_sum(T + lane * nt, nb);
+  if constexpr (FMT == CRABML_HIP_Q4_K) {
+    // nb super-blocks, nine terms each (q4k_class_terms / q4k_ordered_sum, gemv_core.hpp); dynamic LDS = 8 * 12 nb floats
+    const int stride = nb * 12;
+    float* T = ord_terms + (size_t)wv_i * 2 * stride;
+    rows_terms_q4k<2, true>(w.q, (const i32x4*)w.d, act, local, m, nb, lane, T, stride);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS stores have landed
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2) s = q4k_ordered_sum(T + lane * stride, nb);
+  } else {
+    const int nt = (nb + 3) & ~3;
+    float* T = ord_terms + (size_t)wv_i * 2 * nt;
+    rows_terms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, T, nt);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2) s = ordered_sum(T + lane * nt, nb);
+  }
   const float s1 = __shfl(s, 1, 64);
   if (lane == 0) qkv_epilogue(e, pre, row0, s, s1);
 }

@@ -243,7 +243,11 @@ __device__ __forceinline__ unsigned long long ld_granule(const unsigned long lon
 // wg_index / nwg_all: this workgroup's index among the SPLIT * nchunks workgroups of the stage.
 // DEFER (the fast step's hop-free norm, gemv_core.hpp `RmsTail`; Q8_0 rhs, one workgroup per chunk): no gather.  The workgroup
 // quantizes x * w_norm of its own 32 rows and leaves its chunk's sum of squares for the consuming launch.
-template <int FMT, int SPLIT, bool TP = false, bool DEFER = false>
+// ORD (strict-order device, Q4_K): the caller has already put the rows' ORDERED dots into hv[part * ROWS ..] (wave 0, after a barrier);
+// the chunk's sum of squares is one 32-element scan from -0.0 (rms_norm.rs:35-38; with two workgroups per chunk the second continues
+// the first one's scan from its granule) and the chunk sums are added strictly in chunk order (rms_norm.rs:38-40), as
+// k_gemv_res_nq_ord does.
+template <int FMT, int SPLIT, bool TP = false, bool DEFER = false, bool ORD = false>
 __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, float wn, f32x4 wn4, unsigned epoch, float* hv,
                                             float* __restrict__ x, signed char* __restrict__ q, void* __restrict__ d,
                                             void* __restrict__ isum, const NormGather& ng, float eps, int blk, int part, int nchunks,
@@ -257,10 +261,13 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
   // every row goes out as a {value, epoch} granule when another workgroup needs it (the partner of a split chunk;
   // the seven neighbours of a Q8_K super-block), the workgroup's ordered sum of squares as one more
   constexpr bool ROWG = SPLIT > 1 || KQ;
+  static_assert(!ORD || (KQ && !TP && !DEFER), "the ordered epilogue: Q4_K layers on one device");
+  if constexpr (!ORD) {
 #pragma unroll
-  for (int r = 0; r < RW; r++) {
-    const float s = wave_sum_f32(acc[r]);
-    if (lane == 0) hv[part * ROWS + wave * RW + r] = s;
+    for (int r = 0; r < RW; r++) {
+      const float s = wave_sum_f32(acc[r]);
+      if (lane == 0) hv[part * ROWS + wave * RW + r] = s;
+    }
   }
   __syncthreads();
   if (wave != 0) return;
@@ -280,10 +287,32 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
+  auto poll = [&](const unsigned long long* p) -> float {
+    unsigned long long g = ld_granule(p);
+    int tries = 0;
+    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
+      __builtin_amdgcn_s_sleep(2);
+      g = ld_granule(p);
+      tries++;
+    }
+    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
+    return __builtin_bit_cast(float, (unsigned)g);
+  };
   // sum of squares of a chunk = (rows 0..15 in order) + (rows 16..31 in order): a split chunk's two workgroups
   // each own one half (norm_quant_block<HALF> computes the same)
   float cs;
-  {
+  if constexpr (ORD) {
+    cs = -0.0f;
+    if (SPLIT > 1 && part > 0) cs = poll(ng.slots + 2 * blk);  // the first half's scan, continued
+#pragma unroll
+    for (int j = 0; j < ROWS / 4; j++) {
+      const f32x4 t = ((const f32x4*)hv)[part * (ROWS / 4) + j];
+      cs += t[0] * t[0];
+      cs += t[1] * t[1];
+      cs += t[2] * t[2];
+      cs += t[3] * t[3];
+    }
+  } else {
     float h0 = -0.0f, h1 = -0.0f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -370,17 +399,6 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     __hip_atomic_store(ng.slots + wg_index, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, cs),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the granule is on its way before the polls queue up behind it
-  auto poll = [&](const unsigned long long* p) -> float {
-    unsigned long long g = ld_granule(p);
-    int tries = 0;
-    while ((unsigned)(g >> 32) != epoch && tries < (1 << 21)) {
-      __builtin_amdgcn_s_sleep(2);
-      g = ld_granule(p);
-      tries++;
-    }
-    if ((unsigned)(g >> 32) != epoch) *ng.fault = 1;  // a workgroup never arrived: flagged, not hung
-    return __builtin_bit_cast(float, (unsigned)g);
-  };
   // the rows of other workgroups first (published before their sums; the loads fly while the stragglers arrive) ...
   // (Round 3 measured the alternative -- every granule of the hop requested at once, stale ones polled afterwards: ffn_down
   // 9.5 -> 10.3 us, profiles/r03_batched_epilogue_polls_ab.log.  Requested early, most granules come back stale and are
@@ -409,6 +427,12 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
   for (int base = 0; base < nchunks; base += 64) {
     const int c = base + lane;  // this lane's chunk
     float cv;
+    if constexpr (ORD) {  // (SPLIT = 2: the second workgroup's granule holds the whole chunk's scan)
+      cv = c < nchunks ? poll(ng.slots + (SPLIT > 1 ? 2 * c + 1 : c)) : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 64; i++) sum += rl_f(cv, i);
+      continue;
+    }
     if (SPLIT > 1) {
       const float h0 = c < nchunks ? poll(ng.slots + 2 * c) : 0.0f;
       const float h1 = c < nchunks ? poll(ng.slots + 2 * c + 1) : 0.0f;
@@ -450,7 +474,10 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
 
 // QIN (Q4_K): 0 = the rhs planes are read from global memory; 1 = the rhs arrives as f32 (xin) and is quantized into LDS
 // by this workgroup; 2 = the finished planes (act) are copied into LDS
-template <int FMT, int SPLIT, int QIN = 0, bool TP = false, bool DEFER = false>
+// ORD (strict-order device, Q4_K with QIN 1 / 2): the rows' nine-term records go to LDS behind the rhs planes (q4k_class_terms; dynamic
+// LDS = the planes rounded up to 16 bytes + ROWS * 12 nb floats), wave 0 adds them in super-block order, the epilogue keeps the
+// reference's norm order: every bit equals the per-op launches (k_gemv_exact_q4k + k_norm_f32 + k_quantize_q8_k).
+template <int FMT, int SPLIT, int QIN = 0, bool TP = false, bool DEFER = false, bool ORD = false>
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
                                                       float* __restrict__ x,
                                                       const float* __restrict__ wnext, float eps,
@@ -511,6 +538,26 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
     else
       stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs, true);
     const ActQ8_K la{lds_act, sd, sbs, lds_act};
+    if constexpr (ORD) {
+      const int stride = nb * 12;
+      float* T = (float*)((char*)lds_act + (((size_t)nb * 292 + 15) & ~(size_t)15));
+      float* Tw = T + (size_t)(wave * RW) * stride;
+#pragma unroll
+      for (int it = 0; it < PRE; it++) {
+        const int c = it * 64 + lane;
+        const bool live = c < nb * 8;
+        const int cc = live ? c : nb * 8 - 1;
+        const Q4KX xx = q4k_loadx(la, cc);
+#pragma unroll
+        for (int r = 0; r < RW; r++) q4k_class_terms<false>(pw[it][r], xx, cc, live, Tw + (size_t)r * stride + (cc >> 3) * 12);
+      }
+      rows_terms_q4k<RW, false>(w.q, (const i32x4*)w.d, la, row, nchunks * 32, nb, lane, Tw, stride, PRE * 64);
+      __syncthreads();
+      if (wave == 0 && lane < ROWS) hv[part * ROWS + lane] = q4k_ordered_sum(T + (size_t)lane * stride, nb);
+      nq_epilogue<FMT, SPLIT, TP, false, true>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
+                                               (int)blockIdx.x, (int)gridDim.x, tp);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < RW; r++) acc[r] = 0.f;
 #pragma unroll
@@ -806,7 +853,10 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename A
 // path, which the K-quant inner loop otherwise keeps ~57 % busy (rocprofv3 TA_BUSY) while VALU sits at 15 %.
 // QOUT: h leaves the kernel as Q8_K planes (the rhs of ffn_down) as well: the eight workgroups of a 256-row super-block exchange
 // their rows as granules (q8k_exchange_store); hidden % 256 == 0.
-template <bool QOUT>
+// ORD (strict-order device): the nine-term records of the 32 gate and 32 up rows go to LDS behind the planes (dynamic LDS = the planes
+// rounded up to 16 bytes + 64 * 12 nsb floats) and one lane per (matrix, row) adds them in super-block order (q4k_ordered_sum):
+// h bit for bit as k_gemv_exact_q4k x 2 + k_gateup_epi leave it; m % 32 == 0.
+template <bool QOUT, bool ORD = false>
 __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
                                                        float* __restrict__ h, int m, int nsb, Q8KExchange ex, signed char* __restrict__ oq,
                                                        float* __restrict__ od, short* __restrict__ obs, signed char* __restrict__ oqp) {
@@ -832,6 +882,37 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
   for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
   __syncthreads();
   const ActQ8_K la{sq, sd, sbs, sq};
+  __shared__ float hv[32];
+  if constexpr (ORD) {
+    const int stride = nsb * 12;
+    float* T = (float*)((char*)lds_act + (((size_t)nsb * 292 + 15) & ~(size_t)15));  // rows 0..31: gate, 32..63: up
+    float* Tg = T + (size_t)(wave * 2) * stride;
+    {
+      const bool live = lane < nch;
+      const int cc = live ? lane : nch - 1;
+      const Q4KX x = q4k_loadx(la, cc);
+#pragma unroll
+      for (int r = 0; r < 2; r++) q4k_class_terms<false>(pw[r], x, cc, live, Tg + (size_t)r * stride + (cc >> 3) * 12);
+    }
+    rows_terms_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, Tg, stride, 64);
+    rows_terms_q4k<2, false>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, T + (size_t)(32 + wave * 2) * stride, stride);
+    __syncthreads();
+    if (wave == 0) {
+      const float s = q4k_ordered_sum(T + (size_t)lane * stride, nsb);  // lane < 32: gate row `lane`; else up row `lane - 32`
+      const float u = __shfl(s, (lane & 31) + 32, 64);
+      if (lane < 32) {
+        const float hval = silu_mul(s, u, exp_tab);
+        h[(int)blockIdx.x * 32 + lane] = hval;
+        hv[lane] = hval;
+      }
+      if constexpr (QOUT) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        q8k_exchange_store(ex, hv, (int)blockIdx.x * 32, 32, lane, oq, od, obs, oqp);
+      }
+    }
+    return;
+  }
   if (row0 >= m) return;
   float ag[2] = {0.f, 0.f}, au[2];
   if (lane < nch) {
@@ -841,7 +922,6 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
   }
   rows_partial_q4k<2, false>(wg.q, (const i32x4*)wg.d, la, row0, m, nsb, lane, ag, 64);
   rows_partial_q4k<2, false>(wu.q, (const i32x4*)wu.d, la, row0, m, nsb, lane, au);
-  __shared__ float hv[32];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const float g = wave_sum_f32(ag[r]), u = wave_sum_f32(au[r]);

@@ -447,9 +447,9 @@ __device__ __forceinline__ float q4k_ordered_sum(const float* __restrict__ t, in
 // the records of R rows of a Q4_K matrix: T[r * stride + sb * 12 ..]; lane = one 16-byte piece, as rows_partial_q4k
 template <int R, bool HDR_DPP>
 __device__ __forceinline__ void rows_terms_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act, int row0, int m,
-                                               int nsb, int lane, float* __restrict__ T, int stride) {
+                                               int nsb, int lane, float* __restrict__ T, int stride, int cfirst = 0) {
   const int np = nsb * 8;
-  for (int c0 = 0; c0 < np; c0 += 64) {
+  for (int c0 = cfirst; c0 < np; c0 += 64) {  // cfirst: pieces below it were taken by the caller (a multiple of 64)
     const int c = c0 + lane;
     const bool live = c < np;  // (a super-block's eight lanes are live or dead together)
     const int cc = live ? c : np - 1;
