@@ -45,6 +45,11 @@ __device__ __forceinline__ unsigned short hraw(_Float16 x) {
 // dependent chain per reduction); measured on MI355X this made the single-workgroup norm+quantize stage
 // 13.8 us.  DPP row operations are register-to-register: 4 steps reduce each 16-lane row, v_readlane
 // combines the 4 rows.  All lanes must be active (callers keep whole waves converged).
+// the wave's index inside its workgroup as a SCALAR (threadIdx.x >> 6 is uniform per wave, but the compiler cannot know: everything
+// derived from it -- the rows a wave owns, their base addresses -- then lives in VGPRs and every address is 64-bit vector arithmetic;
+// through readfirstlane the row bases become SGPR pairs and the loads take the `saddr + 32-bit lane offset` form)
+__device__ __forceinline__ int wave_in_wg() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);

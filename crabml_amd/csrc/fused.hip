@@ -844,7 +844,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
                                                                             : 1;
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
         if (ordk) {  // (qmode is 1 or 2 here: `qin` holds on every ordered context)
-          const size_t ldso = ((lds + 15) & ~(size_t)15) + (size_t)(32 / split) * 12 * (size_t)(k / 256) * sizeof(float);
+          const size_t ldso = ((lds + 15) & ~(size_t)15) + (size_t)(32 / split) * (size_t)q4k_rec_stride(k / 256) * sizeof(float);
 #define CRABML_NQ_KO(SPLIT_, QIN_, GRID_)                                                                                                \
   launch_k(st, R, k_gemv_res_nq<FMT, SPLIT_, QIN_, false, false, true>, dim3(GRID_), dim3(1024), ldso, planes_k(w), a, xin, c->x, wnext, \
            eps_next, oq, od, ob, ng, k / BE, six(w), NoTp{})
@@ -906,7 +906,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(1, total_rows, dim));
     if (ordk)
-      launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * 12 * (size_t)(dim / BE) * sizeof(float),
+      launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * (size_t)q4k_rec_stride(dim / BE) * sizeof(float),
                planes_k(c->wq[l]), planes_k(c->wk[l]), planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e);
     else
       launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
@@ -935,7 +935,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       const size_t lds = (size_t)dim + (size_t)(dim / 256) * 4 + (size_t)(dim / 16) * 2;
       const ActLayout alh = act_layout(QT, (size_t)hidden_l);
       const Q8KExchange hx{c->h8gran, c->state + 4, c->state + 5, n_segments(c), seg};
-      const size_t ldso = ((lds + 15) & ~(size_t)15) + (size_t)64 * 12 * (size_t)(dim / 256) * sizeof(float);
+      const size_t ldso = ((lds + 15) & ~(size_t)15) + (size_t)64 * (size_t)q4k_rec_stride(dim / 256) * sizeof(float);
       if (ordk && qout)
         launch_k(st, R, k_gateup_k_lds<true, true>, dim3(hidden_l / 32), dim3(1024), ldso, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
@@ -1666,9 +1666,9 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
     auto planes_b = [](size_t k) { return ((k + k / 256 * 4 + k / 16 * 2) + 15) & ~(size_t)15; };
     const int split_dn = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS) ? 2 : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1 : hidden_l / 32 >= 256 ? 2 : 1;
     const int split_wo = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS) ? 2 : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1 : dim_l / 32 >= 256 ? 2 : 1;
-    const size_t gu = planes_b(g.embedding_dim) + (size_t)64 * 12 * (g.embedding_dim / 256) * 4;
-    const size_t dn = planes_b(hidden_l) + (size_t)(32 / split_dn) * 12 * (hidden_l / 256) * 4;
-    const size_t wo = planes_b(dim_l) + (size_t)(32 / split_wo) * 12 * (dim_l / 256) * 4;
+    const size_t gu = planes_b(g.embedding_dim) + (size_t)64 * (size_t)q4k_rec_stride((int)(g.embedding_dim / 256)) * 4;
+    const size_t dn = planes_b(hidden_l) + (size_t)(32 / split_dn) * (size_t)q4k_rec_stride((int)(hidden_l / 256)) * 4;
+    const size_t wo = planes_b(dim_l) + (size_t)(32 / split_wo) * (size_t)q4k_rec_stride((int)(dim_l / 256)) * 4;
     const size_t nq = dn > wo ? dn : wo;
     bool fits = gu <= 150 * 1024 && nq <= 150 * 1024;
     if (fits && gu > 48 * 1024)

@@ -394,7 +394,7 @@ template <int FMT, bool DEFER = false>
 __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e,
                                              Planes6 wv6, RmsTail rt) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * 2;
   const int total = e.dim + 2 * e.kv_dim;
   if (row0 >= total) return;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
 template <int FMT>
 __global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e) {
   extern __shared__ __attribute__((aligned(16))) float ord_terms[];
-  const int lane = threadIdx.x & 63, wv_i = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv_i = wave_in_wg();
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv_i;
   const int row0 = wave * 2;
   const int total = e.dim + 2 * e.kv_dim;
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv
   if (lane == 0) pre = qkv_preload(e, row0);
   float s = 0.0f;
   if constexpr (FMT == CRABML_HIP_Q4_K) {
-    // nb super-blocks, nine terms each (q4k_class_terms / q4k_ordered_sum, gemv_core.hpp); dynamic LDS = 8 * 12 nb floats
-    const int stride = nb * 12;
+    // nb super-blocks, nine terms each (q4k_class_terms / q4k_ordered_sum, gemv_core.hpp); dynamic LDS = 8 * q4k_rec_stride(nb) floats
+    const int stride = q4k_rec_stride(nb);
     float* T = ord_terms + (size_t)wv_i * 2 * stride;
     rows_terms_q4k<2, true>(w.q, (const i32x4*)w.d, act, local, m, nb, lane, T, stride);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS stores have landed

@@ -9,7 +9,7 @@ namespace crabml_hip {
 template <int FMT, int R, bool ADD>  // ADD: x[row] += W.xq (residual); else out[row] = W.xq (tensor-parallel partial sum)
 __global__ __launch_bounds__(128) void k_gemv_res(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x, int m, int nb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   // the residual is loaded up front (its latency overlaps the weight stream instead of trailing the reduction)
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(128) void k_gemv_res(Planes w, typename ActOf<FMT>:
 template <int FMT>
 __global__ __launch_bounds__(256) void k_gemv_res_ord(Planes w, typename ActOf<FMT>::type act, float* __restrict__ x, int m, int nb) {
   extern __shared__ __attribute__((aligned(16))) float ord_terms[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = wave_in_wg();
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
   const int row0 = wave * 2;
   if (row0 >= m) return;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_tp_allreduce(float* __restrict__ buf, i
 // each workgroup for itself (16 KB / 56 KB of L2 reads), instead of a quantizer launch in front of them.
 // cm: the quants go to LDS class-major (the rhs of Q4_K rows; common.hpp) instead of in element order (a Q6_K matrix of a *_K_M mix)
 __device__ __forceinline__ void stage_quant_q8k(const float* __restrict__ x, int nsb, unsigned* sq, float* sd, short* sbs, bool cm) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_in_wg(), nw = blockDim.x >> 6;
   // four super-blocks of loads in flight per wave (ffn_down: 56 super-blocks over 16 waves; a round is one L2 latency)
   for (int sb0 = wave; sb0 < nsb; sb0 += 4 * nw) {
     f32x4 v[4];
@@ -475,7 +475,7 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
 // QIN (Q4_K): 0 = the rhs planes are read from global memory; 1 = the rhs arrives as f32 (xin) and is quantized into LDS
 // by this workgroup; 2 = the finished planes (act) are copied into LDS
 // ORD (strict-order device, Q4_K with QIN 1 / 2): the rows' nine-term records go to LDS behind the rhs planes (q4k_class_terms; dynamic
-// LDS = the planes rounded up to 16 bytes + ROWS * 12 nb floats), wave 0 adds them in super-block order, the epilogue keeps the
+// LDS = the planes rounded up to 16 bytes + ROWS * q4k_rec_stride(nb) floats), wave 0 adds them in super-block order, the epilogue keeps the
 // reference's norm order: every bit equals the per-op launches (k_gemv_exact_q4k + k_norm_f32 + k_quantize_q8_k).
 template <int FMT, int SPLIT, int QIN = 0, bool TP = false, bool DEFER = false, bool ORD = false>
 __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<FMT>::type act, const float* __restrict__ xin,
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
   constexpr int RW = 2 / SPLIT;         // rows per wave
   constexpr int ROWS = 32 / SPLIT;      // rows per workgroup
   __shared__ __attribute__((aligned(16))) float hv[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_in_wg();
   const int blk = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
   const int nchunks = gridDim.x / SPLIT;
   const int row = blk * 32 + part * ROWS + wave * RW;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs, true);
     const ActQ8_K la{lds_act, sd, sbs, lds_act};
     if constexpr (ORD) {
-      const int stride = nb * 12;
+      const int stride = q4k_rec_stride(nb);
       float* T = (float*)((char*)lds_act + (((size_t)nb * 292 + 15) & ~(size_t)15));
       float* Tw = T + (size_t)(wave * RW) * stride;
 #pragma unroll
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq_ord(Planes w, typename Act
   constexpr int RW = 2 / SPLIT, ROWS = 32 / SPLIT;
   extern __shared__ __attribute__((aligned(16))) float ord_terms[];
   __shared__ __attribute__((aligned(16))) float hv[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_in_wg();
   const int blk = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
   const int nchunks = gridDim.x / SPLIT;
   const int row_wg = blk * 32 + part * ROWS;
@@ -840,7 +840,7 @@ template <int FMT>
 __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename ActOf<FMT>::type act,
                                                 const unsigned short* __restrict__ exp_tab, float* __restrict__ h, int m, int nb) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   if (row >= m) return;
   float ag[1], au[1];
   rows_dot<FMT, 1>(wg.q, wg.d, act, row, m, nb, lane, ag);
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename A
 // QOUT: h leaves the kernel as Q8_K planes (the rhs of ffn_down) as well: the eight workgroups of a 256-row super-block exchange
 // their rows as granules (q8k_exchange_store); hidden % 256 == 0.
 // ORD (strict-order device): the nine-term records of the 32 gate and 32 up rows go to LDS behind the planes (dynamic LDS = the planes
-// rounded up to 16 bytes + 64 * 12 nsb floats) and one lane per (matrix, row) adds them in super-block order (q4k_ordered_sum):
+// rounded up to 16 bytes + 64 * q4k_rec_stride(nsb) floats) and one lane per (matrix, row) adds them in super-block order (q4k_ordered_sum):
 // h bit for bit as k_gemv_exact_q4k x 2 + k_gateup_epi leave it; m % 32 == 0.
 template <bool QOUT, bool ORD = false>
 __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
   i32x4* sq = lds_act;
   float* sd = (float*)(sq + k / 16);
   short* sbs = (short*)(sd + nsb);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_in_wg();
   const int row0 = blockIdx.x * 32 + wave * 2;
   // Round 4: the first round of gate pieces is requested BEFORE the activation planes are staged (the weights depend on nothing:
   // their HBM round trip runs under the staging and its barrier); the rest is two rows_partial_q4k passes as before, so every
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
   const ActQ8_K la{sq, sd, sbs, sq};
   __shared__ float hv[32];
   if constexpr (ORD) {
-    const int stride = nsb * 12;
+    const int stride = q4k_rec_stride(nsb);
     float* T = (float*)((char*)lds_act + (((size_t)nsb * 292 + 15) & ~(size_t)15));  // rows 0..31: gate, 32..63: up
     float* Tg = T + (size_t)(wave * 2) * stride;
     {
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(1024) void k_gateup_q(Planes wg, Planes wu, typenam
   using F = BlockFmt<FMT>;
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   __shared__ float hv[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_in_wg();
   const int blk = blockIdx.x;
   const int row = blk * 32 + wave * 2;  // rows row, row+1
   RmsReq rq{0.f, 0.f};
@@ -1030,7 +1030,7 @@ template <int FMT>
 __global__ __launch_bounds__(1024) void k_gateup_h(Planes wg, Planes wu, typename ActOf<FMT>::type act, const unsigned short* __restrict__ exp_tab,
                                                    float* __restrict__ h, int m, int nb) {
   using F = BlockFmt<FMT>;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_in_wg();
   const int row = ((int)blockIdx.x * (int)(blockDim.x >> 6) + wave) * 2;
   if (row >= m) return;
   float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(1024) void k_gateup_q_ord(Planes wg, Planes wu, typ
                                                        unsigned short* __restrict__ d, void* __restrict__ isum, int nb) {
   constexpr bool Q81 = FMT == CRABML_HIP_Q4_1;
   extern __shared__ __attribute__((aligned(16))) float ord_terms[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_in_wg();
   const int blk = blockIdx.x;
   const int row = blk * 32 + wave * 2;
   const int nt = ((nb + 3) & ~3) + 4;

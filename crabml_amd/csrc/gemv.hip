@@ -25,7 +25,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gemv_q4_0(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
                                                    ActQ8_0 act, float* __restrict__ out, int m, int nb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -62,7 +62,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gemv_q8_0(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
                                                    ActQ8_0 act, float* __restrict__ out, int m, int nb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -79,7 +79,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gemv_q4_1(const i32x4* __restrict__ wq, const unsigned* __restrict__ wdm,
                                                    ActQ8_1 act, float* __restrict__ out, int m, int nb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -103,7 +103,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gemv_q4_k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, ActQ8_K act,
                                                    float* __restrict__ out, int m, int nsb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -120,7 +120,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gemv_q5_k(const char* __restrict__ w, size_t off_qh, ActQ8_K act, float* __restrict__ out, int m,
                                                    int nsb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -137,7 +137,7 @@ template <class P, int R>
 __global__ __launch_bounds__(256) void k_gemv_pieces(const char* __restrict__ w, size_t off, size_t n, typename P::Act act,
                                                      float* __restrict__ out, int m, int nbr) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -173,7 +173,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gemv_q6_k(const char* __restrict__ w, size_t off_qh, ActQ8_K act,
                                                    float* __restrict__ out, int m, int nsb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -192,7 +192,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gemv_q8_k(const i32x4* __restrict__ wq, const float* __restrict__ wd,
                                                    ActQ8_K act, float* __restrict__ out, int m, int nsb) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * R;
   if (row0 >= m) return;
   float acc[R];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_gemv_q8_k(const i32x4* __restrict__ wq,
 __global__ __launch_bounds__(256) void k_gemv_f32(const float* __restrict__ w, const float* __restrict__ x,
                                                   float* __restrict__ out, int m, int k) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   if (row >= m) return;
   const float* wr = w + (size_t)row * k;
   float acc = 0.f;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_gemv_f16(const unsigned short* __restri
                                                   const unsigned short* __restrict__ x16, float* __restrict__ out,
                                                   int m, int k) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   if (row >= m) return;
   const unsigned short* wr = w + (size_t)row * k;
   float acc = 0.f;

@@ -360,8 +360,10 @@ __device__ __forceinline__ void q4k_ints(const Q4KPiece<HDR_DPP>& w, const Q4KX&
     lo = __builtin_amdgcn_sdot4(w.qv[i] & 0x0F0F0F0F, x.xl[i], lo, false);
     hi = __builtin_amdgcn_sdot4((w.qv[i] >> 4) & 0x0F0F0F0F, x.xh[i], hi, false);
   }
-  isum = sc_lo * lo + sc_hi * hi;          // exact (the reference's aux32 lanes hold integers < 2^24)
-  msum = m_lo * x.bs_lo + m_hi * x.bs_hi;  // i32: the intended math of buf_q4_k.rs:238-241
+  // (v_mul_i32_i24 / v_mad_i32_i24: every factor is below 2^23 -- |lo|, |hi| <= 16 * 15 * 128, the 6-bit fields, |bsum| <= 16 * 128 --
+  // where a plain 32-bit multiply is a quarter-rate instruction)
+  isum = __mul24(sc_lo, lo) + __mul24(sc_hi, hi);          // exact (the reference's aux32 lanes hold integers < 2^24)
+  msum = __mul24(m_lo, x.bs_lo) + __mul24(m_hi, x.bs_hi);  // i32: the intended math of buf_q4_k.rs:238-241
 }
 template <bool HDR_DPP>
 __device__ __forceinline__ float q4k_term(const Q4KPiece<HDR_DPP>& w, const Q4KX& x, int c, int* dbg = nullptr) {
@@ -408,12 +410,12 @@ __device__ __forceinline__ void q4k_class_terms(const Q4KPiece<HDR_DPP>& w, cons
   for (int i = 0; i < 4; i++) {
     const int lo = __builtin_amdgcn_sdot4(w.qv[i] & 0x0F0F0F0F, x.xl[i], 0, false);
     const int hi = __builtin_amdgcn_sdot4((w.qv[i] >> 4) & 0x0F0F0F0F, x.xh[i], 0, false);
-    int a = live ? sc_lo * lo + sc_hi * hi : 0;
-    a += dpp_i<0x4E>(a);                // lane ^ 2 (quad_perm [2,3,0,1])
-    a += dpp_i<0x1B>(dpp_i<0x141>(a));  // lane ^ 4 (row_half_mirror: j -> 7 - j, then quad_perm [3,2,1,0]: j -> j ^ 3)
+    int a = live ? __mul24(sc_lo, lo) + __mul24(sc_hi, hi) : 0;  // (24-bit factors: full-rate multiplies)
+    a += dpp_i<0x4E>(a);   // lane ^ 2 (quad_perm [2,3,0,1])
+    a += dpp_i<0x104>(a);  // row_shl:4 -- lane j takes lane j + 4 of its row: the p = 0 lanes (j < 2 of every 8) hold the four pairs' sum
     A[i] = a;
   }
-  int ms = live ? m_lo * x.bs_lo + m_hi * x.bs_hi : 0;  // i32: the intended math of buf_q4_k.rs:238-241
+  int ms = live ? __mul24(m_lo, x.bs_lo) + __mul24(m_hi, x.bs_hi) : 0;  // i32: the intended math of buf_q4_k.rs:238-241
   ms += dpp_i<0xB1>(ms);
   ms += dpp_i<0x4E>(ms);
   ms += dpp_i<0x141>(ms);
@@ -423,12 +425,39 @@ __device__ __forceinline__ void q4k_class_terms(const Q4KPiece<HDR_DPP>& w, cons
     if (h == 0) t[8] = (h2f((unsigned short)(h0 >> 16)) * x.d8) * (float)ms;
   }
 }
+// floats per row of a record table: 12 per super-block + 4 of padding, so that the chain lanes (one per row) read their 16-byte pieces
+// four LDS banks apart (a stride of 12 nsb floats is a multiple of 64 banks for nsb = 16: every lane on the same banks)
+__host__ __device__ inline int q4k_rec_stride(int nsb) { return nsb * 12 + 4; }
 // the nine chains of one row over its nsb records (12 floats each, 16-byte aligned), in super-block order: buf_q4_k.rs:263-276
 __device__ __forceinline__ float q4k_ordered_sum(const float* __restrict__ t, int nsb) {
   float sums[8], sumf = 0.0f;
 #pragma unroll
   for (int l = 0; l < 8; l++) sums[l] = 0.0f;
-  for (int sb = 0; sb < nsb; sb++) {
+  // four records' reads in flight ahead of their adds (the nine chains are independent of each other: one dependent add per record)
+  int sb = 0;
+  for (; sb + 4 <= nsb; sb += 4) {
+    f32x4 a[4], b[4];
+    float m[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      a[u] = *(const f32x4*)(t + (sb + u) * 12);
+      b[u] = *(const f32x4*)(t + (sb + u) * 12 + 4);
+      m[u] = t[(sb + u) * 12 + 8];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      sums[0] += a[u][0];
+      sums[1] += a[u][1];
+      sums[2] += a[u][2];
+      sums[3] += a[u][3];
+      sums[4] += b[u][0];
+      sums[5] += b[u][1];
+      sums[6] += b[u][2];
+      sums[7] += b[u][3];
+      sumf -= m[u];
+    }
+  }
+  for (; sb < nsb; sb++) {
     const f32x4 a = *(const f32x4*)(t + sb * 12), b = *(const f32x4*)(t + sb * 12 + 4);
     sums[0] += a[0];
     sums[1] += a[1];
