@@ -179,6 +179,7 @@ struct crabml_hip_llama {
   float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr, *pf_qr = nullptr, *pf_attn = nullptr,
         *pf_tmp = nullptr, *pf_g = nullptr, *pf_u = nullptr;
   char *pf_act_dim = nullptr, *pf_act_hid = nullptr;
+  void* pf_xh = nullptr;  // the fast pass's Q4_0 GEMMs: the current rhs rows as pre-scaled f16 (gemm_f16w.hip), cap x max(dim, hidden) halfs
   float* pf_scores = nullptr;          // long prompts: [PF_LONG_ROWS][n_heads][seq_len] f32 scores
   unsigned short* pf_p16 = nullptr;    //               and f16 probabilities, allocated on first use
   std::vector<std::pair<void*, size_t>> allocs;
@@ -1048,6 +1049,7 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   CH_TRY(A(cap * hidden * 4, (void**)&c->pf_u));
   CH_TRY(A(cap * act_bytes(c->qt, dim), (void**)&c->pf_act_dim));
   CH_TRY(A(cap * act_bytes(c->qt, hidden), (void**)&c->pf_act_hid));
+  if (c->qt == CRABML_HIP_Q8_0 && !c->dev->strict_order) CH_TRY(A(cap * (dim > hidden ? dim : hidden) * 2, &c->pf_xh));
   c->pf_cap = cap;
   return 0;
 }
@@ -1159,9 +1161,11 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       k_norm_f32_rows<12><<<rows, 1024, norm_lds, st>>>(c->pf_x, wn, dim, eps, c->pf_xn, half);
   };
   // CpuTensorBuf::quantize for the rhs of matmul_vec (buf/api.rs:142-159): F32 weights take the rows as they are
+  const void* xh_of = nullptr;  // the planes c->pf_xh was made from (reset whenever planes are rewritten)
   auto quant_rows = [&](const float* src, int n, char* planes) -> const void* {
     if (c->qt == CRABML_HIP_F32) return src;
     launch_quantize_act_rows(st, c->qt, src, B, (size_t)n, planes);
+    xh_of = nullptr;
     return planes;
   };
   static const bool gemm_exact_hook = [] {  // A/B hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_EXACT=1): the fast pass with matmul_vec's own scaling
@@ -1169,7 +1173,24 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const char* e = getenv("CRABML_HIP_GEMM_EXACT");
     return h && h[0] == '1' && e && e[0] == '1';
   }();
+  // The fast pass, Q4_0 weights x Q8_0 rows, >= 32 rows: the weight-stationary f16 GEMM (gemm_f16w.hip; block scales folded into f16
+  // operands, f32 accumulation inside the matrix core -- a stated deviation of the fast tier).  The rows' pre-scaled f16 planes are
+  // made once per rhs (q / k / v and gate / up share theirs): xh_of remembers which planes pf_xh currently holds.
+  static const bool f16w_off = [] {  // A/B hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_INT8=1): the int8 kernels in the fast pass too
+    const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+    const char* e = getenv("CRABML_HIP_GEMM_INT8");
+    return h && h[0] == '1' && e && e[0] == '1';
+  }();
+  const bool f16w = !strict && !gemm_exact_hook && !f16w_off && c->qt == CRABML_HIP_Q8_0 && c->pf_xh != nullptr && B >= 32;
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
+    if (f16w && w->dtype == CRABML_HIP_Q4_0) {
+      if (xh_of != act) {
+        const ActLayout al = act_layout(CRABML_HIP_Q8_0, (size_t)k);
+        launch_q8_0_rows_to_f16(st, act, al.total, al.off_d, B, (size_t)k, c->pf_xh);
+        xh_of = act;
+      }
+      if (launch_gemm_f16w(dev, w, (size_t)m, (size_t)k, c->pf_xh, B, out)) return 0;
+    }
     if (!strict) {
       dev->gemm_fused_add = !gemm_exact_hook;
       const int rc = launch_gemv(dev, w, m, k, act, B, out, nullptr);
@@ -1208,6 +1229,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
         CRABML_NQR(12, false);
     }
 #undef CRABML_NQR
+    xh_of = nullptr;
     return c->pf_act_dim;
   };
   bool pending_down = false;  // (fuse_rows) the previous layer's ffn_down output sits in pf_tmp, not yet added to pf_x
@@ -1276,6 +1298,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       else
         k_gateup_epi_quant<false><<<gq, 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table, hidden, c->pf_act_hid, alh.total,
                                                       alh.off_d, alh.off_aux);
+      xh_of = nullptr;
       a = c->pf_act_hid;
     } else {
       k_gateup_epi<<<(unsigned)(((size_t)B * hidden + 255) / 256), 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table,
