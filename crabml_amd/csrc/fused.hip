@@ -1049,7 +1049,11 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   CH_TRY(A(cap * hidden * 4, (void**)&c->pf_u));
   CH_TRY(A(cap * act_bytes(c->qt, dim), (void**)&c->pf_act_dim));
   CH_TRY(A(cap * act_bytes(c->qt, hidden), (void**)&c->pf_act_hid));
-  if (c->qt == CRABML_HIP_Q8_0 && !c->dev->strict_order) CH_TRY(A(cap * (dim > hidden ? dim : hidden) * 2, &c->pf_xh));
+  if (c->qt == CRABML_HIP_Q8_0 && !c->dev->strict_order) {  // (+ 4 KB of zeroed slack: the GEMM's look-ahead reads, gemm_f16w.hip)
+    const size_t xb = cap * (dim > hidden ? dim : hidden) * 2 + 4096;
+    CH_TRY(A(xb, &c->pf_xh));
+    CH_HIP(c->dev, hipMemsetAsync(c->pf_xh, 0, xb, c->dev->stream));
+  }
   c->pf_cap = cap;
   return 0;
 }
@@ -1181,7 +1185,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const char* e = getenv("CRABML_HIP_GEMM_INT8");
     return h && h[0] == '1' && e && e[0] == '1';
   }();
-  const bool f16w = !strict && !gemm_exact_hook && !f16w_off && c->qt == CRABML_HIP_Q8_0 && c->pf_xh != nullptr && B >= 32;
+  const bool f16w = !strict && !gemm_exact_hook && !f16w_off && c->qt == CRABML_HIP_Q8_0 && c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
     if (f16w && w->dtype == CRABML_HIP_Q4_0) {
       if (xh_of != act) {
@@ -1189,7 +1193,8 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
         launch_q8_0_rows_to_f16(st, act, al.total, al.off_d, B, (size_t)k, c->pf_xh);
         xh_of = act;
       }
-      if (launch_gemm_f16w(dev, w, (size_t)m, (size_t)k, c->pf_xh, B, out)) return 0;
+      const size_t mm = (size_t)m;
+      if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out)) return 0;
     }
     if (!strict) {
       dev->gemm_fused_add = !gemm_exact_hook;
@@ -1242,9 +1247,22 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       norm_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);  // llama2.rs:230-234
       a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
     }
-    CH_TRY(gemm(c->wq[l], dim, dim, a, c->pf_q));  // llama2.rs:244-246
-    CH_TRY(gemm(c->wk[l], kv_dim, dim, a, c->pf_k));
-    CH_TRY(gemm(c->wv[l], kv_dim, dim, a, c->pf_v));
+    bool qkv_done = false;  // llama2.rs:244-246
+    if (f16w && c->wq[l]->dtype == CRABML_HIP_Q4_0 && c->wk[l]->dtype == CRABML_HIP_Q4_0 && c->wv[l]->dtype == CRABML_HIP_Q4_0) {
+      // the three GEMMs of the same rhs as ONE launch (the 1024-row k / v matrices alone leave most of the chip idle)
+      const ActLayout al = act_layout(CRABML_HIP_Q8_0, (size_t)dim);
+      launch_q8_0_rows_to_f16(st, a, al.total, al.off_d, B, (size_t)dim, c->pf_xh);
+      xh_of = a;
+      const crabml_hip_buf* ws[3] = {c->wq[l], c->wk[l], c->wv[l]};
+      const size_t ms[3] = {(size_t)dim, (size_t)kv_dim, (size_t)kv_dim};
+      float* outs[3] = {c->pf_q, c->pf_k, c->pf_v};
+      qkv_done = launch_gemm_f16w(dev, ws, ms, 3, (size_t)dim, c->pf_xh, B, outs);
+    }
+    if (!qkv_done) {
+      CH_TRY(gemm(c->wq[l], dim, dim, a, c->pf_q));
+      CH_TRY(gemm(c->wk[l], kv_dim, dim, a, c->pf_k));
+      CH_TRY(gemm(c->wv[l], kv_dim, dim, a, c->pf_v));
+    }
     QkvEpi e{c->pf_qr, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim, kv_dim, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int pairs = (dim + 2 * kv_dim) / 2;

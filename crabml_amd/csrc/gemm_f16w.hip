@@ -16,7 +16,9 @@
 // amortized (the int8 kernel: 10.75).  A fragments come straight from global memory in MFMA layout: lane (i, g) loads the whole
 // 16-byte block kb0 + g of row i (64 contiguous bytes per row and chunk) and step s = 0..3 of the chunk feeds dword s of every
 // lane -- an MFMA's 32 k-slots then span FOUR blocks (8 elements of each), which the folded scales allow.  B' tiles (128 columns x
-// 128 k-slots x 2 B = 32 KB per chunk) go through LDS, double-buffered, one barrier per chunk, shared by the workgroup's four waves.
+// 128 k-slots x 2 B = 32 KB per chunk) go through LDS, double-buffered, one barrier per chunk, shared by the workgroup's four waves;
+// the fragment reads are conflict-free ds_read_b128 (layout: GemmF16Geo), a group of tiles ahead of the MFMAs that consume them.
+#include <cstdlib>
 #include <type_traits>
 
 #include "devutil.hpp"
@@ -59,29 +61,48 @@ void launch_q8_0_rows_to_f16(hipStream_t st, const void* planes, size_t row_stri
 
 // one dword of a Q4_0 block (quant bytes 4 s .. 4 s + 3: low nibbles = elements 4 s .., high nibbles = 16 + 4 s ..; buf_q4_0.rs:24-33)
 // -> the lane's eight f16 k-slots (q - 8) * d.  0x6400 | n is the f16 number 1024 + n; -1032 makes it n - 8 exactly.
-__device__ __forceinline__ f16x8 unpack_q4_0_f16(unsigned w, f16x2 d2) {
+// (x & 0x000F000F) | 0x64006400 as ONE v_and_or_b32: a VOP3 instruction takes a single scalar / literal operand, so the compiler
+// splits it unless one constant sits in a VGPR -- `magic` (loop-invariant, one register)
+__device__ __forceinline__ unsigned and_or_magic(unsigned x, unsigned magic) {
+  unsigned r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(0x000F000Fu), "v"(magic));
+  return r;
+}
+__device__ __forceinline__ f16x8 unpack_q4_0_f16(unsigned w, f16x2 d2, unsigned magic) {
   const f16x2 bias = {(_Float16)-1032.0f, (_Float16)-1032.0f};
-  const unsigned u0 = (w & 0x000F000Fu) | 0x64006400u, u1 = ((w >> 8) & 0x000F000Fu) | 0x64006400u;
-  const unsigned u2 = ((w >> 4) & 0x000F000Fu) | 0x64006400u, u3 = ((w >> 12) & 0x000F000Fu) | 0x64006400u;
+  const unsigned u0 = and_or_magic(w, magic), u1 = and_or_magic(w >> 8, magic);
+  const unsigned u2 = and_or_magic(w >> 4, magic), u3 = and_or_magic(w >> 12, magic);
   const f16x2 p0 = (__builtin_bit_cast(f16x2, u0) + bias) * d2, p1 = (__builtin_bit_cast(f16x2, u1) + bias) * d2;
   const f16x2 p2 = (__builtin_bit_cast(f16x2, u2) + bias) * d2, p3 = (__builtin_bit_cast(f16x2, u3) + bias) * d2;
   return f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
 }
 
+template <int T_>
 struct GemmF16Geo {
-  static constexpr int T = 8, CW = 16 * T;     // column tiles per wave / prompt rows per workgroup
+  static constexpr int T = T_, CW = 16 * T;    // column tiles per wave / prompt rows per workgroup
   static constexpr int KCH = 4;                // blocks per chunk
-  static constexpr int CSTR = KCH * 64 + 16;   // bytes per column in an LDS buffer: 256 + 16 of padding (fragment reads: 16 lanes of a
-                                               // tile, four banks each, cover the 64 banks once)
-  static constexpr int BUF = CW * CSTR, LDS_BYTES = 2 * BUF;
-  static constexpr int B_LOADS = CW * KCH * 4 / 256;  // 16-byte pieces per thread and chunk (8)
+  // An LDS buffer is [block of the chunk g][column][80 bytes]: a column's 64 bytes of one block + 16 of padding.  ds_read_b128 is
+  // serviced in four 16-lane groups that mix lanes of two k-slot groups g (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27}, ...) over 64
+  // banks: with 80-byte columns the 16 columns of a tile sit on the 16 different 16-byte slots of the 256-byte bank row (5 i mod 16),
+  // and the blocks' planes are a multiple of 256 bytes apart, so every lane group is conflict-free whichever g its lanes belong to.
+  static constexpr int CSTR = 80, GSTR = CW * CSTR;
+  static_assert(GSTR % 256 == 0, "block planes must be whole bank rows apart");
+  static constexpr int BUF = KCH * GSTR, LDS_BYTES = 2 * BUF;
+  static constexpr int B_LOADS = CW * KCH * 4 / 256;  // 16-byte pieces per thread and chunk (T)
 };
 
-template <int F>  // 16-row fragments per wave: the workgroup's four waves own 64 F consecutive weight rows
-__global__ __launch_bounds__(256, 2) void k_gemm_f16w(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd,
-                                                      const i32x4* __restrict__ xh, float* __restrict__ out, int m, int nb, int n,
-                                                      int row_tiles) {
-  using G = GemmF16Geo;
+// Up to three weight matrices against the same rhs in ONE launch (wq | wk | wv: the 1024-row k / v GEMMs alone leave most of the
+// chip idle for a whole serial k loop): row tile rt belongs to the first matrix whose cumulative tile count exceeds it.
+struct F16wMats {
+  const i32x4* wq[3];
+  const unsigned short* wd[3];
+  float* out[3];
+  int m[3];
+  int tiles_end[3];  // cumulative row tiles
+};
+template <int F, int T_>  // F 16-row fragments x T_ 16-column tiles per wave: the workgroup's four waves own 64 F consecutive weight rows
+__global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4* __restrict__ xh, int nb, int n, int row_tiles) {
+  using G = GemmF16Geo<T_>;
   constexpr int T = G::T, KCH = G::KCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char f16w_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_wg();
@@ -98,7 +119,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(const i32x4* __restrict__ 
       ct = (int)blockIdx.x / row_tiles;
     }
   }
-  const int r0 = rt * 64 * F + wave * 16 * F, c0 = ct * G::CW;
+  const int ti = rt < mats.tiles_end[0] ? 0 : rt < mats.tiles_end[1] ? 1 : 2;  // (uniform)
+  const i32x4* __restrict__ wq = ti == 0 ? mats.wq[0] : ti == 1 ? mats.wq[1] : mats.wq[2];
+  const unsigned short* __restrict__ wd = ti == 0 ? mats.wd[0] : ti == 1 ? mats.wd[1] : mats.wd[2];
+  float* __restrict__ out = ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2];
+  const int m = ti == 0 ? mats.m[0] : ti == 1 ? mats.m[1] : mats.m[2];
+  const int rt_l = rt - (ti == 0 ? 0 : ti == 1 ? mats.tiles_end[0] : mats.tiles_end[1]);
+  const int r0 = rt_l * 64 * F + wave * 16 * F, c0 = ct * G::CW;
   const int nchunks = (nb + KCH - 1) / KCH;
 
   // A: the lane's block (row i of fragment f, block kb0 + g) and its scale.  HBM latency is several chunk times (a chunk is ~0.4 us of
@@ -120,16 +147,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(const i32x4* __restrict__ 
     }
   };
   // B': 128 columns x 256 bytes per chunk, 8 pieces per thread (piece p: column p / 16, 16 bytes p % 16 of the chunk)
-  i32x4 rb[2][G::B_LOADS];
+  // (one base pointer per piece, advanced by a chunk = 256 bytes per fetch: the fetches come in chunk order.  Past a column's end --
+  // a ragged last chunk, the look-ahead of the last iterations -- a piece reads the next column's first blocks, or the zeroed slack
+  // behind the planes (launch_gemm_f16w's contract): finite values against zero weights, or never consumed)
+  constexpr int NBD = F == 1 ? 4 : 2;  // register sets of B' pieces in flight (one wave per SIMD needs the longer look-ahead)
+  i32x4 rb[NBD][G::B_LOADS];
+  const i32x4* pb[G::B_LOADS];
+#pragma unroll
+  for (int u = 0; u < G::B_LOADS; u++) {
+    const int p = tid + 256 * u, col = p >> 4, pc = p & 15;
+    const int gcol = c0 + col < n ? c0 + col : n - 1;
+    pb[u] = xh + (size_t)gcol * nb * 4 + pc;
+  }
   auto fetch_b = [&](i32x4 (&r)[G::B_LOADS], int ch) {
-    const int cc = ch < nchunks ? ch : nchunks - 1;
+    (void)ch;
 #pragma unroll
     for (int u = 0; u < G::B_LOADS; u++) {
-      const int p = tid + 256 * u, col = p >> 4, pc = p & 15;
-      const int gcol = c0 + col < n ? c0 + col : n - 1;
-      const int kb = cc * KCH + (pc >> 2);
-      const int gkb = kb < nb ? kb : nb - 1;  // (the tail chunk re-reads the last block: finite values against zero weights)
-      r[u] = xh[((size_t)gcol * nb + gkb) * 4 + (pc & 3)];
+      r[u] = *pb[u];
+      pb[u] += KCH * 4;
     }
   };
   auto commit_b = [&](const i32x4 (&r)[G::B_LOADS], int buf) {
@@ -137,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(const i32x4* __restrict__ 
 #pragma unroll
     for (int u = 0; u < G::B_LOADS; u++) {
       const int p = tid + 256 * u, col = p >> 4, pc = p & 15;
-      *(i32x4*)(S + col * G::CSTR + pc * 16) = r[u];
+      *(i32x4*)(S + (pc >> 2) * G::GSTR + col * G::CSTR + (pc & 3) * 16) = r[u];
     }
   };
 
@@ -146,37 +181,55 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(const i32x4* __restrict__ 
   for (int f = 0; f < F; f++)
 #pragma unroll
     for (int t = 0; t < T; t++) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned magic = 0x64006400u;
+  asm volatile("" : "+v"(magic));  // pinned in a VGPR (and_or_magic)
 
   fetch_b(rb[0], 0);
   fetch_a(aq[0], ad[0], 0);
   fetch_a(aq[1], ad[1], 1);
   fetch_a(aq[2], ad[2], 2);
   commit_b(rb[0], 0);
-  fetch_b(rb[1], 1);  // chunk c + 1 sits in rb[(c + 1) & 1] when chunk c is multiplied
-  fetch_b(rb[0], 2);
+  // chunk c sits in rb[c % NBD] from NBD chunks before it is committed (the fetches come in chunk order: pb advances)
+#pragma unroll
+  for (int c = 1; c <= NBD; c++) fetch_b(rb[c % NBD], c);
   __syncthreads();
   // chunk ch (ring slot J, LDS buffer ch & 1)
   auto chunk = [&](auto Jc, int ch) {
     constexpr int J = decltype(Jc)::value;
     fetch_a(aq[(J + 3) & 3], ad[(J + 3) & 3], ch + 3);
-    const unsigned char* S = f16w_lds + (J & 1) * G::BUF + i * G::CSTR + g * 64;
+    const unsigned char* S = f16w_lds + (J & 1) * G::BUF + g * G::GSTR + i * G::CSTR;
     f16x2 d2[F];
 #pragma unroll
     for (int f = 0; f < F; f++) d2[f] = __builtin_bit_cast(f16x2, ad[J][f] | (ad[J][f] << 16));
+    // B' fragments in groups of TG tiles, two groups in registers: group q + 1 is read from LDS while group q is multiplied (left
+    // to itself the compiler reads ONE fragment, waits, multiplies: 32 exposed LDS round trips per chunk with the SIMD almost to
+    // itself).  The scheduling barriers keep the reads of a group ahead of the MFMAs of the previous one.
+    constexpr int TG = T >= 4 ? 4 : T, NG = 4 * (T / TG);  // groups per chunk (4 steps x T / TG)
+    f16x8 bq[2][TG];
+    auto read_group = [&](f16x8 (&dst)[TG], int q) {
+      const int s = q / (T / TG), t0 = (q % (T / TG)) * TG;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      f16x8 a[F];
+      for (int t = 0; t < TG; t++) dst[t] = *(const f16x8*)(S + (t0 + t) * 16 * G::CSTR + s * 16);
+    };
+    read_group(bq[0], 0);
+    f16x8 a[F];
 #pragma unroll
-      for (int f = 0; f < F; f++) a[f] = unpack_q4_0_f16((unsigned)aq[J][f][s], d2[f]);
+    for (int q = 0; q < NG; q++) {
+      const int s = q / (T / TG), t0 = (q % (T / TG)) * TG;
+      if (q + 1 < NG) read_group(bq[(q + 1) & 1], q + 1);
+      if (q % (T / TG) == 0) {
 #pragma unroll
-      for (int t = 0; t < T; t++) {
-        const f16x8 b = *(const f16x8*)(S + t * 16 * G::CSTR + s * 16);
-#pragma unroll
-        for (int f = 0; f < F; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[f], b, acc[f][t], 0, 0, 0);
+        for (int f = 0; f < F; f++) a[f] = unpack_q4_0_f16((unsigned)aq[J][f][s], d2[f], magic);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TG; t++)
+#pragma unroll
+        for (int f = 0; f < F; f++) acc[f][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[f], bq[q & 1][t], acc[f][t0 + t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    commit_b(rb[(J + 1) & 1], (J + 1) & 1);  // chunk ch + 1 into the other buffer (read last in iteration ch - 1: behind its barrier)
-    fetch_b(rb[(J + 1) & 1], ch + 3);        // ... and the freed register set takes chunk ch + 3
+    commit_b(rb[(J + 1) % NBD], (J + 1) & 1);  // chunk ch + 1 into the other buffer (read last in iteration ch - 1: behind its barrier)
+    fetch_b(rb[(J + 1) % NBD], ch + 1 + NBD);  // ... and the freed register set takes chunk ch + 1 + NBD
     __syncthreads();
   };
   for (int ch = 0; ch < nchunks; ch += 4) {  // (uniform conditions: every thread takes the barrier inside a chunk or none does)
@@ -205,35 +258,57 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(const i32x4* __restrict__ 
   }
 }
 
-// xh: the rows' pre-scaled f16 planes (launch_q8_0_rows_to_f16); returns false when the shape is not covered
-bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* xh, size_t b, float* out) {
-  if (w->dtype != CRABML_HIP_Q4_0 || k % 32 != 0 || m % 4 != 0 || b < 32) return false;
-  using G = GemmF16Geo;
-  hipStream_t st = dev->stream;
-  const char* wp = (const char*)w->ptr;
-  const int nb = (int)(k / 32);
-  const int col_tiles = (int)((b + G::CW - 1) / G::CW);
-  // 128-row workgroups (two fragments per wave: every B' fragment read from LDS feeds two MFMAs) when that still covers the chip
+// xh: the rows' pre-scaled f16 planes (launch_q8_0_rows_to_f16) FOLLOWED BY zeroed slack (the kernel's look-ahead reads run up to
+// three chunks past the last column's end: fused.hip allocates 4 KB); returns false when the shape is not covered
+template <int F, int T>
+static bool launch_f16w_t(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b) {
+  using G = GemmF16Geo<T>;
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute((const void*)k_gemm_f16w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_gemm_f16w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_gemm_f16w<F, T>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     raised = true;
   }
-  const bool wide = ((m + 127) / 128) * (size_t)col_tiles >= (size_t)dev->n_cu;
-  if (wide) {
-    const int row_tiles = (int)((m + 127) / 128);
-    k_gemm_f16w<2><<<dim3(row_tiles * col_tiles), 256, G::LDS_BYTES, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale),
-                                                                          (const i32x4*)xh, out, (int)m, nb, (int)b, row_tiles);
-  } else {
-    const int row_tiles = (int)((m + 63) / 64);
-    k_gemm_f16w<1><<<dim3(row_tiles * col_tiles), 256, G::LDS_BYTES, st>>>((const i32x4*)wp, (const unsigned short*)(wp + w->wl.off_scale),
-                                                                          (const i32x4*)xh, out, (int)m, nb, (int)b, row_tiles);
-  }
+  const int col_tiles = (int)((b + G::CW - 1) / G::CW);
+  k_gemm_f16w<F, T><<<dim3(row_tiles * col_tiles), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b, row_tiles);
   return true;
+}
+// nw weight matrices (Q4_0, the same k) against the same rhs rows: out[j] (b, m[j]) = W[j] . x
+bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
+                      float* const* out) {
+  if (nw < 1 || nw > 3 || k % 32 != 0 || b < 32) return false;
+  for (int j = 0; j < nw; j++)
+    if (w[j]->dtype != CRABML_HIP_Q4_0 || m[j] % 4 != 0) return false;
+  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = <2,8>, 3 = <1,8>, 4 = <2,4>
+    const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+    const char* e = getenv("CRABML_HIP_F16W");
+    return h && h[0] == '1' && e ? atoi(e) : 0;
+  }();
+  size_t mtot = 0;
+  for (int j = 0; j < nw; j++) mtot += m[j];
+  const size_t col128 = (b + 127) / 128;
+  // two fragments per wave (every B' fragment read from LDS feeds two MFMAs) when 128-row tiles still cover the chip
+  int F = ((mtot + 127) / 128) * col128 >= (size_t)dev->n_cu ? 2 : 1;
+  if ((variant & 7) == 1) F = 2;
+  if ((variant & 7) == 3) F = 1;
+  F16wMats mats{};
+  int row_tiles = 0;
+  for (int j = 0; j < 3; j++) {
+    const int jj = j < nw ? j : nw - 1;
+    const char* wp = (const char*)w[jj]->ptr;
+    mats.wq[j] = (const i32x4*)wp;
+    mats.wd[j] = (const unsigned short*)(wp + w[jj]->wl.off_scale);
+    mats.out[j] = out[jj];
+    mats.m[j] = (int)m[jj];
+    if (j < nw) row_tiles += (int)((m[j] + 64 * F - 1) / (64 * F));
+    mats.tiles_end[j] = row_tiles;
+  }
+  // (measured and not kept: the k range of ffn_down / wo cut in two with f32 atomic adds onto a zeroed output -- 32.4k -> 30.1k
+  // prompt tok/s at 512 rows: the memset and 4 M atomics cost more than the second workgroup per CU returns)
+  if ((variant & 7) == 4) return launch_f16w_t<2, 4>(dev, mats, row_tiles, k, xh, b);
+  return F == 2 ? launch_f16w_t<2, 8>(dev, mats, row_tiles, k, xh, b) : launch_f16w_t<1, 8>(dev, mats, row_tiles, k, xh, b);
 }
 
 }  // namespace crabml_hip

@@ -1,5 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-echo "== f16w"; timeout 300 python tools/prefill_bench.py --chunks 128,256,512 --loop 2 2>&1 | tail -4
-echo "== int8"; CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_INT8=1 timeout 300 python tools/prefill_bench.py --chunks 512 --loop 2 2>&1 | tail -2
+for v in 0 3; do echo "== f16w variant $v"; CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=$v timeout 300 python tools/prefill_bench.py --chunks 32,64,128,256,512 --loop 2 2>&1 | tail -6 | head -5; done
 timeout 900 python -m pytest -q -p no:cacheprovider tests/test_hip_prefill.py tests/test_hip_flash_attention.py -m gpu -x -q 2>&1 | tail -3
