@@ -27,7 +27,12 @@ pub struct HipTensorDeviceOptions {
 
     /// CRABML_HIP_FLAG_PER_OP: launch every Tensor call immediately. Default (false): the calls are recorded and
     /// run at the next `export` / `sync` -- a decode token of `Llama2Runner::forward` as the fused step
-    /// (five launches per layer), anything else op by op; the results are the same either way.
+    /// (five launches per layer), anything else op by op.  On a `strict_order` device the results are the same either
+    /// way, bit for bit.  On the default (fast) device a token served by the fused step carries the fused step's
+    /// re-associated sums (deferred 1 / rms, f32 split-KV attention past 96 positions, fused gate / up), a token that is
+    /// replayed op by op -- after a mid-token `sync` / `export`, with `debug_named_tensor`, or when the call sequence
+    /// deviates -- carries the per-op kernels': both inside the backend's stated tolerance of the CPU path, not equal to
+    /// each other.  A host that needs one answer regardless of what it observes uses `strict_order` or `per_op`.
     pub per_op: bool,
 }
 

@@ -140,7 +140,6 @@ struct crabml_hip_device {
   uint16_t* gelu_table = nullptr;
   // measurement hook (crabml_hip_prof_*): event pairs around GEMV launches
   bool prof_on = false;
-  bool gemm_fused_add = false;  // set by the fast prompt pass around its weight GEMMs: the block term's last product and the add as one fma
   struct ProfRec {
     hipEvent_t e0, e1;
     uint32_t dtype;
@@ -152,11 +151,15 @@ struct crabml_hip_device {
   // Tensor ops are RECORDED and run at the next point the host can observe data (export / sync): lazy.hip.  `lazy` off
   // (CRABML_HIP_FLAG_PER_OP): every call launches immediately.  `fuse` off: the queue is replayed op by op, never matched.
   bool lazy = true, fuse = true;
+  bool destroying = false;  // crabml_hip_device_destroy's flush: run what is queued, learn nothing
   bool dry = false;  // test hook (CRABML_HIP_FLAG_DRY + CRABML_HIP_TEST_HOOKS=1): no HIP device behind this object -- ops are
                      // recorded, matched and counted, nothing is computed (the CPU suite drives the recorder / matcher with it)
   crabml_hip::LazyState* lz = nullptr;
 };
 
+namespace crabml_hip {
+inline std::atomic<uint64_t> g_buf_uid{0};
+}
 struct crabml_hip_buf {
   crabml_hip_device* dev = nullptr;
   std::atomic<int> refcnt{1};
@@ -166,6 +169,7 @@ struct crabml_hip_buf {
   size_t bytes = 0;     // size to bind
   bool zero_init = false;  // Tensor::alloc(F32): zero-filled when the memory is bound (vec![0.0; n], cpu_tensor.rs:146-149)
   uint8_t deferred = 0;    // lazy.hip: the value still lives in the fused context (1 = the final RMSNorm of its residual stream)
+  uint64_t uid = ++crabml_hip::g_buf_uid;  // unique per handle for the life of the process (an address is not: the allocator re-uses them)
   size_t cap = 0;       // pool capacity in bytes
   size_t m = 0, k = 0;  // logical 2-D shape of quantized weights
   crabml_hip::WeightLayout wl;

@@ -17,6 +17,7 @@
 //   k_gateup       ffn_gate/ffn_up matmul_vec + silu_inplace + mul_inplace
 //   k_argmax_step  greedy sampler (last maximum) + token/position advance
 #include <chrono>
+#include <thread>
 #include <cmath>
 
 #include "fused_common.hpp"
@@ -116,6 +117,7 @@ struct crabml_hip_llama {
   unsigned out_seq = 0;         // sequence number of the last step whose logits were sent to host_logits
   unsigned lazy_serial = 0;     // lazy.hip: the step serial is set by the host at every begin (see lazy_ctx_begin)
   bool ext_kv = false;          // lazy.hip: kc / vc are the runner's own cache buffers (retained in `held`), not allocations of ours
+  const crabml_hip_buf* ext_kc0 = nullptr;  // ... the first layer's K cache handle (lazy_ctx_orphaned)
   float* tmp = nullptr;      // strict-mode GEMV outputs
   char* act_dim = nullptr;   // Q8_0 planes of the normalized residual (dim)
   char* act_attn = nullptr;  // Q8_0 planes of the attention output (dim_l)
@@ -1197,10 +1199,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out)) return 0;
     }
     if (!strict) {
-      dev->gemm_fused_add = !gemm_exact_hook;
-      const int rc = launch_gemv(dev, w, m, k, act, B, out, nullptr);
-      dev->gemm_fused_add = false;
-      return rc;
+      return launch_gemv(dev, w, m, k, act, B, out, nullptr, !gemm_exact_hook);
     }
     // strict order: the Q4_0 / Q8_0 / Q4_1 MFMA GEMM scales its exact integer tiles block by block in the reference's scalar
     // order, i.e. it IS the strict result (bit for bit) -- the other formats take the scalar-order GEMV row by row
@@ -1785,6 +1784,7 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
         if (rc == 0) rc = set_error(dev, CRABML_HIP_BAD_INPUT, "llama: external kv cache of layer %zu has the wrong type or size", l);
         continue;
       }
+      if (l == 0) c->ext_kc0 = ext_kc[l];
       c->kc[l] = hold(ext_kc[l])->ptr;
       c->vc[l] = hold(ext_vc[l])->ptr;
     } else {
@@ -2343,6 +2343,19 @@ int lazy_ctx_create(crabml_hip_device* dev, const LazyModel& m, crabml_hip_llama
 
 void lazy_ctx_destroy(crabml_hip_llama* c) { (void)crabml_hip_llama_destroy(c); }
 
+bool lazy_ctx_orphaned(const crabml_hip_llama* c) {
+  // one representative of the model (the first layer's wq) and one of the runner (its first K cache): a handle whose references are
+  // all the context's own holds has been released by the host
+  auto sole = [&](const crabml_hip_buf* b) {
+    if (!b) return false;
+    int holds = 0;
+    for (const crabml_hip_buf* h : c->held)
+      if (h == b) holds++;
+    return holds > 0 && b->refcnt.load() <= holds;
+  };
+  return sole(c->wq.empty() ? nullptr : c->wq[0]) || (c->ext_kv && sole(c->ext_kc0));
+}
+
 int lazy_ctx_n_segments(const crabml_hip_llama* c) { return n_segments(c); }
 
 int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos) {
@@ -2410,7 +2423,11 @@ const float* lazy_ctx_wait_logits(crabml_hip_llama* c, int* fault) {
   const unsigned want = c->out_seq;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0; __atomic_load_n((const unsigned*)flag, __ATOMIC_ACQUIRE) != want; spins++) {
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
     if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
       if (hipStreamSynchronize(c->dev->stream) != hipSuccess) return nullptr;
       if (__atomic_load_n((const unsigned*)flag, __ATOMIC_ACQUIRE) != want) return nullptr;

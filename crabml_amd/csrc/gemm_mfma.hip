@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_q8k(const i32x4* __restrict__
 
 // returns false when the shape / format is not covered (the caller falls back to one GEMV per batch row)
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
-                      crabml_hip_device::ProfRec* rec, int* dbg) {
+                      crabml_hip_device::ProfRec* rec, int* dbg, bool fused_add) {
   if (w->dtype != CRABML_HIP_Q4_0 && w->dtype != CRABML_HIP_Q8_0 && w->dtype != CRABML_HIP_Q4_K && w->dtype != CRABML_HIP_Q6_K &&
       w->dtype != CRABML_HIP_Q4_1 && w->dtype != CRABML_HIP_Q8_K)
     return false;
@@ -902,7 +902,7 @@ bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m,
 #define CRABML_GEMM_LAUNCH_FMA(F, N)                                                                                                    \
   launch_k(st, rec, k_gemm_mfma<F, N, true>, dim3(row_tiles * col_tiles), dim3(256), GemmGeo<F, N>::LDS_BYTES, wp, wd, (const char*)act, \
            al.total, al.off_d, al.off_aux, out, (int)m, nb, (int)b, row_tiles)
-  const bool fma = dev->gemm_fused_add && !dev->strict_order;
+  const bool fma = fused_add && !dev->strict_order;
   if (w->dtype == CRABML_HIP_Q4_0 && fma) {
     if (narrow)
       CRABML_GEMM_LAUNCH_FMA(CRABML_HIP_Q4_0, 2);

@@ -266,7 +266,7 @@ static void launch_rows(hipStream_t st, int m, int n_cu, F&& f) {
 }
 
 int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size_t k_, const void* act, size_t b,
-                float* out, crabml_hip_device::ProfRec* rec0) {
+                float* out, crabml_hip_device::ProfRec* rec0, bool fused_add) {
   hipStream_t st = dev->stream;
   const int m = (int)m_, k = (int)k_;
   const char* wp = (const char*)w->ptr;
@@ -275,7 +275,7 @@ int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m_, size
   // F32 weights take the dense f32 rhs as is (row stride k*4); quantized planes are padded per row
   const size_t act_stride = qt == CRABML_HIP_F32 ? k_ * 4 : al.total;
   // a real batch (prefill): the weights are streamed once through the matrix cores instead of once per row
-  if (b >= 16 && launch_gemm_mfma(dev, w, m_, k_, act, b, out, rec0)) return 0;
+  if (b >= 16 && launch_gemm_mfma(dev, w, m_, k_, act, b, out, rec0, nullptr, fused_add)) return 0;
   for (size_t bi = 0; bi < b; bi++) {
     const char* ap = (const char*)act + bi * act_stride;
     float* o = out + bi * m_;

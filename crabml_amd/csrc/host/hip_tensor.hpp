@@ -66,7 +66,7 @@ class HipTensorDevice {
   size_t mem_in_use() const { return crabml_hip_device_mem_in_use(dev_); }
   // counters of the recorded-op queue (crabml_hip_debug.h)
   std::vector<uint64_t> lazy_stats() const {
-    std::vector<uint64_t> v(10, 0);
+    std::vector<uint64_t> v(12, 0);
     check(crabml_hip_debug_lazy_stats(dev_, v.data(), v.size()));
     return v;
   }

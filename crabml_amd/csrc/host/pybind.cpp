@@ -89,9 +89,9 @@ PYBIND11_MODULE(_host, m) {
            [](HipTensorDevice& d) {
              const std::vector<uint64_t> v = d.lazy_stats();
              py::dict r;
-             const char* names[10] = {"recorded", "replayed", "fused_tokens", "fused_ops", "segments", "aborts", "learned", "deferred_bound",
-                                      "wait_ns", "pinned_exports"};
-             for (int i = 0; i < 10; i++) r[names[i]] = v[i];
+             const char* names[12] = {"recorded", "replayed", "fused_tokens", "fused_ops", "segments", "aborts", "learned", "deferred_bound",
+                                      "wait_ns", "pinned_exports", "reactivated", "reaped"};
+             for (int i = 0; i < 12; i++) r[names[i]] = v[i];
              return r;
            })
       .def("sync", &HipTensorDevice::sync, py::call_guard<py::gil_scoped_release>())

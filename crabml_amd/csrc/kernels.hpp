@@ -22,8 +22,10 @@ void launch_quantize_act_rows(hipStream_t st, uint32_t qtype, const float* x, si
 // ---- gemv.hip: W(m,k) x quantized activations (b,k) -> out (b,m)
 // wq: weight planes; aq: activation planes (one set per batch row, stride act_layout(qtype,k).total)
 // rec != nullptr: the (first) kernel is launched with the record's event pair (measurement hook)
+// fused_add (the FAST prompt pass only): a batched rhs's block term takes its second product and the add as one fma -- an explicit
+// argument, never device state: matmul_vec itself is bit-exact and must not pick it up by accident
 int launch_gemv(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
-                float* out, crabml_hip_device::ProfRec* rec = nullptr);
+                float* out, crabml_hip_device::ProfRec* rec = nullptr, bool fused_add = false);
 // gemv_strict.hip: same contract, block terms added in the reference's scalar order (bit-exact; slow)
 int launch_gemv_strict(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b,
                        float* out, const float* add = nullptr);  // add: out[i] = sum + add[i] (the residual; may alias out)
@@ -39,13 +41,13 @@ struct RepackPlan {
 void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, size_t n_blocks, int bb, const RepackPlan& plan);
 void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t n_blocks);
 void launch_q4k_class_major(hipStream_t st, void* qs_plane, size_t blk0, size_t n_blocks);
-// batched rhs on the matrix cores (gemm_mfma.hip); false = not covered
 // gemm_f16w.hip: the fast prompt pass's weight-stationary f16 GEMM (Q4_0 weights) and the rows' pre-scaled f16 planes it reads
 void launch_q8_0_rows_to_f16(hipStream_t st, const void* planes, size_t row_stride, size_t off_d, size_t rows, size_t k, void* xh);
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
                       float* const* out);
+// batched rhs on the matrix cores (gemm_mfma.hip); false = not covered
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
-                      crabml_hip_device::ProfRec* rec, int* dbg = nullptr);
+                      crabml_hip_device::ProfRec* rec, int* dbg = nullptr, bool fused_add = false);
 int launch_piece_ints(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, size_t row, const void* act, int variant,
                       int32_t* out, float* fout);
 // elementwise.hip: plain streaming read of `bytes` bytes (crabml_hip_debug_read_ceiling), timed by the event pair

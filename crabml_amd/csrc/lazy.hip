@@ -458,6 +458,63 @@ void drop_model(crabml_hip_device* dev, LazyState& L) {
   L.model = LazyModel{};
   L.tracking = false;
 }
+// the active context steps aside (the host switched to another runner / model): kept, least recently used first; the oldest goes
+// when more than LAZY_PARKED_MAX wait
+void park_model(crabml_hip_device* dev, LazyState& L) {
+  if (!L.ctx) return;
+  (void)lazy_resolve(dev);  // handles the host still holds of this context's last token get their values now
+  ParkedModel p;
+  p.ctx = L.ctx;
+  p.model = std::move(L.model);
+  p.tmpl = std::move(L.tmpl);
+  p.mentions = std::move(L.mentions);
+  p.slot_xnorm = L.slot_xnorm;
+  p.slot_xfinal = L.slot_xfinal;
+  p.slot_logits = L.slot_logits;
+  L.parked.push_back(std::move(p));
+  L.ctx = nullptr;
+  L.tmpl.clear();
+  L.mentions.clear();
+  L.model = LazyModel{};
+  L.tracking = false;
+  L.check_fault = false;
+  L.fault_requested = false;
+  while (L.parked.size() > LAZY_PARKED_MAX) {
+    lazy_ctx_destroy(L.parked.front().ctx);
+    L.parked.erase(L.parked.begin());
+  }
+}
+void unpark_model(LazyState& L, size_t idx) {
+  ParkedModel p = std::move(L.parked[idx]);
+  L.parked.erase(L.parked.begin() + (long)idx);
+  L.ctx = p.ctx;
+  L.model = std::move(p.model);
+  L.tmpl = std::move(p.tmpl);
+  L.mentions = std::move(p.mentions);
+  L.slot_xnorm = p.slot_xnorm;
+  L.slot_xfinal = p.slot_xfinal;
+  L.slot_logits = p.slot_logits;
+  L.dead = false;
+  L.stats.reactivated++;
+}
+// Contexts whose model or caches the host has released (the context's own holds are all that keeps them alive) are destroyed: they
+// pin device memory -- the weights of a dropped model -- and nothing will be served from them again.  Called with the queue empty
+// (recorded ops hold references of their own).
+void reap_orphans(crabml_hip_device* dev, LazyState& L) {
+  if (L.ctx && !L.tracking && L.q.empty() && lazy_ctx_orphaned(L.ctx)) {
+    drop_model(dev, L);
+    L.stats.reaped++;
+  }
+  for (size_t i = 0; i < L.parked.size();) {
+    if (lazy_ctx_orphaned(L.parked[i].ctx)) {
+      lazy_ctx_destroy(L.parked[i].ctx);
+      L.parked.erase(L.parked.begin() + (long)i);
+      L.stats.reaped++;
+    } else {
+      i++;
+    }
+  }
+}
 
 // at a flush, before the queue runs: does it hold a complete token of a model we do not serve yet?  true: a decode context
 // was built from the token that starts at q[*start]
@@ -470,11 +527,21 @@ bool try_learn(crabml_hip_device* dev, LazyState& L, size_t* start) {
     int sx = -1, sf = -1, sl = -1;
     if (!learn_token(P, M, &sx, &sf, &sl)) continue;
     if (L.ctx && L.model.same_buffers(M)) return false;  // the model we already serve (its token ran op by op for another reason)
-    if (M.wq[0] == L.unfusable) return false;
-    drop_model(dev, L);
+    if (M.wq[0]->uid == L.unfusable_uid) return false;
+    for (size_t pi = 0; pi < L.parked.size(); pi++)
+      if (L.parked[pi].model.same_buffers(M)) {  // a runner we served before takes its turn again: its context is still there
+        ParkedModel again = std::move(L.parked[pi]);
+        L.parked.erase(L.parked.begin() + (long)pi);
+        park_model(dev, L);  // the one being served steps aside (and the oldest parked one goes if too many wait)
+        L.parked.push_back(std::move(again));
+        unpark_model(L, L.parked.size() - 1);
+        *start = i0;
+        return true;
+      }
+    park_model(dev, L);
     crabml_hip_llama* ctx = nullptr;
     if (lazy_ctx_create(dev, M, &ctx) != 0 || !ctx) {
-      L.unfusable = M.wq[0];  // the decode context refused this model (shape / dtype mix): it stays on the per-op launches
+      L.unfusable_uid = M.wq[0]->uid;  // the decode context refused this model (shape / dtype mix): it stays on the per-op launches
       return false;
     }
     L.ctx = ctx;
@@ -598,6 +665,7 @@ int commit_token(crabml_hip_device* dev, LazyState& L) {
   L.q.clear();
   L.tracking = false;
   L.check_fault = true;
+  if (!L.parked.empty()) reap_orphans(dev, L);  // (a host that only ever commits tokens never reaches lazy_flush's tail)
   return 0;
 }
 
@@ -677,7 +745,8 @@ int lazy_flush(crabml_hip_device* dev) {
   if (L.q.empty()) return 0;
   abort_token(L);
   size_t i0 = 0;
-  if (dev->fuse && try_learn(dev, L, &i0)) {  // (before the ops run and release their handles)
+  // (not at crabml_hip_device_destroy's flush: a context built there would be torn down again a moment later)
+  if (dev->fuse && !dev->destroying && try_learn(dev, L, &i0)) {  // (before the ops run and release their handles)
     // the token the context was learned from is served by it right away: whatever precedes it runs op by op, then its ops
     // are fed to the matcher as if they were being recorded now (they stay queued until the token commits, as always)
     std::vector<LazyOp> tail(L.q.begin() + i0, L.q.end());
@@ -689,9 +758,28 @@ int lazy_flush(crabml_hip_device* dev) {
     }
     abort_token(L);
     const int rc2 = run_queue(dev, L);
+    reap_orphans(dev, L);  // (the context that just stepped aside may have been its caches' last owner)
     return rc != 0 ? rc : rc2;
   }
-  return run_queue(dev, L);
+  const int rc = run_queue(dev, L);
+  reap_orphans(dev, L);
+  return rc;
+}
+
+int lazy_release_contexts(crabml_hip_device* dev) {
+  if (!dev->lz) return 0;
+  LazyState& L = *dev->lz;
+  int n = 0;
+  for (ParkedModel& p : L.parked) {
+    lazy_ctx_destroy(p.ctx);
+    n++;
+  }
+  L.parked.clear();
+  if (L.ctx && !L.tracking && L.q.empty()) {  // between tokens: the context is rebuilt from the next token if the host goes on
+    drop_model(dev, L);
+    n++;
+  }
+  return n;
 }
 
 int lazy_resolve(crabml_hip_device* dev) {
@@ -766,6 +854,8 @@ void lazy_destroy(crabml_hip_device* dev) {
   for (LazyOp& o : L.q) release_op(o);  // (device_destroy flushed first; whatever is left is dropped)
   L.q.clear();
   drop_model(dev, L);
+  for (ParkedModel& p : L.parked) lazy_ctx_destroy(p.ctx);
+  L.parked.clear();
   if (L.pin_buf) crabml_hip_buf_release(L.pin_buf);
   delete dev->lz;
   dev->lz = nullptr;
@@ -775,7 +865,7 @@ void lazy_destroy(crabml_hip_device* dev) {
 
 extern "C" int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* out, size_t cap) {
   if (!dev || !out) return CRABML_HIP_BAD_INPUT;
-  uint64_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (dev->lz) {
     const crabml_hip::LazyStats& s = dev->lz->stats;
     v[0] = s.recorded;
@@ -788,7 +878,9 @@ extern "C" int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* o
     v[7] = s.deferred_bound;
     v[8] = s.wait_ns;
     v[9] = s.pinned_exports;
+    v[10] = s.reactivated;
+    v[11] = s.reaped;
   }
-  for (size_t i = 0; i < cap && i < 10; i++) out[i] = v[i];
+  for (size_t i = 0; i < cap && i < 12; i++) out[i] = v[i];
   return 0;
 }

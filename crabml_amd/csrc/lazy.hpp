@@ -17,7 +17,17 @@
 //     the recorded `concatenate` ops name; the recorded ops stay in the queue until the token is complete.  Then the token is
 //     COMMITTED (its ops are dropped; outputs the host still holds are bound: the logits were written in place, the final
 //     normalized row is produced on demand).  An op that deviates from the template before that ABORTS the shadow: the queue is
-//     simply replayed op by op at the next flush, which also overwrites the KV rows.  So the host sees per-op semantics always.
+//     simply replayed op by op at the next flush, which also overwrites the KV rows.  So the host sees per-op SEMANTICS always --
+//     and, on a strict-order device, per-op BITS always.  On the fast device a committed token carries the fused step's
+//     re-associated sums and a replayed one the per-op kernels': both inside FAST_TOL of the reference, not identical to each other
+//     (a token's last bits depend on whether the host looked in the middle of it; include/crabml_hip.h says the same).
+//   * The whole-step launch at the `go` op trusts layer 0: token, position and the FIRST layer's cache handles are verified when
+//     the graph goes out; the deeper layers' concatenate ops are only compared afterwards.  A host that swapped a deeper layer's
+//     cache handle while keeping layer 0's makes the token deviate there -- the shadow is dropped and the queue replayed as always
+//     -- but the graph has by then written row `pos` of the LEARNED context's caches for those layers (buffers the context
+//     retains: never a use-after-free, and a row at or past their live length).
+//   * Contexts: the one being served plus up to two parked ones (runners taking turns on one device keep theirs); a context whose
+//     model or caches the host has released is destroyed at the next flush, every idle one when a device allocation fails.
 #pragma once
 #include <unordered_map>
 
@@ -108,7 +118,20 @@ struct LazyStats {  // crabml_hip_debug_lazy_stats
   uint64_t deferred_bound = 0; // final-norm rows produced on demand for a handle the host kept
   uint64_t wait_ns = 0;        // host time blocked in export / sync (the GPU still working: the host was ahead)
   uint64_t pinned_exports = 0; // exports served from the logits copy that was requested when the token committed
+  uint64_t reactivated = 0;    // parked decode contexts taken back into service (a host whose runners take turns on one device)
+  uint64_t reaped = 0;         // decode contexts dropped because the host released the model or the caches they serve
 };
+
+// a decode context that is not the one being served: the host switched to another runner / model on this device.  Kept (a small
+// LRU) so that runners taking turns do not rebuild their contexts -- allocations and a graph capture -- at every switch.
+struct ParkedModel {
+  crabml_hip_llama* ctx = nullptr;
+  LazyModel model;
+  std::vector<TmplOp> tmpl;
+  std::vector<int> mentions;
+  int slot_xnorm = -1, slot_xfinal = -1, slot_logits = -1;
+};
+constexpr size_t LAZY_PARKED_MAX = 2;
 
 struct LazyState {
   std::vector<LazyOp> q;
@@ -118,7 +141,8 @@ struct LazyState {
   std::vector<TmplOp> tmpl;
   std::vector<int> mentions;  // per slot: how often the token's ops name it (= references the queue holds on it)
   int slot_xnorm = -1, slot_xfinal = -1, slot_logits = -1;
-  const crabml_hip_buf* unfusable = nullptr;  // wq[0] of a model the decode context refused
+  std::vector<ParkedModel> parked;  // least recently used first
+  uint64_t unfusable_uid = 0;  // wq[0] (its uid: addresses are re-used) of a model the decode context refused
   // the token being shadowed
   bool tracking = false;
   size_t next = 0;  // template index of the next expected op
@@ -158,6 +182,9 @@ int lazy_record(crabml_hip_device* dev, const LazyOp& op);  // retains the opera
 int lazy_exec(crabml_hip_device* dev, LazyOp& op);          // the launches of one op, immediately (the eager path uses it too)
 int lazy_resolve(crabml_hip_device* dev);                   // binds deferred handles that are still alive
 void lazy_destroy(crabml_hip_device* dev);
+// drops every decode context nothing is being served from right now (parked ones; the active one between tokens): called when a
+// device allocation fails, before the retry.  Returns the number of contexts dropped.
+int lazy_release_contexts(crabml_hip_device* dev);
 inline void lazy_use(crabml_hip_device* dev, const crabml_hip_buf* b) {
   if (b && b->deferred) (void)lazy_resolve(dev);
 }
@@ -173,6 +200,9 @@ int lazy_fault_check(crabml_hip_device* dev);
 // ---- fused.hip: the decode context as the matcher drives it
 int lazy_ctx_create(crabml_hip_device* dev, const LazyModel& m, crabml_hip_llama** out);
 void lazy_ctx_destroy(crabml_hip_llama* c);
+// the context is the only remaining owner of the weights or of the KV caches it was built over (the host dropped its model or its
+// runner): nothing will ever be served from it again, and it pins their device memory
+bool lazy_ctx_orphaned(const crabml_hip_llama* c);
 int lazy_ctx_begin(crabml_hip_llama* c, size_t token, size_t pos);            // token id / position of the step -> device state
 int lazy_ctx_segment(crabml_hip_llama* c, int seg);                           // enqueue one segment
 bool lazy_ctx_has_graph(const crabml_hip_llama* c);

@@ -132,6 +132,19 @@ int pool_alloc(crabml_hip_device* dev, size_t bytes, void** out, size_t* cap) {
       }
     }
     e = hipMalloc(&p, cls);
+    if (e != hipSuccess && lazy_release_contexts(dev) > 0) {
+      // ... and the decode contexts nothing is being served from (a parked runner's, the last model's between tokens): they retain
+      // their weights and private buffers; the queue rebuilds what the host still uses
+      std::lock_guard<std::mutex> g(dev->mu);
+      for (auto& kv : dev->pool) {
+        for (void* q : kv.second) {
+          (void)hipFree(q);
+          dev->bytes_reserved -= kv.first;
+        }
+        kv.second.clear();
+      }
+      e = hipMalloc(&p, cls);
+    }
     if (e != hipSuccess) return hip_fail(dev, e, "hipMalloc", __FILE__, __LINE__);
   }
   {
@@ -282,6 +295,7 @@ int crabml_hip_device_create(const crabml_hip_device_options_t* opts, crabml_hip
 int crabml_hip_device_destroy(crabml_hip_device_t* dev) {
   if (!dev) return 0;
   if (!dev->dry) (void)hipSetDevice(dev->ordinal);
+  dev->destroying = true;  // (the flush runs what is queued and learns nothing)
   (void)lazy_flush(dev);
   if (!dev->dry) (void)hipStreamSynchronize(dev->stream);
   lazy_destroy(dev);  // the decode context the queue built, its retained buffers

@@ -22,7 +22,9 @@ extern "C" {
 /* counters of the recorded-op queue (crabml_amd/csrc/lazy.hpp, LazyStats): out[0..7] = ops recorded, ops run one launch at a time,
  * tokens served by the fused step, recorded ops those tokens replaced, fused segments enqueued, shadow tokens aborted, decode
  * contexts built, final-norm rows bound on demand, [8] nanoseconds the host spent blocked in export, [9] exports served from
- * the pinned logits copy requested at commit */
+ * the pinned logits copy requested at commit, [10] parked decode contexts taken back into service (runners taking turns on one
+ * device: up to two contexts wait beside the one being served), [11] contexts dropped because the host had released the model or
+ * the caches they served (checked after every flush; also dropped: every idle context when a device allocation fails) */
 int crabml_hip_debug_lazy_stats(crabml_hip_device_t* dev, uint64_t* out, size_t cap);
 
 /* the host NUMA node the device is attached to (sysfs numa_node of its PCI function), -1 if unknown: bench.py runs its host

@@ -12,7 +12,7 @@ import pytest
 from crabml_amd import synth
 from oracle import oracle as o
 from tests.helpers import FAST_TOL, to_oracle
-from tests.test_lazy_queue import F16, F32, caches, forward_py, ops_per_token
+from tests.test_lazy_queue import F16, F32, caches, forward_py, forward_rs, ops_per_token
 
 pytestmark = pytest.mark.gpu
 
@@ -207,3 +207,39 @@ def test_two_runners_taking_turns_on_one_device(ca):
         assert np.array_equal(u32(ra.forward([t], 6 + j)), u32(orr.forward([t], 6 + j))), f"alone, step {j}"
     st1 = lazy.lazy_stats()
     assert st1["fused_tokens"] - st0["fused_tokens"] >= len(extra) - 1, (st0, st1)
+    # each runner's context was built once and parked while the other was being served (round 6)
+    assert st1["learned"] == 2 and st1["reactivated"] >= 10, st1
+
+
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q4_K"])
+@pytest.mark.parametrize("kv_f16", [True, False])
+def test_rust_lifetimes_same_fused_tokens_same_bits(ca, fmt, kv_f16):
+    """The runner's call sequence with every handle released where rustc would release it (tests/test_lazy_queue.forward_rs: moves
+    into consuming calls, statement temporaries, block scopes, caches through Option::take / replace -- llama2.rs:527-603): the
+    matcher has only ever seen the C++ mirror's lifetimes.  Strict device: every token served by the fused step, logits bit-identical
+    to the oracle and cache bytes to the per-op launches; a released runner's context is reaped and the next one learned afresh."""
+    model = synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=29)
+    odev = o.OracleDevice(thread_num=4, use_avx2=False)
+    oconf, ow = to_oracle(model, odev)
+    orr = o.OracleLlamaRunner(oconf, ow, odev, 32, kv_f16)
+    ref = [orr.forward([t], i).copy() for i, t in enumerate(TOKS)]
+    out = {}
+    for mode in ("lazy", "per-op"):
+        dev = ca.HipTensorDevice(0, False, 0, True) if mode == "lazy" else ca.HipTensorDevice(0, False, 0, True, "per-op")
+        conf, w = synth.to_hip(model, dev)
+        kc, vc = caches(conf, dev, 32, kv_f16)
+        for i, t in enumerate(TOKS):
+            lg = forward_rs(conf, w, dev, kc, vc, t, i, eps=model.shape.rms_eps)
+            assert np.array_equal(u32(lg), u32(ref[i])), f"{mode}, step {i}"
+        out[mode] = ([kv_bytes(k) for k in kc], [kv_bytes(v) for v in vc], dev.lazy_stats())
+        if mode == "lazy":
+            del kc, vc  # the "runner" goes: its context is the caches' only owner and is dropped at the next flush
+            kc2, vc2 = caches(conf, dev, 32, kv_f16)
+            for i, t in enumerate(TOKS[:3]):
+                assert np.array_equal(u32(forward_rs(conf, w, dev, kc2, vc2, t, i, eps=model.shape.rms_eps)), u32(ref[i])), f"second cache set, step {i}"
+            st2 = dev.lazy_stats()
+            assert st2["reaped"] == 1 and st2["learned"] == 2 and st2["fused_tokens"] == len(TOKS) + 3, st2
+    st = out["lazy"][2]
+    assert st["fused_tokens"] == len(TOKS) and st["replayed"] == 0 and st["aborts"] == 0, st
+    for a, b in zip(out["lazy"][0] + out["lazy"][1], out["per-op"][0] + out["per-op"][1]):
+        assert np.array_equal(a, b)

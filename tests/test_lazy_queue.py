@@ -90,10 +90,10 @@ def test_a_second_runner_on_the_same_weights_gets_its_own_context():
     # and is then the token the new context is learned from -- and served by
     assert st["aborts"] == 1 and st["fused_tokens"] == 6 and st["replayed"] == 0
     assert st["recorded"] == 6 * n
-    # ... and going back to r1 costs another context
+    # ... and going back to r1 takes its parked context back into service (round 6; before, every switch built a new one)
     r1.forward([9], 3)
     st = dev.lazy_stats()
-    assert st["learned"] == 3 and st["fused_tokens"] == 7 and st["replayed"] == 0
+    assert st["learned"] == 2 and st["reactivated"] == 1 and st["fused_tokens"] == 7 and st["replayed"] == 0
 
 
 def test_named_tensor_snapshots_force_the_per_op_path():
@@ -158,6 +158,72 @@ def forward_py(conf, w, dev, kc, vc, tok, pos, seq, eps=1e-5, ffn_eps=1e-5, extr
     if keep == "final":
         kept += [x, xf]
     return logits, kept
+
+
+def forward_rs(conf, w, dev, kc, vc, tok, pos, eps=1e-5):
+    """The same call sequence with every handle released WHERE RUST WOULD release it (the C++ mirror and forward_py keep a loop body's
+    locals until its end): values are moved into the consuming call (`q.reshape(..)` leaves no `q` behind), temporaries of a method
+    chain die at the end of their statement, a block's locals at its closing brace, and the caches travel through
+    `Option::take()` / `replace()` (llama2.rs:571-597: `self.key_cache[l]` is None while the scores are computed).  The recorded ops
+    hold their own references, so none of this may change what the matcher sees -- same fused tokens, same bits."""
+    dim, hd = conf.embedding_dim, conf.head_size()
+    nh, nkv = conf.n_heads, conf.n_kv_heads
+    x = ca.HipTensor.alloc([1, dim], F32, dev)
+    x.copy_rows_from(w.token_embed, [tok])
+    for l in range(conf.n_layers):
+        x_attn_orig = x.dup()                                  # llama2.rs:229
+        x = x.rms_norm_inplace(eps)                            # (in-place methods consume self and return it)
+        x = x.mul_inplace(w.rms_att_weight[l])
+        q = w.wq[l].matmul_vec(x)                              # :244-246
+        k = w.wk[l].matmul_vec(x)
+        v = w.wv[l].matmul_vec(x)
+        q = q.reshape([1, nh, hd]).rope_inplace(ca.RopeMode.Llama, pos, hd)   # :251-256 (reshape consumes q: no handle stays behind)
+        k = k.reshape([1, nkv, hd]).rope_inplace(ca.RopeMode.Llama, pos, hd)
+        # ---- forward_multi_query_attention(q, k, v, ..) -- q, k, v MOVED in ----
+        kv_k = k.reshape([1, nkv, hd]).transpose([1, 0, 2])    # :542-547 (`k.reshape` takes &self here: the parameter stays alive)
+        kv_v = v.reshape([1, nkv, hd]).transpose([1, 0, 2])
+        kc[l].concatenate(kv_k, 1)
+        vc[l].concatenate(kv_v, 1)
+        del kv_k, kv_v                                         # the block's closing brace (:555)
+        q = q.reshape([1, nh, hd]).transpose([1, 0, 2]).contiguous().scale_inplace(1.0 / math.sqrt(np.float32(hd)))  # :561-565
+        k_cache, kc[l] = kc[l], None                           # self.key_cache[l].take()  (:571)
+        k_orig = k_cache.strider()
+        k_cache = k_cache.transpose([0, 2, 1])                 # consumes the taken cache
+        attn = q.batch_matmul(k_cache)
+        attn = attn.softmax_inplace(2)
+        kc[l] = k_cache.with_strider(k_orig)                   # replace(..)  (:578)
+        del k_cache
+        v_cache, vc[l] = vc[l], None                           # (:584)
+        v_orig = v_cache.strider()
+        x_with_attn = attn.batch_matmul(v_cache)
+        x_with_attn = x_with_attn.reshape([1, dim])
+        vc[l] = v_cache.with_strider(v_orig)                   # (:597)
+        del v_cache
+        x = w.wo[l].matmul_vec(x_with_attn)                    # the old x (the normalized row) is dropped by the assignment
+        del q, attn, x_with_attn                               # the `let x = { .. }` block ends (:601)
+        del k, v                                               # the function returns: its by-value parameters die
+        x = x.add_inplace(x_attn_orig)                         # :266
+        # ---- forward_ffn(x, ..): x MOVED in ----
+        x_orig_ffn = x.dup()
+        x = x.rms_norm_inplace(1e-5)
+        x = x.mul_inplace(w.rms_ffn_weight[l])
+        h1 = w.ffn_gate_weight[l].matmul_vec(x)
+        h2 = w.ffn_up_weight[l].matmul_vec(x)
+        h1 = h1.silu_inplace()
+        h1 = h1.mul_inplace(h2)
+        x = w.ffn_down_weight[l].matmul_vec(h1)                # (drops the normalized row)
+        x = x.add_inplace(x_orig_ffn)
+        del x_orig_ffn, h1, h2                                 # forward_ffn returns
+        del x_attn_orig                                        # the loop body's scope ends
+    x = x.rms_norm_inplace(eps)
+    x = x.mul_inplace(w.rms_final_weight)
+    x_final = ca.HipTensor.alloc([dim], F32, dev)
+    x_final.copy_rows_from(x, [0])
+    ow = w.output_weight if w.output_weight is not None else w.token_embed
+    logits = ow.matmul_vec(x_final)
+    out = np.array(logits.export())                            # forward() ends: x, x_final, logits die after the export
+    del x, x_final, logits
+    return out
 
 
 def caches(conf, dev, seq, f16=True):
@@ -302,3 +368,64 @@ def test_the_runners_greedy_sampler_keeps_the_last_maximum():
             elif case == 5:
                 p = np.round(p * 2).astype(np.float32)  # many ties
             assert ca.sample_argmax(p) == ref(p), (n, case)
+
+
+def test_rust_lifetimes_do_not_change_what_the_matcher_sees():
+    """The op stream with every handle released where rustc would release it (forward_rs): every token is still served by the fused
+    step -- the queue's own references keep operands alive, caches moved out of and back into their Option are the same handles."""
+    dev = dry()
+    s, conf, w = tiny(dev)
+    n = ops_per_token(s.n_layers)
+    kc, vc = caches(conf, dev, 32)
+    for i in range(5):
+        forward_rs(conf, w, dev, kc, vc, i + 1, i, eps=s.rms_eps)
+        st = dev.lazy_stats()
+        assert st["fused_tokens"] == i + 1 and st["replayed"] == 0 and st["aborts"] == 0, st
+        assert st["recorded"] == n * (i + 1) and st["deferred_bound"] == 0
+    # ... and it is the SAME stream as the C++ mirror's: a runner's context (other caches) is learned once, not per token
+    assert dev.lazy_stats()["learned"] == 1
+
+
+def test_runners_taking_turns_keep_their_contexts():
+    """Two runners on one device advancing in turns: each runner's decode context is built once and parked while the other is served
+    (round-5 review: exactly one context was kept and every switch rebuilt it -- allocations and a graph capture inside the flush)."""
+    dev = dry()
+    s, conf, w = tiny(dev)
+    r1, r2 = ca.Llama2Runner(conf, w, dev, 32, True), ca.Llama2Runner(conf, w, dev, 32, True)
+    for i in range(4):
+        r1.forward([i + 1], i)
+        r2.forward([i + 2], i)
+    st = dev.lazy_stats()
+    assert st["learned"] == 2, st                       # one context per runner, ever
+    assert st["reactivated"] == 6, st                   # every later switch takes the parked one back
+    assert st["fused_tokens"] == 8 and st["replayed"] == 0, st
+    # a third and a fourth runner push the oldest context out (at most two wait beside the one being served) ...
+    r3, r4 = ca.Llama2Runner(conf, w, dev, 32, True), ca.Llama2Runner(conf, w, dev, 32, True)
+    r3.forward([1], 0)
+    r4.forward([1], 0)
+    assert dev.lazy_stats()["learned"] == 4
+    r1.forward([9], 4)  # ... r1's was the oldest: built again
+    st = dev.lazy_stats()
+    assert st["learned"] == 5 and st["replayed"] == 0, st
+
+
+def test_a_released_runner_or_model_releases_its_decode_context():
+    """The decode context retains the weights and the runner's caches.  A host that drops its runner (or the whole model) gets that
+    device memory back at the next flush: a context that is the only remaining owner of its caches or weights is destroyed."""
+    dev = dry()
+    s, conf, w = tiny(dev)
+    r = ca.Llama2Runner(conf, w, dev, 32, True)
+    for i in range(3):
+        r.forward([i + 1], i)
+    assert dev.lazy_stats()["reaped"] == 0
+    del r                                              # the runner and its caches go; the weights stay
+    a = ca.HipTensor.new(np.ones(8, np.float32), [8], dev)
+    a.dup().scale_inplace(2.0).export()                # any flush
+    st = dev.lazy_stats()
+    assert st["reaped"] == 1, st  # (its private buffers and the cache blocks are back in the device's pool)
+    # the weights are still usable, and a new runner is learned and served as before
+    r = ca.Llama2Runner(conf, w, dev, 32, True)
+    r.forward([1], 0)
+    r.forward([2], 1)
+    st = dev.lazy_stats()
+    assert st["learned"] == 2 and st["fused_tokens"] == 5 and st["replayed"] == 2, st  # (replayed: the two ops outside any token)
