@@ -307,6 +307,23 @@ def parity_check(ca, synth, model, conf, weights, dev, ordinal, n_pos=4):
             row[name + "_max_rel_logit_err"] = float("%.3g" % max(errs))
             row[name + "_tokens_equal"] = equal
             row[name + "_over_reference_spread"] = round(max(errs) / max(spread), 3) if max(spread) > 0 else None
+        # `value` is timed through the reference's API: the UNCHANGED runner, its Tensor calls recorded and served by the fused step.
+        # Its logits on these tokens must be the fused entry point's, bit for bit (same launches, same buffers' worth of arithmetic),
+        # and every token must have been served by the fused step -- asserted in tests/, recorded here on the benchmarked weights
+        try:
+            f = ca.HipLlamaRunner(hconf, hw, dev, 64, True)
+            r = ca.Llama2Runner(hconf, hw, dev, 64, True)
+            st0 = dev.lazy_stats()["fused_tokens"]
+            same = []
+            for i, t in enumerate(toks):
+                a_ = np.asarray(f.forward(t, i)).copy()
+                b_ = np.asarray(r.forward([t], i)).copy()
+                same.append(bool(np.array_equal(a_.view(np.uint32), b_.view(np.uint32))))
+            row["reference_api_equals_fused_entry_point_bitwise"] = same
+            row["reference_api_tokens_served_by_fused_step"] = int(dev.lazy_stats()["fused_tokens"] - st0)
+            del f, r
+        except Exception as e:  # pragma: no cover
+            row["reference_api_check_error"] = repr(e)
         return row, ref
 
     bench_row, ref = one_model(model, conf, weights, "the benchmark model (synthetic Q4_0 blocks, every block scale d > 0)")
@@ -318,16 +335,24 @@ def parity_check(ca, synth, model, conf, weights, dev, ordinal, n_pos=4):
                         "this run; *_over_reference_spread = the HIP fast path's error divided by it (re-association + a truncating rhs quantizer: "
                         "one ulp moves a block's largest element between the levels 126 and 127)"}
     if model.wtype == synth.Q4_0:
-        try:  # the zero-mean twin: block scales of either sign (the hard case; the benchmark's d > 0 blocks carry a common-mode component)
+        # the zero-mean twin: block scales of either sign (the hard case; the benchmark's d > 0 blocks carry a common-mode component).
+        # The flip is an involution; it is undone only if it completed (a half-flipped model must not reach the timed legs: then
+        # the run stops here)
+        flipped = False
+        try:
             synth.flip_scale_signs(model, 5)
+            flipped = True
             zconf, zw = synth.to_hip(model, dev)
             zrow, _ = one_model(model, zconf, zw, "the same blocks with d of either sign (zero-mean weights)")
             out["models"].append(zrow)
             del zw
         except Exception as e:  # pragma: no cover
             out["zero_mean_error"] = repr(e)
+            if not flipped:
+                raise RuntimeError("parity_check: the sign flip of the benchmark model failed part-way; its weights are not the benchmark's any more") from e
         finally:
-            synth.flip_scale_signs(model, 5)  # (an involution: the benchmark model is back)
+            if flipped:
+                synth.flip_scale_signs(model, 5)  # (the benchmark model is back)
     try:
         sdev = ca.HipTensorDevice(ordinal, False, 0, True)
         sconf, sw = synth.to_hip(model, sdev)
@@ -739,6 +764,12 @@ def main():
                 "kernel_code_hash": kernel_code_hash(),
                 "kernel": STAGES.get(dom["stage"], "?"),
                 "avg_launch_us": round(d_us, 3),
+                # the same fraction from the COMMITTED rocprofv3 --kernel-trace of this command (the tracer adds ~0.3 us per launch):
+                # quoted only while the trace was taken on the kernel code this run executes
+                "frac_rocprof": (round(d_bytes / (pmc["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                 if pmc_ok and pmc.get("rocprof_avg_launch_us") else None),
+                "rocprof_avg_launch_us": pmc.get("rocprof_avg_launch_us") if pmc_ok else None,
+                "rocprof_source": pmc.get("rocprof_source") if pmc_ok else None,
                 "algo_bytes_per_launch": round(d_bytes, 1),
                 "launches_per_token": dom["launches"] / n_prof,
                 "all_gemv_stages": {

@@ -493,6 +493,13 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
            : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
                                                              : 1;
   };
+  // q / k / v rows of exactly 128 units: both 64-unit steps requested up front (5.29 -> 4.66 us per launch on the 8B shape,
+  // profiles/r06_small_stage_ab.md; bit-identical).  A/B hook: CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_QKV_UPFRONT=0 keeps the two rounds.
+  static const int qkv_upfront = [] {
+    const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+    const char* e = getenv("CRABML_HIP_QKV_UPFRONT");
+    return h && h[0] == '1' && e && e[0] == '0' ? 0 : 1;
+  }();
   // the hop-free norm between wo and gate/up of a layer: decided once, for the producer and the consumer alike
   const bool defer_wo = c->defer_norm && !Q81;
   // ... and between ffn_down of layer l and q/k/v of layer l + 1 (the last ffn_down feeds the classifier launch: exact planes)
@@ -631,10 +638,10 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     else if (defer_down && l > 0) {
       if constexpr (!Q81)
         launch_k(st, R, k_qkv<FMT, true>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-                 planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq);
+                 planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq, qkv_upfront);
     } else
       launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq);
+               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq, 0);
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;
@@ -913,7 +920,7 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
                planes_k(c->wq[l]), planes_k(c->wk[l]), planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e);
     else
       launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
-               planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]), RmsTail{nullptr, 0, 0.f, 0.f});
+               planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]), RmsTail{nullptr, 0, 0.f, 0.f}, 0);
     CH_TRY(P1());
     // Q8_K producers: the (short-context) attention kernel assembles the planes of wo's rhs itself; wo copies them
     const bool aq8 = qout && (g.flags & CRABML_HIP_LLAMA_Q8K_ATTN_PRODUCER) && c->attn_variant == 0 && c->attn_s_rows > 0;

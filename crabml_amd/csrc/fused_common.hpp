@@ -392,7 +392,7 @@ struct Planes6 {
 // DEFER: the rhs planes come from a hop-free ffn_down launch -- the row dots are multiplied by 1 / rms (RmsTail, gemv_core.hpp)
 template <int FMT, bool DEFER = false>
 __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e,
-                                             Planes6 wv6, RmsTail rt) {
+                                             Planes6 wv6, RmsTail rt, int upfront = 0) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg();
   const int row0 = wave * 2;
@@ -427,7 +427,10 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
   }
   float inv_rms = 1.0f;
   if constexpr (DEFER && FMT != CRABML_HIP_Q4_K) {
-    inv_rms = rows_partial_rms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc, rt, rq);
+    if (upfront && nb * BlockFmt<FMT>::UNITS == 128)
+      inv_rms = rows_partial_rms_128<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc, rt, rq);
+    else
+      inv_rms = rows_partial_rms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc, rt, rq);
   } else {
     if (!done) rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
   }

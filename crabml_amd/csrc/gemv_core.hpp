@@ -243,6 +243,33 @@ __device__ __forceinline__ float rows_partial_rms(const i32x4* __restrict__ wq, 
   return inv_rms;
 }
 
+// The same for rows of exactly 128 units (k = 4096 in Q4_0: q / k / v of the 8B shape) with BOTH 64-unit steps requested up front --
+// one round of requests per wave instead of two dependent ones.  Same terms, same per-lane order (step 0 then step 1): bit-identical
+// to rows_partial_rms (k_qkv's default for such rows; profiles/r06_small_stage_ab.md).
+template <int FMT, int R, class ACT>
+__device__ __forceinline__ float rows_partial_rms_128(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd, const ACT& act,
+                                                      int row0, int m, int nb, int lane, float acc[R], const RmsTail& rt, RmsReq rq) {
+  using F = BlockFmt<FMT>;
+  typename F::Blk b0[R], b1[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int row = row0 + r < m ? row0 + r : m - 1;
+    b0[r] = F::load(wq, wd, (size_t)row, nb, lane);
+    b1[r] = F::load(wq, wd, (size_t)row, nb, lane + 64);
+  }
+  const XUnit x0 = F::loadx(act, lane), x1 = F::loadx(act, lane + 64);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" : "+v"(rq.v0), "+v"(rq.v1));
+  const float inv_rms = rms_finish(rt, rq, lane);
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    acc[r] = 0.f;
+    acc[r] += F::term(b0[r], x0);
+    acc[r] += F::term(b1[r], x1);
+  }
+  return inv_rms;
+}
+
 // ---- strict order at streaming speed: the block terms of R rows into a term table, then one lane per row adds them in block order ----
 // (CRABML_HIP_FLAG_STRICT_ORDER.)  The reference's scalar dot of these formats is `sumf = 0; for block: sumf += term(block)` with one
 // f32 term per block (buf_q4_0.rs:240-253, buf_q8_0.rs:275-286, buf_q4_1.rs:266-280): the terms are evaluated exactly as the fast

@@ -68,8 +68,11 @@ GEMV_REL = 2e-5  # f32 re-association bound factor: |gpu - oracle| <= GEMV_REL *
 # flipped quant moves the logits by < 5e-4 (tests/test_hip_headline.py).
 # Round 4: every bound is at most 2 x the largest value observed on MI355X for that format (tests/golden/
 # fast_path_errors_observed.json; the K-quant max is 2 x the largest single-flip step).
-FAST_TOL = {"Q4_0": (8e-3, 1.5e-2), "Q8_0": (5.5e-2, 7.5e-2), "Q4_1": (3e-2, 4e-2), "Q4_K": (5e-7, 7e-2), "Q5_K": (5e-7, 7e-2), "Q6_K": (5e-7, 7e-2),
-            "Q8_K": (5e-7, 7e-2), "F32": (2.5e-4, 5.5e-4), "F16": (8.5e-4, 1.2e-3),
+# Round 6: the K-quant max admits ONE flipped quant of the size seen on the 2-layer test model (largest: 3.75e-2; bound 1.2 x that,
+# it was 2 x) -- the flip-COUNT gate below is what keeps a change that corrupts many steps from hiding under it; Q8_0's bounds are
+# per model where the models differ (FAST_TOL_MODEL: 2 x observed on each).
+FAST_TOL = {"Q4_0": (8e-3, 1.5e-2), "Q8_0": (6.2e-2, 7.5e-2), "Q4_1": (3e-2, 4e-2), "Q4_K": (5e-7, 4.5e-2), "Q5_K": (5e-7, 4.5e-2), "Q6_K": (5e-7, 4.5e-2),
+            "Q8_K": (5e-7, 4.5e-2), "F32": (2.5e-4, 5.5e-4), "F16": (8.5e-4, 1.2e-3),
             # the scalar-only formats (round 4), 2 x observed: Q5_0 shares the truncating Q8_0 rhs quantizer and shows Q8_0-sized flips
             # on the tiny-gqa model (median 1.2e-2 / 1.9e-2, max 1.5e-2 / 2.5e-2 on the trait / graph path; Q8_0: 1.5e-2 / 1.8e-2) while
             # its single GEMVs sit inside the re-association bound (tests/test_hip_gemv.py) and the strict step is bit-exact;
@@ -78,7 +81,10 @@ FAST_TOL = {"Q4_0": (8e-3, 1.5e-2), "Q8_0": (5.5e-2, 7.5e-2), "Q4_1": (3e-2, 4e-
             # rounds 1-3 the 8B-depth model overflowed the f16 KV cache).  Zero-mean weights lose the common-mode component that made
             # the relative error look small (4e-4): observed now 1.2-1.5e-2 median, 1.5-1.8e-2 max -- the size of the reference's OWN
             # scalar-vs-AVX2 spread on zero-mean models (profiles/r04_reference_order_sensitivity.log)
-            "Q5_0": (4e-2, 5e-2), "Q5_1": (3e-2, 4e-2), "Q2_K": (5e-7, 7e-2), "Q3_K": (5e-7, 7e-2)}
+            "Q5_0": (4e-2, 5e-2), "Q5_1": (3e-2, 4e-2), "Q2_K": (5e-7, 4.5e-2), "Q3_K": (5e-7, 4.5e-2)}
+# per (model, format) where a model shows less than the format's worst: 2 x observed on MI355X (gpurun_out/fast_path_errors.json of
+# round 6: tiny-gqa Q8_0 median 1.8e-2 / max 2.4e-2 over the trait and fused paths; the 15m model is the format row: 3.1e-2 / 3.7e-2)
+FAST_TOL_MODEL = {("tiny-gqa", "Q8_0"): (3.6e-2, 4.7e-2)}
 # The fast step's long-context attention (k_attn_flash: f32 exp / f32 accumulation instead of the reference's f16 exp table, f16
 # probabilities, f16 products and serial f16 sum) against the oracle, positions 224 .. 4095: (median, max) bounds, 2 x observed.
 # With a round-to-nearest rhs quantizer (K-quants) the 1e-4-sized attention deviation flips a quant of wo's rhs at most steps:
@@ -109,6 +115,9 @@ def check_fast(key, fmt, err):
     except OSError:
         pass
     med, mx = FAST_TOL[fmt]
+    parts = key.split("/")
+    if len(parts) > 1 and (parts[1], fmt) in FAST_TOL_MODEL:
+        med, mx = FAST_TOL_MODEL[(parts[1], fmt)]
     assert np.median(err) <= med and np.max(err) <= mx, (key, err)
     if fmt in ROUND_TO_NEAREST:
         # a second gate for the formats whose rhs quantizer rounds to nearest: the max bound has to admit a step with ONE flipped

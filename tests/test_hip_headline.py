@@ -147,8 +147,10 @@ def test_zero_mean_weights_at_the_8b_shape_strict_exact_and_fast_inside_the_refe
     logit errors look small (5e-4); here the reference's OWN two builds -- scalar and AVX2 order of the block dots -- are 7-10 % of
     max|logit| apart after 32 layers (one ulp moves a block's largest element between the levels 126 and 127 of the truncating
     quantizer, buf_q8_0.rs:119-124).  So: the strict-order device must still be BIT-IDENTICAL (fused entry point and the unchanged
-    runner through the queue), and the fast step -- hop-free norm and all -- must sit inside k = 2 x the reference's own
-    scalar-vs-AVX2 distance, computed here, on the same model and tokens (not a constant)."""
+    runner through the queue), and the fast step -- hop-free norm and all -- must sit inside k = 1.5 x the reference's own
+    scalar-vs-AVX2 distance, computed here, on the same model and tokens (not a constant; round 5 allowed 2 x, observed: 1.28 x for
+    Q4_0, 1.02 x for Q8_0 -- a change that moves it fails loudly).  Greedy-token agreement is recorded three ways -- the fast step
+    and the reference's AVX2 build, each against the scalar oracle, and against each other -- in gpurun_out/headline_parity.json."""
     model = synth.build_model(synth.SHAPES["llama3-8b"], synth.TYPE_BY_NAME[fmt], seed=8)
     if fmt == "Q4_0":
         synth.flip_scale_signs(model, 5)
@@ -177,9 +179,15 @@ def test_zero_mean_weights_at_the_8b_shape_strict_exact_and_fast_inside_the_refe
     res = {"reference_avx2_vs_scalar": spread}
     for name, flags in (("fast", 0), ("fast_exact_norm", EXACT_NORM)):
         f = ca.HipLlamaRunner(fconf, fw, fdev, SEQ, True, extra_flags=flags)
-        errs = [rel(f.forward(t, i), ref[i]) for i, t in enumerate(toks)]
+        lgs = [f.forward(t, i).copy() for i, t in enumerate(toks)]
+        errs = [rel(lg, ref[i]) for i, lg in enumerate(lgs)]
         res[name] = errs
+        am = lambda xs: [int(o.argmax_last(x)) for x in xs]  # noqa: E731
+        t_fast, t_ref, t_avx = am(lgs), am(ref), am(avx)
+        res[name + "_greedy_agreement"] = {"positions": len(toks), "fast_vs_scalar_oracle": sum(a == b for a, b in zip(t_fast, t_ref)),
+                                           "reference_avx2_vs_scalar_oracle": sum(a == b for a, b in zip(t_avx, t_ref)),
+                                           "fast_vs_reference_avx2": sum(a == b for a, b in zip(t_fast, t_avx))}
         del f
-        assert max(errs) <= 2.0 * max(spread), (fmt, name, errs, spread)
+        assert max(errs) <= 1.5 * max(spread), (fmt, name, errs, spread)
     _RESULTS[f"zero_mean/{fmt}"] = res
     _write_results()

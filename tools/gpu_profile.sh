@@ -17,7 +17,7 @@ python $REPO/tools/rocpd_summary.py "$DB" >> $OUT/kernel_trace_$TAG.md 2>> $OUT/
 head -22 $OUT/kernel_trace_$TAG.md
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -- python $REPO/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-parity-check --no-context --no-prefill --no-c3 --no-gemv-points --no-trait $* > /dev/null 2>> $OUT/prof_$TAG.err
 DB2=$(find $OUT/pmc_$TAG -name "*_results.db" | head -1)
-cd $REPO && python tools/pmc_traffic.py "$DB2" $OUT/${TAG}_pmc_fetch_size.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic_$TAG.json
+cd $REPO && python tools/pmc_traffic.py "$DB2" $OUT/${TAG}_pmc_fetch_size.md --trace="$DB" --trace-md=${TAG}_fused_path_kernel_trace.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic_$TAG.json
 # the reference's API: Llama2Runner<HipTensor> unchanged, one Tensor call after the other -- which kernels do its calls become?
 cd /tmp
 rm -rf $OUT/prof_trait_$TAG

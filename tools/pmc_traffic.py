@@ -23,7 +23,7 @@ ALGO_BYTES = 66191360   # 2 x 14336 x 4096 / 32 x 18 + 4 x 4096 + 4 x 2 x 14336 
 
 
 def main():
-    dbs = [p for a in sys.argv[1:] if a.endswith(".db") for p in glob.glob(a)]
+    dbs = [p for a in sys.argv[1:] if a.endswith(".db") and not a.startswith("--") for p in glob.glob(a)]
     md_out = next((a for a in sys.argv[1:] if a.endswith(".md")), None)
     if not dbs:
         sys.exit("no rocpd database given")
@@ -36,11 +36,28 @@ def main():
     if kib is None:
         sys.exit(f"{KERNEL} not found in the PMC table")
     hbm = int(round(kib * 1024 * 2))
+    # optional second database (--trace=...db): the rocprofv3 --kernel-trace of the same command -> the dominant kernel's average
+    # duration, quoted by bench.py as roofline.frac_rocprof beside its own event-timed fraction
+    trace = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--trace=")), None)
+    trace_md = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--trace-md=")), None)
+    avg_us = None
+    if trace:
+        import sqlite3
+
+        c = sqlite3.connect(trace)
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+        name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
+        d = [e - s0 for n, s0, e in c.execute(f"select {name_col}, start, end from kernels") if KERNEL + "<" in n or KERNEL + "(" in n]
+        if d:
+            avg_us = round(sum(d) / len(d) / 1e3, 3)
     # the tracked copy of the table: gpu_profile.sh writes gpurun_out/<tag>_pmc_fetch_size.md, which is committed as profiles/<same name>
     tracked = "profiles/" + os.path.basename(md_out) if md_out else os.path.basename(dbs[0])
     out = {"source": tracked + " (rocprofv3 --pmc FETCH_SIZE, separate pass; FETCH_SIZE KiB x 1024 x 2 gfx950 correction)",
            "dominant_kernel": KERNEL + "<Q4_0>", "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": ALGO_BYTES,
            "ratio": round(hbm / ALGO_BYTES, 4), "kernel_code_hash": bench.kernel_code_hash()}
+    if avg_us:
+        out["rocprof_avg_launch_us"] = avg_us
+        out["rocprof_source"] = ("profiles/" + os.path.basename(trace_md) if trace_md else os.path.basename(trace)) + " (rocprofv3 --kernel-trace --stats of the bench command)"
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     if md_out:
