@@ -241,5 +241,10 @@ def test_rust_lifetimes_same_fused_tokens_same_bits(ca, fmt, kv_f16):
             assert st2["reaped"] == 1 and st2["learned"] == 2 and st2["fused_tokens"] == len(TOKS) + 3, st2
     st = out["lazy"][2]
     assert st["fused_tokens"] == len(TOKS) and st["replayed"] == 0 and st["aborts"] == 0, st
+    # only the appended rows are defined (Tensor::alloc leaves f16 contents unspecified)
+    sh = model.shape
+    hd, es = sh.dim // sh.n_heads, (np.uint16 if kv_f16 else np.uint32)
     for a, b in zip(out["lazy"][0] + out["lazy"][1], out["per-op"][0] + out["per-op"][1]):
+        a = a.view(es).reshape(sh.n_kv_heads, 32, hd)[:, :len(TOKS)]
+        b = b.view(es).reshape(sh.n_kv_heads, 32, hd)[:, :len(TOKS)]
         assert np.array_equal(a, b)
