@@ -945,11 +945,6 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       const size_t lds = (size_t)dim + (size_t)(dim / 256) * 4 + (size_t)(dim / 16) * 2;
       const ActLayout alh = act_layout(QT, (size_t)hidden_l);
       const Q8KExchange hx{c->h8gran, c->state + 4, c->state + 5, n_segments(c), seg};
-      static const bool gu_il = [] {  // A/B hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_Q4K_GU_IL=0 / 1): gate and up rows advancing together
-        const char* h = getenv("CRABML_HIP_TEST_HOOKS");
-        const char* e = getenv("CRABML_HIP_Q4K_GU_IL");
-        return h && h[0] == '1' && e ? e[0] == '1' : false;
-      }();
       const size_t ldso = ((lds + 15) & ~(size_t)15) + (size_t)64 * (size_t)q4k_rec_stride(dim / 256) * sizeof(float);
       if (ordk && qout)
         launch_k(st, R, k_gateup_k_lds<true, true>, dim3(hidden_l / 32), dim3(1024), ldso, planes_k(c->gate[l]), planes_k(c->up[l]),
