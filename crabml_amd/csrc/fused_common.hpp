@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv
   } else {
     const int nt = (nb + 3) & ~3;
     float* T = ord_terms + (size_t)wv_i * 2 * nt;
-    rows_terms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, T, nt);
+    rows_terms<FMT, 2, typename ActOf<FMT>::type, true>(w.q, w.d, act, local, m, nb, lane, T, nt);
     __builtin_amdgcn_wave_barrier();
     if (lane < 2) s = ordered_sum(T + lane * nt, nb);
   }

@@ -275,11 +275,30 @@ __device__ __forceinline__ float rows_partial_rms_128(const i32x4* __restrict__ 
 // f32 term per block (buf_q4_0.rs:240-253, buf_q8_0.rs:275-286, buf_q4_1.rs:266-280): the terms are evaluated exactly as the fast
 // kernels do (same loads, same integers, the reference's expression per block), parked in LDS -- T[r * stride + block] -- and added by
 // ordered_sum.  Bit-identical to the one-thread-per-row loop (k_gemv_strict) and to the oracle.
-template <int FMT, int R, class ACT>
+template <int FMT, int R, class ACT, bool UPFRONT = false>
 __device__ __forceinline__ void rows_terms(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd, const ACT& act, int row0,
                                            int m, int nb, int lane, float* __restrict__ T, int stride) {
   using F = BlockFmt<FMT>;
   const int nu = nb * F::UNITS;
+  if (UPFRONT && nu == 128) {  // (uniform) rows of exactly two 64-unit steps: one round of requests (k_qkv_ord; as rows_partial_rms_128)
+    typename F::Blk b0[R], b1[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      b0[r] = F::load(wq, wd, (size_t)row, nb, lane);
+      b1[r] = F::load(wq, wd, (size_t)row, nb, lane + 64);
+    }
+    const XUnit x0 = F::loadx(act, lane), x1 = F::loadx(act, lane + 64);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float t0 = F::term(b0[r], x0), t1 = F::term(b1[r], x1);
+      if (F::UNITS == 1 || (lane & 1) == 0) {
+        T[r * stride + lane / F::UNITS] = t0;
+        T[r * stride + (lane + 64) / F::UNITS] = t1;
+      }
+    }
+    return;
+  }
   for (int u0 = 0; u0 < nu; u0 += 64) {
     const int u = u0 + lane;
     const bool live = u < nu;  // (Q8_0: nu is even, the two lanes of a block are live or dead together)

@@ -1,8 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-echo "== stage_times default"; timeout 300 python tools/stage_times.py --steps 32
-echo "== stage_times qkv two rounds"; CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_QKV_UPFRONT=0 timeout 300 python tools/stage_times.py --steps 32 | grep -E "qkv|sum"
-timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --no-context --no-prefill --no-gemv-points 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print({k:d.get(k) for k in ['value','value_strict','ms_per_step']}, d['fused_entry_point']['tokens_per_s'], d.get('c3_positions_0_127'))"
+for wt in Q4_K Q8_0 Q4_1; do
+timeout 900 python bench.py --wtype $wt --steps 20 --warmup 5 --no-cpu-baseline --no-context --no-prefill --no-gemv-points > gpurun_out/r06_bench_$wt.json 2>gpurun_out/r06_bench_$wt.err
+python - <<PY
+import json
+d=json.load(open('gpurun_out/r06_bench_$wt.json'))
+print('$wt', {k:d.get(k) for k in ['value','value_strict']}, d['fused_entry_point']['tokens_per_s'], d.get('c3_positions_0_127',{}).get('tokens_per_s'), d['roofline']['avg_launch_us'], d['roofline']['frac'])
+PY
+done
