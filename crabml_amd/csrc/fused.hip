@@ -181,6 +181,7 @@ struct crabml_hip_llama {
   float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr, *pf_qr = nullptr, *pf_attn = nullptr,
         *pf_tmp = nullptr, *pf_g = nullptr, *pf_u = nullptr;
   char *pf_act_dim = nullptr, *pf_act_hid = nullptr;
+  float* pf_split = nullptr;  // ... and the second k half's partial (rows, dim) tiles of a split wo / ffn_down GEMM
   void* pf_xh = nullptr;  // the fast pass's Q4_0 GEMMs: the current rhs rows as pre-scaled f16 (gemm_f16w.hip), cap x max(dim, hidden) halfs
   float* pf_scores = nullptr;          // long prompts: [PF_LONG_ROWS][n_heads][seq_len] f32 scores
   unsigned short* pf_p16 = nullptr;    //               and f16 probabilities, allocated on first use
@@ -1061,6 +1062,7 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   if (c->qt == CRABML_HIP_Q8_0 && !c->dev->strict_order) {  // (+ 4 KB of zeroed slack: the GEMM's look-ahead reads, gemm_f16w.hip)
     const size_t xb = cap * (dim > hidden ? dim : hidden) * 2 + 4096;
     CH_TRY(A(xb, &c->pf_xh));
+    CH_TRY(A(cap * dim * 4, (void**)&c->pf_split));
     CH_HIP(c->dev, hipMemsetAsync(c->pf_xh, 0, xb, c->dev->stream));
   }
   c->pf_cap = cap;
@@ -1203,7 +1205,13 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
         xh_of = act;
       }
       const size_t mm = (size_t)m;
-      if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out)) return 0;
+      int split = 1;
+      // (wo / ffn_down: few row tiles, a long k -- two workgroups per tile, the second half's partial tiles in pf_split, added here)
+      float* second = (out == c->pf_tmp && (mm * B) % 4 == 0) ? c->pf_split : nullptr;
+      if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out, second, &split)) {
+        if (split == 2) launch_add2_f32(st, out, second, mm * B);
+        return 0;
+      }
     }
     if (!strict) {
       return launch_gemv(dev, w, m, k, act, B, out, nullptr, !gemm_exact_hook);

@@ -59,6 +59,14 @@ void launch_q8_0_rows_to_f16(hipStream_t st, const void* planes, size_t row_stri
                                                                                                (unsigned short*)xh);
 }
 
+__global__ __launch_bounds__(256) void k_add2_f32(float* __restrict__ a, const float* __restrict__ b, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) ((f32x4*)a)[i] = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+}
+void launch_add2_f32(hipStream_t st, float* a, const float* b, size_t n) {  // a += b (n % 4 == 0): the two k halves of a split GEMM
+  k_add2_f32<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(a, b, n / 4);
+}
+
 // one dword of a Q4_0 block (quant bytes 4 s .. 4 s + 3: low nibbles = elements 4 s .., high nibbles = 16 + 4 s ..; buf_q4_0.rs:24-33)
 // -> the lane's eight f16 k-slots (q - 8) * d.  0x6400 | n is the f16 number 1024 + n; -1032 makes it n - 8 exactly.
 // (x & 0x000F000F) | 0x64006400 as ONE v_and_or_b32: a VOP3 instruction takes a single scalar / literal operand, so the compiler
@@ -97,36 +105,45 @@ struct F16wMats {
   const i32x4* wq[3];
   const unsigned short* wd[3];
   float* out[3];
+  float* out2[3];    // ksplit = 2: the second k half's partial tiles (the caller adds the two)
   int m[3];
   int tiles_end[3];  // cumulative row tiles
 };
 template <int F, int T_>  // F 16-row fragments x T_ 16-column tiles per wave: the workgroup's four waves own 64 F consecutive weight rows
-__global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4* __restrict__ xh, int nb, int n, int row_tiles) {
+// ksplit = 2: two workgroups per output tile, each over half of k, each writing its own partial buffer (out / out2) -- ffn_down and
+// wo have few row tiles and a long serial k loop: one wave per SIMD otherwise
+__global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4* __restrict__ xh, int nb, int n, int row_tiles, int ksplit) {
   using G = GemmF16Geo<T_>;
   constexpr int T = G::T, KCH = G::KCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char f16w_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_wg();
   const int i = lane & 15, g = lane >> 4;
-  int rt, ct;
-  {  // XCD-aware tile order (gemm_mfma.hip): the column tiles of a weight row tile back to back on ONE XCD
-    const int col_tiles = (int)gridDim.x / row_tiles;
+  int rt, ct, ks;
+  {  // XCD-aware tile order (gemm_mfma.hip): the column tiles (and k halves) of a weight row tile back to back on ONE XCD
+    const int per_row = (int)gridDim.x / row_tiles, col_tiles = per_row / ksplit;
+    int sub;
     if ((row_tiles & 7) == 0) {
       const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-      ct = j % col_tiles;
-      rt = (j / col_tiles) * 8 + x;
+      sub = j % per_row;
+      rt = (j / per_row) * 8 + x;
     } else {
       rt = (int)blockIdx.x % row_tiles;
-      ct = (int)blockIdx.x / row_tiles;
+      sub = (int)blockIdx.x / row_tiles;
     }
+    ct = sub % col_tiles;
+    ks = sub / col_tiles;
   }
   const int ti = rt < mats.tiles_end[0] ? 0 : rt < mats.tiles_end[1] ? 1 : 2;  // (uniform)
   const i32x4* __restrict__ wq = ti == 0 ? mats.wq[0] : ti == 1 ? mats.wq[1] : mats.wq[2];
   const unsigned short* __restrict__ wd = ti == 0 ? mats.wd[0] : ti == 1 ? mats.wd[1] : mats.wd[2];
-  float* __restrict__ out = ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2];
+  float* __restrict__ out = ks == 0 ? (ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2]) : (ti == 0 ? mats.out2[0] : ti == 1 ? mats.out2[1] : mats.out2[2]);
   const int m = ti == 0 ? mats.m[0] : ti == 1 ? mats.m[1] : mats.m[2];
   const int rt_l = rt - (ti == 0 ? 0 : ti == 1 ? mats.tiles_end[0] : mats.tiles_end[1]);
   const int r0 = rt_l * 64 * F + wave * 16 * F, c0 = ct * G::CW;
-  const int nchunks = (nb + KCH - 1) / KCH;
+  // this workgroup's chunks: [ch_lo, ch_lo + nchunks) of the row's ceil(nb / KCH)
+  const int all_chunks = (nb + KCH - 1) / KCH, per_piece = (all_chunks + ksplit - 1) / ksplit;
+  const int ch_lo = ks * per_piece;
+  const int nchunks = all_chunks - ch_lo < per_piece ? all_chunks - ch_lo : per_piece;  // (>= 1: the launcher splits only long rows)
 
   // A: the lane's block (row i of fragment f, block kb0 + g) and its scale.  HBM latency is several chunk times (a chunk is ~0.4 us of
   // MFMAs and a workgroup has the SIMD almost to itself): a RING of four register sets, chunk c + 3 requested while chunk c is
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   i32x4 aq[4][F];
   unsigned ad[4][F];
   auto fetch_a = [&](i32x4 (&q)[F], unsigned (&d)[F], int ch) {
-    const int cc = ch < nchunks ? ch : nchunks - 1;  // (past the end: re-read the last chunk, never consumed)
+    const int cc = ch_lo + (ch < nchunks ? ch : nchunks - 1);  // (past the end: re-read the last chunk, never consumed)
     const int kb = cc * KCH + g;
     const int gkb = kb < nb ? kb : nb - 1;
 #pragma unroll
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   for (int u = 0; u < G::B_LOADS; u++) {
     const int p = tid + 256 * u, col = p >> 4, pc = p & 15;
     const int gcol = c0 + col < n ? c0 + col : n - 1;
-    pb[u] = xh + (size_t)gcol * nb * 4 + pc;
+    pb[u] = xh + ((size_t)gcol * nb + (size_t)ch_lo * KCH) * 4 + pc;
   }
   auto fetch_b = [&](i32x4 (&r)[G::B_LOADS], int ch) {
     (void)ch;
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
 // xh: the rows' pre-scaled f16 planes (launch_q8_0_rows_to_f16) FOLLOWED BY zeroed slack (the kernel's look-ahead reads run up to
 // three chunks past the last column's end: fused.hip allocates 4 KB); returns false when the shape is not covered
 template <int F, int T>
-static bool launch_f16w_t(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b) {
+static bool launch_f16w_t(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit) {
   using G = GemmF16Geo<T>;
   static bool raised = false;
   if (!raised) {
@@ -272,16 +289,21 @@ static bool launch_f16w_t(crabml_hip_device* dev, const F16wMats& mats, int row_
     raised = true;
   }
   const int col_tiles = (int)((b + G::CW - 1) / G::CW);
-  k_gemm_f16w<F, T><<<dim3(row_tiles * col_tiles), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b, row_tiles);
+  k_gemm_f16w<F, T><<<dim3(row_tiles * col_tiles * ksplit), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b,
+                                                                                          row_tiles, ksplit);
   return true;
 }
 // nw weight matrices (Q4_0, the same k) against the same rhs rows: out[j] (b, m[j]) = W[j] . x
+// out2 (nullable; one matrix only): a second (b, m) buffer -- when the launch would leave one wave per SIMD (few row tiles, a long k:
+// ffn_down, wo) the k range is cut in two, the halves' partial tiles go to out and out2 and *split_out = 2: the caller adds them
+// (k_add2_f32).  (Measured and not kept: the halves added with f32 atomics onto a zeroed output -- 32.4k -> 30.1k prompt tok/s.)
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
-                      float* const* out) {
+                      float* const* out, float* out2, int* split_out) {
+  if (split_out) *split_out = 1;
   if (nw < 1 || nw > 3 || k % 32 != 0 || b < 32) return false;
   for (int j = 0; j < nw; j++)
     if (w[j]->dtype != CRABML_HIP_Q4_0 || m[j] % 4 != 0) return false;
-  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = <2,8>, 3 = <1,8>, 4 = <2,4>
+  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = <2,8>, 3 = <1,8>, 4 = <2,4>; +8 = never split k
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_F16W");
     return h && h[0] == '1' && e ? atoi(e) : 0;
@@ -301,14 +323,16 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
     mats.wq[j] = (const i32x4*)wp;
     mats.wd[j] = (const unsigned short*)(wp + w[jj]->wl.off_scale);
     mats.out[j] = out[jj];
+    mats.out2[j] = out2;
     mats.m[j] = (int)m[jj];
     if (j < nw) row_tiles += (int)((m[j] + 64 * F - 1) / (64 * F));
     mats.tiles_end[j] = row_tiles;
   }
-  // (measured and not kept: the k range of ffn_down / wo cut in two with f32 atomic adds onto a zeroed output -- 32.4k -> 30.1k
-  // prompt tok/s at 512 rows: the memset and 4 M atomics cost more than the second workgroup per CU returns)
-  if ((variant & 7) == 4) return launch_f16w_t<2, 4>(dev, mats, row_tiles, k, xh, b);
-  return F == 2 ? launch_f16w_t<2, 8>(dev, mats, row_tiles, k, xh, b) : launch_f16w_t<1, 8>(dev, mats, row_tiles, k, xh, b);
+  int ksplit = 1;
+  if (out2 != nullptr && split_out != nullptr && nw == 1 && (size_t)row_tiles * col128 < (size_t)dev->n_cu * 3 / 2 && k >= 4096 && !(variant & 8)) ksplit = 2;
+  if (split_out) *split_out = ksplit;
+  if ((variant & 7) == 4) return launch_f16w_t<2, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
+  return F == 2 ? launch_f16w_t<2, 8>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
 }
 
 }  // namespace crabml_hip

@@ -44,7 +44,8 @@ void launch_q4k_class_major(hipStream_t st, void* qs_plane, size_t blk0, size_t 
 // gemm_f16w.hip: the fast prompt pass's weight-stationary f16 GEMM (Q4_0 weights) and the rows' pre-scaled f16 planes it reads
 void launch_q8_0_rows_to_f16(hipStream_t st, const void* planes, size_t row_stride, size_t off_d, size_t rows, size_t k, void* xh);
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
-                      float* const* out);
+                      float* const* out, float* out2 = nullptr, int* split_out = nullptr);
+void launch_add2_f32(hipStream_t st, float* a, const float* b, size_t n);
 // batched rhs on the matrix cores (gemm_mfma.hip); false = not covered
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
                       crabml_hip_device::ProfRec* rec, int* dbg = nullptr, bool fused_add = false);
