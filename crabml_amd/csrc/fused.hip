@@ -642,7 +642,9 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
                  planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq, qkv_upfront);
     } else
       launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
-               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq, 0);
+               planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0}, rtq,
+               // few, short waves (a tensor-parallel rank's rows; small models): two steps per request round
+               (qkv_upfront && total_rows / 2 <= 4 * dev->n_cu) ? 1 : 0);
     CH_TRY(P1(&pr));
     // attention (llama2.rs:571-590) -> attn (f32) [+ Q8_0 planes for wo]; spare CUs prefetch wo
     const bool attn_quant = (hd % 32) == 0;

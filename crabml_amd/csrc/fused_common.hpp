@@ -432,6 +432,12 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
     else
       inv_rms = rows_partial_rms<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc, rt, rq);
   } else {
+    if constexpr (FMT != CRABML_HIP_Q4_K) {
+      if (!done && upfront && (nb * BlockFmt<FMT>::UNITS) % 128 == 0) {
+        rows_partial_2step<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
+        done = true;
+      }
+    }
     if (!done) rows_dot<FMT, 2>(w.q, w.d, act, local, m, nb, lane, acc);
   }
   float s0 = wave_sum_f32(acc[0]), s1 = wave_sum_f32(acc[1]);

@@ -1032,7 +1032,7 @@ template <int FMT>
 __global__ __launch_bounds__(1024) void k_gateup_h(Planes wg, Planes wu, typename ActOf<FMT>::type act, const unsigned short* __restrict__ exp_tab,
                                                    float* __restrict__ h, int m, int nb) {
   using F = BlockFmt<FMT>;
-  const int lane = threadIdx.x & 63, wave = wave_in_wg();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = ((int)blockIdx.x * (int)(blockDim.x >> 6) + wave) * 2;
   if (row >= m) return;
   float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;

@@ -204,6 +204,33 @@ __device__ __forceinline__ void rows_partial(const i32x4* __restrict__ wq, const
   }
 }
 
+// rows_partial with TWO 64-unit steps requested per round (rows of a multiple of 128 units): for launches of few, short waves -- a
+// tensor-parallel rank's q|k|v: 640 waves of four steps -- halving a wave's dependent round trips shortens the launch; with many
+// resident waves it only delays each wave's first use (profiles/r06_small_stage_ab.md).  Same terms, same per-lane order.
+template <int FMT, int R, class ACT>
+__device__ __forceinline__ void rows_partial_2step(const i32x4* __restrict__ wq, const unsigned short* __restrict__ wd, const ACT& act,
+                                                   int row0, int m, int nb, int lane, float acc[R]) {
+  using F = BlockFmt<FMT>;
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.f;
+  const int nu = nb * F::UNITS;  // (a multiple of 128: the caller checked)
+  for (int u = lane; u < nu; u += 128) {
+    typename F::Blk b0[R], b1[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int row = row0 + r < m ? row0 + r : m - 1;
+      b0[r] = F::load(wq, wd, (size_t)row, nb, u);
+      b1[r] = F::load(wq, wd, (size_t)row, nb, u + 64);
+    }
+    const XUnit x0 = F::loadx(act, u), x1 = F::loadx(act, u + 64);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      acc[r] += F::term(b0[r], x0);
+      acc[r] += F::term(b1[r], x1);
+    }
+  }
+}
+
 // rows_partial for a wave that also has to form 1 / rms from the chunk sums it requested when it started (RmsTail): a uniform trip
 // count (lanes past the row's units redo the last one and add nothing) so that the whole wave can run the reduction INSIDE the
 // first step -- behind that step's weight requests, while they are in flight.  After its last step a wave is on the launch's
