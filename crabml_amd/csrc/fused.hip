@@ -1198,7 +1198,8 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const char* e = getenv("CRABML_HIP_GEMM_INT8");
     return h && h[0] == '1' && e && e[0] == '1';
   }();
-  const bool f16w = !strict && !gemm_exact_hook && !f16w_off && c->qt == CRABML_HIP_Q8_0 && c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
+  const bool f16w = !strict && !gemm_exact_hook && !f16w_off && !(g.flags & CRABML_HIP_LLAMA_PREFILL_INT8_GEMM) && c->qt == CRABML_HIP_Q8_0 &&
+                    c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
     if (f16w && w->dtype == CRABML_HIP_Q4_0) {
       if (xh_of != act) {

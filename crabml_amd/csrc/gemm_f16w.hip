@@ -275,18 +275,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel)
+static bool f16w_raise_lds(const crabml_hip_device* dev, const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> have;
+  std::lock_guard<std::mutex> g(mu);
+  int& cur = have[{dev->ordinal, fn}];
+  if (bytes <= cur) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  cur = bytes;
+  return true;
+}
 // xh: the rows' pre-scaled f16 planes (launch_q8_0_rows_to_f16) FOLLOWED BY zeroed slack (the kernel's look-ahead reads run up to
 // three chunks past the last column's end: fused.hip allocates 4 KB); returns false when the shape is not covered
 template <int F, int T>
 static bool launch_f16w_t(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit) {
   using G = GemmF16Geo<T>;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute((const void*)k_gemm_f16w<F, T>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    raised = true;
+  if (!f16w_raise_lds(dev, (const void*)k_gemm_f16w<F, T>, G::LDS_BYTES)) {  // (80 KB of dynamic LDS: raised once per device)
+    (void)hipGetLastError();
+    return false;
   }
   const int col_tiles = (int)((b + G::CW - 1) / G::CW);
   k_gemm_f16w<F, T><<<dim3(row_tiles * col_tiles * ksplit), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b,

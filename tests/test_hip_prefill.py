@@ -10,7 +10,7 @@ import pytest
 
 from crabml_amd import synth
 from oracle import oracle as o
-from tests.helpers import to_oracle
+from tests.helpers import FAST_TOL, to_oracle
 
 EXACT = 4194304  # CRABML_HIP_LLAMA_EXACT_ATTENTION: the fast step keeps the reference's exact attention arithmetic
 pytestmark = pytest.mark.gpu
@@ -228,3 +228,40 @@ def test_prefill_row_fusion_equals_the_separate_launches(ca, fmt):
             assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), (fmt, strict, chunk)
             nxt = int(np.argmax(la))
             assert list(a.decode_greedy(nxt, 5)) == list(b.decode_greedy(nxt, 5))
+
+
+PREFILL_INT8_GEMM = 524288  # CRABML_HIP_LLAMA_PREFILL_INT8_GEMM (include/crabml_hip_debug.h)
+
+
+@pytest.mark.parametrize("shape,n", [("tiny-gqa", 200), ("15m", 173), ("tiny-hd128", 384)])
+def test_fast_prompt_pass_f16_weight_gemm(ca, shape, n):
+    """Passes of >= 160 rows, Q4_0 weights, fast device: the weight GEMMs run on the f16 matrix cores with the block scales folded
+    into the operands (k_gemm_f16w, gemm_f16w.hip -- a stated deviation of the fast tier: two f16 roundings per product instead of
+    exact integer block dots).  Against the oracle's token loop it must sit inside the fast tolerance the int8 kernels are held to;
+    against the int8 kernels (A/B flag) the two passes must agree far inside it; the cache rows they leave are the same rows up to
+    that noise; the greedy continuation starts with the same token.  Shapes: k = 512 / 1024 (4 and 8 whole chunks), 288 / 768 (the
+    15M model: 9 and 24 blocks -- a ragged last chunk, rows that are no multiple of 64), ragged last column tiles (200 = 128 + 72,
+    173 = 128 + 45), three full tiles (384)."""
+    model = synth.build_model(synth.SHAPES[shape], synth.Q4_0, seed=91)
+    prompt = [(11 * i + 5) % model.shape.vocab for i in range(n)]
+    odev = o.OracleDevice(thread_num=8, use_avx2=False)
+    oconf, ow = to_oracle(model, odev)
+    orr = o.OracleLlamaRunner(oconf, ow, odev, n + 16, True)
+    ref = None
+    for i, t in enumerate(prompt):
+        ref = orr.forward([t], i)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=512)
+    b = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=512, extra_flags=PREFILL_INT8_GEMM)
+    la, lb = np.array(a.prefill(prompt)), np.array(b.prefill(prompt))
+    scale = float(np.max(np.abs(ref)))
+    ea, eb, eab = (float(np.max(np.abs(x - y))) / scale for x, y in ((la, ref), (lb, ref), (la, lb)))
+    tol = FAST_TOL["Q4_0"][1]
+    assert eb <= tol, ("int8 pass vs oracle", eb)
+    assert ea <= tol, ("f16 pass vs oracle", ea)
+    assert eab <= tol, ("f16 pass vs int8 pass", eab)
+    assert not np.array_equal(la, lb)  # (the two passes are different arithmetic: equal logits would mean the flag does nothing)
+    nxt = int(np.argmax(ref))
+    assert list(a.decode_greedy(nxt, 4))[0] == list(b.decode_greedy(nxt, 4))[0]
+    assert a.kv_cache_len() == b.kv_cache_len() == n + 4
