@@ -1,18 +1,20 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_steps20_warmup5.json 2> gpurun_out/r06_bench.err; echo "rc=$?"
+timeout 1500 python bench.py > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err; echo "rc=$?"
+for wt in Q4_K Q8_0 Q4_1 Q4_K_M Q6_K; do
+timeout 900 python bench.py --wtype $wt --steps 20 --warmup 5 --no-cpu-baseline --no-context --no-gemv-points > gpurun_out/r06_bench_$wt.json 2>gpurun_out/r06_bench_$wt.err; echo "$wt rc=$?"
+done
 python - <<'PY'
 import json
+rows=[]
+for wt,f in [('Q4_0','r06_bench_steps20_warmup5'),('Q4_K','r06_bench_Q4_K'),('Q8_0','r06_bench_Q8_0'),('Q4_1','r06_bench_Q4_1'),('Q4_K_M','r06_bench_Q4_K_M'),('Q6_K','r06_bench_Q6_K')]:
+    d=json.load(open(f'gpurun_out/{f}.json'))
+    r=d['roofline']
+    rows.append(f"| {wt} | {d.get('value')} | {d['fused_entry_point']['tokens_per_s']} | {d.get('value_strict')} | {d.get('c3_positions_0_127',{}).get('tokens_per_s')} | {d.get('trait_path',{}).get('per_op_launches_tokens_per_s')} | {(d.get('prefill') or {}).get('prompt_tokens_per_s')} | {r['kernel'][:40]} | {r['avg_launch_us']} | {r['frac']} |")
+print("\n".join(rows))
 d=json.load(open('gpurun_out/r06_bench_steps20_warmup5.json'))
-for k in ['value','value_strict','value_strict_through_reference_api','ms_per_step']: print(k, d.get(k))
-print('fused', d['fused_entry_point']['tokens_per_s'])
-print('c3', d.get('c3_positions_0_127'))
-print('context', d.get('context'))
-print('prefill', d.get('prefill'))
-r=d['roofline']; print({k:r.get(k) for k in ['frac','frac_rocprof','achieved','avg_launch_us','traffic','frac_of_measured','measured_read_ceiling']})
-print('cpu', d.get('cpu_baseline'))
-print('trait', d.get('trait_path'))
-pc=d.get('parity_check',{}); print({k:pc.get(k) for k in ['strict_bit_identical','fast_max_rel_logit_err','strict_tokens_per_s']}); 
-for m in pc.get('models',[]): print(m.get('model')[:40], m.get('fast_over_reference_spread'), m.get('reference_api_equals_fused_entry_point_bitwise'), m.get('reference_api_tokens_served_by_fused_step'), m.get('fast_tokens_equal'), m.get('reference_avx2_vs_scalar_tokens_equal'))
-print('gemv_points', [(p, v.get('frac_of_peak')) for p,v in d.get('gemv_points',{}).get('points',{}).items()])
+r=d['roofline']; print({k:r.get(k) for k in ['frac','frac_rocprof','traffic','avg_launch_us','rocprof_avg_launch_us','frac_of_measured']})
+print(d['value'], d['fused_entry_point']['tokens_per_s'], d['value_strict'], d['cpu_baseline']['sample'], d['prefill']['prompt_tokens_per_s'], d['trait_path']['per_op_launches_tokens_per_s'])
+d=json.load(open('gpurun_out/r06_bench_default.json')); print('default', d['value'], d['fused_entry_point']['tokens_per_s'], d['value_strict'], d['roofline']['frac'])
 PY
