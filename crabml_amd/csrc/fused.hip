@@ -182,7 +182,7 @@ struct crabml_hip_llama {
         *pf_tmp = nullptr, *pf_g = nullptr, *pf_u = nullptr;
   char *pf_act_dim = nullptr, *pf_act_hid = nullptr;
   float* pf_split = nullptr;  // ... and the second k half's partial (rows, dim) tiles of a split wo / ffn_down GEMM
-  void* pf_xh = nullptr;  // the fast pass's Q4_0 GEMMs: the current rhs rows as pre-scaled f16 (gemm_f16w.hip), cap x max(dim, hidden) halfs
+  void* pf_xh = nullptr;  // the fast pass's f16 GEMMs: the current rhs rows as pre-scaled f16 (gemm_f16w.hip), gemm_f16w_xh_bytes(cap, max(dim, hidden))
   float* pf_scores = nullptr;          // long prompts: [PF_LONG_ROWS][n_heads][seq_len] f32 scores
   unsigned short* pf_p16 = nullptr;    //               and f16 probabilities, allocated on first use
   std::vector<std::pair<void*, size_t>> allocs;
@@ -1061,8 +1061,8 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   CH_TRY(A(cap * hidden * 4, (void**)&c->pf_u));
   CH_TRY(A(cap * act_bytes(c->qt, dim), (void**)&c->pf_act_dim));
   CH_TRY(A(cap * act_bytes(c->qt, hidden), (void**)&c->pf_act_hid));
-  if (c->qt == CRABML_HIP_Q8_0 && !c->dev->strict_order) {  // (+ 4 KB of zeroed slack: the GEMM's look-ahead reads, gemm_f16w.hip)
-    const size_t xb = cap * (dim > hidden ? dim : hidden) * 2 + 4096;
+  if ((c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_K) && !c->dev->strict_order) {  // (whole column tiles + the look-ahead's slack)
+    const size_t xb = gemm_f16w_xh_bytes(cap, dim > hidden ? dim : hidden);
     CH_TRY(A(xb, &c->pf_xh));
     CH_TRY(A(cap * dim * 4, (void**)&c->pf_split));
     CH_HIP(c->dev, hipMemsetAsync(c->pf_xh, 0, xb, c->dev->stream));
@@ -1190,7 +1190,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const char* e = getenv("CRABML_HIP_GEMM_EXACT");
     return h && h[0] == '1' && e && e[0] == '1';
   }();
-  // The fast pass, Q4_0 weights x Q8_0 rows, >= 32 rows: the weight-stationary f16 GEMM (gemm_f16w.hip; block scales folded into f16
+  // The fast pass, Q4_0 / Q8_0 weights x Q8_0 rows or Q4_K x Q8_K, >= 160 rows: the weight-stationary f16 GEMM (gemm_f16w.hip; block scales folded into f16
   // operands, f32 accumulation inside the matrix core -- a stated deviation of the fast tier).  The rows' pre-scaled f16 planes are
   // made once per rhs (q / k / v and gate / up share theirs): xh_of remembers which planes pf_xh currently holds.
   static const bool f16w_off = [] {  // A/B hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_INT8=1): the int8 kernels in the fast pass too
@@ -1198,13 +1198,12 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const char* e = getenv("CRABML_HIP_GEMM_INT8");
     return h && h[0] == '1' && e && e[0] == '1';
   }();
-  const bool f16w = !strict && !gemm_exact_hook && !f16w_off && !(g.flags & CRABML_HIP_LLAMA_PREFILL_INT8_GEMM) && c->qt == CRABML_HIP_Q8_0 &&
-                    c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
+  const bool f16w = !strict && !gemm_exact_hook && !f16w_off && !(g.flags & CRABML_HIP_LLAMA_PREFILL_INT8_GEMM) &&
+                    (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
-    if (f16w && w->dtype == CRABML_HIP_Q4_0) {
+    if (f16w && gemm_f16w_covers(w->dtype, c->qt) && (c->qt != CRABML_HIP_Q8_K || k % 256 == 0)) {
       if (xh_of != act) {
-        const ActLayout al = act_layout(CRABML_HIP_Q8_0, (size_t)k);
-        launch_q8_0_rows_to_f16(st, act, al.total, al.off_d, B, (size_t)k, c->pf_xh);
+        launch_rows_to_f16(st, c->qt, act, B, (size_t)k, c->pf_xh);
         xh_of = act;
       }
       const size_t mm = (size_t)m;
@@ -1265,10 +1264,9 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
     }
     bool qkv_done = false;  // llama2.rs:244-246
-    if (f16w && c->wq[l]->dtype == CRABML_HIP_Q4_0 && c->wk[l]->dtype == CRABML_HIP_Q4_0 && c->wv[l]->dtype == CRABML_HIP_Q4_0) {
+    if (f16w && gemm_f16w_covers(c->wq[l]->dtype, c->qt) && c->wk[l]->dtype == c->wq[l]->dtype && c->wv[l]->dtype == c->wq[l]->dtype) {
       // the three GEMMs of the same rhs as ONE launch (the 1024-row k / v matrices alone leave most of the chip idle)
-      const ActLayout al = act_layout(CRABML_HIP_Q8_0, (size_t)dim);
-      launch_q8_0_rows_to_f16(st, a, al.total, al.off_d, B, (size_t)dim, c->pf_xh);
+      launch_rows_to_f16(st, c->qt, a, B, (size_t)dim, c->pf_xh);
       xh_of = a;
       const crabml_hip_buf* ws[3] = {c->wq[l], c->wk[l], c->wv[l]};
       const size_t ms[3] = {(size_t)dim, (size_t)kv_dim, (size_t)kv_dim};
@@ -1324,11 +1322,10 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
     }
     bool gu_done = false;  // llama2.rs:620-630
-    if (f16w && c->gate[l]->dtype == CRABML_HIP_Q4_0 && c->up[l]->dtype == CRABML_HIP_Q4_0) {
+    if (f16w && gemm_f16w_covers(c->gate[l]->dtype, c->qt) && c->up[l]->dtype == c->gate[l]->dtype) {
       // gate and up as ONE launch: 2 x 448 workgroups fill the last round of the chip better than 448 twice
       if (xh_of != a) {
-        const ActLayout al = act_layout(CRABML_HIP_Q8_0, (size_t)dim);
-        launch_q8_0_rows_to_f16(st, a, al.total, al.off_d, B, (size_t)dim, c->pf_xh);
+        launch_rows_to_f16(st, c->qt, a, B, (size_t)dim, c->pf_xh);
         xh_of = a;
       }
       const crabml_hip_buf* ws[2] = {c->gate[l], c->up[l]};

@@ -1,5 +1,5 @@
-// gemm_f16w.hip -- the FAST prompt pass's weight GEMM (crabml_hip_llama_prefill on the fast device; Q4_0 weights, Q8_0 rows):
-// weight-stationary on the f16 matrix cores.
+// gemm_f16w.hip -- the FAST prompt pass's weight GEMM (crabml_hip_llama_prefill on the fast device; Q4_0 / Q8_0 weights x Q8_0 rows,
+// Q4_K weights x Q8_K rows): weight-stationary on the f16 matrix cores.
 //
 // matmul_vec with a batched rhs is `C[b, m] = W[m, k] . x[b, k]` (matmul_vec.rs:41-76: the (b, k) rhs contract; llama2.rs:111-129).
 // The bit-exact form (gemm_mfma.hip: exact int8 tiles, then the reference's per-block `sumf += (sumi as f32 * d_w) * d_x`) pays
@@ -18,7 +18,14 @@
 // lane -- an MFMA's 32 k-slots then span FOUR blocks (8 elements of each), which the folded scales allow.  B' tiles (128 columns x
 // 128 k-slots x 2 B = 32 KB per chunk) go through LDS, double-buffered, one barrier per chunk, shared by the workgroup's four waves;
 // the fragment reads are conflict-free ds_read_b128 (layout: GemmF16Geo), a group of tiles ahead of the MFMAs that consume them.
-#include <cstdlib>
+//
+// Q8_0 weights: the lane's block is 32 bytes (two loads); step s takes dwords s and 4 + s -- the same k-slot order as Q4_0's nibbles,
+// so both formats share one B'.  A' = q_w * d_w (q_w exact).
+// Q4_K weights (Q8_K rows): a chunk is HALF a super-block -- lane (i, g) loads the 16-byte class-major piece h of pair g (dword s =
+// class 4 h + s: elements 8 k + 4 h + s of sub-blocks 2 g (low nibbles) and 2 g + 1 (high); common.hpp) and, once per super-block, the
+// 16-byte header.  A' = n * fl16(d * sc) - fl16(dmin * m) (buf_q4_k.rs:225-263's d * sc * q - dmin * m, per element): n exact, the
+// product exact inside ONE v_pk_fma_f16, so three f16 roundings per weight element; B' = q_x * d_x from the Q8_K planes in the
+// matching slot order (k_rows_to_f16<true>).#include <cstdlib>
 #include <type_traits>
 
 #include "devutil.hpp"
@@ -37,26 +44,50 @@ __device__ __forceinline__ int f16w_slot_elem(int slot) {
   const int s = slot >> 3, e = slot & 7;
   return (e >= 4 ? 16 : 0) + 4 * s + ((e >> 1) & 1) + 2 * (e & 1);
 }
-__global__ __launch_bounds__(256) void k_q8_0_rows_to_f16(const char* __restrict__ planes, size_t row_stride, size_t off_d, int nb,
-                                                          unsigned short* __restrict__ xh) {
+// Q8_K rows (Q4_K weights): slot group kb = 4 cc + g of chunk cc = (super-block, half h), step s = class l = 4 h + s of pair g;
+// slot e: k = 0, 2, 1, 3 of sub-block 2 g (e < 4) / 2 g + 1 (e >= 4), element 8 k + l -- unpack_q4_k_f16's order
+template <bool Q8K>
+__global__ __launch_bounds__(256) void k_rows_to_f16(const char* __restrict__ planes, size_t row_stride, size_t off_d, int nb,
+                                                     unsigned short* __restrict__ xh) {
   const size_t col = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (block, 8-slot group)
   if (t >= nb * 4) return;
   const int kb = t >> 2, s = t & 3;
   const char* p = planes + col * row_stride;
-  const float d = h2f(((const unsigned short*)(p + off_d))[kb]);
-  const signed char* q = (const signed char*)p + kb * 32;
+  float d;
+  const signed char* q;
+  int at[8];
+  if constexpr (Q8K) {
+    const int cc = kb >> 2, g = kb & 3, sb = cc >> 1, l = 4 * (cc & 1) + s;
+    d = ((const float*)(p + off_d))[sb];
+    q = (const signed char*)p + sb * 256 + 64 * g;
+#pragma unroll
+    for (int e = 0; e < 8; e++) at[e] = (e >= 4 ? 32 : 0) + 8 * (((e >> 1) & 1) + 2 * (e & 1)) + l;
+  } else {
+    d = h2f(((const unsigned short*)(p + off_d))[kb]);
+    q = (const signed char*)p + kb * 32;
+#pragma unroll
+    for (int e = 0; e < 8; e++) at[e] = f16w_slot_elem(8 * s + e);
+  }
   unsigned short o[8];
 #pragma unroll
-  for (int e = 0; e < 8; e++) o[e] = f2h((float)q[f16w_slot_elem(8 * s + e)] * d);  // (7-bit x 11-bit: exact in f32, one rounding)
+  for (int e = 0; e < 8; e++) o[e] = f2h((float)q[at[e]] * d);  // (Q8_0: 7-bit x 11-bit, exact in f32, one rounding; Q8_K: f32 d, two)
   unsigned short* dst = xh + (col * nb + kb) * 32 + 8 * s;
   *(i32x4*)dst = i32x4{(int)(o[0] | ((unsigned)o[1] << 16)), (int)(o[2] | ((unsigned)o[3] << 16)), (int)(o[4] | ((unsigned)o[5] << 16)),
                        (int)(o[6] | ((unsigned)o[7] << 16))};
 }
-void launch_q8_0_rows_to_f16(hipStream_t st, const void* planes, size_t row_stride, size_t off_d, size_t rows, size_t k, void* xh) {
+// planes: `rows` sets of Q8_0 / Q8_K activation planes (act_layout(qtype, k)), row_stride bytes apart
+bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, const void* planes, size_t rows, size_t k, void* xh) {
+  const ActLayout al = act_layout(act_qtype, k);
   const int nb = (int)(k / 32);
-  k_q8_0_rows_to_f16<<<dim3((unsigned)((nb * 4 + 255) / 256), (unsigned)rows), 256, 0, st>>>((const char*)planes, row_stride, off_d, nb,
-                                                                                               (unsigned short*)xh);
+  const dim3 grid((unsigned)((nb * 4 + 255) / 256), (unsigned)rows);
+  if (act_qtype == CRABML_HIP_Q8_0)
+    k_rows_to_f16<false><<<grid, 256, 0, st>>>((const char*)planes, al.total, al.off_d, nb, (unsigned short*)xh);
+  else if (act_qtype == CRABML_HIP_Q8_K && k % 256 == 0)
+    k_rows_to_f16<true><<<grid, 256, 0, st>>>((const char*)planes, al.total, al.off_d, nb, (unsigned short*)xh);
+  else
+    return false;
+  return true;
 }
 
 __global__ __launch_bounds__(256) void k_add2_f32(float* __restrict__ a, const float* __restrict__ b, size_t n4) {
@@ -85,6 +116,45 @@ __device__ __forceinline__ f16x8 unpack_q4_0_f16(unsigned w, f16x2 d2, unsigned 
   return f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
 }
 
+// Q8_0: the bytes of a dword as f16 (b ^ 0x80 = b + 128 unsigned; 0x6400 | u = 1024 + u; -1152 makes it b exactly), pairs (b0, b2), (b1, b3)
+__device__ __forceinline__ unsigned and_or_magic8(unsigned x, unsigned magic) {
+  unsigned r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(0x00FF00FFu), "v"(magic));
+  return r;
+}
+__device__ __forceinline__ f16x8 unpack_q8_0_f16(unsigned w0, unsigned w1, f16x2 d2, unsigned magic) {
+  const f16x2 bias = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+  const unsigned x0 = w0 ^ 0x80808080u, x1 = w1 ^ 0x80808080u;
+  const unsigned u0 = and_or_magic8(x0, magic), u1 = and_or_magic8(x0 >> 8, magic);
+  const unsigned u2 = and_or_magic8(x1, magic), u3 = and_or_magic8(x1 >> 8, magic);
+  const f16x2 p0 = (__builtin_bit_cast(f16x2, u0) + bias) * d2, p1 = (__builtin_bit_cast(f16x2, u1) + bias) * d2;
+  const f16x2 p2 = (__builtin_bit_cast(f16x2, u2) + bias) * d2, p3 = (__builtin_bit_cast(f16x2, u3) + bias) * d2;
+  return f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+// Q4_K: one class dword of the lane's pair; cs = {d sc_lo, -dmin m_lo, d sc_hi, -dmin m_hi}, each in both halves
+struct Q4KF16Consts {
+  f16x2 c_lo, o_lo, c_hi, o_hi;
+};
+__device__ __forceinline__ f16x8 unpack_q4_k_f16(unsigned w, const Q4KF16Consts& cs, unsigned magic) {
+  const f16x2 bias = {(_Float16)-1024.0f, (_Float16)-1024.0f};
+  const unsigned u0 = and_or_magic(w, magic), u1 = and_or_magic(w >> 8, magic);
+  const unsigned u2 = and_or_magic(w >> 4, magic), u3 = and_or_magic(w >> 12, magic);
+  const f16x2 p0 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, u0) + bias, cs.c_lo, cs.o_lo);
+  const f16x2 p1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, u1) + bias, cs.c_lo, cs.o_lo);
+  const f16x2 p2 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, u2) + bias, cs.c_hi, cs.o_hi);
+  const f16x2 p3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, u3) + bias, cs.c_hi, cs.o_hi);
+  return f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+__device__ __forceinline__ Q4KF16Consts q4k_f16_consts(i32x4 hdr, int g) {
+  const unsigned f = q4k_pair_field((unsigned)hdr[1], (unsigned)hdr[2], (unsigned)hdr[3], g);
+  const float d = h2f((unsigned short)((unsigned)hdr[0] & 0xffffu)), dmin = h2f((unsigned short)((unsigned)hdr[0] >> 16));
+  const _Float16 c_lo = (_Float16)(d * (float)(f & 63u)), c_hi = (_Float16)(d * (float)((f >> 6) & 63u));  // (11 x 6 bits: exact in f32)
+  const _Float16 o_lo = (_Float16)-(dmin * (float)((f >> 12) & 63u)), o_hi = (_Float16)-(dmin * (float)(f >> 18));
+  return Q4KF16Consts{f16x2{c_lo, c_lo}, f16x2{o_lo, o_lo}, f16x2{c_hi, c_hi}, f16x2{o_hi, o_hi}};
+}
+
+enum { WF_Q4_0 = 0, WF_Q8_0 = 1, WF_Q4_K = 2 };  // the weight format of a GEMM
+
 template <int T_>
 struct GemmF16Geo {
   static constexpr int T = T_, CW = 16 * T;    // column tiles per wave / prompt rows per workgroup
@@ -102,14 +172,14 @@ struct GemmF16Geo {
 // Up to three weight matrices against the same rhs in ONE launch (wq | wk | wv: the 1024-row k / v GEMMs alone leave most of the
 // chip idle for a whole serial k loop): row tile rt belongs to the first matrix whose cumulative tile count exceeds it.
 struct F16wMats {
-  const i32x4* wq[3];
-  const unsigned short* wd[3];
+  const i32x4* wq[3];  // the quant plane
+  const char* wd[3];   // the scale plane (f16 per block; Q4_K: the 16-byte headers)
   float* out[3];
   float* out2[3];    // ksplit = 2: the second k half's partial tiles (the caller adds the two)
   int m[3];
   int tiles_end[3];  // cumulative row tiles
 };
-template <int F, int T_>  // F 16-row fragments x T_ 16-column tiles per wave: the workgroup's four waves own 64 F consecutive weight rows
+template <int WF, int F, int T_>  // F 16-row fragments x T_ 16-column tiles per wave: the workgroup's four waves own 64 F consecutive weight rows
 // ksplit = 2: two workgroups per output tile, each over half of k, each writing its own partial buffer (out / out2) -- ffn_down and
 // wo have few row tiles and a long serial k loop: one wave per SIMD otherwise
 __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4* __restrict__ xh, int nb, int n, int row_tiles, int ksplit) {
@@ -135,54 +205,68 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   }
   const int ti = rt < mats.tiles_end[0] ? 0 : rt < mats.tiles_end[1] ? 1 : 2;  // (uniform)
   const i32x4* __restrict__ wq = ti == 0 ? mats.wq[0] : ti == 1 ? mats.wq[1] : mats.wq[2];
-  const unsigned short* __restrict__ wd = ti == 0 ? mats.wd[0] : ti == 1 ? mats.wd[1] : mats.wd[2];
+  const char* __restrict__ wsc = ti == 0 ? mats.wd[0] : ti == 1 ? mats.wd[1] : mats.wd[2];
+  const unsigned short* __restrict__ wd = (const unsigned short*)wsc;
+  const i32x4* __restrict__ wh = (const i32x4*)wsc;
   float* __restrict__ out = ks == 0 ? (ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2]) : (ti == 0 ? mats.out2[0] : ti == 1 ? mats.out2[1] : mats.out2[2]);
   const int m = ti == 0 ? mats.m[0] : ti == 1 ? mats.m[1] : mats.m[2];
   const int rt_l = rt - (ti == 0 ? 0 : ti == 1 ? mats.tiles_end[0] : mats.tiles_end[1]);
   const int r0 = rt_l * 64 * F + wave * 16 * F, c0 = ct * G::CW;
   // this workgroup's chunks: [ch_lo, ch_lo + nchunks) of the row's ceil(nb / KCH)
-  const int all_chunks = (nb + KCH - 1) / KCH, per_piece = (all_chunks + ksplit - 1) / ksplit;
+  // (Q4_K: an even chunk is half 0 of its super-block -- the pieces start on super-block boundaries)
+  const int all_chunks = (nb + KCH - 1) / KCH;
+  const int per_piece = WF == WF_Q4_K ? (((all_chunks + ksplit - 1) / ksplit + 1) & ~1) : (all_chunks + ksplit - 1) / ksplit;
   const int ch_lo = ks * per_piece;
   const int nchunks = all_chunks - ch_lo < per_piece ? all_chunks - ch_lo : per_piece;  // (>= 1: the launcher splits only long rows)
 
   // A: the lane's block (row i of fragment f, block kb0 + g) and its scale.  HBM latency is several chunk times (a chunk is ~0.4 us of
   // MFMAs and a workgroup has the SIMD almost to itself): a RING of four register sets, chunk c + 3 requested while chunk c is
   // multiplied; B' (L2-resident) two chunks ahead in two register sets.  All ring indices are compile-time (chunk loop unrolled by 4).
-  i32x4 aq[4][F];
-  unsigned ad[4][F];
-  auto fetch_a = [&](i32x4 (&q)[F], unsigned (&d)[F], int ch) {
+  constexpr int NQ = WF == WF_Q8_0 ? 2 : 1;  // 16-byte quant loads per fragment and chunk
+  i32x4 aq[4][NQ * F];
+  unsigned ad[4][F];   // Q4_0 / Q8_0: the block's scale
+  i32x4 hq[2][F];      // Q4_K: the super-block header of ring slots (0, 1) / (2, 3), fetched with the even slot
+  auto fetch_a = [&](auto Jc, int ch) {
+    constexpr int J = decltype(Jc)::value;
     const int cc = ch_lo + (ch < nchunks ? ch : nchunks - 1);  // (past the end: re-read the last chunk, never consumed)
-    const int kb = cc * KCH + g;
-    const int gkb = kb < nb ? kb : nb - 1;
+    if constexpr (WF == WF_Q4_K) {
+      const int nsb = nb >> 3, sb = cc >> 1, h = cc & 1;
 #pragma unroll
-    for (int f = 0; f < F; f++) {
-      const int row = r0 + 16 * f + i;
-      const size_t blk = (size_t)(row < m ? row : m - 1) * nb + gkb;
-      q[f] = __builtin_nontemporal_load(wq + blk);
-      const unsigned dv = __builtin_nontemporal_load(wd + blk);
-      d[f] = kb < nb ? dv : 0u;  // past the row's end: scale 0, the slots add nothing
+      for (int f = 0; f < F; f++) {
+        const int row = r0 + 16 * f + i;
+        const size_t blk = (size_t)(row < m ? row : m - 1) * nsb + sb;
+        aq[J][f] = __builtin_nontemporal_load(wq + blk * 8 + 2 * g + h);
+        if constexpr ((J & 1) == 0) hq[J >> 1][f] = __builtin_nontemporal_load(wh + blk);
+      }
+    } else {
+      const int kb = cc * KCH + g;
+      const int gkb = kb < nb ? kb : nb - 1;
+#pragma unroll
+      for (int f = 0; f < F; f++) {
+        const int row = r0 + 16 * f + i;
+        const size_t blk = (size_t)(row < m ? row : m - 1) * nb + gkb;
+#pragma unroll
+        for (int u = 0; u < NQ; u++) aq[J][NQ * f + u] = __builtin_nontemporal_load(wq + blk * NQ + u);
+        const unsigned dv = __builtin_nontemporal_load(wd + blk);
+        ad[J][f] = kb < nb ? dv : 0u;  // past the row's end: scale 0, the slots add nothing
+      }
     }
   };
-  // B': 128 columns x 256 bytes per chunk, 8 pieces per thread (piece p: column p / 16, 16 bytes p % 16 of the chunk)
-  // (one base pointer per piece, advanced by a chunk = 256 bytes per fetch: the fetches come in chunk order.  Past a column's end --
-  // a ragged last chunk, the look-ahead of the last iterations -- a piece reads the next column's first blocks, or the zeroed slack
-  // behind the planes (launch_gemm_f16w's contract): finite values against zero weights, or never consumed)
-  constexpr int NBD = F == 1 ? 4 : 2;  // register sets of B' pieces in flight (one wave per SIMD needs the longer look-ahead)
+  // B': 128 columns x 256 bytes per chunk, 8 pieces per thread (piece p: column p / 16, 16 bytes p % 16 of the chunk): ONE 32-bit
+  // byte offset per thread, advanced by a chunk = 256 bytes per fetch (the fetches come in chunk order), against a scalar base per
+  // piece -- 16 columns further each (global_load ... s[base], v offset: no per-piece pointer registers).  Columns past n (a ragged
+  // last tile) and the look-ahead of the last iterations read whatever follows in xh -- launch_gemm_f16w's contract keeps that
+  // inside the allocation; finite or not, it meets only output columns that are never stored, zero weights, or is never consumed.
+  constexpr int NBD = (F == 1 && WF == WF_Q4_0) ? 4 : 2;  // register sets of B' pieces in flight (one wave per SIMD: the longer look-ahead)
   i32x4 rb[NBD][G::B_LOADS];
-  const i32x4* pb[G::B_LOADS];
-#pragma unroll
-  for (int u = 0; u < G::B_LOADS; u++) {
-    const int p = tid + 256 * u, col = p >> 4, pc = p & 15;
-    const int gcol = c0 + col < n ? c0 + col : n - 1;
-    pb[u] = xh + ((size_t)gcol * nb + (size_t)ch_lo * KCH) * 4 + pc;
-  }
+  const char* xbase = (const char*)xh + ((size_t)c0 * nb + (size_t)ch_lo * KCH) * 64;  // (uniform)
+  const unsigned xstep = 16u * (unsigned)nb * 64u;                                        // 16 columns
+  unsigned xoff = (unsigned)(tid >> 4) * (unsigned)nb * 64u + (unsigned)(tid & 15) * 16u;
   auto fetch_b = [&](i32x4 (&r)[G::B_LOADS], int ch) {
     (void)ch;
 #pragma unroll
-    for (int u = 0; u < G::B_LOADS; u++) {
-      r[u] = *pb[u];
-      pb[u] += KCH * 4;
-    }
+    for (int u = 0; u < G::B_LOADS; u++) r[u] = *(const i32x4*)(xbase + (size_t)u * xstep + xoff);
+    xoff += KCH * 64;
   };
   auto commit_b = [&](const i32x4 (&r)[G::B_LOADS], int buf) {
     unsigned char* S = f16w_lds + buf * G::BUF;
@@ -202,9 +286,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   asm volatile("" : "+v"(magic));  // pinned in a VGPR (and_or_magic)
 
   fetch_b(rb[0], 0);
-  fetch_a(aq[0], ad[0], 0);
-  fetch_a(aq[1], ad[1], 1);
-  fetch_a(aq[2], ad[2], 2);
+  fetch_a(std::integral_constant<int, 0>{}, 0);
+  fetch_a(std::integral_constant<int, 1>{}, 1);
+  fetch_a(std::integral_constant<int, 2>{}, 2);
+  Q4KF16Consts cs[F];  // Q4_K: the lane's pair's constants of the current super-block (made in the even slot)
   commit_b(rb[0], 0);
   // chunk c sits in rb[c % NBD] from NBD chunks before it is committed (the fetches come in chunk order: pb advances)
 #pragma unroll
@@ -213,11 +298,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   // chunk ch (ring slot J, LDS buffer ch & 1)
   auto chunk = [&](auto Jc, int ch) {
     constexpr int J = decltype(Jc)::value;
-    fetch_a(aq[(J + 3) & 3], ad[(J + 3) & 3], ch + 3);
+    fetch_a(std::integral_constant<int, (J + 3) & 3>{}, ch + 3);
     const unsigned char* S = f16w_lds + (J & 1) * G::BUF + g * G::GSTR + i * G::CSTR;
     f16x2 d2[F];
 #pragma unroll
-    for (int f = 0; f < F; f++) d2[f] = __builtin_bit_cast(f16x2, ad[J][f] | (ad[J][f] << 16));
+    for (int f = 0; f < F; f++) {
+      if constexpr (WF == WF_Q4_K) {
+        if constexpr ((J & 1) == 0) cs[f] = q4k_f16_consts(hq[J >> 1][f], g);
+      } else {
+        d2[f] = __builtin_bit_cast(f16x2, ad[J][f] | (ad[J][f] << 16));
+      }
+    }
     // B' fragments in groups of TG tiles, two groups in registers: group q + 1 is read from LDS while group q is multiplied (left
     // to itself the compiler reads ONE fragment, waits, multiplies: 32 exposed LDS round trips per chunk with the SIMD almost to
     // itself).  The scheduling barriers keep the reads of a group ahead of the MFMAs of the previous one.
@@ -236,7 +327,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
       if (q + 1 < NG) read_group(bq[(q + 1) & 1], q + 1);
       if (q % (T / TG) == 0) {
 #pragma unroll
-        for (int f = 0; f < F; f++) a[f] = unpack_q4_0_f16((unsigned)aq[J][f][s], d2[f], magic);
+        for (int f = 0; f < F; f++) {
+          if constexpr (WF == WF_Q4_0) a[f] = unpack_q4_0_f16((unsigned)aq[J][f][s], d2[f], magic);
+          if constexpr (WF == WF_Q8_0) a[f] = unpack_q8_0_f16((unsigned)aq[J][2 * f][s], (unsigned)aq[J][2 * f + 1][s], d2[f], magic);
+          if constexpr (WF == WF_Q4_K) a[f] = unpack_q4_k_f16((unsigned)aq[J][f][s], cs[f], magic);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -286,21 +381,36 @@ static bool f16w_raise_lds(const crabml_hip_device* dev, const void* fn, int byt
   cur = bytes;
   return true;
 }
-// xh: the rows' pre-scaled f16 planes (launch_q8_0_rows_to_f16) FOLLOWED BY zeroed slack (the kernel's look-ahead reads run up to
-// three chunks past the last column's end: fused.hip allocates 4 KB); returns false when the shape is not covered
-template <int F, int T>
+// xh: the rows' pre-scaled f16 planes (launch_rows_to_f16) inside an allocation of gemm_f16w_xh_bytes(b, k): the kernel reads whole
+// 128-column tiles and up to three chunks past the last column's end; returns false when the shape is not covered
+template <int WF, int F, int T>
 static bool launch_f16w_t(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit) {
   using G = GemmF16Geo<T>;
-  if (!f16w_raise_lds(dev, (const void*)k_gemm_f16w<F, T>, G::LDS_BYTES)) {  // (80 KB of dynamic LDS: raised once per device)
+  if (!f16w_raise_lds(dev, (const void*)k_gemm_f16w<WF, F, T>, G::LDS_BYTES)) {  // (80 KB of dynamic LDS: raised once per device)
     (void)hipGetLastError();
     return false;
   }
   const int col_tiles = (int)((b + G::CW - 1) / G::CW);
-  k_gemm_f16w<F, T><<<dim3(row_tiles * col_tiles * ksplit), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b,
+  k_gemm_f16w<WF, F, T><<<dim3(row_tiles * col_tiles * ksplit), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b,
                                                                                           row_tiles, ksplit);
   return true;
 }
-// nw weight matrices (Q4_0, the same k) against the same rhs rows: out[j] (b, m[j]) = W[j] . x
+size_t gemm_f16w_xh_bytes(size_t rows, size_t k) { return ((rows + 127) / 128 * 128) * k * 2 + 4096; }
+// the weight formats the kernel covers, and the rows' format each pairs with (CpuTensorBuf::quantize's choice: buf/api.rs:142-159)
+bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype) {
+  if (act_qtype == CRABML_HIP_Q8_0) return w_dtype == CRABML_HIP_Q4_0 || w_dtype == CRABML_HIP_Q8_0;
+  return act_qtype == CRABML_HIP_Q8_K && w_dtype == CRABML_HIP_Q4_K;
+}
+template <int WF>
+static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit, int F,
+                            int variant) {
+  if constexpr (WF == WF_Q4_0)
+    if ((variant & 7) == 4) return launch_f16w_t<WF, 2, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
+  if constexpr (WF != WF_Q8_0)  // (Q8_0's 32-byte blocks: two fragments per wave do not fit the 256 registers of two waves per SIMD)
+    if (F == 2) return launch_f16w_t<WF, 2, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
+  return launch_f16w_t<WF, 1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
+}
+// nw weight matrices (one format, the same k) against the same rhs rows: out[j] (b, m[j]) = W[j] . x
 // out2 (nullable; one matrix only): a second (b, m) buffer -- when the launch would leave one wave per SIMD (few row tiles, a long k:
 // ffn_down, wo) the k range is cut in two, the halves' partial tiles go to out and out2 and *split_out = 2: the caller adds them
 // (k_add2_f32).  (Measured and not kept: the halves added with f32 atomics onto a zeroed output -- 32.4k -> 30.1k prompt tok/s.)
@@ -308,8 +418,11 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
                       float* const* out, float* out2, int* split_out) {
   if (split_out) *split_out = 1;
   if (nw < 1 || nw > 3 || k % 32 != 0 || b < 32) return false;
+  const uint32_t dt = w[0]->dtype;
+  if (dt != CRABML_HIP_Q4_0 && dt != CRABML_HIP_Q8_0 && dt != CRABML_HIP_Q4_K) return false;
+  if (dt == CRABML_HIP_Q4_K && k % 256 != 0) return false;
   for (int j = 0; j < nw; j++)
-    if (w[j]->dtype != CRABML_HIP_Q4_0 || m[j] % 4 != 0) return false;
+    if (w[j]->dtype != dt || m[j] % 4 != 0) return false;
   static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = <2,8>, 3 = <1,8>, 4 = <2,4>; +8 = never split k
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_F16W");
@@ -321,14 +434,14 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   // two fragments per wave (every B' fragment read from LDS feeds two MFMAs) when 128-row tiles still cover the chip
   int F = ((mtot + 127) / 128) * col128 >= (size_t)dev->n_cu ? 2 : 1;
   if ((variant & 7) == 1) F = 2;
-  if ((variant & 7) == 3) F = 1;
+  if ((variant & 7) == 3 || dt == CRABML_HIP_Q8_0) F = 1;
   F16wMats mats{};
   int row_tiles = 0;
   for (int j = 0; j < 3; j++) {
     const int jj = j < nw ? j : nw - 1;
     const char* wp = (const char*)w[jj]->ptr;
     mats.wq[j] = (const i32x4*)wp;
-    mats.wd[j] = (const unsigned short*)(wp + w[jj]->wl.off_scale);
+    mats.wd[j] = wp + w[jj]->wl.off_scale;
     mats.out[j] = out[jj];
     mats.out2[j] = out2;
     mats.m[j] = (int)m[jj];
@@ -338,8 +451,9 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   int ksplit = 1;
   if (out2 != nullptr && split_out != nullptr && nw == 1 && (size_t)row_tiles * col128 < (size_t)dev->n_cu * 3 / 2 && k >= 4096 && !(variant & 8)) ksplit = 2;
   if (split_out) *split_out = ksplit;
-  if ((variant & 7) == 4) return launch_f16w_t<2, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
-  return F == 2 ? launch_f16w_t<2, 8>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
+  if (dt == CRABML_HIP_Q8_0) return launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  if (dt == CRABML_HIP_Q4_K) return launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  return launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
 }
 
 }  // namespace crabml_hip
