@@ -1061,7 +1061,7 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   CH_TRY(A(cap * hidden * 4, (void**)&c->pf_u));
   CH_TRY(A(cap * act_bytes(c->qt, dim), (void**)&c->pf_act_dim));
   CH_TRY(A(cap * act_bytes(c->qt, hidden), (void**)&c->pf_act_hid));
-  if ((c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_K) && !c->dev->strict_order) {  // (whole column tiles + the look-ahead's slack)
+  if ((c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && !c->dev->strict_order) {  // (whole column tiles + the look-ahead's slack)
     const size_t xb = gemm_f16w_xh_bytes(cap, dim > hidden ? dim : hidden);
     CH_TRY(A(xb, &c->pf_xh));
     CH_TRY(A(cap * dim * 4, (void**)&c->pf_split));
@@ -1178,7 +1178,15 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       k_norm_f32_rows<12><<<rows, 1024, norm_lds, st>>>(c->pf_x, wn, dim, eps, c->pf_xn, half);
   };
   // CpuTensorBuf::quantize for the rhs of matmul_vec (buf/api.rs:142-159): F32 weights take the rows as they are
-  const void* xh_of = nullptr;  // the planes c->pf_xh was made from (reset whenever planes are rewritten)
+  const void* xh_of = nullptr;  // the planes c->pf_xh was made from (reset whenever planes are rewritten) ...
+  int xh_order = -1;            // ... and the k-slot order it is in (gemm_f16w_order of the weight format)
+  auto rows_to_f16 = [&](const crabml_hip_buf* w, const void* act, int k) {
+    const int order = gemm_f16w_order(w->dtype);
+    if (xh_of == act && xh_order == order) return;
+    launch_rows_to_f16(st, c->qt, w->dtype, act, B, (size_t)k, c->pf_xh);
+    xh_of = act;
+    xh_order = order;
+  };
   auto quant_rows = [&](const float* src, int n, char* planes) -> const void* {
     if (c->qt == CRABML_HIP_F32) return src;
     launch_quantize_act_rows(st, c->qt, src, B, (size_t)n, planes);
@@ -1199,13 +1207,10 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     return h && h[0] == '1' && e && e[0] == '1';
   }();
   const bool f16w = !strict && !gemm_exact_hook && !f16w_off && !(g.flags & CRABML_HIP_LLAMA_PREFILL_INT8_GEMM) &&
-                    (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
+                    (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
     if (f16w && gemm_f16w_covers(w->dtype, c->qt) && (c->qt != CRABML_HIP_Q8_K || k % 256 == 0)) {
-      if (xh_of != act) {
-        launch_rows_to_f16(st, c->qt, act, B, (size_t)k, c->pf_xh);
-        xh_of = act;
-      }
+      rows_to_f16(w, act, k);
       const size_t mm = (size_t)m;
       int split = 1;
       // (wo / ffn_down: few row tiles, a long k -- two workgroups per tile, the second half's partial tiles in pf_split, added here)
@@ -1266,8 +1271,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     bool qkv_done = false;  // llama2.rs:244-246
     if (f16w && gemm_f16w_covers(c->wq[l]->dtype, c->qt) && c->wk[l]->dtype == c->wq[l]->dtype && c->wv[l]->dtype == c->wq[l]->dtype) {
       // the three GEMMs of the same rhs as ONE launch (the 1024-row k / v matrices alone leave most of the chip idle)
-      launch_rows_to_f16(st, c->qt, a, B, (size_t)dim, c->pf_xh);
-      xh_of = a;
+      rows_to_f16(c->wq[l], a, dim);
       const crabml_hip_buf* ws[3] = {c->wq[l], c->wk[l], c->wv[l]};
       const size_t ms[3] = {(size_t)dim, (size_t)kv_dim, (size_t)kv_dim};
       float* outs[3] = {c->pf_q, c->pf_k, c->pf_v};
@@ -1324,10 +1328,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     bool gu_done = false;  // llama2.rs:620-630
     if (f16w && gemm_f16w_covers(c->gate[l]->dtype, c->qt) && c->up[l]->dtype == c->gate[l]->dtype) {
       // gate and up as ONE launch: 2 x 448 workgroups fill the last round of the chip better than 448 twice
-      if (xh_of != a) {
-        launch_rows_to_f16(st, c->qt, a, B, (size_t)dim, c->pf_xh);
-        xh_of = a;
-      }
+      rows_to_f16(c->gate[l], a, dim);
       const crabml_hip_buf* ws[2] = {c->gate[l], c->up[l]};
       const size_t ms[2] = {(size_t)hidden, (size_t)hidden};
       float* outs[2] = {c->pf_g, c->pf_u};

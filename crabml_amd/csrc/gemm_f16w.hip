@@ -1,5 +1,5 @@
 // gemm_f16w.hip -- the FAST prompt pass's weight GEMM (crabml_hip_llama_prefill on the fast device; Q4_0 / Q8_0 weights x Q8_0 rows,
-// Q4_K weights x Q8_K rows): weight-stationary on the f16 matrix cores.
+// Q4_1 x Q8_1, Q4_K / Q6_K x Q8_K): weight-stationary on the f16 matrix cores.
 //
 // matmul_vec with a batched rhs is `C[b, m] = W[m, k] . x[b, k]` (matmul_vec.rs:41-76: the (b, k) rhs contract; llama2.rs:111-129).
 // The bit-exact form (gemm_mfma.hip: exact int8 tiles, then the reference's per-block `sumf += (sumi as f32 * d_w) * d_x`) pays
@@ -25,7 +25,13 @@
 // class 4 h + s: elements 8 k + 4 h + s of sub-blocks 2 g (low nibbles) and 2 g + 1 (high); common.hpp) and, once per super-block, the
 // 16-byte header.  A' = n * fl16(d * sc) - fl16(dmin * m) (buf_q4_k.rs:225-263's d * sc * q - dmin * m, per element): n exact, the
 // product exact inside ONE v_pk_fma_f16, so three f16 roundings per weight element; B' = q_x * d_x from the Q8_K planes in the
-// matching slot order (k_rows_to_f16<true>).#include <cstdlib>
+// matching slot order (k_rows_to_f16<1>).
+// Q4_1 weights (Q8_1 rows): Q4_0's loads and slot order; A' = n * d + m in one v_pk_fma_f16 (buf_q4_1.rs: d * q + m per element --
+// the rows' `s` term of the integer form is not needed).
+// Q6_K weights (Q8_K rows): a chunk is one 128-element half of a super-block -- lane (i, g) loads 16 bytes of ql (g < 2: ql[0..31],
+// the low nibbles are quarter 0, the high ones quarter 2; g >= 2: ql[32..63], quarters 1 and 3; buf_q6_k.rs:21-48) and the 16 bytes
+// of qh that carry the same l's two high bits, and once per super-block the 16 int8 scales and d.  A' = (q - 32) * fl16(d * sc),
+// q - 32 exact.  Its own B' slot order (k_rows_to_f16<2>): a Q4_K_M layer converts the rows once per order it needs.#include <cstdlib>
 #include <type_traits>
 
 #include "devutil.hpp"
@@ -46,7 +52,8 @@ __device__ __forceinline__ int f16w_slot_elem(int slot) {
 }
 // Q8_K rows (Q4_K weights): slot group kb = 4 cc + g of chunk cc = (super-block, half h), step s = class l = 4 h + s of pair g;
 // slot e: k = 0, 2, 1, 3 of sub-block 2 g (e < 4) / 2 g + 1 (e >= 4), element 8 k + l -- unpack_q4_k_f16's order
-template <bool Q8K>
+// Q6_K weights: chunk cc = (super-block, half), g, step s: element 128 half + 32 (g >> 1) + 16 (g & 1) + 4 s + k (e < 4), + 64 (e >= 4)
+template <int ORDER>  // 0: Q8_0 / Q8_1 rows (block order); 1: Q8_K rows for Q4_K weights; 2: Q8_K rows for Q6_K weights
 __global__ __launch_bounds__(256) void k_rows_to_f16(const char* __restrict__ planes, size_t row_stride, size_t off_d, int nb,
                                                      unsigned short* __restrict__ xh) {
   const size_t col = blockIdx.y;
@@ -57,7 +64,13 @@ __global__ __launch_bounds__(256) void k_rows_to_f16(const char* __restrict__ pl
   float d;
   const signed char* q;
   int at[8];
-  if constexpr (Q8K) {
+  if constexpr (ORDER == 2) {
+    const int cc = kb >> 2, g = kb & 3, sb = cc >> 1;
+    d = ((const float*)(p + off_d))[sb];
+    q = (const signed char*)p + sb * 256 + 128 * (cc & 1) + 32 * (g >> 1) + 16 * (g & 1) + 4 * s;
+#pragma unroll
+    for (int e = 0; e < 8; e++) at[e] = (e >= 4 ? 64 : 0) + ((e >> 1) & 1) + 2 * (e & 1);
+  } else if constexpr (ORDER == 1) {
     const int cc = kb >> 2, g = kb & 3, sb = cc >> 1, l = 4 * (cc & 1) + s;
     d = ((const float*)(p + off_d))[sb];
     q = (const signed char*)p + sb * 256 + 64 * g;
@@ -76,17 +89,18 @@ __global__ __launch_bounds__(256) void k_rows_to_f16(const char* __restrict__ pl
   *(i32x4*)dst = i32x4{(int)(o[0] | ((unsigned)o[1] << 16)), (int)(o[2] | ((unsigned)o[3] << 16)), (int)(o[4] | ((unsigned)o[5] << 16)),
                        (int)(o[6] | ((unsigned)o[7] << 16))};
 }
-// planes: `rows` sets of Q8_0 / Q8_K activation planes (act_layout(qtype, k)), row_stride bytes apart
-bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, const void* planes, size_t rows, size_t k, void* xh) {
+// planes: `rows` sets of activation planes (act_layout(act_qtype, k)); the slot order is the one the weight format w_dtype reads
+int gemm_f16w_order(uint32_t w_dtype) { return w_dtype == CRABML_HIP_Q4_K ? 1 : w_dtype == CRABML_HIP_Q6_K ? 2 : 0; }
+bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, uint32_t w_dtype, const void* planes, size_t rows, size_t k, void* xh) {
+  if (!gemm_f16w_covers(w_dtype, act_qtype) || (act_qtype == CRABML_HIP_Q8_K && k % 256 != 0)) return false;
   const ActLayout al = act_layout(act_qtype, k);
   const int nb = (int)(k / 32);
   const dim3 grid((unsigned)((nb * 4 + 255) / 256), (unsigned)rows);
-  if (act_qtype == CRABML_HIP_Q8_0)
-    k_rows_to_f16<false><<<grid, 256, 0, st>>>((const char*)planes, al.total, al.off_d, nb, (unsigned short*)xh);
-  else if (act_qtype == CRABML_HIP_Q8_K && k % 256 == 0)
-    k_rows_to_f16<true><<<grid, 256, 0, st>>>((const char*)planes, al.total, al.off_d, nb, (unsigned short*)xh);
-  else
-    return false;
+  switch (gemm_f16w_order(w_dtype)) {
+    case 0: k_rows_to_f16<0><<<grid, 256, 0, st>>>((const char*)planes, al.total, al.off_d, nb, (unsigned short*)xh); break;
+    case 1: k_rows_to_f16<1><<<grid, 256, 0, st>>>((const char*)planes, al.total, al.off_d, nb, (unsigned short*)xh); break;
+    default: k_rows_to_f16<2><<<grid, 256, 0, st>>>((const char*)planes, al.total, al.off_d, nb, (unsigned short*)xh); break;
+  }
   return true;
 }
 
@@ -153,7 +167,23 @@ __device__ __forceinline__ Q4KF16Consts q4k_f16_consts(i32x4 hdr, int g) {
   return Q4KF16Consts{f16x2{c_lo, c_lo}, f16x2{o_lo, o_lo}, f16x2{c_hi, c_hi}, f16x2{o_hi, o_hi}};
 }
 
-enum { WF_Q4_0 = 0, WF_Q8_0 = 1, WF_Q4_K = 2 };  // the weight format of a GEMM
+// Q6_K: one dword of ql and the matching dword of qh, already shifted so that bits 0-1 of each byte belong to the low nibbles' quarter
+// and bits 4-5 to the high nibbles'
+__device__ __forceinline__ unsigned and_or_hi2(unsigned x, unsigned acc) {
+  unsigned r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(0x00300030u), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ f16x8 unpack_q6_k_f16(unsigned w, unsigned hw, f16x2 c_lo, f16x2 c_hi, unsigned magic) {
+  const f16x2 bias = {(_Float16)-1056.0f, (_Float16)-1056.0f};  // 1024 + q -> q - 32
+  const unsigned u0 = and_or_hi2(hw << 4, and_or_magic(w, magic)), u1 = and_or_hi2(hw >> 4, and_or_magic(w >> 8, magic));
+  const unsigned u2 = and_or_hi2(hw, and_or_magic(w >> 4, magic)), u3 = and_or_hi2(hw >> 8, and_or_magic(w >> 12, magic));
+  const f16x2 p0 = (__builtin_bit_cast(f16x2, u0) + bias) * c_lo, p1 = (__builtin_bit_cast(f16x2, u1) + bias) * c_lo;
+  const f16x2 p2 = (__builtin_bit_cast(f16x2, u2) + bias) * c_hi, p3 = (__builtin_bit_cast(f16x2, u3) + bias) * c_hi;
+  return f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+
+enum { WF_Q4_0 = 0, WF_Q8_0 = 1, WF_Q4_K = 2, WF_Q6_K = 3, WF_Q4_1 = 4 };  // the weight format of a GEMM
 
 template <int T_>
 struct GemmF16Geo {
@@ -173,7 +203,9 @@ struct GemmF16Geo {
 // chip idle for a whole serial k loop): row tile rt belongs to the first matrix whose cumulative tile count exceeds it.
 struct F16wMats {
   const i32x4* wq[3];  // the quant plane
-  const char* wd[3];   // the scale plane (f16 per block; Q4_K: the 16-byte headers)
+  const char* wd[3];   // the scale plane (f16 per block; Q4_1: (d, m); Q4_K: the 16-byte headers; Q6_K: the qh plane)
+  const char* ws2[3];  // Q6_K: the int8 scales (16 per super-block) ...
+  const char* ws3[3];  // ... and d (f16 per super-block)
   float* out[3];
   float* out2[3];    // ksplit = 2: the second k half's partial tiles (the caller adds the two)
   int m[3];
@@ -208,6 +240,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   const char* __restrict__ wsc = ti == 0 ? mats.wd[0] : ti == 1 ? mats.wd[1] : mats.wd[2];
   const unsigned short* __restrict__ wd = (const unsigned short*)wsc;
   const i32x4* __restrict__ wh = (const i32x4*)wsc;
+  const i32x4* __restrict__ w6s = (const i32x4*)(ti == 0 ? mats.ws2[0] : ti == 1 ? mats.ws2[1] : mats.ws2[2]);
+  const unsigned short* __restrict__ w6d = (const unsigned short*)(ti == 0 ? mats.ws3[0] : ti == 1 ? mats.ws3[1] : mats.ws3[2]);
   float* __restrict__ out = ks == 0 ? (ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2]) : (ti == 0 ? mats.out2[0] : ti == 1 ? mats.out2[1] : mats.out2[2]);
   const int m = ti == 0 ? mats.m[0] : ti == 1 ? mats.m[1] : mats.m[2];
   const int rt_l = rt - (ti == 0 ? 0 : ti == 1 ? mats.tiles_end[0] : mats.tiles_end[1]);
@@ -215,17 +249,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   // this workgroup's chunks: [ch_lo, ch_lo + nchunks) of the row's ceil(nb / KCH)
   // (Q4_K: an even chunk is half 0 of its super-block -- the pieces start on super-block boundaries)
   const int all_chunks = (nb + KCH - 1) / KCH;
-  const int per_piece = WF == WF_Q4_K ? (((all_chunks + ksplit - 1) / ksplit + 1) & ~1) : (all_chunks + ksplit - 1) / ksplit;
+  const int per_piece = (WF == WF_Q4_K || WF == WF_Q6_K) ? (((all_chunks + ksplit - 1) / ksplit + 1) & ~1) : (all_chunks + ksplit - 1) / ksplit;
   const int ch_lo = ks * per_piece;
   const int nchunks = all_chunks - ch_lo < per_piece ? all_chunks - ch_lo : per_piece;  // (>= 1: the launcher splits only long rows)
 
   // A: the lane's block (row i of fragment f, block kb0 + g) and its scale.  HBM latency is several chunk times (a chunk is ~0.4 us of
   // MFMAs and a workgroup has the SIMD almost to itself): a RING of four register sets, chunk c + 3 requested while chunk c is
   // multiplied; B' (L2-resident) two chunks ahead in two register sets.  All ring indices are compile-time (chunk loop unrolled by 4).
-  constexpr int NQ = WF == WF_Q8_0 ? 2 : 1;  // 16-byte quant loads per fragment and chunk
+  constexpr int NQ = (WF == WF_Q8_0 || WF == WF_Q6_K) ? 2 : 1;  // 16-byte quant loads per fragment and chunk
   i32x4 aq[4][NQ * F];
-  unsigned ad[4][F];   // Q4_0 / Q8_0: the block's scale
-  i32x4 hq[2][F];      // Q4_K: the super-block header of ring slots (0, 1) / (2, 3), fetched with the even slot
+  unsigned ad[4][F];   // Q4_0 / Q8_0: the block's scale; Q4_1: d | m << 16
+  i32x4 hq[2][F];      // Q4_K: the super-block header of ring slots (0, 1) / (2, 3), fetched with the even slot; Q6_K: the 16 scales
+  unsigned hd[2][F];   // Q6_K: d
   auto fetch_a = [&](auto Jc, int ch) {
     constexpr int J = decltype(Jc)::value;
     const int cc = ch_lo + (ch < nchunks ? ch : nchunks - 1);  // (past the end: re-read the last chunk, never consumed)
@@ -238,6 +273,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
         aq[J][f] = __builtin_nontemporal_load(wq + blk * 8 + 2 * g + h);
         if constexpr ((J & 1) == 0) hq[J >> 1][f] = __builtin_nontemporal_load(wh + blk);
       }
+    } else if constexpr (WF == WF_Q6_K) {
+      const int nsb = nb >> 3, sb = cc >> 1, half = cc & 1;
+#pragma unroll
+      for (int f = 0; f < F; f++) {
+        const int row = r0 + 16 * f + i;
+        const size_t blk = (size_t)(row < m ? row : m - 1) * nsb + sb;
+        aq[J][2 * f] = __builtin_nontemporal_load(wq + blk * 8 + 4 * half + g);
+        aq[J][2 * f + 1] = __builtin_nontemporal_load(wh + blk * 4 + 2 * half + (g & 1));  // (wh: the qh plane, 64 bytes per super-block)
+        if constexpr ((J & 1) == 0) {
+          hq[J >> 1][f] = __builtin_nontemporal_load(w6s + blk);
+          hd[J >> 1][f] = __builtin_nontemporal_load(w6d + blk);
+        }
+      }
     } else {
       const int kb = cc * KCH + g;
       const int gkb = kb < nb ? kb : nb - 1;
@@ -247,8 +295,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
         const size_t blk = (size_t)(row < m ? row : m - 1) * nb + gkb;
 #pragma unroll
         for (int u = 0; u < NQ; u++) aq[J][NQ * f + u] = __builtin_nontemporal_load(wq + blk * NQ + u);
-        const unsigned dv = __builtin_nontemporal_load(wd + blk);
-        ad[J][f] = kb < nb ? dv : 0u;  // past the row's end: scale 0, the slots add nothing
+        unsigned dv;
+        if constexpr (WF == WF_Q4_1)
+          dv = __builtin_nontemporal_load((const unsigned*)wsc + blk);
+        else
+          dv = __builtin_nontemporal_load(wd + blk);
+        ad[J][f] = kb < nb ? dv : 0u;  // past the row's end: scale 0 (and m 0), the slots add nothing
       }
     }
   };
@@ -289,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   fetch_a(std::integral_constant<int, 0>{}, 0);
   fetch_a(std::integral_constant<int, 1>{}, 1);
   fetch_a(std::integral_constant<int, 2>{}, 2);
-  Q4KF16Consts cs[F];  // Q4_K: the lane's pair's constants of the current super-block (made in the even slot)
+  Q4KF16Consts cs[F];  // Q4_K: the lane's pair's constants of the current super-block (made in the even slot); Q4_1: (d, m); Q6_K: d sc
   commit_b(rb[0], 0);
   // chunk c sits in rb[c % NBD] from NBD chunks before it is committed (the fetches come in chunk order: pb advances)
 #pragma unroll
@@ -305,6 +357,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
     for (int f = 0; f < F; f++) {
       if constexpr (WF == WF_Q4_K) {
         if constexpr ((J & 1) == 0) cs[f] = q4k_f16_consts(hq[J >> 1][f], g);
+      } else if constexpr (WF == WF_Q6_K) {
+        // the lane's two scales of a half: sc[8 half + (g & 1) + 2 (g >> 1)] (low nibbles' quarter) and 4 further (high nibbles');
+        // both halves' in the even slot (the odd slot's fetch re-uses the header registers): c_* = half 0, o_* = half 1
+        if constexpr ((J & 1) == 0) {
+          const int sh = 8 * ((g & 1) + 2 * (g >> 1));
+          const float d = h2f((unsigned short)hd[J >> 1][f]);
+          _Float16 c[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) c[u] = (_Float16)(d * (float)(signed char)(((unsigned)hq[J >> 1][f][u] >> sh) & 0xffu));
+          cs[f].c_lo = f16x2{c[0], c[0]};
+          cs[f].c_hi = f16x2{c[1], c[1]};
+          cs[f].o_lo = f16x2{c[2], c[2]};
+          cs[f].o_hi = f16x2{c[3], c[3]};
+        }
+      } else if constexpr (WF == WF_Q4_1) {
+        const unsigned dm = ad[J][f];
+        cs[f].c_lo = cs[f].c_hi = __builtin_bit_cast(f16x2, (dm & 0xffffu) | (dm << 16));
+        cs[f].o_lo = cs[f].o_hi = __builtin_bit_cast(f16x2, (dm >> 16) | (dm & 0xffff0000u));
       } else {
         d2[f] = __builtin_bit_cast(f16x2, ad[J][f] | (ad[J][f] << 16));
       }
@@ -330,7 +400,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
         for (int f = 0; f < F; f++) {
           if constexpr (WF == WF_Q4_0) a[f] = unpack_q4_0_f16((unsigned)aq[J][f][s], d2[f], magic);
           if constexpr (WF == WF_Q8_0) a[f] = unpack_q8_0_f16((unsigned)aq[J][2 * f][s], (unsigned)aq[J][2 * f + 1][s], d2[f], magic);
-          if constexpr (WF == WF_Q4_K) a[f] = unpack_q4_k_f16((unsigned)aq[J][f][s], cs[f], magic);
+          if constexpr (WF == WF_Q4_K || WF == WF_Q4_1) a[f] = unpack_q4_k_f16((unsigned)aq[J][f][s], cs[f], magic);
+          if constexpr (WF == WF_Q6_K)
+            a[f] = unpack_q6_k_f16((unsigned)aq[J][2 * f][s], (unsigned)aq[J][2 * f + 1][s] >> (2 * (g >> 1)), (J & 1) ? cs[f].o_lo : cs[f].c_lo,
+                                   (J & 1) ? cs[f].o_hi : cs[f].c_hi, magic);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -399,14 +472,15 @@ size_t gemm_f16w_xh_bytes(size_t rows, size_t k) { return ((rows + 127) / 128 * 
 // the weight formats the kernel covers, and the rows' format each pairs with (CpuTensorBuf::quantize's choice: buf/api.rs:142-159)
 bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype) {
   if (act_qtype == CRABML_HIP_Q8_0) return w_dtype == CRABML_HIP_Q4_0 || w_dtype == CRABML_HIP_Q8_0;
-  return act_qtype == CRABML_HIP_Q8_K && w_dtype == CRABML_HIP_Q4_K;
+  if (act_qtype == CRABML_HIP_Q8_1) return w_dtype == CRABML_HIP_Q4_1;
+  return act_qtype == CRABML_HIP_Q8_K && (w_dtype == CRABML_HIP_Q4_K || w_dtype == CRABML_HIP_Q6_K);
 }
 template <int WF>
 static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit, int F,
                             int variant) {
   if constexpr (WF == WF_Q4_0)
     if ((variant & 7) == 4) return launch_f16w_t<WF, 2, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
-  if constexpr (WF != WF_Q8_0)  // (Q8_0's 32-byte blocks: two fragments per wave do not fit the 256 registers of two waves per SIMD)
+  if constexpr (WF != WF_Q8_0 && WF != WF_Q6_K)  // (32 bytes per lane and chunk: two fragments per wave do not fit the 256 registers of two waves per SIMD)
     if (F == 2) return launch_f16w_t<WF, 2, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
   return launch_f16w_t<WF, 1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
 }
@@ -419,8 +493,8 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   if (split_out) *split_out = 1;
   if (nw < 1 || nw > 3 || k % 32 != 0 || b < 32) return false;
   const uint32_t dt = w[0]->dtype;
-  if (dt != CRABML_HIP_Q4_0 && dt != CRABML_HIP_Q8_0 && dt != CRABML_HIP_Q4_K) return false;
-  if (dt == CRABML_HIP_Q4_K && k % 256 != 0) return false;
+  if (dt != CRABML_HIP_Q4_0 && dt != CRABML_HIP_Q8_0 && dt != CRABML_HIP_Q4_K && dt != CRABML_HIP_Q6_K && dt != CRABML_HIP_Q4_1) return false;
+  if ((dt == CRABML_HIP_Q4_K || dt == CRABML_HIP_Q6_K) && k % 256 != 0) return false;
   for (int j = 0; j < nw; j++)
     if (w[j]->dtype != dt || m[j] % 4 != 0) return false;
   static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = <2,8>, 3 = <1,8>, 4 = <2,4>; +8 = never split k
@@ -434,7 +508,7 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   // two fragments per wave (every B' fragment read from LDS feeds two MFMAs) when 128-row tiles still cover the chip
   int F = ((mtot + 127) / 128) * col128 >= (size_t)dev->n_cu ? 2 : 1;
   if ((variant & 7) == 1) F = 2;
-  if ((variant & 7) == 3 || dt == CRABML_HIP_Q8_0) F = 1;
+  if ((variant & 7) == 3 || dt == CRABML_HIP_Q8_0 || dt == CRABML_HIP_Q6_K) F = 1;
   F16wMats mats{};
   int row_tiles = 0;
   for (int j = 0; j < 3; j++) {
@@ -442,6 +516,8 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
     const char* wp = (const char*)w[jj]->ptr;
     mats.wq[j] = (const i32x4*)wp;
     mats.wd[j] = wp + w[jj]->wl.off_scale;
+    mats.ws2[j] = wp + w[jj]->wl.off_scale + w[jj]->wl.n_blocks * 64;  // (Q6_K: ql | qh | scales | d, common.hpp)
+    mats.ws3[j] = wp + w[jj]->wl.off_scale + w[jj]->wl.n_blocks * 80;
     mats.out[j] = out[jj];
     mats.out2[j] = out2;
     mats.m[j] = (int)m[jj];
@@ -453,6 +529,8 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   if (split_out) *split_out = ksplit;
   if (dt == CRABML_HIP_Q8_0) return launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
   if (dt == CRABML_HIP_Q4_K) return launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  if (dt == CRABML_HIP_Q6_K) return launch_f16w_fmt<WF_Q6_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  if (dt == CRABML_HIP_Q4_1) return launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
   return launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
 }
 

@@ -41,11 +41,12 @@ struct RepackPlan {
 void launch_repack(hipStream_t st, const void* raw, void* base, size_t blk0, size_t n_blocks, int bb, const RepackPlan& plan);
 void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t n_blocks);
 void launch_q4k_class_major(hipStream_t st, void* qs_plane, size_t blk0, size_t n_blocks);
-// gemm_f16w.hip: the fast prompt pass's weight-stationary f16 GEMM (Q4_0 / Q8_0 weights x Q8_0 rows, Q4_K x Q8_K) and the rows'
-// pre-scaled f16 planes it reads (one slot order per ROW format: Q4_0 and Q8_0 weights share theirs)
+// gemm_f16w.hip: the fast prompt pass's weight-stationary f16 GEMM (Q4_0 / Q8_0 weights x Q8_0 rows, Q4_1 x Q8_1, Q4_K / Q6_K x Q8_K)
+// and the rows' pre-scaled f16 planes it reads, in the k-slot order of the weight format (gemm_f16w_order: Q4_K and Q6_K have their own)
 bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype);
+int gemm_f16w_order(uint32_t w_dtype);
 size_t gemm_f16w_xh_bytes(size_t rows, size_t k);  // the allocation behind xh: whole 128-row tiles + the look-ahead's slack
-bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, const void* planes, size_t rows, size_t k, void* xh);
+bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, uint32_t w_dtype, const void* planes, size_t rows, size_t k, void* xh);
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
                       float* const* out, float* out2 = nullptr, int* split_out = nullptr);
 void launch_add2_f32(hipStream_t st, float* a, const float* b, size_t n);

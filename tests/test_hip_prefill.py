@@ -254,16 +254,17 @@ def _record_f16w(key, row):
 
 @pytest.mark.parametrize("fmt,shape,n", [("Q4_0", "tiny-gqa", 200), ("Q4_0", "15m", 173), ("Q4_0", "tiny-hd128", 384),
                                          ("Q8_0", "tiny-gqa", 200), ("Q8_0", "15m", 173), ("Q4_K", "tiny-gqa", 200),
-                                         ("Q4_K", "tiny-hd128", 384), ("Q4_K_M", "tiny-gqa", 173)])
+                                         ("Q4_K", "tiny-hd128", 384), ("Q4_K_M", "tiny-gqa", 173), ("Q6_K", "tiny-gqa", 200),
+                                         ("Q6_K", "tiny-hd128", 384), ("Q4_1", "tiny-gqa", 200), ("Q4_1", "15m", 173)])
 def test_fast_prompt_pass_f16_weight_gemm(ca, fmt, shape, n):
-    """Passes of >= 160 rows, Q4_0 / Q8_0 / Q4_K weights, fast device: the weight GEMMs run on the f16 matrix cores with the block
+    """Passes of >= 160 rows, Q4_0 / Q8_0 / Q4_1 / Q4_K / Q6_K weights, fast device: the weight GEMMs run on the f16 matrix cores with the block
     scales folded into the operands (k_gemm_f16w, gemm_f16w.hip -- a stated deviation of the fast tier: two (Q4_K: three) f16
     roundings per product instead of exact integer block dots).  Against the oracle's token loop it must sit inside the fast
     tolerance the int8 kernels are held to; against the int8 kernels (A/B flag) the two passes must agree inside it; the greedy
     continuation starts with the same token.  Shapes: k = 512 / 1024 (4 and 8 whole chunks; 2 and 4 super-blocks), 288 / 768 (the
     15M model: 9 and 24 blocks -- a ragged last chunk, rows that are no multiple of 64), ragged last column tiles (200 = 128 + 72,
-    173 = 128 + 45), three full tiles (384).  Q4_K_M: the llama.cpp mix -- the Q6_K matrices of a layer take the int8 kernels, the
-    q | k | v launch splits where v is Q6_K."""
+    173 = 128 + 45), three full tiles (384).  Q4_K_M: the llama.cpp mix -- the q | k | v launch splits where v is Q6_K, and the rows'
+    f16 planes are made once per k-slot order (Q4_K's and Q6_K's differ)."""
     if fmt == "Q4_K_M":
         model = synth.build_model(synth.SHAPES[shape], synth.Q4_K, seed=91, k_m_mix=True)
         tol_fmt = "Q4_K"
