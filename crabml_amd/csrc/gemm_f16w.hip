@@ -309,7 +309,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   // piece -- 16 columns further each (global_load ... s[base], v offset: no per-piece pointer registers).  Columns past n (a ragged
   // last tile) and the look-ahead of the last iterations read whatever follows in xh -- launch_gemm_f16w's contract keeps that
   // inside the allocation; finite or not, it meets only output columns that are never stored, zero weights, or is never consumed.
-  constexpr int NBD = (F == 1 && WF == WF_Q4_0) ? 4 : 2;  // register sets of B' pieces in flight (one wave per SIMD: the longer look-ahead)
+  // register sets of B' pieces in flight (one wave per SIMD: the longer look-ahead; the 32-byte-per-lane formats with two fragments:
+  // one set -- B' is L2-resident and a chunk of 64 MFMAs per wave is longer than an L2 round trip)
+  constexpr int NBD = (F == 1 && WF == WF_Q4_0) ? 4 : (F == 2 && (WF == WF_Q8_0 || WF == WF_Q6_K)) ? 1 : 2;
   i32x4 rb[NBD][G::B_LOADS];
   const char* xbase = (const char*)xh + ((size_t)c0 * nb + (size_t)ch_lo * KCH) * 64;  // (uniform)
   const unsigned xstep = 16u * (unsigned)nb * 64u;                                        // 16 columns
@@ -480,8 +482,7 @@ static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int ro
                             int variant) {
   if constexpr (WF == WF_Q4_0)
     if ((variant & 7) == 4) return launch_f16w_t<WF, 2, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
-  if constexpr (WF != WF_Q8_0 && WF != WF_Q6_K)  // (32 bytes per lane and chunk: two fragments per wave do not fit the 256 registers of two waves per SIMD)
-    if (F == 2) return launch_f16w_t<WF, 2, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
+  if (F == 2) return launch_f16w_t<WF, 2, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
   return launch_f16w_t<WF, 1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
 }
 // nw weight matrices (one format, the same k) against the same rhs rows: out[j] (b, m[j]) = W[j] . x
@@ -508,7 +509,7 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   // two fragments per wave (every B' fragment read from LDS feeds two MFMAs) when 128-row tiles still cover the chip
   int F = ((mtot + 127) / 128) * col128 >= (size_t)dev->n_cu ? 2 : 1;
   if ((variant & 7) == 1) F = 2;
-  if ((variant & 7) == 3 || dt == CRABML_HIP_Q8_0 || dt == CRABML_HIP_Q6_K) F = 1;
+  if ((variant & 7) == 3) F = 1;
   F16wMats mats{};
   int row_tiles = 0;
   for (int j = 0; j < 3; j++) {
