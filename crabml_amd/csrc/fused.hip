@@ -181,7 +181,8 @@ struct crabml_hip_llama {
   float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr, *pf_qr = nullptr, *pf_attn = nullptr,
         *pf_tmp = nullptr, *pf_g = nullptr, *pf_u = nullptr;
   char *pf_act_dim = nullptr, *pf_act_hid = nullptr;
-  float* pf_split = nullptr;  // ... and the second k half's partial (rows, dim) tiles of a split wo / ffn_down GEMM
+  float* pf_split = nullptr;  // ... and pf_split_floats of scratch for the partial tiles of its k pieces
+  size_t pf_split_floats = 0;
   void* pf_xh = nullptr;  // the fast pass's f16 GEMMs: the current rhs rows as pre-scaled f16 (gemm_f16w.hip), gemm_f16w_xh_bytes(cap, max(dim, hidden))
   float* pf_scores = nullptr;          // long prompts: [PF_LONG_ROWS][n_heads][seq_len] f32 scores
   unsigned short* pf_p16 = nullptr;    //               and f16 probabilities, allocated on first use
@@ -1064,7 +1065,9 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   if ((c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && !c->dev->strict_order) {  // (whole column tiles + the look-ahead's slack)
     const size_t xb = gemm_f16w_xh_bytes(cap, dim > hidden ? dim : hidden);
     CH_TRY(A(xb, &c->pf_xh));
-    CH_TRY(A(cap * dim * 4, (void**)&c->pf_split));
+    // (the widest split launch is q | k | v; up to 7 partial buffers of a short pass, 3 of a full one)
+    c->pf_split_floats = (cap + 1024) * (dim + 2 * kv_dim > hidden ? dim + 2 * kv_dim : hidden);
+    CH_TRY(A(c->pf_split_floats * 4, (void**)&c->pf_split));
     CH_HIP(c->dev, hipMemsetAsync(c->pf_xh, 0, xb, c->dev->stream));
   }
   c->pf_cap = cap;
@@ -1206,19 +1209,18 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const char* e = getenv("CRABML_HIP_GEMM_INT8");
     return h && h[0] == '1' && e && e[0] == '1';
   }();
+  static const int f16w_min = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W_MIN=rows): the smallest pass that takes it
+    const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+    const char* e = getenv("CRABML_HIP_F16W_MIN");
+    return h && h[0] == '1' && e ? atoi(e) : 32;
+  }();
   const bool f16w = !strict && !gemm_exact_hook && !f16w_off && !(g.flags & CRABML_HIP_LLAMA_PREFILL_INT8_GEMM) &&
-                    (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= 160;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
+                    (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= f16w_min;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
     if (f16w && gemm_f16w_covers(w->dtype, c->qt) && (c->qt != CRABML_HIP_Q8_K || k % 256 == 0)) {
       rows_to_f16(w, act, k);
       const size_t mm = (size_t)m;
-      int split = 1;
-      // (wo / ffn_down: few row tiles, a long k -- two workgroups per tile, the second half's partial tiles in pf_split, added here)
-      float* second = (out == c->pf_tmp && (mm * B) % 4 == 0) ? c->pf_split : nullptr;
-      if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out, second, &split)) {
-        if (split == 2) launch_add2_f32(st, out, second, mm * B);
-        return 0;
-      }
+      if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out, c->pf_split, c->pf_split_floats)) return 0;
     }
     if (!strict) {
       return launch_gemv(dev, w, m, k, act, B, out, nullptr, !gemm_exact_hook);
@@ -1275,7 +1277,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       const crabml_hip_buf* ws[3] = {c->wq[l], c->wk[l], c->wv[l]};
       const size_t ms[3] = {(size_t)dim, (size_t)kv_dim, (size_t)kv_dim};
       float* outs[3] = {c->pf_q, c->pf_k, c->pf_v};
-      qkv_done = launch_gemm_f16w(dev, ws, ms, 3, (size_t)dim, c->pf_xh, B, outs);
+      qkv_done = launch_gemm_f16w(dev, ws, ms, 3, (size_t)dim, c->pf_xh, B, outs, c->pf_split, c->pf_split_floats);
     }
     if (!qkv_done) {
       CH_TRY(gemm(c->wq[l], dim, dim, a, c->pf_q));
@@ -1332,7 +1334,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       const crabml_hip_buf* ws[2] = {c->gate[l], c->up[l]};
       const size_t ms[2] = {(size_t)hidden, (size_t)hidden};
       float* outs[2] = {c->pf_g, c->pf_u};
-      gu_done = launch_gemm_f16w(dev, ws, ms, 2, (size_t)dim, c->pf_xh, B, outs);
+      gu_done = launch_gemm_f16w(dev, ws, ms, 2, (size_t)dim, c->pf_xh, B, outs, c->pf_split, c->pf_split_floats);
     }
     if (!gu_done) {
       CH_TRY(gemm(c->gate[l], hidden, dim, a, c->pf_g));

@@ -104,12 +104,24 @@ bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, uint32_t w_dtype, co
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_add2_f32(float* __restrict__ a, const float* __restrict__ b, size_t n4) {
+// the k pieces of a split GEMM: out[j] += part[j][0] + part[j][1] + ... in piece order (deterministic), every matrix of the launch at once
+struct F16wParts {
+  float* out[3];
+  const float* part[3];  // matrix j's first partial; the next pieces follow pstride floats apart
+  size_t end4[3];        // cumulative f32x4 counts
+  size_t pstride;
+  int nparts;
+};
+__global__ __launch_bounds__(256) void k_addn_f32(F16wParts a) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n4) ((f32x4*)a)[i] = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
-}
-void launch_add2_f32(hipStream_t st, float* a, const float* b, size_t n) {  // a += b (n % 4 == 0): the two k halves of a split GEMM
-  k_add2_f32<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(a, b, n / 4);
+  if (i >= a.end4[2]) return;
+  const int j = i < a.end4[0] ? 0 : i < a.end4[1] ? 1 : 2;
+  const size_t li = i - (j == 0 ? 0 : j == 1 ? a.end4[0] : a.end4[1]);
+  float* o = j == 0 ? a.out[0] : j == 1 ? a.out[1] : a.out[2];
+  const float* p = j == 0 ? a.part[0] : j == 1 ? a.part[1] : a.part[2];
+  f32x4 v = ((const f32x4*)o)[li];
+  for (int s = 0; s < a.nparts; s++) v = v + ((const f32x4*)(p + (size_t)s * a.pstride))[li];
+  ((f32x4*)o)[li] = v;
 }
 
 // one dword of a Q4_0 block (quant bytes 4 s .. 4 s + 3: low nibbles = elements 4 s .., high nibbles = 16 + 4 s ..; buf_q4_0.rs:24-33)
@@ -207,13 +219,14 @@ struct F16wMats {
   const char* ws2[3];  // Q6_K: the int8 scales (16 per super-block) ...
   const char* ws3[3];  // ... and d (f16 per super-block)
   float* out[3];
-  float* out2[3];    // ksplit = 2: the second k half's partial tiles (the caller adds the two)
+  float* out2[3];    // ksplit > 1: k piece s >= 1 writes its partial tiles to out2[j] + (s - 1) pstride (k_addn_f32 adds them)
+  size_t pstride;
   int m[3];
   int tiles_end[3];  // cumulative row tiles
 };
 template <int WF, int F, int T_>  // F 16-row fragments x T_ 16-column tiles per wave: the workgroup's four waves own 64 F consecutive weight rows
-// ksplit = 2: two workgroups per output tile, each over half of k, each writing its own partial buffer (out / out2) -- ffn_down and
-// wo have few row tiles and a long serial k loop: one wave per SIMD otherwise
+// ksplit > 1: that many workgroups per output tile, each over its piece of k, each writing its own partial buffer -- ffn_down and wo
+// have few row tiles and a long serial k loop (one wave per SIMD otherwise), and a short pass has few tiles altogether
 __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4* __restrict__ xh, int nb, int n, int row_tiles, int ksplit) {
   using G = GemmF16Geo<T_>;
   constexpr int T = G::T, KCH = G::KCH;
@@ -242,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   const i32x4* __restrict__ wh = (const i32x4*)wsc;
   const i32x4* __restrict__ w6s = (const i32x4*)(ti == 0 ? mats.ws2[0] : ti == 1 ? mats.ws2[1] : mats.ws2[2]);
   const unsigned short* __restrict__ w6d = (const unsigned short*)(ti == 0 ? mats.ws3[0] : ti == 1 ? mats.ws3[1] : mats.ws3[2]);
-  float* __restrict__ out = ks == 0 ? (ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2]) : (ti == 0 ? mats.out2[0] : ti == 1 ? mats.out2[1] : mats.out2[2]);
+  float* __restrict__ out = ks == 0 ? (ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2])
+                                    : (ti == 0 ? mats.out2[0] : ti == 1 ? mats.out2[1] : mats.out2[2]) + (size_t)(ks - 1) * mats.pstride;
   const int m = ti == 0 ? mats.m[0] : ti == 1 ? mats.m[1] : mats.m[2];
   const int rt_l = rt - (ti == 0 ? 0 : ti == 1 ? mats.tiles_end[0] : mats.tiles_end[1]);
   const int r0 = rt_l * 64 * F + wave * 16 * F, c0 = ct * G::CW;
@@ -477,41 +491,47 @@ bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype) {
   if (act_qtype == CRABML_HIP_Q8_1) return w_dtype == CRABML_HIP_Q4_1;
   return act_qtype == CRABML_HIP_Q8_K && (w_dtype == CRABML_HIP_Q4_K || w_dtype == CRABML_HIP_Q6_K);
 }
+// wave tile: T column tiles of 16 prompt rows -- 8 (128-row workgroup tiles) from 65 rows up; short passes (a short prompt, the ragged
+// tail of a long one) take 4 / 2: the MFMAs of an empty column tile cost what a full one's do
+static int f16w_col_tiles_per_wave(size_t b, int variant) { return (variant & 16) ? 8 : b <= 32 ? 2 : b <= 64 ? 4 : 8; }
 template <int WF>
 static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit, int F,
                             int variant) {
-  if constexpr (WF == WF_Q4_0)
-    if ((variant & 7) == 4) return launch_f16w_t<WF, 2, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
-  if (F == 2) return launch_f16w_t<WF, 2, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
-  return launch_f16w_t<WF, 1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
+  switch (f16w_col_tiles_per_wave(b, variant)) {
+    case 2: return F == 2 ? launch_f16w_t<WF, 2, 2>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 2>(dev, mats, row_tiles, k, xh, b, ksplit);
+    case 4: return F == 2 ? launch_f16w_t<WF, 2, 4>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
+    default: return F == 2 ? launch_f16w_t<WF, 2, 8>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
+  }
 }
 // nw weight matrices (one format, the same k) against the same rhs rows: out[j] (b, m[j]) = W[j] . x
-// out2 (nullable; one matrix only): a second (b, m) buffer -- when the launch would leave one wave per SIMD (few row tiles, a long k:
-// ffn_down, wo) the k range is cut in two, the halves' partial tiles go to out and out2 and *split_out = 2: the caller adds them
-// (k_add2_f32).  (Measured and not kept: the halves added with f32 atomics onto a zeroed output -- 32.4k -> 30.1k prompt tok/s.)
+// ws (nullable), ws_floats: scratch for split launches.  When the output tiles alone leave the chip underfilled -- wo / ffn_down (few
+// row tiles, a long k), any short pass -- the k range is cut into 2 / 4 / 8 pieces, one workgroup each: piece 0 writes out, the
+// others their own partial buffers in ws, and k_addn_f32 adds them in piece order.  (Measured and not kept: the pieces added with
+// f32 atomics onto a zeroed output -- 32.4k -> 30.1k prompt tok/s, and the sum's order would vary from run to run.)
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
-                      float* const* out, float* out2, int* split_out) {
-  if (split_out) *split_out = 1;
-  if (nw < 1 || nw > 3 || k % 32 != 0 || b < 32) return false;
+                      float* const* out, float* ws, size_t ws_floats) {
+  if (nw < 1 || nw > 3 || k % 32 != 0 || b < 16) return false;
   const uint32_t dt = w[0]->dtype;
   if (dt != CRABML_HIP_Q4_0 && dt != CRABML_HIP_Q8_0 && dt != CRABML_HIP_Q4_K && dt != CRABML_HIP_Q6_K && dt != CRABML_HIP_Q4_1) return false;
   if ((dt == CRABML_HIP_Q4_K || dt == CRABML_HIP_Q6_K) && k % 256 != 0) return false;
   for (int j = 0; j < nw; j++)
     if (w[j]->dtype != dt || m[j] % 4 != 0) return false;
-  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = <2,8>, 3 = <1,8>, 4 = <2,4>; +8 = never split k
+  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = two fragments, 3 = one; +8 = never split k; +16 = T = 8 always; +32 = k pieces of >= 8 chunks
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_F16W");
     return h && h[0] == '1' && e ? atoi(e) : 0;
   }();
   size_t mtot = 0;
   for (int j = 0; j < nw; j++) mtot += m[j];
-  const size_t col128 = (b + 127) / 128;
+  const size_t cw = 16 * (size_t)f16w_col_tiles_per_wave(b, variant), col128 = (b + cw - 1) / cw;  // (column tiles of the launch)
   // two fragments per wave (every B' fragment read from LDS feeds two MFMAs) when 128-row tiles still cover the chip
   int F = ((mtot + 127) / 128) * col128 >= (size_t)dev->n_cu ? 2 : 1;
   if ((variant & 7) == 1) F = 2;
   if ((variant & 7) == 3) F = 1;
   F16wMats mats{};
+  F16wParts parts{};
   int row_tiles = 0;
+  size_t before = 0;  // output elements of the matrices before j
   for (int j = 0; j < 3; j++) {
     const int jj = j < nw ? j : nw - 1;
     const char* wp = (const char*)w[jj]->ptr;
@@ -520,19 +540,42 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
     mats.ws2[j] = wp + w[jj]->wl.off_scale + w[jj]->wl.n_blocks * 64;  // (Q6_K: ql | qh | scales | d, common.hpp)
     mats.ws3[j] = wp + w[jj]->wl.off_scale + w[jj]->wl.n_blocks * 80;
     mats.out[j] = out[jj];
-    mats.out2[j] = out2;
+    mats.out2[j] = ws + before;
     mats.m[j] = (int)m[jj];
-    if (j < nw) row_tiles += (int)((m[j] + 64 * F - 1) / (64 * F));
+    parts.out[j] = out[jj];
+    parts.part[j] = ws + before;
+    if (j < nw) {
+      row_tiles += (int)((m[j] + 64 * F - 1) / (64 * F));
+      before += b * m[j];
+    }
     mats.tiles_end[j] = row_tiles;
+    parts.end4[j] = before / 4;
   }
+  mats.pstride = parts.pstride = before;
+  // pieces of k: double while the launch is short of ~1.5 workgroups per CU, every piece keeps >= 4 chunks (and whole super-blocks),
+  // and the partial buffers fit the scratch
   int ksplit = 1;
-  if (out2 != nullptr && split_out != nullptr && nw == 1 && (size_t)row_tiles * col128 < (size_t)dev->n_cu * 3 / 2 && k >= 4096 && !(variant & 8)) ksplit = 2;
-  if (split_out) *split_out = ksplit;
-  if (dt == CRABML_HIP_Q8_0) return launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
-  if (dt == CRABML_HIP_Q4_K) return launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
-  if (dt == CRABML_HIP_Q6_K) return launch_f16w_fmt<WF_Q6_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
-  if (dt == CRABML_HIP_Q4_1) return launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
-  return launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  const size_t chunks = (k + 127) / 128;
+  if (ws != nullptr && !(variant & 8) && k % 128 == 0)
+    while (ksplit < 8 && (size_t)row_tiles * col128 * ksplit < (size_t)dev->n_cu * 3 / 2 && chunks % (size_t)(4 * ksplit) == 0 &&
+           chunks / (size_t)(2 * ksplit) >= (size_t)((variant & 32) ? 8 : 4) && (size_t)(2 * ksplit - 1) * before <= ws_floats)
+      ksplit *= 2;
+  bool ok;
+  if (dt == CRABML_HIP_Q8_0)
+    ok = launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  else if (dt == CRABML_HIP_Q4_K)
+    ok = launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  else if (dt == CRABML_HIP_Q6_K)
+    ok = launch_f16w_fmt<WF_Q6_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  else if (dt == CRABML_HIP_Q4_1)
+    ok = launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  else
+    ok = launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+  if (ok && ksplit > 1) {
+    parts.nparts = ksplit - 1;
+    k_addn_f32<<<(unsigned)((parts.end4[2] + 255) / 256), 256, 0, dev->stream>>>(parts);
+  }
+  return ok;
 }
 
 }  // namespace crabml_hip
