@@ -294,3 +294,35 @@ def test_fast_prompt_pass_f16_weight_gemm(ca, fmt, shape, n):
     nxt = int(np.argmax(ref))
     assert list(a.decode_greedy(nxt, 4))[0] == list(b.decode_greedy(nxt, 4))[0]
     assert a.kv_cache_len() == b.kv_cache_len() == n + 4
+
+
+@pytest.mark.parametrize("fmt,n", [("Q4_0", 200), ("Q4_K", 40), ("Q6_K", 64), ("Q8_0", 33), ("Q4_1", 130)])
+def test_fast_prompt_pass_f16_weight_gemm_k_pieces(ca, fmt, n):
+    """A wide feed-forward (hidden = 4096 against dim = 512, one layer): ffn_down's k range is cut into 8 pieces of 4 chunks (two
+    super-blocks) and gate | up, q | k | v and wo (k = 512) into none -- the partial tiles of the pieces are added in piece order by
+    k_addn_f32.  Row counts: 200 (T = 8, two column tiles), 40 and 64 (T = 4), 33 (T = 4, one row past T = 2's tile), 130.
+    Same bounds as above: oracle token loop, the int8 pass, the two against each other."""
+    shape = synth.ModelShape("tiny-wide", 512, 4096, 1, 4, 2, 512, 256, 1e-5, None)
+    model = synth.build_model(shape, getattr(synth, fmt), seed=17)
+    prompt = [(13 * i + 3) % shape.vocab for i in range(n)]
+    odev = o.OracleDevice(thread_num=8, use_avx2=False)
+    oconf, ow = to_oracle(model, odev)
+    orr = o.OracleLlamaRunner(oconf, ow, odev, n + 16, True)
+    ref = None
+    for i, t in enumerate(prompt):
+        ref = orr.forward([t], i)
+    dev = ca.HipTensorDevice(0)
+    conf, w = synth.to_hip(model, dev)
+    a = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=512)
+    b = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=512, extra_flags=PREFILL_INT8_GEMM)
+    la, lb = np.array(a.prefill(prompt)), np.array(b.prefill(prompt))
+    la2 = np.array(ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=512).prefill(prompt))
+    assert np.array_equal(la.view(np.uint32), la2.view(np.uint32))  # (the pieces are added in a fixed order: run to run the same bits)
+    scale = float(np.max(np.abs(ref)))
+    ea, eb, eab = (float(np.max(np.abs(x - y))) / scale for x, y in ((la, ref), (lb, ref), (la, lb)))
+    tol = FAST_TOL[fmt][1]
+    _record_f16w("tiny-wide/%s/%d" % (fmt, n), {"f16_vs_oracle": ea, "int8_vs_oracle": eb, "f16_vs_int8": eab, "bound": tol})
+    assert eb <= tol, ("int8 pass vs oracle", eb)
+    assert ea <= tol, ("f16 pass vs oracle", ea)
+    assert eab <= tol, ("f16 pass vs int8 pass", eab)
+    assert not np.array_equal(la, lb)
