@@ -130,6 +130,7 @@ struct crabml_hip_llama {
   bool q8k_producers = false;            // attention / gate-up emit the Q8_K planes of wo's / ffn_down's rhs themselves
   unsigned tp_salt = 0;      // P2P group: epoch salt of this context (see TpP2P::salt)
   bool tp_dry = false;       // CRABML_HIP_LLAMA_TP_DRY_RUN: a lone rank that skips the all-reduces (timing only)
+  bool k_norm_in = false;    // fast Q4_K step: gate | up normalizes and quantizes wo's f32 row itself (k_gateup_k_lds<.., NORMIN>)
   bool kfused = false;       // Q4_K layers, fast mode: fused GEMV kernels with the Q4_K inner loop (enqueue_segment_k)
   bool generic = false;      // per-op launches (strict-order device, or a weight format without fused kernels)
   bool ord = false;          // strict-order device, Q4_0 / Q8_0 / Q4_1 layers: the fused launches with block-ordered sums (k_*_ord)
@@ -842,19 +843,21 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
   // wnext / eps_next: the RMSNorm that consumes this GEMV's output (norm epilogue only); xin: the f32 rhs
   // qmode: 0 = rhs planes from global memory, 1 = quantize the f32 rhs in the kernel's prologue, 2 = copy finished planes
   auto gemv_out = [&](const crabml_hip_buf* w, const Act& a, const float* xin, int k, uint32_t stage, const float* wnext,
-                      float eps_next, int qmode) -> int {
+                      float eps_next, int qmode, bool x_only = false) -> int {
     CH_TRY(P0(stage, dim, k));
     if constexpr (FMT == CRABML_HIP_Q4_K) {
       if (nepi) {
-        NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg};
+        NormGather ng{c->slots, c->slots + dim / 16, c->state + 4, c->state + 5, n_segments(c), seg, c->rsums};
         ActLayout al = act_layout(QT, (size_t)dim);
         ng.qp = (signed char*)(c->act_dim + al.off_p);
-        signed char* oq = (signed char*)c->act_dim;
+        signed char* oq = x_only ? nullptr : (signed char*)c->act_dim;  // (x_only: the consumer quantizes, nq_epilogue)
         void* od = (void*)(c->act_dim + al.off_d);
         void* ob = (void*)(c->act_dim + al.off_aux);
+        // (x_only: no hop pairs the halves of a chunk -- two 16-row workgroups per chunk whenever that still fits the chip twice)
         const int split = (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS)  ? 2
                           : (g.flags & CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER) ? 1
                           : (k / 32 >= 256 && dim / 32 <= dev->n_cu)        ? 2
+                          : (x_only && dim / 32 <= dev->n_cu)               ? 2
                                                                             : 1;
         const size_t lds = (size_t)k + (size_t)(k / 256) * 4 + (size_t)(k / 16) * 2;
         if (ordk) {  // (qmode is 1 or 2 here: `qin` holds on every ordered context)
@@ -941,7 +944,8 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       enqueue_attention(c, l, nullptr, nullptr, nullptr, PrefetchPlan{}, 0, prof);
     }
     if (!qin) launch_quantize_act(st, QT, c->attn, (size_t)dim_l, c->act_attn);
-    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), c->attn, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f, aq8 ? 2 : qin ? 1 : 0));
+    CH_TRY(gemv_out(c->wo[l], act_k(c->act_attn, dim_l), c->attn, dim_l, 2, (const float*)c->rms_ffn[l]->ptr, 1e-5f, aq8 ? 2 : qin ? 1 : 0,
+                    qout && c->k_norm_in));
   } else {
     if (!nepi) norm_quant((const float*)c->rms_ffn[l]->ptr, 1e-5f, tp, QT);  // llama2.rs:611
     CH_TRY(P0(3, 2.0 * hidden_l, dim));
@@ -953,19 +957,24 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
       if (ordk && qout)
         launch_k(st, R, k_gateup_k_lds<true, true>, dim3(hidden_l / 32), dim3(1024), ldso, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
-                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p));
+                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p), (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr, 1);
       else if (ordk)
         launch_k(st, R, k_gateup_k_lds<false, true>, dim3(hidden_l / 32), dim3(1024), ldso, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)nullptr,
-                 (float*)nullptr, (short*)nullptr, (signed char*)nullptr);
+                 (float*)nullptr, (short*)nullptr, (signed char*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr, 1);
+      else if (qout && c->k_norm_in)  // wo left x only (below): this launch normalizes and quantizes the row itself
+        launch_k(st, R, k_gateup_k_lds<true, false, true>, dim3(hidden_l / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
+                 act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
+                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p), (const float*)c->x,
+                 (const float*)c->rms_ffn[l]->ptr, 1e-5f, (const float*)c->rsums, dim / 32 <= dev->n_cu ? 2 : 1);
       else if (qout)
         launch_k(st, R, k_gateup_k_lds<true>, dim3(hidden_l / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)c->act_hid,
-                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p));
+                 (float*)(c->act_hid + alh.off_d), (short*)(c->act_hid + alh.off_aux), (signed char*)(c->act_hid + alh.off_p), (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr, 1);
       else
         launch_k(st, R, k_gateup_k_lds<false>, dim3((hidden_l + 31) / 32), dim3(1024), lds, planes_k(c->gate[l]), planes_k(c->up[l]),
                  act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / 256, hx, (signed char*)nullptr,
-                 (float*)nullptr, (short*)nullptr, (signed char*)nullptr);
+                 (float*)nullptr, (short*)nullptr, (signed char*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr, 1);
     } else {
       launch_k(st, R, k_gateup<FMT>, dim3((hidden_l + 1) / 2), dim3(128), 0, planes_k(c->gate[l]), planes_k(c->up[l]),
                act_k(c->act_dim, dim), (const unsigned short*)dev->exp_table, c->h, hidden_l, dim / BE);
@@ -1966,6 +1975,10 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
   }
   c->q8k_producers = c->norm_epi_k && !(g.flags & (CRABML_HIP_LLAMA_NO_RHS_PROLOGUE | CRABML_HIP_LLAMA_NO_Q8K_PRODUCERS)) && dim_l % 256 == 0 &&
                      hidden_l % 256 == 0 && (hd == 64 || hd == 128 || hd == 256) && (int)(hidden_l / 32) <= 2 * dev->n_cu;
+  // the fast Q4_K step: wo leaves x only, gate | up normalizes and quantizes the row itself (k_gateup_k_lds<.., NORMIN>; the same bits)
+  c->k_norm_in = c->q8k_producers && wt == CRABML_HIP_Q4_K && tp == 1 && !ord && !dev->strict_order && g.embedding_dim % 256 == 0 && g.embedding_dim / 256 <= 32 &&
+                 !(g.flags & (CRABML_HIP_LLAMA_NO_K_NORM_IN | CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS | CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER));
+  if (c->k_norm_in && !c->rsums) A(g.embedding_dim / 16 * 4, (void**)&c->rsums);
   if (c->q8k_producers) {
     A(dim_l * 8, (void**)&c->a8gran);
     A(hidden_l * 8, (void**)&c->h8gran);

@@ -281,7 +281,7 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     const float xv = mo + res;  // x = matmul_out + x (llama2.rs:266 / :636)
     x[row + lane] = xv;
     hv[part * ROWS + lane] = xv;
-    if (ROWG)
+    if (ROWG && q != nullptr)
       __hip_atomic_store(ng.pair + row + lane, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xv),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -335,6 +335,13 @@ __device__ __forceinline__ void nq_epilogue(float (&acc)[2 / SPLIT], float res, 
     } else {
       cs = h0;
     }
+  }
+  // q == nullptr (the fast Q4_K step's wo): x and the chunk's sum of squares (a plain store, read after the kernel boundary) are all
+  // this launch leaves -- the consuming gate | up launch normalizes and quantizes the row itself (k_gateup_k_lds<.., NORMIN>): no row
+  // granules, no gather of the sums, no super-block exchange
+  if (q == nullptr) {
+    if (lane == 0) ng.sums[wg_index] = cs;
+    return;
   }
   if constexpr (DEFER) {
     static_assert(!DEFER || (!KQ && !Q81 && !TP), "the hop-free epilogue: Q8_0 rhs");
@@ -856,10 +863,18 @@ __global__ __launch_bounds__(128) void k_gateup(Planes wg, Planes wu, typename A
 // ORD (strict-order device): the nine-term records of the 32 gate and 32 up rows go to LDS behind the planes (dynamic LDS = the planes
 // rounded up to 16 bytes + 64 * q4k_rec_stride(nsb) floats) and one lane per (matrix, row) adds them in super-block order (q4k_ordered_sum):
 // h bit for bit as k_gemv_exact_q4k x 2 + k_gateup_epi leave it; m % 32 == 0.
-template <bool QOUT, bool ORD = false>
+// NORMIN (the fast step): the rhs arrives as the f32 row xin (wo's output, residual added) with wo's chunk sums of squares (csums:
+// sum_parts per 32-row chunk) -- every workgroup adds the sums, normalizes (x / rms) * wnorm and quantizes the row to Q8_K into LDS
+// itself, a wave per super-block: 32 KB of L2 reads per workgroup instead of wo's two in-launch hops (every workgroup of wo waiting
+// for all others' sums, then for its super-block's seven neighbours).  The sums keep the order the gathering epilogue used
+// (nq_epilogue: a chunk = its halves; 64 chunks per round through wave_sum_f32; rounds added in order), so the planes are bit for
+// bit the ones wo used to leave.
+template <bool QOUT, bool ORD = false, bool NORMIN = false>
 __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, ActQ8_K act, const unsigned short* __restrict__ exp_tab,
                                                        float* __restrict__ h, int m, int nsb, Q8KExchange ex, signed char* __restrict__ oq,
-                                                       float* __restrict__ od, short* __restrict__ obs, signed char* __restrict__ oqp) {
+                                                       float* __restrict__ od, short* __restrict__ obs, signed char* __restrict__ oqp,
+                                                       const float* __restrict__ xin, const float* __restrict__ wnorm, float eps,
+                                                       const float* __restrict__ csums, int sum_parts) {
   extern __shared__ i32x4 lds_act[];  // q[k] | d[k/256] f32 | bsums[k/16] i16
   const int k = nsb * 256;
   i32x4* sq = lds_act;
@@ -873,13 +888,62 @@ __global__ __launch_bounds__(1024, 8) void k_gateup_k_lds(Planes wg, Planes wu, 
   // per lane in flight with a second register set -- 90 VGPRs, ONE workgroup per CU, 18.0 us instead of 17.1; pinned to 64
   // VGPRs it spills.)
   const int nch = nsb * 8;
+  // NORMIN: the row, the norm weights and wo's chunk sums are requested BEFORE the first weight pieces (loads return in order: behind
+  // the pieces they would wait for an HBM round trip instead of an L2 one).  (host: nsb <= 32 -- at most two super-blocks per wave,
+  // four rounds of 64 chunks)
+  f32x4 xv[2], wv[2];
+  float ca[2];
+  if constexpr (NORMIN) {
+    static_assert(!ORD, "the strict-order step keeps wo's ordered epilogue");
+    const int nch32 = k / 32;
+    {  // round `wave` of the chunk sums (waves past the last round re-read its last chunk: unused)
+      const int cch = wave * 64 + lane, cc = cch < nch32 ? cch : nch32 - 1;
+      ca[0] = csums[cc * sum_parts];
+      ca[1] = csums[cc * sum_parts + sum_parts - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int sb = wave + 16 * u;
+      xv[u] = ((const f32x4*)xin)[(sb < nsb ? sb : 0) * 64 + lane];
+      wv[u] = ((const f32x4*)wnorm)[(sb < nsb ? sb : 0) * 64 + lane];
+    }
+  }
   Q4KPiece<false> pw[2];
 #pragma unroll
   for (int r = 0; r < 2; r++)
     pw[r] = q4k_load<false>(wg.q, (const i32x4*)wg.d, (size_t)(row0 + r < m ? row0 + r : m - 1), nsb, lane < nch ? lane : nch - 1, lane);
-  for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.qp[i];  // (class-major: the rhs of Q4_K rows)
-  for (int i = threadIdx.x; i < nsb; i += 1024) sd[i] = act.d[i];
-  for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
+  if constexpr (NORMIN) {
+    const int nch32 = k / 32, nrounds = (nch32 + 63) / 64;
+    // round r of the chunk sums = chunks 64 r .. + 63, one per lane of wave r (lanes past the row add +0.0, as the gather did), rounds
+    // added in order
+    __shared__ float s_round[16];
+    if (wave < nrounds) {
+      const int cch = wave * 64 + lane;
+      const float cs = cch < nch32 ? (sum_parts == 2 ? ca[0] + ca[1] : ca[0]) : 0.0f;
+      const float ws = wave_sum_f32(cs);
+      if (lane == 0) s_round[wave] = ws;
+    }
+    __syncthreads();
+    float sum = 0.0f;
+    for (int r = 0; r < nrounds; r++) sum += s_round[r];
+    const float rms = sqrtf(sum / (float)k + eps);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int sb = wave + 16 * u;
+      if (sb >= nsb) break;  // (wave-uniform)
+      f32x4 xn;
+#pragma unroll
+      for (int i = 0; i < 4; i++) xn[i] = (xv[u][i] / rms) * wv[u][i];  // rms_norm.rs:41-45, then the weight (llama2.rs:611)
+      const Q8KLane o = q8k_wave_quant(xn, lane);
+      q8k_store_class_major((signed char*)sq + sb * 256, lane, o.packed);
+      if ((lane & 3) == 0) sbs[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
+      if (lane == 0) sd[sb] = o.d;
+    }
+  } else {
+    for (int i = threadIdx.x; i < k / 16; i += 1024) sq[i] = act.qp[i];  // (class-major: the rhs of Q4_K rows)
+    for (int i = threadIdx.x; i < nsb; i += 1024) sd[i] = act.d[i];
+    for (int i = threadIdx.x; i < k / 16; i += 1024) sbs[i] = act.bsums[i];
+  }
   __syncthreads();
   const ActQ8_K la{sq, sd, sbs, sq};
   __shared__ float hv[32];

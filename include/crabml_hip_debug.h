@@ -104,6 +104,8 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
 #define CRABML_HIP_LLAMA_PREFILL_INT8_GEMM 524288 /* A/B: the fast prompt pass keeps the bit-exact int8 matrix-core GEMM (with the fused last
                                                      product) for Q4_0 weights at every pass size, instead of the weight-stationary f16 GEMM
                                                      from 160 rows (gemm_f16w.hip; a stated deviation of the fast tier) */
+#define CRABML_HIP_LLAMA_NO_K_NORM_IN 16777216 /* A/B, fast Q4_K step: wo gathers the row's sums and quantizes its output to Q8_K itself (two
+                                                  in-launch hops) instead of leaving x for gate | up to normalize and quantize (bit-identical) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_NEVER 32  /* 32-row chunk always / never (default: only for long rows)   */
 
