@@ -872,8 +872,9 @@ def main():
             prefill = {"prompt_tokens": n_p, "rows_per_pass": 512, "ms": round(best * 1e3, 2),
                        "prompt_tokens_per_s": round(n_p / best, 1),
                        "vs_token_loop": round(n_p / best / (total_tokens / elapsed_max / args.gpus), 2),
-                       "note": "llama2.rs:124-129 token loop as (rows, k) matmul_vec passes on the int8 MFMA GEMM + causal "
-                               "attention (fast step: flash attention on the f16 matrix cores); host clock around the blocking call, best of 2"}
+                       "note": "llama2.rs:124-129 token loop as (rows, k) passes: weight GEMMs weight-stationary on the f16 matrix cores "
+                               "(gemm_f16w.hip, a stated deviation of the fast tier; matmul_vec itself and the strict device keep the bit-exact "
+                               "int8 MFMA GEMM) + causal flash attention on the f16 matrix cores; host clock around the blocking call, best of 2"}
             del pr
             # a long prompt: attention is O(n^2) there (the fast step runs it on the f16 matrix cores, k_attn_flash_rows)
             n_l = 4096

@@ -1210,9 +1210,10 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     const char* e = getenv("CRABML_HIP_GEMM_EXACT");
     return h && h[0] == '1' && e && e[0] == '1';
   }();
-  // The fast pass, Q4_0 / Q8_0 weights x Q8_0 rows or Q4_K x Q8_K, >= 160 rows: the weight-stationary f16 GEMM (gemm_f16w.hip; block scales folded into f16
-  // operands, f32 accumulation inside the matrix core -- a stated deviation of the fast tier).  The rows' pre-scaled f16 planes are
-  // made once per rhs (q / k / v and gate / up share theirs): xh_of remembers which planes pf_xh currently holds.
+  // The fast pass, Q4_0 / Q8_0 weights x Q8_0 rows, Q4_1 x Q8_1, Q4_K / Q6_K x Q8_K, >= 32 rows: the weight-stationary f16 GEMM
+  // (gemm_f16w.hip; block scales folded into f16 operands, f32 accumulation inside the matrix core -- a stated deviation of the fast
+  // tier).  The rows' pre-scaled f16 planes are made once per rhs and k-slot order (q / k / v and gate / up share theirs): xh_of /
+  // xh_order remember what pf_xh currently holds.
   static const bool f16w_off = [] {  // A/B hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_INT8=1): the int8 kernels in the fast pass too
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_GEMM_INT8");
@@ -1224,7 +1225,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     return h && h[0] == '1' && e ? atoi(e) : 32;
   }();
   const bool f16w = !strict && !gemm_exact_hook && !f16w_off && !(g.flags & CRABML_HIP_LLAMA_PREFILL_INT8_GEMM) &&
-                    (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= f16w_min;  // (below: the int8 kernels' smaller tiles cover the chip better -- 128 rows tie, 64 lose 12 %)
+                    (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= f16w_min;  // (shorter passes: the int8 kernels / the GEMV)
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
     if (f16w && gemm_f16w_covers(w->dtype, c->qt) && (c->qt != CRABML_HIP_Q8_K || k % 256 == 0)) {
       rows_to_f16(w, act, k);

@@ -102,8 +102,9 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
 #define CRABML_HIP_LLAMA_NO_H_CONSUMER_QUANT 4096 /* A/B, tensor-parallel ranks: gate/up quantizes h itself (hidden / tp / 32 workgroups of 32 rows, k_gateup_q)
                                                    instead of leaving h as f32 from one workgroup per CU for ffn_down's prologue (bit-identical) */
 #define CRABML_HIP_LLAMA_PREFILL_INT8_GEMM 524288 /* A/B: the fast prompt pass keeps the bit-exact int8 matrix-core GEMM (with the fused last
-                                                     product) for Q4_0 weights at every pass size, instead of the weight-stationary f16 GEMM
-                                                     from 160 rows (gemm_f16w.hip; a stated deviation of the fast tier) */
+                                                     product) at every pass size, instead of the weight-stationary f16 GEMM that Q4_0 / Q8_0 /
+                                                     Q4_1 / Q4_K / Q6_K weights take from 32 rows (gemm_f16w.hip; a stated deviation of the
+                                                     fast tier) */
 #define CRABML_HIP_LLAMA_NO_K_NORM_IN 16777216 /* A/B, fast Q4_K step: wo gathers the row's sums and quantizes its output to Q8_K itself (two
                                                   in-launch hops) instead of leaving x for gate | up to normalize and quantize (bit-identical) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */

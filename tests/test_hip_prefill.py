@@ -257,7 +257,7 @@ def _record_f16w(key, row):
                                          ("Q4_K", "tiny-hd128", 384), ("Q4_K_M", "tiny-gqa", 173), ("Q6_K", "tiny-gqa", 200),
                                          ("Q6_K", "tiny-hd128", 384), ("Q4_1", "tiny-gqa", 200), ("Q4_1", "15m", 173)])
 def test_fast_prompt_pass_f16_weight_gemm(ca, fmt, shape, n):
-    """Passes of >= 160 rows, Q4_0 / Q8_0 / Q4_1 / Q4_K / Q6_K weights, fast device: the weight GEMMs run on the f16 matrix cores with the block
+    """Passes of >= 32 rows, Q4_0 / Q8_0 / Q4_1 / Q4_K / Q6_K weights, fast device: the weight GEMMs run on the f16 matrix cores with the block
     scales folded into the operands (k_gemm_f16w, gemm_f16w.hip -- a stated deviation of the fast tier: two (Q4_K: three) f16
     roundings per product instead of exact integer block dots).  Against the oracle's token loop it must sit inside the fast
     tolerance the int8 kernels are held to; against the int8 kernels (A/B flag) the two passes must agree inside it; the greedy

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 --pmc MfmaUtil VALUBusy (own pass, no tracing domains) of the prompt pass: the weight GEMMs (f16 weight-stationary from 160 rows, int8 below) and the fast step's flash attention.
+# rocprofv3 --pmc MfmaUtil VALUBusy (own pass, no tracing domains) of the prompt pass: the weight GEMMs (f16 weight-stationary from 32 rows, int8 below) and the fast step's flash attention.
 # usage: gpurun --timeout 900 -- 'bash tools/gpu_profile_prefill.sh TAG'
 TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
