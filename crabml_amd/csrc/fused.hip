@@ -23,6 +23,7 @@
 #include "fused_common.hpp"
 #include "fused_attention.hpp"
 #include "fused_ffn.hpp"
+#include "prefill_rows.hpp"
 #include "lazy.hpp"
 
 
@@ -1189,22 +1190,6 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     else
       k_norm_f32_rows<12><<<rows, 1024, norm_lds, st>>>(c->pf_x, wn, dim, eps, c->pf_xn, half);
   };
-  // CpuTensorBuf::quantize for the rhs of matmul_vec (buf/api.rs:142-159): F32 weights take the rows as they are
-  const void* xh_of = nullptr;  // the planes c->pf_xh was made from (reset whenever planes are rewritten) ...
-  int xh_order = -1;            // ... and the k-slot order it is in (gemm_f16w_order of the weight format)
-  auto rows_to_f16 = [&](const crabml_hip_buf* w, const void* act, int k) {
-    const int order = gemm_f16w_order(w->dtype);
-    if (xh_of == act && xh_order == order) return;
-    launch_rows_to_f16(st, c->qt, w->dtype, act, B, (size_t)k, c->pf_xh);
-    xh_of = act;
-    xh_order = order;
-  };
-  auto quant_rows = [&](const float* src, int n, char* planes) -> const void* {
-    if (c->qt == CRABML_HIP_F32) return src;
-    launch_quantize_act_rows(st, c->qt, src, B, (size_t)n, planes);
-    xh_of = nullptr;
-    return planes;
-  };
   static const bool gemm_exact_hook = [] {  // A/B hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_GEMM_EXACT=1): the fast pass with matmul_vec's own scaling
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_GEMM_EXACT");
@@ -1226,6 +1211,35 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
   }();
   const bool f16w = !strict && !gemm_exact_hook && !f16w_off && !(g.flags & CRABML_HIP_LLAMA_PREFILL_INT8_GEMM) &&
                     (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && c->pf_xh != nullptr && B >= f16w_min;  // (shorter passes: the int8 kernels / the GEMV)
+  // CpuTensorBuf::quantize for the rhs of matmul_vec (buf/api.rs:142-159): F32 weights take the rows as they are
+  const void* xh_of = nullptr;  // the planes c->pf_xh was made from (reset whenever planes are rewritten) ...
+  int xh_order = -1;            // ... and the k-slot order it is in (gemm_f16w_order of the weight format)
+  auto rows_to_f16 = [&](const crabml_hip_buf* w, const void* act, int k) {
+    const int order = gemm_f16w_order(w->dtype);
+    if (xh_of == act && xh_order == order) return;
+    launch_rows_to_f16(st, c->qt, w->dtype, act, B, (size_t)k, c->pf_xh);
+    xh_of = act;
+    xh_order = order;
+  };
+  // ... written by the kernel that quantizes the rows when the GEMM that reads them next is the f16 one (f16w_rows.hpp: the same
+  // bits as k_rows_to_f16 from the finished planes, one launch fewer per GEMM; A/B: CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS)
+  auto xh_target = [&](const crabml_hip_buf* next, int k, int* order) -> void* {
+    if (!f16w || next == nullptr || (g.flags & CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS) || !gemm_f16w_covers(next->dtype, c->qt) ||
+        (c->qt == CRABML_HIP_Q8_K && k % 256 != 0))
+      return nullptr;
+    *order = gemm_f16w_order(next->dtype);
+    return c->pf_xh;
+  };
+  // next: the weight matrix whose GEMM reads these planes first
+  auto quant_rows = [&](const float* src, int n, char* planes, const crabml_hip_buf* next) -> const void* {
+    if (c->qt == CRABML_HIP_F32) return src;
+    int order = 0;
+    void* xh = xh_target(next, n, &order);
+    launch_quantize_act_rows(st, c->qt, src, B, (size_t)n, planes, xh, order);
+    xh_of = xh ? planes : nullptr;
+    xh_order = order;
+    return planes;
+  };
   auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
     if (f16w && gemm_f16w_covers(w->dtype, c->qt) && (c->qt != CRABML_HIP_Q8_K || k % 256 == 0)) {
       rows_to_f16(w, act, k);
@@ -1250,11 +1264,17 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
   const ActLayout ald = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)dim);
   const ActLayout alh = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)hidden);
   // pending = the wo / ffn_down output that has not been added to x yet (folded into the next norm)
-  auto norm_quant_rows = [&](const float* wn, float eps, const float* pending) -> const void* {
+  auto norm_quant_rows = [&](const float* wn, float eps, const float* pending, const crabml_hip_buf* next) -> const void* {
     const bool q81 = c->qt == CRABML_HIP_Q8_1;
-#define CRABML_NQR(NIT_, Q_)                                                                                                    \
-  k_norm_quant_rows<NIT_, Q_><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d, \
-                                                            ald.off_aux, half)
+    int order = 0;
+    unsigned short* xh = (unsigned short*)xh_target(next, dim, &order);
+#define CRABML_NQR(NIT_, Q_)                                                                                                         \
+  if (xh)                                                                                                                            \
+    k_norm_quant_rows_h<NIT_, Q_><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d,  \
+                                                                ald.off_aux, half, xh);                                              \
+  else                                                                                                                               \
+    k_norm_quant_rows<NIT_, Q_><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d,    \
+                                                              ald.off_aux, half)
     if (dim <= 4096) {
       if (q81)
         CRABML_NQR(4, true);
@@ -1267,18 +1287,19 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
         CRABML_NQR(12, false);
     }
 #undef CRABML_NQR
-    xh_of = nullptr;
+    xh_of = xh ? c->pf_act_dim : nullptr;
+    xh_order = order;
     return c->pf_act_dim;
   };
   bool pending_down = false;  // (fuse_rows) the previous layer's ffn_down output sits in pf_tmp, not yet added to pf_x
   for (int l = 0; l < L; l++) {
     const void* a;
     if (fuse_rows) {
-      a = norm_quant_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, pending_down ? c->pf_tmp : nullptr);
+      a = norm_quant_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, pending_down ? c->pf_tmp : nullptr, c->wq[l]);
       pending_down = false;
     } else {
       norm_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);  // llama2.rs:230-234
-      a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+      a = quant_rows(c->pf_xn, dim, c->pf_act_dim, c->wq[l]);
     }
     bool qkv_done = false;  // llama2.rs:244-246
     if (f16w && gemm_f16w_covers(c->wq[l]->dtype, c->qt) && c->wk[l]->dtype == c->wq[l]->dtype && c->wv[l]->dtype == c->wq[l]->dtype) {
@@ -1328,14 +1349,14 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
                                                                    c->pf_attn, nullptr, nullptr, nullptr, n_heads, n_kv, hd, seq_cap,
                                                                    PrefetchPlan{}, dev->strict_order ? 256 : 0);
     }
-    a = quant_rows(c->pf_attn, dim, c->pf_act_dim);
+    a = quant_rows(c->pf_attn, dim, c->pf_act_dim, c->wo[l]);
     CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp));  // llama2.rs:600
     if (fuse_rows) {
-      a = norm_quant_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f, c->pf_tmp);  // x += wo out (:266), FFN norm (:611), quantize
+      a = norm_quant_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f, c->pf_tmp, c->gate[l]);  // x += wo out (:266), FFN norm (:611), quantize
     } else {
       k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);  // :266
       norm_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f);  // llama2.rs:611
-      a = quant_rows(c->pf_xn, dim, c->pf_act_dim);
+      a = quant_rows(c->pf_xn, dim, c->pf_act_dim, c->gate[l]);
     }
     bool gu_done = false;  // llama2.rs:620-630
     if (f16w && gemm_f16w_covers(c->gate[l]->dtype, c->qt) && c->up[l]->dtype == c->gate[l]->dtype) {
@@ -1352,18 +1373,27 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     }
     if (fuse_rows) {
       const dim3 gq((unsigned)((hidden + 255) / 256), rows);
-      if (c->qt == CRABML_HIP_Q8_1)
+      int order = 0;
+      unsigned short* xh = (unsigned short*)xh_target(c->down[l], hidden, &order);
+      if (c->qt == CRABML_HIP_Q8_1 && xh)
+        k_gateup_epi_quant_h<true><<<gq, 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table, hidden, c->pf_act_hid, alh.total,
+                                                       alh.off_d, alh.off_aux, xh);
+      else if (xh)
+        k_gateup_epi_quant_h<false><<<gq, 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table, hidden, c->pf_act_hid, alh.total,
+                                                        alh.off_d, alh.off_aux, xh);
+      else if (c->qt == CRABML_HIP_Q8_1)
         k_gateup_epi_quant<true><<<gq, 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table, hidden, c->pf_act_hid, alh.total,
                                                      alh.off_d, alh.off_aux);
       else
         k_gateup_epi_quant<false><<<gq, 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table, hidden, c->pf_act_hid, alh.total,
                                                       alh.off_d, alh.off_aux);
-      xh_of = nullptr;
+      xh_of = xh ? c->pf_act_hid : nullptr;
+      xh_order = order;
       a = c->pf_act_hid;
     } else {
       k_gateup_epi<<<(unsigned)(((size_t)B * hidden + 255) / 256), 256, 0, st>>>(c->pf_g, c->pf_u, (const unsigned short*)dev->exp_table,
                                                                                  c->pf_g, (int)(B * hidden));
-      a = quant_rows(c->pf_g, hidden, c->pf_act_hid);
+      a = quant_rows(c->pf_g, hidden, c->pf_act_hid, c->down[l]);
     }
     CH_TRY(gemm(c->down[l], dim, hidden, a, c->pf_tmp));  // llama2.rs:633-636
     if (fuse_rows && l + 1 < L)

@@ -31,10 +31,12 @@
 // Q6_K weights (Q8_K rows): a chunk is one 128-element half of a super-block -- lane (i, g) loads 16 bytes of ql (g < 2: ql[0..31],
 // the low nibbles are quarter 0, the high ones quarter 2; g >= 2: ql[32..63], quarters 1 and 3; buf_q6_k.rs:21-48) and the 16 bytes
 // of qh that carry the same l's two high bits, and once per super-block the 16 int8 scales and d.  A' = (q - 32) * fl16(d * sc),
-// q - 32 exact.  Its own B' slot order (k_rows_to_f16<2>): a Q4_K_M layer converts the rows once per order it needs.#include <cstdlib>
+// q - 32 exact.  Its own B' slot order (k_rows_to_f16<2>): a Q4_K_M layer converts the rows once per order it needs.
+#include <cstdlib>
 #include <type_traits>
 
 #include "devutil.hpp"
+#include "f16w_rows.hpp"
 #include "kernels.hpp"
 
 namespace crabml_hip {
@@ -42,14 +44,8 @@ namespace crabml_hip {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// ---- B': the Q8_0 rows of a prompt pass as pre-scaled f16, in the GEMM's k-slot order ---------------------------------------
-// xh[col][kb][32] f16; inside a block, slot 8 s + e (s = 0..3 = the dword of the weight block the slot pairs with) holds element
-//   e = 0, 1: 4 s, 4 s + 2     e = 2, 3: 4 s + 1, 4 s + 3     e = 4, 5: 16 + 4 s, 16 + 4 s + 2     e = 6, 7: 16 + 4 s + 1, 16 + 4 s + 3
-// -- the order in which unpack_q4_0_f16 below takes the nibbles out of a dword (two masks per packed pair, no byte permute).
-__device__ __forceinline__ int f16w_slot_elem(int slot) {
-  const int s = slot >> 3, e = slot & 7;
-  return (e >= 4 ? 16 : 0) + 4 * s + ((e >> 1) & 1) + 2 * (e & 1);
-}
+// ---- B': the rows of a prompt pass as pre-scaled f16, in the GEMM's k-slot order: xh[col][kb][32] f16 ------------------------
+// (the slot orders and the conversion of one 8-slot group: f16w_rows.hpp, shared with the row kernels that write B' themselves)
 // Q8_K rows (Q4_K weights): slot group kb = 4 cc + g of chunk cc = (super-block, half h), step s = class l = 4 h + s of pair g;
 // slot e: k = 0, 2, 1, 3 of sub-block 2 g (e < 4) / 2 g + 1 (e >= 4), element 8 k + l -- unpack_q4_k_f16's order
 // Q6_K weights: chunk cc = (super-block, half), g, step s: element 128 half + 32 (g >> 1) + 16 (g & 1) + 4 s + k (e < 4), + 64 (e >= 4)
@@ -59,35 +55,7 @@ __global__ __launch_bounds__(256) void k_rows_to_f16(const char* __restrict__ pl
   const size_t col = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (block, 8-slot group)
   if (t >= nb * 4) return;
-  const int kb = t >> 2, s = t & 3;
-  const char* p = planes + col * row_stride;
-  float d;
-  const signed char* q;
-  int at[8];
-  if constexpr (ORDER == 2) {
-    const int cc = kb >> 2, g = kb & 3, sb = cc >> 1;
-    d = ((const float*)(p + off_d))[sb];
-    q = (const signed char*)p + sb * 256 + 128 * (cc & 1) + 32 * (g >> 1) + 16 * (g & 1) + 4 * s;
-#pragma unroll
-    for (int e = 0; e < 8; e++) at[e] = (e >= 4 ? 64 : 0) + ((e >> 1) & 1) + 2 * (e & 1);
-  } else if constexpr (ORDER == 1) {
-    const int cc = kb >> 2, g = kb & 3, sb = cc >> 1, l = 4 * (cc & 1) + s;
-    d = ((const float*)(p + off_d))[sb];
-    q = (const signed char*)p + sb * 256 + 64 * g;
-#pragma unroll
-    for (int e = 0; e < 8; e++) at[e] = (e >= 4 ? 32 : 0) + 8 * (((e >> 1) & 1) + 2 * (e & 1)) + l;
-  } else {
-    d = h2f(((const unsigned short*)(p + off_d))[kb]);
-    q = (const signed char*)p + kb * 32;
-#pragma unroll
-    for (int e = 0; e < 8; e++) at[e] = f16w_slot_elem(8 * s + e);
-  }
-  unsigned short o[8];
-#pragma unroll
-  for (int e = 0; e < 8; e++) o[e] = f2h((float)q[at[e]] * d);  // (Q8_0: 7-bit x 11-bit, exact in f32, one rounding; Q8_K: f32 d, two)
-  unsigned short* dst = xh + (col * nb + kb) * 32 + 8 * s;
-  *(i32x4*)dst = i32x4{(int)(o[0] | ((unsigned)o[1] << 16)), (int)(o[2] | ((unsigned)o[3] << 16)), (int)(o[4] | ((unsigned)o[5] << 16)),
-                       (int)(o[6] | ((unsigned)o[7] << 16))};
+  rows_to_f16_piece<ORDER>(planes + col * row_stride, off_d, t, xh + col * (size_t)nb * 32);
 }
 // planes: `rows` sets of activation planes (act_layout(act_qtype, k)); the slot order is the one the weight format w_dtype reads
 int gemm_f16w_order(uint32_t w_dtype) { return w_dtype == CRABML_HIP_Q4_K ? 1 : w_dtype == CRABML_HIP_Q6_K ? 2 : 0; }

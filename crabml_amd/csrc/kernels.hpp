@@ -17,7 +17,8 @@ inline void launch_k(hipStream_t st, crabml_hip_device::ProfRec* rec, K kernel, 
 
 // ---- quantize.hip: activation quantizers (buf_q8_0.rs:87-134, buf_q8_1.rs:90-129, buf_q8_k.rs:84-131)
 void launch_quantize_act(hipStream_t st, uint32_t qtype, const float* x, size_t n, void* planes);
-void launch_quantize_act_rows(hipStream_t st, uint32_t qtype, const float* x, size_t rows, size_t n, void* planes);
+void launch_quantize_act_rows(hipStream_t st, uint32_t qtype, const float* x, size_t rows, size_t n, void* planes, void* xh = nullptr,
+                              int xh_order = 0);  // xh: the rows' f16 planes for gemm_f16w.hip, written alongside (f16w_rows.hpp)
 
 // ---- gemv.hip: W(m,k) x quantized activations (b,k) -> out (b,m)
 // wq: weight planes; aq: activation planes (one set per batch row, stride act_layout(qtype,k).total)

@@ -1,0 +1,50 @@
+// prefill_rows.hpp -- row kernels of the FAST prompt pass that also leave the row's pre-scaled f16 plane B' for the weight GEMM that
+// reads it next (gemm_f16w.hip; slot orders: f16w_rows.hpp): the same arithmetic as the kernels they wrap, one k_rows_to_f16 launch
+// fewer per GEMM.  B' is bit for bit what k_rows_to_f16 makes from the finished planes.
+#pragma once
+#include "f16w_rows.hpp"
+#include "fused_common.hpp"
+#include "fused_ffn.hpp"
+
+namespace crabml_hip {
+
+// k_norm_quant_rows (residual add + RMSNorm + quantize, one workgroup per row; Q8_0 / Q8_1 planes) + the row's B' (order 0): the
+// planes are read back by the workgroup that has just written them
+template <int NIT, bool Q81>
+__global__ __launch_bounds__(1024) void k_norm_quant_rows_h(float* __restrict__ x, const float* __restrict__ addv, const float* __restrict__ w,
+                                                           int cols, float eps, char* __restrict__ planes, size_t row_stride, size_t off_d,
+                                                           size_t off_aux, int half, unsigned short* __restrict__ xh) {
+  extern __shared__ float lds[];
+  __shared__ float s_rms;
+  NormLds L{lds, lds + cols};
+  const size_t r = blockIdx.x;
+  char* p = planes + r * row_stride;
+  norm_quant_block<NIT, true, Q81>(x + r * cols, addv ? addv + r * cols : nullptr, w, cols, eps, L, &s_rms, (signed char*)p,
+                                   (unsigned short*)(p + off_d), (void*)(p + off_aux), nullptr, half);
+  __threadfence_block();
+  __syncthreads();
+  const int nb = cols / 32;
+  for (int t = threadIdx.x; t < nb * 4; t += blockDim.x) rows_to_f16_piece<0>(p, off_d, t, xh + r * (size_t)cols);
+}
+
+// k_gateup_epi_quant (h = silu(g) * u quantized straight into the rows' Q8_0 / Q8_1 planes) + the rows' B' (order 0)
+template <bool Q81>
+__global__ __launch_bounds__(256) void k_gateup_epi_quant_h(const float* __restrict__ g, const float* __restrict__ u,
+                                                            const unsigned short* __restrict__ exp_tab, int hidden, char* __restrict__ planes,
+                                                            size_t row_stride, size_t off_d, size_t off_aux, unsigned short* __restrict__ xh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // hidden % 32 == 0: half-waves are all-live or all-dead
+  const size_t r = blockIdx.y;
+  const bool live = i < hidden;
+  const float h = live ? silu_mul(g[r * hidden + i], u[r * hidden + i], exp_tab) : 0.0f;
+  const QLane o = quant_lane32<Q81>(h, live);
+  if (!live) return;
+  char* p = planes + r * row_stride;
+  ((signed char*)p)[i] = o.q;
+  if ((threadIdx.x & 31) == 0) {
+    ((unsigned short*)(p + off_d))[i >> 5] = o.d;
+    store_qaux<Q81>((void*)(p + off_aux), i >> 5, o.aux);
+  }
+  xh[r * (size_t)hidden + (i & ~31) + f16w_slot_of_elem(i & 31)] = f16w_value((int)o.q, h2f(o.d));
+}
+
+}  // namespace crabml_hip

@@ -105,6 +105,9 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
                                                      product) at every pass size, instead of the weight-stationary f16 GEMM that Q4_0 / Q8_0 /
                                                      Q4_1 / Q4_K / Q6_K weights take from 32 rows (gemm_f16w.hip; a stated deviation of the
                                                      fast tier) */
+#define CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS 33554432 /* A/B, fast prompt pass: the rows' f16 planes for the weight GEMM are made by their
+                                                              own launch (k_rows_to_f16) instead of by the kernels that quantize the rows
+                                                              (bit-identical) */
 #define CRABML_HIP_LLAMA_NO_K_NORM_IN 16777216 /* A/B, fast Q4_K step: wo gathers the row's sums and quantizes its output to Q8_K itself (two
                                                   in-launch hops) instead of leaving x for gate | up to normalize and quantize (bit-identical) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */
