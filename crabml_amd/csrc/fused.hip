@@ -1359,19 +1359,25 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       a = quant_rows(c->pf_xn, dim, c->pf_act_dim, c->gate[l]);
     }
     bool gu_done = false;  // llama2.rs:620-630
+    int h_done = 0;        // the launch stored h = silu(g) * u (pf_g) instead of g and u
     if (f16w && gemm_f16w_covers(c->gate[l]->dtype, c->qt) && c->up[l]->dtype == c->gate[l]->dtype) {
-      // gate and up as ONE launch: 2 x 448 workgroups fill the last round of the chip better than 448 twice
+      // gate and up as ONE launch: 2 x 448 workgroups fill the last round of the chip better than 448 twice -- and, where 64-row tiles
+      // of both cover the chip, with SiLU * mul as the epilogue (a wave holds the same 16 rows of both matrices)
       rows_to_f16(c->gate[l], a, dim);
       const crabml_hip_buf* ws[2] = {c->gate[l], c->up[l]};
       const size_t ms[2] = {(size_t)hidden, (size_t)hidden};
       float* outs[2] = {c->pf_g, c->pf_u};
-      gu_done = launch_gemm_f16w(dev, ws, ms, 2, (size_t)dim, c->pf_xh, B, outs, c->pf_split, c->pf_split_floats);
+      const bool epi = !(g.flags & CRABML_HIP_LLAMA_PREFILL_NO_GU_EPILOGUE);
+      gu_done = launch_gemm_f16w(dev, ws, ms, 2, (size_t)dim, c->pf_xh, B, outs, c->pf_split, c->pf_split_floats,
+                                 epi ? (const unsigned short*)dev->exp_table : nullptr, epi ? &h_done : nullptr);
     }
     if (!gu_done) {
       CH_TRY(gemm(c->gate[l], hidden, dim, a, c->pf_g));
       CH_TRY(gemm(c->up[l], hidden, dim, a, c->pf_u));
     }
-    if (fuse_rows) {
+    if (h_done) {  // h sits in pf_g: quantize it (the quantizer launch's arithmetic is quant_lane32's, bit for bit)
+      a = quant_rows(c->pf_g, hidden, c->pf_act_hid, c->down[l]);
+    } else if (fuse_rows) {
       const dim3 gq((unsigned)((hidden + 255) / 256), rows);
       int order = 0;
       unsigned short* xh = (unsigned short*)xh_target(c->down[l], hidden, &order);

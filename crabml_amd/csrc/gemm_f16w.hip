@@ -189,10 +189,19 @@ struct F16wMats {
   float* out[3];
   float* out2[3];    // ksplit > 1: k piece s >= 1 writes its partial tiles to out2[j] + (s - 1) pstride (k_addn_f32 adds them)
   size_t pstride;
+  const unsigned short* exp_tab;  // GU launches: the f16 exp table of silu (silu.rs:6-13)
   int m[3];
   int tiles_end[3];  // cumulative row tiles
 };
-template <int WF, int F, int T_>  // F 16-row fragments x T_ 16-column tiles per wave: the workgroup's four waves own 64 F consecutive weight rows
+// h = silu(g) * u (silu.rs:6-13, arithmetic.rs:57-66; fused_ffn.hpp silu_mul: the exp through the reference's f16 table)
+__device__ __forceinline__ float f16w_silu_mul(float g, float u, const unsigned short* __restrict__ exp_tab) {
+  const float nexp = h2f(exp_tab[f2h(-g)]);
+  return (g / (1.0f + nexp)) * u;
+}
+// GU (F = 2, two matrices of the same shape: ffn_gate and ffn_up): fragment 0 holds 16 rows of the FIRST matrix, fragment 1 the same
+// 16 rows of the SECOND -- the workgroup owns 64 rows of both -- and the epilogue stores h = silu(g) * u (out[0]) instead of g and u:
+// the (rows, hidden) f32 pair never makes its trip through memory (llama2.rs:620-630).  One k piece only (silu is not linear).
+template <int WF, int F, int T_, bool GU = false>  // F 16-row fragments x T_ 16-column tiles per wave: the workgroup's four waves own 64 F consecutive weight rows
 // ksplit > 1: that many workgroups per output tile, each over its piece of k, each writing its own partial buffer -- ffn_down and wo
 // have few row tiles and a long serial k loop (one wave per SIMD otherwise), and a short pass has few tiles altogether
 __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4* __restrict__ xh, int nb, int n, int row_tiles, int ksplit) {
@@ -216,18 +225,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
     ct = sub % col_tiles;
     ks = sub / col_tiles;
   }
-  const int ti = rt < mats.tiles_end[0] ? 0 : rt < mats.tiles_end[1] ? 1 : 2;  // (uniform)
-  const i32x4* __restrict__ wq = ti == 0 ? mats.wq[0] : ti == 1 ? mats.wq[1] : mats.wq[2];
-  const char* __restrict__ wsc = ti == 0 ? mats.wd[0] : ti == 1 ? mats.wd[1] : mats.wd[2];
-  const unsigned short* __restrict__ wd = (const unsigned short*)wsc;
-  const i32x4* __restrict__ wh = (const i32x4*)wsc;
-  const i32x4* __restrict__ w6s = (const i32x4*)(ti == 0 ? mats.ws2[0] : ti == 1 ? mats.ws2[1] : mats.ws2[2]);
-  const unsigned short* __restrict__ w6d = (const unsigned short*)(ti == 0 ? mats.ws3[0] : ti == 1 ? mats.ws3[1] : mats.ws3[2]);
+  static_assert(!GU || F == 2, "gate | up: one fragment of each matrix per wave");
+  const int ti = GU ? 0 : rt < mats.tiles_end[0] ? 0 : rt < mats.tiles_end[1] ? 1 : 2;  // (uniform)
+  // fragment f's matrix: the row tile's (ti), or -- GU -- matrix f
+#define F16W_SEL(arr, j) ((j) == 0 ? mats.arr[0] : (j) == 1 ? mats.arr[1] : mats.arr[2])
+#define F16W_PTRS(f)                                                                   \
+  const int mj = GU ? (f) : ti;                                                        \
+  const i32x4* __restrict__ wq = F16W_SEL(wq, mj);                                     \
+  const char* __restrict__ wsc = F16W_SEL(wd, mj);                                     \
+  const unsigned short* __restrict__ wd = (const unsigned short*)wsc;                  \
+  const i32x4* __restrict__ wh = (const i32x4*)wsc;                                    \
+  const i32x4* __restrict__ w6s = (const i32x4*)F16W_SEL(ws2, mj);                     \
+  const unsigned short* __restrict__ w6d = (const unsigned short*)F16W_SEL(ws3, mj);   \
+  (void)wq; (void)wd; (void)wh; (void)w6s; (void)w6d; (void)wsc
   float* __restrict__ out = ks == 0 ? (ti == 0 ? mats.out[0] : ti == 1 ? mats.out[1] : mats.out[2])
                                     : (ti == 0 ? mats.out2[0] : ti == 1 ? mats.out2[1] : mats.out2[2]) + (size_t)(ks - 1) * mats.pstride;
   const int m = ti == 0 ? mats.m[0] : ti == 1 ? mats.m[1] : mats.m[2];
   const int rt_l = rt - (ti == 0 ? 0 : ti == 1 ? mats.tiles_end[0] : mats.tiles_end[1]);
-  const int r0 = rt_l * 64 * F + wave * 16 * F, c0 = ct * G::CW;
+  constexpr int FSTEP = GU ? 0 : 16;  // rows between a wave's fragments
+  const int r0 = GU ? rt_l * 64 + wave * 16 : rt_l * 64 * F + wave * 16 * F, c0 = ct * G::CW;
   // this workgroup's chunks: [ch_lo, ch_lo + nchunks) of the row's ceil(nb / KCH)
   // (Q4_K: an even chunk is half 0 of its super-block -- the pieces start on super-block boundaries)
   const int all_chunks = (nb + KCH - 1) / KCH;
@@ -250,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
       const int nsb = nb >> 3, sb = cc >> 1, h = cc & 1;
 #pragma unroll
       for (int f = 0; f < F; f++) {
-        const int row = r0 + 16 * f + i;
+        F16W_PTRS(f);
+        const int row = r0 + FSTEP * f + i;
         const size_t blk = (size_t)(row < m ? row : m - 1) * nsb + sb;
         aq[J][f] = __builtin_nontemporal_load(wq + blk * 8 + 2 * g + h);
         if constexpr ((J & 1) == 0) hq[J >> 1][f] = __builtin_nontemporal_load(wh + blk);
@@ -259,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
       const int nsb = nb >> 3, sb = cc >> 1, half = cc & 1;
 #pragma unroll
       for (int f = 0; f < F; f++) {
-        const int row = r0 + 16 * f + i;
+        F16W_PTRS(f);
+        const int row = r0 + FSTEP * f + i;
         const size_t blk = (size_t)(row < m ? row : m - 1) * nsb + sb;
         aq[J][2 * f] = __builtin_nontemporal_load(wq + blk * 8 + 4 * half + g);
         aq[J][2 * f + 1] = __builtin_nontemporal_load(wh + blk * 4 + 2 * half + (g & 1));  // (wh: the qh plane, 64 bytes per super-block)
@@ -273,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
       const int gkb = kb < nb ? kb : nb - 1;
 #pragma unroll
       for (int f = 0; f < F; f++) {
-        const int row = r0 + 16 * f + i;
+        F16W_PTRS(f);
+        const int row = r0 + FSTEP * f + i;
         const size_t blk = (size_t)(row < m ? row : m - 1) * nb + gkb;
 #pragma unroll
         for (int u = 0; u < NQ; u++) aq[J][NQ * f + u] = __builtin_nontemporal_load(wq + blk * NQ + u);
@@ -408,6 +427,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
     if (ch + 3 < nchunks) chunk(std::integral_constant<int, 3>{}, ch + 3);
   }
   // D: lane (i, g) holds rows 4 g .. 4 g + 3 of column i of every tile
+  if constexpr (GU) {
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int col = c0 + 16 * t + i;
+      if (col >= n) continue;
+      const int row = r0 + 4 * g;
+      f32x4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; r++) hv[r] = f16w_silu_mul(acc[0][t][r], acc[1][t][r], mats.exp_tab);
+      float* o = out + (size_t)col * m + row;
+      if (row + 3 < m) {
+        *(f32x4*)o = hv;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (row + r < m) o[r] = hv[r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < T; t++) {
     const int col = c0 + 16 * t + i;
@@ -440,15 +479,15 @@ static bool f16w_raise_lds(const crabml_hip_device* dev, const void* fn, int byt
 }
 // xh: the rows' pre-scaled f16 planes (launch_rows_to_f16) inside an allocation of gemm_f16w_xh_bytes(b, k): the kernel reads whole
 // 128-column tiles and up to three chunks past the last column's end; returns false when the shape is not covered
-template <int WF, int F, int T>
+template <int WF, int F, int T, bool GU = false>
 static bool launch_f16w_t(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit) {
   using G = GemmF16Geo<T>;
-  if (!f16w_raise_lds(dev, (const void*)k_gemm_f16w<WF, F, T>, G::LDS_BYTES)) {  // (80 KB of dynamic LDS: raised once per device)
+  if (!f16w_raise_lds(dev, (const void*)k_gemm_f16w<WF, F, T, GU>, G::LDS_BYTES)) {  // (80 KB of dynamic LDS: raised once per device)
     (void)hipGetLastError();
     return false;
   }
   const int col_tiles = (int)((b + G::CW - 1) / G::CW);
-  k_gemm_f16w<WF, F, T><<<dim3(row_tiles * col_tiles * ksplit), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b,
+  k_gemm_f16w<WF, F, T, GU><<<dim3(row_tiles * col_tiles * ksplit), 256, G::LDS_BYTES, dev->stream>>>(mats, (const i32x4*)xh, (int)(k / 32), (int)b,
                                                                                           row_tiles, ksplit);
   return true;
 }
@@ -464,7 +503,14 @@ bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype) {
 static int f16w_col_tiles_per_wave(size_t b, int variant) { return (variant & 16) ? 8 : b <= 32 ? 2 : b <= 64 ? 4 : 8; }
 template <int WF>
 static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit, int F,
-                            int variant) {
+                            int variant, bool gu) {
+  if (gu) {
+    switch (f16w_col_tiles_per_wave(b, variant)) {
+      case 2: return launch_f16w_t<WF, 2, 2, true>(dev, mats, row_tiles, k, xh, b, 1);
+      case 4: return launch_f16w_t<WF, 2, 4, true>(dev, mats, row_tiles, k, xh, b, 1);
+      default: return launch_f16w_t<WF, 2, 8, true>(dev, mats, row_tiles, k, xh, b, 1);
+    }
+  }
   switch (f16w_col_tiles_per_wave(b, variant)) {
     case 2: return F == 2 ? launch_f16w_t<WF, 2, 2>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 2>(dev, mats, row_tiles, k, xh, b, ksplit);
     case 4: return F == 2 ? launch_f16w_t<WF, 2, 4>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
@@ -477,14 +523,15 @@ static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int ro
 // others their own partial buffers in ws, and k_addn_f32 adds them in piece order.  (Measured and not kept: the pieces added with
 // f32 atomics onto a zeroed output -- 32.4k -> 30.1k prompt tok/s, and the sum's order would vary from run to run.)
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
-                      float* const* out, float* ws, size_t ws_floats) {
+                      float* const* out, float* ws, size_t ws_floats, const unsigned short* gu_exp_tab, int* gu_done) {
+  if (gu_done) *gu_done = 0;
   if (nw < 1 || nw > 3 || k % 32 != 0 || b < 16) return false;
   const uint32_t dt = w[0]->dtype;
   if (dt != CRABML_HIP_Q4_0 && dt != CRABML_HIP_Q8_0 && dt != CRABML_HIP_Q4_K && dt != CRABML_HIP_Q6_K && dt != CRABML_HIP_Q4_1) return false;
   if ((dt == CRABML_HIP_Q4_K || dt == CRABML_HIP_Q6_K) && k % 256 != 0) return false;
   for (int j = 0; j < nw; j++)
     if (w[j]->dtype != dt || m[j] % 4 != 0) return false;
-  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = two fragments, 3 = one; +8 = never split k; +16 = T = 8 always; +32 = k pieces of >= 8 chunks
+  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = two fragments, 3 = one; +8 = never split k; +16 = T = 8 always; +32 = k pieces of >= 8 chunks; +64 = no gate | up epilogue
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_F16W");
     return h && h[0] == '1' && e ? atoi(e) : 0;
@@ -496,7 +543,13 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   int F = ((mtot + 127) / 128) * col128 >= (size_t)dev->n_cu ? 2 : 1;
   if ((variant & 7) == 1) F = 2;
   if ((variant & 7) == 3) F = 1;
+  // gate | up with the SiLU * mul epilogue (out[0] = h, out[1] untouched): when 64-row tiles of both matrices cover the chip without
+  // cutting k
+  const bool gu = gu_exp_tab != nullptr && gu_done != nullptr && nw == 2 && m[0] == m[1] && !(variant & 64) &&
+                  ((m[0] + 63) / 64) * col128 * 2 >= (size_t)dev->n_cu * 3;
+  if (gu) F = 2;
   F16wMats mats{};
+  mats.exp_tab = gu_exp_tab;
   F16wParts parts{};
   int row_tiles = 0;
   size_t before = 0;  // output elements of the matrices before j
@@ -513,9 +566,10 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
     parts.out[j] = out[jj];
     parts.part[j] = ws + before;
     if (j < nw) {
-      row_tiles += (int)((m[j] + 64 * F - 1) / (64 * F));
+      if (!gu) row_tiles += (int)((m[j] + 64 * F - 1) / (64 * F));
       before += b * m[j];
     }
+    if (gu) row_tiles = (int)((m[0] + 63) / 64);
     mats.tiles_end[j] = row_tiles;
     parts.end4[j] = before / 4;
   }
@@ -524,21 +578,22 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   // and the partial buffers fit the scratch
   int ksplit = 1;
   const size_t chunks = (k + 127) / 128;
-  if (ws != nullptr && !(variant & 8) && k % 128 == 0)
+  if (ws != nullptr && !(variant & 8) && k % 128 == 0 && !gu)
     while (ksplit < 8 && (size_t)row_tiles * col128 * ksplit < (size_t)dev->n_cu * 3 / 2 && chunks % (size_t)(4 * ksplit) == 0 &&
            chunks / (size_t)(2 * ksplit) >= (size_t)((variant & 32) ? 8 : 4) && (size_t)(2 * ksplit - 1) * before <= ws_floats)
       ksplit *= 2;
   bool ok;
   if (dt == CRABML_HIP_Q8_0)
-    ok = launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+    ok = launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
   else if (dt == CRABML_HIP_Q4_K)
-    ok = launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+    ok = launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
   else if (dt == CRABML_HIP_Q6_K)
-    ok = launch_f16w_fmt<WF_Q6_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+    ok = launch_f16w_fmt<WF_Q6_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
   else if (dt == CRABML_HIP_Q4_1)
-    ok = launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+    ok = launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
   else
-    ok = launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant);
+    ok = launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
+  if (ok && gu) *gu_done = 1;
   if (ok && ksplit > 1) {
     parts.nparts = ksplit - 1;
     k_addn_f32<<<(unsigned)((parts.end4[2] + 255) / 256), 256, 0, dev->stream>>>(parts);

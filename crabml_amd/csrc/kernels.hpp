@@ -49,7 +49,9 @@ int gemm_f16w_order(uint32_t w_dtype);
 size_t gemm_f16w_xh_bytes(size_t rows, size_t k);  // the allocation behind xh: whole 128-row tiles + the look-ahead's slack
 bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, uint32_t w_dtype, const void* planes, size_t rows, size_t k, void* xh);
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
-                      float* const* out, float* ws = nullptr, size_t ws_floats = 0);  // ws: scratch for the partial tiles of k pieces
+                      float* const* out, float* ws = nullptr, size_t ws_floats = 0,  // ws: scratch for the partial tiles of k pieces
+                      const unsigned short* gu_exp_tab = nullptr, int* gu_done = nullptr);
+// gu_exp_tab / gu_done (two matrices = ffn_gate, ffn_up): the launch may store h = silu(g) * u to out[0] instead of g and u (*gu_done = 1)
 // batched rhs on the matrix cores (gemm_mfma.hip); false = not covered
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,
                       crabml_hip_device::ProfRec* rec, int* dbg = nullptr, bool fused_add = false);

@@ -108,6 +108,8 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
 #define CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS 33554432 /* A/B, fast prompt pass: the rows' f16 planes for the weight GEMM are made by their
                                                               own launch (k_rows_to_f16) instead of by the kernels that quantize the rows
                                                               (bit-identical) */
+#define CRABML_HIP_LLAMA_PREFILL_NO_GU_EPILOGUE 67108864 /* A/B, fast prompt pass: gate | up leave g and u and SiLU * mul (+ quantize) stays its own
+                                                           launch, instead of being the f16 GEMM's epilogue (bit-identical) */
 #define CRABML_HIP_LLAMA_NO_K_NORM_IN 16777216 /* A/B, fast Q4_K step: wo gathers the row's sums and quantizes its output to Q8_K itself (two
                                                   in-launch hops) instead of leaving x for gate | up to normalize and quantize (bit-identical) */
 #define CRABML_HIP_LLAMA_SPLIT_CHUNKS_ALWAYS 16 /* test / tuning hooks for the norm epilogue: two workgroups per */

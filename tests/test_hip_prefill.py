@@ -331,24 +331,31 @@ def test_fast_prompt_pass_f16_weight_gemm_k_pieces(ca, fmt, n):
 
 
 SEPARATE_F16_ROWS = 33554432  # CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS
+NO_GU_EPILOGUE = 67108864  # CRABML_HIP_LLAMA_PREFILL_NO_GU_EPILOGUE
 
 
 @pytest.mark.parametrize("fmt,shape,n", [("Q4_0", "tiny-gqa", 200), ("Q4_0", "15m", 77), ("Q8_0", "tiny-hd128", 96), ("Q4_1", "tiny-gqa", 130),
-                                         ("Q4_K", "tiny-gqa", 200), ("Q4_K_M", "tiny-gqa", 64), ("Q6_K", "tiny-hd128", 40)])
+                                         ("Q4_K", "tiny-gqa", 200), ("Q4_K_M", "tiny-gqa", 64), ("Q6_K", "tiny-hd128", 40),
+                                         ("Q4_0", "wide-ffn", 200), ("Q4_K", "wide-ffn", 173), ("Q8_0", "wide-ffn", 130)])
 def test_fast_prompt_pass_rows_write_their_own_f16_planes(ca, fmt, shape, n):
     """The kernels that quantize the rows of a fast prompt pass (norm + quantize, SiLU * mul + quantize, the stand-alone quantizer for
     the attention output and for Q8_K rows) also leave the pre-scaled f16 planes the next weight GEMM reads (f16w_rows.hpp), in that
     GEMM's k-slot order -- the same bits k_rows_to_f16 makes from the finished planes in its own launch (the A/B flag): logits, the
-    greedy continuation and the cache rows are bit-identical.  Q4_K_M: where v is Q6_K its GEMM re-makes the planes in its own order."""
+    greedy continuation and the cache rows are bit-identical.  Q4_K_M: where v is Q6_K its GEMM re-makes the planes in its own order.
+    Likewise SiLU * mul as the epilogue of the gate | up GEMM (one fragment of each matrix per wave; h quantized by the quantizer
+    launch) against the separate SiLU * mul + quantize launch -- on these small shapes the epilogue form is taken where 64-row tiles of
+    both matrices cover 1.5 workgroups per CU (the 8B shape's passes; here the `wide-ffn` cases)."""
     kw = dict(seed=23)
-    model = (synth.build_model(synth.SHAPES[shape], synth.Q4_K, k_m_mix=True, **kw) if fmt == "Q4_K_M"
-             else synth.build_model(synth.SHAPES[shape], getattr(synth, fmt), **kw))
+    # wide-ffn: hidden = 12288 -- 192 row tiles of 64 x two column tiles = 1.5 workgroups per CU: the gate | up launch takes the
+    # SiLU * mul epilogue (one pass of > 128 rows; the 48-row passes keep the separate launch)
+    shp = synth.ModelShape("wide-ffn", 512, 12288, 1, 4, 2, 512, 256, 1e-5, None) if shape == "wide-ffn" else synth.SHAPES[shape]
+    model = (synth.build_model(shp, synth.Q4_K, k_m_mix=True, **kw) if fmt == "Q4_K_M" else synth.build_model(shp, getattr(synth, fmt), **kw))
     prompt = [(17 * i + 2) % model.shape.vocab for i in range(n)]
     dev = ca.HipTensorDevice(0)
     conf, w = synth.to_hip(model, dev)
     for chunk in (512, 48):  # one pass / passes of 48 rows and a ragged tail
         a = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=chunk)
-        b = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=chunk, extra_flags=SEPARATE_F16_ROWS)
+        b = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=chunk, extra_flags=SEPARATE_F16_ROWS | NO_GU_EPILOGUE)
         la, lb = np.array(a.prefill(prompt)), np.array(b.prefill(prompt))
         assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), (fmt, shape, chunk)
         nxt = int(np.argmax(la))
