@@ -1240,11 +1240,14 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     xh_order = order;
     return planes;
   };
-  auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out) -> int {
+  // defer (nullable): a GEMM cut into k pieces may leave the sum of its pieces to the row kernel that consumes `out` (pf_split holds them)
+  auto gemm = [&](const crabml_hip_buf* w, int m, int k, const void* act, float* out, int* defer = nullptr) -> int {
+    if (defer) *defer = 0;
+    if (g.flags & CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS) defer = nullptr;  // (A/B: every reduce its own launch)
     if (f16w && gemm_f16w_covers(w->dtype, c->qt) && (c->qt != CRABML_HIP_Q8_K || k % 256 == 0)) {
       rows_to_f16(w, act, k);
       const size_t mm = (size_t)m;
-      if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out, c->pf_split, c->pf_split_floats)) return 0;
+      if (launch_gemm_f16w(dev, &w, &mm, 1, (size_t)k, c->pf_xh, B, &out, c->pf_split, c->pf_split_floats, nullptr, nullptr, defer)) return 0;
     }
     if (!strict) {
       return launch_gemv(dev, w, m, k, act, B, out, nullptr, !gemm_exact_hook);
@@ -1264,14 +1267,16 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
   const ActLayout ald = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)dim);
   const ActLayout alh = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)hidden);
   // pending = the wo / ffn_down output that has not been added to x yet (folded into the next norm)
-  auto norm_quant_rows = [&](const float* wn, float eps, const float* pending, const crabml_hip_buf* next) -> const void* {
+  // nparts: `pending` is piece 0 of a GEMM cut into k pieces, the others wait in pf_split (gemm's defer)
+  auto norm_quant_rows = [&](const float* wn, float eps, float* pending, const crabml_hip_buf* next, int nparts = 0) -> const void* {
     const bool q81 = c->qt == CRABML_HIP_Q8_1;
     int order = 0;
     unsigned short* xh = (unsigned short*)xh_target(next, dim, &order);
+    const size_t pstride = B * (size_t)dim;
 #define CRABML_NQR(NIT_, Q_)                                                                                                         \
-  if (xh)                                                                                                                            \
+  if (xh || nparts > 0)                                                                                                              \
     k_norm_quant_rows_h<NIT_, Q_><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d,  \
-                                                                ald.off_aux, half, xh);                                              \
+                                                                ald.off_aux, half, xh, c->pf_split, pstride, nparts);                \
   else                                                                                                                               \
     k_norm_quant_rows<NIT_, Q_><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d,    \
                                                               ald.off_aux, half)
@@ -1292,10 +1297,12 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     return c->pf_act_dim;
   };
   bool pending_down = false;  // (fuse_rows) the previous layer's ffn_down output sits in pf_tmp, not yet added to pf_x
+  int down_parts = 0;         // ... as piece 0 of this many + 1 k pieces
   for (int l = 0; l < L; l++) {
     const void* a;
     if (fuse_rows) {
-      a = norm_quant_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, pending_down ? c->pf_tmp : nullptr, c->wq[l]);
+      a = norm_quant_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, pending_down ? c->pf_tmp : nullptr, c->wq[l],
+                          pending_down ? down_parts : 0);
       pending_down = false;
     } else {
       norm_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps);  // llama2.rs:230-234
@@ -1350,9 +1357,10 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
                                                                    PrefetchPlan{}, dev->strict_order ? 256 : 0);
     }
     a = quant_rows(c->pf_attn, dim, c->pf_act_dim, c->wo[l]);
-    CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp));  // llama2.rs:600
+    int wo_parts = 0;
+    CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp, fuse_rows ? &wo_parts : nullptr));  // llama2.rs:600
     if (fuse_rows) {
-      a = norm_quant_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f, c->pf_tmp, c->gate[l]);  // x += wo out (:266), FFN norm (:611), quantize
+      a = norm_quant_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f, c->pf_tmp, c->gate[l], wo_parts);  // x += wo out (:266), FFN norm (:611), quantize
     } else {
       k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);  // :266
       norm_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f);  // llama2.rs:611
@@ -1401,7 +1409,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
                                                                                  c->pf_g, (int)(B * hidden));
       a = quant_rows(c->pf_g, hidden, c->pf_act_hid, c->down[l]);
     }
-    CH_TRY(gemm(c->down[l], dim, hidden, a, c->pf_tmp));  // llama2.rs:633-636
+    CH_TRY(gemm(c->down[l], dim, hidden, a, c->pf_tmp, fuse_rows && l + 1 < L ? &down_parts : nullptr));  // llama2.rs:633-636
     if (fuse_rows && l + 1 < L)
       pending_down = true;  // added by the next layer's norm launch
     else

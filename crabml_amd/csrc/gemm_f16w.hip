@@ -523,8 +523,9 @@ static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int ro
 // others their own partial buffers in ws, and k_addn_f32 adds them in piece order.  (Measured and not kept: the pieces added with
 // f32 atomics onto a zeroed output -- 32.4k -> 30.1k prompt tok/s, and the sum's order would vary from run to run.)
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
-                      float* const* out, float* ws, size_t ws_floats, const unsigned short* gu_exp_tab, int* gu_done) {
+                      float* const* out, float* ws, size_t ws_floats, const unsigned short* gu_exp_tab, int* gu_done, int* defer_parts) {
   if (gu_done) *gu_done = 0;
+  if (defer_parts) *defer_parts = 0;
   if (nw < 1 || nw > 3 || k % 32 != 0 || b < 16) return false;
   const uint32_t dt = w[0]->dtype;
   if (dt != CRABML_HIP_Q4_0 && dt != CRABML_HIP_Q8_0 && dt != CRABML_HIP_Q4_K && dt != CRABML_HIP_Q6_K && dt != CRABML_HIP_Q4_1) return false;
@@ -594,7 +595,9 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   else
     ok = launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
   if (ok && gu) *gu_done = 1;
-  if (ok && ksplit > 1) {
+  if (ok && ksplit > 1 && defer_parts != nullptr && nw == 1) {
+    *defer_parts = ksplit - 1;  // the caller's next row kernel adds the pieces (ws + s * b * m, s = 0 ..) in the same order
+  } else if (ok && ksplit > 1) {
     parts.nparts = ksplit - 1;
     k_addn_f32<<<(unsigned)((parts.end4[2] + 255) / 256), 256, 0, dev->stream>>>(parts);
   }

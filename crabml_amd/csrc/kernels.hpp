@@ -50,7 +50,9 @@ size_t gemm_f16w_xh_bytes(size_t rows, size_t k);  // the allocation behind xh: 
 bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, uint32_t w_dtype, const void* planes, size_t rows, size_t k, void* xh);
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
                       float* const* out, float* ws = nullptr, size_t ws_floats = 0,  // ws: scratch for the partial tiles of k pieces
-                      const unsigned short* gu_exp_tab = nullptr, int* gu_done = nullptr);
+                      const unsigned short* gu_exp_tab = nullptr, int* gu_done = nullptr, int* defer_parts = nullptr);
+// defer_parts (one matrix): a launch cut into k pieces leaves piece 0 in out and pieces 1.. in ws (b * m floats apart) and returns
+// their number instead of launching the reduce: the row kernel that consumes out adds them first, in piece order (prefill_rows.hpp)
 // gu_exp_tab / gu_done (two matrices = ffn_gate, ffn_up): the launch may store h = silu(g) * u to out[0] instead of g and u (*gu_done = 1)
 // batched rhs on the matrix cores (gemm_mfma.hip); false = not covered
 bool launch_gemm_mfma(crabml_hip_device* dev, const crabml_hip_buf* w, size_t m, size_t k, const void* act, size_t b, float* out,

@@ -10,17 +10,34 @@ namespace crabml_hip {
 
 // k_norm_quant_rows (residual add + RMSNorm + quantize, one workgroup per row; Q8_0 / Q8_1 planes) + the row's B' (order 0): the
 // planes are read back by the workgroup that has just written them
+// xh nullable.  parts / pstride / nparts: addv (the wo / ffn_down output that is about to be added to x) is piece 0 of a GEMM that was
+// cut into k pieces (launch_gemm_f16w, defer_parts): the other pieces are added to it first, in piece order -- k_addn_f32's
+// arithmetic, by the thread that reads the element next
 template <int NIT, bool Q81>
-__global__ __launch_bounds__(1024) void k_norm_quant_rows_h(float* __restrict__ x, const float* __restrict__ addv, const float* __restrict__ w,
+__global__ __launch_bounds__(1024) void k_norm_quant_rows_h(float* __restrict__ x, float* __restrict__ addv, const float* __restrict__ w,
                                                            int cols, float eps, char* __restrict__ planes, size_t row_stride, size_t off_d,
-                                                           size_t off_aux, int half, unsigned short* __restrict__ xh) {
+                                                           size_t off_aux, int half, unsigned short* __restrict__ xh,
+                                                           const float* __restrict__ parts, size_t pstride, int nparts) {
   extern __shared__ float lds[];
   __shared__ float s_rms;
   NormLds L{lds, lds + cols};
   const size_t r = blockIdx.x;
   char* p = planes + r * row_stride;
+  if (nparts > 0) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int i = it * 1024 + threadIdx.x;  // (norm_quant_block's own element -> thread mapping)
+      if (i < cols) {
+        float v = addv[r * cols + i];
+        for (int s = 0; s < nparts; s++) v = v + parts[(size_t)s * pstride + r * cols + i];
+        addv[r * cols + i] = v;
+      }
+    }
+    __threadfence_block();
+  }
   norm_quant_block<NIT, true, Q81>(x + r * cols, addv ? addv + r * cols : nullptr, w, cols, eps, L, &s_rms, (signed char*)p,
                                    (unsigned short*)(p + off_d), (void*)(p + off_aux), nullptr, half);
+  if (xh == nullptr) return;
   __threadfence_block();
   __syncthreads();
   const int nb = cols / 32;

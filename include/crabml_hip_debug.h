@@ -106,8 +106,9 @@ int crabml_hip_debug_flash_attention_rows(crabml_hip_device_t* dev, const float*
                                                      Q4_1 / Q4_K / Q6_K weights take from 32 rows (gemm_f16w.hip; a stated deviation of the
                                                      fast tier) */
 #define CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS 33554432 /* A/B, fast prompt pass: the rows' f16 planes for the weight GEMM are made by their
-                                                              own launch (k_rows_to_f16) instead of by the kernels that quantize the rows
-                                                              (bit-identical) */
+                                                              own launch (k_rows_to_f16) instead of by the kernels that quantize the rows,
+                                                              and the k pieces of a split wo / ffn_down GEMM are added by their own launch
+                                                              (k_addn_f32) instead of by the norm kernel that consumes them (bit-identical) */
 #define CRABML_HIP_LLAMA_PREFILL_NO_GU_EPILOGUE 67108864 /* A/B, fast prompt pass: gate | up leave g and u and SiLU * mul (+ quantize) stays its own
                                                            launch, instead of being the f16 GEMM's epilogue (bit-identical) */
 #define CRABML_HIP_LLAMA_NO_K_NORM_IN 16777216 /* A/B, fast Q4_K step: wo gathers the row's sums and quantizes its output to Q8_K itself (two
