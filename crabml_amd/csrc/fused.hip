@@ -185,6 +185,7 @@ struct crabml_hip_llama {
   char *pf_act_dim = nullptr, *pf_act_hid = nullptr;
   float* pf_split = nullptr;  // ... and pf_split_floats of scratch for the partial tiles of its k pieces
   size_t pf_split_floats = 0;
+  void* pf_xh2 = nullptr;  // a second one: the gate | up launch reads pf_xh while its epilogue writes ffn_down's
   void* pf_xh = nullptr;  // the fast pass's f16 GEMMs: the current rhs rows as pre-scaled f16 (gemm_f16w.hip), gemm_f16w_xh_bytes(cap, max(dim, hidden))
   float* pf_scores = nullptr;          // long prompts: [PF_LONG_ROWS][n_heads][seq_len] f32 scores
   unsigned short* pf_p16 = nullptr;    //               and f16 probabilities, allocated on first use
@@ -1075,6 +1076,8 @@ int prefill_alloc(crabml_hip_llama* c, size_t cap) {
   if ((c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1 || c->qt == CRABML_HIP_Q8_K) && !c->dev->strict_order) {  // (whole column tiles + the look-ahead's slack)
     const size_t xb = gemm_f16w_xh_bytes(cap, dim > hidden ? dim : hidden);
     CH_TRY(A(xb, &c->pf_xh));
+    CH_TRY(A(xb, &c->pf_xh2));
+    CH_HIP(c->dev, hipMemsetAsync(c->pf_xh2, 0, xb, c->dev->stream));
     // (the widest split launch is q | k | v; up to 7 partial buffers of a short pass, 3 of a full one)
     c->pf_split_floats = (cap + 1024) * (dim + 2 * kv_dim > hidden ? dim + 2 * kv_dim : hidden);
     CH_TRY(A(c->pf_split_floats * 4, (void**)&c->pf_split));
@@ -1376,14 +1379,34 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
       const size_t ms[2] = {(size_t)hidden, (size_t)hidden};
       float* outs[2] = {c->pf_g, c->pf_u};
       const bool epi = !(g.flags & CRABML_HIP_LLAMA_PREFILL_NO_GU_EPILOGUE);
+      // ... and, for Q8_0 / Q8_1 rows, with the row quantizer behind it (h leaves as ffn_down's planes; its f16 planes go to pf_xh2:
+      // pf_xh is this launch's own rhs)
+      F16wHQuant hq{};
+      int hq_order = 0;
+      if (epi && fuse_rows && !(g.flags & CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS)) {
+        hq.planes = c->pf_act_hid;
+        hq.stride = alh.total;
+        hq.off_d = alh.off_d;
+        hq.off_aux = alh.off_aux;
+        hq.q81 = c->qt == CRABML_HIP_Q8_1;
+        hq.xh = xh_target(c->down[l], hidden, &hq_order) ? (unsigned short*)c->pf_xh2 : nullptr;
+      }
       gu_done = launch_gemm_f16w(dev, ws, ms, 2, (size_t)dim, c->pf_xh, B, outs, c->pf_split, c->pf_split_floats,
-                                 epi ? (const unsigned short*)dev->exp_table : nullptr, epi ? &h_done : nullptr);
+                                 epi ? (const unsigned short*)dev->exp_table : nullptr, epi ? &h_done : nullptr, nullptr, &hq);
+      if (h_done == 2) {
+        a = c->pf_act_hid;
+        if (hq.xh) std::swap(c->pf_xh, c->pf_xh2);  // (ffn_down's GEMM reads what this launch wrote)
+        xh_of = hq.xh ? (const void*)c->pf_act_hid : nullptr;
+        xh_order = hq_order;
+      }
     }
     if (!gu_done) {
       CH_TRY(gemm(c->gate[l], hidden, dim, a, c->pf_g));
       CH_TRY(gemm(c->up[l], hidden, dim, a, c->pf_u));
     }
-    if (h_done) {  // h sits in pf_g: quantize it (the quantizer launch's arithmetic is quant_lane32's, bit for bit)
+    if (h_done == 2) {
+      // (quantized by the launch itself)
+    } else if (h_done) {  // h sits in pf_g: quantize it (the quantizer launch's arithmetic is quant_lane32's, bit for bit)
       a = quant_rows(c->pf_g, hidden, c->pf_act_hid, c->down[l]);
     } else if (fuse_rows) {
       const dim3 gq((unsigned)((hidden + 255) / 256), rows);

@@ -190,6 +190,7 @@ struct F16wMats {
   float* out2[3];    // ksplit > 1: k piece s >= 1 writes its partial tiles to out2[j] + (s - 1) pstride (k_addn_f32 adds them)
   size_t pstride;
   const unsigned short* exp_tab;  // GU launches: the f16 exp table of silu (silu.rs:6-13)
+  F16wHQuant hq;                   // GU launches: h leaves as Q8_0 / Q8_1 planes (+ ffn_down's B') instead of f32 (planes == nullptr: f32)
   int m[3];
   int tiles_end[3];  // cumulative row tiles
 };
@@ -428,6 +429,76 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   }
   // D: lane (i, g) holds rows 4 g .. 4 g + 3 of column i of every tile
   if constexpr (GU) {
+    if (mats.hq.planes != nullptr) {
+      // h = silu(g) * u of the workgroup's 64 rows x CW columns through LDS (the B' buffers are done), then ONE THREAD per
+      // (column, 32-row block) runs the row quantizer on it (quant_lane32's arithmetic, buf_q8_0.rs:87-134 / buf_q8_1.rs:90-129: the
+      // block maximum and the integer sum do not depend on the order) and writes the block's quants, scale, sum and -- in the slot
+      // order of ffn_down's GEMM -- its 32 pre-scaled halfs: h never exists as f32 in memory
+      constexpr int CS = 68;  // floats per column (64 rows + 4: 16-byte aligned columns, four banks apart)
+      float* H = (float*)f16w_lds;
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        f32x4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) hv[r] = f16w_silu_mul(acc[0][t][r], acc[1][t][r], mats.exp_tab);
+        *(f32x4*)(H + (16 * t + i) * CS + wave * 16 + 4 * g) = hv;
+      }
+      __syncthreads();
+      const F16wHQuant& hq = mats.hq;
+      const int nbh = m / 32;
+      for (int b = tid; b < G::CW * 2; b += 256) {
+        const int col = c0 + (b >> 1), hb = rt_l * 2 + (b & 1);
+        if (col >= n || hb >= nbh) continue;
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = *(const f32x4*)(H + (b >> 1) * CS + 32 * (b & 1) + 4 * j);
+        float amax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) amax = fmaxf(amax, fabsf(v[j][r]));
+        const float dd = amax / 127.0f;
+        const unsigned short dh = f2h(dd);
+        int q[32], sum = 0;
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+          const float x = v[e >> 2][e & 3];
+          if (hq.q81) {
+            q[e] = (int)fminf(fmaxf(x / dd, -128.0f), 127.0f);
+          } else {
+            q[e] = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(x / dd) & 0xffu);
+          }
+          sum += q[e];
+        }
+        char* p = hq.planes + (size_t)col * hq.stride;
+        i32x4 pk[2];
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          pk[e >> 2][e & 3] = (int)(((unsigned)q[4 * e] & 0xffu) | (((unsigned)q[4 * e + 1] & 0xffu) << 8) | (((unsigned)q[4 * e + 2] & 0xffu) << 16) |
+                                    (((unsigned)q[4 * e + 3] & 0xffu) << 24));
+        ((i32x4*)(p + (size_t)hb * 32))[0] = pk[0];
+        ((i32x4*)(p + (size_t)hb * 32))[1] = pk[1];
+        ((unsigned short*)(p + hq.off_d))[hb] = dh;
+        if (hq.q81)
+          ((unsigned short*)(p + hq.off_aux))[hb] = f2h((float)sum * dd);
+        else
+          ((int*)(p + hq.off_aux))[hb] = sum;
+        if (hq.xh != nullptr) {
+          const float ds = h2f(dh);
+          unsigned short* xr = hq.xh + ((size_t)col * nbh + hb) * 32;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++) {
+            unsigned short o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = f16w_value(q[f16w_slot_elem(8 * s4 + e)], ds);
+            *(i32x4*)(xr + 8 * s4) = i32x4{(int)(o[0] | ((unsigned)o[1] << 16)), (int)(o[2] | ((unsigned)o[3] << 16)),
+                                           (int)(o[4] | ((unsigned)o[5] << 16)), (int)(o[6] | ((unsigned)o[7] << 16))};
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < T; t++) {
       const int col = c0 + 16 * t + i;
@@ -523,7 +594,8 @@ static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int ro
 // others their own partial buffers in ws, and k_addn_f32 adds them in piece order.  (Measured and not kept: the pieces added with
 // f32 atomics onto a zeroed output -- 32.4k -> 30.1k prompt tok/s, and the sum's order would vary from run to run.)
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
-                      float* const* out, float* ws, size_t ws_floats, const unsigned short* gu_exp_tab, int* gu_done, int* defer_parts) {
+                      float* const* out, float* ws, size_t ws_floats, const unsigned short* gu_exp_tab, int* gu_done, int* defer_parts,
+                      const F16wHQuant* hq) {
   if (gu_done) *gu_done = 0;
   if (defer_parts) *defer_parts = 0;
   if (nw < 1 || nw > 3 || k % 32 != 0 || b < 16) return false;
@@ -551,6 +623,8 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   if (gu) F = 2;
   F16wMats mats{};
   mats.exp_tab = gu_exp_tab;
+  const bool hquant = gu && hq != nullptr && hq->planes != nullptr && m[0] % 32 == 0;
+  if (hquant) mats.hq = *hq;
   F16wParts parts{};
   int row_tiles = 0;
   size_t before = 0;  // output elements of the matrices before j
@@ -594,7 +668,7 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
     ok = launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
   else
     ok = launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
-  if (ok && gu) *gu_done = 1;
+  if (ok && gu) *gu_done = hquant ? 2 : 1;
   if (ok && ksplit > 1 && defer_parts != nullptr && nw == 1) {
     *defer_parts = ksplit - 1;  // the caller's next row kernel adds the pieces (ws + s * b * m, s = 0 ..) in the same order
   } else if (ok && ksplit > 1) {

@@ -44,13 +44,20 @@ void launch_q4k_pack_scales(hipStream_t st, void* hdr_plane, size_t blk0, size_t
 void launch_q4k_class_major(hipStream_t st, void* qs_plane, size_t blk0, size_t n_blocks);
 // gemm_f16w.hip: the fast prompt pass's weight-stationary f16 GEMM (Q4_0 / Q8_0 weights x Q8_0 rows, Q4_1 x Q8_1, Q4_K / Q6_K x Q8_K)
 // and the rows' pre-scaled f16 planes it reads, in the k-slot order of the weight format (gemm_f16w_order: Q4_K and Q6_K have their own)
+struct F16wHQuant {  // gate | up launches: where h goes as Q8_0 / Q8_1 row planes (act_layout) and, optionally, as ffn_down's f16 planes
+  char* planes = nullptr;
+  size_t stride = 0, off_d = 0, off_aux = 0;
+  unsigned short* xh = nullptr;
+  int q81 = 0;
+};
 bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype);
 int gemm_f16w_order(uint32_t w_dtype);
 size_t gemm_f16w_xh_bytes(size_t rows, size_t k);  // the allocation behind xh: whole 128-row tiles + the look-ahead's slack
 bool launch_rows_to_f16(hipStream_t st, uint32_t act_qtype, uint32_t w_dtype, const void* planes, size_t rows, size_t k, void* xh);
 bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, const size_t* m, int nw, size_t k, const void* xh, size_t b,
                       float* const* out, float* ws = nullptr, size_t ws_floats = 0,  // ws: scratch for the partial tiles of k pieces
-                      const unsigned short* gu_exp_tab = nullptr, int* gu_done = nullptr, int* defer_parts = nullptr);
+                      const unsigned short* gu_exp_tab = nullptr, int* gu_done = nullptr, int* defer_parts = nullptr,
+                      const F16wHQuant* hq = nullptr);  // hq: *gu_done = 2 -- h left as quantized row planes, no f32 h
 // defer_parts (one matrix): a launch cut into k pieces leaves piece 0 in out and pieces 1.. in ws (b * m floats apart) and returns
 // their number instead of launching the reduce: the row kernel that consumes out adds them first, in piece order (prefill_rows.hpp)
 // gu_exp_tab / gu_done (two matrices = ffn_gate, ffn_up): the launch may store h = silu(g) * u to out[0] instead of g and u (*gu_done = 1)
