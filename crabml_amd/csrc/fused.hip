@@ -1267,6 +1267,10 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
   // Q8_0 / Q8_1 rhs: residual add + RMSNorm + quantize as one launch per row (k_norm_quant_rows), SiLU * mul + quantize as one
   // (k_gateup_epi_quant): the (rows, dim) / (rows, hidden) f32 intermediates make one trip through memory instead of three
   const bool fuse_rows = (c->qt == CRABML_HIP_Q8_0 || c->qt == CRABML_HIP_Q8_1) && !(g.flags & CRABML_HIP_LLAMA_NO_PREFILL_ROW_FUSION);
+  // Q8_K rhs (K-quant layers): the same for residual add + RMSNorm + quantize (k_norm_quant_rows_k); SiLU * mul keeps its own launch
+  // (from 192 rows: one 1024-thread workgroup per row is a chain of four barriers -- below, the four small launches run 1-2 % faster)
+  const bool fuse_k = c->qt == CRABML_HIP_Q8_K && dim % 256 == 0 && B >= 192 && !(g.flags & CRABML_HIP_LLAMA_NO_PREFILL_ROW_FUSION);
+  const bool fuse_norm = fuse_rows || fuse_k;
   const ActLayout ald = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)dim);
   const ActLayout alh = act_layout(c->qt == CRABML_HIP_F32 ? CRABML_HIP_Q8_0 : c->qt, (size_t)hidden);
   // pending = the wo / ffn_down output that has not been added to x yet (folded into the next norm)
@@ -1276,6 +1280,17 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     int order = 0;
     unsigned short* xh = (unsigned short*)xh_target(next, dim, &order);
     const size_t pstride = B * (size_t)dim;
+    if (fuse_k) {
+      if (dim <= 4096)
+        k_norm_quant_rows_k<4><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_xn, c->pf_act_dim, ald.total, ald.off_d,
+                                                            ald.off_aux, ald.off_p, half, xh, order, c->pf_split, pstride, nparts);
+      else
+        k_norm_quant_rows_k<12><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_xn, c->pf_act_dim, ald.total, ald.off_d,
+                                                             ald.off_aux, ald.off_p, half, xh, order, c->pf_split, pstride, nparts);
+      xh_of = xh ? c->pf_act_dim : nullptr;
+      xh_order = order;
+      return c->pf_act_dim;
+    }
 #define CRABML_NQR(NIT_, Q_)                                                                                                         \
   if (xh || nparts > 0)                                                                                                              \
     k_norm_quant_rows_h<NIT_, Q_><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d,  \
@@ -1303,7 +1318,7 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
   int down_parts = 0;         // ... as piece 0 of this many + 1 k pieces
   for (int l = 0; l < L; l++) {
     const void* a;
-    if (fuse_rows) {
+    if (fuse_norm) {
       a = norm_quant_rows((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, pending_down ? c->pf_tmp : nullptr, c->wq[l],
                           pending_down ? down_parts : 0);
       pending_down = false;
@@ -1361,8 +1376,8 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     }
     a = quant_rows(c->pf_attn, dim, c->pf_act_dim, c->wo[l]);
     int wo_parts = 0;
-    CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp, fuse_rows ? &wo_parts : nullptr));  // llama2.rs:600
-    if (fuse_rows) {
+    CH_TRY(gemm(c->wo[l], dim, dim, a, c->pf_tmp, fuse_norm ? &wo_parts : nullptr));  // llama2.rs:600
+    if (fuse_norm) {
       a = norm_quant_rows((const float*)c->rms_ffn[l]->ptr, 1e-5f, c->pf_tmp, c->gate[l], wo_parts);  // x += wo out (:266), FFN norm (:611), quantize
     } else {
       k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);  // :266
@@ -1432,8 +1447,8 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
                                                                                  c->pf_g, (int)(B * hidden));
       a = quant_rows(c->pf_g, hidden, c->pf_act_hid, c->down[l]);
     }
-    CH_TRY(gemm(c->down[l], dim, hidden, a, c->pf_tmp, fuse_rows && l + 1 < L ? &down_parts : nullptr));  // llama2.rs:633-636
-    if (fuse_rows && l + 1 < L)
+    CH_TRY(gemm(c->down[l], dim, hidden, a, c->pf_tmp, fuse_norm && l + 1 < L ? &down_parts : nullptr));  // llama2.rs:633-636
+    if (fuse_norm && l + 1 < L)
       pending_down = true;  // added by the next layer's norm launch
     else
       k_res_epi<<<(unsigned)(((size_t)B * dim + 255) / 256), 256, 0, st>>>(c->pf_tmp, c->pf_x, (int)(B * dim), 1);

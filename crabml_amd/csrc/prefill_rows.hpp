@@ -44,6 +44,53 @@ __global__ __launch_bounds__(1024) void k_norm_quant_rows_h(float* __restrict__ 
   for (int t = threadIdx.x; t < nb * 4; t += blockDim.x) rows_to_f16_piece<0>(p, off_d, t, xh + r * (size_t)cols);
 }
 
+// Q8_K rows (K-quant layers): residual add (+ the k pieces of the GEMM that made it) + RMSNorm (k_norm_f32_rows' arithmetic: xn goes to
+// memory as there) + the Q8_K quantizer (k_quantize_q8_k's: a wave per super-block, on the xn the workgroup has just written) + the
+// row's B' in the k-slot order of the weight format that reads it -- one launch where the pass had k_addn_f32, k_res_epi, k_norm_f32_rows
+// and k_quantize_q8_k
+template <int NIT>
+__global__ __launch_bounds__(1024) void k_norm_quant_rows_k(float* __restrict__ x, float* __restrict__ addv, const float* __restrict__ w, int cols,
+                                                           float eps, float* __restrict__ xn, char* __restrict__ planes, size_t row_stride,
+                                                           size_t off_d, size_t off_aux, size_t off_p, int half, unsigned short* __restrict__ xh,
+                                                           int xh_order, const float* __restrict__ parts, size_t pstride, int nparts) {
+  extern __shared__ float lds[];
+  __shared__ float s_rms;
+  NormLds L{lds, lds + cols};
+  const size_t r = blockIdx.x;
+  if (nparts > 0) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int i = it * 1024 + threadIdx.x;  // (norm_quant_block's own element -> thread mapping)
+      if (i < cols) {
+        float v = addv[r * cols + i];
+        for (int s = 0; s < nparts; s++) v = v + parts[(size_t)s * pstride + r * cols + i];
+        addv[r * cols + i] = v;
+      }
+    }
+    __threadfence_block();
+  }
+  float* xr = xn + r * cols;
+  norm_quant_block<NIT, false>(x + r * cols, addv ? addv + r * cols : nullptr, w, cols, eps, L, &s_rms, nullptr, nullptr, nullptr, xr, half);
+  __threadfence_block();
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nsb = cols / 256;
+  char* p = planes + r * row_stride;
+  for (int sb = wave; sb < nsb; sb += 16) {
+    const f32x4 v = ((const f32x4*)xr)[sb * 64 + lane];
+    const Q8KLane o = q8k_wave_quant(v, lane);
+    *(unsigned*)(p + sb * 256 + lane * 4) = o.packed;
+    q8k_store_class_major((signed char*)(p + off_p) + sb * 256, lane, o.packed);
+    if ((lane & 3) == 0) ((short*)(p + off_aux))[sb * 16 + (lane >> 2)] = (short)o.quad_sum;
+    if (lane == 0) ((float*)(p + off_d))[sb] = o.d;
+    if (xh) {
+      unsigned short* xo = xh + r * (size_t)cols;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        xo[f16w_pos_q8k(xh_order, sb, 4 * lane + i)] = f16w_value((int)(signed char)((o.packed >> (8 * i)) & 0xffu), o.d);
+    }
+  }
+}
+
 // k_gateup_epi_quant (h = silu(g) * u quantized straight into the rows' Q8_0 / Q8_1 planes) + the rows' B' (order 0)
 template <bool Q81>
 __global__ __launch_bounds__(256) void k_gateup_epi_quant_h(const float* __restrict__ g, const float* __restrict__ u,

@@ -230,6 +230,27 @@ def test_prefill_row_fusion_equals_the_separate_launches(ca, fmt):
             assert list(a.decode_greedy(nxt, 5)) == list(b.decode_greedy(nxt, 5))
 
 
+@pytest.mark.parametrize("fmt", ["Q4_K", "Q4_K_M", "Q6_K"])
+def test_prefill_row_fusion_k_quants_equals_the_separate_launches(ca, fmt):
+    """Q8_K rows (K-quant layers), passes of >= 192 rows: residual add (+ the k pieces of the GEMM behind it) + RMSNorm + Q8_K quantize
+    (+ the next GEMM's f16 planes) as ONE launch per prompt row (k_norm_quant_rows_k) against k_addn_f32 / k_res_epi / k_norm_f32_rows /
+    k_quantize_q8_k (flag 262144): same logits and the same decoding afterwards, bit for bit, fast and strict, one pass of 200 rows
+    and passes of 192 + 8 (the short tail keeps the separate launches)."""
+    model = (synth.build_model(synth.SHAPES["tiny-gqa"], synth.Q4_K, seed=29, k_m_mix=True) if fmt == "Q4_K_M"
+             else synth.build_model(synth.SHAPES["tiny-gqa"], synth.TYPE_BY_NAME[fmt], seed=29))
+    prompt = [(7 * i + 4) % 1000 for i in range(200)]
+    for strict in (False, True):
+        dev = ca.HipTensorDevice(0, False, 0, strict)
+        conf, w = synth.to_hip(model, dev)
+        for chunk in (512, 192):
+            a = ca.HipLlamaRunner(conf, w, dev, 232, True, prefill_chunk=chunk)
+            b = ca.HipLlamaRunner(conf, w, dev, 232, True, prefill_chunk=chunk, extra_flags=262144)
+            la, lb = a.prefill(prompt), b.prefill(prompt)
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), (fmt, strict, chunk)
+            nxt = int(np.argmax(la))
+            assert list(a.decode_greedy(nxt, 5)) == list(b.decode_greedy(nxt, 5))
+
+
 PREFILL_INT8_GEMM = 524288  # CRABML_HIP_LLAMA_PREFILL_INT8_GEMM (include/crabml_hip_debug.h)
 
 
