@@ -1280,6 +1280,32 @@ int prefill_chunk(crabml_hip_llama* c, const uint32_t* tokens, size_t B, size_t 
     int order = 0;
     unsigned short* xh = (unsigned short*)xh_target(next, dim, &order);
     const size_t pstride = B * (size_t)dim;
+    // Q8_0 / Q8_1 rows of 4096 / 8192 elements: the 256-thread form (a thread owns half a quant block / a whole one; prefill_rows.hpp)
+    static const bool rows_1024 = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_NORM_ROWS_1024=1): the 1024-thread kernel
+      const char* h = getenv("CRABML_HIP_TEST_HOOKS");
+      const char* e = getenv("CRABML_HIP_NORM_ROWS_1024");
+      return h && h[0] == '1' && e && e[0] == '1';
+    }();
+    if (!fuse_k && !rows_1024 && (dim == 4096 || dim == 8192) && !(g.flags & CRABML_HIP_LLAMA_PREFILL_SEPARATE_F16_ROWS)) {
+#define CRABML_NQW(E_, Q_)                                                                                                            \
+  k_norm_quant_rows_w<E_, Q_><<<rows, 256, 0, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_act_dim, ald.total, ald.off_d, ald.off_aux, \
+                                                    half, xh, c->pf_split, pstride, nparts)
+      if (dim == 4096) {
+        if (q81)
+          CRABML_NQW(16, true);
+        else
+          CRABML_NQW(16, false);
+      } else {
+        if (q81)
+          CRABML_NQW(32, true);
+        else
+          CRABML_NQW(32, false);
+      }
+#undef CRABML_NQW
+      xh_of = xh ? c->pf_act_dim : nullptr;
+      xh_order = order;
+      return c->pf_act_dim;
+    }
     if (fuse_k) {
       if (dim <= 4096)
         k_norm_quant_rows_k<4><<<rows, 1024, norm_lds, st>>>(c->pf_x, pending, wn, dim, eps, c->pf_xn, c->pf_act_dim, ald.total, ald.off_d,

@@ -44,6 +44,149 @@ __global__ __launch_bounds__(1024) void k_norm_quant_rows_h(float* __restrict__ 
   for (int t = threadIdx.x; t < nb * 4; t += blockDim.x) rows_to_f16_piece<0>(p, off_d, t, xh + r * (size_t)cols);
 }
 
+// The same row (residual add + k pieces + RMSNorm + Q8_0 / Q8_1 quantize + B'), 256 threads instead of 1024: a thread owns E = cols / 256
+// CONSECUTIVE elements -- 16 (half a 32-element chunk and quant block; cols = 4096) or 32 (a whole one; 8192) -- so the chunk's sum of
+// squares, the block maximum and the block's integer sum are one register scan plus, for E = 16, one exchange with the neighbouring
+// lane; nothing but the chunk sums goes through LDS (two barriers where norm_quant_block has four, and eight rows per CU in flight
+// instead of two).  Arithmetic = norm_quant_block's, bit for bit: a chunk's squares from -0.0 in element order (half: rows 0..15 and
+// 16..31 separately, then added -- the fast step's order; else one 32-element scan, rms_norm.rs:35-38); the chunk sums added as there
+// (half: 64 per round through wave_sum_f32, rounds in order; else strictly in chunk order); (x / rms) * w; quant_lane32's quantizer
+// (maximum and integer sum do not depend on the order).
+template <int E, bool Q81>
+__global__ __launch_bounds__(256) void k_norm_quant_rows_w(float* __restrict__ x, const float* __restrict__ addv, const float* __restrict__ w,
+                                                          int cols, float eps, char* __restrict__ planes, size_t row_stride, size_t off_d,
+                                                          size_t off_aux, int half, unsigned short* __restrict__ xh,
+                                                          const float* __restrict__ parts, size_t pstride, int nparts) {
+  static_assert(E == 16 || E == 32, "half a block or a whole one per thread");
+  constexpr int V = E / 4;
+  __shared__ float cs_lds[256];
+  __shared__ float s_rms;
+  const size_t r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const size_t e0 = r * (size_t)cols + (size_t)E * tid;
+  f32x4 xv[V], wv[V];
+#pragma unroll
+  for (int j = 0; j < V; j++) {
+    xv[j] = ((const f32x4*)(x + e0))[j];
+    wv[j] = ((const f32x4*)(w + (size_t)E * tid))[j];
+  }
+  if (addv != nullptr) {
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      f32x4 a = ((const f32x4*)(addv + e0))[j];
+      for (int s = 0; s < nparts; s++) a = a + ((const f32x4*)(parts + (size_t)s * pstride + e0))[j];  // (k_addn_f32's order)
+      xv[j] = a + xv[j];  // x = matmul_out + x (llama2.rs:266 / :636)
+      ((f32x4*)(x + e0))[j] = xv[j];
+    }
+  }
+  // ---- the chunk's sum of squares
+  float cs;
+  if constexpr (E == 32) {
+    float s0 = -0.0f, s1 = -0.0f;
+#pragma unroll
+    for (int j = 0; j < V; j++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float& a = (half && j >= 4) ? s1 : s0;
+        a += xv[j][i] * xv[j][i];
+      }
+    cs = half ? s0 + s1 : s0;
+    cs_lds[tid] = cs;
+  } else {
+    float hs = -0.0f;
+#pragma unroll
+    for (int j = 0; j < V; j++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) hs += xv[j][i] * xv[j][i];
+    const float other = dpp_f<0xB1>(hs);  // the neighbouring lane's (lane ^ 1)
+    if (half) {
+      cs = (tid & 1) ? other + hs : hs + other;  // rows 0..15 + rows 16..31
+    } else {
+      float sc = other;  // the odd lane continues the even lane's scan
+#pragma unroll
+      for (int j = 0; j < V; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) sc += xv[j][i] * xv[j][i];
+      cs = sc;  // (meaningful in the odd lane)
+    }
+    if ((tid & 1) == 1) cs_lds[tid >> 1] = cs;
+  }
+  __syncthreads();
+  const int nchunks = cols / 32;
+  if (tid < 64) {
+    float sum = 0.0f;
+    for (int base = 0; base < nchunks; base += 64) {
+      const float v = base + tid < nchunks ? cs_lds[base + tid] : 0.0f;
+      if (half) {
+        sum += wave_sum_f32(v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 64; i++) sum += rl_f(v, i);
+      }
+    }
+    if (tid == 0) s_rms = sqrtf(sum / (float)cols + eps);
+  }
+  __syncthreads();
+  const float rms = s_rms;
+  // ---- normalize, quantize (a 32-element block = this thread, or this thread and lane ^ 1)
+  float amax = 0.0f;
+#pragma unroll
+  for (int j = 0; j < V; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      xv[j][i] = (xv[j][i] / rms) * wv[j][i];
+      amax = fmaxf(amax, fabsf(xv[j][i]));
+    }
+  if constexpr (E == 16) amax = fmaxf(amax, dpp_f<0xB1>(amax));
+  const float dd = amax / 127.0f;
+  const unsigned short dh = f2h(dd);
+  int q[E], sum = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const float v = xv[e >> 2][e & 3];
+    if constexpr (Q81)
+      q[e] = (int)fminf(fmaxf(v / dd, -128.0f), 127.0f);
+    else
+      q[e] = (int)(signed char)(unsigned char)((unsigned)rs_f32_as_i32(v / dd) & 0xffu);
+    sum += q[e];
+  }
+  if constexpr (E == 16) sum += dpp_i<0xB1>(sum);
+  char* p = planes + r * row_stride;
+#pragma unroll
+  for (int j = 0; j < E / 16; j++) {
+    i32x4 pk;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      pk[i] = (int)(((unsigned)q[16 * j + 4 * i] & 0xffu) | (((unsigned)q[16 * j + 4 * i + 1] & 0xffu) << 8) |
+                    (((unsigned)q[16 * j + 4 * i + 2] & 0xffu) << 16) | (((unsigned)q[16 * j + 4 * i + 3] & 0xffu) << 24));
+    ((i32x4*)(p + (size_t)E * tid))[j] = pk;
+  }
+  const int blk = E == 32 ? tid : tid >> 1;
+  if (E == 32 || (tid & 1) == 0) {
+    ((unsigned short*)(p + off_d))[blk] = dh;
+    if constexpr (Q81)
+      ((unsigned short*)(p + off_aux))[blk] = f2h((float)sum * dd);
+    else
+      ((int*)(p + off_aux))[blk] = sum;
+  }
+  if (xh != nullptr) {
+    const float ds = h2f(dh);
+    unsigned short* xr = xh + r * (size_t)cols + (size_t)blk * 32;
+#pragma unroll
+    for (int hj = 0; hj < E / 16; hj++) {
+      const int hi = E == 32 ? hj : (tid & 1);  // which 16 elements of the block
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {  // elements 16 hi + 4 s4 + {0, 2, 1, 3} -> slots 8 s4 + 4 hi + {0, 1, 2, 3} (f16w_slot_of_elem)
+        const int b = 16 * hj + 4 * s4;
+        const unsigned lo = (unsigned)f16w_value(q[b], ds) | ((unsigned)f16w_value(q[b + 2], ds) << 16);
+        const unsigned hi2 = (unsigned)f16w_value(q[b + 1], ds) | ((unsigned)f16w_value(q[b + 3], ds) << 16);
+        *(unsigned long long*)(xr + 8 * s4 + 4 * hi) = (unsigned long long)lo | ((unsigned long long)hi2 << 32);
+      }
+    }
+  }
+  (void)lane;
+}
+
 // Q8_K rows (K-quant layers): residual add (+ the k pieces of the GEMM that made it) + RMSNorm (k_norm_f32_rows' arithmetic: xn goes to
 // memory as there) + the Q8_K quantizer (k_quantize_q8_k's: a wave per super-block, on the xn the workgroup has just written) + the
 // row's B' in the k-slot order of the weight format that reads it -- one launch where the pass had k_addn_f32, k_res_epi, k_norm_f32_rows

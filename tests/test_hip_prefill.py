@@ -357,7 +357,8 @@ NO_GU_EPILOGUE = 67108864  # CRABML_HIP_LLAMA_PREFILL_NO_GU_EPILOGUE
 
 @pytest.mark.parametrize("fmt,shape,n", [("Q4_0", "tiny-gqa", 200), ("Q4_0", "15m", 77), ("Q8_0", "tiny-hd128", 96), ("Q4_1", "tiny-gqa", 130),
                                          ("Q4_K", "tiny-gqa", 200), ("Q4_K_M", "tiny-gqa", 64), ("Q6_K", "tiny-hd128", 40),
-                                         ("Q4_0", "wide-ffn", 200), ("Q4_K", "wide-ffn", 173), ("Q8_0", "wide-ffn", 130)])
+                                         ("Q4_0", "wide-ffn", 200), ("Q4_K", "wide-ffn", 173), ("Q8_0", "wide-ffn", 130),
+                                         ("Q4_0", "dim-4096", 200), ("Q4_1", "dim-4096", 70), ("Q8_0", "dim-8192", 130)])
 def test_fast_prompt_pass_rows_write_their_own_f16_planes(ca, fmt, shape, n):
     """The kernels that quantize the rows of a fast prompt pass (norm + quantize, SiLU * mul + quantize, the stand-alone quantizer for
     the attention output and for Q8_K rows) also leave the pre-scaled f16 planes the next weight GEMM reads (f16w_rows.hpp), in that
@@ -369,15 +370,20 @@ def test_fast_prompt_pass_rows_write_their_own_f16_planes(ca, fmt, shape, n):
     kw = dict(seed=23)
     # wide-ffn: hidden = 12288 -- 192 row tiles of 64 x two column tiles = 1.5 workgroups per CU: the gate | up launch takes the
     # SiLU * mul epilogue (one pass of > 128 rows; the 48-row passes keep the separate launch)
-    shp = synth.ModelShape("wide-ffn", 512, 12288, 1, 4, 2, 512, 256, 1e-5, None) if shape == "wide-ffn" else synth.SHAPES[shape]
+    # dim-4096 / dim-8192: rows of 4096 / 8192 elements take the 256-thread norm + quantize kernel (k_norm_quant_rows_w: a thread owns
+    # half a quant block / a whole one) -- against the 1024-thread kernel behind the flag, on the fast AND the strict device
+    shp = (synth.ModelShape("wide-ffn", 512, 12288, 1, 4, 2, 512, 256, 1e-5, None) if shape == "wide-ffn"
+           else synth.ModelShape("dim-4096", 4096, 1024, 1, 32, 8, 512, 256, 1e-5, None) if shape == "dim-4096"
+           else synth.ModelShape("dim-8192", 8192, 1024, 1, 64, 8, 512, 256, 1e-5, None) if shape == "dim-8192" else synth.SHAPES[shape])
     model = (synth.build_model(shp, synth.Q4_K, k_m_mix=True, **kw) if fmt == "Q4_K_M" else synth.build_model(shp, getattr(synth, fmt), **kw))
     prompt = [(17 * i + 2) % model.shape.vocab for i in range(n)]
-    dev = ca.HipTensorDevice(0)
-    conf, w = synth.to_hip(model, dev)
-    for chunk in (512, 48):  # one pass / passes of 48 rows and a ragged tail
-        a = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=chunk)
-        b = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=chunk, extra_flags=SEPARATE_F16_ROWS | NO_GU_EPILOGUE)
-        la, lb = np.array(a.prefill(prompt)), np.array(b.prefill(prompt))
-        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), (fmt, shape, chunk)
-        nxt = int(np.argmax(la))
-        assert list(a.decode_greedy(nxt, 6)) == list(b.decode_greedy(nxt, 6))
+    for strict in ((False, True) if shape.startswith("dim-") else (False,)):
+        dev = ca.HipTensorDevice(0, False, 0, strict)
+        conf, w = synth.to_hip(model, dev)
+        for chunk in (512, 48):  # one pass / passes of 48 rows and a ragged tail
+            a = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=chunk)
+            b = ca.HipLlamaRunner(conf, w, dev, n + 16, True, prefill_chunk=chunk, extra_flags=SEPARATE_F16_ROWS | NO_GU_EPILOGUE)
+            la, lb = np.array(a.prefill(prompt)), np.array(b.prefill(prompt))
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), (fmt, shape, chunk, strict)
+            nxt = int(np.argmax(la))
+            assert list(a.decode_greedy(nxt, 6)) == list(b.decode_greedy(nxt, 6))
