@@ -571,7 +571,7 @@ bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype) {
 }
 // wave tile: T column tiles of 16 prompt rows -- 8 (128-row workgroup tiles) from 65 rows up; short passes (a short prompt, the ragged
 // tail of a long one) take 4 / 2: the MFMAs of an empty column tile cost what a full one's do
-static int f16w_col_tiles_per_wave(size_t b, int variant) { return (variant & 16) ? 8 : b <= 32 ? 2 : b <= 64 ? 4 : 8; }
+static int f16w_col_tiles_per_wave(size_t b, int variant) { return (variant & 512) ? 4 : (variant & 16) ? 8 : b <= 32 ? 2 : b <= 64 ? 4 : 8; }
 template <int WF>
 static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit, int F,
                             int variant, bool gu) {
@@ -604,7 +604,7 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   if ((dt == CRABML_HIP_Q4_K || dt == CRABML_HIP_Q6_K) && k % 256 != 0) return false;
   for (int j = 0; j < nw; j++)
     if (w[j]->dtype != dt || m[j] % 4 != 0) return false;
-  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = two fragments, 3 = one; +8 = never split k; +16 = T = 8 always; +32 = k pieces of >= 8 chunks; +64 = no gate | up epilogue
+  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = two fragments, 3 = one; +8 = never split k; +16 = T = 8 always; +32 = k pieces of >= 8 chunks; +64 = no gate | up epilogue; +512 = T = 4 always
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_F16W");
     return h && h[0] == '1' && e ? atoi(e) : 0;
