@@ -574,15 +574,15 @@ bool gemm_f16w_covers(uint32_t w_dtype, uint32_t act_qtype) {
 static int f16w_col_tiles_per_wave(size_t b, int variant) { return (variant & 512) ? 4 : (variant & 16) ? 8 : b <= 32 ? 2 : b <= 64 ? 4 : 8; }
 template <int WF>
 static bool launch_f16w_fmt(crabml_hip_device* dev, const F16wMats& mats, int row_tiles, size_t k, const void* xh, size_t b, int ksplit, int F,
-                            int variant, bool gu) {
+                            int variant, bool gu, int T) {
   if (gu) {
-    switch (f16w_col_tiles_per_wave(b, variant)) {
+    switch (T) {
       case 2: return launch_f16w_t<WF, 2, 2, true>(dev, mats, row_tiles, k, xh, b, 1);
       case 4: return launch_f16w_t<WF, 2, 4, true>(dev, mats, row_tiles, k, xh, b, 1);
       default: return launch_f16w_t<WF, 2, 8, true>(dev, mats, row_tiles, k, xh, b, 1);
     }
   }
-  switch (f16w_col_tiles_per_wave(b, variant)) {
+  switch (T) {
     case 2: return F == 2 ? launch_f16w_t<WF, 2, 2>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 2>(dev, mats, row_tiles, k, xh, b, ksplit);
     case 4: return F == 2 ? launch_f16w_t<WF, 2, 4>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 4>(dev, mats, row_tiles, k, xh, b, ksplit);
     default: return F == 2 ? launch_f16w_t<WF, 2, 8>(dev, mats, row_tiles, k, xh, b, ksplit) : launch_f16w_t<WF, 1, 8>(dev, mats, row_tiles, k, xh, b, ksplit);
@@ -604,16 +604,23 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
   if ((dt == CRABML_HIP_Q4_K || dt == CRABML_HIP_Q6_K) && k % 256 != 0) return false;
   for (int j = 0; j < nw; j++)
     if (w[j]->dtype != dt || m[j] % 4 != 0) return false;
-  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = two fragments, 3 = one; +8 = never split k; +16 = T = 8 always; +32 = k pieces of >= 8 chunks; +64 = no gate | up epilogue; +512 = T = 4 always
+  static const int variant = [] {  // lab hook (CRABML_HIP_TEST_HOOKS=1 CRABML_HIP_F16W=n): 1 = two fragments, 3 = one; +8 = never split k; +16 = T = 8 always; +32 = k pieces of >= 8 chunks; +64 = no gate | up epilogue; +512 = T = 4 always; +1024 = narrow launches as <2, 4>
     const char* h = getenv("CRABML_HIP_TEST_HOOKS");
     const char* e = getenv("CRABML_HIP_F16W");
     return h && h[0] == '1' && e ? atoi(e) : 0;
   }();
   size_t mtot = 0;
   for (int j = 0; j < nw; j++) mtot += m[j];
-  const size_t cw = 16 * (size_t)f16w_col_tiles_per_wave(b, variant), col128 = (b + cw - 1) / cw;  // (column tiles of the launch)
+  int T = f16w_col_tiles_per_wave(b, variant);
+  size_t cw = 16 * (size_t)T, col128 = (b + cw - 1) / cw;  // (column tiles of the launch)
   // two fragments per wave (every B' fragment read from LDS feeds two MFMAs) when 128-row tiles still cover the chip
   int F = ((mtot + 127) / 128) * col128 >= (size_t)dev->n_cu ? 2 : 1;
+  if ((variant & 1024) && F == 1 && T == 8 && b >= 128) {  // lab: narrow launches as two fragments x four column tiles
+    F = 2;
+    T = 4;
+    cw = 64;
+    col128 = (b + cw - 1) / cw;
+  }
   if ((variant & 7) == 1) F = 2;
   if ((variant & 7) == 3) F = 1;
   // gate | up with the SiLU * mul epilogue (out[0] = h, out[1] untouched): when 64-row tiles of both matrices cover the chip without
@@ -659,15 +666,15 @@ bool launch_gemm_f16w(crabml_hip_device* dev, const crabml_hip_buf* const* w, co
       ksplit *= 2;
   bool ok;
   if (dt == CRABML_HIP_Q8_0)
-    ok = launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
+    ok = launch_f16w_fmt<WF_Q8_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu, T);
   else if (dt == CRABML_HIP_Q4_K)
-    ok = launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
+    ok = launch_f16w_fmt<WF_Q4_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu, T);
   else if (dt == CRABML_HIP_Q6_K)
-    ok = launch_f16w_fmt<WF_Q6_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
+    ok = launch_f16w_fmt<WF_Q6_K>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu, T);
   else if (dt == CRABML_HIP_Q4_1)
-    ok = launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
+    ok = launch_f16w_fmt<WF_Q4_1>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu, T);
   else
-    ok = launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu);
+    ok = launch_f16w_fmt<WF_Q4_0>(dev, mats, row_tiles, k, xh, b, ksplit, F, variant, gu, T);
   if (ok && gu) *gu_done = hquant ? 2 : 1;
   if (ok && ksplit > 1 && defer_parts != nullptr && nw == 1) {
     *defer_parts = ksplit - 1;  // the caller's next row kernel adds the pieces (ws + s * b * m, s = 0 ..) in the same order
