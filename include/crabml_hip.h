@@ -241,7 +241,7 @@ typedef struct crabml_hip_llama_config { /* crabml-llama2/src/model.rs:30-53 */
   void* tp_comm; /* crabml_hip_tp_comm_t*; NULL with tp_size > 1 = a rank of the single-device simulation */
   size_t attn_long_from; /* cached positions from which attention runs as the multi-workgroup kernels (0 = default: 96 for the
                           * fast step's split-KV kernels, 224 for the exact ones) */
-  size_t prefill_chunk;  /* rows per batched prefill pass (0 = default 512) */
+  size_t prefill_chunk;  /* rows per batched prefill pass (0 = default: 1024, 512 on a strict-order device; never more than seq_len) */
 } crabml_hip_llama_config_t;
 typedef struct crabml_hip_llama_weights { /* crabml-llama2/src/model.rs:55-84; per-layer arrays of n_layers */
   const crabml_hip_buf_t* token_embed;
