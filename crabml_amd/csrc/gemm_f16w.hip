@@ -537,6 +537,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(F16wMats mats, const i32x4
   }
 }
 
+#undef F16W_PTRS
+#undef F16W_SEL
+
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel)
 static bool f16w_raise_lds(const crabml_hip_device* dev, const void* fn, int bytes) {
   static std::mutex mu;

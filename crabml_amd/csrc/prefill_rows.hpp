@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_norm_quant_rows_w(float* __restrict__ x
   __shared__ float cs_lds[256];
   __shared__ float s_rms;
   const size_t r = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const size_t e0 = r * (size_t)cols + (size_t)E * tid;
   f32x4 xv[V], wv[V];
 #pragma unroll
@@ -184,7 +184,6 @@ __global__ __launch_bounds__(256) void k_norm_quant_rows_w(float* __restrict__ x
       }
     }
   }
-  (void)lane;
 }
 
 // Q8_K rows (K-quant layers): residual add (+ the k pieces of the GEMM that made it) + RMSNorm (k_norm_f32_rows' arithmetic: xn goes to
