@@ -19,7 +19,8 @@ ap.add_argument("--steps", type=int, default=32)
 ap.add_argument("--fast", action="store_true", help="the default (fast) device instead, for comparison")
 ap.add_argument("--flags", type=int, default=0, help="extra CRABML_HIP_LLAMA_* flags (A/B runs)")
 a = ap.parse_args()
-model = synth.build_model(synth.SHAPES[a.model], synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers)
+k_m = a.wtype.upper() == "Q4_K_M"  # llama.cpp's mix: Q4_K body, attn_v / ffn_down in Q6_K on some layers, Q6_K classifier
+model = synth.build_model(synth.SHAPES[a.model], synth.Q4_K if k_m else synth.TYPE_BY_NAME[a.wtype], seed=8, n_layers=a.layers, k_m_mix=k_m)
 dev = ca.HipTensorDevice(0) if a.fast else ca.HipTensorDevice(0, False, 0, True)
 conf, w = synth.to_hip(model, dev)
 r = ca.HipLlamaRunner(conf, w, dev, a.steps + 24, True, extra_flags=a.flags)
