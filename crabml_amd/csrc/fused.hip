@@ -143,10 +143,6 @@ struct crabml_hip_llama {
   bool defer_norm = false;
   float* rsums = nullptr;    // [dim / 16] chunk sums of squares of the residual stream
   bool norm_epi_k = false;   // the same for Q4_K layers (Q8_K planes out of the epilogue)
-  // strict-order device, a Q4_K body with Q6_K attn_v / ffn_down on SOME layers (llama.cpp's *_K_M recipe): the pure layers take the
-  // ordered fused launches (enqueue_segment_k, ORD), the layers marked here the per-op segments (enqueue_segment_generic) -- both
-  // bit-identical to the reference; empty otherwise
-  std::vector<unsigned char> layer_generic;
   unsigned* out_tokens = nullptr;
   int out_cap = 0;
   float* am_val = nullptr;  // argmax partials
@@ -643,7 +639,7 @@ int enqueue_segment_t(crabml_hip_llama* c, int seg) {
     const RmsTail rtq{c->rsums, dim / 32, 1.0f / (float)dim, g.rms_norm_eps};
     if (c->ord)
       launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * ((dim / 32 + 3) & ~3) * sizeof(float), planes_of(c->wq[l]),
-               planes_of(c->wk[l]), planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e);
+               planes_of(c->wk[l]), planes_of(c->wv[l]), act_view<FMT>(ad), dim / 32, e, Planes6{nullptr, 0});
     else if (defer_down && l > 0) {
       if constexpr (!Q81)
         launch_k(st, R, k_qkv<FMT, true>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_of(c->wq[l]), planes_of(c->wk[l]),
@@ -908,11 +904,8 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     return P1();
   };
 
-  // the layer before segment `seg` ran as per-op segments (layer_generic): x is all it left -- no planes from a norm epilogue
-  auto prev_generic = [&](int layer) { return !c->layer_generic.empty() && layer > 0 && c->layer_generic[layer - 1] != 0; };
   if (seg == 2 * L) {
-    const void* act = nepi && !prev_generic(L) ? (const void*)c->act_dim
-                                               : norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, c->out_qt);
+    const void* act = nepi ? (const void*)c->act_dim : norm_quant((const float*)c->rms_final->ptr, g.rms_norm_eps, tp, c->out_qt);
     if (prof)
       CH_TRY(prof_begin(dev, &pr, c->output->dtype, 5,
                         (double)c->vocab_l * (double)(dim / block_elems(c->output->dtype)) * (double)block_bytes(c->output->dtype) +
@@ -926,14 +919,14 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
     if (l == 0)
       k_embed<<<(dim + 255) / 256, 256, 0, st>>>((const char*)c->token_embed->ptr, (int)c->token_embed->dtype,
                                                   c->token_embed->wl.off_scale, token_d, dim, c->x);
-    if (!nepi || l == 0 || prev_generic(l)) norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, QT);
+    if (!nepi || l == 0) norm_quant((const float*)c->rms_att[l]->ptr, g.rms_norm_eps, tp && l > 0, QT);
     QkvEpi e{c->qbuf, c->kc[l], c->vc[l], c->rope, pos_d, 1.0f / std::sqrt((float)hd), dim_l, kv_dim_l, hd,
              (int)g.rope_dim, c->npairs, seq_cap, kv16 ? 1 : 0};
     const int total_rows = dim_l + 2 * kv_dim_l;
     CH_TRY(P0(1, total_rows, dim));
     if (ordk)
       launch_k(st, R, k_qkv_ord<FMT>, dim3((total_rows / 2 + 3) / 4), dim3(256), (size_t)8 * (size_t)q4k_rec_stride(dim / BE) * sizeof(float),
-               planes_k(c->wq[l]), planes_k(c->wk[l]), planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e);
+               planes_k(c->wq[l]), planes_k(c->wk[l]), planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]));
     else
       launch_k(st, R, k_qkv<FMT>, dim3((total_rows / 2 + 1) / 2), dim3(128), 0, planes_k(c->wq[l]), planes_k(c->wk[l]),
                planes_k(c->wv[l]), act_k(c->act_dim, dim), dim / BE, e, six(c->wv[l]), RmsTail{nullptr, 0, 0.f, 0.f}, 0);
@@ -998,8 +991,6 @@ int enqueue_segment_k(crabml_hip_llama* c, int seg) {
 }
 
 int enqueue_segment(crabml_hip_llama* c, int seg) {
-  if (c->kfused && !c->layer_generic.empty() && seg < 2 * (int)c->cfg.n_layers && c->layer_generic[seg / 2])
-    return enqueue_segment_generic(c, seg);  // (a strict *_K_M context: this layer holds a Q6_K matrix)
   if (c->kfused)
     return c->wtype == CRABML_HIP_Q4_K ? enqueue_segment_k<CRABML_HIP_Q4_K>(c, seg) : enqueue_segment_k<CRABML_HIP_Q4_1>(c, seg);
   if (c->generic) return enqueue_segment_generic(c, seg);
@@ -1795,20 +1786,16 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
   // segments, each GEMV picking its kernel by the tensor's own dtype
   bool mixed = false;
   bool mix_v_down_q6k = true;  // every deviating tensor is an attn_v / ffn_down in Q6_K inside a Q4_K layer (the *_K_M recipe)
-  std::vector<unsigned char> layer_mixed(g.n_layers, 0);
-  size_t check_layer = 0;
   auto check_w = [&](const crabml_hip_buf* b, size_t m, size_t k, bool v_or_down) {
     if (!b) return false;
     if (b->dtype != wt) {
       if (vec_dot_rhs_dtype(b->dtype) != qt || k % block_elems(b->dtype)) return false;
       mixed = true;
-      layer_mixed[check_layer] = 1;
       if (!(v_or_down && wt == CRABML_HIP_Q4_K && b->dtype == CRABML_HIP_Q6_K)) mix_v_down_q6k = false;
     }
     return check(b, m, k, b->dtype);
   };
   for (size_t l = 0; l < g.n_layers; l++) {
-    check_layer = l;
     if (!check_w(w->wq[l], dim_l, g.embedding_dim, false) || !check_w(w->wk[l], kv_dim_l, g.embedding_dim, false) ||
         !check_w(w->wv[l], kv_dim_l, g.embedding_dim, true) || !check_w(w->wo[l], g.embedding_dim, dim_l, false) ||
         !check_w(w->ffn_gate_weight[l], hidden_l, g.embedding_dim, false) ||
@@ -1863,7 +1850,7 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
   // f32 terms per super-block (eight exact class sums x d, and dmin x sumi) parked in LDS and added in super-block order, the
   // reference's norm order in the wo / ffn_down epilogue (k_qkv_ord, k_gemv_res_nq<.., ORD>, k_gateup_k_lds<.., ORD>); bit-identical
   // to the per-op segments they replace (16 launches per layer).  The term tables must fit LDS.
-  // (a *_K_M mix: its pure Q4_K layers only -- layer_generic)
+  // (a *_K_M mix too: its Q6_K attn_v / ffn_down rows leave the same records, rows_terms_q6k)
   bool ordk = dev->strict_order && wt == CRABML_HIP_Q4_K && (!mixed || mix_v_down_q6k) && out_qt == CRABML_HIP_Q8_K && tp == 1 &&
               !(g.flags & (CRABML_HIP_LLAMA_NO_NORM_EPILOGUE | CRABML_HIP_LLAMA_NO_KQUANT_FUSION | CRABML_HIP_LLAMA_NO_RHS_PROLOGUE)) &&
               g.embedding_dim % 256 == 0 && dim_l % 256 == 0 && hidden_l % 256 == 0 && (int)(g.embedding_dim / 32) <= dev->n_cu;
@@ -1888,10 +1875,7 @@ static int llama_create_impl(crabml_hip_device_t* dev, const crabml_hip_llama_co
     if (!fits) ordk = false;
   }
   if (ordk) ord = true;
-  if (ordk && mixed) {
-    generic = false;
-    c->layer_generic = layer_mixed;
-  }
+  if (ordk && mixed) generic = false;
   c->generic = generic;
   c->ord = ord;
   // Q4_K always; Q4_1 when it cannot take the 5-kernel path (mixed classifier format) or for the A/B flag

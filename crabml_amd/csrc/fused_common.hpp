@@ -451,7 +451,7 @@ __global__ __launch_bounds__(128) void k_qkv(Planes wq, Planes wk, Planes wv, ty
 // added in block order by one lane per row (rows_terms / ordered_sum, gemv_core.hpp) -- q, k and v rows bit-identical to the scalar
 // loops of the reference, then the same epilogue.  Workgroup = 4 waves x one (even, odd) row pair; dynamic LDS = 8 * nt floats.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e) {
+__global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv, typename ActOf<FMT>::type act, int nb, QkvEpi e, Planes6 wv6) {
   extern __shared__ __attribute__((aligned(16))) float ord_terms[];
   const int lane = threadIdx.x & 63, wv_i = wave_in_wg();
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv_i;
@@ -474,7 +474,10 @@ __global__ __launch_bounds__(256) void k_qkv_ord(Planes wq, Planes wk, Planes wv
     // nb super-blocks, nine terms each (q4k_class_terms / q4k_ordered_sum, gemv_core.hpp); dynamic LDS = 8 * q4k_rec_stride(nb) floats
     const int stride = q4k_rec_stride(nb);
     float* T = ord_terms + (size_t)wv_i * 2 * stride;
-    rows_terms_q4k<2, true>(w.q, (const i32x4*)w.d, act, local, m, nb, lane, T, stride);
+    if (wv6.base != nullptr && row0 >= e.dim + e.kv_dim)  // the V rows of this layer are Q6_K (wave-uniform): the same records
+      rows_terms_q6k<2>(wv6.base, wv6.off_qh, act, local, m, nb, lane, T, stride);
+    else
+      rows_terms_q4k<2, true>(w.q, (const i32x4*)w.d, act, local, m, nb, lane, T, stride);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS stores have landed
     __builtin_amdgcn_wave_barrier();
     if (lane < 2) s = q4k_ordered_sum(T + lane * stride, nb);

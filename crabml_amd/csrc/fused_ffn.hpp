@@ -527,6 +527,16 @@ __global__ __launch_bounds__(1024) void k_gemv_res_nq(Planes w, typename ActOf<F
       else
         stage_quant_q8k(xin, nb, (unsigned*)lds_act, sd, sbs, false);
       const ActQ8_K la6{lds_act, sd, sbs, lds_act};
+      if constexpr (ORD) {  // the strict-order step: the rows' records (rows_terms_q6k), chained in super-block order by wave 0
+        const int stride = q4k_rec_stride(nb);
+        float* T = (float*)((char*)lds_act + (((size_t)nb * 292 + 15) & ~(size_t)15));
+        rows_terms_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, T + (size_t)(wave * RW) * stride, stride);
+        __syncthreads();
+        if (wave == 0 && lane < ROWS) hv[part * ROWS + lane] = q4k_ordered_sum(T + (size_t)lane * stride, nb);
+        nq_epilogue<FMT, SPLIT, TP, false, true>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
+                                                 (int)blockIdx.x, (int)gridDim.x, tp);
+        return;
+      }
       rows_partial_q6k<RW>(w6.base, w6.off_qh, la6, row, nchunks * 32, nb, lane, acc);
       nq_epilogue<FMT, SPLIT, TP>(acc, res, wn, wn4, epoch, hv, x, q, d, isum, ng, eps, blk, part, nchunks, row, lane, wave,
                                   (int)blockIdx.x, (int)gridDim.x, tp);

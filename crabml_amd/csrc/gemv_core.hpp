@@ -564,6 +564,74 @@ __device__ __forceinline__ void rows_terms_q4k(const i32x4* __restrict__ wq, con
   }
 }
 
+// The same records for R rows of a Q6_K matrix standing in a Q4_K layer (attn_v / ffn_down of the *_K_M mixes) on the strict-order
+// device (buf_q6_k.rs:183-234: eight f32 lanes, element e feeds lane e % 8 -- exact integers scale * q8 * (q6 - 32) summed per
+// super-block, `sums[l] += aux32[l] * d` in super-block order, the lanes added in order at the end; k_gemv_exact_q6k's arithmetic).
+// A record is Q4_K's 12 floats with float 8 = +0.0 (Q6_K has no minimum term: q4k_ordered_sum's `sumf -= 0.0` changes no bit), so the
+// ordered launches keep ONE table layout and ONE chain.  planes ql | qh | scales | d; act: Q8_K planes in ELEMENT order (act.q);
+// lane = one 16-byte ql piece (8 per super-block); the levels are made signed bytes (q6 - 32), the v_dot4 sums split by byte position.
+template <int R>
+__device__ __forceinline__ void rows_terms_q6k(const char* __restrict__ w, size_t off_qh, const ActQ8_K& act, int row0, int m, int nsb, int lane,
+                                               float* __restrict__ T, int stride) {
+  const size_t n = off_qh / 128;
+  const i32x4* wql = (const i32x4*)w;
+  const i32x4* wqh = (const i32x4*)(w + off_qh);
+  const i32x4* wsc = (const i32x4*)(w + off_qh + n * 64);
+  const unsigned short* wd = (const unsigned short*)(w + off_qh + n * 80);
+  const int np = nsb * 8;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < np;
+    const int cc = live ? c : np - 1;
+    const int sb = cc >> 3, h = (cc >> 2) & 1, a = (cc >> 1) & 1, p = cc & 1;
+    const int gi = 8 * h + p + 2 * a;  // the low nibbles' 16-element scale group; the high nibbles' is gi + 4
+    const i32x4* xq = act.q + (size_t)sb * 16 + gi;
+    const i32x4 xl = xq[0], xh = xq[4];
+    const float d8 = act.d[sb];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const size_t blk = (size_t)(row0 + r < m ? row0 + r : m - 1) * nsb + sb;
+      const i32x4 qv = __builtin_nontemporal_load(wql + blk * 8 + (cc & 7));
+      const i32x4 hv = __builtin_nontemporal_load(wqh + blk * 4 + 2 * h + p);
+      const i32x4 sc4 = __builtin_nontemporal_load(wsc + blk);
+      const int sc_lo = (int)(signed char)(((unsigned)sc4[gi >> 2] >> (8 * (gi & 3))) & 0xFFu);
+      const int sc_hi = (int)(signed char)(((unsigned)sc4[(gi + 4) >> 2] >> (8 * (gi & 3))) & 0xFFu);
+      int lo[8], hi[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) lo[l] = hi[l] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = (unsigned)qv[i], hb = (unsigned)hv[i] >> (2 * a);
+        const unsigned l6 = (q & 0x0F0F0F0Fu) | ((hb & 0x03030303u) << 4);
+        const unsigned h6 = ((q >> 4) & 0x0F0F0F0Fu) | (((hb >> 4) & 0x03030303u) << 4);
+        // 0 .. 63 -> signed bytes v - 32 without carries between bytes
+        const int ls = (int)((((l6 | 0x80808080u) - 0x20202020u)) ^ 0x80808080u);
+        const int hs = (int)((((h6 | 0x80808080u) - 0x20202020u)) ^ 0x80808080u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          lo[4 * (i & 1) + k] = __builtin_amdgcn_sdot4(ls, (int)((unsigned)xl[i] & (0xFFu << (8 * k))), lo[4 * (i & 1) + k], false);
+          hi[4 * (i & 1) + k] = __builtin_amdgcn_sdot4(hs, (int)((unsigned)xh[i] & (0xFFu << (8 * k))), hi[4 * (i & 1) + k], false);
+        }
+      }
+      int A[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        A[l] = live ? sc_lo * lo[l] + sc_hi * hi[l] : 0;
+        A[l] += dpp_i<0xB1>(A[l]);
+        A[l] += dpp_i<0x4E>(A[l]);
+        A[l] += dpp_i<0x141>(A[l]);
+      }
+      if (live && (lane & 7) == 0) {
+        const float d = h2f(wd[blk]) * d8;
+        float* t = T + (size_t)r * stride + sb * 12;
+        *(f32x4*)t = f32x4{(float)A[0] * d, (float)A[1] * d, (float)A[2] * d, (float)A[3] * d};
+        *(f32x4*)(t + 4) = f32x4{(float)A[4] * d, (float)A[5] * d, (float)A[6] * d, (float)A[7] * d};
+        t[8] = 0.0f;
+      }
+    }
+  }
+}
+
 template <int R, bool HDR_DPP = true, bool DBG = false>
 __device__ __forceinline__ void rows_partial_q4k(const i32x4* __restrict__ wq, const i32x4* __restrict__ wh, const ActQ8_K& act,
                                                  int row0, int m, int nsb, int lane, float acc[R], int c0 = 0, int* dbg = nullptr) {
