@@ -1,4 +1,5 @@
 #!/bin/bash
+# the bench lines of a round (driver arguments, defaults) and the per-format table: gpurun --timeout 3000 -- "bash tools/gpu_bench_lines.sh" (writes gpurun_out/r06_bench_*.json)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_steps20_warmup5.json 2> gpurun_out/r06_bench.err; echo "rc=$?"
 timeout 1500 python bench.py > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err; echo "rc=$?"
