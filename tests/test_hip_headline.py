@@ -29,6 +29,8 @@ SEQ = 32
 # largest value observed on MI355X for this seed (4.9e-4 for Q4_0, 5.0e-4 for Q4_K; the test records what it sees in
 # gpurun_out/headline_parity.json, last committed copy: tests/golden/headline_parity_observed.json)
 FAST_TOL = {"Q4_0": 2e-3, "Q4_K": 2e-3}
+# the same for the last-row logits of a 200-token prompt pass (test_fast_prompt_pass_against_the_oracle_at_the_8b_shape)
+PROMPT_TOL = {"Q4_0": 2e-3, "Q4_K": 2e-3}  # observed (200 rows): f16 pass 4.6e-4 / 3.9e-4, int8 pass 5.9e-4 / 4.4e-4
 _RESULTS = {}
 
 
@@ -191,3 +193,41 @@ def test_zero_mean_weights_at_the_8b_shape_strict_exact_and_fast_inside_the_refe
         assert max(errs) <= 1.5 * max(spread), (fmt, name, errs, spread)
     _RESULTS[f"zero_mean/{fmt}"] = res
     _write_results()
+
+
+def test_fast_prompt_pass_against_the_oracle_at_the_8b_shape(ca, headline):
+    """The fast prompt pass (crabml_hip_llama_prefill: the f16 weight GEMM with its epilogues, flash attention, the fused row kernels) at
+    the headline shape: a 136-token prompt in one pass (two column tiles) -- every GEMM as the f16 kernel, gate | up with the SiLU * mul (+ quantizer)
+    epilogue -- against the oracle's token loop over the same tokens (last-row logits), next to the same pass on the bit-exact int8
+    GEMMs (CRABML_HIP_LLAMA_PREFILL_INT8_GEMM).  Bound: PROMPT_TOL of max |logit| (4 x observed on MI355X for this seed), and the f16
+    pass no further from the oracle than 2 x the int8 pass + 1e-3; the greedy token agrees with the oracle's or sits inside the error."""
+    fmt, model, _ = headline
+    n = 136
+    toks = [(31 * i + 7) % 50000 for i in range(n)]
+    odev = o.OracleDevice(thread_num=_threads(), use_avx2=False)
+    oconf, ow = to_oracle(model, odev)
+    orr = o.OracleLlamaRunner(oconf, ow, odev, n + 8, True)
+    ref = None
+    for i, t in enumerate(toks):
+        ref = orr.forward([t], i)
+    ref = ref.copy()
+    del orr
+    dev = ca.HipTensorDevice(0, False, 0, False)
+    conf, w = synth.to_hip(model, dev)
+    scale = float(np.max(np.abs(ref)))
+    out = {}
+    for name, flags in (("f16", 0), ("int8", 524288)):
+        r = ca.HipLlamaRunner(conf, w, dev, n + 8, True, extra_flags=flags)
+        lg = np.array(r.prefill(toks))
+        d = np.abs(lg.astype(np.float64) - ref.astype(np.float64))
+        a_h, a_o = o.argmax_last(lg), o.argmax_last(ref)
+        out[name] = {"max_rel_logit_err": float(np.max(d)) / scale, "median_rel_logit_err": float(np.median(d)) / scale,
+                     "token_equal": bool(a_h == a_o), "oracle_gap_where_different": float(ref[a_o] - ref[a_h]) / scale}
+        del r
+    _RESULTS[f"fast_prompt_pass/{fmt}"] = dict(out, rows=n, tolerance=PROMPT_TOL[fmt])
+    _write_results()
+    ef, ei = out["f16"]["max_rel_logit_err"], out["int8"]["max_rel_logit_err"]
+    assert ei <= PROMPT_TOL[fmt], (fmt, out)
+    assert ef <= PROMPT_TOL[fmt] and ef <= 2 * ei + 1e-3, (fmt, out)
+    for name in ("f16", "int8"):
+        assert out[name]["token_equal"] or out[name]["oracle_gap_where_different"] <= 2 * out[name]["max_rel_logit_err"], (fmt, name, out)
